@@ -1,0 +1,197 @@
+/*
+ * pointflow_hip.h  --  C ABI of libpointflow_hip.so (MI355X / gfx950 native PointFlow hot path).
+ *
+ * Drop-in boundary for the reference's operator layer.  The reference binds
+ * its one native op through a pybind module taking at::Tensor by value
+ * (reference pointmvsnet/functions/csrc/main.cpp:3-6, gather_knn.h:7-13); everything else on the path
+ * is a chain of ATen calls.  This library exposes the same operators -- and the fused forms the
+ * MI355X pipeline uses -- as plain `extern "C"` functions over raw device pointers, sizes and a
+ * hipStream_t, with no torch types in any signature.  The Python host side
+ * (pointmvsnet_amd/_lib.py) binds them with ctypes; INTEGRATION.md shows the stub a reference
+ * maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in `_host`;
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued on it and the call returns
+ *     without synchronising (the reference launches on the default stream,
+ *     gather_knn_kernel.cu:138 -- a latent bug that is not reproduced);
+ *   - tensors are dense row-major float32 unless stated; indices are int64 as the reference API
+ *     mandates (functions/gather_knn.py:10-24, utils/torch_utils.py:16-22);
+ *   - return value: PF_OK, a negative PF_ERR_* for argument errors (nothing was launched), or a
+ *     positive hipError_t;
+ *   - out-of-range neighbour indices never fault: the access is skipped / clamped and a sticky
+ *     device status bit is raised, readable with pf_check_status() (the reference uses a device
+ *     assert, gather_knn_kernel.cu:85).
+ */
+#ifndef POINTFLOW_HIP_H_
+#define POINTFLOW_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PF_OK 0
+#define PF_ERR_INVALID_ARG (-1)
+#define PF_ERR_UNSUPPORTED (-2)
+
+#define PF_STATUS_BAD_INDEX 1u
+
+#define PF_MAX_VIEWS 8
+#define PF_GEMM_TILE 64 /* points per GEMM / stats tile */
+
+/* ---- packed camera block consumed by pf_flow_features_f32 (floats, device) -----------------
+ *  [0..8]   inverse of the reference-view intrinsic, row-major      (model.py:168-169)
+ *  [9..17]  inverse of the reference-view rotation                   (model.py:57,177)
+ *  [18..20] reference-view translation                                (model.py:56)
+ *  [21..23] world-point mean, [24..26] std                            (model.py:46-48)
+ *  [27 + 21*v .. ] view v: intrinsic K (9, row-major) then extrinsic [R|t] (12, row-major 3x4)
+ */
+#define PF_CAM_KREF_INV 0
+#define PF_CAM_RREF_INV 9
+#define PF_CAM_TREF 18
+#define PF_CAM_MEAN 21
+#define PF_CAM_STD 24
+#define PF_CAM_VIEWS 27
+#define PF_CAM_VIEW_STRIDE 21
+#define PF_CAM_FLOATS(V) (PF_CAM_VIEWS + PF_CAM_VIEW_STRIDE * (V))
+
+const char* pf_version(void);
+const char* pf_error_string(int code);
+/* Number of compute units / LDS bytes of the current device, and its gcnArchName. */
+int pf_device_info(int* cu_count, int* lds_bytes_per_block, char* arch_host, int arch_len);
+/* Synchronises `stream`, returns the sticky status bits in *status_host and clears them. */
+int pf_check_status(unsigned* status_host, void* stream);
+
+/* ---- row G : gather_knn ------------------------------------------------------------------
+ * Replaces dgcnn_ext.gather_knn_forward / gather_knn_backward
+ * (reference functions/csrc/gather_knn_kernel.cu:25-47 and :97-148).
+ *   forward : out[b,c,n,j] = feature[b,c,index[b,n,j]]      feature (B,C,N), index (B,N,K), out (B,C,N,K)
+ *   backward: grad_in[b,c,index[b,n,j]] += grad_out[b,c,n,j]  (grad_in is zeroed by the call)
+ * float32 and float64 like the reference's AT_DISPATCH_FLOATING_TYPES (:134). */
+int pf_gather_knn_forward_f32(const float* feature, const int64_t* index, float* out,
+                              int64_t B, int64_t C, int64_t N, int64_t K, void* stream);
+int pf_gather_knn_forward_f64(const double* feature, const int64_t* index, double* out,
+                              int64_t B, int64_t C, int64_t N, int64_t K, void* stream);
+int pf_gather_knn_backward_f32(const float* grad_out, const int64_t* index, float* grad_in,
+                               int64_t B, int64_t C, int64_t N, int64_t K, void* stream);
+int pf_gather_knn_backward_f64(const double* grad_out, const int64_t* index, double* grad_in,
+                               int64_t B, int64_t C, int64_t N, int64_t K, void* stream);
+
+/* ---- row K : lattice kNN -------------------------------------------------------------------
+ * Replaces get_knn_3d (reference utils/torch_utils.py:16-61).  xyz is (B,3,D,H,W) addressed through
+ * `strides_host` (5 element strides, host array) so the strided sub-lattice views of
+ * model.py:251-252 need no copy.  Candidates are the kernel_size^3 window, zero outside the lattice;
+ * d2 = (dx*dx + dy*dy) + dz*dz in float32 without contraction; ranking: smaller d2 first, ties by
+ * smaller candidate code (the reference's tie order is unspecified).
+ *   idx_out  (B, D*H*W, knn) int64: n + offsets, one global clamp to [0, DHW-1] (torch_utils.py:55-59)
+ *   code_out (B, D*H*W, knn) uint8 or NULL: the window candidate code of each pick (kernel_size<=5)
+ * Limits: kernel_size odd, <= 7; knn <= min(32, kernel_size^3). */
+int pf_knn_lattice_f32(const float* xyz, const int64_t* strides_host, int64_t B, int64_t D, int64_t H,
+                       int64_t W, int kernel_size, int knn, int64_t* idx_out, uint8_t* code_out,
+                       void* stream);
+
+/* ---- row W : the warp ----------------------------------------------------------------------
+ * Replaces FeatureFetcher.forward (reference utils/feature_fetcher.py:13-60): p = R X + t,
+ * (x/z, y/z, 1) K^T, bilinear sample at pixel index (u-.5, v-.5), zero padding, legacy
+ * align_corners=True.  maps (B,V,C,H,W), pts (B,3,N), K (B,V,3,3),
+ * E (B,V,3,4) or NULL (identity), out (B,V,C,N).  V <= PF_MAX_VIEWS.
+ * backward: gradient w.r.t. the maps only (the grid is built under no_grad, :29); grad_maps is
+ * zeroed by the call. */
+int pf_fetch_forward_f32(const float* maps, const float* pts, const float* K, const float* E, float* out,
+                         int64_t B, int64_t V, int64_t C, int64_t H, int64_t W, int64_t N, void* stream);
+int pf_fetch_backward_f32(const float* grad_out, const float* pts, const float* K, const float* E,
+                          float* grad_maps, int64_t B, int64_t V, int64_t C, int64_t H, int64_t W,
+                          int64_t N, void* stream);
+
+/* ---- rows W+V : fetch + variance over views --------------------------------------------------
+ * Fuses FeatureFetcher with E[x^2]-E[x]^2 over V (reference model.py:102-111, :187-190); never
+ * materialises (B,V,C,N).  ref_override != 0 reproduces model.py:103-106: view 0 contributes the
+ * un-warped reference feature maps[b,0,c, n mod (H*W)].  out (B,C,N). */
+int pf_fetch_variance_f32(const float* maps, const float* pts, const float* K, const float* E, float* out,
+                          int64_t B, int64_t V, int64_t C, int64_t H, int64_t W, int64_t N,
+                          int ref_override, void* stream);
+
+/* ---- bilinear resize (align_corners = False), the F.interpolate of model.py:184 -------------
+ * in (P, IH, IW) -> out (P, OH, OW). */
+int pf_resize_bilinear_f32(const float* in, float* out, int64_t P, int64_t IH, int64_t IW, int64_t OH,
+                           int64_t OW, void* stream);
+
+/* ---- row F (+U, +T ordering) : flow feature assembly ------------------------------------------
+ * One launch builds what reference model.py:153-204 builds with ~100 ATen calls, for batch item 0..0
+ * (one scene): for the 5 hypotheses depth + i*interval, i=-2..2: un-project the pixel centres of the
+ * (h,w) flow grid, project into every view, bilinear-fetch the three (already resized to (h,w)) pyramid
+ * levels maps1/2/3 (V,c_l,h,w), variance over views, append (world-mean)/std repeated 8x.
+ * depth_in (dh,dw) is nearest-resized to (h,w) on the fly (model.py:153-158).
+ * Points are written in SUB-GRID-MAJOR order for the test-mode tiling of model.py:231-267
+ * (ratio r, G = r*r groups, Ng = 5*(h/r)*(w/r) points each; group g=(y%r)*r+(x%r), local index
+ * d*(h/r)*(w/r) + (y/r)*(w/r) + (x/r)); r = 1 gives the plain (5,h,w) lattice.
+ *   feature (G, c1+c2+c3+24, Ng)    xyz (G, 3, Ng) */
+int pf_flow_features_f32(const float* maps1, const float* maps2, const float* maps3, int c1, int c2, int c3,
+                         int V, int h, int w, const float* depth_in, int dh, int dw, float interval,
+                         const float* cam, int ratio, float* feature, float* xyz, void* stream);
+
+/* ---- rows E0/E1/E2/M building blocks ----------------------------------------------------------
+ * Points are organised as G groups of Ng points; a "tile" is PF_GEMM_TILE consecutive points of one
+ * group; a launch uses T = pf_stat_blocks(G, Ng) blocks per group, each reducing its tiles into one
+ * float64 partial (sum, sum of squares) per column -> deterministic BatchNorm statistics. */
+int pf_stat_blocks(int G, int Ng);
+
+/* Y[m, 0:Nc_store] = act(X[m, 0:K]) * Wt, m over G*Ng points.  Wt is (K, Nc) row-major, Nc a multiple
+ * of 32 (<=128).  X is channel-major (G, K, Ng) when x_point_major == 0 (the reference (B,C,N) layout)
+ * or point-major rows of ldx floats.  act = ReLU(x*in_scale[s,k] + in_shift[s,k]) when in_scale != NULL
+ * (s = g / groups_per_stat) -- the previous layer's BatchNorm+ReLU fused into the load -- else identity.
+ * col_partials (G, T, Nc, 2) float64 or NULL receives per-block column sums of Y. */
+int pf_pointwise_gemm_f32(const float* X, int x_point_major, int64_t ldx, const float* Wt, float* Y,
+                          int64_t ldy, int G, int Ng, int K, int Nc, int Nc_store, const float* in_scale,
+                          const float* in_shift, int groups_per_stat, double* col_partials, void* stream);
+
+/* Pass A of EdgeConv: for rows LE = [l (C) | e (C)] (point-major, ldle floats per point) and local
+ * neighbour indices idx (G, Ng, k): partial sums over all (point, neighbour) pairs of
+ * d = e[idx] - l and d*d per channel -> partials (G, T, C, 2) float64.   C in {32, 64, 128}. */
+int pf_edge_stats_f32(const float* LE, int64_t ldle, int C, const int64_t* idx, int k, int G, int Ng,
+                      double* partials, void* stream);
+
+/* BatchNorm (training mode) statistics -> affine.  Reduces partials (G, T, pcols, 2) over the T blocks
+ * of `groups_per_stat` consecutive groups, columns [col0, col0+C):  mean = S/count,
+ * var = SS/count - mean^2 (biased, used to normalise), scale = gamma*rsqrt(var+eps),
+ * shift = beta - mean*scale; written to scale/shift[s*ld_affine + c].  When running_mean != NULL the
+ * running statistics are updated S times in group order exactly like S successive nn.BatchNorm
+ * calls (momentum, unbiased variance with n = unbias_n; reference runs BN in train mode at test time,
+ * test.py:58).  count = elements per STAT group behind the sums. */
+int pf_bn_finalize_f32(const double* partials, int T, int pcols, int col0, int C, double count,
+                       double unbias_n, const float* gamma, const float* beta, float* running_mean,
+                       float* running_var, float momentum, float eps, int G, int groups_per_stat,
+                       float* scale, float* shift, int ld_affine, void* stream);
+
+/* Pass B of EdgeConv (reference networks.py:37-43 / :74-79):
+ *   concat != 0: Y[m, 0:C]  = relu(l*scale[0:C] + shift[0:C])                       (central half)
+ *                Y[m, C:2C] = mean_j relu((e[idx_j]-l)*scale[C:2C] + shift[C:2C])
+ *   concat == 0: Y[m, 0:C]  = mean_j relu((e[idx_j]-l)*scale[0:C] + shift[0:C])
+ * scale/shift are (S, ld_affine).  Y is point-major with ldy floats per point. */
+int pf_edge_apply_f32(const float* LE, int64_t ldle, int C, const int64_t* idx, int k, int G, int Ng,
+                      const float* scale, const float* shift, int ld_affine, int groups_per_stat,
+                      int concat, float* Y, int64_t ldy, void* stream);
+
+/* ---- rows M (last layer) + H + T : flow head ---------------------------------------------------
+ * Z (G*Ng, ldz) holds the pre-BN output of the 64->16 MLP layer.  Per pixel of the (h,w) grid:
+ * a = relu(Z*scale+shift); flow_d = sum_c w_out[c]*a_c for the 5 hypotheses; p = softmax(-flow);
+ * depth_out = nearest(depth_in) + sum_d p_d*(d-2)*interval  (reference model.py:218-227), written
+ * back in image order (undoing the sub-grid-major point order, model.py:256-266).
+ * flow_prob (5,h,w), depth_out (h,w). */
+int pf_flow_head_f32(const float* Z, int64_t ldz, const float* scale, const float* shift, int ld_affine,
+                     const float* w_out, const float* depth_in, int dh, int dw, float interval, int h,
+                     int w, int ratio, float* flow_prob, float* depth_out, void* stream);
+
+/* ---- row S : soft-argmin + probability map -----------------------------------------------------
+ * cost (B, D, HW) filtered cost volume; depth = sum_k linspace(start,end,D)[k] * softmax(-cost)[k]
+ * (reference model.py:117-124); prob = p[floor(i)] + p[ceil(i)], i = (depth-start)/interval clamped
+ * to [0, D-1] (functions/functions.py:141-175).  params (B,3) = (depth_start, depth_end, interval). */
+int pf_softargmin_prob_f32(const float* cost, const float* params, float* depth, float* prob, int64_t B,
+                           int64_t D, int64_t HW, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POINTFLOW_HIP_H_ */

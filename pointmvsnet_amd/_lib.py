@@ -1,0 +1,91 @@
+"""ctypes binding of libpointflow_hip.so (the C ABI declared in include/pointflow_hip.h).
+
+There is NO fallback: if the library is missing or a call fails, a RuntimeError is raised.  The
+product path never routes through torch eager ops or the CPU oracle for the hot-path operators.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpointflow_hip.so")
+
+_vp, _i, _i64, _f, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double
+
+# name -> argtypes; every entry must exist in include/pointflow_hip.h (tests/test_abi.py checks both ways)
+PROTOTYPES = {
+    "pf_version": ([], ctypes.c_char_p),
+    "pf_error_string": ([_i], ctypes.c_char_p),
+    "pf_device_info": ([ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.c_char_p, _i], _i),
+    "pf_check_status": ([ctypes.POINTER(ctypes.c_uint), _vp], _i),
+    "pf_gather_knn_forward_f32": ([_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp], _i),
+    "pf_gather_knn_forward_f64": ([_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp], _i),
+    "pf_gather_knn_backward_f32": ([_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp], _i),
+    "pf_gather_knn_backward_f64": ([_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp], _i),
+    "pf_knn_lattice_f32": ([_vp, ctypes.POINTER(_i64), _i64, _i64, _i64, _i64, _i, _i, _vp, _vp, _vp], _i),
+    "pf_fetch_forward_f32": ([_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp], _i),
+    "pf_fetch_backward_f32": ([_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp], _i),
+    "pf_fetch_variance_f32": ([_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i, _vp], _i),
+    "pf_resize_bilinear_f32": ([_vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp], _i),
+    "pf_flow_features_f32": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _f, _vp, _i, _vp, _vp, _vp], _i),
+    "pf_stat_blocks": ([_i, _i], _i),
+    "pf_pointwise_gemm_f32": ([_vp, _i, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp], _i),
+    "pf_edge_stats_f32": ([_vp, _i64, _i, _vp, _i, _i, _i, _vp, _vp], _i),
+    "pf_bn_finalize_f32": ([_vp, _i, _i, _i, _i, _d, _d, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _i, _vp], _i),
+    "pf_edge_apply_f32": ([_vp, _i64, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _i64, _vp], _i),
+    "pf_flow_head_f32": ([_vp, _i64, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _i, _i, _i, _vp, _vp, _vp], _i),
+    "pf_softargmin_prob_f32": ([_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp], _i),
+}
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes library; raises RuntimeError when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "pointmvsnet_amd: %s is missing. Build it with `python -m pointmvsnet_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU or eager fallback for the hot path." % LIB_PATH)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as exc:
+        raise RuntimeError("pointmvsnet_amd: cannot load %s: %s" % (LIB_PATH, exc))
+    for name, (argtypes, restype) in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError here == ABI mismatch: fail loudly
+        fn.argtypes = argtypes
+        fn.restype = restype
+    _lib = lib
+    return lib
+
+
+def check(code, what=""):
+    if code != 0:
+        msg = load().pf_error_string(int(code)).decode()
+        raise RuntimeError("pointflow_hip %s failed (%d): %s" % (what, code, msg))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu(*tensors):
+    """The reference raises for non-CUDA tensors (gather_knn_kernel.cu:10,33-34); so do we."""
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("pointmvsnet_amd: expected a GPU (HIP) tensor; this operator has no CPU path")
+
+
+def status():
+    """Synchronise the current stream, return and clear the sticky device status bits."""
+    val = ctypes.c_uint(0)
+    check(load().pf_check_status(ctypes.byref(val), stream()), "pf_check_status")
+    return int(val.value)

@@ -1,0 +1,527 @@
+// Rows E0/E1/E2, M, H (+T): the EdgeConv chain, the flow MLP and the flow head.
+//
+// The reference runs, per EdgeConv, two 1x1 convs, a gather that materialises (B,C,N,16), expand, cat,
+// BatchNorm2d (batch statistics), ReLU and mean -- five passes over 105-210 MB tensors per 25 600
+// points (reference networks.py:18-45, :56-81).  Here the (N,16,C) edge tensor never exists:
+//
+//   pointwise_gemm   [l | e] = x . [W1;W2]^T on the matrix cores (v_mfma_f32_32x32x2_f32: exact f32,
+//                    an fmaf chain in k order), 64-point tiles, A staged through LDS, optional
+//                    BatchNorm+ReLU of the previous layer fused into the A load, optional per-block
+//                    float64 column sums (statistics of the "central" half and of the MLP layers).
+//   edge_stats       pass A: per-channel sum / sum-of-squares of d = e[idx] - l over all (point,
+//                    neighbour) pairs -> per-block float64 partials.
+//   bn_finalize      partials -> scale/shift per stat group, running-stat update (train-mode BN runs
+//                    at test time too: reference test.py:58).  Fixed summation order:
+//                    results are bit-reproducible run to run (no float atomics anywhere).
+//   edge_apply       pass B: y = mean_j relu(scale*d + shift) (+ the central half), written straight
+//                    into its slice of the (N,224) concat buffer that feeds the MLP.
+//   flow_head        last BN+ReLU, the 16->1 conv, softmax over the 5 hypotheses, expected offset, add
+//                    to the prior depth, un-tiling of the sub-grid order.
+//
+// Activations are point-major (N, C): a neighbour's C channels are one or two cache lines, and a wave
+// reads them as 16-byte lanes (C/4 lanes per neighbour row), so the irregular gather is line-granular
+// and mostly L2-resident (e of 25 600 points = 3.3-6.5 MB).  BatchNorm statistics are per stat group
+// (= per sub-grid in test mode, pooled over the batch for the nn.Module API).
+//
+// Algorithmic HBM bytes per point: EdgeConv(C_in->C_out, out C'):
+// 4*C_in + 8*16 + 16*4*C_out + 4*C'.
+#include "pf_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int TILE = PF_GEMM_TILE;
+
+__host__ __device__ inline int keven(int K) { return (K + 1) & ~1; }
+__host__ __device__ inline int kpad(int K) { return keven(K) + 1; }  // odd LDS row stride: conflict-free columns
+
+// ------------------------------------------------------------------------------------------------
+// pointwise GEMM on f32 MFMA
+// ------------------------------------------------------------------------------------------------
+template <bool POINT_MAJOR>
+__global__ __launch_bounds__(256) void pointwise_gemm_kernel(
+    const float* __restrict__ X, int64_t ldx, const float* __restrict__ Wt, float* __restrict__ Y, int64_t ldy,
+    int Ng, int K, int Nc, int Nc_store, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
+    int groups_per_stat, double* __restrict__ partials, int T) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* As = lds;
+  const int KE = keven(K);
+  const int KP = kpad(K);
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int rt = wave & 1;   // row tile (32 points) of this wave
+  const int cw = wave >> 1;  // first column tile of this wave; it also owns cw + 2
+  const int NT = Nc >> 5;
+  const int g = blockIdx.y;
+  const int tb = blockIdx.x;
+  const int tiles = (Ng + TILE - 1) / TILE;
+  const float* sc = in_scale ? in_scale + (int64_t)(g / groups_per_stat) * K : nullptr;
+  const float* sh = in_scale ? in_shift + (int64_t)(g / groups_per_stat) * K : nullptr;
+
+  double csum[2] = {0.0, 0.0}, csq[2] = {0.0, 0.0};
+
+  for (int tile = tb; tile < tiles; tile += T) {
+    const int n0 = tile * TILE;
+    const int rows = min(TILE, Ng - n0);
+    __syncthreads();
+    if (!POINT_MAJOR) {
+      const int p = tid & 63;
+      for (int k = tid >> 6; k < KE; k += 4) {
+        float v = 0.0f;
+        if (k < K && p < rows) {
+          v = X[((int64_t)g * K + k) * Ng + n0 + p];
+          if (sc) v = fmaxf(fmaf(v, sc[k], sh[k]), 0.0f);
+        }
+        As[p * KP + k] = v;
+      }
+    } else {
+      const int total = TILE * KE;
+      for (int e = tid; e < total; e += 256) {
+        const int p = e / KE;
+        const int k = e - p * KE;
+        float v = 0.0f;
+        if (k < K && p < rows) {
+          v = X[((int64_t)g * Ng + n0 + p) * ldx + k];
+          if (sc) v = fmaxf(fmaf(v, sc[k], sh[k]), 0.0f);
+        }
+        As[p * KP + k] = v;
+      }
+    }
+    __syncthreads();
+
+    f32x16 acc0 = {0}, acc1 = {0};
+    const float* arow = As + (32 * rt + (lane & 31)) * KP + (lane >> 5);
+    const int ct0 = cw, ct1 = cw + 2;
+    const float* b0p = Wt + 32 * ct0 + (lane & 31);
+    const float* b1p = Wt + 32 * ct1 + (lane & 31);
+    const int KF = K & ~1;  // full k-pairs; an odd K leaves one half-pair whose second row is zero
+    const int hi = lane >> 5;
+    if (ct1 < NT) {
+      for (int k0 = 0; k0 < KF; k0 += 2) {
+        const float a = arow[k0];
+        const float b0 = b0p[(int64_t)(k0 + hi) * Nc];
+        const float b1 = b1p[(int64_t)(k0 + hi) * Nc];
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+      }
+      if (KF < K) {
+        const float a = arow[KF];
+        const float b0 = hi == 0 ? b0p[(int64_t)KF * Nc] : 0.0f;
+        const float b1 = hi == 0 ? b1p[(int64_t)KF * Nc] : 0.0f;
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+      }
+    } else if (ct0 < NT) {
+      for (int k0 = 0; k0 < KF; k0 += 2) {
+        const float a = arow[k0];
+        const float b0 = b0p[(int64_t)(k0 + hi) * Nc];
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+      }
+      if (KF < K) {
+        const float a = arow[KF];
+        const float b0 = hi == 0 ? b0p[(int64_t)KF * Nc] : 0.0f;
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+      }
+    }
+
+    // epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ct = i == 0 ? ct0 : ct1;
+      if (ct < NT) {
+        const f32x16 acc = i == 0 ? acc0 : acc1;
+        const int col = 32 * ct + (lane & 31);
+        float cs = 0.0f, cq = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = 32 * rt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          const float v = acc[r];
+          if (row < rows) {
+            if (col < Nc_store) Y[((int64_t)g * Ng + n0 + row) * ldy + col] = v;
+            cs += v;
+            cq += v * v;
+          }
+        }
+        csum[i] += (double)cs;
+        csq[i] += (double)cq;
+      }
+    }
+  }
+
+  if (partials != nullptr) {
+    __syncthreads();
+    double* red = reinterpret_cast<double*>(lds);  // [wave][i][32][2]
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      double s = csum[i], q = csq[i];
+      s += __shfl_xor(s, 32);
+      q += __shfl_xor(q, 32);
+      if (lane < 32) {
+        red[((wave * 2 + i) * 32 + lane) * 2 + 0] = s;
+        red[((wave * 2 + i) * 32 + lane) * 2 + 1] = q;
+      }
+    }
+    __syncthreads();
+    if (rt == 0 && lane < 32) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int ct = cw + 2 * i;
+        if (ct < NT) {
+          const int col = 32 * ct + lane;
+          const double s = red[((wave * 2 + i) * 32 + lane) * 2 + 0] + red[(((wave + 1) * 2 + i) * 32 + lane) * 2 + 0];
+          const double q = red[((wave * 2 + i) * 32 + lane) * 2 + 1] + red[(((wave + 1) * 2 + i) * 32 + lane) * 2 + 1];
+          double* o = partials + (((int64_t)g * T + tb) * Nc + col) * 2;
+          o[0] = s;
+          o[1] = q;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// EdgeConv pass A / pass B.  C/4 lanes share one point (16-byte lanes), 256/(C/4) points per pass.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+template <int C>
+__global__ __launch_bounds__(256) void edge_stats_kernel(const float* __restrict__ LE, int64_t ldle,
+                                                         const int64_t* __restrict__ idx, int k, int Ng,
+                                                         double* __restrict__ partials, int T,
+                                                         unsigned* __restrict__ status) {
+  constexpr int Q = C / 4;         // lanes per point
+  constexpr int PPB = 256 / Q;     // points per pass
+  __shared__ double red[256 * 8];
+  const int tid = threadIdx.x;
+  const int q = tid % Q, pl = tid / Q;
+  const int g = blockIdx.y, tb = blockIdx.x;
+  const int tiles = (Ng + TILE - 1) / TILE;
+  double ds[4] = {0, 0, 0, 0}, dq[4] = {0, 0, 0, 0};
+  for (int tile = tb; tile < tiles; tile += T) {
+    const int n0 = tile * TILE;
+    for (int p = pl; p < TILE; p += PPB) {
+      const int n = n0 + p;
+      if (n >= Ng) break;
+      const int64_t row = (int64_t)g * Ng + n;
+      const float4 l = ld4(LE + row * ldle + 4 * q);
+      const int64_t* ip = idx + row * k;
+      float4 s = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
+      for (int j = 0; j < k; ++j) {
+        int64_t i = ip[j];
+        if (i < 0 || i >= Ng) {
+          atomicOr(status, PF_STATUS_BAD_INDEX);
+          i = i < 0 ? 0 : Ng - 1;
+        }
+        const float4 e = ld4(LE + ((int64_t)g * Ng + i) * ldle + C + 4 * q);
+        const float dx = e.x - l.x, dy = e.y - l.y, dz = e.z - l.z, dw = e.w - l.w;
+        s.x += dx; s.y += dy; s.z += dz; s.w += dw;
+        s2.x += dx * dx; s2.y += dy * dy; s2.z += dz * dz; s2.w += dw * dw;
+      }
+      ds[0] += (double)s.x; ds[1] += (double)s.y; ds[2] += (double)s.z; ds[3] += (double)s.w;
+      dq[0] += (double)s2.x; dq[1] += (double)s2.y; dq[2] += (double)s2.z; dq[3] += (double)s2.w;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    red[tid * 8 + c] = ds[c];
+    red[tid * 8 + 4 + c] = dq[c];
+  }
+  __syncthreads();
+  if (tid < 2 * C) {
+    const int qq = tid / 8, comp = tid % 8;
+    double acc = 0.0;
+    for (int s = 0; s < PPB; ++s) acc += red[(s * Q + qq) * 8 + comp];
+    partials[(((int64_t)g * T + tb) * C + 4 * qq + (comp & 3)) * 2 + (comp >> 2)] = acc;
+  }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void edge_apply_kernel(const float* __restrict__ LE, int64_t ldle,
+                                                         const int64_t* __restrict__ idx, int k, int Ng,
+                                                         const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, int ld_affine,
+                                                         int groups_per_stat, int concat, float* __restrict__ Y,
+                                                         int64_t ldy, int T) {
+  constexpr int Q = C / 4;
+  constexpr int PPB = 256 / Q;
+  const int tid = threadIdx.x;
+  const int q = tid % Q, pl = tid / Q;
+  const int g = blockIdx.y, tb = blockIdx.x;
+  const int tiles = (Ng + TILE - 1) / TILE;
+  const int64_t so = (int64_t)(g / groups_per_stat) * ld_affine;
+  const int doff = concat ? C : 0;
+  const float4 dsc = ld4(scale + so + doff + 4 * q), dsh = ld4(shift + so + doff + 4 * q);
+  float4 csc = {0, 0, 0, 0}, csh = {0, 0, 0, 0};
+  if (concat) {
+    csc = ld4(scale + so + 4 * q);
+    csh = ld4(shift + so + 4 * q);
+  }
+  const float kf = (float)k;
+  for (int tile = tb; tile < tiles; tile += T) {
+    const int n0 = tile * TILE;
+    for (int p = pl; p < TILE; p += PPB) {
+      const int n = n0 + p;
+      if (n >= Ng) break;
+      const int64_t row = (int64_t)g * Ng + n;
+      const float4 l = ld4(LE + row * ldle + 4 * q);
+      const int64_t* ip = idx + row * k;
+      float4 a = {0, 0, 0, 0};
+      for (int j = 0; j < k; ++j) {
+        int64_t i = ip[j];
+        i = i < 0 ? 0 : (i >= Ng ? Ng - 1 : i);
+        const float4 e = ld4(LE + ((int64_t)g * Ng + i) * ldle + C + 4 * q);
+        a.x += fmaxf(fmaf(e.x - l.x, dsc.x, dsh.x), 0.0f);
+        a.y += fmaxf(fmaf(e.y - l.y, dsc.y, dsh.y), 0.0f);
+        a.z += fmaxf(fmaf(e.z - l.z, dsc.z, dsh.z), 0.0f);
+        a.w += fmaxf(fmaf(e.w - l.w, dsc.w, dsh.w), 0.0f);
+      }
+      float4 yd = {a.x / kf, a.y / kf, a.z / kf, a.w / kf};
+      float* yo = Y + row * ldy + 4 * q;
+      if (concat) {
+        float4 yc = {fmaxf(fmaf(l.x, csc.x, csh.x), 0.0f), fmaxf(fmaf(l.y, csc.y, csh.y), 0.0f),
+                     fmaxf(fmaf(l.z, csc.z, csh.z), 0.0f), fmaxf(fmaf(l.w, csc.w, csh.w), 0.0f)};
+        *reinterpret_cast<float4*>(yo) = yc;
+        *reinterpret_cast<float4*>(yo + C) = yd;
+      } else {
+        *reinterpret_cast<float4*>(yo) = yd;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm finalize: one workgroup, stat groups in order (running statistics are sequential state)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const double* __restrict__ partials, int T, int pcols,
+                                                           int col0, int C, double count, double unbias_n,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta,
+                                                           float* __restrict__ running_mean,
+                                                           float* __restrict__ running_var, float momentum,
+                                                           float eps, int S, int groups_per_stat,
+                                                           float* __restrict__ scale, float* __restrict__ shift,
+                                                           int ld_affine) {
+  __shared__ double red[1024 * 2];
+  const int tid = threadIdx.x;
+  const int slices = 1024 / C;  // C <= 256 checked on the host
+  const int c = tid % C, sl = tid / C;
+  const int entries = groups_per_stat * T;
+  float rm = 0.0f, rv = 0.0f;
+  const bool track = running_mean != nullptr;
+  if (track && tid < C) {
+    rm = running_mean[tid];
+    rv = running_var[tid];
+  }
+  for (int s = 0; s < S; ++s) {
+    double a = 0.0, b = 0.0;
+    if (sl < slices) {
+      const double* base = partials + ((int64_t)s * entries * pcols + col0 + c) * 2;
+      for (int e = sl; e < entries; e += slices) {
+        a += base[(int64_t)e * pcols * 2 + 0];
+        b += base[(int64_t)e * pcols * 2 + 1];
+      }
+    }
+    __syncthreads();
+    red[tid * 2 + 0] = a;
+    red[tid * 2 + 1] = b;
+    __syncthreads();
+    if (tid < C) {
+      double sum = 0.0, sq = 0.0;
+      for (int i = 0; i < slices; ++i) {
+        sum += red[(i * C + tid) * 2 + 0];
+        sq += red[(i * C + tid) * 2 + 1];
+      }
+      const double mean = sum / count;
+      double var = sq / count - mean * mean;
+      var = var < 0.0 ? 0.0 : var;
+      const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+      const float a_ = invstd * gamma[tid];
+      scale[(int64_t)s * ld_affine + tid] = a_;
+      shift[(int64_t)s * ld_affine + tid] = beta[tid] - (float)mean * a_;
+      if (track) {
+        const double unbiased = unbias_n > 1.0 ? var * (unbias_n / (unbias_n - 1.0)) : var;
+        rm = (1.0f - momentum) * rm + momentum * (float)mean;
+        rv = (1.0f - momentum) * rv + momentum * (float)unbiased;
+      }
+    }
+  }
+  if (track && tid < C) {
+    running_mean[tid] = rm;
+    running_var[tid] = rv;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// flow head
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void flow_head_kernel(const float* __restrict__ Z, int64_t ldz,
+                                                        const float* __restrict__ scale,
+                                                        const float* __restrict__ shift, int ld_affine,
+                                                        const float* __restrict__ w_out,
+                                                        const float* __restrict__ depth_in, int dh, int dw,
+                                                        float interval, int h, int w, int ratio,
+                                                        float* __restrict__ flow_prob,
+                                                        float* __restrict__ depth_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= h * w) return;
+  const int y = i / w, x = i - y * w;
+  const int hs = h / ratio, ws = w / ratio;
+  const int g = (y % ratio) * ratio + (x % ratio);
+  const int64_t Ng = (int64_t)5 * hs * ws;
+  const int64_t loc0 = (int64_t)(y / ratio) * ws + (x / ratio);
+  const float* sc = scale + (int64_t)g * ld_affine;
+  const float* sh = shift + (int64_t)g * ld_affine;
+  float f[5];
+#pragma unroll
+  for (int d = 0; d < 5; ++d) {
+    const float* z = Z + ((int64_t)g * Ng + (int64_t)d * hs * ws + loc0) * ldz;
+    float acc = 0.0f;
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) {
+      const float4 v = ld4(z + 4 * c4);
+      const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = 4 * c4 + u;
+        const float a = fmaxf(fmaf(vv[u], sc[c], sh[c]), 0.0f);
+        acc = fmaf(w_out[c], a, acc);
+      }
+    }
+    f[d] = -acc;
+  }
+  float mx = f[0];
+#pragma unroll
+  for (int d = 1; d < 5; ++d) mx = fmaxf(mx, f[d]);
+  float e[5], den = 0.0f;
+#pragma unroll
+  for (int d = 0; d < 5; ++d) {
+    e[d] = expf(f[d] - mx);
+    den += e[d];
+  }
+  float flow = 0.0f;
+#pragma unroll
+  for (int d = 0; d < 5; ++d) {
+    const float p = e[d] / den;
+    flow_prob[(int64_t)d * h * w + i] = p;
+    flow += p * ((float)(d - 2) * interval);
+  }
+  const float scy = (float)dh / (float)h, scx = (float)dw / (float)w;
+  int sy = (int)floorf((float)y * scy);
+  int sx = (int)floorf((float)x * scx);
+  sy = sy > dh - 1 ? dh - 1 : sy;
+  sx = sx > dw - 1 ? dw - 1 : sx;
+  depth_out[i] = depth_in[sy * dw + sx] + flow;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pf_stat_blocks(int G, int Ng) {
+  if (G <= 0 || Ng <= 0) return 0;
+  const int tiles = (Ng + TILE - 1) / TILE;
+  int cap = 1024 / G;
+  cap = cap < 32 ? 32 : (cap > 256 ? 256 : cap);
+  return tiles < cap ? tiles : cap;
+}
+
+int pf_pointwise_gemm_f32(const float* X, int x_point_major, int64_t ldx, const float* Wt, float* Y, int64_t ldy,
+                          int G, int Ng, int K, int Nc, int Nc_store, const float* in_scale,
+                          const float* in_shift, int groups_per_stat, double* col_partials, void* stream) {
+  PF_REQUIRE(G >= 0 && Ng >= 0 && K >= 1 && Nc >= 32 && Nc_store >= 1 && Nc_store <= Nc);
+  PF_REQUIRE(Nc % 32 == 0 && groups_per_stat >= 1);
+  if (Nc > 128 || K > 1024) return PF_ERR_UNSUPPORTED;
+  PF_REQUIRE((in_scale == nullptr) == (in_shift == nullptr));
+  PF_REQUIRE(G <= 65535);
+  if (G == 0 || Ng == 0) return PF_OK;
+  PF_REQUIRE(X && Wt && Y && ldy >= Nc_store);
+  if (x_point_major) PF_REQUIRE(ldx >= K);
+  const int T = pf_stat_blocks(G, Ng);
+  size_t lds_bytes = (size_t)TILE * kpad(K) * sizeof(float);
+  if (lds_bytes < 4096) lds_bytes = 4096;
+  if (lds_bytes > 64 * 1024) return PF_ERR_UNSUPPORTED;
+  dim3 grid((unsigned)T, (unsigned)G);
+  if (x_point_major) {
+    hipLaunchKernelGGL(pointwise_gemm_kernel<true>, grid, dim3(256), lds_bytes, (hipStream_t)stream, X, ldx, Wt, Y,
+                       ldy, Ng, K, Nc, Nc_store, in_scale, in_shift, groups_per_stat, col_partials, T);
+  } else {
+    hipLaunchKernelGGL(pointwise_gemm_kernel<false>, grid, dim3(256), lds_bytes, (hipStream_t)stream, X, ldx, Wt,
+                       Y, ldy, Ng, K, Nc, Nc_store, in_scale, in_shift, groups_per_stat, col_partials, T);
+  }
+  return pf_launch_status();
+}
+
+int pf_edge_stats_f32(const float* LE, int64_t ldle, int C, const int64_t* idx, int k, int G, int Ng,
+                      double* partials, void* stream) {
+  PF_REQUIRE(G >= 0 && Ng >= 0 && k >= 1 && ldle >= 2 * (int64_t)C && (ldle % 4) == 0 && G <= 65535);
+  if (C != 32 && C != 64 && C != 128) return PF_ERR_UNSUPPORTED;
+  if (G == 0 || Ng == 0) return PF_OK;
+  PF_REQUIRE(LE && idx && partials);
+  unsigned* status = pf_status_ptr();
+  PF_REQUIRE(status != nullptr);
+  const int T = pf_stat_blocks(G, Ng);
+  dim3 grid((unsigned)T, (unsigned)G);
+  hipStream_t s = (hipStream_t)stream;
+  if (C == 32)
+    hipLaunchKernelGGL(edge_stats_kernel<32>, grid, dim3(256), 0, s, LE, ldle, idx, k, Ng, partials, T, status);
+  else if (C == 64)
+    hipLaunchKernelGGL(edge_stats_kernel<64>, grid, dim3(256), 0, s, LE, ldle, idx, k, Ng, partials, T, status);
+  else
+    hipLaunchKernelGGL(edge_stats_kernel<128>, grid, dim3(256), 0, s, LE, ldle, idx, k, Ng, partials, T, status);
+  return pf_launch_status();
+}
+
+int pf_bn_finalize_f32(const double* partials, int T, int pcols, int col0, int C, double count, double unbias_n,
+                       const float* gamma, const float* beta, float* running_mean, float* running_var,
+                       float momentum, float eps, int G, int groups_per_stat, float* scale, float* shift,
+                       int ld_affine, void* stream) {
+  PF_REQUIRE(T >= 1 && pcols >= 1 && col0 >= 0 && C >= 1 && col0 + C <= pcols && count > 0.0);
+  PF_REQUIRE(G >= 1 && groups_per_stat >= 1 && (G % groups_per_stat) == 0 && ld_affine >= C);
+  if (C > 256) return PF_ERR_UNSUPPORTED;
+  PF_REQUIRE(partials && gamma && beta && scale && shift);
+  PF_REQUIRE((running_mean == nullptr) == (running_var == nullptr));
+  const int S = G / groups_per_stat;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, partials, T, pcols, col0, C,
+                     count, unbias_n, gamma, beta, running_mean, running_var, momentum, eps, S, groups_per_stat,
+                     scale, shift, ld_affine);
+  return pf_launch_status();
+}
+
+int pf_edge_apply_f32(const float* LE, int64_t ldle, int C, const int64_t* idx, int k, int G, int Ng,
+                      const float* scale, const float* shift, int ld_affine, int groups_per_stat, int concat,
+                      float* Y, int64_t ldy, void* stream) {
+  PF_REQUIRE(G >= 0 && Ng >= 0 && k >= 1 && ldle >= 2 * (int64_t)C && (ldle % 4) == 0 && G <= 65535);
+  PF_REQUIRE(groups_per_stat >= 1 && (ldy % 4) == 0 && ldy >= (concat ? 2 : 1) * (int64_t)C);
+  PF_REQUIRE((ld_affine % 4) == 0 && ld_affine >= (concat ? 2 : 1) * C);
+  if (C != 32 && C != 64 && C != 128) return PF_ERR_UNSUPPORTED;
+  if (G == 0 || Ng == 0) return PF_OK;
+  PF_REQUIRE(LE && idx && scale && shift && Y);
+  const int T = pf_stat_blocks(G, Ng);
+  dim3 grid((unsigned)T, (unsigned)G);
+  hipStream_t s = (hipStream_t)stream;
+  if (C == 32)
+    hipLaunchKernelGGL(edge_apply_kernel<32>, grid, dim3(256), 0, s, LE, ldle, idx, k, Ng, scale, shift, ld_affine,
+                       groups_per_stat, concat, Y, ldy, T);
+  else if (C == 64)
+    hipLaunchKernelGGL(edge_apply_kernel<64>, grid, dim3(256), 0, s, LE, ldle, idx, k, Ng, scale, shift, ld_affine,
+                       groups_per_stat, concat, Y, ldy, T);
+  else
+    hipLaunchKernelGGL(edge_apply_kernel<128>, grid, dim3(256), 0, s, LE, ldle, idx, k, Ng, scale, shift,
+                       ld_affine, groups_per_stat, concat, Y, ldy, T);
+  return pf_launch_status();
+}
+
+int pf_flow_head_f32(const float* Z, int64_t ldz, const float* scale, const float* shift, int ld_affine,
+                     const float* w_out, const float* depth_in, int dh, int dw, float interval, int h, int w,
+                     int ratio, float* flow_prob, float* depth_out, void* stream) {
+  PF_REQUIRE(h >= 1 && w >= 1 && dh >= 1 && dw >= 1 && ratio >= 1 && h % ratio == 0 && w % ratio == 0);
+  PF_REQUIRE(ldz >= 16 && (ldz % 4) == 0 && ld_affine >= 16 && (int64_t)h * w <= INT32_MAX);
+  PF_REQUIRE(Z && scale && shift && w_out && depth_in && flow_prob && depth_out);
+  dim3 grid((unsigned)pf_cdiv((int64_t)h * w, 256));
+  hipLaunchKernelGGL(flow_head_kernel, grid, dim3(256), 0, (hipStream_t)stream, Z, ldz, scale, shift, ld_affine,
+                     w_out, depth_in, dh, dw, interval, h, w, ratio, flow_prob, depth_out);
+  return pf_launch_status();
+}
+
+}  // extern "C"

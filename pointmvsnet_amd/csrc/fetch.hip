@@ -1,0 +1,384 @@
+// Rows W, V, F (+U): the multi-view feature warp and its fused forms.
+//
+// Mapping: one lane == one world point, the wave walks the channels.  Consecutive lanes are consecutive
+// pixels of the reference grid, whose projections into a source view are neighbouring texels, so every
+// per-channel tap load of a wave falls in one or two 256-byte row segments of the NCHW map (coalesced
+// HBM/L2 reads without re-laying the maps out), and every per-channel store is one contiguous 256-byte
+// segment of the (C,N) output.  Projection / tap arithmetic lives in pf_common.h (pf_project_taps).
+//
+// Algorithmic HBM bytes:
+//   fetch_variance : V*C*H*W*4 (maps, read once) + 3*N*4 (points) + C*N*4 (cost volume written once)
+//   flow_features  : V*(c1+c2+c3)*h*w*4 + 136*N*4 + 3*N*4 + h*w*4
+// The reference moves V*C*N*4 for the fetched features alone and then makes four more passes over it.
+#include <type_traits>
+
+#include "pf_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// W: (B,V,C,N) fetch, forward and backward (reference utils/feature_fetcher.py:13-60)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fetch_fwd_kernel(const float* __restrict__ maps,
+                                                        const float* __restrict__ pts,
+                                                        const float* __restrict__ Kmat,
+                                                        const float* __restrict__ Emat, float* __restrict__ out,
+                                                        int V, int C, int H, int W, int64_t N) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int v = blockIdx.y;
+  const int64_t b = blockIdx.z;
+  if (n >= N) return;
+  const float* pb = pts + b * 3 * N;
+  PfTaps t;
+  pf_project_taps(pb[n], pb[N + n], pb[2 * N + n], Kmat + (b * V + v) * 9,
+                  Emat ? Emat + (b * V + v) * 12 : nullptr, H, W, t);
+  const int64_t HW = (int64_t)H * W;
+  const float* m = maps + (b * V + v) * C * HW;
+  float* o = out + (b * V + v) * C * N + n;
+  for (int c = 0; c < C; ++c) o[(int64_t)c * N] = pf_sample(m + (int64_t)c * HW, t);
+}
+
+__global__ __launch_bounds__(256) void fetch_bwd_kernel(const float* __restrict__ gout,
+                                                        const float* __restrict__ pts,
+                                                        const float* __restrict__ Kmat,
+                                                        const float* __restrict__ Emat,
+                                                        float* __restrict__ gmaps, int V, int C, int H, int W,
+                                                        int64_t N) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int v = blockIdx.y;
+  const int64_t b = blockIdx.z;
+  if (n >= N) return;
+  const float* pb = pts + b * 3 * N;
+  PfTaps t;
+  pf_project_taps(pb[n], pb[N + n], pb[2 * N + n], Kmat + (b * V + v) * 9,
+                  Emat ? Emat + (b * V + v) * 12 : nullptr, H, W, t);
+  const int64_t HW = (int64_t)H * W;
+  float* gm = gmaps + (b * V + v) * C * HW;
+  const float* g = gout + (b * V + v) * C * N + n;
+  for (int c = 0; c < C; ++c) {
+    const float go = g[(int64_t)c * N];
+    float* plane = gm + (int64_t)c * HW;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (t.ok[k]) unsafeAtomicAdd(plane + t.off[k], go * t.wgt[k]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// W+V: fetch + variance over views (reference model.py:102-111 coarse, :187-190 flow)
+// ------------------------------------------------------------------------------------------------
+template <int V>
+__global__ __launch_bounds__(256) void fetch_variance_kernel(const float* __restrict__ maps,
+                                                             const float* __restrict__ pts,
+                                                             const float* __restrict__ Kmat,
+                                                             const float* __restrict__ Emat,
+                                                             float* __restrict__ out, int C, int H, int W,
+                                                             int64_t N, int ref_override) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t b = blockIdx.y;
+  if (n >= N) return;
+  const float* pb = pts + b * 3 * N;
+  const float X = pb[n], Y = pb[N + n], Z = pb[2 * N + n];
+  PfTaps t[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v)
+    pf_project_taps(X, Y, Z, Kmat + (b * V + v) * 9, Emat ? Emat + (b * V + v) * 12 : nullptr, H, W, t[v]);
+  const int64_t HW = (int64_t)H * W;
+  const int ref_off = (int)(n % HW);
+  const float* mb = maps + b * V * C * HW;
+  float* o = out + b * C * N + n;
+  for (int c = 0; c < C; ++c) {
+    float s = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      const float* plane = mb + ((int64_t)v * C + c) * HW;
+      const float f = (v == 0 && ref_override) ? plane[ref_off] : pf_sample(plane, t[v]);
+      if (v == 0) {
+        s = f;
+        s2 = f * f;
+      } else {
+        s = s + f;
+        s2 = s2 + f * f;
+      }
+    }
+    const float m1 = s / (float)V;
+    const float m2 = s2 / (float)V;
+    o[(int64_t)c * N] = m2 - m1 * m1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// bilinear resize, align_corners=False (F.interpolate at reference model.py:184)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void resize_axis(int o, float scale, int in_size, int& i0, int& i1, float& l0,
+                                            float& l1) {
+  float src = scale * ((float)o + 0.5f) - 0.5f;
+  src = src < 0.0f ? 0.0f : src;
+  i0 = (int)src;
+  if (i0 > in_size - 1) i0 = in_size - 1;
+  i1 = i0 + ((i0 < in_size - 1) ? 1 : 0);
+  l1 = fminf(fmaxf(src - (float)i0, 0.0f), 1.0f);
+  l0 = 1.0f - l1;
+}
+
+__global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __restrict__ in,
+                                                              float* __restrict__ out, int IH, int IW, int OH,
+                                                              int OW, float sy, float sx) {
+  const int64_t p = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= OH * OW) return;
+  const int oy = i / OW, ox = i - oy * OW;
+  const float* src = in + p * IH * IW;
+  float v;
+  if (IH == OH && IW == OW) {
+    v = src[i];
+  } else {
+    int y0, y1, x0, x1;
+    float ly0, ly1, lx0, lx1;
+    resize_axis(oy, sy, IH, y0, y1, ly0, ly1);
+    resize_axis(ox, sx, IW, x0, x1, lx0, lx1);
+    const float a = src[y0 * IW + x0], b = src[y0 * IW + x1];
+    const float c = src[y1 * IW + x0], d = src[y1 * IW + x1];
+    v = ly0 * (lx0 * a + lx1 * b) + ly1 * (lx0 * c + lx1 * d);
+  }
+  out[p * OH * OW + i] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// F: flow feature assembly (reference model.py:153-204), sub-grid-major output (model.py:236-255)
+// ------------------------------------------------------------------------------------------------
+template <int V>
+__global__ __launch_bounds__(256) void flow_features_kernel(const float* __restrict__ maps1,
+                                                            const float* __restrict__ maps2,
+                                                            const float* __restrict__ maps3, int c1, int c2,
+                                                            int c3, int h, int w,
+                                                            const float* __restrict__ depth_in, int dh, int dw,
+                                                            float interval, const float* __restrict__ cam,
+                                                            int ratio, float* __restrict__ feature,
+                                                            float* __restrict__ xyz) {
+  const int hs = h / ratio, ws = w / ratio;
+  const int64_t Ng = (int64_t)5 * hs * ws;
+  const int64_t loc = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int g = blockIdx.y;
+  if (loc >= Ng) return;
+  // local index -> (hypothesis d, sub-grid row/col) -> image pixel (y, x)
+  const int d = (int)(loc / ((int64_t)hs * ws));
+  const int rem = (int)(loc - (int64_t)d * hs * ws);
+  const int ysub = rem / ws, xsub = rem - ysub * ws;
+  const int y = ysub * ratio + g / ratio;
+  const int x = xsub * ratio + g % ratio;
+
+  // nearest resize of the prior depth map (model.py:153-158)
+  const float scy = (float)dh / (float)h, scx = (float)dw / (float)w;
+  int sy = (int)floorf((float)y * scy);
+  int sx = (int)floorf((float)x * scx);
+  sy = sy > dh - 1 ? dh - 1 : sy;
+  sx = sx > dw - 1 ? dw - 1 : sx;
+  const float depth = depth_in[sy * dw + sx] + interval * (float)(d - 2);
+
+  // un-projection (model.py:165-178)
+  const float* Ki = cam + PF_CAM_KREF_INV;
+  const float* Ri = cam + PF_CAM_RREF_INV;
+  const float* t0 = cam + PF_CAM_TREF;
+  const float px = (float)x + 0.5f, py = (float)y + 0.5f;
+  const float u0 = fmaf(Ki[2], 1.0f, fmaf(Ki[1], py, Ki[0] * px));
+  const float u1 = fmaf(Ki[5], 1.0f, fmaf(Ki[4], py, Ki[3] * px));
+  const float u2 = fmaf(Ki[8], 1.0f, fmaf(Ki[7], py, Ki[6] * px));
+  const float q0 = u0 * depth - t0[0], q1 = u1 * depth - t0[1], q2 = u2 * depth - t0[2];
+  const float X = fmaf(Ri[2], q2, fmaf(Ri[1], q1, Ri[0] * q0));
+  const float Y = fmaf(Ri[5], q2, fmaf(Ri[4], q1, Ri[3] * q0));
+  const float Z = fmaf(Ri[8], q2, fmaf(Ri[7], q1, Ri[6] * q0));
+
+  const float nx = (X - cam[PF_CAM_MEAN + 0]) / cam[PF_CAM_STD + 0];
+  const float ny = (Y - cam[PF_CAM_MEAN + 1]) / cam[PF_CAM_STD + 1];
+  const float nz = (Z - cam[PF_CAM_MEAN + 2]) / cam[PF_CAM_STD + 2];
+  float* xo = xyz + (int64_t)g * 3 * Ng + loc;
+  xo[0] = nx;
+  xo[Ng] = ny;
+  xo[2 * Ng] = nz;
+
+  PfTaps t[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    const float* cv = cam + PF_CAM_VIEWS + v * PF_CAM_VIEW_STRIDE;
+    pf_project_taps(X, Y, Z, cv, cv + 9, h, w, t[v]);
+  }
+
+  const int ctot = c1 + c2 + c3 + 24;
+  float* fo = feature + (int64_t)g * ctot * Ng + loc;
+  const int64_t hw = (int64_t)h * w;
+  int ch = 0;
+#pragma unroll 1
+  for (int level = 0; level < 3; ++level) {
+    const float* maps = level == 0 ? maps1 : (level == 1 ? maps2 : maps3);
+    const int cl = level == 0 ? c1 : (level == 1 ? c2 : c3);
+    for (int c = 0; c < cl; ++c, ++ch) {
+      float s = 0.0f, s2 = 0.0f;
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        const float f = pf_sample(maps + ((int64_t)v * cl + c) * hw, t[v]);
+        if (v == 0) {
+          s = f;
+          s2 = f * f;
+        } else {
+          s = s + f;
+          s2 = s2 + f * f;
+        }
+      }
+      const float m1 = s / (float)V;
+      const float m2 = s2 / (float)V;
+      fo[(int64_t)ch * Ng] = m2 - m1 * m1;
+    }
+  }
+  // xyz.repeat(1, 8, 1): channel j of the 24 holds axis j % 3 (model.py:193-194)
+#pragma unroll
+  for (int j = 0; j < 24; ++j) {
+    const float val = (j % 3 == 0) ? nx : ((j % 3 == 1) ? ny : nz);
+    fo[(int64_t)(ch + j) * Ng] = val;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// S: soft-argmin + probability map (reference model.py:117-130, functions/functions.py:141-175)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float linspace_at(float start, float end, float step, int k, int D) {
+  // ATen linspace: start + step*k below the midpoint, end - step*(D-1-k) above it
+  return (k < D / 2) ? (start + step * (float)k) : (end - step * (float)(D - 1 - k));
+}
+
+__global__ __launch_bounds__(256) void softargmin_prob_kernel(const float* __restrict__ cost,
+                                                              const float* __restrict__ params,
+                                                              float* __restrict__ depth,
+                                                              float* __restrict__ prob, int D, int64_t HW) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t b = blockIdx.y;
+  if (i >= HW) return;
+  const float start = params[b * 3 + 0], end = params[b * 3 + 1], interval = params[b * 3 + 2];
+  const float step = (D > 1) ? (end - start) / (float)(D - 1) : 0.0f;
+  const float* c = cost + b * D * HW + i;
+  float mx = -c[0];
+  for (int k = 1; k < D; ++k) mx = fmaxf(mx, -c[(int64_t)k * HW]);
+  float den = 0.0f;
+  for (int k = 0; k < D; ++k) den += expf(-c[(int64_t)k * HW] - mx);
+  float acc = 0.0f;
+  for (int k = 0; k < D; ++k) {
+    const float p = expf(-c[(int64_t)k * HW] - mx) / den;
+    acc += linspace_at(start, end, step, k, D) * p;
+  }
+  depth[b * HW + i] = acc;
+  const float fi = (acc - start) / interval;
+  float lo = floorf(fi), hi = ceilf(fi);
+  lo = fminf(fmaxf(lo, 0.0f), (float)(D - 1));
+  hi = fminf(fmaxf(hi, 0.0f), (float)(D - 1));
+  const float plo = expf(-c[(int64_t)(int)lo * HW] - mx) / den;
+  const float phi = expf(-c[(int64_t)(int)hi * HW] - mx) / den;
+  prob[b * HW + i] = plo + phi;
+}
+
+template <typename F>
+int dispatch_views(int V, F&& f) {
+  switch (V) {
+    case 1: return f(std::integral_constant<int, 1>());
+    case 2: return f(std::integral_constant<int, 2>());
+    case 3: return f(std::integral_constant<int, 3>());
+    case 4: return f(std::integral_constant<int, 4>());
+    case 5: return f(std::integral_constant<int, 5>());
+    case 6: return f(std::integral_constant<int, 6>());
+    case 7: return f(std::integral_constant<int, 7>());
+    case 8: return f(std::integral_constant<int, 8>());
+    default: return PF_ERR_UNSUPPORTED;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int pf_fetch_forward_f32(const float* maps, const float* pts, const float* K, const float* E, float* out,
+                         int64_t B, int64_t V, int64_t C, int64_t H, int64_t W, int64_t N, void* stream) {
+  PF_REQUIRE(B >= 0 && V >= 0 && C >= 0 && H >= 1 && W >= 1 && N >= 0);
+  PF_REQUIRE(B <= 65535 && V <= 65535 && H * W <= INT32_MAX && C <= INT32_MAX);
+  if (B == 0 || V == 0 || C == 0 || N == 0) return PF_OK;
+  PF_REQUIRE(maps && pts && K && out);
+  dim3 grid((unsigned)pf_cdiv(N, 256), (unsigned)V, (unsigned)B);
+  hipLaunchKernelGGL(fetch_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, maps, pts, K, E, out, (int)V,
+                     (int)C, (int)H, (int)W, N);
+  return pf_launch_status();
+}
+
+int pf_fetch_backward_f32(const float* grad_out, const float* pts, const float* K, const float* E,
+                          float* grad_maps, int64_t B, int64_t V, int64_t C, int64_t H, int64_t W, int64_t N,
+                          void* stream) {
+  PF_REQUIRE(B >= 0 && V >= 0 && C >= 0 && H >= 1 && W >= 1 && N >= 0);
+  PF_REQUIRE(B <= 65535 && V <= 65535 && H * W <= INT32_MAX && C <= INT32_MAX);
+  if (B == 0 || V == 0 || C == 0) return PF_OK;
+  PF_REQUIRE(grad_maps != nullptr);
+  PF_HIP(hipMemsetAsync(grad_maps, 0, sizeof(float) * (size_t)(B * V * C * H * W), (hipStream_t)stream));
+  if (N == 0) return PF_OK;
+  PF_REQUIRE(grad_out && pts && K);
+  dim3 grid((unsigned)pf_cdiv(N, 256), (unsigned)V, (unsigned)B);
+  hipLaunchKernelGGL(fetch_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, grad_out, pts, K, E, grad_maps,
+                     (int)V, (int)C, (int)H, (int)W, N);
+  return pf_launch_status();
+}
+
+int pf_fetch_variance_f32(const float* maps, const float* pts, const float* K, const float* E, float* out,
+                          int64_t B, int64_t V, int64_t C, int64_t H, int64_t W, int64_t N, int ref_override,
+                          void* stream) {
+  PF_REQUIRE(B >= 0 && V >= 1 && C >= 0 && H >= 1 && W >= 1 && N >= 0);
+  PF_REQUIRE(B <= 65535 && H * W <= INT32_MAX && C <= INT32_MAX);
+  if (V > PF_MAX_VIEWS) return PF_ERR_UNSUPPORTED;
+  if (B == 0 || C == 0 || N == 0) return PF_OK;
+  PF_REQUIRE(maps && pts && K && out);
+  dim3 grid((unsigned)pf_cdiv(N, 256), (unsigned)B);
+  return dispatch_views((int)V, [&](auto vtag) {
+    constexpr int VV = decltype(vtag)::value;
+    hipLaunchKernelGGL(fetch_variance_kernel<VV>, grid, dim3(256), 0, (hipStream_t)stream, maps, pts, K, E, out,
+                       (int)C, (int)H, (int)W, N, ref_override);
+    return pf_launch_status();
+  });
+}
+
+int pf_resize_bilinear_f32(const float* in, float* out, int64_t P, int64_t IH, int64_t IW, int64_t OH,
+                           int64_t OW, void* stream) {
+  PF_REQUIRE(P >= 0 && IH >= 1 && IW >= 1 && OH >= 1 && OW >= 1);
+  PF_REQUIRE(P <= 65535 && IH * IW <= INT32_MAX && OH * OW <= INT32_MAX);
+  if (P == 0) return PF_OK;
+  PF_REQUIRE(in && out);
+  dim3 grid((unsigned)pf_cdiv(OH * OW, 256), (unsigned)P);
+  const float sy = (float)IH / (float)OH, sx = (float)IW / (float)OW;
+  hipLaunchKernelGGL(resize_bilinear_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, out, (int)IH, (int)IW,
+                     (int)OH, (int)OW, sy, sx);
+  return pf_launch_status();
+}
+
+int pf_flow_features_f32(const float* maps1, const float* maps2, const float* maps3, int c1, int c2, int c3,
+                         int V, int h, int w, const float* depth_in, int dh, int dw, float interval,
+                         const float* cam, int ratio, float* feature, float* xyz, void* stream) {
+  PF_REQUIRE(c1 >= 0 && c2 >= 0 && c3 >= 0 && V >= 1 && h >= 1 && w >= 1 && dh >= 1 && dw >= 1 && ratio >= 1);
+  PF_REQUIRE(h % ratio == 0 && w % ratio == 0);
+  PF_REQUIRE(ratio * ratio <= 65535);
+  if (V > PF_MAX_VIEWS) return PF_ERR_UNSUPPORTED;
+  PF_REQUIRE(maps1 && maps2 && maps3 && depth_in && cam && feature && xyz);
+  const int64_t Ng = (int64_t)5 * (h / ratio) * (w / ratio);
+  dim3 grid((unsigned)pf_cdiv(Ng, 256), (unsigned)(ratio * ratio));
+  return dispatch_views(V, [&](auto vtag) {
+    constexpr int VV = decltype(vtag)::value;
+    hipLaunchKernelGGL(flow_features_kernel<VV>, grid, dim3(256), 0, (hipStream_t)stream, maps1, maps2, maps3,
+                       c1, c2, c3, h, w, depth_in, dh, dw, interval, cam, ratio, feature, xyz);
+    return pf_launch_status();
+  });
+}
+
+int pf_softargmin_prob_f32(const float* cost, const float* params, float* depth, float* prob, int64_t B,
+                           int64_t D, int64_t HW, void* stream) {
+  PF_REQUIRE(B >= 0 && D >= 1 && HW >= 0 && B <= 65535 && D <= INT32_MAX);
+  if (B == 0 || HW == 0) return PF_OK;
+  PF_REQUIRE(cost && params && depth && prob);
+  dim3 grid((unsigned)pf_cdiv(HW, 256), (unsigned)B);
+  hipLaunchKernelGGL(softargmin_prob_kernel, grid, dim3(256), 0, (hipStream_t)stream, cost, params, depth, prob,
+                     (int)D, HW);
+  return pf_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,157 @@
+// Row K: lattice kNN (replaces get_knn_3d, reference utils/torch_utils.py:16-61).
+//
+// The reference materialises a (375,3,5,5,5) +-1 weight on the host and a (B,375,D,H,W) conv3d output
+// per call, then topk's it.  Here one 256-thread workgroup owns an 8x32 (h,w) tile of one lattice
+// plane d: it stages the kernel_size planes [d-hk, d+hk] of xyz with a hk-wide halo into LDS as three
+// planar arrays (zero outside the lattice == the conv's zero padding, torch_utils.py:44), and every
+// lane ranks its k^3 window candidates in registers.
+//
+// Exactness: distances are centre - candidate, d2 = (dx*dx + dy*dy) + dz*dz in float32, no contraction
+// (this file is built with -ffp-contract=off), i.e. the value torch.sum(diff**2, dim=1) produces.
+// Ranking key = (bits(d2) << 32) | candidate_code as one uint64: non-negative floats order like their
+// bit patterns, so one integer compare implements "smaller d2 first, then smaller candidate code"
+// (the reference's tie order is unspecified).  The top list is a sorted register array
+// updated by a compare-exchange pass; the loop is fully unrolled so nothing spills to scratch.
+#include "pf_common.h"
+
+namespace {
+
+struct Strides5 {
+  int64_t b, c, d, h, w;
+};
+
+constexpr int TW = 32;
+constexpr int TH = 8;
+
+template <int CAP>
+__global__ __launch_bounds__(256) void knn_lattice_kernel(const float* __restrict__ xyz, Strides5 st, int D,
+                                                          int H, int W, int ks, int knn,
+                                                          int64_t* __restrict__ idx_out,
+                                                          uint8_t* __restrict__ code_out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int hk = ks >> 1;
+  const int LW = TW + 2 * hk;
+  const int LH = TH + 2 * hk;
+  const int plane = LH * LW;
+  const int total = ks * plane;
+  float* lx = lds;
+  float* ly = lds + total;
+  float* lz = lds + 2 * total;
+
+  const int tx = threadIdx.x & (TW - 1);
+  const int ty = threadIdx.x >> 5;
+  const int w0 = blockIdx.x * TW;
+  const int h0 = blockIdx.y * TH;
+  const int b = blockIdx.z / D;
+  const int d = blockIdx.z - b * D;
+
+  for (int e = threadIdx.x; e < total; e += 256) {
+    const int pl = e / plane;
+    const int rem = e - pl * plane;
+    const int r = rem / LW;
+    const int cc = rem - r * LW;
+    const int dd = d - hk + pl, hh = h0 - hk + r, ww = w0 - hk + cc;
+    const bool in = (dd >= 0) && (dd < D) && (hh >= 0) && (hh < H) && (ww >= 0) && (ww < W);
+    float vx = 0.0f, vy = 0.0f, vz = 0.0f;
+    if (in) {
+      const int64_t off = b * st.b + dd * st.d + hh * st.h + ww * st.w;
+      vx = xyz[off];
+      vy = xyz[off + st.c];
+      vz = xyz[off + 2 * st.c];
+    }
+    lx[e] = vx;
+    ly[e] = vy;
+    lz[e] = vz;
+  }
+  __syncthreads();
+
+  const int h = h0 + ty, w = w0 + tx;
+  if (h >= H || w >= W) return;
+
+  const int ce = (hk * LH + ty + hk) * LW + tx + hk;
+  const float cx = lx[ce], cy = ly[ce], cz = lz[ce];
+
+  uint64_t keys[CAP];
+#pragma unroll
+  for (int j = 0; j < CAP; ++j) keys[j] = ~0ull;
+
+  for (int pl = 0; pl < ks; ++pl) {
+    for (int r = 0; r < ks; ++r) {
+      const int rowbase = (pl * LH + ty + r) * LW + tx;
+      for (int cc = 0; cc < ks; ++cc) {
+        const int e = rowbase + cc;
+        const float dx = cx - lx[e];
+        const float dy = cy - ly[e];
+        const float dz = cz - lz[e];
+        const float d2 = (dx * dx + dy * dy) + dz * dz;
+        const uint32_t code = (uint32_t)((pl * ks + r) * ks + cc);
+        const uint64_t key = ((uint64_t)__float_as_uint(d2) << 32) | (uint64_t)code;
+        if (key < keys[CAP - 1]) {
+          keys[CAP - 1] = key;
+#pragma unroll
+          for (int j = CAP - 1; j > 0; --j) {
+            const uint64_t lo = keys[j - 1] < keys[j] ? keys[j - 1] : keys[j];
+            const uint64_t hi = keys[j - 1] < keys[j] ? keys[j] : keys[j - 1];
+            keys[j - 1] = lo;
+            keys[j] = hi;
+          }
+        }
+      }
+    }
+  }
+
+  const int64_t HW = (int64_t)H * W;
+  const int64_t DHW = HW * D;
+  const int64_t n = (int64_t)d * HW + (int64_t)h * W + w;
+  int64_t* op = idx_out + ((int64_t)b * DHW + n) * knn;
+  uint8_t* cp = code_out ? code_out + ((int64_t)b * DHW + n) * knn : nullptr;
+  const int ks2 = ks * ks;
+#pragma unroll
+  for (int j = 0; j < CAP; ++j) {
+    if (j < knn) {
+      const int code = (int)(uint32_t)(keys[j] & 0xffffffffull);
+      const int pd = code / ks2;
+      const int rem = code - pd * ks2;
+      const int ph = rem / ks;
+      const int pw = rem - ph * ks;
+      int64_t v = n + (int64_t)(pd - hk) * HW + (int64_t)(ph - hk) * W + (pw - hk);
+      v = v < 0 ? 0 : (v > DHW - 1 ? DHW - 1 : v);
+      op[j] = v;
+      if (cp) cp[j] = (uint8_t)code;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int pf_knn_lattice_f32(const float* xyz, const int64_t* strides_host, int64_t B, int64_t D, int64_t H,
+                                  int64_t W, int kernel_size, int knn, int64_t* idx_out, uint8_t* code_out,
+                                  void* stream) {
+  PF_REQUIRE(B >= 0 && D >= 0 && H >= 0 && W >= 0);
+  PF_REQUIRE(kernel_size >= 1 && (kernel_size % 2) == 1);  // reference asserts odd (torch_utils.py:24)
+  if (kernel_size > 7) return PF_ERR_UNSUPPORTED;  // LDS window <= 64 KiB
+  const int k3 = kernel_size * kernel_size * kernel_size;
+  PF_REQUIRE(knn >= 1 && knn <= k3);                       // topk would raise for knn > k^3
+  if (knn > 32) return PF_ERR_UNSUPPORTED;
+  if (code_out != nullptr && k3 > 256) return PF_ERR_UNSUPPORTED;
+  if (B == 0 || D == 0 || H == 0 || W == 0) return PF_OK;
+  PF_REQUIRE(xyz != nullptr && strides_host != nullptr && idx_out != nullptr);
+  PF_REQUIRE(B * D <= 65535 && pf_cdiv(H, TH) <= 65535);
+  PF_REQUIRE(D * H * W <= (int64_t)INT32_MAX * 16);
+  Strides5 st{strides_host[0], strides_host[1], strides_host[2], strides_host[3], strides_host[4]};
+  const int hk = kernel_size / 2;
+  const size_t lds_bytes = (size_t)3 * kernel_size * (TH + 2 * hk) * (TW + 2 * hk) * sizeof(float);
+  dim3 grid((unsigned)pf_cdiv(W, TW), (unsigned)pf_cdiv(H, TH), (unsigned)(B * D));
+  hipStream_t s = (hipStream_t)stream;
+  if (knn <= 8) {
+    hipLaunchKernelGGL(knn_lattice_kernel<8>, grid, dim3(256), lds_bytes, s, xyz, st, (int)D, (int)H, (int)W,
+                       kernel_size, knn, idx_out, code_out);
+  } else if (knn <= 16) {
+    hipLaunchKernelGGL(knn_lattice_kernel<16>, grid, dim3(256), lds_bytes, s, xyz, st, (int)D, (int)H, (int)W,
+                       kernel_size, knn, idx_out, code_out);
+  } else {
+    hipLaunchKernelGGL(knn_lattice_kernel<32>, grid, dim3(256), lds_bytes, s, xyz, st, (int)D, (int)H, (int)W,
+                       kernel_size, knn, idx_out, code_out);
+  }
+  return pf_launch_status();
+}

@@ -1,0 +1,89 @@
+// Shared host/device helpers for libpointflow_hip.so (gfx950 only; no CUDA paths).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pointflow_hip.h"
+
+#define PF_WAVE 64
+
+// Per-device sticky status word (bad neighbour index etc.); allocated on first use.
+unsigned* pf_status_ptr();
+
+#define PF_REQUIRE(cond)                 \
+  do {                                   \
+    if (!(cond)) return PF_ERR_INVALID_ARG; \
+  } while (0)
+
+#define PF_HIP(expr)                        \
+  do {                                      \
+    hipError_t _e = (expr);                 \
+    if (_e != hipSuccess) return (int)_e;   \
+  } while (0)
+
+static inline int pf_launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? PF_OK : (int)e;
+}
+
+static inline int64_t pf_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- projection + bilinear taps shared by the fetch kernels -------------------------------------
+// Follows reference utils/feature_fetcher.py:36-55 on the arithmetic of ATen's CPU grid_sample with
+// align_corners=True (the oracle): un-normalise with (g + 1) * ((size - 1) / 2), weights
+// nw = (1-wy)(1-wx) ..., out = ((nw*a + ne*b) + sw*c) + se*d.  Compiled with -ffp-contract=off so the
+// products/sums below stay separate unless written as fmaf.
+struct PfTaps {
+  int off[4];     // y*W + x of the nw, ne, sw, se taps (0 when the tap is outside the map)
+  float wgt[4];   // bilinear weights
+  bool ok[4];     // tap inside the map
+};
+
+__device__ __forceinline__ void pf_project_taps(float X, float Y, float Z, const float* __restrict__ Kv,
+                                                const float* __restrict__ Ev, int H, int W, PfTaps& t) {
+  float px = X, py = Y, pz = Z;
+  if (Ev != nullptr) {
+    px = fmaf(Ev[2], Z, fmaf(Ev[1], Y, Ev[0] * X)) + Ev[3];
+    py = fmaf(Ev[6], Z, fmaf(Ev[5], Y, Ev[4] * X)) + Ev[7];
+    pz = fmaf(Ev[10], Z, fmaf(Ev[9], Y, Ev[8] * X)) + Ev[11];
+  }
+  const float nx = px / pz;
+  const float ny = py / pz;
+  const float u = fmaf(Kv[2], 1.0f, fmaf(Kv[1], ny, Kv[0] * nx));
+  const float v = fmaf(Kv[5], 1.0f, fmaf(Kv[4], ny, Kv[3] * nx));
+  const float gx = ((u - 0.5f) / (float)(W - 1)) * 2.0f - 1.0f;
+  const float gy = ((v - 0.5f) / (float)(H - 1)) * 2.0f - 1.0f;
+  const float ix = (gx + 1.0f) * ((float)(W - 1) / 2.0f);
+  const float iy = (gy + 1.0f) * ((float)(H - 1) / 2.0f);
+  const float x0 = floorf(ix), y0 = floorf(iy);
+  const float wx1 = ix - x0, wy1 = iy - y0;
+  const float wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
+  const float xmax = (float)(W - 1), ymax = (float)(H - 1);
+  const bool vx0 = (x0 >= 0.0f) && (x0 <= xmax);
+  const bool vx1 = (x0 + 1.0f >= 0.0f) && (x0 + 1.0f <= xmax);
+  const bool vy0 = (y0 >= 0.0f) && (y0 <= ymax);
+  const bool vy1 = (y0 + 1.0f >= 0.0f) && (y0 + 1.0f <= ymax);
+  const int xi = (vx0 || vx1) ? (int)x0 : 0;
+  const int yi = (vy0 || vy1) ? (int)y0 : 0;
+  t.ok[0] = vy0 && vx0;
+  t.ok[1] = vy0 && vx1;
+  t.ok[2] = vy1 && vx0;
+  t.ok[3] = vy1 && vx1;
+  t.off[0] = t.ok[0] ? yi * W + xi : 0;
+  t.off[1] = t.ok[1] ? yi * W + xi + 1 : 0;
+  t.off[2] = t.ok[2] ? (yi + 1) * W + xi : 0;
+  t.off[3] = t.ok[3] ? (yi + 1) * W + xi + 1 : 0;
+  t.wgt[0] = wy0 * wx0;
+  t.wgt[1] = wy0 * wx1;
+  t.wgt[2] = wy1 * wx0;
+  t.wgt[3] = wy1 * wx1;
+}
+
+__device__ __forceinline__ float pf_sample(const float* __restrict__ plane, const PfTaps& t) {
+  const float a = t.ok[0] ? plane[t.off[0]] : 0.0f;
+  const float b = t.ok[1] ? plane[t.off[1]] : 0.0f;
+  const float c = t.ok[2] ? plane[t.off[2]] : 0.0f;
+  const float d = t.ok[3] ? plane[t.off[3]] : 0.0f;
+  return ((a * t.wgt[0] + b * t.wgt[1]) + c * t.wgt[2]) + d * t.wgt[3];
+}

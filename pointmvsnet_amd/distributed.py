@@ -1,0 +1,63 @@
+"""Multi-GPU plumbing: one process per GPU over RCCL/xGMI.
+
+* Inference shards *scenes*: every depth map is independent, so ranks take scenes round-robin and
+  there is no data-path collective (``shard_scenes``).
+* Training (BASELINE config 4) is data parallel with one scene per GPU and per-replica BatchNorm, like
+  the reference's ``nn.DataParallel`` (reference train.py:177).  Gradients are combined with ONE
+  all-reduce of a single flat float32 bucket (698 936 parameters = 2.8 MB: latency-bound on xGMI, so
+  bucketing finer would only add launches).  The reduce op is SUM, not mean: the reference loss sums
+  the per-sample MAE over the batch (networks.py:176-179) and DataParallel reduce-adds replica
+  gradients, so averaging would scale the step by 1/world_size.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun); no-op for 1 process.
+    Returns (rank, world_size, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" is RCCL on ROCm
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_scenes(num_scenes, rank, world_size):
+    """Round-robin scene ownership; the union over ranks is exactly range(num_scenes)."""
+    return list(range(rank, num_scenes, world_size))
+
+
+def allreduce_gradients_sum(module, group=None):
+    """Sum gradients across ranks through one flat bucket.  Parameters without a gradient contribute
+    zeros so every rank reduces the same layout.  Returns the number of elements reduced."""
+    params = [p for p in module.parameters() if p.requires_grad]
+    if not params:
+        return 0
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float()
+                      for p in params])
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    offset = 0
+    for p in params:
+        n = p.numel()
+        if p.grad is None:
+            p.grad = torch.empty_like(p)
+        p.grad.copy_(flat[offset:offset + n].view_as(p))
+        offset += n
+    return int(flat.numel())
+
+
+def broadcast_parameters(module, src=0, group=None):
+    """Make every replica start from rank ``src``'s parameters and buffers."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src=src, group=group)

@@ -1,0 +1,334 @@
+"""PointMVSNet model graph on the MI355X operator layer (SURVEY.md section 8, row "glue").
+
+Same class name, constructor, sub-module names (hence state-dict keys), ``forward`` signature and
+``preds`` keys as reference ``pointmvsnet/model.py:15-305``; the reference's own ``model.py`` also runs
+unchanged on this package's operators (``pointmvsnet_amd.compat.install_as_pointmvsnet``).
+
+Two execution paths:
+
+* inference (no autograd graph needed, the reference's ``test.py`` / validation situation): the fused
+  HIP pipeline -- fetch+variance kernel for the cost volume, soft-argmin kernel, and per PointFlow
+  iteration one feature-assembly kernel, one lattice-kNN kernel, the GEMM/stats/apply EdgeConv chain
+  and the MLP/head kernels, with the r*r test-mode sub-grids batched into single launches;
+* training (autograd): the reference's composition on the differentiable HIP operators
+  (``FeatureFetcher``, ``gather_knn``) and stock ATen for the rest, so gradients match the reference.
+
+Camera algebra (3x3 inverses, intrinsic scaling) is done once per forward on the host in float32 with
+the same ATen CPU calls the reference makes (model.py:54-61, :159-170) and uploaded as small constant
+blocks; it is microseconds of work and keeps the geometry bit-identical to the reference's.
+"""
+import collections
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import pointflow
+from .functions.functions import get_pixel_grids, get_propability_map
+from .networks import EdgeConv, EdgeConvNoC, ImageConv, VolumeConv, MAELoss, Valid_MAELoss
+from .nn.mlp import SharedMLP
+from .utils.feature_fetcher import FeatureFetcher, fetch_variance
+from .utils.torch_utils import get_knn_3d
+
+_HYPOTHESES = (-2, -1, 0, 1, 2)
+
+
+def _host_cams(data_batch):
+    cams = data_batch.get("cam_params_list_host")
+    if cams is None:
+        cams = data_batch["cam_params_list"].detach().cpu()   # one small D2H per forward
+    return cams.float()
+
+
+class _Cameras(object):
+    """Host-side (float32, ATen-CPU) camera algebra shared by both paths."""
+
+    def __init__(self, cams_host, is_test):
+        self.ext = cams_host[:, :, 0, :3, :4].clone()                       # (B,V,3,4)
+        self.R = self.ext[:, :, :3, :3]
+        self.t = self.ext[:, :, :3, 3].unsqueeze(-1)
+        self.R_inv = torch.inverse(self.R)
+        self.K_raw = cams_host[:, :, 1, :3, :3].clone()
+        K = self.K_raw.clone()
+        K[:, :, :2, :3] = K[:, :, :2, :3] / 2.0
+        if is_test:
+            K[:, :, :2, :3] = K[:, :, :2, :3] / 4.0
+        self.K_coarse = K
+        self.depth_start = cams_host[:, 0, 1, 3, 0].clone()
+        self.depth_interval = cams_host[:, 0, 1, 3, 1].clone()
+        self.num_depth = int(cams_host[0, 0, 1, 3, 2].long())
+        self.depth_end = self.depth_start + (self.num_depth - 1) * self.depth_interval
+        self.is_test = is_test
+
+    def flow_intrinsics(self, image_scale):
+        K = self.K_raw.clone()
+        K[:, :, :2, :3] *= image_scale if self.is_test else (4 * image_scale)
+        return K
+
+    def packed(self, K_flow, mean, std):
+        """(B, 27 + 21 V) float32 block in the layout of include/pointflow_hip.h (PF_CAM_*)."""
+        B, V = K_flow.shape[:2]
+        kinv = torch.inverse(K_flow[:, 0])
+        rows = []
+        for b in range(B):
+            parts = [kinv[b].reshape(-1), self.R_inv[b, 0].reshape(-1), self.t[b, 0].reshape(-1),
+                     mean[b].reshape(-1), std[b].reshape(-1)]
+            for v in range(V):
+                parts.append(K_flow[b, v].reshape(-1))
+                parts.append(self.ext[b, v].reshape(-1))
+            rows.append(torch.cat(parts))
+        return torch.stack(rows).float().contiguous()
+
+
+class PointMVSNet(nn.Module):
+    def __init__(self, img_base_channels=8, vol_base_channels=8, flow_channels=(64, 64, 16, 1), k=16):
+        super(PointMVSNet, self).__init__()
+        self.k = k
+        self.feature_fetcher = FeatureFetcher()
+        self.coarse_img_conv = ImageConv(img_base_channels)
+        self.coarse_vol_conv = VolumeConv(self.coarse_img_conv.out_channels, vol_base_channels)
+        self.flow_img_conv = ImageConv(img_base_channels)
+        self.flow_edge_conv = nn.ModuleList([EdgeConvNoC(136, 32), EdgeConv(32, 32), EdgeConv(64, 64)])
+        self.flow_mlp = nn.Sequential(
+            SharedMLP(32 + 32 * 2 + 64 * 2, flow_channels[:-1]),
+            nn.Conv1d(flow_channels[-2], flow_channels[-1], 1, bias=False),
+        )
+        self._grid_cache = {}
+
+    # ------------------------------------------------------------------------------------------
+    def _pixel_grid(self, h, w, device):
+        key = (h, w, str(device))
+        if key not in self._grid_cache:
+            self._grid_cache[key] = get_pixel_grids(h, w).to(device)
+        return self._grid_cache[key]
+
+    def _needs_graph(self):
+        return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+
+    # ------------------------------------------------------------------------------------------
+    def forward(self, data_batch, img_scales, inter_scales, isFlow, isTest=False):
+        img_list = data_batch["img_list"]
+        if not img_list.is_cuda:
+            raise RuntimeError("pointmvsnet_amd.PointMVSNet runs on a GPU (HIP) device only; the CPU "
+                               "restatement lives in oracle/ and is test infrastructure")
+        cam = _Cameras(_host_cams(data_batch), isTest)
+        graph = self._needs_graph()
+        dev = img_list.device
+        B, V, _, H, W = img_list.shape
+        preds = collections.OrderedDict()
+
+        K_coarse = cam.K_coarse.to(dev)
+        ext = cam.ext.to(dev)
+        mean_h = data_batch["mean"].detach().cpu().float()
+        std_h = data_batch["std"].detach().cpu().float()
+
+        # ---- coarse stage (reference model.py:71-130) -----------------------------------------
+        coarse_maps = [self.coarse_img_conv(img_list[:, v])["conv3"] for v in range(V)]
+        feature_list = torch.stack(coarse_maps, dim=1)                       # (B,V,C,FH,FW)
+        C, FH, FW = feature_list.shape[2:]
+        D = cam.num_depth
+
+        depths = torch.stack([torch.linspace(float(cam.depth_start[b]), float(cam.depth_end[b]), D)
+                              for b in range(B)], dim=0).to(dev)            # (B,D)
+        grid = self._pixel_grid(FH, FW, dev).view(1, 1, 3, -1).expand(B, 1, 3, -1)
+        uv = torch.matmul(torch.inverse(cam.K_coarse[:, 0]).to(dev).unsqueeze(1), grid)
+        cam_points = (uv.unsqueeze(3) * depths.view(B, 1, 1, D, 1)).view(B, 1, 3, -1)
+        R_inv0 = cam.R_inv[:, 0:1].to(dev)
+        t0 = cam.t[:, 0:1].to(dev)
+        world_points = torch.matmul(R_inv0, cam_points - t0).transpose(1, 2).contiguous().view(B, 3, -1)
+        preds["world_points"] = world_points
+
+        if graph:
+            point_features = self.feature_fetcher(feature_list, world_points, K_coarse, ext)
+            ref = coarse_maps[0].unsqueeze(2).expand(-1, -1, D, -1, -1).contiguous().view(B, C, -1)
+            point_features = torch.cat([ref.unsqueeze(1), point_features[:, 1:]], dim=1)
+            avg = point_features.mean(dim=1)
+            cost = (point_features ** 2).mean(dim=1) - avg ** 2
+        else:
+            cost = fetch_variance(feature_list, world_points, K_coarse, ext, ref_override=True)
+        cost_volume = cost.view(B, C, D, FH, FW)
+        filtered = self.coarse_vol_conv(cost_volume).squeeze(1)              # (B,D,FH,FW)
+
+        d_start = cam.depth_start.to(dev)
+        d_end = cam.depth_end.to(dev)
+        d_int = cam.depth_interval.to(dev)
+        if graph:
+            prob_volume = F.softmax(-filtered, dim=1)
+            pred_depth = torch.sum(depths.view(B, D, 1, 1) * prob_volume, dim=1).unsqueeze(1)
+            prob_map = get_propability_map(prob_volume, pred_depth, d_start, d_int)
+        else:
+            pred_depth, prob_map = pointflow.soft_argmin_prob(filtered, d_start, d_end, d_int)
+        preds["coarse_depth_map"] = pred_depth
+        preds["coarse_prob_map"] = prob_map
+        if not isFlow:
+            return preds
+
+        # ---- flow stage (reference model.py:132-303) --------------------------------------------
+        names = ("conv1", "conv2", "conv3")
+        per_view = [self.flow_img_conv(img_list[:, v]) for v in range(V)]
+        pyramids = {n: torch.stack([pv[n] for pv in per_view], dim=1) for n in names}   # (B,V,c,h_l,w_l)
+        if isTest:
+            pyramids = {n: p.detach() for n, p in pyramids.items()}
+
+        for it, (img_scale, inter_scale) in enumerate(zip(img_scales, inter_scales)):
+            if isTest:
+                pred_depth = pred_depth.detach()
+            interval_h = inter_scale * cam.depth_interval                   # (B,) float32 on the host
+            h, w = int(H * img_scale), int(W * img_scale)
+            K_flow = cam.flow_intrinsics(img_scale)
+            if isTest and img_scale not in (0.125, 0.25, 0.5, 1.0):
+                raise NotImplementedError
+            ratio = int(img_scale * 8) if (isTest and img_scale != 0.125) else 1
+            if graph:
+                pred_depth, flow_prob = self._point_flow_autograd(
+                    pyramids, pred_depth, interval_h.to(dev), K_flow.to(dev), ext, cam, data_batch, h, w, ratio)
+            else:
+                packed = cam.packed(K_flow, mean_h, std_h).to(dev)
+                outs, probs = [], []
+                for b in range(B):
+                    pyr_b = [pyramids[n][b].contiguous() for n in names]
+                    d_b, p_b = pointflow.flow_iteration(pyr_b, pred_depth[b, 0].contiguous(),
+                                                        float(interval_h[b]), packed[b], h, w, ratio,
+                                                        self.flow_edge_conv, self.flow_mlp, k=self.k)
+                    outs.append(d_b)
+                    probs.append(p_b)
+                pred_depth = torch.stack(outs, dim=0).unsqueeze(1)
+                flow_prob = torch.stack(probs, dim=0)
+            preds["flow{}_prob".format(it + 1)] = flow_prob
+            preds["flow{}".format(it + 1)] = pred_depth
+        return preds
+
+    # ------------------------------------------------------------------------------------------
+    # differentiable composition (training): reference model.py:150-295 on the HIP operators
+    # ------------------------------------------------------------------------------------------
+    def _sub_flow_autograd(self, xyz, feature, interval):
+        B, _, D, hs, ws = xyz.shape
+        nn_idx = get_knn_3d(xyz, D, knn=self.k)
+        x = feature.contiguous().view(B, -1, D * hs * ws)
+        edges = []
+        for conv in self.flow_edge_conv:
+            x = conv(x, nn_idx)
+            edges.append(x)
+        flow = self.flow_mlp(torch.cat(edges, dim=1)).contiguous().view(B, D, hs, ws)
+        prob = F.softmax(-flow, dim=1)
+        length = torch.tensor(_HYPOTHESES, dtype=torch.float32, device=xyz.device).view(1, -1, 1, 1) \
+            * interval.view(-1, 1, 1, 1)
+        return torch.sum(prob * length, dim=1, keepdim=True), prob
+
+    def _point_flow_autograd(self, pyramids, depth_map, interval, K_flow, ext, cam, data_batch, h, w, ratio):
+        dev = depth_map.device
+        B = depth_map.shape[0]
+        if depth_map.shape[2] != h:
+            depth_map = F.interpolate(depth_map, (h, w), mode="nearest")
+        mean = data_batch["mean"].to(dev).unsqueeze(-1)
+        std = data_batch["std"].to(dev).unsqueeze(-1)
+        grid = self._pixel_grid(h, w, dev).view(1, 1, 3, -1).expand(B, 1, 3, -1)
+        uv = torch.matmul(torch.inverse(K_flow[:, 0].cpu()).to(dev).unsqueeze(1), grid)
+        R_inv0 = cam.R_inv[:, 0:1].to(dev)
+        t0 = cam.t[:, 0:1].to(dev)
+        resized = {}
+        for name, fm in pyramids.items():
+            V, c, fh, fw = fm.shape[1:]
+            r = F.interpolate(fm.reshape(-1, c, fh, fw), (h, w), mode="bilinear", align_corners=False)
+            resized[name] = r.view(B, V, c, h, w)
+        feats, xyzs = [], []
+        for i in _HYPOTHESES:
+            d = depth_map + interval.view(-1, 1, 1, 1) * i
+            cam_points = uv * d.view(B, 1, 1, -1)
+            world = torch.matmul(R_inv0, cam_points - t0).transpose(1, 2).contiguous().view(B, 3, -1)
+            chunks = []
+            for name in ("conv1", "conv2", "conv3"):
+                pf = self.feature_fetcher(resized[name], world, K_flow, ext)
+                avg = pf.mean(dim=1)
+                chunks.append((pf ** 2).mean(dim=1) - avg ** 2)
+            xyz = (world - mean) / std
+            chunks.append(xyz.repeat(1, 8, 1))
+            feats.append(torch.cat(chunks, dim=1))
+            xyzs.append(xyz)
+        feature = torch.stack(feats, dim=2)                                  # (B,136,5,h*w)
+        xyz = torch.stack(xyzs, dim=2).contiguous().view(B, 3, 5, h, w)
+        if ratio == 1:
+            flow, prob = self._sub_flow_autograd(xyz, feature.view(B, -1, 5, h, w), interval)
+        else:
+            hs, ws = h // ratio, w // ratio
+            f7 = feature.view(B, -1, 5, hs, ratio, ws, ratio)
+            x7 = xyz.view(B, 3, 5, hs, ratio, ws, ratio)
+            rows_f, rows_p = [], []
+            for i in range(ratio):
+                cols_f, cols_p = [], []
+                for j in range(ratio):
+                    fij, pij = self._sub_flow_autograd(x7[:, :, :, :, i, :, j], f7[:, :, :, :, i, :, j], interval)
+                    cols_f.append(fij)
+                    cols_p.append(pij)
+                rows_f.append(torch.stack(cols_f, dim=4))
+                rows_p.append(torch.stack(cols_p, dim=4))
+            flow = torch.stack(rows_f, dim=3).contiguous().view(B, 1, h, w)
+            prob = torch.stack(rows_p, dim=3).contiguous().view(B, 5, h, w)
+        return depth_map + flow, prob
+
+
+class PointMVSNetLoss(nn.Module):
+    """Coarse + flow1 + flow2 masked MAE, each divided by the number of terms (reference model.py:308-339)."""
+
+    def __init__(self, valid_threshold):
+        super(PointMVSNetLoss, self).__init__()
+        self.maeloss = MAELoss()
+        self.valid_maeloss = Valid_MAELoss(valid_threshold)
+
+    def forward(self, preds, labels, isFlow):
+        gt = labels["gt_depth_img"]
+        interval = labels["cam_params_list"][:, 0, 1, 3, 1]
+        stages = [("coarse_loss", "coarse_depth_map", 1.0)]
+        if isFlow:
+            stages += [("flow1_loss", "flow1", 0.75), ("flow2_loss", "flow2", 0.375)]
+        losses = {}
+        for name, key, scale in stages:
+            pred = preds[key]
+            target = F.interpolate(gt, (pred.shape[2], pred.shape[3]))
+            losses[name] = self.maeloss(pred, target, scale * interval if scale != 1.0 else interval)
+        n = float(len(losses))
+        return {k: v / n for k, v in losses.items()}
+
+
+def _less_pct(pred, gt, interval, threshold, mask):
+    err = torch.abs(pred - gt) / interval.view(-1, 1, 1, 1)
+    return torch.sum(mask * (err <= threshold).float()) / (torch.sum(mask) + 1e-7)
+
+
+class PointMVSNetMetric(nn.Module):
+    """<1 / <3 interval accuracies per stage (reference model.py:342-420)."""
+
+    def __init__(self, valid_threshold):
+        super(PointMVSNetMetric, self).__init__()
+        self.valid_threshold = valid_threshold
+
+    def forward(self, preds, labels, isFlow):
+        gt = labels["gt_depth_img"]
+        interval = labels["cam_params_list"][:, 0, 1, 3, 1]
+        coarse = preds["coarse_depth_map"]
+        target = F.interpolate(gt, (coarse.shape[2], coarse.shape[3]))
+        valid = (target != 0.0).float()
+        metrics = {"<1_pct_cor": _less_pct(coarse, target, interval, 1.0, valid),
+                   "<3_pct_cor": _less_pct(coarse, target, interval, 3.0, valid)}
+        if isFlow:
+            before = coarse
+            for name, scale in (("flow1", 0.75), ("flow2", 0.375)):
+                pred = preds[name]
+                target = F.interpolate(gt, (pred.shape[2], pred.shape[3]))
+                iv = scale * interval
+                if before.size(2) != pred.size(2):
+                    before = F.interpolate(before, (pred.shape[2], pred.shape[3]))
+                prior_err = torch.abs(before - target) / iv.view(-1, 1, 1, 1)
+                mask = (prior_err < self.valid_threshold).float() * (target != 0.0).float()
+                metrics["<1_pct_" + name] = _less_pct(pred, target, iv, 1.0, mask)
+                metrics["<3_pct_" + name] = _less_pct(pred, target, iv, 3.0, mask)
+                before = pred
+        return metrics
+
+
+def build_pointmvsnet(cfg):
+    net = PointMVSNet(img_base_channels=cfg.MODEL.IMG_BASE_CHANNELS,
+                      vol_base_channels=cfg.MODEL.VOL_BASE_CHANNELS,
+                      flow_channels=cfg.MODEL.FLOW_CHANNELS)
+    return net, PointMVSNetLoss(valid_threshold=cfg.MODEL.VALID_THRESHOLD), \
+        PointMVSNetMetric(valid_threshold=cfg.MODEL.VALID_THRESHOLD)

@@ -1,0 +1,232 @@
+"""Host-side orchestration of the fused PointFlow kernels.
+
+Everything here is plumbing over the C ABI (include/pointflow_hip.h): buffer allocation with torch,
+weight packing, and the launch sequence.  No arithmetic of the hot path happens in torch.
+
+Point organisation: ``G`` groups of ``Ng`` points.  Test-mode inference at image scale s > 1/8 splits
+the (5,h,w) lattice into r*r strided sub-lattices that the reference processes sequentially, each with
+its own kNN and its own BatchNorm batch statistics (reference model.py:231-267); here they are the
+groups of one batched launch (G = r*r, one stat group per group).  The nn.Module API of EdgeConv uses
+G = batch size with all groups pooled into one stat group (BatchNorm2d pools over the batch).
+"""
+import torch
+
+from . import _lib
+from .utils.torch_utils import knn_lattice
+
+_F32 = torch.float32
+
+
+# ---------------------------------------------------------------------------------------------
+# small helpers
+# ---------------------------------------------------------------------------------------------
+def stat_blocks(G, Ng):
+    return int(_lib.load().pf_stat_blocks(int(G), int(Ng)))
+
+
+def pack_weight_t(*convs):
+    """Stack 1x1 conv weights (Cout_i, K, 1) along the output axis, transpose to (K, Nc) row-major and
+    zero-pad Nc to a multiple of 32 (MFMA column tiles).  Returns (Wt, Cout_total)."""
+    w = torch.cat([c.reshape(c.shape[0], c.shape[1]) for c in convs], dim=0).detach().to(_F32)
+    cout, K = w.shape
+    nc = (cout + 31) // 32 * 32
+    wt = torch.zeros((K, nc), dtype=_F32, device=w.device)
+    wt[:, :cout] = w.t()
+    return wt.contiguous(), cout
+
+
+def pointwise_gemm(X, point_major, ldx, Wt, Y, ldy, G, Ng, K, nc_store, in_affine=None, groups_per_stat=1,
+                   want_stats=False):
+    """Y[:, :nc_store] = act(X) @ Wt (see pf_pointwise_gemm_f32).  Returns the float64 column partials
+    (G, T, Nc, 2) when ``want_stats``."""
+    Nc = Wt.shape[1]
+    T = stat_blocks(G, Ng)
+    partials = torch.empty((G, T, Nc, 2), dtype=torch.float64, device=Wt.device) if want_stats else None
+    sc, sh = in_affine if in_affine is not None else (None, None)
+    _lib.check(_lib.load().pf_pointwise_gemm_f32(
+        _lib.ptr(X), int(bool(point_major)), int(ldx), _lib.ptr(Wt), _lib.ptr(Y), int(ldy), int(G), int(Ng),
+        int(K), int(Nc), int(nc_store), _lib.ptr(sc), _lib.ptr(sh), int(groups_per_stat), _lib.ptr(partials),
+        _lib.stream()), "pointwise_gemm")
+    return partials
+
+
+def bn_affine(bn, partials, col0, C, count, unbias_n, G, groups_per_stat, scale, shift, ch0=0):
+    """Train-mode BatchNorm statistics -> (scale, shift) rows, plus the running-stat update the module
+    would have made (one update per stat group, in order).  ``ch0`` selects the slice of the module's
+    channels (EdgeConv's BN covers [central | difference])."""
+    if bn.momentum is None:
+        raise NotImplementedError("cumulative-average BatchNorm momentum is not supported")
+    T, pcols = partials.shape[1], partials.shape[2]
+    track = bn.track_running_stats and bn.running_mean is not None
+    rm = bn.running_mean[ch0:ch0 + C] if track else None
+    rv = bn.running_var[ch0:ch0 + C] if track else None
+    _lib.check(_lib.load().pf_bn_finalize_f32(
+        _lib.ptr(partials), int(T), int(pcols), int(col0), int(C), float(count), float(unbias_n),
+        _lib.ptr(bn.weight.detach()[ch0:ch0 + C]), _lib.ptr(bn.bias.detach()[ch0:ch0 + C]), _lib.ptr(rm),
+        _lib.ptr(rv), float(bn.momentum), float(bn.eps), int(G), int(groups_per_stat), _lib.ptr(scale),
+        _lib.ptr(shift), int(scale.stride(0)), _lib.stream()), "bn_finalize")
+
+
+def eval_affine(bn, S, ld, ch0=0, C=None, out=None):
+    """Eval-mode BatchNorm (running statistics) folded to scale/shift rows."""
+    C = bn.num_features - ch0 if C is None else C
+    inv = torch.rsqrt(bn.running_var[ch0:ch0 + C] + bn.eps) * bn.weight.detach()[ch0:ch0 + C]
+    sh = bn.bias.detach()[ch0:ch0 + C] - bn.running_mean[ch0:ch0 + C] * inv
+    return inv, sh
+
+
+# ---------------------------------------------------------------------------------------------
+# EdgeConv (rows E0 / E1 / E2)
+# ---------------------------------------------------------------------------------------------
+def edge_conv_fused(X, point_major, ldx, K, G, Ng, idx, conv1_w, conv2_w, bn, concat, Y, ldy,
+                    groups_per_stat=1):
+    """One EdgeConv / EdgeConvNoC layer on G groups of Ng points (reference networks.py:18-45, :56-81).
+
+    X: channel-major (G,K,Ng) or point-major rows; idx (G,Ng,k) int64 group-local; Y: point-major view
+    with ``ldy`` floats per point receiving [central | diff] (concat) or diff (NoC)."""
+    lib = _lib.load()
+    C = conv1_w.shape[0]
+    k = idx.shape[-1]
+    dev = Y.device
+    S = G // groups_per_stat
+    training = bn.training or not bn.track_running_stats
+    Wt, _ = pack_weight_t(conv1_w, conv2_w)                      # (K, 2C): [l | e]
+    LE = torch.empty((G * Ng, 2 * C), dtype=_F32, device=dev)
+    cbn = 2 * C if concat else C
+    scale = torch.empty((S, cbn), dtype=_F32, device=dev)
+    shift = torch.empty((S, cbn), dtype=_F32, device=dev)
+    part_l = pointwise_gemm(X, point_major, ldx, Wt, LE, 2 * C, G, Ng, K, 2 * C,
+                            groups_per_stat=groups_per_stat, want_stats=(concat and training))
+    if training:
+        T = stat_blocks(G, Ng)
+        part_d = torch.empty((G, T, C, 2), dtype=torch.float64, device=dev)
+        _lib.check(lib.pf_edge_stats_f32(_lib.ptr(LE), 2 * C, C, _lib.ptr(idx), k, G, Ng, _lib.ptr(part_d),
+                                         _lib.stream()), "edge_stats")
+        n_pairs = float(groups_per_stat) * Ng * k
+        if concat:
+            bn_affine(bn, part_l, 0, C, float(groups_per_stat) * Ng, n_pairs, G, groups_per_stat,
+                      scale, shift, ch0=0)
+            bn_affine(bn, part_d, 0, C, n_pairs, n_pairs, G, groups_per_stat, scale[:, C:], shift[:, C:], ch0=C)
+        else:
+            bn_affine(bn, part_d, 0, C, n_pairs, n_pairs, G, groups_per_stat, scale, shift, ch0=0)
+        if bn.track_running_stats and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(S)
+    else:
+        sc, sh = eval_affine(bn, S, cbn)
+        scale.copy_(sc.unsqueeze(0).expand(S, cbn))
+        shift.copy_(sh.unsqueeze(0).expand(S, cbn))
+    _lib.check(lib.pf_edge_apply_f32(_lib.ptr(LE), 2 * C, C, _lib.ptr(idx), k, G, Ng, _lib.ptr(scale),
+                                     _lib.ptr(shift), cbn, groups_per_stat, int(bool(concat)), _lib.ptr(Y),
+                                     int(ldy), _lib.stream()), "edge_apply")
+    return Y
+
+
+def _bn_affine_from_gemm(bn, partials, C, G, Ng, groups_per_stat, dev):
+    """BatchNorm1d after a pointwise GEMM: statistics over the points of a stat group."""
+    S = G // groups_per_stat
+    scale = torch.empty((S, C), dtype=_F32, device=dev)
+    shift = torch.empty((S, C), dtype=_F32, device=dev)
+    if bn.training or not bn.track_running_stats:
+        n = float(groups_per_stat) * Ng
+        bn_affine(bn, partials, 0, C, n, n, G, groups_per_stat, scale, shift)
+        if bn.track_running_stats and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(S)
+    else:
+        sc, sh = eval_affine(bn, S, C)
+        scale.copy_(sc.unsqueeze(0).expand(S, C))
+        shift.copy_(sh.unsqueeze(0).expand(S, C))
+    return scale, shift
+
+
+# ---------------------------------------------------------------------------------------------
+# rows F, K, E*, M, H, T for one scene: one PointFlow iteration
+# ---------------------------------------------------------------------------------------------
+def resize_maps(maps, h, w):
+    """(V,C,IH,IW) -> (V,C,h,w), bilinear align_corners=False (the F.interpolate of model.py:184)."""
+    V, C, IH, IW = maps.shape
+    if IH == h and IW == w:
+        return maps
+    out = torch.empty((V, C, h, w), dtype=_F32, device=maps.device)
+    _lib.check(_lib.load().pf_resize_bilinear_f32(_lib.ptr(maps), _lib.ptr(out), V * C, IH, IW, h, w,
+                                                  _lib.stream()), "resize_bilinear")
+    return out
+
+
+def flow_features(levels, depth, interval, cam, h, w, ratio):
+    """Row F.  levels: three (V,c,h,w) maps; depth (dh,dw); cam: packed camera block (device float32).
+    Returns feature (G, 136, Ng) and xyz (G, 3, Ng) in sub-grid-major order."""
+    V = levels[0].shape[0]
+    c1, c2, c3 = (int(l.shape[1]) for l in levels)
+    G = ratio * ratio
+    Ng = 5 * (h // ratio) * (w // ratio)
+    dev = depth.device
+    feature = torch.empty((G, c1 + c2 + c3 + 24, Ng), dtype=_F32, device=dev)
+    xyz = torch.empty((G, 3, Ng), dtype=_F32, device=dev)
+    _lib.check(_lib.load().pf_flow_features_f32(
+        _lib.ptr(levels[0]), _lib.ptr(levels[1]), _lib.ptr(levels[2]), c1, c2, c3, V, h, w, _lib.ptr(depth),
+        int(depth.shape[-2]), int(depth.shape[-1]), float(interval), _lib.ptr(cam), int(ratio),
+        _lib.ptr(feature), _lib.ptr(xyz), _lib.stream()), "flow_features")
+    return feature, xyz
+
+
+def flow_iteration(pyramid, depth, interval, cam, h, w, ratio, edge_convs, flow_mlp, k=16):
+    """One PointFlow refinement of one scene (reference model.py:150-295 for batch item b).
+
+    pyramid: three contiguous (V,c,H_l,W_l) feature maps of this scene; depth: (dh,dw) prior depth map;
+    interval: float hypothesis spacing; cam: packed camera block for this scale.
+    Returns (depth_out (h,w), flow_prob (5,h,w))."""
+    lib = _lib.load()
+    dev = depth.device
+    levels = [resize_maps(m, h, w) for m in pyramid]
+    feature, xyz = flow_features(levels, depth, interval, cam, h, w, ratio)
+    G, Cin, Ng = feature.shape
+    hs, ws = h // ratio, w // ratio
+    idx = knn_lattice(xyz.view(G, 3, 5, hs, ws), 5, k)                     # (G, Ng, k), group-local
+
+    widths = []
+    for m in edge_convs:
+        c = m.conv1.weight.shape[0]
+        widths.append(2 * c if m.concat else c)
+    ctot = sum(widths)
+    edges = torch.empty((G * Ng, ctot), dtype=_F32, device=dev)            # the (N,224) concat buffer
+    col = 0
+    X, pm, ldx, K = feature, False, 0, Cin
+    for m, wdt in zip(edge_convs, widths):
+        Y = edges[:, col:]
+        edge_conv_fused(X, pm, ldx, K, G, Ng, idx, m.conv1.weight, m.conv2.weight, m.bn, m.concat, Y, ctot)
+        X, pm, ldx, K = Y, True, ctot, wdt
+        col += wdt
+
+    # flow MLP: SharedMLP (conv1d + BN1d + ReLU) x3, then Conv1d 16->1 (model.py:40-43)
+    shared, last = flow_mlp[0], flow_mlp[1]
+    X, ldx, K = edges, ctot, ctot
+    affine = None
+    for layer in shared:
+        Wt, cout = pack_weight_t(layer.conv.weight)
+        Z = torch.empty((G * Ng, cout), dtype=_F32, device=dev)
+        part = pointwise_gemm(X, True, ldx, Wt, Z, cout, G, Ng, K, cout, in_affine=affine, want_stats=True)
+        affine = _bn_affine_from_gemm(layer.bn, part, cout, G, Ng, 1, dev)
+        X, ldx, K = Z, cout, cout
+    if K != 16 or last.weight.shape[0] != 1:
+        raise NotImplementedError("flow head kernel is built for the reference widths (..., 16, 1)")
+    depth_out = torch.empty((h, w), dtype=_F32, device=dev)
+    flow_prob = torch.empty((5, h, w), dtype=_F32, device=dev)
+    w_out = last.weight.detach().reshape(-1).to(_F32).contiguous()
+    _lib.check(lib.pf_flow_head_f32(_lib.ptr(X), ldx, _lib.ptr(affine[0]), _lib.ptr(affine[1]), 16,
+                                    _lib.ptr(w_out), _lib.ptr(depth), int(depth.shape[-2]),
+                                    int(depth.shape[-1]), float(interval), h, w, ratio, _lib.ptr(flow_prob),
+                                    _lib.ptr(depth_out), _lib.stream()), "flow_head")
+    return depth_out, flow_prob
+
+
+def soft_argmin_prob(cost, depth_start, depth_end, depth_interval):
+    """Row S: cost (B,D,H,W) filtered volume -> depth (B,1,H,W), prob (B,1,H,W).
+    depth_start/end/interval: (B,) float32 tensors on the same device."""
+    B, D, H, W = cost.shape
+    cost = cost.contiguous()
+    params = torch.stack([depth_start, depth_end, depth_interval], dim=1).to(_F32).contiguous()
+    depth = torch.empty((B, 1, H, W), dtype=_F32, device=cost.device)
+    prob = torch.empty((B, 1, H, W), dtype=_F32, device=cost.device)
+    _lib.check(_lib.load().pf_softargmin_prob_f32(_lib.ptr(cost), _lib.ptr(params), _lib.ptr(depth),
+                                                  _lib.ptr(prob), B, D, H * W, _lib.stream()), "softargmin_prob")
+    return depth, prob

@@ -1,0 +1,82 @@
+"""FeatureFetcher: the multi-view warp.
+
+Same ``nn.Module`` surface as reference utils/feature_fetcher.py:8-60: forward(feature_maps (B,V,C,H,W),
+pts (B,3,N), cam_intrinsics (B,V,3,3), cam_extrinsics (B,V,3,4) or None) -> (B,V,C,N), a fresh
+contiguous tensor (the model writes into it in place, model.py:106), differentiable w.r.t. the
+feature maps only (the sampling grid is built under no_grad in the reference, :29).
+"""
+import torch
+import torch.nn as nn
+
+from .. import _lib
+
+
+class _Fetch(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, maps, pts, K, E):
+        B, V, C, H, W = maps.shape
+        N = pts.size(2)
+        out = torch.empty((B, V, C, N), dtype=torch.float32, device=maps.device)
+        with torch.cuda.device(maps.device):
+            _lib.check(_lib.load().pf_fetch_forward_f32(_lib.ptr(maps), _lib.ptr(pts), _lib.ptr(K), _lib.ptr(E),
+                                                        _lib.ptr(out), B, V, C, H, W, N, _lib.stream()),
+                       "fetch_forward")
+        ctx.save_for_backward(pts, K, E if E is not None else torch.empty(0, device=maps.device))
+        ctx.has_ext = E is not None
+        ctx.shape = (B, V, C, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        pts, K, E = ctx.saved_tensors
+        B, V, C, H, W = ctx.shape
+        N = pts.size(2)
+        g = grad_out.contiguous()
+        grad_maps = torch.empty((B, V, C, H, W), dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            _lib.check(_lib.load().pf_fetch_backward_f32(_lib.ptr(g), _lib.ptr(pts), _lib.ptr(K),
+                                                         _lib.ptr(E) if ctx.has_ext else None,
+                                                         _lib.ptr(grad_maps), B, V, C, H, W, N, _lib.stream()),
+                       "fetch_backward")
+        return grad_maps, None, None, None
+
+
+def _prep(feature_maps, pts, cam_intrinsics, cam_extrinsics):
+    _lib.require_gpu(feature_maps, pts, cam_intrinsics, cam_extrinsics)
+    if feature_maps.dim() != 5 or pts.dim() != 3 or pts.size(1) != 3:
+        raise RuntimeError("FeatureFetcher: expected feature_maps (B,V,C,H,W) and pts (B,3,N)")
+    B, V = feature_maps.shape[:2]
+    maps = feature_maps.float().contiguous()
+    p = pts.detach().float().contiguous()
+    K = cam_intrinsics.detach().float().reshape(B, V, 3, 3).contiguous()
+    E = None if cam_extrinsics is None else cam_extrinsics.detach().float().reshape(B, V, 3, 4).contiguous()
+    return maps, p, K, E
+
+
+class FeatureFetcher(nn.Module):
+    def __init__(self, mode="bilinear"):
+        super(FeatureFetcher, self).__init__()
+        if mode != "bilinear":
+            raise NotImplementedError("FeatureFetcher: only the reference default mode 'bilinear' is built")
+        self.mode = mode
+
+    def forward(self, feature_maps, pts, cam_intrinsics, cam_extrinsics):
+        maps, p, K, E = _prep(feature_maps, pts, cam_intrinsics, cam_extrinsics)
+        return _Fetch.apply(maps, p, K, E)
+
+
+def fetch_variance(feature_maps, pts, cam_intrinsics, cam_extrinsics, ref_override=False):
+    """Fused rows W+V: variance over views of the fetched features, (B,C,N); inference only.
+
+    ``ref_override`` makes view 0 contribute its un-warped map (reference model.py:103-106)."""
+    maps, p, K, E = _prep(feature_maps, pts, cam_intrinsics, cam_extrinsics)
+    B, V, C, H, W = maps.shape
+    N = p.size(2)
+    if ref_override and N % (H * W) != 0:
+        raise RuntimeError("fetch_variance: ref_override needs N to be a multiple of H*W")
+    out = torch.empty((B, C, N), dtype=torch.float32, device=maps.device)
+    with torch.cuda.device(maps.device):
+        _lib.check(_lib.load().pf_fetch_variance_f32(_lib.ptr(maps), _lib.ptr(p), _lib.ptr(K), _lib.ptr(E),
+                                                     _lib.ptr(out), B, V, C, H, W, N, int(bool(ref_override)),
+                                                     _lib.stream()), "fetch_variance")
+    return out
