@@ -1,0 +1,191 @@
+"""Benchmark: depth-maps/sec of the PointFlow path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one whole PointMVSNet.forward(isFlow=True, isTest=True) on one synthetic DTU-like scene of
+the named workload (default BASELINE configs[1]: 640x512, 3 views, 48 depth hypotheses, 2 flow
+iterations), i.e. one depth map, with both ImageConv towers and VolumeConv inside the timed region and
+the inputs resident in HBM when it starts.  Multi-GPU = one process per GPU, scenes sharded round-robin
+(pointmvsnet_amd.distributed.shard_scenes), no data-path collective; timing is bracketed by a barrier and
+torch.cuda.synchronize() on both sides and the MAX over ranks is used; `value` is the whole-job rate.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline     - the dominant hand-written kernel of the path: achieved = algorithmic bytes per launch /
+                 average launch duration measured with HIP events inside the timed region (two event
+                 records per launch of that one entry point; which entry point is dominant is decided in
+                 an instrumented calibration pass before the timed region);
+  cpu_baseline - the CPU oracle (oracle/pointflow_oracle.py, a port of the reference's op sequence) timed
+                 on this host's cores on a bounded sample of the same workload (rank 0, N=1 only);
+  kernels      - per-entry-point time split of the calibration pass (informational).
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from pointmvsnet_amd import _lib, distributed, synthetic  # noqa: E402
+from pointmvsnet_amd.model import PointMVSNet  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+WORKLOAD_TEXT = {
+    "cfg1": "cfg1: DTU 640x512 (160x128 depth grid), 3 views, 48 hypotheses, 1 flow iter",
+    "cfg2": "cfg2: DTU 640x512, 3 source views, 48 depth hypotheses, 2 flow iters",
+    "cfg3": "cfg3: DTU 1280x960, 5 views, 96 depth hypotheses, 3 flow iters",
+    "cfg5": "cfg5: 1600x1152, 7 views, 96 hypotheses, 3 flow iters (variance aggregation)",
+    "tiny": "tiny: 192x128, 3 views, 8 hypotheses, 2 flow iters (smoke only)",
+    "small": "small: 320x256, 3 views, 16 hypotheses, 3 flow iters (smoke only)",
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="cfg2", choices=sorted(synthetic.CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-repeats", type=int, default=5)
+    return ap.parse_args()
+
+
+def to_device(data, dev):
+    out = {k: v.to(dev) for k, v in data.items()}
+    out["cam_params_list_host"] = data["cam_params_list"]
+    out["mean_host"], out["std_host"] = data["mean"], data["std"]       # host copy: no D2H inside the step
+    return out
+
+
+def cpu_baseline(net, data, img_scales, inter_scales, repeats, text):
+    """The oracle restates the reference op-for-op on torch-CPU (oracle/pointflow_oracle.py); it is the
+    checker, timed here only as the CPU baseline the north star is quoted against."""
+    from oracle import pointflow_oracle as O
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    times = []
+    with torch.no_grad():
+        O.forward(sd, data, img_scales, inter_scales, True, True)              # warm-up
+        for _ in range(max(1, repeats)):
+            t0 = time.perf_counter()
+            O.forward(sd, data, img_scales, inter_scales, True, True)
+            times.append(time.perf_counter() - t0)
+    med = statistics.median(times)
+    return {"value": 1.0 / med, "unit": "depth-maps/s", "cores": int(torch.get_num_threads()),
+            "host_cpus": int(os.cpu_count() or 0), "kind": "port",
+            "sample": "%d x whole forward of %s, median %.3f s (1 warm-up)" % (len(times), text, med)}
+
+
+def main():
+    args = parse_args()
+    rank, world, local = distributed.init_from_env()
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    _lib.load()
+
+    h, w, V, D, _, img_scales, inter_scales = synthetic.CONFIGS[args.config]
+    total_steps = args.warmup + args.steps
+    # every rank owns its own scenes (weak scaling: per-GPU work fixed as N grows)
+    my_scenes = distributed.shard_scenes(world * total_steps, rank, world)
+    n_unique = min(4, len(my_scenes))
+    scenes = []
+    for i in range(n_unique):
+        data, _, _ = synthetic.make_config(args.config, seed=my_scenes[i])
+        scenes.append(to_device(data, dev))
+    net = PointMVSNet()
+    synthetic.seed_weights(net, seed=0)
+    net = net.to(dev).train()                                                   # reference test.py:58
+
+    def step(i):
+        with torch.no_grad():
+            return net(scenes[i % n_unique], img_scales, inter_scales, isFlow=True, isTest=True)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    # ---- warm-up, then a calibration pass that times every hand-written entry point --------------
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    cal = _lib.KernelTimer()
+    _lib.set_timer(cal)
+    for i in range(2):
+        step(i)
+    _lib.set_timer(None)
+    split = cal.summary()
+    dominant = max(split.items(), key=lambda kv: kv[1]["ms"])[0] if split else None
+
+    # ---- timed region ------------------------------------------------------------------------------
+    timer = _lib.KernelTimer(only=dominant)
+    _lib.set_timer(timer)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        preds = step(args.warmup + i)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    _lib.set_timer(None)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(preds["flow%d" % len(img_scales)]).all()
+
+    if rank != 0:
+        return
+    roof = None
+    if dominant is not None:
+        s = timer.summary()[dominant]
+        avg_s = s["ms"] / 1e3 / s["launches"]
+        avg_bytes = s["bytes"] / s["launches"]
+        achieved = avg_bytes / avg_s / 1e9
+        roof = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": avg_s * 1e6,
+                "launches": s["launches"], "algorithmic_bytes_per_launch": avg_bytes}
+    kernels = {k: {"launches_per_step": v["launches"] / 2.0, "us_per_step": v["ms"] * 1e3 / 2.0,
+                   "algo_GBps": (v["bytes"] / (v["ms"] / 1e3) / 1e9) if v["ms"] > 0 else None}
+               for k, v in sorted(split.items(), key=lambda kv: -kv[1]["ms"])}
+    result = {
+        "metric": "depth-maps/sec (DTU 640x512, 3 src views, 2 flow iters)" if args.config == "cfg2"
+        else "depth-maps/sec (%s)" % args.config,
+        "value": world * args.steps / elapsed,
+        "unit": "depth-maps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": WORKLOAD_TEXT[args.config], "height": h, "width": w, "views": V, "depth_planes": D,
+                   "img_scales": list(img_scales), "inter_scales": list(inter_scales), "batch_per_gpu": 1,
+                   "parallelism": "scene-sharded replicas x%d (no data-path collective)" % world,
+                   "mode": "PointMVSNet.forward(isFlow=True, isTest=True), BatchNorm in train mode (test.py:58)"},
+        "roofline": roof,
+        "kernels": kernels,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        data_cpu, _, _ = synthetic.make_config(args.config, seed=my_scenes[0])
+        result["cpu_baseline"] = cpu_baseline(net, data_cpu, img_scales, inter_scales, args.cpu_repeats,
+                                              WORKLOAD_TEXT[args.config])
+        result["speedup_vs_cpu_baseline"] = result["value"] / result["cpu_baseline"]["value"]
+    else:
+        result["cpu_baseline"] = None
+    print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

@@ -89,3 +89,57 @@ def status():
     val = ctypes.c_uint(0)
     check(load().pf_check_status(ctypes.byref(val), stream()), "pf_check_status")
     return int(val.value)
+
+
+# ---------------------------------------------------------------------------------------------
+# optional per-kernel timing with HIP events (bench.py roofline leg)
+# ---------------------------------------------------------------------------------------------
+class KernelTimer(object):
+    """Records a HIP event pair around selected C-ABI calls, on the stream the kernels are launched on
+    (torch's current stream), together with the call's algorithmic byte count.  ``only`` restricts
+    the instrumentation to one entry point so that the timed region of bench.py carries two event
+    records per launch of the dominant kernel and nothing else."""
+
+    def __init__(self, only=None):
+        self.only = only
+        self.records = []          # (name, start_event, end_event, algo_bytes)
+
+    def wants(self, name):
+        return self.only is None or name == self.only
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, e0, e1, nbytes in self.records:
+            s = out.setdefault(name, {"launches": 0, "ms": 0.0, "bytes": 0.0})
+            s["launches"] += 1
+            s["ms"] += e0.elapsed_time(e1)
+            s["bytes"] += float(nbytes or 0)
+        return out
+
+
+_timer = None
+
+
+def set_timer(timer):
+    global _timer
+    _timer = timer
+
+
+def call(name, *args, **kw):
+    """Invoke C-ABI entry point ``name`` and raise on a non-zero return.  ``algo_bytes`` (keyword) is the
+    algorithmic HBM byte count of this launch, used only by KernelTimer."""
+    algo_bytes = kw.pop("algo_bytes", None)
+    fn = getattr(load(), name)
+    t = _timer
+    if t is not None and t.wants(name):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        code = fn(*args)
+        e1.record()
+        t.records.append((name, e0, e1, algo_bytes))
+    else:
+        code = fn(*args)
+    if code != 0:
+        check(code, name)

@@ -38,9 +38,9 @@ class _Ext(object):
         x, idx = input.contiguous(), index.contiguous()
         out = torch.empty((B, C, N, K), dtype=x.dtype, device=x.device)
         with torch.cuda.device(x.device):
-            fn = getattr(_lib.load(), "pf_gather_knn_forward_" + _SUFFIX[x.dtype])
-            _lib.check(fn(_lib.ptr(x), _lib.ptr(idx), _lib.ptr(out), B, C, N, K, _lib.stream()),
-                       "gather_knn_forward")
+            _lib.call("pf_gather_knn_forward_" + _SUFFIX[x.dtype], _lib.ptr(x), _lib.ptr(idx), _lib.ptr(out),
+                      B, C, N, K, _lib.stream(),
+                      algo_bytes=float(B) * (x.element_size() * C * N * (1 + K) + 8.0 * N * K))
         return out
 
     @staticmethod
@@ -52,9 +52,9 @@ class _Ext(object):
         g, idx = grad_output.contiguous(), index.contiguous()
         grad_in = torch.empty((B, C, N), dtype=g.dtype, device=g.device)
         with torch.cuda.device(g.device):
-            fn = getattr(_lib.load(), "pf_gather_knn_backward_" + _SUFFIX[g.dtype])
-            _lib.check(fn(_lib.ptr(g), _lib.ptr(idx), _lib.ptr(grad_in), B, C, N, K, _lib.stream()),
-                       "gather_knn_backward")
+            _lib.call("pf_gather_knn_backward_" + _SUFFIX[g.dtype], _lib.ptr(g), _lib.ptr(idx), _lib.ptr(grad_in),
+                      B, C, N, K, _lib.stream(),
+                      algo_bytes=float(B) * (g.element_size() * C * N * (1 + K) + 8.0 * N * K))
         return grad_in
 
 

@@ -119,8 +119,9 @@ class PointMVSNet(nn.Module):
 
         K_coarse = cam.K_coarse.to(dev)
         ext = cam.ext.to(dev)
-        mean_h = data_batch["mean"].detach().cpu().float()
-        std_h = data_batch["std"].detach().cpu().float()
+        mean_h = data_batch["mean_host"] if "mean_host" in data_batch else data_batch["mean"].detach().cpu()
+        std_h = data_batch["std_host"] if "std_host" in data_batch else data_batch["std"].detach().cpu()
+        mean_h, std_h = mean_h.float(), std_h.float()
 
         # ---- coarse stage (reference model.py:71-130) -----------------------------------------
         coarse_maps = [self.coarse_img_conv(img_list[:, v])["conv3"] for v in range(V)]

@@ -43,10 +43,10 @@ def pointwise_gemm(X, point_major, ldx, Wt, Y, ldy, G, Ng, K, nc_store, in_affin
     T = stat_blocks(G, Ng)
     partials = torch.empty((G, T, Nc, 2), dtype=torch.float64, device=Wt.device) if want_stats else None
     sc, sh = in_affine if in_affine is not None else (None, None)
-    _lib.check(_lib.load().pf_pointwise_gemm_f32(
-        _lib.ptr(X), int(bool(point_major)), int(ldx), _lib.ptr(Wt), _lib.ptr(Y), int(ldy), int(G), int(Ng),
-        int(K), int(Nc), int(nc_store), _lib.ptr(sc), _lib.ptr(sh), int(groups_per_stat), _lib.ptr(partials),
-        _lib.stream()), "pointwise_gemm")
+    _lib.call("pf_pointwise_gemm_f32",
+              _lib.ptr(X), int(bool(point_major)), int(ldx), _lib.ptr(Wt), _lib.ptr(Y), int(ldy), int(G), int(Ng),
+              int(K), int(Nc), int(nc_store), _lib.ptr(sc), _lib.ptr(sh), int(groups_per_stat), _lib.ptr(partials),
+              _lib.stream(), algo_bytes=4.0 * G * Ng * (K + nc_store) + 4.0 * K * Nc)
     return partials
 
 
@@ -60,11 +60,11 @@ def bn_affine(bn, partials, col0, C, count, unbias_n, G, groups_per_stat, scale,
     track = bn.track_running_stats and bn.running_mean is not None
     rm = bn.running_mean[ch0:ch0 + C] if track else None
     rv = bn.running_var[ch0:ch0 + C] if track else None
-    _lib.check(_lib.load().pf_bn_finalize_f32(
-        _lib.ptr(partials), int(T), int(pcols), int(col0), int(C), float(count), float(unbias_n),
-        _lib.ptr(bn.weight.detach()[ch0:ch0 + C]), _lib.ptr(bn.bias.detach()[ch0:ch0 + C]), _lib.ptr(rm),
-        _lib.ptr(rv), float(bn.momentum), float(bn.eps), int(G), int(groups_per_stat), _lib.ptr(scale),
-        _lib.ptr(shift), int(scale.stride(0)), _lib.stream()), "bn_finalize")
+    _lib.call("pf_bn_finalize_f32",
+              _lib.ptr(partials), int(T), int(pcols), int(col0), int(C), float(count), float(unbias_n),
+              _lib.ptr(bn.weight.detach()[ch0:ch0 + C]), _lib.ptr(bn.bias.detach()[ch0:ch0 + C]), _lib.ptr(rm),
+              _lib.ptr(rv), float(bn.momentum), float(bn.eps), int(G), int(groups_per_stat), _lib.ptr(scale),
+              _lib.ptr(shift), int(scale.stride(0)), _lib.stream(), algo_bytes=16.0 * G * T * C)
 
 
 def eval_affine(bn, S, ld, ch0=0, C=None, out=None):
@@ -84,7 +84,6 @@ def edge_conv_fused(X, point_major, ldx, K, G, Ng, idx, conv1_w, conv2_w, bn, co
 
     X: channel-major (G,K,Ng) or point-major rows; idx (G,Ng,k) int64 group-local; Y: point-major view
     with ``ldy`` floats per point receiving [central | diff] (concat) or diff (NoC)."""
-    lib = _lib.load()
     C = conv1_w.shape[0]
     k = idx.shape[-1]
     dev = Y.device
@@ -100,8 +99,8 @@ def edge_conv_fused(X, point_major, ldx, K, G, Ng, idx, conv1_w, conv2_w, bn, co
     if training:
         T = stat_blocks(G, Ng)
         part_d = torch.empty((G, T, C, 2), dtype=torch.float64, device=dev)
-        _lib.check(lib.pf_edge_stats_f32(_lib.ptr(LE), 2 * C, C, _lib.ptr(idx), k, G, Ng, _lib.ptr(part_d),
-                                         _lib.stream()), "edge_stats")
+        _lib.call("pf_edge_stats_f32", _lib.ptr(LE), 2 * C, C, _lib.ptr(idx), k, G, Ng, _lib.ptr(part_d),
+                  _lib.stream(), algo_bytes=float(G) * Ng * (4.0 * C + 8.0 * k + 4.0 * C * k))
         n_pairs = float(groups_per_stat) * Ng * k
         if concat:
             bn_affine(bn, part_l, 0, C, float(groups_per_stat) * Ng, n_pairs, G, groups_per_stat,
@@ -115,9 +114,9 @@ def edge_conv_fused(X, point_major, ldx, K, G, Ng, idx, conv1_w, conv2_w, bn, co
         sc, sh = eval_affine(bn, S, cbn)
         scale.copy_(sc.unsqueeze(0).expand(S, cbn))
         shift.copy_(sh.unsqueeze(0).expand(S, cbn))
-    _lib.check(lib.pf_edge_apply_f32(_lib.ptr(LE), 2 * C, C, _lib.ptr(idx), k, G, Ng, _lib.ptr(scale),
-                                     _lib.ptr(shift), cbn, groups_per_stat, int(bool(concat)), _lib.ptr(Y),
-                                     int(ldy), _lib.stream()), "edge_apply")
+    _lib.call("pf_edge_apply_f32", _lib.ptr(LE), 2 * C, C, _lib.ptr(idx), k, G, Ng, _lib.ptr(scale),
+              _lib.ptr(shift), cbn, groups_per_stat, int(bool(concat)), _lib.ptr(Y), int(ldy), _lib.stream(),
+              algo_bytes=float(G) * Ng * (4.0 * C + 8.0 * k + 4.0 * C * k + 4.0 * cbn))
     return Y
 
 
@@ -147,8 +146,8 @@ def resize_maps(maps, h, w):
     if IH == h and IW == w:
         return maps
     out = torch.empty((V, C, h, w), dtype=_F32, device=maps.device)
-    _lib.check(_lib.load().pf_resize_bilinear_f32(_lib.ptr(maps), _lib.ptr(out), V * C, IH, IW, h, w,
-                                                  _lib.stream()), "resize_bilinear")
+    _lib.call("pf_resize_bilinear_f32", _lib.ptr(maps), _lib.ptr(out), V * C, IH, IW, h, w, _lib.stream(),
+              algo_bytes=4.0 * V * C * (IH * IW + h * w))
     return out
 
 
@@ -162,10 +161,11 @@ def flow_features(levels, depth, interval, cam, h, w, ratio):
     dev = depth.device
     feature = torch.empty((G, c1 + c2 + c3 + 24, Ng), dtype=_F32, device=dev)
     xyz = torch.empty((G, 3, Ng), dtype=_F32, device=dev)
-    _lib.check(_lib.load().pf_flow_features_f32(
-        _lib.ptr(levels[0]), _lib.ptr(levels[1]), _lib.ptr(levels[2]), c1, c2, c3, V, h, w, _lib.ptr(depth),
-        int(depth.shape[-2]), int(depth.shape[-1]), float(interval), _lib.ptr(cam), int(ratio),
-        _lib.ptr(feature), _lib.ptr(xyz), _lib.stream()), "flow_features")
+    _lib.call("pf_flow_features_f32",
+              _lib.ptr(levels[0]), _lib.ptr(levels[1]), _lib.ptr(levels[2]), c1, c2, c3, V, h, w, _lib.ptr(depth),
+              int(depth.shape[-2]), int(depth.shape[-1]), float(interval), _lib.ptr(cam), int(ratio),
+              _lib.ptr(feature), _lib.ptr(xyz), _lib.stream(),
+              algo_bytes=4.0 * V * (c1 + c2 + c3) * h * w + 4.0 * G * Ng * (c1 + c2 + c3 + 24 + 3) + 4.0 * h * w)
     return feature, xyz
 
 
@@ -175,7 +175,6 @@ def flow_iteration(pyramid, depth, interval, cam, h, w, ratio, edge_convs, flow_
     pyramid: three contiguous (V,c,H_l,W_l) feature maps of this scene; depth: (dh,dw) prior depth map;
     interval: float hypothesis spacing; cam: packed camera block for this scale.
     Returns (depth_out (h,w), flow_prob (5,h,w))."""
-    lib = _lib.load()
     dev = depth.device
     levels = [resize_maps(m, h, w) for m in pyramid]
     feature, xyz = flow_features(levels, depth, interval, cam, h, w, ratio)
@@ -212,10 +211,10 @@ def flow_iteration(pyramid, depth, interval, cam, h, w, ratio, edge_convs, flow_
     depth_out = torch.empty((h, w), dtype=_F32, device=dev)
     flow_prob = torch.empty((5, h, w), dtype=_F32, device=dev)
     w_out = last.weight.detach().reshape(-1).to(_F32).contiguous()
-    _lib.check(lib.pf_flow_head_f32(_lib.ptr(X), ldx, _lib.ptr(affine[0]), _lib.ptr(affine[1]), 16,
-                                    _lib.ptr(w_out), _lib.ptr(depth), int(depth.shape[-2]),
-                                    int(depth.shape[-1]), float(interval), h, w, ratio, _lib.ptr(flow_prob),
-                                    _lib.ptr(depth_out), _lib.stream()), "flow_head")
+    _lib.call("pf_flow_head_f32", _lib.ptr(X), ldx, _lib.ptr(affine[0]), _lib.ptr(affine[1]), 16,
+              _lib.ptr(w_out), _lib.ptr(depth), int(depth.shape[-2]), int(depth.shape[-1]), float(interval), h, w,
+              ratio, _lib.ptr(flow_prob), _lib.ptr(depth_out), _lib.stream(),
+              algo_bytes=4.0 * G * Ng * 16 + 4.0 * h * w * 7)
     return depth_out, flow_prob
 
 
@@ -227,6 +226,6 @@ def soft_argmin_prob(cost, depth_start, depth_end, depth_interval):
     params = torch.stack([depth_start, depth_end, depth_interval], dim=1).to(_F32).contiguous()
     depth = torch.empty((B, 1, H, W), dtype=_F32, device=cost.device)
     prob = torch.empty((B, 1, H, W), dtype=_F32, device=cost.device)
-    _lib.check(_lib.load().pf_softargmin_prob_f32(_lib.ptr(cost), _lib.ptr(params), _lib.ptr(depth),
-                                                  _lib.ptr(prob), B, D, H * W, _lib.stream()), "softargmin_prob")
+    _lib.call("pf_softargmin_prob_f32", _lib.ptr(cost), _lib.ptr(params), _lib.ptr(depth), _lib.ptr(prob),
+              B, D, H * W, _lib.stream(), algo_bytes=4.0 * B * H * W * (D + 2))
     return depth, prob

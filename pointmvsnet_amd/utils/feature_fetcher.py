@@ -18,9 +18,9 @@ class _Fetch(torch.autograd.Function):
         N = pts.size(2)
         out = torch.empty((B, V, C, N), dtype=torch.float32, device=maps.device)
         with torch.cuda.device(maps.device):
-            _lib.check(_lib.load().pf_fetch_forward_f32(_lib.ptr(maps), _lib.ptr(pts), _lib.ptr(K), _lib.ptr(E),
-                                                        _lib.ptr(out), B, V, C, H, W, N, _lib.stream()),
-                       "fetch_forward")
+            _lib.call("pf_fetch_forward_f32", _lib.ptr(maps), _lib.ptr(pts), _lib.ptr(K), _lib.ptr(E),
+                      _lib.ptr(out), B, V, C, H, W, N, _lib.stream(),
+                      algo_bytes=4.0 * B * (V * C * H * W + 3 * N + V * C * N))
         ctx.save_for_backward(pts, K, E if E is not None else torch.empty(0, device=maps.device))
         ctx.has_ext = E is not None
         ctx.shape = (B, V, C, H, W)
@@ -34,10 +34,9 @@ class _Fetch(torch.autograd.Function):
         g = grad_out.contiguous()
         grad_maps = torch.empty((B, V, C, H, W), dtype=torch.float32, device=g.device)
         with torch.cuda.device(g.device):
-            _lib.check(_lib.load().pf_fetch_backward_f32(_lib.ptr(g), _lib.ptr(pts), _lib.ptr(K),
-                                                         _lib.ptr(E) if ctx.has_ext else None,
-                                                         _lib.ptr(grad_maps), B, V, C, H, W, N, _lib.stream()),
-                       "fetch_backward")
+            _lib.call("pf_fetch_backward_f32", _lib.ptr(g), _lib.ptr(pts), _lib.ptr(K),
+                      _lib.ptr(E) if ctx.has_ext else None, _lib.ptr(grad_maps), B, V, C, H, W, N, _lib.stream(),
+                      algo_bytes=4.0 * B * (V * C * H * W + 3 * N + V * C * N))
         return grad_maps, None, None, None
 
 
@@ -76,7 +75,7 @@ def fetch_variance(feature_maps, pts, cam_intrinsics, cam_extrinsics, ref_overri
         raise RuntimeError("fetch_variance: ref_override needs N to be a multiple of H*W")
     out = torch.empty((B, C, N), dtype=torch.float32, device=maps.device)
     with torch.cuda.device(maps.device):
-        _lib.check(_lib.load().pf_fetch_variance_f32(_lib.ptr(maps), _lib.ptr(p), _lib.ptr(K), _lib.ptr(E),
-                                                     _lib.ptr(out), B, V, C, H, W, N, int(bool(ref_override)),
-                                                     _lib.stream()), "fetch_variance")
+        _lib.call("pf_fetch_variance_f32", _lib.ptr(maps), _lib.ptr(p), _lib.ptr(K), _lib.ptr(E), _lib.ptr(out),
+                  B, V, C, H, W, N, int(bool(ref_override)), _lib.stream(),
+                  algo_bytes=4.0 * B * (V * C * H * W + 3 * N + C * N))
     return out

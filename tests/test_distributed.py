@@ -1,0 +1,61 @@
+"""CPU, world_size 2 over gloo: scene sharding and the single flat-bucket SUM all-reduce used by the
+data-parallel training configuration."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from pointmvsnet_amd import distributed as D
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r, w, _ = D.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    torch.manual_seed(100 + rank)                         # replicas start different on purpose
+    net = torch.nn.Sequential(torch.nn.Conv1d(4, 8, 1, bias=False), torch.nn.BatchNorm1d(8), torch.nn.Conv1d(8, 1, 1))
+    D.broadcast_parameters(net, src=0)
+    x = torch.full((1, 4, 6), float(rank + 1))
+    net(x).sum().backward()
+    local = [p.grad.clone() for p in net.parameters()]
+    n = D.allreduce_gradients_sum(net)
+    gathered = [torch.zeros_like(torch.cat([g.reshape(-1) for g in local])) for _ in range(world)]
+    dist.all_gather(gathered, torch.cat([g.reshape(-1) for g in local]))
+    want = sum(gathered)                                   # SUM, not mean
+    got = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+    out[rank] = (n, bool(torch.allclose(got, want, rtol=1e-6, atol=1e-7)), D.shard_scenes(7, rank, world),
+                 float(list(net.parameters())[0].sum()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_bucket_allreduce_sum_and_scene_sharding_world2():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    assert out[0][1] and out[1][1]
+    assert out[0][0] == out[1][0] == 4 * 8 + 8 + 8 + 8 + 1
+    assert sorted(out[0][2] + out[1][2]) == list(range(7)) and out[0][2] == [0, 2, 4, 6]
+    assert out[0][3] == out[1][3]                          # broadcast made the replicas identical
+
+
+def test_single_process_is_a_noop():
+    net = torch.nn.Linear(3, 2)
+    net(torch.ones(1, 3)).sum().backward()
+    before = net.weight.grad.clone()
+    assert D.allreduce_gradients_sum(net) == 8
+    assert torch.equal(net.weight.grad, before)
+    assert D.shard_scenes(5, 0, 1) == [0, 1, 2, 3, 4]

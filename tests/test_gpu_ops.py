@@ -1,0 +1,399 @@
+"""GPU parity tests, operator level: every HIP entry point against the CPU oracle on identical
+seeded inputs and against the golden vectors produced by the reference itself.
+
+Tolerances (float ops) are stated where used; integer / index work is bit-exact.  Measured errors are
+appended to gpurun_out/parity_report.jsonl.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden, report
+from oracle import bruteforce as BF
+from oracle import pointflow_oracle as O
+from pointmvsnet_amd import _lib, pointflow, synthetic
+from pointmvsnet_amd.functions.gather_knn import GatherKNN, dgcnn_ext, gather_knn
+from pointmvsnet_amd.networks import EdgeConv, EdgeConvNoC, VolumeConv
+from pointmvsnet_amd.utils.feature_fetcher import FeatureFetcher, fetch_variance
+from pointmvsnet_amd.utils.torch_utils import get_knn_3d, knn_lattice
+
+pytestmark = pytest.mark.gpu
+
+
+def _maxabs(a, b):
+    return float((a.double().cpu() - b.double().cpu()).abs().max())
+
+
+# ---------------------------------------------------------------------------------------------
+# row G
+# ---------------------------------------------------------------------------------------------
+def test_gather_knn_reference_selftest(dev):
+    # the reference's own known-answer test (functions/gather_knn.py:27-56), forward and backward
+    g = load_golden("gather_knn_selftest")
+    f = g["feature"].to(dev).requires_grad_(True)
+    out = gather_knn(f, g["index"].to(dev))
+    assert torch.equal(out.cpu(), g["out"])
+    out.backward(torch.ones_like(out))
+    assert torch.allclose(f.grad.cpu(), g["grad"], rtol=1e-6, atol=1e-6)
+    assert _lib.status() == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("B,C,N,K", [(1, 1, 1, 1), (2, 7, 133, 5), (1, 64, 5000, 16), (3, 32, 257, 1)])
+def test_gather_knn_forward_backward(dev, dtype, B, C, N, K):
+    g = torch.Generator().manual_seed(B * 1000 + N)
+    x = torch.randn(B, C, N, generator=g, dtype=dtype)
+    idx = torch.randint(0, N, (B, N, K), generator=g)
+    out = dgcnn_ext.gather_knn_forward(x.to(dev), idx.to(dev))
+    assert torch.equal(out.cpu(), O.gather_knn(x, idx))                      # bit-exact copy
+    go = torch.randn(B, C, N, K, generator=g, dtype=dtype)
+    gi = dgcnn_ext.gather_knn_backward(go.to(dev), idx.to(dev))
+    ref = O.gather_knn_backward(go.double(), idx)
+    err = _maxabs(gi, ref)
+    report("gather_bwd_%s" % str(dtype), err=err)
+    # atomics reorder the (at most N*K) additions: float32 1e-5 abs on O(sqrt(K)) sums, float64 1e-12
+    assert err < (2e-5 if dtype == torch.float32 else 1e-12)
+
+
+def test_gather_knn_empty_and_noncontiguous(dev):
+    x = torch.randn(2, 4, 9, device=dev)
+    idx = torch.randint(0, 9, (2, 9, 0), device=dev)
+    assert gather_knn(x, idx).shape == (2, 4, 9, 0)
+    xt = torch.randn(2, 9, 4, device=dev).transpose(1, 2)                    # non-contiguous input
+    idx = torch.randint(0, 9, (2, 9, 3), device=dev)
+    assert torch.equal(gather_knn(xt, idx).cpu(), O.gather_knn(xt.cpu().contiguous(), idx.cpu()))
+
+
+def test_gather_knn_errors(dev):
+    x = torch.randn(2, 4, 9, device=dev)
+    with pytest.raises(RuntimeError):
+        gather_knn(x.cpu(), torch.zeros(2, 9, 3, dtype=torch.int64))       # CPU tensors: no fallback
+    with pytest.raises(RuntimeError):
+        gather_knn(x, torch.zeros(2, 8, 3, dtype=torch.int64, device=dev))  # shape mismatch
+    with pytest.raises(RuntimeError):
+        gather_knn(x, torch.zeros(2, 9, 3, dtype=torch.int32, device=dev))  # index dtype
+    bad = torch.full((2, 9, 3), 9, dtype=torch.int64, device=dev)           # out of range: flagged, no fault
+    out = gather_knn(x, bad)
+    assert _lib.status() & 1
+    assert float(out.abs().max()) == 0.0
+    assert _lib.status() == 0
+
+
+# ---------------------------------------------------------------------------------------------
+# row K
+# ---------------------------------------------------------------------------------------------
+def _check_knn_against_reference_idx(xyz_cpu, idx_gpu, ref_idx, ks, knn):
+    """Index SETS must match the reference; rows may differ only inside exact-tie groups."""
+    mine = np.sort(idx_gpu.cpu().numpy(), axis=2)
+    ref = np.sort(ref_idx.numpy(), axis=2)
+    n_diff = 0
+    for b in range(mine.shape[0]):
+        rows = np.where((mine[b] != ref[b]).any(axis=1))[0]
+        if len(rows) == 0:
+            continue
+        d2 = BF.knn_window_d2(xyz_cpu[b].numpy(), ks)
+        srt = np.sort(d2, axis=0)
+        for n in rows:                    # a tie at the k-th rank is the only legal reason
+            assert knn < srt.shape[0] and srt[knn - 1, n] == srt[knn, n]
+        n_diff += len(rows)
+    return n_diff
+
+
+@pytest.mark.parametrize("name,ks,knn", [("knn_lattice_far", 5, 16), ("knn_lattice_origin", 5, 16),
+                                         ("knn_lattice_k3", 3, 8)])
+def test_knn_lattice_vs_reference_and_tie_rule(dev, name, ks, knn):
+    g = load_golden(name)
+    idx, codes = knn_lattice(g["xyz"].to(dev), ks, knn, with_codes=True)
+    assert idx.dtype == torch.int64 and idx.shape == g["idx"].shape
+    for b in range(g["xyz"].shape[0]):
+        bf_idx, bf_code = BF.knn_window(g["xyz"][b].numpy(), ks, knn)
+        assert np.array_equal(idx[b].cpu().numpy(), bf_idx)                  # bit-exact incl. order (stated tie rule)
+        assert np.array_equal(codes[b].cpu().numpy(), bf_code)
+    n_diff = _check_knn_against_reference_idx(g["xyz"], idx, g["idx"], ks, knn)
+    report("knn_rows_in_tie_groups_" + name, rows=n_diff)
+    if name == "knn_lattice_far":
+        assert n_diff == 0
+
+
+def test_knn_lattice_strided_view_and_api(dev):
+    g = load_golden("knn_lattice_strided")
+    full = g["xyz_full"].to(dev)
+    sub = full.view(1, 3, 5, 6, 2, 8, 2)[:, :, :, :, 1, :, 0]               # as model.py:251-252
+    assert not sub.is_contiguous()
+    idx = get_knn_3d(sub, 5, knn=16)
+    assert _check_knn_against_reference_idx(sub.cpu().contiguous(), idx, g["idx"], 5, 16) == 0
+    assert get_knn_3d(sub, 5).shape == (1, 5 * 6 * 8, 20)                    # default knn=20
+    with pytest.raises(AssertionError):
+        get_knn_3d(sub, 4, knn=8)                                            # even window (reference asserts)
+
+
+@pytest.mark.parametrize("shape", [(1, 5, 1, 1), (2, 5, 3, 70), (1, 1, 9, 33), (1, 5, 64, 80)])
+def test_knn_lattice_shapes_vs_oracle(dev, shape):
+    B, D, H, W = shape
+    g = torch.Generator().manual_seed(D * H * W)
+    xyz = torch.randn(B, 3, D, H, W, generator=g) * 0.3 + torch.tensor([1.0, 2.0, -3.0]).view(1, 3, 1, 1, 1)
+    knn = min(16, 125)
+    idx = knn_lattice(xyz.to(dev), 5, knn)
+    for b in range(B):
+        bf_idx, _ = BF.knn_window(xyz[b].numpy(), 5, knn)
+        assert np.array_equal(idx[b].cpu().numpy(), bf_idx)
+    assert _check_knn_against_reference_idx(xyz, idx, O.knn_lattice(xyz, 5, knn), 5, knn) >= 0
+
+
+def test_knn_full_size_properties(dev):
+    # BASELINE config-2 flow-2 size (4 sub-grids of 5x64x80): properties that need no oracle
+    g = torch.Generator().manual_seed(5)
+    G, D, H, W = 4, 5, 64, 80
+    base = torch.stack(torch.meshgrid(torch.arange(W).float(), torch.arange(H).float(), torch.arange(D).float(),
+                                      indexing="xy"), 0)                    # (3,H,W,D)
+    xyz = base.permute(0, 3, 1, 2).unsqueeze(0).repeat(G, 1, 1, 1, 1) * 0.1 + 5.0
+    xyz = xyz + 0.01 * torch.randn(xyz.shape, generator=g)
+    idx, codes = knn_lattice(xyz.to(dev), 5, 16, with_codes=True)
+    N = D * H * W
+    idx_c = idx.cpu()
+    assert torch.equal(idx_c[:, :, 0], torch.arange(N).view(1, N).expand(G, N))   # self is the nearest
+    assert int(codes[:, :, 0].min()) == 62 and int(codes[:, :, 0].max()) == 62      # centre code
+    assert int(idx_c.min()) >= 0 and int(idx_c.max()) < N
+    assert (idx_c.sort(dim=2)[0].diff(dim=2) > 0).all()                             # 16 distinct neighbours
+    again = knn_lattice(xyz.to(dev), 5, 16)
+    assert torch.equal(again, idx)                                                   # deterministic
+
+
+# ---------------------------------------------------------------------------------------------
+# rows W, V
+# ---------------------------------------------------------------------------------------------
+def test_fetch_reference_selftest(dev):
+    g = load_golden("feature_fetch_selftest")
+    torch.manual_seed(0)
+    _ = torch.rand(3, 2, 3, 4)
+    feats = torch.rand(3, 2, 16, 240, 320)
+    out = FeatureFetcher()(feats.to(dev), g["pts"].to(dev), g["K"].to(dev), g["E"].to(dev))
+    err = _maxabs(out, g["out"])
+    report("fetch_selftest", err=err)
+    # the reference's own acceptance (utils/feature_fetcher.py:97): rtol 1e-2 against the texel
+    assert np.allclose(out[:, 0, :, 0].cpu().numpy(), feats[:, 0, :, 80, 60].numpy(), rtol=1e-2, atol=1e-4)
+    assert err < 2e-3        # ill-conditioned random extrinsics amplify 1-ulp projection differences
+
+
+def test_fetch_random_vs_reference(dev):
+    g = load_golden("feature_fetch_random")
+    fetcher = FeatureFetcher()
+    out = fetcher(g["feats"].to(dev), g["pts"].to(dev), g["K"].to(dev), g["E"].to(dev))
+    scale = float(g["feats"].abs().max())
+    err = _maxabs(out, g["out"])
+    report("fetch_random", err=err, scale=scale)
+    # float32 projection rounds to ~1 ulp of the pixel coordinate (4e-6 at u~50): tolerance 3e-5 * max|map|
+    assert err < 3e-5 * scale
+    assert out.is_contiguous() and out.shape == g["out"].shape
+    out[:, 0] = 1.0                                                          # writable, like model.py:106
+    # identity extrinsics path (cam_extrinsics=None, feature_fetcher.py:33-35)
+    o2 = fetcher(g["feats"].to(dev), g["pts"].to(dev), g["K"].to(dev), None)
+    r2 = O.fetch_features(g["feats"], g["pts"], g["K"], None)
+    assert _maxabs(o2, r2) < 3e-5 * scale
+
+
+def test_fetch_backward_vs_autograd_oracle(dev):
+    g = load_golden("feature_fetch_random")
+    feats = g["feats"].clone().requires_grad_(True)
+    ref = O.fetch_features(feats, g["pts"], g["K"], g["E"])
+    go = torch.randn(ref.shape, generator=torch.Generator().manual_seed(2))
+    ref.backward(go)
+    f2 = g["feats"].to(dev).requires_grad_(True)
+    out = FeatureFetcher()(f2, g["pts"].to(dev), g["K"].to(dev), g["E"].to(dev))
+    out.backward(go.to(dev))
+    err = _maxabs(f2.grad, feats.grad)
+    report("fetch_backward", err=err, scale=float(feats.grad.abs().max()))
+    assert err < 1e-4 * float(feats.grad.abs().max())
+
+
+@pytest.mark.parametrize("V", [2, 3, 5, 7])
+@pytest.mark.parametrize("ref_override", [False, True])
+def test_fetch_variance_vs_oracle(dev, V, ref_override):
+    gen = torch.Generator().manual_seed(V)
+    B, C, H, W, D = 1, 8, 16, 20, 3
+    data = synthetic.make_scene(128, 160, V, D, seed=V, batch=B)
+    cams = data["cam_params_list"]
+    K = cams[:, :, 1, :3, :3].clone()
+    K[:, :, :2, :3] /= 8.0
+    E = cams[:, :, 0, :3, :4].clone()
+    feats = torch.randn(B, V, C, H, W, generator=gen)
+    N = D * H * W
+    pts = torch.randn(B, 3, N, generator=gen) * torch.tensor([40.0, 30.0, 80.0]).view(1, 3, 1) \
+        + torch.tensor([0.0, 0.0, 600.0]).view(1, 3, 1)
+    pf = O.fetch_features(feats, pts, K, E)
+    if ref_override:
+        pf[:, 0] = feats[:, 0].unsqueeze(2).expand(-1, -1, D, -1, -1).contiguous().view(B, C, -1)
+    ref = O.variance_over_views(pf)
+    out = fetch_variance(feats.to(dev), pts.to(dev), K.to(dev), E.to(dev), ref_override=ref_override)
+    scale = float((pf ** 2).max())
+    err = _maxabs(out, ref)
+    report("fetch_variance_V%d_%d" % (V, int(ref_override)), err=err, scale=scale)
+    # E[x^2]-E[x]^2 cancels: absolute accuracy is that of E[x^2] -> 6e-5 * max|x|^2
+    assert err < 6e-5 * scale
+
+
+def test_fetch_errors(dev):
+    f = FeatureFetcher()
+    with pytest.raises(RuntimeError):
+        f(torch.randn(1, 2, 4, 8, 8), torch.randn(1, 3, 5), torch.eye(3).view(1, 1, 3, 3).expand(1, 2, 3, 3), None)
+    with pytest.raises(NotImplementedError):
+        FeatureFetcher(mode="nearest")
+    with pytest.raises(RuntimeError):   # more views than the fused kernel is built for
+        fetch_variance(torch.randn(1, 9, 4, 8, 8, device=dev), torch.randn(1, 3, 5, device=dev),
+                       torch.eye(3, device=dev).view(1, 1, 3, 3).expand(1, 9, 3, 3), None)
+
+
+def test_resize_bilinear_vs_interpolate(dev):
+    g = torch.Generator().manual_seed(4)
+    for (ih, iw, oh, ow) in [(32, 40, 16, 20), (16, 20, 32, 40), (8, 10, 32, 40), (12, 16, 12, 16), (7, 9, 20, 31)]:
+        x = torch.randn(3, 5, ih, iw, generator=g)
+        ref = F.interpolate(x, (oh, ow), mode="bilinear", align_corners=False)
+        out = pointflow.resize_maps(x.to(dev), oh, ow)
+        err = _maxabs(out, ref)
+        report("resize_%dx%d_%dx%d" % (ih, iw, oh, ow), err=err)
+        assert err < 2e-6 * float(x.abs().max())
+
+
+# ---------------------------------------------------------------------------------------------
+# row S
+# ---------------------------------------------------------------------------------------------
+def test_softargmin_prob_vs_oracle(dev):
+    g = torch.Generator().manual_seed(6)
+    B, D, H, W = 2, 48, 16, 20
+    cost = torch.randn(B, D, H, W, generator=g) * 2.0
+    start = torch.tensor([425.0, 500.0])
+    interval = torch.tensor([10.6, 5.325])
+    end = start + (D - 1) * interval
+    depth, prob_vol = O.soft_argmin(cost, start, end, D)
+    pm = O.probability_map(prob_vol, depth, start, interval)
+    d2, p2 = pointflow.soft_argmin_prob(cost.to(dev), start.to(dev), end.to(dev), interval.to(dev))
+    e_d, e_p = _maxabs(d2, depth), _maxabs(p2, pm)
+    report("softargmin", depth_err=e_d, prob_err=e_p)
+    assert e_d < 1e-6 * float(depth.abs().max()) * 4            # depth within ~4 ulp (1e-4 rel is the contract)
+    frac = ((depth - start.view(-1, 1, 1, 1)) / interval.view(-1, 1, 1, 1))
+    safe = ((frac - frac.round()).abs() > 1e-3)                 # floor/ceil are discontinuous at integers
+    assert float((p2.cpu() - pm).abs()[safe].max()) < 5e-6
+
+
+# ---------------------------------------------------------------------------------------------
+# rows E0 / E1 / E2 and the GEMM building block
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("point_major", [False, True])
+@pytest.mark.parametrize("G,Ng,K,cout", [(1, 64, 32, 64), (2, 100, 136, 64), (3, 1000, 224, 64), (1, 333, 64, 128),
+                                         (2, 65, 64, 16), (1, 70, 7, 32)])
+def test_pointwise_gemm_vs_fp64(dev, point_major, G, Ng, K, cout):
+    gen = torch.Generator().manual_seed(G * Ng + K)
+    w = torch.randn(cout, K, 1, generator=gen)
+    if point_major:
+        ldx = K + 4
+        x = torch.randn(G * Ng, ldx, generator=gen)
+        xm = x[:, :K].view(G, Ng, K)
+    else:
+        ldx = 0
+        x = torch.randn(G, K, Ng, generator=gen)
+        xm = x.transpose(1, 2)
+    sc = torch.rand(G, K, generator=gen) + 0.5
+    sh = torch.randn(G, K, generator=gen) * 0.3
+    for affine in (None, (sc, sh)):
+        a = xm.double()
+        if affine is not None:
+            a = torch.relu(a * sc.double().unsqueeze(1) + sh.double().unsqueeze(1))
+        ref = a @ w[:, :, 0].double().t()                                    # (G,Ng,cout)
+        Wt, _ = pointflow.pack_weight_t(w.to(dev))
+        Y = torch.full((G * Ng, cout + 3), -7.0, device=dev)
+        aff = None if affine is None else (sc.to(dev), sh.to(dev))
+        part = pointflow.pointwise_gemm(x.to(dev), point_major, ldx, Wt, Y, cout + 3, G, Ng, K, cout,
+                                        in_affine=aff, want_stats=True)
+        out = Y[:, :cout].view(G, Ng, cout)
+        scale = float(ref.abs().max())
+        err = _maxabs(out, ref)
+        report("gemm_K%d_c%d_pm%d_aff%d" % (K, cout, int(point_major), int(affine is not None)), err=err, scale=scale)
+        assert err < 2e-6 * scale * max(1.0, (K / 32.0) ** 0.5)              # float32 fma chain of length K
+        assert float((Y[:, cout:] + 7.0).abs().max()) == 0.0                 # padding columns untouched
+        sums = part.sum(dim=1).cpu()                                         # (G, Nc, 2)
+        assert torch.allclose(sums[:, :cout, 0], ref.sum(dim=1), rtol=1e-5, atol=1e-4 * scale)
+        assert torch.allclose(sums[:, :cout, 1], (ref ** 2).sum(dim=1), rtol=1e-5)
+
+
+@pytest.mark.parametrize("name,concat", [("edgeconv_noc", False), ("edgeconv_32", True), ("edgeconv_64", True)])
+def test_edgeconv_fused_vs_reference(dev, name, concat):
+    g = load_golden(name)
+    cin = g["x"].shape[1]
+    cout = g["y"].shape[1] // (2 if concat else 1)
+    mod = (EdgeConv if concat else EdgeConvNoC)(cin, cout)
+    synthetic.seed_weights(mod, seed=1)
+    mod = mod.to(dev).train()
+    with torch.no_grad():
+        y = mod(g["x"].to(dev), g["idx"].to(dev))
+    assert y.shape == g["y"].shape and y.is_contiguous()
+    err = _maxabs(y, g["y"])
+    e_rm = _maxabs(mod.bn.running_mean, g["running_mean"])
+    e_rv = float(((mod.bn.running_var.cpu() - g["running_var"]).abs() / g["running_var"]).max())
+    report("edgeconv_fused_" + name, err=err, rm_err=e_rm, rv_rel_err=e_rv, scale=float(g["y"].abs().max()))
+    # BN batch statistics are reduced in a different order (float64 partials): 2e-5 abs on O(1) activations
+    assert err < 2e-5 * max(1.0, float(g["y"].abs().max()))
+    assert e_rm < 1e-5 and e_rv < 1e-5
+    assert int(mod.bn.num_batches_tracked) == int(g["num_batches_tracked"])
+    # run-to-run bit reproducibility (no float atomics in the fused path)
+    mod2 = (EdgeConv if concat else EdgeConvNoC)(cin, cout)
+    synthetic.seed_weights(mod2, seed=1)
+    mod2 = mod2.to(dev).train()
+    with torch.no_grad():
+        assert torch.equal(mod2(g["x"].to(dev), g["idx"].to(dev)), y)
+
+
+@pytest.mark.parametrize("name,concat", [("edgeconv_noc", False), ("edgeconv_32", True)])
+def test_edgeconv_autograd_path_vs_oracle(dev, name, concat):
+    g = load_golden(name)
+    cin = g["x"].shape[1]
+    cout = g["y"].shape[1] // (2 if concat else 1)
+    mod = (EdgeConv if concat else EdgeConvNoC)(cin, cout)
+    synthetic.seed_weights(mod, seed=1)
+    # oracle gradients on the CPU
+    sd = {"m." + k: v.clone().requires_grad_(v.is_floating_point() and v.dim() > 0 and "running" not in k)
+          for k, v in mod.state_dict().items()}
+    x_ref = g["x"].clone().requires_grad_(True)
+    y_ref = O.edge_conv(x_ref, g["idx"], sd, "m", concat)
+    go = torch.randn(y_ref.shape, generator=torch.Generator().manual_seed(9))
+    y_ref.backward(go)
+    mod = mod.to(dev).train()
+    x = g["x"].to(dev).requires_grad_(True)
+    y = mod(x, g["idx"].to(dev))
+    assert _maxabs(y, g["y"]) < 2e-5 * max(1.0, float(g["y"].abs().max()))
+    y.backward(go.to(dev))
+    e_x = _maxabs(x.grad, x_ref.grad) / float(x_ref.grad.abs().max())
+    e_w = _maxabs(mod.conv2.weight.grad, sd["m.conv2.weight"].grad) / float(sd["m.conv2.weight"].grad.abs().max())
+    report("edgeconv_autograd_" + name, dx_rel=e_x, dw_rel=e_w)
+    assert e_x < 2e-4 and e_w < 2e-4
+
+
+def test_edgeconv_eval_mode_uses_running_stats(dev):
+    g = load_golden("edgeconv_32")
+    mod = EdgeConv(32, 32)
+    synthetic.seed_weights(mod, seed=1)
+    sd = {"m." + k: v for k, v in mod.state_dict().items()}
+    x, idx = g["x"], g["idx"]
+    local = F.conv1d(x, sd["m.conv1.weight"])
+    edge = F.conv1d(x, sd["m.conv2.weight"])
+    nb = O.gather_knn(edge, idx)
+    cen = local.unsqueeze(-1).expand(-1, -1, -1, 16)
+    e = torch.cat([cen, nb - cen], 1)
+    e = F.batch_norm(e, sd["m.bn.running_mean"], sd["m.bn.running_var"], sd["m.bn.weight"], sd["m.bn.bias"], False)
+    ref = F.relu(e).mean(3)
+    mod = mod.to(dev).eval()
+    with torch.no_grad():
+        y = mod(x.to(dev), idx.to(dev))
+    assert _maxabs(y, ref) < 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+def test_volume_conv_vs_reference(dev):
+    g = load_golden("volume_conv")
+    mod = VolumeConv(64, 8)
+    synthetic.seed_weights(mod, seed=2)
+    mod = mod.to(dev).train()
+    with torch.no_grad():
+        y = mod(g["x"].to(dev))
+    err = _maxabs(y, g["y"])
+    report("volume_conv", err=err, scale=float(g["y"].abs().max()))
+    assert err < 2e-4 * float(g["y"].abs().max())       # library conv3d (MIOpen) vs mkldnn accumulation order

@@ -1,0 +1,119 @@
+"""CPU: host-side logic -- module surface, state-dict contract, camera packing, compat aliasing, loud
+failure without a GPU, synthetic-input determinism."""
+import json
+import os
+
+import pytest
+import torch
+
+from conftest import GOLDEN_DIR, REFERENCE_DIR
+from pointmvsnet_amd import synthetic
+from pointmvsnet_amd.model import PointMVSNet, PointMVSNetLoss, PointMVSNetMetric, _Cameras
+
+
+def test_state_dict_keys_match_reference_checkpoint_contract():
+    want = json.load(open(os.path.join(GOLDEN_DIR, "state_dict_keys.json")))
+    got = {k: list(v.shape) for k, v in PointMVSNet().state_dict().items()}
+    assert got == want
+    assert sum(p.numel() for p in PointMVSNet().parameters()) == 698936
+
+
+def test_seed_weights_is_construction_order_independent():
+    a, b = PointMVSNet(), PointMVSNet()
+    synthetic.seed_weights(a, 0)
+    synthetic.seed_weights(b, 0)
+    for (ka, va), (kb, vb) in zip(sorted(a.state_dict().items()), sorted(b.state_dict().items())):
+        assert ka == kb and torch.equal(va, vb)
+    c = PointMVSNet()
+    synthetic.seed_weights(c, 1)
+    assert not torch.equal(c.state_dict()["flow_mlp.1.weight"], a.state_dict()["flow_mlp.1.weight"])
+
+
+def test_synthetic_scene_geometry_is_sane():
+    data, scales, inters = synthetic.make_config("cfg2")
+    assert data["img_list"].shape == (1, 3, 3, 512, 640) and data["cam_params_list"].shape == (1, 3, 2, 4, 4)
+    R = data["cam_params_list"][0, :, 0, :3, :3].double()
+    eye = torch.eye(3, dtype=torch.float64).expand(3, 3, 3)
+    assert torch.allclose(R @ R.transpose(1, 2), eye, atol=1e-6)             # proper rotations
+    again, _, _ = synthetic.make_config("cfg2")
+    assert torch.equal(again["img_list"], data["img_list"])                  # deterministic
+    other, _, _ = synthetic.make_config("cfg2", seed=1)
+    assert not torch.equal(other["img_list"], data["img_list"])
+
+
+def test_camera_pack_layout_matches_header():
+    data, _, _ = synthetic.make_config("tiny")
+    cam = _Cameras(data["cam_params_list"], True)
+    K = cam.flow_intrinsics(0.25)
+    pack = cam.packed(K, data["mean"], data["std"])
+    V = 3
+    assert pack.shape == (1, 27 + 21 * V)
+    assert torch.allclose(pack[0, 0:9].view(3, 3) @ K[0, 0], torch.eye(3), atol=1e-4)
+    assert torch.equal(pack[0, 18:21], cam.t[0, 0].reshape(-1))
+    assert torch.equal(pack[0, 21:24], data["mean"][0]) and torch.equal(pack[0, 24:27], data["std"][0])
+    for v in range(V):
+        base = 27 + 21 * v
+        assert torch.equal(pack[0, base:base + 9].view(3, 3), K[0, v])
+        assert torch.equal(pack[0, base + 9:base + 21].view(3, 4), cam.ext[0, v])
+    # intrinsic scaling rules of reference model.py:59-61 and :162-163
+    raw = data["cam_params_list"][0, 0, 1, 0, 0]
+    assert torch.isclose(cam.K_coarse[0, 0, 0, 0], raw / 8.0)
+    assert torch.isclose(_Cameras(data["cam_params_list"], False).K_coarse[0, 0, 0, 0], raw / 2.0)
+    assert torch.isclose(_Cameras(data["cam_params_list"], False).flow_intrinsics(0.25)[0, 0, 0, 0], raw)
+
+
+def test_operators_fail_loudly_without_gpu():
+    from pointmvsnet_amd.functions.gather_knn import gather_knn
+    from pointmvsnet_amd.networks import EdgeConv
+    from pointmvsnet_amd.utils.feature_fetcher import FeatureFetcher
+    from pointmvsnet_amd.utils.torch_utils import get_knn_3d
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        gather_knn(torch.randn(1, 2, 4), torch.zeros(1, 4, 2, dtype=torch.int64))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        get_knn_3d(torch.randn(1, 3, 5, 4, 4), 5, knn=16)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        FeatureFetcher()(torch.randn(1, 2, 4, 8, 8), torch.randn(1, 3, 5), torch.eye(3).expand(1, 2, 3, 3), None)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        EdgeConv(8, 32)(torch.randn(1, 8, 10), torch.zeros(1, 10, 4, dtype=torch.int64))
+    data, s, i = synthetic.make_config("tiny")
+    with pytest.raises(RuntimeError, match="GPU"):
+        PointMVSNet()(data, s, i, isFlow=True, isTest=True)
+
+
+def test_missing_library_is_a_hard_error(monkeypatch, tmp_path):
+    from pointmvsnet_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU or eager fallback"):
+        _lib.load()
+
+
+def test_loss_and_metric_surface():
+    loss_fn, metric_fn = PointMVSNetLoss(valid_threshold=8.0), PointMVSNetMetric(valid_threshold=8.0)
+    g = torch.Generator().manual_seed(0)
+    gt = 500 + 50 * torch.rand(2, 1, 32, 40, generator=g)
+    gt[:, :, :4] = 0.0
+    cams = torch.zeros(2, 3, 2, 4, 4)
+    cams[:, 0, 1, 3, 1] = 10.6
+    preds = {"coarse_depth_map": gt[:, :, ::2, ::2] + 3.0, "flow1": gt[:, :, ::2, ::2] + 1.0, "flow2": gt + 0.5}
+    labels = {"gt_depth_img": gt, "cam_params_list": cams}
+    losses = loss_fn(preds, labels, True)
+    assert set(losses) == {"coarse_loss", "flow1_loss", "flow2_loss"}
+    # masked MAE in interval units, summed over the batch of 2, divided by the 3 terms
+    assert torch.isclose(losses["coarse_loss"], torch.tensor(2 * (3.0 / 10.6) / 3), rtol=1e-4)
+    assert torch.isclose(losses["flow2_loss"], torch.tensor(2 * (0.5 / (0.375 * 10.6)) / 3), rtol=1e-4)
+    m = metric_fn(preds, labels, True)
+    assert float(m["<1_pct_cor"]) == 1.0 and float(m["<1_pct_flow2"]) == 1.0
+    assert set(m) == {"<1_pct_cor", "<3_pct_cor", "<1_pct_flow1", "<3_pct_flow1", "<1_pct_flow2", "<3_pct_flow2"}
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE_DIR), reason="reference tree only exists in the build container")
+def test_reference_model_py_imports_unchanged_on_our_operator_layer():
+    from pointmvsnet_amd import compat, networks
+    ref = compat.load_reference_model(os.path.join(REFERENCE_DIR, "pointmvsnet", "model.py"))
+    net = ref.PointMVSNet()
+    assert isinstance(net.flow_edge_conv[1], networks.EdgeConv)              # our classes behind their names
+    assert type(net.feature_fetcher).__module__ == "pointmvsnet_amd.utils.feature_fetcher"
+    want = json.load(open(os.path.join(GOLDEN_DIR, "state_dict_keys.json")))
+    assert {k: list(v.shape) for k, v in net.state_dict().items()} == want
+    assert ref.get_knn_3d.__module__ == "pointmvsnet_amd.utils.torch_utils"
