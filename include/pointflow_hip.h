@@ -137,12 +137,14 @@ int pf_flow_features_f32(const float* maps1, const float* maps2, const float* ma
  * group; a launch uses T = pf_stat_blocks(G, Ng) blocks per group, each reducing its tiles into one
  * float64 partial (sum, sum of squares) per column -> deterministic BatchNorm statistics. */
 int pf_stat_blocks(int G, int Ng);
+/* Blocks per group used by pf_pointwise_gemm_f32 (128-point tiles); its partials are (G, Tg, Nc, 2). */
+int pf_gemm_blocks(int G, int Ng);
 
-/* Y[m, 0:Nc_store] = act(X[m, 0:K]) * Wt, m over G*Ng points.  Wt is (K, Nc) row-major, Nc a multiple
- * of 32 (<=128).  X is channel-major (G, K, Ng) when x_point_major == 0 (the reference (B,C,N) layout)
+/* Y[m, 0:Nc_store] = act(X[m, 0:K]) * Wt, m over G*Ng points.  Wt is (K, Nc) row-major, Nc in
+ * {32, 64, 128}.  X is channel-major (G, K, Ng) when x_point_major == 0 (the reference (B,C,N) layout)
  * or point-major rows of ldx floats.  act = ReLU(x*in_scale[s,k] + in_shift[s,k]) when in_scale != NULL
  * (s = g / groups_per_stat) -- the previous layer's BatchNorm+ReLU fused into the load -- else identity.
- * col_partials (G, T, Nc, 2) float64 or NULL receives per-block column sums of Y. */
+ * col_partials (G, pf_gemm_blocks(G,Ng), Nc, 2) float64 or NULL receives per-block column sums of Y. */
 int pf_pointwise_gemm_f32(const float* X, int x_point_major, int64_t ldx, const float* Wt, float* Y,
                           int64_t ldy, int G, int Ng, int K, int Nc, int Nc_store, const float* in_scale,
                           const float* in_shift, int groups_per_stat, double* col_partials, void* stream);
@@ -173,6 +175,17 @@ int pf_bn_finalize_f32(const double* partials, int T, int pcols, int col0, int C
 int pf_edge_apply_f32(const float* LE, int64_t ldle, int C, const int64_t* idx, int k, int G, int Ng,
                       const float* scale, const float* shift, int ld_affine, int groups_per_stat,
                       int concat, float* Y, int64_t ldy, void* stream);
+
+/* ---- train-mode BatchNorm for the conv stacks around the path (ImageConv / VolumeConv) ----------
+ * x (N, C, S) contiguous (NCHW / NCDHW with S = spatial size).  pf_channel_stats_f32 writes float64
+ * partial (sum, sum of squares) per (sample, block, channel): partials (N, pf_norm_blocks(S), C, 2), the
+ * layout pf_bn_finalize_f32 reduces (G = N samples; groups_per_stat samples pooled per statistic, e.g.
+ * the batch of one reference conv call, nn/conv.py:29-35).  pf_channel_affine_f32 applies
+ * y = x*scale[s,c] + shift[s,c] (s = n / samples_per_stat) with optional ReLU; y may alias x. */
+int pf_norm_blocks(int64_t S);
+int pf_channel_stats_f32(const float* x, int64_t N, int64_t C, int64_t S, double* partials, void* stream);
+int pf_channel_affine_f32(const float* x, float* y, const float* scale, const float* shift, int64_t N, int64_t C,
+                          int64_t S, int samples_per_stat, int relu, void* stream);
 
 /* ---- rows M (last layer) + H + T : flow head ---------------------------------------------------
  * Z (G*Ng, ldz) holds the pre-BN output of the 64->16 MLP layer.  Per pixel of the (h,w) grid:

@@ -5,9 +5,10 @@
 // points (reference networks.py:18-45, :56-81).  Here the (N,16,C) edge tensor never exists:
 //
 //   pointwise_gemm   [l | e] = x . [W1;W2]^T on the matrix cores (v_mfma_f32_32x32x2_f32: exact f32,
-//                    an fmaf chain in k order), 64-point tiles, A staged through LDS, optional
-//                    BatchNorm+ReLU of the previous layer fused into the A load, optional per-block
-//                    float64 column sums (statistics of the "central" half and of the MLP layers).
+//                    an fmaf chain in k order), 128-point tiles, K streamed through double-buffered
+//                    LDS, optional BatchNorm+ReLU of the previous layer fused into the A staging,
+//                    optional per-block float64 column sums (statistics of the "central" half and of
+//                    the MLP layers).
 //   edge_stats       pass A: per-channel sum / sum-of-squares of d = e[idx] - l over all (point,
 //                    neighbour) pairs -> per-block float64 partials.
 //   bn_finalize      partials -> scale/shift per stat group, running-stat update (train-mode BN runs
@@ -33,149 +34,179 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int TILE = PF_GEMM_TILE;
 
-__host__ __device__ inline int keven(int K) { return (K + 1) & ~1; }
-__host__ __device__ inline int kpad(int K) { return keven(K) + 1; }  // odd LDS row stride: conflict-free columns
-
 // ------------------------------------------------------------------------------------------------
 // pointwise GEMM on f32 MFMA
+//
+// Block = 256 threads = 4 waves, tile = 128 points x Nc columns; wave w owns points [32w, 32w+32) and all
+// NT = Nc/32 column tiles (NT accumulators of 16 registers).  K is streamed in chunks of KC through two
+// LDS buffers: chunk c+1 travels global -> registers while the matrix cores work on chunk c, then
+// registers -> LDS, one barrier per chunk.  A is kept k-major in LDS ([k][point], row stride 130) so the
+// MFMA A operand (lane = point, k = lane>>5) and the B operand (lane = column) are both conflict-free
+// 32-lane rows.  v_mfma_f32_32x32x2_f32 is an exact float32 fmaf chain in k order (64 cycles/SIMD);
+// the bound is the fp32 matrix peak (157 TF), not HBM: 2*K*Nc flop per point vs 4*(K+Nc) bytes.
 // ------------------------------------------------------------------------------------------------
-template <bool POINT_MAJOR>
-__global__ __launch_bounds__(256) void pointwise_gemm_kernel(
+constexpr int GT = 128;        // points per GEMM tile
+constexpr int LDA = GT + 2;    // 130: 4*LDA = 8 (mod 32) -> transposed staging writes are <= 2-way (free)
+
+template <bool POINT_MAJOR, int NT>
+__global__ __launch_bounds__(256, 2) void pointwise_gemm_kernel(
     const float* __restrict__ X, int64_t ldx, const float* __restrict__ Wt, float* __restrict__ Y, int64_t ldy,
-    int Ng, int K, int Nc, int Nc_store, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
+    int Ng, int K, int Nc_store, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
     int groups_per_stat, double* __restrict__ partials, int T) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* As = lds;
-  const int KE = keven(K);
-  const int KP = kpad(K);
+  constexpr int NC = NT * 32;
+  constexpr int KC = NT == 4 ? 16 : 32;
+  constexpr int NA = KC * GT / 256;   // A floats staged per thread per chunk (16 or 8)
+  constexpr int NW = KC * NC / 256;   // W floats staged per thread per chunk
+  __shared__ __attribute__((aligned(16))) float As[2][KC][LDA];
+  __shared__ __attribute__((aligned(16))) float Ws[2][KC][NC];
+
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
-  const int rt = wave & 1;   // row tile (32 points) of this wave
-  const int cw = wave >> 1;  // first column tile of this wave; it also owns cw + 2
-  const int NT = Nc >> 5;
-  const int g = blockIdx.y;
-  const int tb = blockIdx.x;
-  const int tiles = (Ng + TILE - 1) / TILE;
+  const int hi = lane >> 5, lo = lane & 31;
+  const int g = blockIdx.y, tb = blockIdx.x;
+  const int tiles = (Ng + GT - 1) / GT;
+  const int chunks = (K + KC - 1) / KC;
   const float* sc = in_scale ? in_scale + (int64_t)(g / groups_per_stat) * K : nullptr;
   const float* sh = in_scale ? in_shift + (int64_t)(g / groups_per_stat) * K : nullptr;
 
-  double csum[2] = {0.0, 0.0}, csq[2] = {0.0, 0.0};
+  double csum[NT], csq[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) csum[t] = csq[t] = 0.0;
 
   for (int tile = tb; tile < tiles; tile += T) {
-    const int n0 = tile * TILE;
-    const int rows = min(TILE, Ng - n0);
-    __syncthreads();
-    if (!POINT_MAJOR) {
-      const int p = tid & 63;
-      for (int k = tid >> 6; k < KE; k += 4) {
-        float v = 0.0f;
-        if (k < K && p < rows) {
-          v = X[((int64_t)g * K + k) * Ng + n0 + p];
-          if (sc) v = fmaxf(fmaf(v, sc[k], sh[k]), 0.0f);
-        }
-        As[p * KP + k] = v;
-      }
-    } else {
-      const int total = TILE * KE;
-      for (int e = tid; e < total; e += 256) {
-        const int p = e / KE;
-        const int k = e - p * KE;
-        float v = 0.0f;
-        if (k < K && p < rows) {
-          v = X[((int64_t)g * Ng + n0 + p) * ldx + k];
-          if (sc) v = fmaxf(fmaf(v, sc[k], sh[k]), 0.0f);
-        }
-        As[p * KP + k] = v;
-      }
-    }
-    __syncthreads();
+    const int n0 = tile * GT;
+    const int rows = min(GT, Ng - n0);
+    float ra[NA], rw[NW];
 
-    f32x16 acc0 = {0}, acc1 = {0};
-    const float* arow = As + (32 * rt + (lane & 31)) * KP + (lane >> 5);
-    const int ct0 = cw, ct1 = cw + 2;
-    const float* b0p = Wt + 32 * ct0 + (lane & 31);
-    const float* b1p = Wt + 32 * ct1 + (lane & 31);
-    const int KF = K & ~1;  // full k-pairs; an odd K leaves one half-pair whose second row is zero
-    const int hi = lane >> 5;
-    if (ct1 < NT) {
-      for (int k0 = 0; k0 < KF; k0 += 2) {
-        const float a = arow[k0];
-        const float b0 = b0p[(int64_t)(k0 + hi) * Nc];
-        const float b1 = b1p[(int64_t)(k0 + hi) * Nc];
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+    auto load_chunk = [&](int c) {
+      const int k0 = c * KC;
+      if (!POINT_MAJOR) {
+        const int p = tid & (GT - 1), kr = tid >> 7;                // 2 k-rows per pass, 512 B per row
+#pragma unroll
+        for (int r = 0; r < NA; ++r) {
+          const int k = k0 + 2 * r + kr;
+          ra[r] = (k < K && p < rows) ? X[((int64_t)g * K + k) * Ng + n0 + p] : 0.0f;
+        }
+      } else {
+        const int kk = tid & (KC - 1), pr = tid / KC;               // KC consecutive k of 256/KC rows per pass
+#pragma unroll
+        for (int r = 0; r < NA; ++r) {
+          const int p = r * (256 / KC) + pr;
+          const int k = k0 + kk;
+          ra[r] = (k < K && p < rows) ? X[((int64_t)g * Ng + n0 + p) * ldx + k] : 0.0f;
+        }
       }
-      if (KF < K) {
-        const float a = arow[KF];
-        const float b0 = hi == 0 ? b0p[(int64_t)KF * Nc] : 0.0f;
-        const float b1 = hi == 0 ? b1p[(int64_t)KF * Nc] : 0.0f;
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < NW; ++r) {
+        const int e = tid + 256 * r;
+        const int k = k0 + e / NC, j = e % NC;
+        rw[r] = k < K ? Wt[(int64_t)k * NC + j] : 0.0f;
       }
-    } else if (ct0 < NT) {
-      for (int k0 = 0; k0 < KF; k0 += 2) {
-        const float a = arow[k0];
-        const float b0 = b0p[(int64_t)(k0 + hi) * Nc];
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+    };
+    auto store_chunk = [&](int c, int buf) {
+      const int k0 = c * KC;
+      if (!POINT_MAJOR) {
+        const int p = tid & (GT - 1), kr = tid >> 7;
+#pragma unroll
+        for (int r = 0; r < NA; ++r) {
+          const int kl = 2 * r + kr;
+          float v = ra[r];
+          if (sc && k0 + kl < K && p < rows) v = fmaxf(fmaf(v, sc[k0 + kl], sh[k0 + kl]), 0.0f);
+          As[buf][kl][p] = v;
+        }
+      } else {
+        const int kk = tid & (KC - 1), pr = tid / KC;
+        float s1 = 1.0f, s0 = 0.0f;
+        const bool aff = sc && (k0 + kk < K);
+        if (aff) {
+          s1 = sc[k0 + kk];
+          s0 = sh[k0 + kk];
+        }
+#pragma unroll
+        for (int r = 0; r < NA; ++r) {
+          const int p = r * (256 / KC) + pr;
+          float v = ra[r];
+          if (aff && p < rows) v = fmaxf(fmaf(v, s1, s0), 0.0f);
+          As[buf][kk][p] = v;
+        }
       }
-      if (KF < K) {
-        const float a = arow[KF];
-        const float b0 = hi == 0 ? b0p[(int64_t)KF * Nc] : 0.0f;
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < NW; ++r) {
+        const int e = tid + 256 * r;
+        Ws[buf][e / NC][e % NC] = rw[r];
       }
+    };
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    __syncthreads();                    // previous tile's last chunk has been consumed
+    load_chunk(0);
+    store_chunk(0, 0);
+    __syncthreads();
+    for (int c = 0; c < chunks; ++c) {
+      const int buf = c & 1;
+      if (c + 1 < chunks) load_chunk(c + 1);
+#pragma unroll 4
+      for (int kp = 0; kp < KC / 2; ++kp) {
+        const float a = As[buf][2 * kp + hi][32 * wave + lo];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const float b = Ws[buf][2 * kp + hi][32 * t + lo];
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+        }
+      }
+      if (c + 1 < chunks) store_chunk(c + 1, buf ^ 1);
+      __syncthreads();
     }
 
     // epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int ct = i == 0 ? ct0 : ct1;
-      if (ct < NT) {
-        const f32x16 acc = i == 0 ? acc0 : acc1;
-        const int col = 32 * ct + (lane & 31);
-        float cs = 0.0f, cq = 0.0f;
+    for (int t = 0; t < NT; ++t) {
+      const int col = 32 * t + lo;
+      float cs = 0.0f, cq = 0.0f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = 32 * rt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          const float v = acc[r];
-          if (row < rows) {
-            if (col < Nc_store) Y[((int64_t)g * Ng + n0 + row) * ldy + col] = v;
-            cs += v;
-            cq += v * v;
-          }
+      for (int r = 0; r < 16; ++r) {
+        const int row = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const float v = acc[t][r];
+        if (row < rows) {
+          if (col < Nc_store) Y[((int64_t)g * Ng + n0 + row) * ldy + col] = v;
+          cs += v;
+          cq += v * v;
         }
-        csum[i] += (double)cs;
-        csq[i] += (double)cq;
       }
+      csum[t] += (double)cs;
+      csq[t] += (double)cq;
     }
   }
 
   if (partials != nullptr) {
     __syncthreads();
-    double* red = reinterpret_cast<double*>(lds);  // [wave][i][32][2]
+    double* red = reinterpret_cast<double*>(&As[0][0][0]);  // [wave][NC][2] doubles <= 8 KB
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      double s = csum[i], q = csq[i];
+    for (int t = 0; t < NT; ++t) {
+      double s = csum[t], q = csq[t];
       s += __shfl_xor(s, 32);
       q += __shfl_xor(q, 32);
       if (lane < 32) {
-        red[((wave * 2 + i) * 32 + lane) * 2 + 0] = s;
-        red[((wave * 2 + i) * 32 + lane) * 2 + 1] = q;
+        red[((wave * NC) + 32 * t + lane) * 2 + 0] = s;
+        red[((wave * NC) + 32 * t + lane) * 2 + 1] = q;
       }
     }
     __syncthreads();
-    if (rt == 0 && lane < 32) {
+    if (tid < NC) {
+      double s = 0.0, q = 0.0;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int ct = cw + 2 * i;
-        if (ct < NT) {
-          const int col = 32 * ct + lane;
-          const double s = red[((wave * 2 + i) * 32 + lane) * 2 + 0] + red[(((wave + 1) * 2 + i) * 32 + lane) * 2 + 0];
-          const double q = red[((wave * 2 + i) * 32 + lane) * 2 + 1] + red[(((wave + 1) * 2 + i) * 32 + lane) * 2 + 1];
-          double* o = partials + (((int64_t)g * T + tb) * Nc + col) * 2;
-          o[0] = s;
-          o[1] = q;
-        }
+      for (int w = 0; w < 4; ++w) {
+        s += red[((w * NC) + tid) * 2 + 0];
+        q += red[((w * NC) + tid) * 2 + 1];
       }
+      double* o = partials + (((int64_t)g * T + tb) * NC + tid) * 2;
+      o[0] = s;
+      o[1] = q;
     }
   }
 }
@@ -317,9 +348,23 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const double* __restr
     double a = 0.0, b = 0.0;
     if (sl < slices) {
       const double* base = partials + ((int64_t)s * entries * pcols + col0 + c) * 2;
-      for (int e = sl; e < entries; e += slices) {
-        a += base[(int64_t)e * pcols * 2 + 0];
-        b += base[(int64_t)e * pcols * 2 + 1];
+      const int64_t estride = (int64_t)pcols * 2;
+      int e = sl;
+      // 8 independent 16-byte loads in flight per lane (a dependent chain of global loads costs ~0.5 us each)
+      for (; e + 7 * slices < entries; e += 8 * slices) {
+        double2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const double2*>(base + (int64_t)(e + u * slices) * estride);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          a += v[u].x;
+          b += v[u].y;
+        }
+      }
+      for (; e < entries; e += slices) {
+        const double2 v = *reinterpret_cast<const double2*>(base + (int64_t)e * estride);
+        a += v.x;
+        b += v.y;
       }
     }
     __syncthreads();
@@ -426,29 +471,41 @@ int pf_stat_blocks(int G, int Ng) {
   return tiles < cap ? tiles : cap;
 }
 
+int pf_gemm_blocks(int G, int Ng) {
+  if (G <= 0 || Ng <= 0) return 0;
+  const int tiles = (Ng + GT - 1) / GT;
+  int cap = 1024 / G;
+  cap = cap < 32 ? 32 : (cap > 256 ? 256 : cap);
+  return tiles < cap ? tiles : cap;
+}
+
 int pf_pointwise_gemm_f32(const float* X, int x_point_major, int64_t ldx, const float* Wt, float* Y, int64_t ldy,
                           int G, int Ng, int K, int Nc, int Nc_store, const float* in_scale,
                           const float* in_shift, int groups_per_stat, double* col_partials, void* stream) {
   PF_REQUIRE(G >= 0 && Ng >= 0 && K >= 1 && Nc >= 32 && Nc_store >= 1 && Nc_store <= Nc);
   PF_REQUIRE(Nc % 32 == 0 && groups_per_stat >= 1);
-  if (Nc > 128 || K > 1024) return PF_ERR_UNSUPPORTED;
+  if (Nc != 32 && Nc != 64 && Nc != 128) return PF_ERR_UNSUPPORTED;
   PF_REQUIRE((in_scale == nullptr) == (in_shift == nullptr));
   PF_REQUIRE(G <= 65535);
   if (G == 0 || Ng == 0) return PF_OK;
   PF_REQUIRE(X && Wt && Y && ldy >= Nc_store);
   if (x_point_major) PF_REQUIRE(ldx >= K);
-  const int T = pf_stat_blocks(G, Ng);
-  size_t lds_bytes = (size_t)TILE * kpad(K) * sizeof(float);
-  if (lds_bytes < 4096) lds_bytes = 4096;
-  if (lds_bytes > 64 * 1024) return PF_ERR_UNSUPPORTED;
+  const int T = pf_gemm_blocks(G, Ng);
   dim3 grid((unsigned)T, (unsigned)G);
+  hipStream_t s = (hipStream_t)stream;
+#define PF_GEMM_LAUNCH(PM, NTV)                                                                                  \
+  hipLaunchKernelGGL((pointwise_gemm_kernel<PM, NTV>), grid, dim3(256), 0, s, X, ldx, Wt, Y, ldy, Ng, K, Nc_store, \
+                     in_scale, in_shift, groups_per_stat, col_partials, T)
   if (x_point_major) {
-    hipLaunchKernelGGL(pointwise_gemm_kernel<true>, grid, dim3(256), lds_bytes, (hipStream_t)stream, X, ldx, Wt, Y,
-                       ldy, Ng, K, Nc, Nc_store, in_scale, in_shift, groups_per_stat, col_partials, T);
+    if (Nc == 32) PF_GEMM_LAUNCH(true, 1);
+    else if (Nc == 64) PF_GEMM_LAUNCH(true, 2);
+    else PF_GEMM_LAUNCH(true, 4);
   } else {
-    hipLaunchKernelGGL(pointwise_gemm_kernel<false>, grid, dim3(256), lds_bytes, (hipStream_t)stream, X, ldx, Wt,
-                       Y, ldy, Ng, K, Nc, Nc_store, in_scale, in_shift, groups_per_stat, col_partials, T);
+    if (Nc == 32) PF_GEMM_LAUNCH(false, 1);
+    else if (Nc == 64) PF_GEMM_LAUNCH(false, 2);
+    else PF_GEMM_LAUNCH(false, 4);
   }
+#undef PF_GEMM_LAUNCH
   return pf_launch_status();
 }
 

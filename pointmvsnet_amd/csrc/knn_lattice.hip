@@ -8,10 +8,9 @@
 //
 // Exactness: distances are centre - candidate, d2 = (dx*dx + dy*dy) + dz*dz in float32, no contraction
 // (this file is built with -ffp-contract=off), i.e. the value torch.sum(diff**2, dim=1) produces.
-// Ranking key = (bits(d2) << 32) | candidate_code as one uint64: non-negative floats order like their
-// bit patterns, so one integer compare implements "smaller d2 first, then smaller candidate code"
-// (the reference's tie order is unspecified).  The top list is a sorted register array
-// updated by a compare-exchange pass; the loop is fully unrolled so nothing spills to scratch.
+// Ranking: smaller d2 first, ties by smaller candidate code (the reference's tie order is unspecified,
+// SURVEY.md F10).  The top list is a sorted register array updated by one compare-exchange pass per
+// accepted candidate; everything is unrolled so nothing spills to scratch.
 #include "pf_common.h"
 
 namespace {
@@ -71,9 +70,16 @@ __global__ __launch_bounds__(256) void knn_lattice_kernel(const float* __restric
   const int ce = (hk * LH + ty + hk) * LW + tx + hk;
   const float cx = lx[ce], cy = ly[ce], cz = lz[ce];
 
-  uint64_t keys[CAP];
+  // Sorted top list in registers: distances and window codes side by side.  Candidates are visited in
+  // increasing code order and a candidate enters / moves up only on a STRICTLY smaller distance, so equal
+  // distances keep the smaller code first -- the (d2, code) order -- with one 32-bit compare per exchange.
+  float bd[CAP];
+  int bc[CAP];
 #pragma unroll
-  for (int j = 0; j < CAP; ++j) keys[j] = ~0ull;
+  for (int j = 0; j < CAP; ++j) {
+    bd[j] = __builtin_huge_valf();
+    bc[j] = 0;
+  }
 
   for (int pl = 0; pl < ks; ++pl) {
     for (int r = 0; r < ks; ++r) {
@@ -84,16 +90,20 @@ __global__ __launch_bounds__(256) void knn_lattice_kernel(const float* __restric
         const float dy = cy - ly[e];
         const float dz = cz - lz[e];
         const float d2 = (dx * dx + dy * dy) + dz * dz;
-        const uint32_t code = (uint32_t)((pl * ks + r) * ks + cc);
-        const uint64_t key = ((uint64_t)__float_as_uint(d2) << 32) | (uint64_t)code;
-        if (key < keys[CAP - 1]) {
-          keys[CAP - 1] = key;
+        if (d2 < bd[CAP - 1]) {
+          bd[CAP - 1] = d2;
+          bc[CAP - 1] = (pl * ks + r) * ks + cc;
 #pragma unroll
           for (int j = CAP - 1; j > 0; --j) {
-            const uint64_t lo = keys[j - 1] < keys[j] ? keys[j - 1] : keys[j];
-            const uint64_t hi = keys[j - 1] < keys[j] ? keys[j] : keys[j - 1];
-            keys[j - 1] = lo;
-            keys[j] = hi;
+            const bool sw = bd[j] < bd[j - 1];
+            const float dlo = sw ? bd[j] : bd[j - 1];
+            const float dhi = sw ? bd[j - 1] : bd[j];
+            const int clo = sw ? bc[j] : bc[j - 1];
+            const int chi = sw ? bc[j - 1] : bc[j];
+            bd[j - 1] = dlo;
+            bd[j] = dhi;
+            bc[j - 1] = clo;
+            bc[j] = chi;
           }
         }
       }
@@ -109,7 +119,7 @@ __global__ __launch_bounds__(256) void knn_lattice_kernel(const float* __restric
 #pragma unroll
   for (int j = 0; j < CAP; ++j) {
     if (j < knn) {
-      const int code = (int)(uint32_t)(keys[j] & 0xffffffffull);
+      const int code = bc[j];
       const int pd = code / ks2;
       const int rem = code - pd * ks2;
       const int ph = rem / ks;

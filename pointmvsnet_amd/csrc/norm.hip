@@ -1,0 +1,143 @@
+// Train-mode BatchNorm for the conv stacks on either side of the path (ImageConv, VolumeConv: SURVEY.md
+// section 8(f) items 1-2): per-(sample group, channel) statistics and the fused affine + ReLU epilogue.
+//
+// The library BatchNorm the reference ends up in costs ~26 us per call on MI355X regardless of size
+// (rocprofv3, profiles/r01_*): 70 calls per depth map.  Here: one streaming reduction (float4 loads,
+// float64 block partials in the same (G, T, C, 2) layout pf_bn_finalize_f32 consumes), the shared
+// finalize kernel, and one streaming normalise+ReLU pass in place.  Both passes are HBM-bound:
+// 4*N*C*S bytes read, then read + written.
+#include "pf_common.h"
+
+namespace {
+
+// x is (N, C, S) contiguous.  grid = (T, C, N); block t of (n, c) reduces elements [t*chunk, (t+1)*chunk).
+__global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restrict__ x, int C, int64_t S,
+                                                            int64_t chunk, double* __restrict__ partials, int T) {
+  __shared__ double red[2 * 4];
+  const int t = blockIdx.x, c = blockIdx.y, n = blockIdx.z;
+  const float* p = x + ((int64_t)n * C + c) * S;
+  const int64_t lo = (int64_t)t * chunk;
+  const int64_t hi = min(S, lo + chunk);
+  float s0 = 0.0f, s1 = 0.0f, q0 = 0.0f, q1 = 0.0f;
+  double ds = 0.0, dq = 0.0;
+  if (((uintptr_t)(p + lo) & 15) == 0) {
+    const int64_t n4 = (hi - lo) >> 2;
+    const float4* p4 = reinterpret_cast<const float4*>(p + lo);
+    int64_t i = threadIdx.x;
+    for (; i + 256 < n4; i += 512) {           // two independent 16-byte loads in flight
+      const float4 a = p4[i], b = p4[i + 256];
+      s0 += (a.x + a.y) + (a.z + a.w);
+      q0 += (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
+      s1 += (b.x + b.y) + (b.z + b.w);
+      q1 += (b.x * b.x + b.y * b.y) + (b.z * b.z + b.w * b.w);
+    }
+    for (; i < n4; i += 256) {
+      const float4 a = p4[i];
+      s0 += (a.x + a.y) + (a.z + a.w);
+      q0 += (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
+    }
+    for (int64_t j = lo + (n4 << 2) + threadIdx.x; j < hi; j += 256) {
+      const float v = p[j];
+      s0 += v;
+      q0 += v * v;
+    }
+  } else {
+    for (int64_t j = lo + threadIdx.x; j < hi; j += 256) {
+      const float v = p[j];
+      s0 += v;
+      q0 += v * v;
+    }
+  }
+  ds = (double)s0 + (double)s1;
+  dq = (double)q0 + (double)q1;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    ds += __shfl_xor(ds, off);
+    dq += __shfl_xor(dq, off);
+  }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    red[wave * 2 + 0] = ds;
+    red[wave * 2 + 1] = dq;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double* o = partials + (((int64_t)n * T + t) * C + c) * 2;
+    o[0] = (red[0] + red[2]) + (red[4] + red[6]);
+    o[1] = (red[1] + red[3]) + (red[5] + red[7]);
+  }
+}
+
+// y = act(x * scale[s, c] + shift[s, c]), s = n / samples_per_stat; grid = (blocks, C, N)
+__global__ __launch_bounds__(256) void channel_affine_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                             const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, int C, int64_t S,
+                                                             int samples_per_stat, int relu) {
+  const int c = blockIdx.y, n = blockIdx.z;
+  const int64_t so = (int64_t)(n / samples_per_stat) * C + c;
+  const float a = scale[so], b = shift[so];
+  const float* p = x + ((int64_t)n * C + c) * S;
+  float* o = y + ((int64_t)n * C + c) * S;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  if ((((uintptr_t)p | (uintptr_t)o) & 15) == 0 && (S & 3) == 0) {
+    const int64_t n4 = S >> 2;
+    const float4* p4 = reinterpret_cast<const float4*>(p);
+    float4* o4 = reinterpret_cast<float4*>(o);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+      float4 v = p4[i];
+      v.x = fmaf(v.x, a, b);
+      v.y = fmaf(v.y, a, b);
+      v.z = fmaf(v.z, a, b);
+      v.w = fmaf(v.w, a, b);
+      if (relu) {
+        v.x = fmaxf(v.x, 0.0f);
+        v.y = fmaxf(v.y, 0.0f);
+        v.z = fmaxf(v.z, 0.0f);
+        v.w = fmaxf(v.w, 0.0f);
+      }
+      o4[i] = v;
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < S; i += stride) {
+      float v = fmaf(p[i], a, b);
+      o[i] = relu ? fmaxf(v, 0.0f) : v;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int pf_norm_blocks(int64_t S) {
+  if (S <= 0) return 0;
+  const int64_t t = (S + 8191) / 8192;       // >= 8192 elements (32 KB) per block
+  return (int)(t > 64 ? 64 : t);
+}
+
+int pf_channel_stats_f32(const float* x, int64_t N, int64_t C, int64_t S, double* partials, void* stream) {
+  PF_REQUIRE(N >= 0 && C >= 0 && S >= 0 && N <= 65535 && C <= 65535);
+  if (N == 0 || C == 0 || S == 0) return PF_OK;
+  PF_REQUIRE(x && partials);
+  const int T = pf_norm_blocks(S);
+  int64_t chunk = (S + T - 1) / T;
+  chunk = (chunk + 3) & ~(int64_t)3;          // keep every block's start 16-byte aligned relative to the plane
+  dim3 grid((unsigned)T, (unsigned)C, (unsigned)N);
+  hipLaunchKernelGGL(channel_stats_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, (int)C, S, chunk, partials, T);
+  return pf_launch_status();
+}
+
+int pf_channel_affine_f32(const float* x, float* y, const float* scale, const float* shift, int64_t N, int64_t C,
+                          int64_t S, int samples_per_stat, int relu, void* stream) {
+  PF_REQUIRE(N >= 0 && C >= 0 && S >= 0 && N <= 65535 && C <= 65535 && samples_per_stat >= 1);
+  if (N == 0 || C == 0 || S == 0) return PF_OK;
+  PF_REQUIRE(x && y && scale && shift);
+  int64_t blocks = (S / 4 + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 64 ? 64 : blocks);
+  dim3 grid((unsigned)blocks, (unsigned)C, (unsigned)N);
+  hipLaunchKernelGGL(channel_affine_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, scale, shift, (int)C, S,
+                     samples_per_stat, relu);
+  return pf_launch_status();
+}
+
+}  // extern "C"

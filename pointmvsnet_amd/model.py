@@ -124,8 +124,11 @@ class PointMVSNet(nn.Module):
         mean_h, std_h = mean_h.float(), std_h.float()
 
         # ---- coarse stage (reference model.py:71-130) -----------------------------------------
-        coarse_maps = [self.coarse_img_conv(img_list[:, v])["conv3"] for v in range(V)]
-        feature_list = torch.stack(coarse_maps, dim=1)                       # (B,V,C,FH,FW)
+        if graph:
+            coarse_maps = [self.coarse_img_conv(img_list[:, v])["conv3"] for v in range(V)]
+            feature_list = torch.stack(coarse_maps, dim=1)                   # (B,V,C,FH,FW)
+        else:
+            feature_list = self.coarse_img_conv.forward_views(img_list)["conv3"].contiguous()
         C, FH, FW = feature_list.shape[2:]
         D = cam.num_depth
 
@@ -148,7 +151,8 @@ class PointMVSNet(nn.Module):
         else:
             cost = fetch_variance(feature_list, world_points, K_coarse, ext, ref_override=True)
         cost_volume = cost.view(B, C, D, FH, FW)
-        filtered = self.coarse_vol_conv(cost_volume).squeeze(1)              # (B,D,FH,FW)
+        vol = self.coarse_vol_conv if graph else self.coarse_vol_conv.forward_fused
+        filtered = vol(cost_volume).squeeze(1)                               # (B,D,FH,FW)
 
         d_start = cam.depth_start.to(dev)
         d_end = cam.depth_end.to(dev)
@@ -162,12 +166,16 @@ class PointMVSNet(nn.Module):
         preds["coarse_depth_map"] = pred_depth
         preds["coarse_prob_map"] = prob_map
         if not isFlow:
+            pointflow.flush_counters()
             return preds
 
         # ---- flow stage (reference model.py:132-303) --------------------------------------------
         names = ("conv1", "conv2", "conv3")
-        per_view = [self.flow_img_conv(img_list[:, v]) for v in range(V)]
-        pyramids = {n: torch.stack([pv[n] for pv in per_view], dim=1) for n in names}   # (B,V,c,h_l,w_l)
+        if graph:
+            per_view = [self.flow_img_conv(img_list[:, v]) for v in range(V)]
+            pyramids = {n: torch.stack([pv[n] for pv in per_view], dim=1) for n in names}   # (B,V,c,h_l,w_l)
+        else:
+            pyramids = self.flow_img_conv.forward_views(img_list)
         if isTest:
             pyramids = {n: p.detach() for n, p in pyramids.items()}
 
@@ -197,6 +205,7 @@ class PointMVSNet(nn.Module):
                 flow_prob = torch.stack(probs, dim=0)
             preds["flow{}_prob".format(it + 1)] = flow_prob
             preds["flow{}".format(it + 1)] = pred_depth
+        pointflow.flush_counters()
         return preds
 
     # ------------------------------------------------------------------------------------------

@@ -61,6 +61,7 @@ class _EdgeConvBase(nn.Module):
         with torch.cuda.device(x.device):
             pointflow.edge_conv_fused(x, False, 0, cin, B, N, idx, self.conv1.weight, self.conv2.weight,
                                       self.bn, self.concat, out, width, groups_per_stat=B)
+            pointflow.flush_counters()
         return out.view(B, N, width).transpose(1, 2).contiguous()
 
     def forward(self, feature, knn_inds):
@@ -80,6 +81,17 @@ class EdgeConv(_EdgeConvBase):
 class EdgeConvNoC(_EdgeConvBase):
     """(B,C_in,N) -> (B, C_out, N): mean_k ReLU(BN(e[idx] - l))."""
     concat = False
+
+
+def _block_fused(block, x, samples_per_stat):
+    """conv (library) -> HIP BatchNorm statistics/finalize -> HIP affine+ReLU in place; ``block`` is one of
+    the nn.conv blocks or a plain nn.ConvNd (no BN / ReLU)."""
+    if not hasattr(block, "bn"):
+        return block(x)
+    y = block._crop(block.conv(x), x)
+    if block.bn is not None:
+        return pointflow.batch_norm_act_(y.contiguous(), block.bn, block.relu, samples_per_stat)
+    return F.relu(y, inplace=True) if block.relu else y
 
 
 class ImageConv(nn.Module):
@@ -110,6 +122,19 @@ class ImageConv(nn.Module):
             out[name] = x
         return out
 
+    def forward_views(self, img_list):
+        """Inference fast path: all V views of (B,V,3,H,W) in ONE pass through the tower with per-view
+        BatchNorm statistics -- numerically the reference's V separate calls (model.py:71-77), a third of
+        the launches.  Returns {"conv0".."conv3"} with tensors (B,V,c,h,w)."""
+        B, V = img_list.shape[:2]
+        x = img_list.transpose(0, 1).reshape(V * B, *img_list.shape[2:])      # view-major: stat groups contiguous
+        out = {}
+        for name in ("conv0", "conv1", "conv2", "conv3"):
+            for block in getattr(self, name):
+                x = _block_fused(block, x, B)
+            out[name] = x.view(V, B, *x.shape[1:]).transpose(0, 1)
+        return out
+
 
 class VolumeConv(nn.Module):
     """3-level 3D U-Net regulariser with additive skips; last conv is plain."""
@@ -131,6 +156,21 @@ class VolumeConv(nn.Module):
         self.conv5_0 = Deconv3d(4 * b, 2 * b, 3, 2, padding=1, output_padding=1)
         self.conv6_0 = Deconv3d(2 * b, b, 3, 2, padding=1, output_padding=1)
         self.conv6_2 = nn.Conv3d(b, 1, 3, padding=1, bias=False)
+
+    def forward_fused(self, x):
+        """Inference fast path: library convs + HIP BatchNorm/ReLU kernels (statistics pooled over the batch)."""
+        B = x.shape[0]
+        f = lambda blk, t: _block_fused(blk, t, B)   # noqa: E731
+        full = f(self.conv0_1, x)
+        half = f(self.conv1_0, x)
+        quarter = f(self.conv2_0, half)
+        eighth = f(self.conv3_1, f(self.conv3_0, quarter))
+        half = f(self.conv1_1, half)
+        quarter = f(self.conv2_1, quarter)
+        up = f(self.conv4_0, eighth)
+        up = f(self.conv5_0, up + quarter)
+        up = f(self.conv6_0, up + half)
+        return self.conv6_2(up + full)
 
     def forward(self, x):
         full = self.conv0_1(x)

@@ -40,7 +40,7 @@ def pointwise_gemm(X, point_major, ldx, Wt, Y, ldy, G, Ng, K, nc_store, in_affin
     """Y[:, :nc_store] = act(X) @ Wt (see pf_pointwise_gemm_f32).  Returns the float64 column partials
     (G, T, Nc, 2) when ``want_stats``."""
     Nc = Wt.shape[1]
-    T = stat_blocks(G, Ng)
+    T = int(_lib.load().pf_gemm_blocks(int(G), int(Ng)))
     partials = torch.empty((G, T, Nc, 2), dtype=torch.float64, device=Wt.device) if want_stats else None
     sc, sh = in_affine if in_affine is not None else (None, None)
     _lib.call("pf_pointwise_gemm_f32",
@@ -67,12 +67,62 @@ def bn_affine(bn, partials, col0, C, count, unbias_n, G, groups_per_stat, scale,
               _lib.ptr(shift), int(scale.stride(0)), _lib.stream(), algo_bytes=16.0 * G * T * C)
 
 
+_pending_counters = []
+
+
+def bump_counter(bn, n):
+    """``num_batches_tracked += n`` deferred to one fused launch (flush_counters) instead of one tiny
+    elementwise kernel per BatchNorm module (82 of them per depth map in eager PyTorch)."""
+    if bn.track_running_stats and bn.num_batches_tracked is not None:
+        _pending_counters.append((bn.num_batches_tracked, int(n)))
+
+
+def flush_counters():
+    if _pending_counters:
+        tensors = [t for t, _ in _pending_counters]
+        counts = [n for _, n in _pending_counters]
+        del _pending_counters[:]
+        torch._foreach_add_(tensors, counts)
+
+
 def eval_affine(bn, S, ld, ch0=0, C=None, out=None):
     """Eval-mode BatchNorm (running statistics) folded to scale/shift rows."""
     C = bn.num_features - ch0 if C is None else C
     inv = torch.rsqrt(bn.running_var[ch0:ch0 + C] + bn.eps) * bn.weight.detach()[ch0:ch0 + C]
     sh = bn.bias.detach()[ch0:ch0 + C] - bn.running_mean[ch0:ch0 + C] * inv
     return inv, sh
+
+
+# ---------------------------------------------------------------------------------------------
+# BatchNorm (+ReLU) for the conv stacks around the path (ImageConv / VolumeConv)
+# ---------------------------------------------------------------------------------------------
+def batch_norm_act_(x, bn, relu, samples_per_stat):
+    """In-place train/eval BatchNorm + optional ReLU on a contiguous (N,C,*spatial) conv output.
+
+    ``samples_per_stat`` consecutive samples share one set of batch statistics == one reference module
+    call (the reference runs each view through the tower separately, model.py:71-77, so views batched
+    along N keep per-view statistics and the running statistics are updated once per view, in order)."""
+    N, C = x.shape[:2]
+    S = x[0, 0].numel()
+    G = N // samples_per_stat
+    dev = x.device
+    scale = torch.empty((G, C), dtype=_F32, device=dev)
+    shift = torch.empty((G, C), dtype=_F32, device=dev)
+    if bn.training or not bn.track_running_stats:
+        T = int(_lib.load().pf_norm_blocks(S))
+        partials = torch.empty((N, T, C, 2), dtype=torch.float64, device=dev)
+        _lib.call("pf_channel_stats_f32", _lib.ptr(x), N, C, S, _lib.ptr(partials), _lib.stream(),
+                  algo_bytes=4.0 * N * C * S)
+        n = float(samples_per_stat) * S
+        bn_affine(bn, partials, 0, C, n, n, N, samples_per_stat, scale, shift)
+        bump_counter(bn, G)
+    else:
+        sc, sh = eval_affine(bn, G, C)
+        scale.copy_(sc.unsqueeze(0).expand(G, C))
+        shift.copy_(sh.unsqueeze(0).expand(G, C))
+    _lib.call("pf_channel_affine_f32", _lib.ptr(x), _lib.ptr(x), _lib.ptr(scale), _lib.ptr(shift), N, C, S,
+              int(samples_per_stat), int(bool(relu)), _lib.stream(), algo_bytes=8.0 * N * C * S)
+    return x
 
 
 # ---------------------------------------------------------------------------------------------
@@ -108,8 +158,7 @@ def edge_conv_fused(X, point_major, ldx, K, G, Ng, idx, conv1_w, conv2_w, bn, co
             bn_affine(bn, part_d, 0, C, n_pairs, n_pairs, G, groups_per_stat, scale[:, C:], shift[:, C:], ch0=C)
         else:
             bn_affine(bn, part_d, 0, C, n_pairs, n_pairs, G, groups_per_stat, scale, shift, ch0=0)
-        if bn.track_running_stats and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(S)
+        bump_counter(bn, S)
     else:
         sc, sh = eval_affine(bn, S, cbn)
         scale.copy_(sc.unsqueeze(0).expand(S, cbn))
@@ -128,8 +177,7 @@ def _bn_affine_from_gemm(bn, partials, C, G, Ng, groups_per_stat, dev):
     if bn.training or not bn.track_running_stats:
         n = float(groups_per_stat) * Ng
         bn_affine(bn, partials, 0, C, n, n, G, groups_per_stat, scale, shift)
-        if bn.track_running_stats and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(S)
+        bump_counter(bn, S)
     else:
         sc, sh = eval_affine(bn, S, C)
         scale.copy_(sc.unsqueeze(0).expand(S, C))
@@ -169,15 +217,10 @@ def flow_features(levels, depth, interval, cam, h, w, ratio):
     return feature, xyz
 
 
-def flow_iteration(pyramid, depth, interval, cam, h, w, ratio, edge_convs, flow_mlp, k=16):
-    """One PointFlow refinement of one scene (reference model.py:150-295 for batch item b).
-
-    pyramid: three contiguous (V,c,H_l,W_l) feature maps of this scene; depth: (dh,dw) prior depth map;
-    interval: float hypothesis spacing; cam: packed camera block for this scale.
-    Returns (depth_out (h,w), flow_prob (5,h,w))."""
+def flow_chain(feature, xyz, depth, interval, h, w, ratio, edge_convs, flow_mlp, k=16):
+    """Rows K, E0-E2, M, H, T on assembled point features: feature (G,136,Ng) / xyz (G,3,Ng) in
+    sub-grid-major order (see flow_features) -> (depth_out (h,w), flow_prob (5,h,w))."""
     dev = depth.device
-    levels = [resize_maps(m, h, w) for m in pyramid]
-    feature, xyz = flow_features(levels, depth, interval, cam, h, w, ratio)
     G, Cin, Ng = feature.shape
     hs, ws = h // ratio, w // ratio
     idx = knn_lattice(xyz.view(G, 3, 5, hs, ws), 5, k)                     # (G, Ng, k), group-local
@@ -216,6 +259,17 @@ def flow_iteration(pyramid, depth, interval, cam, h, w, ratio, edge_convs, flow_
               ratio, _lib.ptr(flow_prob), _lib.ptr(depth_out), _lib.stream(),
               algo_bytes=4.0 * G * Ng * 16 + 4.0 * h * w * 7)
     return depth_out, flow_prob
+
+
+def flow_iteration(pyramid, depth, interval, cam, h, w, ratio, edge_convs, flow_mlp, k=16):
+    """One PointFlow refinement of one scene (reference model.py:150-295 for batch item b).
+
+    pyramid: three contiguous (V,c,H_l,W_l) feature maps of this scene; depth: (dh,dw) prior depth map;
+    interval: float hypothesis spacing; cam: packed camera block for this scale.
+    Returns (depth_out (h,w), flow_prob (5,h,w))."""
+    levels = [resize_maps(m, h, w) for m in pyramid]
+    feature, xyz = flow_features(levels, depth, interval, cam, h, w, ratio)
+    return flow_chain(feature, xyz, depth, interval, h, w, ratio, edge_convs, flow_mlp, k=k)
 
 
 def soft_argmin_prob(cost, depth_start, depth_end, depth_interval):

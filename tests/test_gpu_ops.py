@@ -397,3 +397,68 @@ def test_volume_conv_vs_reference(dev):
     err = _maxabs(y, g["y"])
     report("volume_conv", err=err, scale=float(g["y"].abs().max()))
     assert err < 2e-4 * float(g["y"].abs().max())       # library conv3d (MIOpen) vs mkldnn accumulation order
+
+
+# ---------------------------------------------------------------------------------------------
+# BatchNorm kernels for the conv stacks, batched-view ImageConv, fused VolumeConv
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape,sps", [((3, 8, 64, 80), 1), ((6, 16, 7, 9), 2), ((1, 8, 6, 16, 20), 1),
+                                       ((2, 5, 3, 5, 7), 2), ((4, 3, 33), 1)])
+@pytest.mark.parametrize("relu", [True, False])
+def test_batch_norm_act_vs_torch_per_group(dev, shape, sps, relu):
+    gen = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(shape, generator=gen) * 2.0 + 0.7
+    C = shape[1]
+    bn_cls = {3: torch.nn.BatchNorm1d, 4: torch.nn.BatchNorm2d, 5: torch.nn.BatchNorm3d}[len(shape)]
+    ref_bn, bn = bn_cls(C), bn_cls(C)
+    synthetic.seed_weights(ref_bn, 3)
+    synthetic.seed_weights(bn, 3)
+    ref_bn.train()
+    outs = []
+    for g0 in range(0, shape[0], sps):                  # the reference: one module call per group, in order
+        y = ref_bn(x[g0:g0 + sps])
+        outs.append(F.relu(y) if relu else y)
+    ref = torch.cat(outs)
+    bn = bn.to(dev).train()
+    y = pointflow.batch_norm_act_(x.to(dev).contiguous(), bn, relu, sps)
+    pointflow.flush_counters()
+    err = _maxabs(y, ref)
+    report("bn_act_%s" % "x".join(map(str, shape)), err=err)
+    assert err < 5e-6 * max(1.0, float(ref.abs().max()))
+    assert _maxabs(bn.running_mean, ref_bn.running_mean) < 1e-6
+    assert float(((bn.running_var.cpu() - ref_bn.running_var).abs() / ref_bn.running_var).max()) < 1e-5
+    assert int(bn.num_batches_tracked) == int(ref_bn.num_batches_tracked) == shape[0] // sps
+
+
+def test_image_conv_batched_views_equals_per_view_calls(dev):
+    from pointmvsnet_amd.networks import ImageConv
+    gen = torch.Generator().manual_seed(12)
+    imgs = torch.randn(2, 3, 3, 64, 96, generator=gen)
+    a, b = ImageConv(8), ImageConv(8)
+    synthetic.seed_weights(a, 5)
+    synthetic.seed_weights(b, 5)
+    a, b = a.to(dev).train(), b.to(dev).train()
+    with torch.no_grad():
+        per_view = [a(imgs[:, v].to(dev)) for v in range(3)]               # reference call pattern (model.py:71-77)
+        fused = b.forward_views(imgs.to(dev))
+        pointflow.flush_counters()
+    for name in ("conv0", "conv1", "conv2", "conv3"):
+        want = torch.stack([pv[name] for pv in per_view], dim=1)
+        err = _maxabs(fused[name], want)
+        report("image_conv_views_" + name, err=err, scale=float(want.abs().max()))
+        assert fused[name].shape == want.shape
+        assert err < 2e-4 * float(want.abs().max())
+    for (ka, va), (kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert torch.allclose(va.float(), vb.float(), rtol=1e-4, atol=1e-5), ka
+
+
+def test_volume_conv_fused_vs_reference(dev):
+    g = load_golden("volume_conv")
+    mod = VolumeConv(64, 8)
+    synthetic.seed_weights(mod, seed=2)
+    mod = mod.to(dev).train()
+    with torch.no_grad():
+        y = mod.forward_fused(g["x"].to(dev))
+    err = _maxabs(y, g["y"])
+    report("volume_conv_fused", err=err, scale=float(g["y"].abs().max()))
+    assert err < 2e-4 * float(g["y"].abs().max())
