@@ -333,24 +333,31 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const double* __restr
                                                            float eps, int S, int groups_per_stat,
                                                            float* __restrict__ scale, float* __restrict__ shift,
                                                            int ld_affine) {
-  __shared__ double red[1024 * 2];
+  // Phase 1 (parallel): all (stat group, channel) pairs of a round are reduced at once -- one batch of
+  // independent loads for the whole launch instead of one global round trip per stat group.
+  // Phase 2 (sequential in s, from LDS): affine parameters + the running-statistics recurrence.
+  __shared__ double2 red[1024];
+  __shared__ double2 stat[1024];
   const int tid = threadIdx.x;
-  const int slices = 1024 / C;  // C <= 256 checked on the host
-  const int c = tid % C, sl = tid / C;
   const int entries = groups_per_stat * T;
+  const int64_t estride = (int64_t)pcols * 2;
+  const int Sc = max(1, 1024 / C);  // stat groups per round (C <= 256 checked on the host)
   float rm = 0.0f, rv = 0.0f;
   const bool track = running_mean != nullptr;
   if (track && tid < C) {
     rm = running_mean[tid];
     rv = running_var[tid];
   }
-  for (int s = 0; s < S; ++s) {
+  for (int s0 = 0; s0 < S; s0 += Sc) {
+    const int ns = min(Sc, S - s0);
+    const int P = ns * C;
+    const int slices = max(1, 1024 / P);
     double a = 0.0, b = 0.0;
-    if (sl < slices) {
+    if (tid < P * slices) {
+      const int pair = tid % P, sl = tid / P;
+      const int s = s0 + pair / C, c = pair % C;
       const double* base = partials + ((int64_t)s * entries * pcols + col0 + c) * 2;
-      const int64_t estride = (int64_t)pcols * 2;
       int e = sl;
-      // 8 independent 16-byte loads in flight per lane (a dependent chain of global loads costs ~0.5 us each)
       for (; e + 7 * slices < entries; e += 8 * slices) {
         double2 v[8];
 #pragma unroll
@@ -368,26 +375,32 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const double* __restr
       }
     }
     __syncthreads();
-    red[tid * 2 + 0] = a;
-    red[tid * 2 + 1] = b;
+    red[tid] = make_double2(a, b);
     __syncthreads();
-    if (tid < C) {
+    if (tid < P) {
       double sum = 0.0, sq = 0.0;
       for (int i = 0; i < slices; ++i) {
-        sum += red[(i * C + tid) * 2 + 0];
-        sq += red[(i * C + tid) * 2 + 1];
+        sum += red[i * P + tid].x;
+        sq += red[i * P + tid].y;
       }
       const double mean = sum / count;
       double var = sq / count - mean * mean;
-      var = var < 0.0 ? 0.0 : var;
-      const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-      const float a_ = invstd * gamma[tid];
-      scale[(int64_t)s * ld_affine + tid] = a_;
-      shift[(int64_t)s * ld_affine + tid] = beta[tid] - (float)mean * a_;
-      if (track) {
-        const double unbiased = unbias_n > 1.0 ? var * (unbias_n / (unbias_n - 1.0)) : var;
-        rm = (1.0f - momentum) * rm + momentum * (float)mean;
-        rv = (1.0f - momentum) * rv + momentum * (float)unbiased;
+      stat[tid] = make_double2(mean, var < 0.0 ? 0.0 : var);
+    }
+    __syncthreads();
+    if (tid < C) {
+      const float g_ = gamma[tid], b_ = beta[tid];
+      for (int si = 0; si < ns; ++si) {
+        const double2 mv = stat[si * C + tid];
+        const float invstd = (float)(1.0 / sqrt(mv.y + (double)eps));
+        const float a_ = invstd * g_;
+        scale[(int64_t)(s0 + si) * ld_affine + tid] = a_;
+        shift[(int64_t)(s0 + si) * ld_affine + tid] = b_ - (float)mv.x * a_;
+        if (track) {
+          const double unbiased = unbias_n > 1.0 ? mv.y * (unbias_n / (unbias_n - 1.0)) : mv.y;
+          rm = (1.0f - momentum) * rm + momentum * (float)mv.x;
+          rv = (1.0f - momentum) * rv + momentum * (float)unbiased;
+        }
       }
     }
   }

@@ -11,9 +11,27 @@
 // Ranking: smaller d2 first, ties by smaller candidate code (the reference's tie order is unspecified,
 // SURVEY.md F10).  The top list is a sorted register array updated by one compare-exchange pass per
 // accepted candidate; everything is unrolled so nothing spills to scratch.
+#include <utility>
+
 #include "pf_common.h"
 
 namespace {
+
+// Insert (nd, nc) into the ascending list (bd, bc), dropping the last entry.  Written as a fold over
+// compile-time indices: every array access has a constant index from the front end on, so the lists
+// live in registers.  (A runtime-indexed `for j` version gets its selects folded into a select of the
+// INDEX before unrolling, and then every access becomes a 16-way compare/cndmask chain: 5x slower.)
+// new[j] = (nd < old[j-1]) ? old[j-1] : ((nd < old[j]) ? nd : old[j]); strict '<' keeps equal distances
+// in arrival (= code) order.
+template <int CAP, int... Js>
+__device__ __forceinline__ void insert_sorted(float (&bd)[CAP], int (&bc)[CAP], float nd, int nc,
+                                              std::integer_sequence<int, Js...>) {
+  const float od[CAP] = {bd[Js]...};
+  const int oc[CAP] = {bc[Js]...};
+  const bool lt[CAP] = {(nd < od[Js])...};
+  ((bd[Js] = (Js > 0 && lt[Js > 0 ? Js - 1 : 0]) ? od[Js > 0 ? Js - 1 : 0] : (lt[Js] ? nd : od[Js])), ...);
+  ((bc[Js] = (Js > 0 && lt[Js > 0 ? Js - 1 : 0]) ? oc[Js > 0 ? Js - 1 : 0] : (lt[Js] ? nc : oc[Js])), ...);
+}
 
 struct Strides5 {
   int64_t b, c, d, h, w;
@@ -90,22 +108,8 @@ __global__ __launch_bounds__(256) void knn_lattice_kernel(const float* __restric
         const float dy = cy - ly[e];
         const float dz = cz - lz[e];
         const float d2 = (dx * dx + dy * dy) + dz * dz;
-        if (d2 < bd[CAP - 1]) {
-          bd[CAP - 1] = d2;
-          bc[CAP - 1] = (pl * ks + r) * ks + cc;
-#pragma unroll
-          for (int j = CAP - 1; j > 0; --j) {
-            const bool sw = bd[j] < bd[j - 1];
-            const float dlo = sw ? bd[j] : bd[j - 1];
-            const float dhi = sw ? bd[j - 1] : bd[j];
-            const int clo = sw ? bc[j] : bc[j - 1];
-            const int chi = sw ? bc[j - 1] : bc[j];
-            bd[j - 1] = dlo;
-            bd[j] = dhi;
-            bc[j - 1] = clo;
-            bc[j] = chi;
-          }
-        }
+        if (d2 < bd[CAP - 1])
+          insert_sorted<CAP>(bd, bc, d2, (pl * ks + r) * ks + cc, std::make_integer_sequence<int, CAP>());
       }
     }
   }

@@ -79,10 +79,12 @@ def bump_counter(bn, n):
 
 def flush_counters():
     if _pending_counters:
-        tensors = [t for t, _ in _pending_counters]
-        counts = [n for _, n in _pending_counters]
+        merged = {}
+        for t, n in _pending_counters:                 # a module may be bumped several times per forward
+            key = t.data_ptr()
+            merged[key] = (t, merged[key][1] + n) if key in merged else (t, n)
         del _pending_counters[:]
-        torch._foreach_add_(tensors, counts)
+        torch._foreach_add_([t for t, _ in merged.values()], [n for _, n in merged.values()])
 
 
 def eval_affine(bn, S, ld, ch0=0, C=None, out=None):

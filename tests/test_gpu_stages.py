@@ -82,7 +82,13 @@ def test_flow_iteration_stagewise_vs_oracle(dev, cfg, it):
                             for g in range(ratio * ratio)])
     same = (idx.cpu().sort(dim=2)[0] == want_idx.sort(dim=2)[0]).all(dim=2)
     report("stage_K_%s_it%d" % (cfg, it), rows_differing=float((~same).sum()), rows=float(same.numel()))
-    assert float((~same).float().mean()) < 1e-3        # only exact-tie rows may differ (none expected)
+    assert float((~same).float().mean()) < 1e-3        # only exact-tie rows may differ
+    import numpy as np
+    from oracle import bruteforce as BF
+    for gi in torch.nonzero((~same).any(dim=1)).flatten().tolist():
+        srt = np.sort(BF.knn_window_d2(x_ref[gi].reshape(3, 5, hs, ws).numpy(), 5), axis=0)
+        for n in torch.nonzero(~same[gi]).flatten().tolist():
+            assert srt[15, n] == srt[16, n], "neighbour sets differ without a tie at the 16th rank"
 
     net = net.to(dev).train()
     with torch.no_grad():
