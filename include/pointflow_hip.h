@@ -123,13 +123,15 @@ int pf_resize_bilinear_f32(const float* in, float* out, int64_t P, int64_t IH, i
  * (one scene): for the 5 hypotheses depth + i*interval, i=-2..2: un-project the pixel centres of the
  * (h,w) flow grid, project into every view, bilinear-fetch the three (already resized to (h,w)) pyramid
  * levels maps1/2/3 (V,c_l,h,w), variance over views, append (world-mean)/std repeated 8x.
- * depth_in (dh,dw) is nearest-resized to (h,w) on the fly (model.py:153-158).
+ * depth_in (dh,dw) is nearest-resized to (h,w) on the fly (model.py:153-158).  `interval` is a DEVICE pointer
+ * to the hypothesis spacing (one float): scene constants live in device memory so that a captured
+ * hipGraph of the whole forward can be replayed on a new scene by refreshing small buffers.
  * Points are written in SUB-GRID-MAJOR order for the test-mode tiling of model.py:231-267
  * (ratio r, G = r*r groups, Ng = 5*(h/r)*(w/r) points each; group g=(y%r)*r+(x%r), local index
  * d*(h/r)*(w/r) + (y/r)*(w/r) + (x/r)); r = 1 gives the plain (5,h,w) lattice.
  *   feature (G, c1+c2+c3+24, Ng)    xyz (G, 3, Ng) */
 int pf_flow_features_f32(const float* maps1, const float* maps2, const float* maps3, int c1, int c2, int c3,
-                         int V, int h, int w, const float* depth_in, int dh, int dw, float interval,
+                         int V, int h, int w, const float* depth_in, int dh, int dw, const float* interval,
                          const float* cam, int ratio, float* feature, float* xyz, void* stream);
 
 /* ---- rows E0/E1/E2/M building blocks ----------------------------------------------------------
@@ -194,7 +196,7 @@ int pf_channel_affine_f32(const float* x, float* y, const float* scale, const fl
  * back in image order (undoing the sub-grid-major point order, model.py:256-266).
  * flow_prob (5,h,w), depth_out (h,w). */
 int pf_flow_head_f32(const float* Z, int64_t ldz, const float* scale, const float* shift, int ld_affine,
-                     const float* w_out, const float* depth_in, int dh, int dw, float interval, int h,
+                     const float* w_out, const float* depth_in, int dh, int dw, const float* interval, int h,
                      int w, int ratio, float* flow_prob, float* depth_out, void* stream);
 
 /* ---- row S : soft-argmin + probability map -----------------------------------------------------

@@ -28,7 +28,7 @@ PROTOTYPES = {
     "pf_fetch_backward_f32": ([_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp], _i),
     "pf_fetch_variance_f32": ([_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i, _vp], _i),
     "pf_resize_bilinear_f32": ([_vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp], _i),
-    "pf_flow_features_f32": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _f, _vp, _i, _vp, _vp, _vp], _i),
+    "pf_flow_features_f32": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp], _i),
     "pf_stat_blocks": ([_i, _i], _i),
     "pf_gemm_blocks": ([_i, _i], _i),
     "pf_pointwise_gemm_f32": ([_vp, _i, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp], _i),
@@ -38,7 +38,7 @@ PROTOTYPES = {
     "pf_edge_stats_f32": ([_vp, _i64, _i, _vp, _i, _i, _i, _vp, _vp], _i),
     "pf_bn_finalize_f32": ([_vp, _i, _i, _i, _i, _d, _d, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _i, _vp], _i),
     "pf_edge_apply_f32": ([_vp, _i64, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _i64, _vp], _i),
-    "pf_flow_head_f32": ([_vp, _i64, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _i, _i, _i, _vp, _vp, _vp], _i),
+    "pf_flow_head_f32": ([_vp, _i64, _vp, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp], _i),
     "pf_softargmin_prob_f32": ([_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp], _i),
 }
 

@@ -418,7 +418,8 @@ __global__ __launch_bounds__(256) void flow_head_kernel(const float* __restrict_
                                                         const float* __restrict__ shift, int ld_affine,
                                                         const float* __restrict__ w_out,
                                                         const float* __restrict__ depth_in, int dh, int dw,
-                                                        float interval, int h, int w, int ratio,
+                                                        const float* __restrict__ interval_p, int h, int w,
+                                                        int ratio,
                                                         float* __restrict__ flow_prob,
                                                         float* __restrict__ depth_out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -458,6 +459,7 @@ __global__ __launch_bounds__(256) void flow_head_kernel(const float* __restrict_
     den += e[d];
   }
   float flow = 0.0f;
+  const float interval = interval_p[0];
 #pragma unroll
   for (int d = 0; d < 5; ++d) {
     const float p = e[d] / den;
@@ -583,11 +585,11 @@ int pf_edge_apply_f32(const float* LE, int64_t ldle, int C, const int64_t* idx, 
 }
 
 int pf_flow_head_f32(const float* Z, int64_t ldz, const float* scale, const float* shift, int ld_affine,
-                     const float* w_out, const float* depth_in, int dh, int dw, float interval, int h, int w,
-                     int ratio, float* flow_prob, float* depth_out, void* stream) {
+                     const float* w_out, const float* depth_in, int dh, int dw, const float* interval, int h,
+                     int w, int ratio, float* flow_prob, float* depth_out, void* stream) {
   PF_REQUIRE(h >= 1 && w >= 1 && dh >= 1 && dw >= 1 && ratio >= 1 && h % ratio == 0 && w % ratio == 0);
   PF_REQUIRE(ldz >= 16 && (ldz % 4) == 0 && ld_affine >= 16 && (int64_t)h * w <= INT32_MAX);
-  PF_REQUIRE(Z && scale && shift && w_out && depth_in && flow_prob && depth_out);
+  PF_REQUIRE(Z && scale && shift && w_out && depth_in && interval && flow_prob && depth_out);
   dim3 grid((unsigned)pf_cdiv((int64_t)h * w, 256));
   hipLaunchKernelGGL(flow_head_kernel, grid, dim3(256), 0, (hipStream_t)stream, Z, ldz, scale, shift, ld_affine,
                      w_out, depth_in, dh, dw, interval, h, w, ratio, flow_prob, depth_out);

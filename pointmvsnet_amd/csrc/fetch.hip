@@ -153,7 +153,8 @@ __global__ __launch_bounds__(256) void flow_features_kernel(const float* __restr
                                                             const float* __restrict__ maps3, int c1, int c2,
                                                             int c3, int h, int w,
                                                             const float* __restrict__ depth_in, int dh, int dw,
-                                                            float interval, const float* __restrict__ cam,
+                                                            const float* __restrict__ interval_p,
+                                                            const float* __restrict__ cam,
                                                             int ratio, float* __restrict__ feature,
                                                             float* __restrict__ xyz) {
   const int hs = h / ratio, ws = w / ratio;
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(256) void flow_features_kernel(const float* __restr
   int sx = (int)floorf((float)x * scx);
   sy = sy > dh - 1 ? dh - 1 : sy;
   sx = sx > dw - 1 ? dw - 1 : sx;
-  const float depth = depth_in[sy * dw + sx] + interval * (float)(d - 2);
+  const float depth = depth_in[sy * dw + sx] + interval_p[0] * (float)(d - 2);
 
   // un-projection (model.py:165-178)
   const float* Ki = cam + PF_CAM_KREF_INV;
@@ -353,13 +354,13 @@ int pf_resize_bilinear_f32(const float* in, float* out, int64_t P, int64_t IH, i
 }
 
 int pf_flow_features_f32(const float* maps1, const float* maps2, const float* maps3, int c1, int c2, int c3,
-                         int V, int h, int w, const float* depth_in, int dh, int dw, float interval,
+                         int V, int h, int w, const float* depth_in, int dh, int dw, const float* interval,
                          const float* cam, int ratio, float* feature, float* xyz, void* stream) {
   PF_REQUIRE(c1 >= 0 && c2 >= 0 && c3 >= 0 && V >= 1 && h >= 1 && w >= 1 && dh >= 1 && dw >= 1 && ratio >= 1);
   PF_REQUIRE(h % ratio == 0 && w % ratio == 0);
   PF_REQUIRE(ratio * ratio <= 65535);
   if (V > PF_MAX_VIEWS) return PF_ERR_UNSUPPORTED;
-  PF_REQUIRE(maps1 && maps2 && maps3 && depth_in && cam && feature && xyz);
+  PF_REQUIRE(maps1 && maps2 && maps3 && depth_in && interval && cam && feature && xyz);
   const int64_t Ng = (int64_t)5 * (h / ratio) * (w / ratio);
   dim3 grid((unsigned)pf_cdiv(Ng, 256), (unsigned)(ratio * ratio));
   return dispatch_views(V, [&](auto vtag) {

@@ -65,8 +65,9 @@ class _Cameras(object):
         K[:, :, :2, :3] *= image_scale if self.is_test else (4 * image_scale)
         return K
 
-    def packed(self, K_flow, mean, std):
-        """(B, 27 + 21 V) float32 block in the layout of include/pointflow_hip.h (PF_CAM_*)."""
+    def packed(self, K_flow, mean, std, interval=None):
+        """(B, 27 + 21 V + 1) float32: the PF_CAM_* block of include/pointflow_hip.h followed by the
+        hypothesis interval of this PointFlow iteration (read by the kernels through a device pointer)."""
         B, V = K_flow.shape[:2]
         kinv = torch.inverse(K_flow[:, 0])
         rows = []
@@ -76,8 +77,82 @@ class _Cameras(object):
             for v in range(V):
                 parts.append(K_flow[b, v].reshape(-1))
                 parts.append(self.ext[b, v].reshape(-1))
+            parts.append(torch.zeros(1) if interval is None else interval[b].reshape(1))
             rows.append(torch.cat(parts))
         return torch.stack(rows).float().contiguous()
+
+
+class ScenePlan(object):
+    """Every host-derived constant of one forward, in ONE pinned host block mirrored by ONE device block.
+
+    ``update_(data_batch)`` redoes the camera algebra on the host (same ATen-CPU calls as the reference)
+    and refreshes the device block with a single asynchronous copy; ``PointMVSNet.run(plan, imgs)`` then
+    touches the device only.  That split is what makes the whole forward capturable in a hipGraph and
+    replayable on a new scene (pointmvsnet_amd/graph.py), and it replaces ~45 tiny pageable H2D copies per
+    depth map by one."""
+
+    def __init__(self, device, B, V, H, W, img_scales, inter_scales, is_test, num_depth):
+        self.device, self.B, self.V, self.H, self.W = device, B, V, H, W
+        self.img_scales, self.inter_scales = tuple(img_scales), tuple(inter_scales)
+        self.is_test, self.D = bool(is_test), int(num_depth)
+        for s in self.img_scales:
+            if is_test and s not in (0.125, 0.25, 0.5, 1.0):
+                raise NotImplementedError
+        P = 27 + 21 * V + 1
+        self._layout = {}
+        off = 0
+        for name, shape in [("K_coarse", (B, V, 3, 3)), ("ext", (B, V, 3, 4)), ("Kinv0", (B, 1, 3, 3)),
+                            ("Rinv0", (B, 1, 3, 3)), ("t0", (B, 1, 3, 1)), ("depths", (B, self.D)),
+                            ("sa_params", (B, 3))] + [("pack%d" % i, (B, P)) for i in range(len(self.img_scales))]:
+            n = 1
+            for d in shape:
+                n *= d
+            n_pad = (n + 3) // 4 * 4                       # keep every slice 16-byte aligned
+            self._layout[name] = (off, n, shape)
+            off += n_pad
+        self.host = torch.zeros(off, dtype=torch.float32)
+        if torch.cuda.is_available():
+            self.host = self.host.pin_memory()
+        self.dev = torch.zeros(off, dtype=torch.float32, device=device)
+        self._copied = None
+
+    def _h(self, name):
+        off, n, shape = self._layout[name]
+        return self.host[off:off + n].view(shape)
+
+    def d(self, name):
+        off, n, shape = self._layout[name]
+        return self.dev[off:off + n].view(shape)
+
+    def matches(self, device, B, V, H, W, img_scales, inter_scales, is_test, num_depth):
+        return (self.device == device and (self.B, self.V, self.H, self.W) == (B, V, H, W)
+                and self.img_scales == tuple(img_scales) and self.inter_scales == tuple(inter_scales)
+                and self.is_test == bool(is_test) and self.D == int(num_depth))
+
+    def update_(self, data_batch):
+        cam = _Cameras(_host_cams(data_batch), self.is_test)
+        if cam.num_depth != self.D:
+            raise RuntimeError("ScenePlan: num_depth changed (%d -> %d); build a new plan" % (self.D, cam.num_depth))
+        mean_h = data_batch["mean_host"] if "mean_host" in data_batch else data_batch["mean"].detach().cpu()
+        std_h = data_batch["std_host"] if "std_host" in data_batch else data_batch["std"].detach().cpu()
+        mean_h, std_h = mean_h.float(), std_h.float()
+        if self._copied is not None:
+            self._copied.synchronize()                     # the previous async copy has left the pinned block
+        self._h("K_coarse").copy_(cam.K_coarse)
+        self._h("ext").copy_(cam.ext)
+        self._h("Kinv0").copy_(torch.inverse(cam.K_coarse[:, 0]).unsqueeze(1))
+        self._h("Rinv0").copy_(cam.R_inv[:, 0:1])
+        self._h("t0").copy_(cam.t[:, 0:1])
+        for b in range(self.B):
+            self._h("depths")[b].copy_(torch.linspace(float(cam.depth_start[b]), float(cam.depth_end[b]), self.D))
+        self._h("sa_params").copy_(torch.stack([cam.depth_start, cam.depth_end, cam.depth_interval], dim=1))
+        for i, (s, inter) in enumerate(zip(self.img_scales, self.inter_scales)):
+            self._h("pack%d" % i).copy_(cam.packed(cam.flow_intrinsics(s), mean_h, std_h, inter * cam.depth_interval))
+        self.dev.copy_(self.host, non_blocking=True)
+        if self.dev.is_cuda:
+            self._copied = torch.cuda.Event()
+            self._copied.record()
+        return self
 
 
 class PointMVSNet(nn.Module):
@@ -94,6 +169,7 @@ class PointMVSNet(nn.Module):
             nn.Conv1d(flow_channels[-2], flow_channels[-1], 1, bias=False),
         )
         self._grid_cache = {}
+        self._plan = None
 
     # ------------------------------------------------------------------------------------------
     def _pixel_grid(self, h, w, device):
@@ -106,32 +182,89 @@ class PointMVSNet(nn.Module):
         return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
 
     # ------------------------------------------------------------------------------------------
+    def make_plan(self, data_batch, img_scales, inter_scales, isTest):
+        """Allocate the constant blocks for this shape of problem and fill them from ``data_batch``."""
+        img_list = data_batch["img_list"]
+        B, V, _, H, W = img_list.shape
+        D = int(_host_cams(data_batch)[0, 0, 1, 3, 2].long())
+        plan = ScenePlan(img_list.device, B, V, H, W, img_scales, inter_scales, isTest, D)
+        return plan.update_(data_batch)
+
     def forward(self, data_batch, img_scales, inter_scales, isFlow, isTest=False):
         img_list = data_batch["img_list"]
         if not img_list.is_cuda:
             raise RuntimeError("pointmvsnet_amd.PointMVSNet runs on a GPU (HIP) device only; the CPU "
                                "restatement lives in oracle/ and is test infrastructure")
+        if self._needs_graph():
+            return self._forward_autograd(data_batch, img_scales, inter_scales, isFlow, isTest)
+        B, V, _, H, W = img_list.shape
+        D = int(_host_cams(data_batch)[0, 0, 1, 3, 2].long())
+        plan = self._plan
+        if plan is None or not plan.matches(img_list.device, B, V, H, W, img_scales, inter_scales, isTest, D):
+            plan = self._plan = ScenePlan(img_list.device, B, V, H, W, img_scales, inter_scales, isTest, D)
+        plan.update_(data_batch)
+        return self.run(plan, img_list, isFlow)
+
+    def run(self, plan, img_list, isFlow=True):
+        """Device-only inference forward (capturable in a hipGraph): fused HIP pipeline, SURVEY.md section 8."""
+        B, V, H, W, D = plan.B, plan.V, plan.H, plan.W, plan.D
+        dev = img_list.device
+        preds = collections.OrderedDict()
+
+        # ---- coarse stage (reference model.py:71-130) -----------------------------------------
+        feature_list = self.coarse_img_conv.forward_views(img_list)["conv3"].contiguous()   # (B,V,C,FH,FW)
+        C, FH, FW = feature_list.shape[2:]
+        grid = self._pixel_grid(FH, FW, dev).view(1, 1, 3, -1).expand(B, 1, 3, -1)
+        uv = torch.matmul(plan.d("Kinv0"), grid)
+        cam_points = (uv.unsqueeze(3) * plan.d("depths").view(B, 1, 1, D, 1)).view(B, 1, 3, -1)
+        world_points = torch.matmul(plan.d("Rinv0"), cam_points - plan.d("t0")).transpose(1, 2).contiguous() \
+            .view(B, 3, -1)
+        preds["world_points"] = world_points
+        cost = fetch_variance(feature_list, world_points, plan.d("K_coarse"), plan.d("ext"), ref_override=True)
+        filtered = self.coarse_vol_conv.forward_fused(cost.view(B, C, D, FH, FW)).squeeze(1)   # (B,D,FH,FW)
+        pred_depth, prob_map = pointflow.soft_argmin_params(filtered, plan.d("sa_params"))
+        preds["coarse_depth_map"] = pred_depth
+        preds["coarse_prob_map"] = prob_map
+        if not isFlow:
+            pointflow.flush_counters()
+            return preds
+
+        # ---- flow stage (reference model.py:132-303) --------------------------------------------
+        names = ("conv1", "conv2", "conv3")
+        pyramids = self.flow_img_conv.forward_views(img_list)
+        for it, img_scale in enumerate(plan.img_scales):
+            h, w = int(H * img_scale), int(W * img_scale)
+            ratio = int(img_scale * 8) if (plan.is_test and img_scale != 0.125) else 1
+            packed = plan.d("pack%d" % it)
+            outs, probs = [], []
+            for b in range(B):
+                pyr_b = [pyramids[n][b].contiguous() for n in names]
+                d_b, p_b = pointflow.flow_iteration(pyr_b, pred_depth[b, 0], packed[b, -1:], packed[b], h, w, ratio,
+                                                    self.flow_edge_conv, self.flow_mlp, k=self.k)
+                outs.append(d_b)
+                probs.append(p_b)
+            pred_depth = torch.stack(outs, dim=0).unsqueeze(1) if B > 1 else outs[0].view(1, 1, h, w)
+            flow_prob = torch.stack(probs, dim=0) if B > 1 else probs[0].unsqueeze(0)
+            preds["flow{}_prob".format(it + 1)] = flow_prob
+            preds["flow{}".format(it + 1)] = pred_depth
+        pointflow.flush_counters()
+        return preds
+
+    # ------------------------------------------------------------------------------------------
+    def _forward_autograd(self, data_batch, img_scales, inter_scales, isFlow, isTest):
+        """Training path: the reference composition on differentiable HIP operators (model.py:45-305)."""
+        img_list = data_batch["img_list"]
         cam = _Cameras(_host_cams(data_batch), isTest)
-        graph = self._needs_graph()
         dev = img_list.device
         B, V, _, H, W = img_list.shape
         preds = collections.OrderedDict()
-
         K_coarse = cam.K_coarse.to(dev)
         ext = cam.ext.to(dev)
-        mean_h = data_batch["mean_host"] if "mean_host" in data_batch else data_batch["mean"].detach().cpu()
-        std_h = data_batch["std_host"] if "std_host" in data_batch else data_batch["std"].detach().cpu()
-        mean_h, std_h = mean_h.float(), std_h.float()
 
-        # ---- coarse stage (reference model.py:71-130) -----------------------------------------
-        if graph:
-            coarse_maps = [self.coarse_img_conv(img_list[:, v])["conv3"] for v in range(V)]
-            feature_list = torch.stack(coarse_maps, dim=1)                   # (B,V,C,FH,FW)
-        else:
-            feature_list = self.coarse_img_conv.forward_views(img_list)["conv3"].contiguous()
+        coarse_maps = [self.coarse_img_conv(img_list[:, v])["conv3"] for v in range(V)]
+        feature_list = torch.stack(coarse_maps, dim=1)                       # (B,V,C,FH,FW)
         C, FH, FW = feature_list.shape[2:]
         D = cam.num_depth
-
         depths = torch.stack([torch.linspace(float(cam.depth_start[b]), float(cam.depth_end[b]), D)
                               for b in range(B)], dim=0).to(dev)            # (B,D)
         grid = self._pixel_grid(FH, FW, dev).view(1, 1, 3, -1).expand(B, 1, 3, -1)
@@ -142,67 +275,38 @@ class PointMVSNet(nn.Module):
         world_points = torch.matmul(R_inv0, cam_points - t0).transpose(1, 2).contiguous().view(B, 3, -1)
         preds["world_points"] = world_points
 
-        if graph:
-            point_features = self.feature_fetcher(feature_list, world_points, K_coarse, ext)
-            ref = coarse_maps[0].unsqueeze(2).expand(-1, -1, D, -1, -1).contiguous().view(B, C, -1)
-            point_features = torch.cat([ref.unsqueeze(1), point_features[:, 1:]], dim=1)
-            avg = point_features.mean(dim=1)
-            cost = (point_features ** 2).mean(dim=1) - avg ** 2
-        else:
-            cost = fetch_variance(feature_list, world_points, K_coarse, ext, ref_override=True)
-        cost_volume = cost.view(B, C, D, FH, FW)
-        vol = self.coarse_vol_conv if graph else self.coarse_vol_conv.forward_fused
-        filtered = vol(cost_volume).squeeze(1)                               # (B,D,FH,FW)
+        point_features = self.feature_fetcher(feature_list, world_points, K_coarse, ext)
+        ref = coarse_maps[0].unsqueeze(2).expand(-1, -1, D, -1, -1).contiguous().view(B, C, -1)
+        point_features = torch.cat([ref.unsqueeze(1), point_features[:, 1:]], dim=1)
+        avg = point_features.mean(dim=1)
+        cost = (point_features ** 2).mean(dim=1) - avg ** 2
+        filtered = self.coarse_vol_conv(cost.view(B, C, D, FH, FW)).squeeze(1)
 
         d_start = cam.depth_start.to(dev)
-        d_end = cam.depth_end.to(dev)
         d_int = cam.depth_interval.to(dev)
-        if graph:
-            prob_volume = F.softmax(-filtered, dim=1)
-            pred_depth = torch.sum(depths.view(B, D, 1, 1) * prob_volume, dim=1).unsqueeze(1)
-            prob_map = get_propability_map(prob_volume, pred_depth, d_start, d_int)
-        else:
-            pred_depth, prob_map = pointflow.soft_argmin_prob(filtered, d_start, d_end, d_int)
+        prob_volume = F.softmax(-filtered, dim=1)
+        pred_depth = torch.sum(depths.view(B, D, 1, 1) * prob_volume, dim=1).unsqueeze(1)
         preds["coarse_depth_map"] = pred_depth
-        preds["coarse_prob_map"] = prob_map
+        preds["coarse_prob_map"] = get_propability_map(prob_volume, pred_depth, d_start, d_int)
         if not isFlow:
-            pointflow.flush_counters()
             return preds
 
-        # ---- flow stage (reference model.py:132-303) --------------------------------------------
         names = ("conv1", "conv2", "conv3")
-        if graph:
-            per_view = [self.flow_img_conv(img_list[:, v]) for v in range(V)]
-            pyramids = {n: torch.stack([pv[n] for pv in per_view], dim=1) for n in names}   # (B,V,c,h_l,w_l)
-        else:
-            pyramids = self.flow_img_conv.forward_views(img_list)
+        per_view = [self.flow_img_conv(img_list[:, v]) for v in range(V)]
+        pyramids = {n: torch.stack([pv[n] for pv in per_view], dim=1) for n in names}   # (B,V,c,h_l,w_l)
         if isTest:
             pyramids = {n: p.detach() for n, p in pyramids.items()}
-
         for it, (img_scale, inter_scale) in enumerate(zip(img_scales, inter_scales)):
             if isTest:
                 pred_depth = pred_depth.detach()
-            interval_h = inter_scale * cam.depth_interval                   # (B,) float32 on the host
+                if img_scale not in (0.125, 0.25, 0.5, 1.0):
+                    raise NotImplementedError
+            interval = (inter_scale * cam.depth_interval).to(dev)
             h, w = int(H * img_scale), int(W * img_scale)
-            K_flow = cam.flow_intrinsics(img_scale)
-            if isTest and img_scale not in (0.125, 0.25, 0.5, 1.0):
-                raise NotImplementedError
             ratio = int(img_scale * 8) if (isTest and img_scale != 0.125) else 1
-            if graph:
-                pred_depth, flow_prob = self._point_flow_autograd(
-                    pyramids, pred_depth, interval_h.to(dev), K_flow.to(dev), ext, cam, data_batch, h, w, ratio)
-            else:
-                packed = cam.packed(K_flow, mean_h, std_h).to(dev)
-                outs, probs = [], []
-                for b in range(B):
-                    pyr_b = [pyramids[n][b].contiguous() for n in names]
-                    d_b, p_b = pointflow.flow_iteration(pyr_b, pred_depth[b, 0].contiguous(),
-                                                        float(interval_h[b]), packed[b], h, w, ratio,
-                                                        self.flow_edge_conv, self.flow_mlp, k=self.k)
-                    outs.append(d_b)
-                    probs.append(p_b)
-                pred_depth = torch.stack(outs, dim=0).unsqueeze(1)
-                flow_prob = torch.stack(probs, dim=0)
+            pred_depth, flow_prob = self._point_flow_autograd(
+                pyramids, pred_depth, interval, cam.flow_intrinsics(img_scale).to(dev), ext, cam, data_batch, h, w,
+                ratio)
             preds["flow{}_prob".format(it + 1)] = flow_prob
             preds["flow{}".format(it + 1)] = pred_depth
         pointflow.flush_counters()

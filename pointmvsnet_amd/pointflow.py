@@ -24,9 +24,25 @@ def stat_blocks(G, Ng):
     return int(_lib.load().pf_stat_blocks(int(G), int(Ng)))
 
 
+_pack_cache = {}
+
+
 def pack_weight_t(*convs):
     """Stack 1x1 conv weights (Cout_i, K, 1) along the output axis, transpose to (K, Nc) row-major and
-    zero-pad Nc to a multiple of 32 (MFMA column tiles).  Returns (Wt, Cout_total)."""
+    zero-pad Nc to a multiple of 32 (MFMA column tiles).  Returns (Wt, Cout_total).  Cached per
+    (storage, version) of the parameters, so inference re-packs nothing."""
+    key = tuple((c.data_ptr(), c._version, tuple(c.shape)) for c in convs)
+    hit = _pack_cache.get(key)
+    if hit is not None:
+        return hit
+    if len(_pack_cache) > 256:
+        _pack_cache.clear()
+    out = _pack_weight_t(*convs)
+    _pack_cache[key] = out
+    return out
+
+
+def _pack_weight_t(*convs):
     w = torch.cat([c.reshape(c.shape[0], c.shape[1]) for c in convs], dim=0).detach().to(_F32)
     cout, K = w.shape
     nc = (cout + 31) // 32 * 32
@@ -202,8 +218,8 @@ def resize_maps(maps, h, w):
 
 
 def flow_features(levels, depth, interval, cam, h, w, ratio):
-    """Row F.  levels: three (V,c,h,w) maps; depth (dh,dw); cam: packed camera block (device float32).
-    Returns feature (G, 136, Ng) and xyz (G, 3, Ng) in sub-grid-major order."""
+    """Row F.  levels: three (V,c,h,w) maps; depth (dh,dw); interval: 1-element device tensor; cam: packed
+    camera block (device float32).  Returns feature (G, 136, Ng) and xyz (G, 3, Ng), sub-grid-major."""
     V = levels[0].shape[0]
     c1, c2, c3 = (int(l.shape[1]) for l in levels)
     G = ratio * ratio
@@ -213,7 +229,7 @@ def flow_features(levels, depth, interval, cam, h, w, ratio):
     xyz = torch.empty((G, 3, Ng), dtype=_F32, device=dev)
     _lib.call("pf_flow_features_f32",
               _lib.ptr(levels[0]), _lib.ptr(levels[1]), _lib.ptr(levels[2]), c1, c2, c3, V, h, w, _lib.ptr(depth),
-              int(depth.shape[-2]), int(depth.shape[-1]), float(interval), _lib.ptr(cam), int(ratio),
+              int(depth.shape[-2]), int(depth.shape[-1]), _lib.ptr(interval), _lib.ptr(cam), int(ratio),
               _lib.ptr(feature), _lib.ptr(xyz), _lib.stream(),
               algo_bytes=4.0 * V * (c1 + c2 + c3) * h * w + 4.0 * G * Ng * (c1 + c2 + c3 + 24 + 3) + 4.0 * h * w)
     return feature, xyz
@@ -257,7 +273,7 @@ def flow_chain(feature, xyz, depth, interval, h, w, ratio, edge_convs, flow_mlp,
     flow_prob = torch.empty((5, h, w), dtype=_F32, device=dev)
     w_out = last.weight.detach().reshape(-1).to(_F32).contiguous()
     _lib.call("pf_flow_head_f32", _lib.ptr(X), ldx, _lib.ptr(affine[0]), _lib.ptr(affine[1]), 16,
-              _lib.ptr(w_out), _lib.ptr(depth), int(depth.shape[-2]), int(depth.shape[-1]), float(interval), h, w,
+              _lib.ptr(w_out), _lib.ptr(depth), int(depth.shape[-2]), int(depth.shape[-1]), _lib.ptr(interval), h, w,
               ratio, _lib.ptr(flow_prob), _lib.ptr(depth_out), _lib.stream(),
               algo_bytes=4.0 * G * Ng * 16 + 4.0 * h * w * 7)
     return depth_out, flow_prob
@@ -267,7 +283,7 @@ def flow_iteration(pyramid, depth, interval, cam, h, w, ratio, edge_convs, flow_
     """One PointFlow refinement of one scene (reference model.py:150-295 for batch item b).
 
     pyramid: three contiguous (V,c,H_l,W_l) feature maps of this scene; depth: (dh,dw) prior depth map;
-    interval: float hypothesis spacing; cam: packed camera block for this scale.
+    interval: 1-element device tensor (hypothesis spacing); cam: packed camera block for this scale.
     Returns (depth_out (h,w), flow_prob (5,h,w))."""
     levels = [resize_maps(m, h, w) for m in pyramid]
     feature, xyz = flow_features(levels, depth, interval, cam, h, w, ratio)
@@ -277,9 +293,14 @@ def flow_iteration(pyramid, depth, interval, cam, h, w, ratio, edge_convs, flow_
 def soft_argmin_prob(cost, depth_start, depth_end, depth_interval):
     """Row S: cost (B,D,H,W) filtered volume -> depth (B,1,H,W), prob (B,1,H,W).
     depth_start/end/interval: (B,) float32 tensors on the same device."""
+    return soft_argmin_params(cost, torch.stack([depth_start, depth_end, depth_interval], dim=1).to(_F32))
+
+
+def soft_argmin_params(cost, params):
+    """Row S with params (B,3) = (depth_start, depth_end, depth_interval) already on the device."""
     B, D, H, W = cost.shape
     cost = cost.contiguous()
-    params = torch.stack([depth_start, depth_end, depth_interval], dim=1).to(_F32).contiguous()
+    params = params.contiguous()
     depth = torch.empty((B, 1, H, W), dtype=_F32, device=cost.device)
     prob = torch.empty((B, 1, H, W), dtype=_F32, device=cost.device)
     _lib.call("pf_softargmin_prob_f32", _lib.ptr(cost), _lib.ptr(params), _lib.ptr(depth), _lib.ptr(prob),

@@ -153,3 +153,25 @@ def test_reference_model_py_runs_unchanged_on_our_operators(dev):
         preds = net({k: v.to(dev) for k, v in data.items()}, img_scales, inter_scales, isFlow=True, isTest=True)
     rel = float(((preds["flow2"].cpu() - g["flow2"]).abs() / g["flow2"]).max())
     assert rel < 1e-3      # modern grid_sample default differs from the pinned one (F7): loose bound only
+
+
+def test_graphed_forward_matches_eager_and_replays_on_new_scenes(dev):
+    from pointmvsnet_amd.graph import GraphedForward
+    data_a, img_scales, inter_scales = synthetic.make_config("tiny", seed=0)
+    data_b, _, _ = synthetic.make_config("tiny", seed=7)
+    eager = _model(dev)
+    graphed_net = _model(dev)
+    with torch.no_grad():
+        want_a = eager(_to(data_a, dev), img_scales, inter_scales, isFlow=True, isTest=True)
+        want_b = eager(_to(data_b, dev), img_scales, inter_scales, isFlow=True, isTest=True)
+        g = GraphedForward(graphed_net, _to(data_a, dev), img_scales, inter_scales, warmup=1)
+        got_a = {k: v.clone() for k, v in g(_to(data_a, dev)).items()}
+        got_b = {k: v.clone() for k, v in g(_to(data_b, dev)).items()}
+    for key in ("coarse_depth_map", "flow1", "flow2", "flow2_prob"):
+        # batch statistics do not depend on the running statistics, so replays equal eager bit for bit
+        assert torch.equal(got_a[key], want_a[key]), key
+        assert torch.equal(got_b[key], want_b[key]), key
+    assert not torch.equal(got_a["flow2"], got_b["flow2"])
+    # warm-up (1) + capture (1: capture itself does not execute) + 2 replays worth of BN updates
+    nbt = int(graphed_net.flow_mlp[0][0].bn.num_batches_tracked)
+    assert nbt == (1 + 2) * 5, nbt

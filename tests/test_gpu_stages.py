@@ -58,9 +58,9 @@ def test_flow_iteration_stagewise_vs_oracle(dev, cfg, it):
 
     # ---- stage F: feature assembly on the oracle's pyramids and prior depth -----------------------
     cam = _Cameras(cams, True)
-    packed = cam.packed(cam.flow_intrinsics(s), data["mean"], data["std"]).to(dev)
+    packed = cam.packed(cam.flow_intrinsics(s), data["mean"], data["std"], interval).to(dev)
     levels = [pointflow.resize_maps(pyr[n][0].to(dev).contiguous(), h, w) for n in ("conv1", "conv2", "conv3")]
-    f_gpu, x_gpu = pointflow.flow_features(levels, prior[0, 0].to(dev).contiguous(), float(interval[0]),
+    f_gpu, x_gpu = pointflow.flow_features(levels, prior[0, 0].to(dev).contiguous(), packed[0, -1:],
                                            packed[0], h, w, ratio)
     hs, ws = h // ratio, w // ratio
     # oracle tensors re-ordered to the sub-grid-major layout: (C,5,hs,r,ws,r) -> (r,r,C,5,hs,ws)
@@ -92,7 +92,7 @@ def test_flow_iteration_stagewise_vs_oracle(dev, cfg, it):
 
     net = net.to(dev).train()
     with torch.no_grad():
-        d_gpu, p_gpu = pointflow.flow_chain(f_in, x_in, prior[0, 0].to(dev).contiguous(), float(interval[0]), h, w,
+        d_gpu, p_gpu = pointflow.flow_chain(f_in, x_in, prior[0, 0].to(dev).contiguous(), packed[0, -1:], h, w,
                                             ratio, net.flow_edge_conv, net.flow_mlp, k=16)
         # the oracle on the same tensors (sub-grids sequential, model.py:231-267)
         flow = torch.zeros(1, 1, hs, ratio, ws, ratio)

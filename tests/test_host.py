@@ -45,9 +45,11 @@ def test_camera_pack_layout_matches_header():
     data, _, _ = synthetic.make_config("tiny")
     cam = _Cameras(data["cam_params_list"], True)
     K = cam.flow_intrinsics(0.25)
-    pack = cam.packed(K, data["mean"], data["std"])
+    interval = 0.75 * cam.depth_interval
+    pack = cam.packed(K, data["mean"], data["std"], interval)
     V = 3
-    assert pack.shape == (1, 27 + 21 * V)
+    assert pack.shape == (1, 27 + 21 * V + 1)           # PF_CAM_FLOATS(V) + the hypothesis interval
+    assert torch.equal(pack[0, -1], interval[0])
     assert torch.allclose(pack[0, 0:9].view(3, 3) @ K[0, 0], torch.eye(3), atol=1e-4)
     assert torch.equal(pack[0, 18:21], cam.t[0, 0].reshape(-1))
     assert torch.equal(pack[0, 21:24], data["mean"][0]) and torch.equal(pack[0, 24:27], data["std"][0])
@@ -60,6 +62,24 @@ def test_camera_pack_layout_matches_header():
     assert torch.isclose(cam.K_coarse[0, 0, 0, 0], raw / 8.0)
     assert torch.isclose(_Cameras(data["cam_params_list"], False).K_coarse[0, 0, 0, 0], raw / 2.0)
     assert torch.isclose(_Cameras(data["cam_params_list"], False).flow_intrinsics(0.25)[0, 0, 0, 0], raw)
+
+
+def test_scene_plan_blocks_are_one_aligned_buffer():
+    from pointmvsnet_amd.model import ScenePlan
+    data, scales, inters = synthetic.make_config("tiny")
+    plan = ScenePlan(torch.device("cpu"), 1, 3, 128, 192, scales, inters, True, 8).update_(data)
+    cam = _Cameras(data["cam_params_list"], True)
+    assert torch.equal(plan.d("K_coarse"), cam.K_coarse) and torch.equal(plan.d("ext"), cam.ext)
+    assert torch.equal(plan.d("depths")[0], torch.linspace(425.0, float(cam.depth_end[0]), 8))
+    assert torch.equal(plan.d("sa_params")[0], torch.stack([cam.depth_start[0], cam.depth_end[0], cam.depth_interval[0]]))
+    assert torch.equal(plan.d("pack1")[0, -1], (0.75 * cam.depth_interval)[0])
+    for name in ("K_coarse", "ext", "Kinv0", "Rinv0", "t0", "depths", "sa_params", "pack0", "pack1"):
+        assert plan.d(name).data_ptr() % 16 == 0
+    assert plan.matches(torch.device("cpu"), 1, 3, 128, 192, scales, inters, True, 8)
+    assert not plan.matches(torch.device("cpu"), 1, 3, 128, 192, scales, inters, False, 8)
+    other, _, _ = synthetic.make_config("tiny", seed=4)
+    plan.update_(other)
+    assert torch.equal(plan.d("ext"), _Cameras(other["cam_params_list"], True).ext)
 
 
 def test_operators_fail_loudly_without_gpu():
