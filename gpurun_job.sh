@@ -5,7 +5,7 @@ timeout 1500 python -m pytest tests -m gpu -q --timeout 600 > gpurun_out/pytest_
 echo "pytest exit $?" >> gpurun_out/pytest_gpu.log
 timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1
 echo "smoke exit $?" >> gpurun_out/smoke.log
-timeout 600 python bench.py --steps 20 --warmup 3 > gpurun_out/bench.log 2>&1
+timeout 600 python bench.py --steps 30 --warmup 3 > gpurun_out/bench.log 2>&1
 echo "bench exit $?" >> gpurun_out/bench.log
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp

@@ -111,13 +111,27 @@ class KernelTimer(object):
     def wants(self, name):
         return self.only is None or name == self.only
 
+    @staticmethod
+    def _pair_overhead_ms():
+        """Elapsed time of an EMPTY event pair on this stream (the floor every record below contains)."""
+        vals = []
+        for _ in range(21):
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            e1.record()
+            torch.cuda.synchronize()
+            vals.append(e0.elapsed_time(e1))
+        return sorted(vals)[len(vals) // 2]
+
     def summary(self):
         torch.cuda.synchronize()
+        floor = self._pair_overhead_ms()
         out = {}
         for name, e0, e1, nbytes in self.records:
-            s = out.setdefault(name, {"launches": 0, "ms": 0.0, "bytes": 0.0})
+            s = out.setdefault(name, {"launches": 0, "ms": 0.0, "bytes": 0.0, "event_floor_ms": floor})
             s["launches"] += 1
-            s["ms"] += e0.elapsed_time(e1)
+            s["ms"] += max(e0.elapsed_time(e1) - floor, 0.0005)
             s["bytes"] += float(nbytes or 0)
         return out
 

@@ -29,16 +29,23 @@ _pack_cache = {}
 
 def pack_weight_t(*convs):
     """Stack 1x1 conv weights (Cout_i, K, 1) along the output axis, transpose to (K, Nc) row-major and
-    zero-pad Nc to a multiple of 32 (MFMA column tiles).  Returns (Wt, Cout_total).  Cached per
-    (storage, version) of the parameters, so inference re-packs nothing."""
-    key = tuple((c.data_ptr(), c._version, tuple(c.shape)) for c in convs)
+    zero-pad Nc to a multiple of 32 (MFMA column tiles).  Returns (Wt, Cout_total).  Cached per parameter
+    OBJECT (weak reference) and version counter, so inference re-packs nothing and a recycled address or
+    an optimizer step can never serve a stale pack."""
+    import weakref
+    key = tuple(id(c) for c in convs)
     hit = _pack_cache.get(key)
     if hit is not None:
-        return hit
+        refs, versions, out = hit
+        if all(r() is c for r, c in zip(refs, convs)) and versions == tuple(c._version for c in convs):
+            return out
     if len(_pack_cache) > 256:
         _pack_cache.clear()
     out = _pack_weight_t(*convs)
-    _pack_cache[key] = out
+    try:
+        _pack_cache[key] = (tuple(weakref.ref(c) for c in convs), tuple(c._version for c in convs), out)
+    except TypeError:
+        pass
     return out
 
 
