@@ -189,6 +189,16 @@ int pf_channel_stats_f32(const float* x, int64_t N, int64_t C, int64_t S, double
 int pf_channel_affine_f32(const float* x, float* y, const float* scale, const float* shift, int64_t N, int64_t C,
                           int64_t S, int samples_per_stat, int relu, void* stream);
 
+/* ---- row R : 3x3x3 convolution of VolumeConv on the f32 matrix cores ---------------------------------
+ * Replaces nn.Conv3d(k=3, padding=1, stride 1|2, bias=False) inside the Conv3d blocks of reference
+ * networks.py:133-142 (nn/conv.py:108,115-121).  x (N,Cin,Di,Hi,Wi) NCDHW, Cin % 4 == 0, Cout <= 64;
+ * wp = weights packed on the host as (27 taps [kd][kh][kw], Cin, 16*ceil(Cout/16)) with zero padding;
+ * y (N,Cout,Do,Ho,Wo).  partials (N, pf_conv3d_blocks(Do,Ho,Wo), Cout, 2) float64 or NULL receives the
+ * per-block (sum, sum of squares) of y per channel -- the BatchNorm batch statistics for free. */
+int pf_conv3d_blocks(int64_t Do, int64_t Ho, int64_t Wo);
+int pf_conv3d_k3_f32(const float* x, const float* wp, float* y, int64_t N, int64_t Cin, int64_t Cout, int64_t Di,
+                     int64_t Hi, int64_t Wi, int stride, double* partials, void* stream);
+
 /* ---- rows M (last layer) + H + T : flow head ---------------------------------------------------
  * Z (G*Ng, ldz) holds the pre-BN output of the 64->16 MLP layer.  Per pixel of the (h,w) grid:
  * a = relu(Z*scale+shift); flow_d = sum_c w_out[c]*a_c for the 5 hypotheses; p = softmax(-flow);

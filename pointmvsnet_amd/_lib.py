@@ -32,6 +32,8 @@ PROTOTYPES = {
     "pf_stat_blocks": ([_i, _i], _i),
     "pf_gemm_blocks": ([_i, _i], _i),
     "pf_pointwise_gemm_f32": ([_vp, _i, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp], _i),
+    "pf_conv3d_blocks": ([_i64, _i64, _i64], _i),
+    "pf_conv3d_k3_f32": ([_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i, _vp, _vp], _i),
     "pf_norm_blocks": ([_i64], _i),
     "pf_channel_stats_f32": ([_vp, _i64, _i64, _i64, _vp, _vp], _i),
     "pf_channel_affine_f32": ([_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _vp], _i),
@@ -148,6 +150,7 @@ def call(name, *args, **kw):
     """Invoke C-ABI entry point ``name`` and raise on a non-zero return.  ``algo_bytes`` (keyword) is the
     algorithmic HBM byte count of this launch, used only by KernelTimer."""
     algo_bytes = kw.pop("algo_bytes", None)
+    kw.pop("flops", None)
     fn = getattr(load(), name)
     t = _timer
     if t is not None and t.wants(name):

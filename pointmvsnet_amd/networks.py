@@ -88,7 +88,17 @@ def _block_fused(block, x, samples_per_stat):
     the nn.conv blocks or a plain nn.ConvNd (no BN / ReLU)."""
     if not hasattr(block, "bn"):
         return block(x)
-    y = block._crop(block.conv(x), x)
+    conv = block.conv
+    training_bn = block.bn is not None and (block.bn.training or not block.bn.track_running_stats)
+    if (type(conv) is nn.Conv3d and conv.kernel_size == (3, 3, 3) and conv.padding == (1, 1, 1)
+            and conv.stride in ((1, 1, 1), (2, 2, 2)) and conv.dilation == (1, 1, 1) and conv.groups == 1
+            and conv.bias is None and conv.in_channels % 4 == 0 and conv.out_channels <= 64):
+        # row R on the f32 matrix cores; the BN batch statistics come out of the conv epilogue
+        y, partials = pointflow.conv3d_k3(x.contiguous(), conv.weight, conv.stride[0], training_bn)
+        if block.bn is not None:
+            return pointflow.batch_norm_act_(y, block.bn, block.relu, samples_per_stat, partials=partials)
+        return F.relu(y, inplace=True) if block.relu else y
+    y = block._crop(conv(x), x)
     if block.bn is not None:
         return pointflow.batch_norm_act_(y.contiguous(), block.bn, block.relu, samples_per_stat)
     return F.relu(y, inplace=True) if block.relu else y

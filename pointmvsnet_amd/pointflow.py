@@ -121,12 +121,49 @@ def eval_affine(bn, S, ld, ch0=0, C=None, out=None):
 # ---------------------------------------------------------------------------------------------
 # BatchNorm (+ReLU) for the conv stacks around the path (ImageConv / VolumeConv)
 # ---------------------------------------------------------------------------------------------
-def batch_norm_act_(x, bn, relu, samples_per_stat):
+def conv3d_k3(x, weight, stride, want_stats):
+    """3x3x3 / pad 1 conv3d on the f32 matrix cores (pf_conv3d_k3_f32).  Returns (y, partials or None)."""
+    N, Cin, Di, Hi, Wi = x.shape
+    Cout = weight.shape[0]
+    Do, Ho, Wo = (Di - 1) // stride + 1, (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
+    wp = pack_conv3d_weight(weight)
+    y = torch.empty((N, Cout, Do, Ho, Wo), dtype=_F32, device=x.device)
+    partials = None
+    if want_stats:
+        T = int(_lib.load().pf_conv3d_blocks(Do, Ho, Wo))
+        partials = torch.empty((N, T, Cout, 2), dtype=torch.float64, device=x.device)
+    _lib.call("pf_conv3d_k3_f32", _lib.ptr(x), _lib.ptr(wp), _lib.ptr(y), N, Cin, Cout, Di, Hi, Wi, int(stride),
+              _lib.ptr(partials), _lib.stream(),
+              algo_bytes=4.0 * N * (Cin * Di * Hi * Wi + Cout * Do * Ho * Wo) + 4.0 * 27 * Cin * Cout,
+              flops=2.0 * N * Do * Ho * Wo * 27 * Cin * Cout)
+    return y, partials
+
+
+def pack_conv3d_weight(weight):
+    """(Cout,Cin,3,3,3) -> (27, Cin, 16*ceil(Cout/16)) zero padded; cached like pack_weight_t."""
+    import weakref
+    key = ("c3", id(weight))
+    hit = _pack_cache.get(key)
+    if hit is not None and hit[0]() is weight and hit[1] == weight._version:
+        return hit[2]
+    cout, cin = weight.shape[:2]
+    ncp = (cout + 15) // 16 * 16
+    wp = torch.zeros((27, cin, ncp), dtype=_F32, device=weight.device)
+    wp[:, :, :cout] = weight.detach().to(_F32).permute(2, 3, 4, 1, 0).reshape(27, cin, cout)
+    try:
+        _pack_cache[key] = (weakref.ref(weight), weight._version, wp)
+    except TypeError:
+        pass
+    return wp
+
+
+def batch_norm_act_(x, bn, relu, samples_per_stat, partials=None):
     """In-place train/eval BatchNorm + optional ReLU on a contiguous (N,C,*spatial) conv output.
 
     ``samples_per_stat`` consecutive samples share one set of batch statistics == one reference module
     call (the reference runs each view through the tower separately, model.py:71-77, so views batched
-    along N keep per-view statistics and the running statistics are updated once per view, in order)."""
+    along N keep per-view statistics and the running statistics are updated once per view, in order).
+    ``partials``: per-block statistics already produced by the convolution's epilogue (N, T, C, 2)."""
     N, C = x.shape[:2]
     S = x[0, 0].numel()
     G = N // samples_per_stat
@@ -134,10 +171,11 @@ def batch_norm_act_(x, bn, relu, samples_per_stat):
     scale = torch.empty((G, C), dtype=_F32, device=dev)
     shift = torch.empty((G, C), dtype=_F32, device=dev)
     if bn.training or not bn.track_running_stats:
-        T = int(_lib.load().pf_norm_blocks(S))
-        partials = torch.empty((N, T, C, 2), dtype=torch.float64, device=dev)
-        _lib.call("pf_channel_stats_f32", _lib.ptr(x), N, C, S, _lib.ptr(partials), _lib.stream(),
-                  algo_bytes=4.0 * N * C * S)
+        if partials is None:
+            T = int(_lib.load().pf_norm_blocks(S))
+            partials = torch.empty((N, T, C, 2), dtype=torch.float64, device=dev)
+            _lib.call("pf_channel_stats_f32", _lib.ptr(x), N, C, S, _lib.ptr(partials), _lib.stream(),
+                      algo_bytes=4.0 * N * C * S)
         n = float(samples_per_stat) * S
         bn_affine(bn, partials, 0, C, n, n, N, samples_per_stat, scale, shift)
         bump_counter(bn, G)

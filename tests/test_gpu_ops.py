@@ -462,3 +462,28 @@ def test_volume_conv_fused_vs_reference(dev):
     err = _maxabs(y, g["y"])
     report("volume_conv_fused", err=err, scale=float(g["y"].abs().max()))
     assert err < 2e-4 * float(g["y"].abs().max())
+
+
+# ---------------------------------------------------------------------------------------------
+# row R: MFMA conv3d with fused BN statistics
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,Cin,Cout,D,H,W,stride", [(1, 64, 8, 8, 16, 24, 1), (1, 64, 16, 8, 16, 24, 2),
+                                                     (2, 16, 32, 5, 7, 19, 1), (1, 32, 64, 6, 9, 33, 2),
+                                                     (1, 4, 3, 3, 3, 3, 1), (1, 16, 16, 1, 1, 1, 1),
+                                                     (1, 8, 40, 4, 6, 17, 1)])
+def test_conv3d_k3_vs_fp64(dev, N, Cin, Cout, D, H, W, stride):
+    gen = torch.Generator().manual_seed(N * 1000 + Cin + Cout + D * H * W)
+    x = torch.randn(N, Cin, D, H, W, generator=gen)
+    w = torch.randn(Cout, Cin, 3, 3, 3, generator=gen) / (27 * Cin) ** 0.5
+    ref = F.conv3d(x.double(), w.double(), None, stride, 1)
+    y, part = pointflow.conv3d_k3(x.to(dev), w.to(dev), stride, True)
+    assert y.shape == ref.shape
+    scale = float(ref.abs().max())
+    err = _maxabs(y, ref)
+    report("conv3d_%d_%d_s%d" % (Cin, Cout, stride), err=err, scale=scale)
+    assert err < 3e-6 * scale * max(1.0, (27 * Cin / 256.0) ** 0.5)      # float32 fmaf chain of length 27*Cin
+    sums = part.sum(dim=1).cpu()                                         # (N, Cout, 2)
+    assert torch.allclose(sums[..., 0], ref.sum(dim=(2, 3, 4)), rtol=1e-5, atol=1e-4 * scale)
+    assert torch.allclose(sums[..., 1], (ref ** 2).sum(dim=(2, 3, 4)), rtol=1e-5)
+    y2, none = pointflow.conv3d_k3(x.to(dev), w.to(dev), stride, False)
+    assert none is None and torch.equal(y2, y)                           # deterministic
