@@ -10,7 +10,7 @@ echo "bench exit $?" >> gpurun_out/bench.log
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/prof
-timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof -o r1 -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/rocprof.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof -o r1 -- python $R/bench.py --eager --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/rocprof.log 2>&1
 echo "rocprof exit $?" >> $R/gpurun_out/rocprof.log
 cd $R
 tail -8 gpurun_out/pytest_gpu.log; tail -4 gpurun_out/smoke.log; tail -2 gpurun_out/bench.log | cut -c1-1500

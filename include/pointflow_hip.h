@@ -188,6 +188,14 @@ int pf_norm_blocks(int64_t S);
 int pf_channel_stats_f32(const float* x, int64_t N, int64_t C, int64_t S, double* partials, void* stream);
 int pf_channel_affine_f32(const float* x, float* y, const float* scale, const float* shift, int64_t N, int64_t C,
                           int64_t S, int samples_per_stat, int relu, void* stream);
+/* Finalize + normalise in one launch: every block reduces the partials (N, T, C, 2) of its own
+ * (stat group, channel) in a fixed order, then streams y = act(gamma*(x-mean)*rsqrt(var+eps)+beta);
+ * one block per channel applies the running-statistics recurrence over the N/samples_per_stat stat groups
+ * in order.  count = elements per stat group (= samples_per_stat * S). */
+int pf_channel_bn_apply_f32(const float* x, float* y, const double* partials, int T, int64_t N, int64_t C, int64_t S,
+                            int samples_per_stat, double count, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, float momentum, float eps, int relu,
+                            void* stream);
 
 /* ---- row R : 3x3x3 convolution of VolumeConv on the f32 matrix cores ---------------------------------
  * Replaces nn.Conv3d(k=3, padding=1, stride 1|2, bias=False) inside the Conv3d blocks of reference

@@ -69,15 +69,8 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restr
 }
 
 // y = act(x * scale[s, c] + shift[s, c]), s = n / samples_per_stat; grid = (blocks, C, N)
-__global__ __launch_bounds__(256) void channel_affine_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                             const float* __restrict__ scale,
-                                                             const float* __restrict__ shift, int C, int64_t S,
-                                                             int samples_per_stat, int relu) {
-  const int c = blockIdx.y, n = blockIdx.z;
-  const int64_t so = (int64_t)(n / samples_per_stat) * C + c;
-  const float a = scale[so], b = shift[so];
-  const float* p = x + ((int64_t)n * C + c) * S;
-  float* o = y + ((int64_t)n * C + c) * S;
+__device__ __forceinline__ void affine_stream(const float* __restrict__ p, float* __restrict__ o, int64_t S,
+                                              float a, float b, int relu) {
   const int64_t stride = (int64_t)gridDim.x * 256;
   if ((((uintptr_t)p | (uintptr_t)o) & 15) == 0 && (S & 3) == 0) {
     const int64_t n4 = S >> 2;
@@ -103,6 +96,76 @@ __global__ __launch_bounds__(256) void channel_affine_kernel(const float* __rest
       o[i] = relu ? fmaxf(v, 0.0f) : v;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void channel_affine_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                             const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, int C, int64_t S,
+                                                             int samples_per_stat, int relu) {
+  const int c = blockIdx.y, n = blockIdx.z;
+  const int64_t so = (int64_t)(n / samples_per_stat) * C + c;
+  affine_stream(x + ((int64_t)n * C + c) * S, y + ((int64_t)n * C + c) * S, S, scale[so], shift[so], relu);
+}
+
+// Block-wide, fixed-order reduction of the `entries` float64 partial pairs of (stat group s, channel c).
+__device__ __forceinline__ double2 reduce_partials(const double* __restrict__ partials, int64_t first_entry,
+                                                   int entries, int C, int c, double2* red) {
+  double a = 0.0, b = 0.0;
+  for (int e = threadIdx.x; e < entries; e += 256) {
+    const double2 v = *reinterpret_cast<const double2*>(partials + ((first_entry + e) * C + c) * 2);
+    a += v.x;
+    b += v.y;
+  }
+  red[threadIdx.x] = make_double2(a, b);
+  __syncthreads();
+#pragma unroll
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) {
+      red[threadIdx.x].x += red[threadIdx.x + off].x;
+      red[threadIdx.x].y += red[threadIdx.x + off].y;
+    }
+    __syncthreads();
+  }
+  const double2 r = red[0];
+  __syncthreads();
+  return r;
+}
+
+// BatchNorm finalize fused into the normalise pass: every block reduces the (<= a few hundred) float64
+// partials of ITS (stat group, channel) itself -- a 1-2 us prologue instead of a separate launch -- and
+// block (x=0, n=0) of each channel additionally applies the running-statistics recurrence over all
+// stat groups in order (one update per reference module call).
+__global__ __launch_bounds__(256) void channel_bn_apply_kernel(
+    const float* __restrict__ x, float* __restrict__ y, const double* __restrict__ partials, int T, int C, int64_t S,
+    int samples_per_stat, int G, double count, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float* __restrict__ running_mean, float* __restrict__ running_var, float momentum, float eps, int relu) {
+  __shared__ double2 red[256];
+  const int c = blockIdx.y, n = blockIdx.z;
+  const int s = n / samples_per_stat;
+  const int entries = samples_per_stat * T;
+  const double2 sums = reduce_partials(partials, (int64_t)s * entries, entries, C, c, red);
+  const double mean = sums.x / count;
+  double var = sums.y / count - mean * mean;
+  var = var < 0.0 ? 0.0 : var;
+  const float a = (float)(1.0 / sqrt(var + (double)eps)) * gamma[c];
+  const float b = beta[c] - (float)mean * a;
+  if (running_mean != nullptr && blockIdx.x == 0 && n == 0) {
+    float rm = running_mean[c], rv = running_var[c];
+    for (int g = 0; g < G; ++g) {
+      const double2 sg = reduce_partials(partials, (int64_t)g * entries, entries, C, c, red);
+      const double m = sg.x / count;
+      double v = sg.y / count - m * m;
+      v = v < 0.0 ? 0.0 : v;
+      const double unbiased = count > 1.0 ? v * (count / (count - 1.0)) : v;
+      rm = (1.0f - momentum) * rm + momentum * (float)m;
+      rv = (1.0f - momentum) * rv + momentum * (float)unbiased;
+    }
+    if (threadIdx.x == 0) {
+      running_mean[c] = rm;
+      running_var[c] = rv;
+    }
+  }
+  affine_stream(x + ((int64_t)n * C + c) * S, y + ((int64_t)n * C + c) * S, S, a, b, relu);
 }
 
 }  // namespace
@@ -137,6 +200,24 @@ int pf_channel_affine_f32(const float* x, float* y, const float* scale, const fl
   dim3 grid((unsigned)blocks, (unsigned)C, (unsigned)N);
   hipLaunchKernelGGL(channel_affine_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, scale, shift, (int)C, S,
                      samples_per_stat, relu);
+  return pf_launch_status();
+}
+
+int pf_channel_bn_apply_f32(const float* x, float* y, const double* partials, int T, int64_t N, int64_t C, int64_t S,
+                            int samples_per_stat, double count, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, float momentum, float eps, int relu,
+                            void* stream) {
+  PF_REQUIRE(N >= 0 && C >= 0 && S >= 0 && N <= 65535 && C <= 65535 && samples_per_stat >= 1 && T >= 1);
+  PF_REQUIRE(N % samples_per_stat == 0 && count > 0.0);
+  PF_REQUIRE((running_mean == nullptr) == (running_var == nullptr));
+  if (N == 0 || C == 0 || S == 0) return PF_OK;
+  PF_REQUIRE(x && y && partials && gamma && beta);
+  int64_t blocks = (S / 4 + 1023) / 1024;     // >= 4096 elements per block amortise the statistics prologue
+  blocks = blocks < 1 ? 1 : (blocks > 64 ? 64 : blocks);
+  dim3 grid((unsigned)blocks, (unsigned)C, (unsigned)N);
+  hipLaunchKernelGGL(channel_bn_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, partials, T, (int)C, S,
+                     samples_per_stat, (int)(N / samples_per_stat), count, gamma, beta, running_mean, running_var,
+                     momentum, eps, relu);
   return pf_launch_status();
 }
 

@@ -168,23 +168,27 @@ def batch_norm_act_(x, bn, relu, samples_per_stat, partials=None):
     S = x[0, 0].numel()
     G = N // samples_per_stat
     dev = x.device
-    scale = torch.empty((G, C), dtype=_F32, device=dev)
-    shift = torch.empty((G, C), dtype=_F32, device=dev)
     if bn.training or not bn.track_running_stats:
+        if bn.momentum is None:
+            raise NotImplementedError("cumulative-average BatchNorm momentum is not supported")
         if partials is None:
             T = int(_lib.load().pf_norm_blocks(S))
             partials = torch.empty((N, T, C, 2), dtype=torch.float64, device=dev)
             _lib.call("pf_channel_stats_f32", _lib.ptr(x), N, C, S, _lib.ptr(partials), _lib.stream(),
                       algo_bytes=4.0 * N * C * S)
-        n = float(samples_per_stat) * S
-        bn_affine(bn, partials, 0, C, n, n, N, samples_per_stat, scale, shift)
+        track = bn.track_running_stats and bn.running_mean is not None
+        _lib.call("pf_channel_bn_apply_f32", _lib.ptr(x), _lib.ptr(x), _lib.ptr(partials), int(partials.shape[1]),
+                  N, C, S, int(samples_per_stat), float(samples_per_stat) * S, _lib.ptr(bn.weight.detach()),
+                  _lib.ptr(bn.bias.detach()), _lib.ptr(bn.running_mean if track else None),
+                  _lib.ptr(bn.running_var if track else None), float(bn.momentum), float(bn.eps), int(bool(relu)),
+                  _lib.stream(), algo_bytes=8.0 * N * C * S)
         bump_counter(bn, G)
     else:
         sc, sh = eval_affine(bn, G, C)
-        scale.copy_(sc.unsqueeze(0).expand(G, C))
-        shift.copy_(sh.unsqueeze(0).expand(G, C))
-    _lib.call("pf_channel_affine_f32", _lib.ptr(x), _lib.ptr(x), _lib.ptr(scale), _lib.ptr(shift), N, C, S,
-              int(samples_per_stat), int(bool(relu)), _lib.stream(), algo_bytes=8.0 * N * C * S)
+        scale = sc.unsqueeze(0).expand(G, C).contiguous()
+        shift = sh.unsqueeze(0).expand(G, C).contiguous()
+        _lib.call("pf_channel_affine_f32", _lib.ptr(x), _lib.ptr(x), _lib.ptr(scale), _lib.ptr(shift), N, C, S,
+                  int(samples_per_stat), int(bool(relu)), _lib.stream(), algo_bytes=8.0 * N * C * S)
     return x
 
 
