@@ -199,11 +199,12 @@ int pf_channel_bn_apply_f32(const float* x, float* y, const double* partials, in
 
 /* ---- row R : 3x3x3 convolution of VolumeConv on the f32 matrix cores ---------------------------------
  * Replaces nn.Conv3d(k=3, padding=1, stride 1|2, bias=False) inside the Conv3d blocks of reference
- * networks.py:133-142 (nn/conv.py:108,115-121).  x (N,Cin,Di,Hi,Wi) NCDHW, Cin % 4 == 0, Cout <= 64;
- * wp = weights packed on the host as (27 taps [kd][kh][kw], Cin, 16*ceil(Cout/16)) with zero padding;
- * y (N,Cout,Do,Ho,Wo).  partials (N, pf_conv3d_blocks(Do,Ho,Wo), Cout, 2) float64 or NULL receives the
- * per-block (sum, sum of squares) of y per channel -- the BatchNorm batch statistics for free. */
-int pf_conv3d_blocks(int64_t Do, int64_t Ho, int64_t Wo);
+ * networks.py:133-142 (nn/conv.py:108,115-121).  x (N,Cin,Di,Hi,Wi) NCDHW, Cin % 4 == 0, Cout <= 32;
+ * wp = weights packed on the host as (Cin/4, 27 taps [kd][kh][kw], 4, 16*ceil(Cout/16)), zero padded:
+ * wp[g][tap][k][co] = W[co][4g+k][kd][kh][kw];  y (N,Cout,Do,Ho,Wo).
+ * partials (N, pf_conv3d_blocks(...), Cout, 2) float64 or NULL receives the per-block (sum, sum of
+ * squares) of y per channel -- the BatchNorm batch statistics for free. */
+int pf_conv3d_blocks(int64_t Cin, int64_t Cout, int64_t Di, int64_t Hi, int64_t Wi, int stride);
 int pf_conv3d_k3_f32(const float* x, const float* wp, float* y, int64_t N, int64_t Cin, int64_t Cout, int64_t Di,
                      int64_t Hi, int64_t Wi, int stride, double* partials, void* stream);
 

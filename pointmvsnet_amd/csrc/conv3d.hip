@@ -8,13 +8,20 @@
 // (171 us) + GEMM (103 us).  M = output voxels, N = output channels, K = 27 taps x C_in; nothing is
 // materialised.
 //
-// Mapping: one wave owns 16 consecutive output voxels along W of one (d, h) row and all output channels
-// (NT column tiles of 16).  v_mfma_f32_16x16x4_f32: the 4-deep k-group is 4 INPUT CHANNELS at one tap, so
-// lane l (row i = l&15, k = l>>4) reads x[ci0 + k][d'][h'][w' + i]: four 64-byte row segments per
-// instruction straight from the NCDHW tensor (taps overlap, so L1/L2 serve the 27x reuse), and B is the
-// host-packed weight wp[tap][ci][co] (64 contiguous bytes per k).  d/h padding is a wave-uniform skip, w
-// padding a per-lane zero.  Exact float32 (an fmaf chain over (tap, ci)).  The 4 waves of a block take 4
-// consecutive h rows so they share two of their three input rows in L1.
+// Structure (v2; v1 fed the MFMA A/B operands straight from global memory and was texture-address bound
+// at 16 TF/s):
+//   * a 256-thread block owns an output tile of TD x 4 x 16 voxels (d x h x w); wave w owns h-row w, i.e.
+//     TD segments of 16 voxels along W, and all NT column tiles of 16 output channels;
+//   * K is walked in groups of 4 input channels.  For each group the block stages the input sub-volume
+//     it needs -- 4 x ((TD-1)s+3) x (3s+3) x (15s+3) voxels, zero-filled outside the tensor, so the
+//     compute loop has no boundary code -- and the group's 27 x 4 x 16NT weights into LDS, double
+//     buffered: group g+1 travels global -> registers while the matrix cores work on group g;
+//   * v_mfma_f32_16x16x4_f32: lane l (row i = l&15, k = l>>4) reads A = xs[k][d*s+kd][h*s+kh][i*s+kw] and
+//     B = ws[tap][k][16t + i] from LDS (plane stride padded to 16 mod 32 banks: conflict-free); a B value
+//     is reused for the TD depth slices.  Exact float32: an fmaf chain over (channel group, tap, channel).
+//   * epilogue: accumulators go through a per-wave LDS transpose so that each channel's 16 voxels leave as
+//     one 64-byte segment, and per-channel sum / sum-of-squares are folded into float64 block partials
+//     (the (N, T, C, 2) layout pf_bn_finalize_f32 / pf_channel_bn_apply_f32 consume).
 // Bound: fp32 MFMA (2*27*C_in*C_out flop per voxel vs 4*(C_in + C_out) bytes).
 #include "pf_common.h"
 
@@ -22,172 +29,307 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int NT, int STRIDE>
+struct ConvGeom {
+  int Cin, Cout, Di, Hi, Wi, Do, Ho, Wo;
+  int ID, IH, IW, IWP, plane;   // staged sub-volume: depth, height, width, padded row, padded channel stride
+  int tiles_d, tiles_h, tiles_w;
+};
+
+template <int NT, int STRIDE, int TD>
 __global__ __launch_bounds__(256) void conv3d_k3_kernel(const float* __restrict__ x, const float* __restrict__ wp,
-                                                        float* __restrict__ y, int Cin, int Cout, int Di, int Hi,
-                                                        int Wi, int Do, int Ho, int Wo,
+                                                        float* __restrict__ y, ConvGeom g,
                                                         double* __restrict__ partials) {
   constexpr int NCP = NT * 16;
-  __shared__ float tile[4][NCP][17];          // per-wave transpose buffer for coalesced stores
-  __shared__ double red[4][NCP][2];
+  constexpr int WSZ = 27 * 4 * NCP;                 // weights of one channel group
+  constexpr int NWR = (WSZ + 255) / 256;            // weight floats staged per thread
+  constexpr int MAXROWS = 4 * ((TD - 1) * STRIDE + 3) * (3 * STRIDE + 3);
+  constexpr int NXR = (MAXROWS + 7) / 8;            // input rows staged per thread (8 rows of 32 lanes per pass)
+  constexpr int XPASS = STRIDE == 1 ? 1 : 2;        // a staged row has 18 (stride 1) or 33 (stride 2) floats
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int xs_size = 4 * g.plane;
+  float* xs0 = lds;
+  float* ws0 = lds + 2 * xs_size;
+  float* tile = ws0 + 2 * WSZ;                       // [4 waves][NCP][17]
+  double* red = reinterpret_cast<double*>(tile + 4 * NCP * 17);   // [4][NCP][2]
+
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int li = lane & 15, lk = lane >> 4;
   const int n = blockIdx.y;
-  const int tiles_w = (Wo + 15) >> 4;
-  const int hgroups = (Ho + 3) >> 2;
-  const int64_t total = (int64_t)Do * tiles_w * hgroups;      // block-level work items: (do, wtile, 4 h rows)
-  const int64_t plane_i = (int64_t)Hi * Wi, vol_i = plane_i * Di;
-  const int64_t plane_o = (int64_t)Ho * Wo, vol_o = plane_o * Do;
-  const float* xb = x + (int64_t)n * Cin * vol_i;
-  float* yb = y + (int64_t)n * Cout * vol_o;
-  const int cgroups = Cin >> 2;
+  const int64_t plane_i = (int64_t)g.Hi * g.Wi, vol_i = plane_i * g.Di;
+  const int64_t plane_o = (int64_t)g.Ho * g.Wo, vol_o = plane_o * g.Do;
+  const float* xb = x + (int64_t)n * g.Cin * vol_i;
+  float* yb = y + (int64_t)n * g.Cout * vol_o;
+  const int cgroups = g.Cin >> 2;
+  const int rows_total = 4 * g.ID * g.IH;
+  const int srow = tid >> 5, scol = tid & 31;        // staging: 8 rows x 32 columns per pass
 
   double ssum[NT], ssq[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) ssum[t] = ssq[t] = 0.0;
 
+  const int64_t total = (int64_t)g.tiles_d * g.tiles_h * g.tiles_w;
   for (int64_t item = blockIdx.x; item < total; item += gridDim.x) {
-    const int hg = (int)(item % hgroups);
-    const int64_t rest = item / hgroups;
-    const int wt = (int)(rest % tiles_w);
-    const int od = (int)(rest / tiles_w);
-    const int oh = hg * 4 + wave;
-    const int ow0 = wt * 16;
-    const bool row_ok = oh < Ho;
+    const int tw = (int)(item % g.tiles_w);
+    const int64_t rest = item / g.tiles_w;
+    const int th = (int)(rest % g.tiles_h);
+    const int td = (int)(rest / g.tiles_h);
+    const int od0 = td * TD, oh0 = th * 4, ow0 = tw * 16;
+    const int id0 = od0 * STRIDE - 1, ih0 = oh0 * STRIDE - 1, iw0 = ow0 * STRIDE - 1;
 
-    f32x4 acc[NT];
+    // staging plan of this tile: row = (ch * ID + dz) * IH + hy of the 4-channel sub-volume; the same for
+    // every channel group, so the index arithmetic is done once per tile
+    int gofs[NXR], lofs[NXR];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    for (int r = 0; r < NXR; ++r) {
+      const int row = r * 8 + srow;
+      const int ch = row / (g.ID * g.IH);
+      const int rem = row - ch * g.ID * g.IH;
+      const int dz = rem / g.IH, hy = rem - dz * g.IH;
+      const int id = id0 + dz, ih = ih0 + hy;
+      const bool in = row < rows_total;
+      const bool rok = in && id >= 0 && id < g.Di && ih >= 0 && ih < g.Hi;
+      gofs[r] = rok ? (int)((int64_t)ch * vol_i + (int64_t)id * plane_i + (int64_t)ih * g.Wi) : -1;
+      lofs[r] = in ? ch * g.plane + rem * g.IWP : -1;
+    }
 
-    if (row_ok) {
-      const int ow = ow0 + li;
+    float rx[NXR * XPASS], rw[NWR];
+    auto load_group = [&](int cg) {
+      const float* src = xb + (int64_t)cg * 4 * vol_i;
+#pragma unroll
+      for (int r = 0; r < NXR; ++r) {
+#pragma unroll
+        for (int p = 0; p < XPASS; ++p) {
+          const int col = scol + 32 * p;
+          const int iw = iw0 + col;
+          rx[r * XPASS + p] = (gofs[r] >= 0 && col < g.IW && iw >= 0 && iw < g.Wi) ? src[gofs[r] + iw] : 0.0f;
+        }
+      }
+      const float* wsrc = wp + (int64_t)cg * WSZ;
+#pragma unroll
+      for (int r = 0; r < NWR; ++r) {
+        const int e = tid + 256 * r;
+        rw[r] = e < WSZ ? wsrc[e] : 0.0f;
+      }
+    };
+    auto store_group = [&](int buf) {
+      float* xs = xs0 + buf * xs_size;
+      float* ws = ws0 + buf * WSZ;
+#pragma unroll
+      for (int r = 0; r < NXR; ++r) {
+        if (lofs[r] >= 0) {
+#pragma unroll
+          for (int p = 0; p < XPASS; ++p) {
+            const int col = scol + 32 * p;
+            if (col < g.IW) xs[lofs[r] + col] = rx[r * XPASS + p];
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < NWR; ++r) {
+        const int e = tid + 256 * r;
+        if (e < WSZ) ws[e] = rw[r];
+      }
+    };
+
+    f32x4 acc[TD][NT];
+#pragma unroll
+    for (int d = 0; d < TD; ++d)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[d][t] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+
+    __syncthreads();                       // the previous tile's last group has been consumed
+    load_group(0);
+    store_group(0);
+    __syncthreads();
+    for (int cg = 0; cg < cgroups; ++cg) {
+      const int buf = cg & 1;
+      if (cg + 1 < cgroups) load_group(cg + 1);
+      const float* xs = xs0 + buf * xs_size + lk * g.plane + (wave * STRIDE) * g.IWP + li * STRIDE;
+      const float* ws = ws0 + buf * WSZ + lk * NCP + li;
+#pragma unroll
       for (int kd = 0; kd < 3; ++kd) {
-        const int id = od * STRIDE + kd - 1;
-        if (id < 0 || id >= Di) continue;
+#pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
-          const int ih = oh * STRIDE + kh - 1;
-          if (ih < 0 || ih >= Hi) continue;
 #pragma unroll
           for (int kw = 0; kw < 3; ++kw) {
-            const int iw = ow * STRIDE + kw - 1;
-            const bool ok = (ow < Wo) && (iw >= 0) && (iw < Wi);
-            const float* ap = xb + (int64_t)lk * vol_i + (int64_t)id * plane_i + (int64_t)ih * Wi + (ok ? iw : 0);
-            const float* bp = wp + ((int64_t)((kd * 3 + kh) * 3 + kw) * Cin + lk) * NCP + li;
-#pragma unroll 8
-            for (int cg = 0; cg < cgroups; ++cg) {
-              const float a = ok ? ap[(int64_t)cg * 4 * vol_i] : 0.0f;
+            const int tap = (kd * 3 + kh) * 3 + kw;
+            float b[NT];
 #pragma unroll
-              for (int t = 0; t < NT; ++t) {
-                const float b = bp[(int64_t)cg * 4 * NCP + 16 * t];
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
-              }
+            for (int t = 0; t < NT; ++t) b[t] = ws[tap * 4 * NCP + 16 * t];
+#pragma unroll
+            for (int d = 0; d < TD; ++d) {
+              const float a = xs[((d * STRIDE + kd) * g.IH + kh) * g.IWP + kw];
+#pragma unroll
+              for (int t = 0; t < NT; ++t) acc[d][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[t], acc[d][t], 0, 0, 0);
             }
           }
         }
       }
+      if (cg + 1 < cgroups) store_group(buf ^ 1);
+      __syncthreads();
     }
 
-    // epilogue: C/D layout col = lane&15 (channel), row = (lane>>4)*4 + r (voxel).  Transpose through LDS
-    // so that each channel's 16 voxels leave as one 64-byte segment; accumulate BN statistics on the way.
+    // epilogue: C/D layout col = lane&15 (channel), row = (lane>>4)*4 + r (voxel along W)
+    const int oh = oh0 + wave;
+    float* tl = tile + wave * NCP * 17;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      float s = 0.0f, q = 0.0f;
+    for (int d = 0; d < TD; ++d) {
+      const int od = od0 + d;
+      const bool row_ok = oh < g.Ho && od < g.Do;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int pos = lk * 4 + r;
-        const float v = acc[t][r];
-        tile[wave][16 * t + li][pos] = v;
-        if (row_ok && ow0 + pos < Wo) {
-          s += v;
-          q += v * v;
+      for (int t = 0; t < NT; ++t) {
+        float s = 0.0f, q = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int pos = lk * 4 + r;
+          const float v = acc[d][t][r];
+          tl[(16 * t + li) * 17 + pos] = v;
+          if (row_ok && ow0 + pos < g.Wo) {
+            s += v;
+            q += v * v;
+          }
+        }
+        s += __shfl_xor(s, 16);
+        q += __shfl_xor(q, 16);
+        s += __shfl_xor(s, 32);
+        q += __shfl_xor(q, 32);
+        ssum[t] += (double)s;
+        ssq[t] += (double)q;
+      }
+      // `tl` is private to the wave and a wave's LDS operations execute in order: no workgroup barrier,
+      // only keep the compiler from moving the reads above the writes
+      __builtin_amdgcn_wave_barrier();
+      if (row_ok) {
+        for (int e = lane; e < NCP * 16; e += 64) {
+          const int co = e >> 4, pos = e & 15;
+          if (co < g.Cout && ow0 + pos < g.Wo)
+            yb[(int64_t)co * vol_o + (int64_t)od * plane_o + (int64_t)oh * g.Wo + ow0 + pos] = tl[co * 17 + pos];
         }
       }
-      s += __shfl_xor(s, 16);
-      q += __shfl_xor(q, 16);
-      s += __shfl_xor(s, 32);
-      q += __shfl_xor(q, 32);
-      ssum[t] += (double)s;
-      ssq[t] += (double)q;
+      __builtin_amdgcn_wave_barrier();
     }
-    // tile[wave] is private to the wave and LDS operations of one wave execute in order: no workgroup
-    // barrier, just keep the compiler from moving the reads above the writes
-    __builtin_amdgcn_wave_barrier();
-    if (row_ok) {
-      for (int e = lane; e < NCP * 16; e += 64) {
-        const int co = e >> 4, pos = e & 15;
-        if (co < Cout && ow0 + pos < Wo)
-          yb[(int64_t)co * vol_o + (int64_t)od * plane_o + (int64_t)oh * Wo + ow0 + pos] = tile[wave][co][pos];
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
   }
 
   if (partials != nullptr) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       if (lane < 16) {
-        red[wave][16 * t + lane][0] = ssum[t];
-        red[wave][16 * t + lane][1] = ssq[t];
+        red[((wave * NCP) + 16 * t + lane) * 2 + 0] = ssum[t];
+        red[((wave * NCP) + 16 * t + lane) * 2 + 1] = ssq[t];
       }
     }
     __syncthreads();
-    if (tid < Cout) {
+    if (tid < g.Cout) {
       double s = 0.0, q = 0.0;
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
-        s += red[w][tid][0];
-        q += red[w][tid][1];
+        s += red[((w * NCP) + tid) * 2 + 0];
+        q += red[((w * NCP) + tid) * 2 + 1];
       }
-      double* o = partials + (((int64_t)n * gridDim.x + blockIdx.x) * Cout + tid) * 2;
+      double* o = partials + (((int64_t)n * gridDim.x + blockIdx.x) * g.Cout + tid) * 2;
       o[0] = s;
       o[1] = q;
     }
   }
 }
 
-int blocks_for(int64_t Do, int64_t Ho, int64_t Wo) {
-  const int64_t total = Do * ((Wo + 15) / 16) * ((Ho + 3) / 4);
-  return (int)(total < 1024 ? total : 1024);
+ConvGeom make_geom(int64_t Cin, int64_t Cout, int64_t Di, int64_t Hi, int64_t Wi, int stride, int td) {
+  ConvGeom g;
+  g.Cin = (int)Cin;
+  g.Cout = (int)Cout;
+  g.Di = (int)Di;
+  g.Hi = (int)Hi;
+  g.Wi = (int)Wi;
+  g.Do = (int)((Di - 1) / stride + 1);
+  g.Ho = (int)((Hi - 1) / stride + 1);
+  g.Wo = (int)((Wi - 1) / stride + 1);
+  g.ID = (td - 1) * stride + 3;
+  g.IH = 3 * stride + 3;
+  g.IW = 15 * stride + 3;
+  g.IWP = g.IW + 1;
+  const int raw = g.ID * g.IH * g.IWP;
+  // channel planes 16 banks apart for unit-stride reads, 17 for stride-2 reads (the 16 lanes of a plane
+  // then use every other bank): the two planes of a 32-lane LDS group never collide
+  const int want = stride == 1 ? 16 : 17;
+  g.plane = raw + ((want - raw % 32) + 32) % 32;
+  g.tiles_d = (g.Do + td - 1) / td;
+  g.tiles_h = (g.Ho + 3) / 4;
+  g.tiles_w = (g.Wo + 15) / 16;
+  return g;
+}
+
+size_t lds_bytes_for(const ConvGeom& g, int NT) {
+  const int NCP = NT * 16;
+  return sizeof(float) * (size_t)(2 * 4 * g.plane + 2 * 27 * 4 * NCP + 4 * NCP * 17) + sizeof(double) * (size_t)(4 * NCP * 2);
+}
+
+// Deepest tile (TD in {4,2,1}) whose LDS image fits 64 KiB and that still leaves >= 512 blocks of work
+// (2 per CU); if none has 512 blocks, the shallowest that fits.
+int pick_td(int64_t Cin, int64_t Cout, int64_t Di, int64_t Hi, int64_t Wi, int stride) {
+  const int NT = (int)((Cout + 15) / 16);
+  int best = 0;
+  for (int td = stride == 1 ? 4 : 2; td >= 1; td >>= 1) {   // stride-2 TD=4 would need > 64 KiB of LDS
+    const ConvGeom g = make_geom(Cin, Cout, Di, Hi, Wi, stride, td);
+    if (lds_bytes_for(g, NT) > 64 * 1024) continue;
+    best = td;
+    if ((int64_t)g.tiles_d * g.tiles_h * g.tiles_w >= 512) return td;
+  }
+  return best;
+}
+
+int blocks_for(const ConvGeom& g) {
+  const int64_t total = (int64_t)g.tiles_d * g.tiles_h * g.tiles_w;
+  return (int)(total < 2048 ? total : 2048);
+}
+
+template <int NT, int STRIDE, int TD>
+int launch(const float* x, const float* wp, float* y, const ConvGeom& g, int64_t N, double* partials,
+           hipStream_t s) {
+  const size_t lds_bytes = lds_bytes_for(g, NT);
+  if (lds_bytes > 64 * 1024) return PF_ERR_UNSUPPORTED;
+  dim3 grid((unsigned)blocks_for(g), (unsigned)N);
+  hipLaunchKernelGGL((conv3d_k3_kernel<NT, STRIDE, TD>), grid, dim3(256), lds_bytes, s, x, wp, y, g, partials);
+  return pf_launch_status();
+}
+
+template <int NT, int STRIDE>
+int launch_td(int td, const float* x, const float* wp, float* y, const ConvGeom& g, int64_t N, double* partials,
+              hipStream_t s) {
+  if constexpr (STRIDE == 1) {
+    if (td == 4) return launch<NT, STRIDE, 4>(x, wp, y, g, N, partials, s);
+  }
+  if (td == 2) return launch<NT, STRIDE, 2>(x, wp, y, g, N, partials, s);
+  return launch<NT, STRIDE, 1>(x, wp, y, g, N, partials, s);
 }
 
 }  // namespace
 
 extern "C" {
 
-int pf_conv3d_blocks(int64_t Do, int64_t Ho, int64_t Wo) {
-  if (Do <= 0 || Ho <= 0 || Wo <= 0) return 0;
-  return blocks_for(Do, Ho, Wo);
+int pf_conv3d_blocks(int64_t Cin, int64_t Cout, int64_t Di, int64_t Hi, int64_t Wi, int stride) {
+  if (Cin <= 0 || Cout <= 0 || Di <= 0 || Hi <= 0 || Wi <= 0 || (stride != 1 && stride != 2)) return 0;
+  const int td = pick_td(Cin, Cout, Di, Hi, Wi, stride);
+  if (td == 0) return 0;
+  return blocks_for(make_geom(Cin, Cout, Di, Hi, Wi, stride, td));
 }
 
 int pf_conv3d_k3_f32(const float* x, const float* wp, float* y, int64_t N, int64_t Cin, int64_t Cout, int64_t Di,
                      int64_t Hi, int64_t Wi, int stride, double* partials, void* stream) {
   PF_REQUIRE(N >= 0 && Cin >= 4 && Cout >= 1 && Di >= 1 && Hi >= 1 && Wi >= 1 && N <= 65535);
   PF_REQUIRE(stride == 1 || stride == 2);
-  if ((Cin % 4) != 0 || Cout > 64) return PF_ERR_UNSUPPORTED;
-  PF_REQUIRE(Di * Hi * Wi <= INT32_MAX);
+  if ((Cin % 4) != 0 || Cout > 32) return PF_ERR_UNSUPPORTED;
+  PF_REQUIRE(Cin * Di * Hi * Wi <= INT32_MAX);
   if (N == 0) return PF_OK;
   PF_REQUIRE(x && wp && y);
-  const int64_t Do = (Di + 2 - 3) / stride + 1, Ho = (Hi + 2 - 3) / stride + 1, Wo = (Wi + 2 - 3) / stride + 1;
-  dim3 grid((unsigned)blocks_for(Do, Ho, Wo), (unsigned)N);
+  const int td = pick_td(Cin, Cout, Di, Hi, Wi, stride);
+  if (td == 0) return PF_ERR_UNSUPPORTED;
+  const ConvGeom g = make_geom(Cin, Cout, Di, Hi, Wi, stride, td);
   hipStream_t s = (hipStream_t)stream;
   const int NT = (int)((Cout + 15) / 16);
-#define PF_CONV_LAUNCH(NTV, SV)                                                                                  \
-  hipLaunchKernelGGL((conv3d_k3_kernel<NTV, SV>), grid, dim3(256), 0, s, x, wp, y, (int)Cin, (int)Cout, (int)Di, \
-                     (int)Hi, (int)Wi, (int)Do, (int)Ho, (int)Wo, partials)
-  if (stride == 1) {
-    if (NT == 1) PF_CONV_LAUNCH(1, 1);
-    else if (NT == 2) PF_CONV_LAUNCH(2, 1);
-    else if (NT == 3) PF_CONV_LAUNCH(3, 1);
-    else PF_CONV_LAUNCH(4, 1);
-  } else {
-    if (NT == 1) PF_CONV_LAUNCH(1, 2);
-    else if (NT == 2) PF_CONV_LAUNCH(2, 2);
-    else if (NT == 3) PF_CONV_LAUNCH(3, 2);
-    else PF_CONV_LAUNCH(4, 2);
-  }
-#undef PF_CONV_LAUNCH
-  return pf_launch_status();
+  if (stride == 1)
+    return NT == 1 ? launch_td<1, 1>(td, x, wp, y, g, N, partials, s) : launch_td<2, 1>(td, x, wp, y, g, N, partials, s);
+  return NT == 1 ? launch_td<1, 2>(td, x, wp, y, g, N, partials, s) : launch_td<2, 2>(td, x, wp, y, g, N, partials, s);
 }
 
 }  // extern "C"

@@ -92,7 +92,7 @@ def _block_fused(block, x, samples_per_stat):
     training_bn = block.bn is not None and (block.bn.training or not block.bn.track_running_stats)
     if (type(conv) is nn.Conv3d and conv.kernel_size == (3, 3, 3) and conv.padding == (1, 1, 1)
             and conv.stride in ((1, 1, 1), (2, 2, 2)) and conv.dilation == (1, 1, 1) and conv.groups == 1
-            and conv.bias is None and conv.in_channels % 4 == 0 and conv.out_channels <= 64
+            and conv.bias is None and conv.in_channels % 4 == 0 and conv.out_channels <= 32
             and x[0, 0].numel() // (conv.stride[0] ** 3) >= 16384):
         # (small volumes do not fill the chip with one wave per 16 voxels: the library GEMM path is faster)
         # row R on the f32 matrix cores; the BN batch statistics come out of the conv epilogue

@@ -130,7 +130,7 @@ def conv3d_k3(x, weight, stride, want_stats):
     y = torch.empty((N, Cout, Do, Ho, Wo), dtype=_F32, device=x.device)
     partials = None
     if want_stats:
-        T = int(_lib.load().pf_conv3d_blocks(Do, Ho, Wo))
+        T = int(_lib.load().pf_conv3d_blocks(Cin, Cout, Di, Hi, Wi, int(stride)))
         partials = torch.empty((N, T, Cout, 2), dtype=torch.float64, device=x.device)
     _lib.call("pf_conv3d_k3_f32", _lib.ptr(x), _lib.ptr(wp), _lib.ptr(y), N, Cin, Cout, Di, Hi, Wi, int(stride),
               _lib.ptr(partials), _lib.stream(),
@@ -140,7 +140,7 @@ def conv3d_k3(x, weight, stride, want_stats):
 
 
 def pack_conv3d_weight(weight):
-    """(Cout,Cin,3,3,3) -> (27, Cin, 16*ceil(Cout/16)) zero padded; cached like pack_weight_t."""
+    """(Cout,Cin,3,3,3) -> (Cin/4, 27, 4, 16*ceil(Cout/16)) zero padded; cached like pack_weight_t."""
     import weakref
     key = ("c3", id(weight))
     hit = _pack_cache.get(key)
@@ -148,8 +148,8 @@ def pack_conv3d_weight(weight):
         return hit[2]
     cout, cin = weight.shape[:2]
     ncp = (cout + 15) // 16 * 16
-    wp = torch.zeros((27, cin, ncp), dtype=_F32, device=weight.device)
-    wp[:, :, :cout] = weight.detach().to(_F32).permute(2, 3, 4, 1, 0).reshape(27, cin, cout)
+    wp = torch.zeros((cin // 4, 27, 4, ncp), dtype=_F32, device=weight.device)
+    wp[..., :cout] = weight.detach().to(_F32).permute(1, 2, 3, 4, 0).reshape(cin // 4, 4, 27, cout).transpose(1, 2)
     try:
         _pack_cache[key] = (weakref.ref(weight), weight._version, wp)
     except TypeError:
