@@ -207,6 +207,10 @@ int pf_channel_bn_apply_f32(const float* x, float* y, const double* partials, in
 int pf_conv3d_blocks(int64_t Cin, int64_t Cout, int64_t Di, int64_t Hi, int64_t Wi, int stride);
 int pf_conv3d_k3_f32(const float* x, const float* wp, float* y, int64_t N, int64_t Cin, int64_t Cout, int64_t Di,
                      int64_t Hi, int64_t Wi, int stride, double* partials, void* stream);
+/* 3x3x3 / pad 1 / stride 1 conv3d with Cout <= 4 (VolumeConv's 8 -> 1 output layer, networks.py:147);
+ * w is the unpacked (Cout, Cin, 3, 3, 3) weight. */
+int pf_conv3d_k3_few_f32(const float* x, const float* w, float* y, int64_t N, int64_t Cin, int64_t Cout, int64_t D,
+                         int64_t H, int64_t W, void* stream);
 
 /* ---- rows M (last layer) + H + T : flow head ---------------------------------------------------
  * Z (G*Ng, ldz) holds the pre-BN output of the 64->16 MLP layer.  Per pixel of the (h,w) grid:

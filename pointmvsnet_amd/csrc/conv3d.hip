@@ -234,6 +234,51 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(const float* __restrict_
   }
 }
 
+// Few output channels (VolumeConv's last layer, 8 -> 1: reference networks.py:147): no GEMM shape to speak
+// of -- 216 multiply-adds per voxel against 36 bytes moved -- so one lane per output voxel, weights in
+// LDS, taps served by L1 (neighbouring lanes share 2 of 3 taps along W, neighbouring rows/planes by L2).
+template <int COUT>
+__global__ __launch_bounds__(256) void conv3d_k3_few_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            float* __restrict__ y, int Cin, int D, int H, int W) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];     // [COUT][Cin][27]
+  for (int e = threadIdx.x; e < COUT * Cin * 27; e += 256) wl[e] = w[e];
+  __syncthreads();
+  const int64_t plane = (int64_t)H * W, vol = plane * D;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int n = blockIdx.y;
+  if (i >= vol) return;
+  const int od = (int)(i / plane);
+  const int rem = (int)(i - (int64_t)od * plane);
+  const int oh = rem / W, ow = rem - oh * W;
+  float acc[COUT];
+#pragma unroll
+  for (int c = 0; c < COUT; ++c) acc[c] = 0.0f;
+  const float* xb = x + (int64_t)n * Cin * vol;
+  for (int ci = 0; ci < Cin; ++ci) {
+    const float* xc = xb + (int64_t)ci * vol;
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd) {
+      const int id = od + kd - 1;
+      const bool dok = id >= 0 && id < D;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int ih = oh + kh - 1;
+        const bool hok = dok && ih >= 0 && ih < H;
+        const float* row = xc + (int64_t)id * plane + (int64_t)ih * W;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int iw = ow + kw - 1;
+          const float v = (hok && iw >= 0 && iw < W) ? row[iw] : 0.0f;
+#pragma unroll
+          for (int c = 0; c < COUT; ++c) acc[c] = fmaf(v, wl[(c * Cin + ci) * 27 + (kd * 3 + kh) * 3 + kw], acc[c]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < COUT; ++c) y[((int64_t)n * COUT + c) * vol + i] = acc[c];
+}
+
 ConvGeom make_geom(int64_t Cin, int64_t Cout, int64_t Di, int64_t Hi, int64_t Wi, int stride, int td) {
   ConvGeom g;
   g.Cin = (int)Cin;
@@ -259,6 +304,8 @@ ConvGeom make_geom(int64_t Cin, int64_t Cout, int64_t Di, int64_t Hi, int64_t Wi
   return g;
 }
 
+constexpr size_t kMaxLds = 80 * 1024;    // two blocks per CU still fit in the 160 KiB of a CU
+
 size_t lds_bytes_for(const ConvGeom& g, int NT) {
   const int NCP = NT * 16;
   return sizeof(float) * (size_t)(2 * 4 * g.plane + 2 * 27 * 4 * NCP + 4 * NCP * 17) + sizeof(double) * (size_t)(4 * NCP * 2);
@@ -269,9 +316,9 @@ size_t lds_bytes_for(const ConvGeom& g, int NT) {
 int pick_td(int64_t Cin, int64_t Cout, int64_t Di, int64_t Hi, int64_t Wi, int stride) {
   const int NT = (int)((Cout + 15) / 16);
   int best = 0;
-  for (int td = stride == 1 ? 4 : 2; td >= 1; td >>= 1) {   // stride-2 TD=4 would need > 64 KiB of LDS
+  for (int td = stride == 1 ? 4 : 2; td >= 1; td >>= 1) {   // stride-2 TD=4 would need > 80 KiB of LDS
     const ConvGeom g = make_geom(Cin, Cout, Di, Hi, Wi, stride, td);
-    if (lds_bytes_for(g, NT) > 64 * 1024) continue;
+    if (lds_bytes_for(g, NT) > kMaxLds) continue;
     best = td;
     if ((int64_t)g.tiles_d * g.tiles_h * g.tiles_w >= 512) return td;
   }
@@ -287,7 +334,15 @@ template <int NT, int STRIDE, int TD>
 int launch(const float* x, const float* wp, float* y, const ConvGeom& g, int64_t N, double* partials,
            hipStream_t s) {
   const size_t lds_bytes = lds_bytes_for(g, NT);
-  if (lds_bytes > 64 * 1024) return PF_ERR_UNSUPPORTED;
+  if (lds_bytes > kMaxLds) return PF_ERR_UNSUPPORTED;
+  if (lds_bytes > 64 * 1024) {           // opt in to more than the default 64 KiB of dynamic LDS (160 KiB per CU)
+    static bool done = false;            // per instantiation
+    if (!done) {
+      PF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_kernel<NT, STRIDE, TD>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
+      done = true;
+    }
+  }
   dim3 grid((unsigned)blocks_for(g), (unsigned)N);
   hipLaunchKernelGGL((conv3d_k3_kernel<NT, STRIDE, TD>), grid, dim3(256), lds_bytes, s, x, wp, y, g, partials);
   return pf_launch_status();
@@ -330,6 +385,25 @@ int pf_conv3d_k3_f32(const float* x, const float* wp, float* y, int64_t N, int64
   if (stride == 1)
     return NT == 1 ? launch_td<1, 1>(td, x, wp, y, g, N, partials, s) : launch_td<2, 1>(td, x, wp, y, g, N, partials, s);
   return NT == 1 ? launch_td<1, 2>(td, x, wp, y, g, N, partials, s) : launch_td<2, 2>(td, x, wp, y, g, N, partials, s);
+}
+
+int pf_conv3d_k3_few_f32(const float* x, const float* w, float* y, int64_t N, int64_t Cin, int64_t Cout, int64_t D,
+                         int64_t H, int64_t W, void* stream) {
+  PF_REQUIRE(N >= 0 && Cin >= 1 && Cout >= 1 && D >= 1 && H >= 1 && W >= 1 && N <= 65535);
+  if (Cout > 4 || Cout * Cin * 27 * sizeof(float) > 48 * 1024) return PF_ERR_UNSUPPORTED;
+  PF_REQUIRE(H * W <= INT32_MAX);
+  if (N == 0) return PF_OK;
+  PF_REQUIRE(x && w && y);
+  const size_t lds = sizeof(float) * (size_t)(Cout * Cin * 27);
+  dim3 grid((unsigned)pf_cdiv(D * H * W, 256), (unsigned)N);
+  hipStream_t s = (hipStream_t)stream;
+  switch ((int)Cout) {
+    case 1: hipLaunchKernelGGL(conv3d_k3_few_kernel<1>, grid, dim3(256), lds, s, x, w, y, (int)Cin, (int)D, (int)H, (int)W); break;
+    case 2: hipLaunchKernelGGL(conv3d_k3_few_kernel<2>, grid, dim3(256), lds, s, x, w, y, (int)Cin, (int)D, (int)H, (int)W); break;
+    case 3: hipLaunchKernelGGL(conv3d_k3_few_kernel<3>, grid, dim3(256), lds, s, x, w, y, (int)Cin, (int)D, (int)H, (int)W); break;
+    default: hipLaunchKernelGGL(conv3d_k3_few_kernel<4>, grid, dim3(256), lds, s, x, w, y, (int)Cin, (int)D, (int)H, (int)W); break;
+  }
+  return pf_launch_status();
 }
 
 }  // extern "C"

@@ -87,12 +87,17 @@ def _block_fused(block, x, samples_per_stat):
     """conv (library) -> HIP BatchNorm statistics/finalize -> HIP affine+ReLU in place; ``block`` is one of
     the nn.conv blocks or a plain nn.ConvNd (no BN / ReLU)."""
     if not hasattr(block, "bn"):
+        if (type(block) is nn.Conv3d and block.kernel_size == (3, 3, 3) and block.padding == (1, 1, 1)
+                and block.stride == (1, 1, 1) and block.dilation == (1, 1, 1) and block.groups == 1
+                and block.bias is None and block.out_channels <= 4 and block.in_channels * block.out_channels <= 256):
+            return pointflow.conv3d_k3_few(x.contiguous(), block.weight)
         return block(x)
     conv = block.conv
     training_bn = block.bn is not None and (block.bn.training or not block.bn.track_running_stats)
     if (type(conv) is nn.Conv3d and conv.kernel_size == (3, 3, 3) and conv.padding == (1, 1, 1)
             and conv.stride in ((1, 1, 1), (2, 2, 2)) and conv.dilation == (1, 1, 1) and conv.groups == 1
-            and conv.bias is None and conv.in_channels % 4 == 0 and conv.out_channels <= 32
+            and conv.bias is None and conv.in_channels % 4 == 0
+            and conv.out_channels <= (32 if conv.stride[0] == 1 else 16)
             and x[0, 0].numel() // (conv.stride[0] ** 3) >= 16384):
         # (small volumes do not fill the chip with one wave per 16 voxels: the library GEMM path is faster)
         # row R on the f32 matrix cores; the BN batch statistics come out of the conv epilogue
@@ -182,7 +187,7 @@ class VolumeConv(nn.Module):
         up = f(self.conv4_0, eighth)
         up = f(self.conv5_0, up + quarter)
         up = f(self.conv6_0, up + half)
-        return self.conv6_2(up + full)
+        return f(self.conv6_2, up + full)
 
     def forward(self, x):
         full = self.conv0_1(x)

@@ -139,6 +139,17 @@ def conv3d_k3(x, weight, stride, want_stats):
     return y, partials
 
 
+def conv3d_k3_few(x, weight):
+    """3x3x3 / pad 1 / stride 1 conv3d with <= 4 output channels (pf_conv3d_k3_few_f32)."""
+    N, Cin, D, H, W = x.shape
+    Cout = weight.shape[0]
+    y = torch.empty((N, Cout, D, H, W), dtype=_F32, device=x.device)
+    w = weight.detach().to(_F32).contiguous()
+    _lib.call("pf_conv3d_k3_few_f32", _lib.ptr(x), _lib.ptr(w), _lib.ptr(y), N, Cin, Cout, D, H, W, _lib.stream(),
+              algo_bytes=4.0 * N * D * H * W * (Cin + Cout))
+    return y
+
+
 def pack_conv3d_weight(weight):
     """(Cout,Cin,3,3,3) -> (Cin/4, 27, 4, 16*ceil(Cout/16)) zero padded; cached like pack_weight_t."""
     import weakref

@@ -468,7 +468,7 @@ def test_volume_conv_fused_vs_reference(dev):
 # row R: MFMA conv3d with fused BN statistics
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("N,Cin,Cout,D,H,W,stride", [(1, 64, 8, 8, 16, 24, 1), (1, 64, 16, 8, 16, 24, 2),
-                                                     (2, 16, 32, 5, 7, 19, 1), (1, 32, 24, 6, 9, 33, 2),
+                                                     (2, 16, 32, 5, 7, 19, 1), (1, 32, 16, 6, 9, 33, 2),
                                                      (1, 4, 3, 3, 3, 3, 1), (1, 16, 16, 1, 1, 1, 1),
                                                      (1, 8, 20, 4, 6, 17, 1), (1, 64, 8, 48, 64, 80, 1),
                                                      (1, 64, 16, 48, 64, 80, 2), (1, 16, 16, 24, 32, 40, 1),
@@ -489,3 +489,15 @@ def test_conv3d_k3_vs_fp64(dev, N, Cin, Cout, D, H, W, stride):
     assert torch.allclose(sums[..., 1], (ref ** 2).sum(dim=(2, 3, 4)), rtol=1e-5)
     y2, none = pointflow.conv3d_k3(x.to(dev), w.to(dev), stride, False)
     assert none is None and torch.equal(y2, y)                           # deterministic
+
+
+@pytest.mark.parametrize("N,Cin,Cout,D,H,W", [(1, 8, 1, 8, 16, 24), (2, 5, 3, 3, 5, 7), (1, 8, 1, 48, 64, 80)])
+def test_conv3d_k3_few_vs_fp64(dev, N, Cin, Cout, D, H, W):
+    gen = torch.Generator().manual_seed(Cin * 100 + D * H * W)
+    x = torch.randn(N, Cin, D, H, W, generator=gen)
+    w = torch.randn(Cout, Cin, 3, 3, 3, generator=gen) / (27 * Cin) ** 0.5
+    ref = F.conv3d(x.double(), w.double(), None, 1, 1)
+    y = pointflow.conv3d_k3_few(x.to(dev), w.to(dev))
+    err = _maxabs(y, ref)
+    report("conv3d_few_%d_%d" % (Cin, Cout), err=err, scale=float(ref.abs().max()))
+    assert err < 3e-6 * float(ref.abs().max())
