@@ -9,8 +9,13 @@ timeout 600 python bench.py --steps 30 --warmup 3 > gpurun_out/bench.log 2>&1
 echo "bench exit $?" >> gpurun_out/bench.log
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-rm -rf $R/gpurun_out/prof
+rm -rf $R/gpurun_out/prof $R/gpurun_out/pmc_fetch $R/gpurun_out/pmc_write
 timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof -o r1 -- python $R/bench.py --eager --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/rocprof.log 2>&1
 echo "rocprof exit $?" >> $R/gpurun_out/rocprof.log
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/pmc_fetch -o f -- python $R/bench.py --eager --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_fetch.log 2>&1
+echo "pmc fetch exit $?" >> $R/gpurun_out/pmc_fetch.log
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/pmc_write -o w -- python $R/bench.py --eager --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_write.log 2>&1
+echo "pmc write exit $?" >> $R/gpurun_out/pmc_write.log
 cd $R
-tail -8 gpurun_out/pytest_gpu.log; tail -4 gpurun_out/smoke.log; tail -2 gpurun_out/bench.log | cut -c1-1500
+ls -la gpurun_out/pmc_fetch gpurun_out/pmc_write
+tail -6 gpurun_out/pytest_gpu.log; tail -3 gpurun_out/smoke.log; tail -2 gpurun_out/bench.log | cut -c1-300; tail -2 gpurun_out/pmc_fetch.log

@@ -247,25 +247,43 @@ __device__ __forceinline__ float linspace_at(float start, float end, float step,
   return (k < D / 2) ? (start + step * (float)k) : (end - step * (float)(D - 1 - k));
 }
 
+// 64 pixels x 4 depth slices per block: the three passes over D (max, sum of exp, expectation) are split
+// over the 4 waves and combined through LDS in a fixed order (5120 pixels alone would be 20 blocks).
 __global__ __launch_bounds__(256) void softargmin_prob_kernel(const float* __restrict__ cost,
                                                               const float* __restrict__ params,
                                                               float* __restrict__ depth,
                                                               float* __restrict__ prob, int D, int64_t HW) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ float sh[4][64];
+  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + lane;
   const int64_t b = blockIdx.y;
-  if (i >= HW) return;
+  const bool ok = i < HW;
   const float start = params[b * 3 + 0], end = params[b * 3 + 1], interval = params[b * 3 + 2];
   const float step = (D > 1) ? (end - start) / (float)(D - 1) : 0.0f;
-  const float* c = cost + b * D * HW + i;
-  float mx = -c[0];
-  for (int k = 1; k < D; ++k) mx = fmaxf(mx, -c[(int64_t)k * HW]);
+  const float* c = cost + b * D * HW + (ok ? i : 0);
+  const int dq = (D + 3) >> 2;
+  const int k0 = q * dq, k1 = min(D, k0 + dq);
+
+  float mx = -__builtin_huge_valf();
+  for (int k = k0; k < k1; ++k) mx = fmaxf(mx, -c[(int64_t)k * HW]);
+  sh[q][lane] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(sh[0][lane], sh[1][lane]), fmaxf(sh[2][lane], sh[3][lane]));
+  __syncthreads();
+
   float den = 0.0f;
-  for (int k = 0; k < D; ++k) den += expf(-c[(int64_t)k * HW] - mx);
+  for (int k = k0; k < k1; ++k) den += expf(-c[(int64_t)k * HW] - mx);
+  sh[q][lane] = den;
+  __syncthreads();
+  den = ((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane];
+  __syncthreads();
+
   float acc = 0.0f;
-  for (int k = 0; k < D; ++k) {
-    const float p = expf(-c[(int64_t)k * HW] - mx) / den;
-    acc += linspace_at(start, end, step, k, D) * p;
-  }
+  for (int k = k0; k < k1; ++k) acc += linspace_at(start, end, step, k, D) * (expf(-c[(int64_t)k * HW] - mx) / den);
+  sh[q][lane] = acc;
+  __syncthreads();
+  if (q != 0 || !ok) return;
+  acc = ((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane];
   depth[b * HW + i] = acc;
   const float fi = (acc - start) / interval;
   float lo = floorf(fi), hi = ceilf(fi);
@@ -376,7 +394,7 @@ int pf_softargmin_prob_f32(const float* cost, const float* params, float* depth,
   PF_REQUIRE(B >= 0 && D >= 1 && HW >= 0 && B <= 65535 && D <= INT32_MAX);
   if (B == 0 || HW == 0) return PF_OK;
   PF_REQUIRE(cost && params && depth && prob);
-  dim3 grid((unsigned)pf_cdiv(HW, 256), (unsigned)B);
+  dim3 grid((unsigned)pf_cdiv(HW, 64), (unsigned)B);
   hipLaunchKernelGGL(softargmin_prob_kernel, grid, dim3(256), 0, (hipStream_t)stream, cost, params, depth, prob,
                      (int)D, HW);
   return pf_launch_status();
