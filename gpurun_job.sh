@@ -1,21 +1,29 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-rm -f gpurun_out/parity_report.jsonl
+rm -rf gpurun_out/prof gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/parity_report.jsonl
+if [ -z "$SKIP_TESTS" ]; then
 timeout 1500 python -m pytest tests -m gpu -q --timeout 600 > gpurun_out/pytest_gpu.log 2>&1
 echo "pytest exit $?" >> gpurun_out/pytest_gpu.log
 timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1
 echo "smoke exit $?" >> gpurun_out/smoke.log
+fi
 timeout 600 python bench.py --steps 30 --warmup 3 > gpurun_out/bench.log 2>&1
 echo "bench exit $?" >> gpurun_out/bench.log
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-rm -rf $R/gpurun_out/prof $R/gpurun_out/pmc_fetch $R/gpurun_out/pmc_write
 timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof -o r1 -- python $R/bench.py --eager --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/rocprof.log 2>&1
 echo "rocprof exit $?" >> $R/gpurun_out/rocprof.log
-timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/pmc_fetch -o f -- python $R/bench.py --eager --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_fetch.log 2>&1
-echo "pmc fetch exit $?" >> $R/gpurun_out/pmc_fetch.log
-timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/pmc_write -o w -- python $R/bench.py --eager --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_write.log 2>&1
-echo "pmc write exit $?" >> $R/gpurun_out/pmc_write.log
 cd $R
-ls -la gpurun_out/pmc_fetch gpurun_out/pmc_write
-tail -6 gpurun_out/pytest_gpu.log; tail -3 gpurun_out/smoke.log; tail -2 gpurun_out/bench.log | cut -c1-300; tail -2 gpurun_out/pmc_fetch.log
+python tools/rocprof_summary.py gpurun_out/prof/r1_results.db gpurun_out/kernel_stats.md --steps 9 --title "eager bench cfg2 (2 warm-up + 2 calibration + 5 timed steps)" --command "rocprofv3 --kernel-trace --stats -- python bench.py --eager --steps 5 --warmup 2 --no-cpu-baseline" --top 60
+python tools/dispatch_list.py gpurun_out/prof/r1_results.db gpurun_out/last_step_dispatches.txt
+rm -rf gpurun_out/prof
+if [ -n "$WITH_PMC" ]; then
+cd /tmp
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/pmc_fetch -o f -- python $R/bench.py --eager --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_fetch.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/pmc_write -o w -- python $R/bench.py --eager --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_write.log 2>&1
+cd $R
+python tools/pmc_summary.py gpurun_out/pmc_fetch/f_results.db gpurun_out/pmc_fetch.json
+python tools/pmc_summary.py gpurun_out/pmc_write/w_results.db gpurun_out/pmc_write.json
+rm -rf gpurun_out/pmc_fetch gpurun_out/pmc_write
+fi
+tail -4 gpurun_out/pytest_gpu.log; tail -2 gpurun_out/smoke.log; tail -2 gpurun_out/bench.log | cut -c1-200
