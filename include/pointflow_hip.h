@@ -212,6 +212,19 @@ int pf_conv3d_k3_f32(const float* x, const float* wp, float* y, int64_t N, int64
 int pf_conv3d_k3_few_f32(const float* x, const float* w, float* y, int64_t N, int64_t Cin, int64_t Cout, int64_t D,
                          int64_t H, int64_t W, void* stream);
 
+/* ---- ImageConv: conv2d on the f32 matrix cores ------------------------
+ * Replaces the nn.Conv2d of the Conv2d blocks of reference networks.py:89-110 (nn/conv.py:62-77) for the
+ * two shapes the towers use: 3x3 / stride 1 / pad 1 and 5x5 / stride 2 / pad 2, bias-free, Cout <= 64.
+ * x (N,Cin,Hi,Wi) NCHW holds the RAW output of the previous conv when in_scale/in_shift (N/sps, Cin) are
+ * given: relu(x*scale+shift) -- the previous block's BatchNorm+ReLU -- is applied while staging, so that
+ * activation is never written to memory.  wp = weights packed as (ceil(Cin/4), K*K, 4, NCP) zero padded,
+ * NCP = 16, 32 or 64 (>= Cout).  partials (N, pf_conv2d_blocks(...), Cout, 2) float64 or NULL receives
+ * the BatchNorm statistics of y; samples_per_stat consecutive samples share in_scale rows. */
+int pf_conv2d_blocks(int64_t Cout, int64_t Hi, int64_t Wi, int kernel_size, int stride);
+int pf_conv2d_f32(const float* x, const float* wp, float* y, int64_t N, int64_t Cin, int64_t Cout, int64_t Hi,
+                  int64_t Wi, int kernel_size, int stride, const float* in_scale, const float* in_shift,
+                  int samples_per_stat, double* partials, void* stream);
+
 /* ---- rows M (last layer) + H + T : flow head ---------------------------------------------------
  * Z (G*Ng, ldz) holds the pre-BN output of the 64->16 MLP layer.  Per pixel of the (h,w) grid:
  * a = relu(Z*scale+shift); flow_d = sum_c w_out[c]*a_c for the 5 hypotheses; p = softmax(-flow);

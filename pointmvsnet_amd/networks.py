@@ -141,16 +141,41 @@ class ImageConv(nn.Module):
 
     def forward_views(self, img_list):
         """Inference fast path: all V views of (B,V,3,H,W) in ONE pass through the tower with per-view
-        BatchNorm statistics -- numerically the reference's V separate calls (model.py:71-77), a third of
-        the launches.  Returns {"conv0".."conv3"} with tensors (B,V,c,h,w)."""
+        BatchNorm statistics -- numerically the reference's V separate calls (model.py:71-77).  Each layer is
+        one pf_conv2d_f32 launch (previous BatchNorm+ReLU applied while staging, this layer's statistics in
+        the epilogue) plus the finalize; only the stage outputs the model consumes ("conv1".."conv3",
+        (B,V,c,h,w)) are materialised -- "conv0" is not returned."""
         B, V = img_list.shape[:2]
-        x = img_list.transpose(0, 1).reshape(V * B, *img_list.shape[2:])      # view-major: stat groups contiguous
+        x = img_list.transpose(0, 1).reshape(V * B, *img_list.shape[2:]).float().contiguous()   # view-major
+        pending = None                      # (scale, shift) of a BatchNorm+ReLU not yet applied to x
         out = {}
         for name in ("conv0", "conv1", "conv2", "conv3"):
             for block in getattr(self, name):
-                x = _block_fused(block, x, B)
-            out[name] = x.view(V, B, *x.shape[1:]).transpose(0, 1)
+                x, pending = _conv2d_block_fused(block, x, pending, B)
+            if name != "conv0":
+                if pending is not None:
+                    x = pointflow.channel_affine_(x, pending, True, B)
+                    pending = None
+                out[name] = x.view(V, B, *x.shape[1:]).transpose(0, 1)
         return out
+
+
+def _conv2d_block_fused(block, x, pending, samples_per_stat):
+    """One tower block on raw activations: returns (raw conv output, pending BN+ReLU affine or None)."""
+    conv, bn, relu = (block.conv, block.bn, block.relu) if hasattr(block, "bn") else (block, None, False)
+    training_bn = bn is not None and (bn.training or not bn.track_running_stats)
+    if pointflow.conv2d_supported(conv):
+        y, partials = pointflow.conv2d(x, conv, pending, samples_per_stat, training_bn)
+    else:
+        if pending is not None:
+            x = pointflow.channel_affine_(x, pending, True, samples_per_stat)
+        y, partials = block._crop(conv(x), x).contiguous() if hasattr(block, "_crop") else conv(x).contiguous(), None
+    if bn is None:
+        return (F.relu(y, inplace=True) if relu else y), None
+    affine = pointflow.bn_affine_rows(y, bn, samples_per_stat, partials)
+    if relu:
+        return y, affine
+    return pointflow.channel_affine_(y, affine, False, samples_per_stat), None
 
 
 class VolumeConv(nn.Module):

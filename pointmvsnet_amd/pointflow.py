@@ -139,6 +139,96 @@ def conv3d_k3(x, weight, stride, want_stats):
     return y, partials
 
 
+def conv2d_supported(conv):
+    """True for the two conv shapes of the feature towers that pf_conv2d_f32 implements."""
+    if type(conv) is not torch.nn.Conv2d or conv.bias is not None or conv.groups != 1 or conv.out_channels > 64:
+        return False
+    if conv.dilation != (1, 1):
+        return False
+    k3 = conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1)
+    k5 = conv.kernel_size == (5, 5) and conv.stride == (2, 2) and conv.padding == (2, 2)
+    return k3 or k5
+
+
+def _conv2d_ncp(cout):
+    nt = (cout + 15) // 16
+    return 16 * (4 if nt == 3 else nt)
+
+
+def pack_conv2d_weight(weight):
+    """(Cout,Cin,K,K) -> (ceil(Cin/4), K*K, 4, NCP) zero padded; cached per parameter object."""
+    import weakref
+    key = ("c2", id(weight))
+    hit = _pack_cache.get(key)
+    if hit is not None and hit[0]() is weight and hit[1] == weight._version:
+        return hit[2]
+    cout, cin, k, _ = weight.shape
+    groups = (cin + 3) // 4
+    ncp = _conv2d_ncp(cout)
+    full = torch.zeros((groups * 4, k * k, cout), dtype=_F32, device=weight.device)
+    full[:cin] = weight.detach().to(_F32).permute(1, 2, 3, 0).reshape(cin, k * k, cout)
+    wp = torch.zeros((groups, k * k, 4, ncp), dtype=_F32, device=weight.device)
+    wp[..., :cout] = full.view(groups, 4, k * k, cout).transpose(1, 2)
+    try:
+        _pack_cache[key] = (weakref.ref(weight), weight._version, wp)
+    except TypeError:
+        pass
+    return wp
+
+
+def conv2d(x, conv, in_affine, samples_per_stat, want_stats):
+    """One feature-tower convolution (pf_conv2d_f32).  ``in_affine`` = (scale, shift) rows (N/sps, Cin) of a
+    pending BatchNorm+ReLU to apply while staging x, or None.  Returns (raw y, statistics partials or None)."""
+    N, Cin, Hi, Wi = x.shape
+    Cout = conv.out_channels
+    ks, stride = conv.kernel_size[0], conv.stride[0]
+    Ho, Wo = (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
+    wp = pack_conv2d_weight(conv.weight)
+    y = torch.empty((N, Cout, Ho, Wo), dtype=_F32, device=x.device)
+    partials = None
+    if want_stats:
+        T = int(_lib.load().pf_conv2d_blocks(Cout, Hi, Wi, ks, stride))
+        partials = torch.empty((N, T, Cout, 2), dtype=torch.float64, device=x.device)
+    sc, sh = in_affine if in_affine is not None else (None, None)
+    _lib.call("pf_conv2d_f32", _lib.ptr(x), _lib.ptr(wp), _lib.ptr(y), N, Cin, Cout, Hi, Wi, int(ks), int(stride),
+              _lib.ptr(sc), _lib.ptr(sh), int(samples_per_stat), _lib.ptr(partials), _lib.stream(),
+              algo_bytes=4.0 * N * (Cin * Hi * Wi + Cout * Ho * Wo) + 4.0 * ks * ks * Cin * Cout,
+              flops=2.0 * N * Ho * Wo * ks * ks * Cin * Cout)
+    return y, partials
+
+
+def channel_affine_(x, affine, relu, samples_per_stat):
+    """In place y = act(x*scale + shift) with (N/sps, C) affine rows."""
+    N, C = x.shape[:2]
+    S = x[0, 0].numel()
+    _lib.call("pf_channel_affine_f32", _lib.ptr(x), _lib.ptr(x), _lib.ptr(affine[0]), _lib.ptr(affine[1]), N, C, S,
+              int(samples_per_stat), int(bool(relu)), _lib.stream(), algo_bytes=8.0 * N * C * S)
+    return x
+
+
+def bn_affine_rows(x, bn, samples_per_stat, partials=None):
+    """(scale, shift) rows (N/sps, C) of BatchNorm ``bn`` for the raw conv output x (N,C,*spatial): batch
+    statistics from ``partials`` (or a statistics pass over x) in train mode, running statistics in eval."""
+    N, C = x.shape[:2]
+    S = x[0, 0].numel()
+    G = N // samples_per_stat
+    dev = x.device
+    if bn.training or not bn.track_running_stats:
+        if partials is None:
+            T = int(_lib.load().pf_norm_blocks(S))
+            partials = torch.empty((N, T, C, 2), dtype=torch.float64, device=dev)
+            _lib.call("pf_channel_stats_f32", _lib.ptr(x), N, C, S, _lib.ptr(partials), _lib.stream(),
+                      algo_bytes=4.0 * N * C * S)
+        scale = torch.empty((G, C), dtype=_F32, device=dev)
+        shift = torch.empty((G, C), dtype=_F32, device=dev)
+        n = float(samples_per_stat) * S
+        bn_affine(bn, partials, 0, C, n, n, N, samples_per_stat, scale, shift)
+        bump_counter(bn, G)
+        return scale, shift
+    sc, sh = eval_affine(bn, G, C)
+    return sc.unsqueeze(0).expand(G, C).contiguous(), sh.unsqueeze(0).expand(G, C).contiguous()
+
+
 def conv3d_k3_few(x, weight):
     """3x3x3 / pad 1 / stride 1 conv3d with <= 4 output channels (pf_conv3d_k3_few_f32)."""
     N, Cin, D, H, W = x.shape

@@ -442,7 +442,8 @@ def test_image_conv_batched_views_equals_per_view_calls(dev):
         per_view = [a(imgs[:, v].to(dev)) for v in range(3)]               # reference call pattern (model.py:71-77)
         fused = b.forward_views(imgs.to(dev))
         pointflow.flush_counters()
-    for name in ("conv0", "conv1", "conv2", "conv3"):
+    assert "conv0" not in fused                        # never consumed by the model: not materialised
+    for name in ("conv1", "conv2", "conv3"):
         want = torch.stack([pv[name] for pv in per_view], dim=1)
         err = _maxabs(fused[name], want)
         report("image_conv_views_" + name, err=err, scale=float(want.abs().max()))
@@ -501,3 +502,36 @@ def test_conv3d_k3_few_vs_fp64(dev, N, Cin, Cout, D, H, W):
     err = _maxabs(y, ref)
     report("conv3d_few_%d_%d" % (Cin, Cout), err=err, scale=float(ref.abs().max()))
     assert err < 3e-6 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,ks,stride", [(3, 3, 8, 64, 96, 3, 1), (3, 8, 8, 40, 56, 3, 1),
+                                                       (2, 8, 16, 64, 96, 5, 2), (3, 16, 16, 33, 47, 3, 1),
+                                                       (1, 16, 32, 31, 45, 5, 2), (3, 32, 32, 16, 20, 3, 1),
+                                                       (3, 32, 64, 32, 40, 5, 2), (3, 64, 64, 16, 20, 3, 1),
+                                                       (1, 12, 40, 9, 17, 3, 1), (3, 8, 8, 512, 640, 3, 1)])
+@pytest.mark.parametrize("affine", [False, True])
+def test_conv2d_vs_fp64(dev, N, Cin, Cout, H, W, ks, stride, affine):
+    gen = torch.Generator().manual_seed(N * 1000 + Cin + Cout + H * W)
+    x = torch.randn(N, Cin, H, W, generator=gen)
+    conv = torch.nn.Conv2d(Cin, Cout, ks, stride=stride, padding=ks // 2, bias=False)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=gen) / (ks * ks * Cin) ** 0.5)
+    sps = 1
+    sc = torch.rand(N, Cin, generator=gen) + 0.5
+    sh = torch.randn(N, Cin, generator=gen) * 0.3
+    xin = x.double()
+    if affine:
+        xin = torch.relu(xin * sc.double().view(N, Cin, 1, 1) + sh.double().view(N, Cin, 1, 1))
+    ref = F.conv2d(xin, conv.weight.double(), None, stride, ks // 2)
+    conv = conv.to(dev)
+    assert pointflow.conv2d_supported(conv)
+    aff = (sc.to(dev), sh.to(dev)) if affine else None
+    y, part = pointflow.conv2d(x.to(dev), conv, aff, sps, True)
+    assert y.shape == ref.shape
+    scale = float(ref.abs().max())
+    err = _maxabs(y, ref)
+    report("conv2d_%d_%d_k%d_aff%d" % (Cin, Cout, ks, int(affine)), err=err, scale=scale)
+    assert err < 3e-6 * scale * max(1.0, (ks * ks * Cin / 256.0) ** 0.5)
+    sums = part.sum(dim=1).cpu()
+    assert torch.allclose(sums[..., 0], ref.sum(dim=(2, 3)), rtol=1e-5, atol=1e-4 * scale)
+    assert torch.allclose(sums[..., 1], (ref ** 2).sum(dim=(2, 3)), rtol=1e-5)
