@@ -220,7 +220,7 @@ int pf_conv3d_k3_few_f32(const float* x, const float* w, float* y, int64_t N, in
  * activation is never written to memory.  wp = weights packed as (ceil(Cin/4), K*K, 4, NCP) zero padded,
  * NCP = 16, 32 or 64 (>= Cout).  partials (N, pf_conv2d_blocks(...), Cout, 2) float64 or NULL receives
  * the BatchNorm statistics of y; samples_per_stat consecutive samples share in_scale rows. */
-int pf_conv2d_blocks(int64_t Cout, int64_t Hi, int64_t Wi, int kernel_size, int stride);
+int pf_conv2d_blocks(int64_t N, int64_t Cout, int64_t Hi, int64_t Wi, int kernel_size, int stride);
 int pf_conv2d_f32(const float* x, const float* wp, float* y, int64_t N, int64_t Cin, int64_t Cout, int64_t Hi,
                   int64_t Wi, int kernel_size, int stride, const float* in_scale, const float* in_shift,
                   int samples_per_stat, double* partials, void* stream);

@@ -35,7 +35,7 @@ PROTOTYPES = {
     "pf_conv3d_blocks": ([_i64, _i64, _i64, _i64, _i64, _i], _i),
     "pf_conv3d_k3_f32": ([_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i, _vp, _vp], _i),
     "pf_conv3d_k3_few_f32": ([_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp], _i),
-    "pf_conv2d_blocks": ([_i64, _i64, _i64, _i, _i], _i),
+    "pf_conv2d_blocks": ([_i64, _i64, _i64, _i64, _i, _i], _i),
     "pf_conv2d_f32": ([_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i, _i, _vp, _vp, _i, _vp, _vp], _i),
     "pf_norm_blocks": ([_i64], _i),
     "pf_channel_stats_f32": ([_vp, _i64, _i64, _i64, _vp, _vp], _i),

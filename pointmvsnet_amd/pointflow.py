@@ -187,7 +187,7 @@ def conv2d(x, conv, in_affine, samples_per_stat, want_stats):
     y = torch.empty((N, Cout, Ho, Wo), dtype=_F32, device=x.device)
     partials = None
     if want_stats:
-        T = int(_lib.load().pf_conv2d_blocks(Cout, Hi, Wi, ks, stride))
+        T = int(_lib.load().pf_conv2d_blocks(N, Cout, Hi, Wi, ks, stride))
         partials = torch.empty((N, T, Cout, 2), dtype=torch.float64, device=x.device)
     sc, sh = in_affine if in_affine is not None else (None, None)
     _lib.call("pf_conv2d_f32", _lib.ptr(x), _lib.ptr(wp), _lib.ptr(y), N, Cin, Cout, Hi, Wi, int(ks), int(stride),
