@@ -164,7 +164,7 @@ def _conv2d_block_fused(block, x, pending, samples_per_stat):
     """One tower block on raw activations: returns (raw conv output, pending BN+ReLU affine or None)."""
     conv, bn, relu = (block.conv, block.bn, block.relu) if hasattr(block, "bn") else (block, None, False)
     training_bn = bn is not None and (bn.training or not bn.track_running_stats)
-    if pointflow.conv2d_supported(conv):
+    if pointflow.conv2d_preferred(conv):
         y, partials = pointflow.conv2d(x, conv, pending, samples_per_stat, training_bn)
     else:
         if pending is not None:

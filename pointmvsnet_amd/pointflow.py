@@ -150,6 +150,15 @@ def conv2d_supported(conv):
     return k3 or k5
 
 
+def conv2d_preferred(conv):
+    """Measured policy (profiles/r01c): the f32-MFMA conv2d beats the library's Winograd kernel plus the
+    separate BatchNorm statistics / normalise passes only for the 3x3 layers with 17..32 output channels
+    (36 us vs 40 + 14 us); at 8/16 channels the 16x16x4 tile is half empty and instruction-bound, and the
+    64-channel layers (64x80 maps) are too small to fill the chip with 128-pixel tiles.  Everything else
+    stays on the library convolution + the HIP BatchNorm kernels until those kernels are reworked."""
+    return conv2d_supported(conv) and conv.kernel_size == (3, 3) and 16 < conv.out_channels <= 32
+
+
 def _conv2d_ncp(cout):
     nt = (cout + 15) // 16
     return 16 * (4 if nt == 3 else nt)
