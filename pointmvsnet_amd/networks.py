@@ -148,20 +148,24 @@ class ImageConv(nn.Module):
         B, V = img_list.shape[:2]
         x = img_list.transpose(0, 1).reshape(V * B, *img_list.shape[2:]).float().contiguous()   # view-major
         pending = None                      # (scale, shift) of a BatchNorm+ReLU not yet applied to x
+        blocks = [(name, blk) for name in ("conv0", "conv1", "conv2", "conv3") for blk in getattr(self, name)]
         out = {}
-        for name in ("conv0", "conv1", "conv2", "conv3"):
-            for block in getattr(self, name):
-                x, pending = _conv2d_block_fused(block, x, pending, B)
-            if name != "conv0":
-                if pending is not None:
-                    x = pointflow.channel_affine_(x, pending, True, B)
-                    pending = None
+        for i, (name, block) in enumerate(blocks):
+            stage_end = i + 1 == len(blocks) or blocks[i + 1][0] != name
+            nxt = blocks[i + 1][1] if i + 1 < len(blocks) else None
+            # the BN+ReLU of this block can stay pending only if the next conv applies it while staging
+            defer = (not (stage_end and name != "conv0")) and nxt is not None and \
+                pointflow.conv2d_preferred(nxt.conv if hasattr(nxt, "bn") else nxt)
+            x, pending = _conv2d_block_fused(block, x, pending, B, defer)
+            if stage_end and name != "conv0":
                 out[name] = x.view(V, B, *x.shape[1:]).transpose(0, 1)
         return out
 
 
-def _conv2d_block_fused(block, x, pending, samples_per_stat):
-    """One tower block on raw activations: returns (raw conv output, pending BN+ReLU affine or None)."""
+def _conv2d_block_fused(block, x, pending, samples_per_stat, defer):
+    """One tower block.  ``pending``: BN+ReLU affine rows not yet applied to x.  Returns (y, pending'): with
+    ``defer`` the block's own BatchNorm+ReLU is returned as affine rows for the next (custom) conv to apply
+    while staging; otherwise y is normalised in place (statistics + fused finalize/normalise)."""
     conv, bn, relu = (block.conv, block.bn, block.relu) if hasattr(block, "bn") else (block, None, False)
     training_bn = bn is not None and (bn.training or not bn.track_running_stats)
     if pointflow.conv2d_preferred(conv):
@@ -169,13 +173,13 @@ def _conv2d_block_fused(block, x, pending, samples_per_stat):
     else:
         if pending is not None:
             x = pointflow.channel_affine_(x, pending, True, samples_per_stat)
-        y, partials = block._crop(conv(x), x).contiguous() if hasattr(block, "_crop") else conv(x).contiguous(), None
+        y = block._crop(conv(x), x).contiguous() if hasattr(block, "_crop") else conv(x).contiguous()
+        partials = None
     if bn is None:
         return (F.relu(y, inplace=True) if relu else y), None
-    affine = pointflow.bn_affine_rows(y, bn, samples_per_stat, partials)
-    if relu:
-        return y, affine
-    return pointflow.channel_affine_(y, affine, False, samples_per_stat), None
+    if defer and relu:
+        return y, pointflow.bn_affine_rows(y, bn, samples_per_stat, partials)
+    return pointflow.batch_norm_act_(y, bn, relu, samples_per_stat, partials=partials), None
 
 
 class VolumeConv(nn.Module):
