@@ -216,7 +216,33 @@ __global__ __launch_bounds__(256, 2) void pointwise_gemm_kernel(
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
-template <int C>
+// Neighbour rows of one point, all in flight at once.  With k known at compile time the 16 indices come
+// in as 8 sixteen-byte loads and the 16 row loads are issued back to back; the runtime-k loop below would
+// otherwise serialise index load -> address -> row load once per neighbour (two dependent global
+// latencies x 16 per point: the kernels were latency-bound at ~1/6 of their L2 rate).
+template <int C, int K>
+__device__ __forceinline__ void gather_rows(const float* __restrict__ LE, int64_t ldle, const int64_t* __restrict__ ip,
+                                            int64_t gbase, int Ng, int q, float4 (&e)[K], bool& bad) {
+  long long ii[K];
+  static_assert(K % 2 == 0, "K must be even");
+#pragma unroll
+  for (int j = 0; j < K / 2; ++j) {
+    const longlong2 v = *reinterpret_cast<const longlong2*>(ip + 2 * j);
+    ii[2 * j] = v.x;
+    ii[2 * j + 1] = v.y;
+  }
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    long long i = ii[j];
+    if (i < 0 || i >= Ng) {
+      bad = true;
+      i = i < 0 ? 0 : Ng - 1;
+    }
+    e[j] = ld4(LE + (gbase + i) * ldle + C + 4 * q);
+  }
+}
+
+template <int C, int K>   // K == 0: neighbour count known only at run time
 __global__ __launch_bounds__(256) void edge_stats_kernel(const float* __restrict__ LE, int64_t ldle,
                                                          const int64_t* __restrict__ idx, int k, int Ng,
                                                          double* __restrict__ partials, int T,
@@ -228,31 +254,45 @@ __global__ __launch_bounds__(256) void edge_stats_kernel(const float* __restrict
   const int q = tid % Q, pl = tid / Q;
   const int g = blockIdx.y, tb = blockIdx.x;
   const int tiles = (Ng + TILE - 1) / TILE;
+  const int64_t gbase = (int64_t)g * Ng;
   double ds[4] = {0, 0, 0, 0}, dq[4] = {0, 0, 0, 0};
+  bool bad = false;
   for (int tile = tb; tile < tiles; tile += T) {
     const int n0 = tile * TILE;
     for (int p = pl; p < TILE; p += PPB) {
       const int n = n0 + p;
       if (n >= Ng) break;
-      const int64_t row = (int64_t)g * Ng + n;
+      const int64_t row = gbase + n;
       const float4 l = ld4(LE + row * ldle + 4 * q);
       const int64_t* ip = idx + row * k;
       float4 s = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
-      for (int j = 0; j < k; ++j) {
-        int64_t i = ip[j];
-        if (i < 0 || i >= Ng) {
-          atomicOr(status, PF_STATUS_BAD_INDEX);
-          i = i < 0 ? 0 : Ng - 1;
+      if constexpr (K > 0) {
+        float4 e[K > 0 ? K : 1];
+        gather_rows<C, (K > 0 ? K : 2)>(LE, ldle, ip, gbase, Ng, q, e, bad);
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+          const float dx = e[j].x - l.x, dy = e[j].y - l.y, dz = e[j].z - l.z, dw = e[j].w - l.w;
+          s.x += dx; s.y += dy; s.z += dz; s.w += dw;
+          s2.x += dx * dx; s2.y += dy * dy; s2.z += dz * dz; s2.w += dw * dw;
         }
-        const float4 e = ld4(LE + ((int64_t)g * Ng + i) * ldle + C + 4 * q);
-        const float dx = e.x - l.x, dy = e.y - l.y, dz = e.z - l.z, dw = e.w - l.w;
-        s.x += dx; s.y += dy; s.z += dz; s.w += dw;
-        s2.x += dx * dx; s2.y += dy * dy; s2.z += dz * dz; s2.w += dw * dw;
+      } else {
+        for (int j = 0; j < k; ++j) {
+          int64_t i = ip[j];
+          if (i < 0 || i >= Ng) {
+            bad = true;
+            i = i < 0 ? 0 : Ng - 1;
+          }
+          const float4 e = ld4(LE + (gbase + i) * ldle + C + 4 * q);
+          const float dx = e.x - l.x, dy = e.y - l.y, dz = e.z - l.z, dw = e.w - l.w;
+          s.x += dx; s.y += dy; s.z += dz; s.w += dw;
+          s2.x += dx * dx; s2.y += dy * dy; s2.z += dz * dz; s2.w += dw * dw;
+        }
       }
       ds[0] += (double)s.x; ds[1] += (double)s.y; ds[2] += (double)s.z; ds[3] += (double)s.w;
       dq[0] += (double)s2.x; dq[1] += (double)s2.y; dq[2] += (double)s2.z; dq[3] += (double)s2.w;
     }
   }
+  if (bad) atomicOr(status, PF_STATUS_BAD_INDEX);
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     red[tid * 8 + c] = ds[c];
@@ -267,7 +307,7 @@ __global__ __launch_bounds__(256) void edge_stats_kernel(const float* __restrict
   }
 }
 
-template <int C>
+template <int C, int K>
 __global__ __launch_bounds__(256) void edge_apply_kernel(const float* __restrict__ LE, int64_t ldle,
                                                          const int64_t* __restrict__ idx, int k, int Ng,
                                                          const float* __restrict__ scale,
@@ -280,6 +320,7 @@ __global__ __launch_bounds__(256) void edge_apply_kernel(const float* __restrict
   const int q = tid % Q, pl = tid / Q;
   const int g = blockIdx.y, tb = blockIdx.x;
   const int tiles = (Ng + TILE - 1) / TILE;
+  const int64_t gbase = (int64_t)g * Ng;
   const int64_t so = (int64_t)(g / groups_per_stat) * ld_affine;
   const int doff = concat ? C : 0;
   const float4 dsc = ld4(scale + so + doff + 4 * q), dsh = ld4(shift + so + doff + 4 * q);
@@ -289,23 +330,36 @@ __global__ __launch_bounds__(256) void edge_apply_kernel(const float* __restrict
     csh = ld4(shift + so + 4 * q);
   }
   const float kf = (float)k;
+  bool bad = false;
   for (int tile = tb; tile < tiles; tile += T) {
     const int n0 = tile * TILE;
     for (int p = pl; p < TILE; p += PPB) {
       const int n = n0 + p;
       if (n >= Ng) break;
-      const int64_t row = (int64_t)g * Ng + n;
+      const int64_t row = gbase + n;
       const float4 l = ld4(LE + row * ldle + 4 * q);
       const int64_t* ip = idx + row * k;
       float4 a = {0, 0, 0, 0};
-      for (int j = 0; j < k; ++j) {
-        int64_t i = ip[j];
-        i = i < 0 ? 0 : (i >= Ng ? Ng - 1 : i);
-        const float4 e = ld4(LE + ((int64_t)g * Ng + i) * ldle + C + 4 * q);
-        a.x += fmaxf(fmaf(e.x - l.x, dsc.x, dsh.x), 0.0f);
-        a.y += fmaxf(fmaf(e.y - l.y, dsc.y, dsh.y), 0.0f);
-        a.z += fmaxf(fmaf(e.z - l.z, dsc.z, dsh.z), 0.0f);
-        a.w += fmaxf(fmaf(e.w - l.w, dsc.w, dsh.w), 0.0f);
+      if constexpr (K > 0) {
+        float4 e[K > 0 ? K : 1];
+        gather_rows<C, (K > 0 ? K : 2)>(LE, ldle, ip, gbase, Ng, q, e, bad);
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+          a.x += fmaxf(fmaf(e[j].x - l.x, dsc.x, dsh.x), 0.0f);
+          a.y += fmaxf(fmaf(e[j].y - l.y, dsc.y, dsh.y), 0.0f);
+          a.z += fmaxf(fmaf(e[j].z - l.z, dsc.z, dsh.z), 0.0f);
+          a.w += fmaxf(fmaf(e[j].w - l.w, dsc.w, dsh.w), 0.0f);
+        }
+      } else {
+        for (int j = 0; j < k; ++j) {
+          int64_t i = ip[j];
+          i = i < 0 ? 0 : (i >= Ng ? Ng - 1 : i);
+          const float4 e = ld4(LE + (gbase + i) * ldle + C + 4 * q);
+          a.x += fmaxf(fmaf(e.x - l.x, dsc.x, dsh.x), 0.0f);
+          a.y += fmaxf(fmaf(e.y - l.y, dsc.y, dsh.y), 0.0f);
+          a.z += fmaxf(fmaf(e.z - l.z, dsc.z, dsh.z), 0.0f);
+          a.w += fmaxf(fmaf(e.w - l.w, dsc.w, dsh.w), 0.0f);
+        }
       }
       float4 yd = {a.x / kf, a.y / kf, a.z / kf, a.w / kf};
       float* yo = Y + row * ldy + 4 * q;
@@ -319,6 +373,7 @@ __global__ __launch_bounds__(256) void edge_apply_kernel(const float* __restrict
       }
     }
   }
+  (void)bad;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -535,12 +590,13 @@ int pf_edge_stats_f32(const float* LE, int64_t ldle, int C, const int64_t* idx, 
   const int T = pf_stat_blocks(G, Ng);
   dim3 grid((unsigned)T, (unsigned)G);
   hipStream_t s = (hipStream_t)stream;
-  if (C == 32)
-    hipLaunchKernelGGL(edge_stats_kernel<32>, grid, dim3(256), 0, s, LE, ldle, idx, k, Ng, partials, T, status);
-  else if (C == 64)
-    hipLaunchKernelGGL(edge_stats_kernel<64>, grid, dim3(256), 0, s, LE, ldle, idx, k, Ng, partials, T, status);
-  else
-    hipLaunchKernelGGL(edge_stats_kernel<128>, grid, dim3(256), 0, s, LE, ldle, idx, k, Ng, partials, T, status);
+#define PF_ES(CV, KV) hipLaunchKernelGGL((edge_stats_kernel<CV, KV>), grid, dim3(256), 0, s, LE, ldle, idx, k, Ng, partials, T, status)
+  if (k == 16) {
+    if (C == 32) PF_ES(32, 16); else if (C == 64) PF_ES(64, 16); else PF_ES(128, 16);
+  } else {
+    if (C == 32) PF_ES(32, 0); else if (C == 64) PF_ES(64, 0); else PF_ES(128, 0);
+  }
+#undef PF_ES
   return pf_launch_status();
 }
 
@@ -572,15 +628,15 @@ int pf_edge_apply_f32(const float* LE, int64_t ldle, int C, const int64_t* idx, 
   const int T = pf_stat_blocks(G, Ng);
   dim3 grid((unsigned)T, (unsigned)G);
   hipStream_t s = (hipStream_t)stream;
-  if (C == 32)
-    hipLaunchKernelGGL(edge_apply_kernel<32>, grid, dim3(256), 0, s, LE, ldle, idx, k, Ng, scale, shift, ld_affine,
-                       groups_per_stat, concat, Y, ldy, T);
-  else if (C == 64)
-    hipLaunchKernelGGL(edge_apply_kernel<64>, grid, dim3(256), 0, s, LE, ldle, idx, k, Ng, scale, shift, ld_affine,
-                       groups_per_stat, concat, Y, ldy, T);
-  else
-    hipLaunchKernelGGL(edge_apply_kernel<128>, grid, dim3(256), 0, s, LE, ldle, idx, k, Ng, scale, shift,
-                       ld_affine, groups_per_stat, concat, Y, ldy, T);
+#define PF_EA(CV, KV)                                                                                         \
+  hipLaunchKernelGGL((edge_apply_kernel<CV, KV>), grid, dim3(256), 0, s, LE, ldle, idx, k, Ng, scale, shift, \
+                     ld_affine, groups_per_stat, concat, Y, ldy, T)
+  if (k == 16) {
+    if (C == 32) PF_EA(32, 16); else if (C == 64) PF_EA(64, 16); else PF_EA(128, 16);
+  } else {
+    if (C == 32) PF_EA(32, 0); else if (C == 64) PF_EA(64, 0); else PF_EA(128, 0);
+  }
+#undef PF_EA
   return pf_launch_status();
 }
 

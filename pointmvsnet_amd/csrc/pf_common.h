@@ -35,9 +35,9 @@ static inline int64_t pf_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // nw = (1-wy)(1-wx) ..., out = ((nw*a + ne*b) + sw*c) + se*d.  Compiled with -ffp-contract=off so the
 // products/sums below stay separate unless written as fmaf.
 struct PfTaps {
-  int off[4];     // y*W + x of the nw, ne, sw, se taps (0 when the tap is outside the map)
-  float wgt[4];   // bilinear weights
-  bool ok[4];     // tap inside the map
+  int off[4];     // y*W + x of the nw, ne, sw, se taps; 0 (a valid address) when the tap is outside the map
+  float wgt[4];   // bilinear weights; exactly 0 for a tap outside the map (zero padding)
+  bool ok[4];     // tap inside the map (only the backward scatter needs it)
 };
 
 __device__ __forceinline__ void pf_project_taps(float X, float Y, float Z, const float* __restrict__ Kv,
@@ -74,16 +74,20 @@ __device__ __forceinline__ void pf_project_taps(float X, float Y, float Z, const
   t.off[1] = t.ok[1] ? yi * W + xi + 1 : 0;
   t.off[2] = t.ok[2] ? (yi + 1) * W + xi : 0;
   t.off[3] = t.ok[3] ? (yi + 1) * W + xi + 1 : 0;
-  t.wgt[0] = wy0 * wx0;
-  t.wgt[1] = wy0 * wx1;
-  t.wgt[2] = wy1 * wx0;
-  t.wgt[3] = wy1 * wx1;
+  // zero weight == the reference's masked gather (value 0) times the weight: the term is +-0 either way.
+  // (Feature maps are finite activations; 0 * inf is not a case the reference can produce a number for.)
+  t.wgt[0] = t.ok[0] ? wy0 * wx0 : 0.0f;
+  t.wgt[1] = t.ok[1] ? wy0 * wx1 : 0.0f;
+  t.wgt[2] = t.ok[2] ? wy1 * wx0 : 0.0f;
+  t.wgt[3] = t.ok[3] ? wy1 * wx1 : 0.0f;
 }
 
+// Unconditional loads (outside taps read element 0 with weight 0): the compiler can issue the taps of
+// several views / channels back to back instead of one exec-masked branch per tap.
 __device__ __forceinline__ float pf_sample(const float* __restrict__ plane, const PfTaps& t) {
-  const float a = t.ok[0] ? plane[t.off[0]] : 0.0f;
-  const float b = t.ok[1] ? plane[t.off[1]] : 0.0f;
-  const float c = t.ok[2] ? plane[t.off[2]] : 0.0f;
-  const float d = t.ok[3] ? plane[t.off[3]] : 0.0f;
+  const float a = plane[t.off[0]];
+  const float b = plane[t.off[1]];
+  const float c = plane[t.off[2]];
+  const float d = plane[t.off[3]];
   return ((a * t.wgt[0] + b * t.wgt[1]) + c * t.wgt[2]) + d * t.wgt[3];
 }

@@ -535,3 +535,24 @@ def test_conv2d_vs_fp64(dev, N, Cin, Cout, H, W, ks, stride, affine):
     sums = part.sum(dim=1).cpu()
     assert torch.allclose(sums[..., 0], ref.sum(dim=(2, 3)), rtol=1e-5, atol=1e-4 * scale)
     assert torch.allclose(sums[..., 1], (ref ** 2).sum(dim=(2, 3)), rtol=1e-5)
+
+
+@pytest.mark.parametrize("concat,k", [(True, 5), (False, 8), (True, 16)])
+def test_edgeconv_fused_arbitrary_indices_vs_first_principles(dev, concat, k):
+    """The module API takes ANY (B,N,k) int64 indices (not only lattice windows) and any k."""
+    gen = torch.Generator().manual_seed(k)
+    B, cin, cout, N = 2, 24, 32, 301
+    x = torch.randn(B, cin, N, generator=gen)
+    idx = torch.randint(0, N, (B, N, k), generator=gen)
+    mod = (EdgeConv if concat else EdgeConvNoC)(cin, cout)
+    synthetic.seed_weights(mod, seed=4)
+    ref, _ = BF.edge_conv(x.numpy(), idx.numpy(), mod.conv1.weight[:, :, 0].detach().numpy(),
+                          mod.conv2.weight[:, :, 0].detach().numpy(), mod.bn.weight.detach().numpy(),
+                          mod.bn.bias.detach().numpy(), concat)
+    mod = mod.to(dev).train()
+    with torch.no_grad():
+        y = mod(x.to(dev), idx.to(dev))
+    err = float(np.abs(y.cpu().numpy() - ref).max())
+    report("edgeconv_arbitrary_k%d" % k, err=err)
+    assert err < 3e-5
+    assert _lib.status() == 0
