@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void flow_features_kernel(const float* __restr
   for (int level = 0; level < 3; ++level) {
     const float* maps = level == 0 ? maps1 : (level == 1 ? maps2 : maps3);
     const int cl = level == 0 ? c1 : (level == 1 ? c2 : c3);
-#pragma unroll 2
+#pragma unroll 4
     for (int c = 0; c < cl; ++c, ++ch) {
       float s = 0.0f, s2 = 0.0f;
 #pragma unroll

@@ -177,3 +177,28 @@ def test_graphed_forward_matches_eager_and_replays_on_new_scenes(dev):
     # warm-up (1) + capture (1: capture itself does not execute) + 2 replays worth of BN updates
     nbt = int(graphed_net.flow_mlp[0][0].bn.num_batches_tracked)
     assert nbt == (1 + 2) * 5, nbt
+
+
+@pytest.mark.parametrize("cfg", ["cfg1", "cfg3"])
+def test_other_baseline_configs_run_and_hold_properties(dev, cfg):
+    """BASELINE configs 1 (1 flow iteration) and 3 (1280x960, 5 views, 96 planes, 3 iterations incl. the
+    16-sub-grid scale 0.5): shapes, finiteness and the size-independent properties of the path."""
+    data, img_scales, inter_scales = synthetic.make_config(cfg, seed=2)
+    net = _model(dev)
+    with torch.no_grad():
+        preds = net(_to(data, dev), img_scales, inter_scales, isFlow=True, isTest=True)
+    H, W = data["img_list"].shape[3:]
+    cams = data["cam_params_list"]
+    interval = float(cams[0, 0, 1, 3, 1])
+    prev = preds["coarse_depth_map"]
+    assert prev.shape == (1, 1, H // 8, W // 8)
+    for it, (s, inter) in enumerate(zip(img_scales, inter_scales)):
+        cur = preds["flow%d" % (it + 1)]
+        assert cur.shape == (1, 1, int(H * s), int(W * s)) and torch.isfinite(cur).all()
+        p = preds["flow%d_prob" % (it + 1)]
+        assert torch.allclose(p.sum(dim=1), torch.ones_like(p[:, 0]), atol=1e-5)
+        up = torch.nn.functional.interpolate(prev, cur.shape[2:], mode="nearest")
+        assert float((cur - up).abs().max()) <= 2 * inter * interval * (1 + 1e-5)
+        prev = cur
+    from pointmvsnet_amd import _lib
+    assert _lib.status() == 0
