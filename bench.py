@@ -36,6 +36,18 @@ from pointmvsnet_amd import _lib, distributed, synthetic  # noqa: E402
 from pointmvsnet_amd.model import PointMVSNet  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_F32_PEAK_TF = 157.3         # same guide: dense f32-input MFMA peak (v_mfma_f32_32x32x2 / 16x16x4)
+
+
+def measured_traffic(entry):
+    """HBM bytes per launch of C-ABI entry point `entry` from the committed PMC passes
+    (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs; tools/pmc_to_traffic.py), or None."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        table = json.load(open(path))
+        return float(table["entries"][entry]["bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
 WORKLOAD_TEXT = {
     "cfg1": "cfg1: DTU 640x512 (160x128 depth grid), 3 views, 48 hypotheses, 1 flow iter",
     "cfg2": "cfg2: DTU 640x512, 3 source views, 48 depth hypotheses, 2 flow iters",
@@ -178,13 +190,24 @@ def main():
         s = timer.summary()[dominant]
         avg_s = s["ms"] / 1e3 / s["launches"]
         avg_bytes = s["bytes"] / s["launches"]
-        achieved = avg_bytes / avg_s / 1e9
-        roof = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": avg_s * 1e6,
-                "launches": s["launches"], "algorithmic_bytes_per_launch": avg_bytes,
-                "timed_in": "timed region" if execution == "eager" else "instrumented eager pass before the timed region"}
+        avg_flops = s["flops"] / s["launches"]
+        ridge = MFMA_F32_PEAK_TF * 1e12 / (HBM_PEAK_GBS * 1e9)              # flop per byte where the roofs meet
+        if avg_flops > 0 and avg_flops / max(avg_bytes, 1.0) > ridge:
+            achieved = avg_flops / avg_s / 1e12
+            roof = {"bound": "mfma", "kernel": dominant, "achieved": achieved, "peak": MFMA_F32_PEAK_TF,
+                    "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TF,
+                    "algorithmic_flops_per_launch": avg_flops}
+        else:
+            achieved = avg_bytes / avg_s / 1e9
+            roof = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS}
+        roof.update({"traffic": measured_traffic(dominant), "avg_launch_us": avg_s * 1e6,
+                     "launches": s["launches"], "algorithmic_bytes_per_launch": avg_bytes,
+                     "timed_in": "timed region" if execution == "eager"
+                     else "instrumented eager pass before the timed region"})
     kernels = {k: {"launches_per_step": v["launches"] / 2.0, "us_per_step": v["ms"] * 1e3 / 2.0,
-                   "algo_GBps": (v["bytes"] / (v["ms"] / 1e3) / 1e9) if v["ms"] > 0 else None}
+                   "algo_GBps": (v["bytes"] / (v["ms"] / 1e3) / 1e9) if v["ms"] > 0 else None,
+                   "algo_TFLOPs": (v["flops"] / (v["ms"] / 1e3) / 1e12) if v["ms"] > 0 and v["flops"] > 0 else None}
                for k, v in sorted(split.items(), key=lambda kv: -kv[1]["ms"])}
     result = {
         "metric": "depth-maps/sec (DTU 640x512, 3 src views, 2 flow iters)" if args.config == "cfg2"

@@ -24,6 +24,7 @@ timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/pmc_write
 cd $R
 python tools/pmc_summary.py gpurun_out/pmc_fetch/f_results.db gpurun_out/pmc_fetch.json
 python tools/pmc_summary.py gpurun_out/pmc_write/w_results.db gpurun_out/pmc_write.json
+python tools/pmc_to_traffic.py gpurun_out/pmc_fetch.json gpurun_out/pmc_write.json gpurun_out/pmc_traffic.json
 rm -rf gpurun_out/pmc_fetch gpurun_out/pmc_write
 fi
 tail -4 gpurun_out/pytest_gpu.log; tail -2 gpurun_out/smoke.log; tail -2 gpurun_out/bench.log | cut -c1-200

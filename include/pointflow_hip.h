@@ -225,6 +225,14 @@ int pf_conv2d_f32(const float* x, const float* wp, float* y, int64_t N, int64_t 
                   int64_t Wi, int kernel_size, int stride, const float* in_scale, const float* in_shift,
                   int samples_per_stat, double* partials, void* stream);
 
+/* Same contract as pf_conv2d_f32 for the few-channel layers (Cin <= 16, Cout = 8 or 16; 3x3/s1 or 5x5/s2),
+ * on plain float32 FMAs.  wp = weights packed as (ceil(Cin/4), 4, K, K, Cout), zero padded over channels.
+ * partials (N, pf_conv2d_small_blocks(...), Cout, 2). */
+int pf_conv2d_small_blocks(int64_t N, int64_t Hi, int64_t Wi, int kernel_size, int stride);
+int pf_conv2d_small_f32(const float* x, const float* wp, float* y, int64_t N, int64_t Cin, int64_t Cout, int64_t Hi,
+                        int64_t Wi, int kernel_size, int stride, const float* in_scale, const float* in_shift,
+                        int samples_per_stat, double* partials, void* stream);
+
 /* ---- rows M (last layer) + H + T : flow head ---------------------------------------------------
  * Z (G*Ng, ldz) holds the pre-BN output of the 64->16 MLP layer.  Per pixel of the (h,w) grid:
  * a = relu(Z*scale+shift); flow_d = sum_c w_out[c]*a_c for the 5 hypotheses; p = softmax(-flow);

@@ -37,6 +37,8 @@ PROTOTYPES = {
     "pf_conv3d_k3_few_f32": ([_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp], _i),
     "pf_conv2d_blocks": ([_i64, _i64, _i64, _i64, _i, _i], _i),
     "pf_conv2d_f32": ([_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i, _i, _vp, _vp, _i, _vp, _vp], _i),
+    "pf_conv2d_small_blocks": ([_i64, _i64, _i64, _i, _i], _i),
+    "pf_conv2d_small_f32": ([_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i, _i, _vp, _vp, _i, _vp, _vp], _i),
     "pf_norm_blocks": ([_i64], _i),
     "pf_channel_stats_f32": ([_vp, _i64, _i64, _i64, _vp, _vp], _i),
     "pf_channel_affine_f32": ([_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _vp], _i),
@@ -112,7 +114,7 @@ class KernelTimer(object):
 
     def __init__(self, only=None):
         self.only = only
-        self.records = []          # (name, start_event, end_event, algo_bytes)
+        self.records = []          # (name, start_event, end_event, algo_bytes, flops)
 
     def wants(self, name):
         return self.only is None or name == self.only
@@ -134,11 +136,12 @@ class KernelTimer(object):
         torch.cuda.synchronize()
         floor = self._pair_overhead_ms()
         out = {}
-        for name, e0, e1, nbytes in self.records:
-            s = out.setdefault(name, {"launches": 0, "ms": 0.0, "bytes": 0.0, "event_floor_ms": floor})
+        for name, e0, e1, nbytes, flops in self.records:
+            s = out.setdefault(name, {"launches": 0, "ms": 0.0, "bytes": 0.0, "flops": 0.0, "event_floor_ms": floor})
             s["launches"] += 1
             s["ms"] += max(e0.elapsed_time(e1) - floor, 0.0005)
             s["bytes"] += float(nbytes or 0)
+            s["flops"] += float(flops or 0)
         return out
 
 
@@ -154,7 +157,7 @@ def call(name, *args, **kw):
     """Invoke C-ABI entry point ``name`` and raise on a non-zero return.  ``algo_bytes`` (keyword) is the
     algorithmic HBM byte count of this launch, used only by KernelTimer."""
     algo_bytes = kw.pop("algo_bytes", None)
-    kw.pop("flops", None)
+    flops = kw.pop("flops", None)
     fn = getattr(load(), name)
     t = _timer
     if t is not None and t.wants(name):
@@ -163,7 +166,7 @@ def call(name, *args, **kw):
         e0.record()
         code = fn(*args)
         e1.record()
-        t.records.append((name, e0, e1, algo_bytes))
+        t.records.append((name, e0, e1, algo_bytes, flops))
     else:
         code = fn(*args)
     if code != 0:

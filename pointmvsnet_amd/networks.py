@@ -154,8 +154,9 @@ class ImageConv(nn.Module):
             stage_end = i + 1 == len(blocks) or blocks[i + 1][0] != name
             nxt = blocks[i + 1][1] if i + 1 < len(blocks) else None
             # the BN+ReLU of this block can stay pending only if the next conv applies it while staging
-            defer = (not (stage_end and name != "conv0")) and nxt is not None and \
-                pointflow.conv2d_preferred(nxt.conv if hasattr(nxt, "bn") else nxt)
+            nconv = None if nxt is None else (nxt.conv if hasattr(nxt, "bn") else nxt)
+            defer = (not (stage_end and name != "conv0")) and nconv is not None and \
+                (pointflow.conv2d_preferred(nconv) or pointflow.conv2d_small_preferred(nconv))
             x, pending = _conv2d_block_fused(block, x, pending, B, defer)
             if stage_end and name != "conv0":
                 out[name] = x.view(V, B, *x.shape[1:]).transpose(0, 1)
@@ -168,7 +169,9 @@ def _conv2d_block_fused(block, x, pending, samples_per_stat, defer):
     while staging; otherwise y is normalised in place (statistics + fused finalize/normalise)."""
     conv, bn, relu = (block.conv, block.bn, block.relu) if hasattr(block, "bn") else (block, None, False)
     training_bn = bn is not None and (bn.training or not bn.track_running_stats)
-    if pointflow.conv2d_preferred(conv):
+    if pointflow.conv2d_small_preferred(conv):
+        y, partials = pointflow.conv2d_small(x, conv, pending, samples_per_stat, training_bn)
+    elif pointflow.conv2d_preferred(conv):
         y, partials = pointflow.conv2d(x, conv, pending, samples_per_stat, training_bn)
     else:
         if pending is not None:

@@ -69,7 +69,8 @@ def pointwise_gemm(X, point_major, ldx, Wt, Y, ldy, G, Ng, K, nc_store, in_affin
     _lib.call("pf_pointwise_gemm_f32",
               _lib.ptr(X), int(bool(point_major)), int(ldx), _lib.ptr(Wt), _lib.ptr(Y), int(ldy), int(G), int(Ng),
               int(K), int(Nc), int(nc_store), _lib.ptr(sc), _lib.ptr(sh), int(groups_per_stat), _lib.ptr(partials),
-              _lib.stream(), algo_bytes=4.0 * G * Ng * (K + nc_store) + 4.0 * K * Nc)
+              _lib.stream(), algo_bytes=4.0 * G * Ng * (K + nc_store) + 4.0 * K * Nc,
+              flops=2.0 * G * Ng * K * nc_store)
     return partials
 
 
@@ -157,6 +158,50 @@ def conv2d_preferred(conv):
     64-channel layers (64x80 maps) are too small to fill the chip with 128-pixel tiles.  Everything else
     stays on the library convolution + the HIP BatchNorm kernels until those kernels are reworked."""
     return conv2d_supported(conv) and conv.kernel_size == (3, 3) and 16 < conv.out_channels <= 32
+
+
+def conv2d_small_preferred(conv):
+    """The few-channel layers (C_out 8 or 16, C_in <= 16) are HBM-bound: plain-FMA kernel (conv2d_small.hip)."""
+    return conv2d_supported(conv) and conv.out_channels in (8, 16) and conv.in_channels <= 16
+
+
+def pack_conv2d_small_weight(weight):
+    """(Cout,Cin,K,K) -> (ceil(Cin/4), 4, K, K, Cout) zero padded; cached per parameter object."""
+    import weakref
+    key = ("c2s", id(weight))
+    hit = _pack_cache.get(key)
+    if hit is not None and hit[0]() is weight and hit[1] == weight._version:
+        return hit[2]
+    cout, cin, k, _ = weight.shape
+    groups = (cin + 3) // 4
+    full = torch.zeros((groups * 4, k, k, cout), dtype=_F32, device=weight.device)
+    full[:cin] = weight.detach().to(_F32).permute(1, 2, 3, 0)
+    wp = full.view(groups, 4, k, k, cout).contiguous()
+    try:
+        _pack_cache[key] = (weakref.ref(weight), weight._version, wp)
+    except TypeError:
+        pass
+    return wp
+
+
+def conv2d_small(x, conv, in_affine, samples_per_stat, want_stats):
+    """Few-channel tower convolution (pf_conv2d_small_f32); same contract as conv2d()."""
+    N, Cin, Hi, Wi = x.shape
+    Cout = conv.out_channels
+    ks, stride = conv.kernel_size[0], conv.stride[0]
+    Ho, Wo = (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
+    wp = pack_conv2d_small_weight(conv.weight)
+    y = torch.empty((N, Cout, Ho, Wo), dtype=_F32, device=x.device)
+    partials = None
+    if want_stats:
+        T = int(_lib.load().pf_conv2d_small_blocks(N, Hi, Wi, ks, stride))
+        partials = torch.empty((N, T, Cout, 2), dtype=torch.float64, device=x.device)
+    sc, sh = in_affine if in_affine is not None else (None, None)
+    _lib.call("pf_conv2d_small_f32", _lib.ptr(x), _lib.ptr(wp), _lib.ptr(y), N, Cin, Cout, Hi, Wi, int(ks),
+              int(stride), _lib.ptr(sc), _lib.ptr(sh), int(samples_per_stat), _lib.ptr(partials), _lib.stream(),
+              algo_bytes=4.0 * N * (Cin * Hi * Wi + Cout * Ho * Wo) + 4.0 * ks * ks * Cin * Cout,
+              flops=2.0 * N * Ho * Wo * ks * ks * Cin * Cout)
+    return y, partials
 
 
 def _conv2d_ncp(cout):

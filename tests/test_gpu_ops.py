@@ -556,3 +556,33 @@ def test_edgeconv_fused_arbitrary_indices_vs_first_principles(dev, concat, k):
     report("edgeconv_arbitrary_k%d" % k, err=err)
     assert err < 3e-5
     assert _lib.status() == 0
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,ks,stride", [(3, 3, 8, 64, 96, 3, 1), (3, 8, 8, 40, 56, 3, 1),
+                                                       (2, 8, 16, 64, 96, 5, 2), (3, 16, 16, 33, 47, 3, 1),
+                                                       (1, 5, 8, 17, 70, 5, 2), (3, 8, 8, 512, 640, 3, 1)])
+@pytest.mark.parametrize("affine", [False, True])
+def test_conv2d_small_vs_fp64(dev, N, Cin, Cout, H, W, ks, stride, affine):
+    gen = torch.Generator().manual_seed(N * 1000 + Cin + Cout + H * W)
+    x = torch.randn(N, Cin, H, W, generator=gen)
+    conv = torch.nn.Conv2d(Cin, Cout, ks, stride=stride, padding=ks // 2, bias=False)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=gen) / (ks * ks * Cin) ** 0.5)
+    sc = torch.rand(N, Cin, generator=gen) + 0.5
+    sh = torch.randn(N, Cin, generator=gen) * 0.3
+    xin = x.double()
+    if affine:
+        xin = torch.relu(xin * sc.double().view(N, Cin, 1, 1) + sh.double().view(N, Cin, 1, 1))
+    ref = F.conv2d(xin, conv.weight.double(), None, stride, ks // 2)
+    conv = conv.to(dev)
+    assert pointflow.conv2d_small_preferred(conv)
+    aff = (sc.to(dev), sh.to(dev)) if affine else None
+    y, part = pointflow.conv2d_small(x.to(dev), conv, aff, 1, True)
+    assert y.shape == ref.shape
+    scale = float(ref.abs().max())
+    err = _maxabs(y, ref)
+    report("conv2d_small_%d_%d_k%d_aff%d" % (Cin, Cout, ks, int(affine)), err=err, scale=scale)
+    assert err < 3e-6 * scale * max(1.0, (ks * ks * Cin / 256.0) ** 0.5)
+    sums = part.sum(dim=1).cpu()
+    assert torch.allclose(sums[..., 0], ref.sum(dim=(2, 3)), rtol=1e-5, atol=1e-4 * scale)
+    assert torch.allclose(sums[..., 1], (ref ** 2).sum(dim=(2, 3)), rtol=1e-5)

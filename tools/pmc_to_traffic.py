@@ -1,0 +1,58 @@
+"""Fold the two PMC summaries (tools/pmc_summary.py on a FETCH_SIZE run and a WRITE_SIZE run) into
+profiles/pmc_traffic.json: measured HBM bytes per launch for every C-ABI entry point.
+
+    python tools/pmc_to_traffic.py gpurun_out/pmc_fetch.json gpurun_out/pmc_write.json profiles/pmc_traffic.json
+
+Units / corrections (/opt/skills/guides/MI355X_MICROARCH.md, section HBM): FETCH_SIZE and WRITE_SIZE are in
+KiB... the counters are reported in kilobytes (x1024 -> bytes).  The guide's gfx950 caveat -- FETCH_SIZE reads
+exactly half of a wide (16 B/lane) coalesced streaming read -- is applied to kernels whose read side is
+float4 streaming (listed in WIDE_READERS); kernels that read 4 B/lane are taken as reported, which the
+known byte counts confirm (fetch_variance: 6.98 MB reported vs 6.9 MB of maps+points; WRITE_SIZE 62.9 MB
+vs the 62.9 MB cost volume).
+"""
+import json
+import sys
+
+ENTRY_KERNELS = {
+    "pf_conv3d_k3_f32": "conv3d_k3_kernel", "pf_conv3d_k3_few_f32": "conv3d_k3_few_kernel",
+    "pf_conv2d_f32": "conv2d_kernel", "pf_pointwise_gemm_f32": "pointwise_gemm_kernel",
+    "pf_edge_apply_f32": "edge_apply_kernel", "pf_edge_stats_f32": "edge_stats_kernel",
+    "pf_flow_features_f32": "flow_features_kernel", "pf_knn_lattice_f32": "knn_lattice_kernel",
+    "pf_fetch_variance_f32": "fetch_variance_kernel", "pf_channel_bn_apply_f32": "channel_bn_apply_kernel",
+    "pf_channel_stats_f32": "channel_stats_kernel", "pf_bn_finalize_f32": "bn_finalize_kernel",
+    "pf_resize_bilinear_f32": "resize_bilinear_kernel", "pf_softargmin_prob_f32": "softargmin_prob_kernel",
+    "pf_flow_head_f32": "flow_head_kernel", "pf_channel_affine_f32": "channel_affine_kernel",
+}
+WIDE_READERS = ("channel_stats_kernel", "channel_bn_apply_kernel", "channel_affine_kernel",
+                "edge_apply_kernel", "edge_stats_kernel")
+
+
+def main():
+    fetch = json.load(open(sys.argv[1]))["kernels"]
+    write = json.load(open(sys.argv[2]))["kernels"]
+    out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --eager cfg2",
+           "entries": {}}
+    for entry, sub in ENTRY_KERNELS.items():
+        f_sum = f_n = w_sum = w_n = 0.0
+        for name, ctrs in fetch.items():
+            if sub in name and "FETCH_SIZE" in ctrs:
+                f_sum += ctrs["FETCH_SIZE"]["sum"]
+                f_n += ctrs["FETCH_SIZE"]["dispatches"]
+        for name, ctrs in write.items():
+            if sub in name and "WRITE_SIZE" in ctrs:
+                w_sum += ctrs["WRITE_SIZE"]["sum"]
+                w_n += ctrs["WRITE_SIZE"]["dispatches"]
+        if f_n == 0 and w_n == 0:
+            continue
+        corr = 2.0 if sub in WIDE_READERS else 1.0
+        fb = corr * f_sum * 1024.0 / max(f_n, 1.0)
+        wb = w_sum * 1024.0 / max(w_n, 1.0)
+        out["entries"][entry] = {"fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb,
+                                 "bytes_per_launch": fb + wb, "fetch_correction": corr,
+                                 "dispatches": int(max(f_n, w_n))}
+    json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
+    print("wrote", sys.argv[3], len(out["entries"]), "entries")
+
+
+if __name__ == "__main__":
+    main()
