@@ -6,8 +6,8 @@
 //
 //   * one lane = one output column, PPT output rows; all C_out accumulators in registers;
 //   * the block's input patch is staged in LDS four channels at a time (the previous layer's
-//     BatchNorm+ReLU applied on the way in, zero outside the image); the group's weights sit in LDS as
-//     [ch][kh][kw][C_out] and are read as 16-byte broadcasts, each reused for the PPT rows;
+//     BatchNorm+ReLU applied on the way in, zero outside the image); the group's weights are wave-uniform
+//     and come through the scalar cache ([ch][kh][kw][C_out], s_load into SGPRs), reused for the PPT rows;
 //   * stores are 128-byte row segments per channel straight from registers; per-channel sum / sum of
 //     squares are carried in registers across the block's tiles and reduced once (float64 partials).
 #include "pf_common.h"
@@ -30,7 +30,6 @@ __global__ __launch_bounds__(256) void conv2d_small_kernel(const float* __restri
   constexpr int PAD = KS / 2;
   constexpr int WSZ = 4 * KS * KS * COUT;
   __shared__ __attribute__((aligned(16))) float xs[4 * IH * IWP];
-  __shared__ __attribute__((aligned(16))) float ws[WSZ];
   __shared__ double red[4][2 * COUT];
   const int tid = threadIdx.x;
   const int col = tid & 31, row = tid >> 5;            // 32 columns x 8 rows of lanes
@@ -82,8 +81,10 @@ __global__ __launch_bounds__(256) void conv2d_small_kernel(const float* __restri
         for (int u = 0; u < U; ++u)
           if (lo[u] >= 0) xs[lo[u]] = v[u];
       }
-      for (int e = tid; e < WSZ; e += 256) ws[e] = wp[(int64_t)cg * WSZ + e];
       __syncthreads();
+      // Weights are wave-uniform: read them through the scalar cache into SGPRs (s_load) instead of LDS
+      // broadcasts -- with them in LDS the kernel was LDS-bandwidth bound (12 LDS cycles per 16 FMAs x 4 SIMDs).
+      const float* __restrict__ wg = wp + (int64_t)cg * WSZ;
 #pragma unroll
       for (int ch = 0; ch < 4; ++ch) {
 #pragma unroll
@@ -91,15 +92,8 @@ __global__ __launch_bounds__(256) void conv2d_small_kernel(const float* __restri
 #pragma unroll
           for (int kw = 0; kw < KS; ++kw) {
             float w[COUT];
-            const float4* wq = reinterpret_cast<const float4*>(ws + ((ch * KS + kh) * KS + kw) * COUT);
 #pragma unroll
-            for (int c4 = 0; c4 < COUT / 4; ++c4) {
-              const float4 t = wq[c4];
-              w[4 * c4 + 0] = t.x;
-              w[4 * c4 + 1] = t.y;
-              w[4 * c4 + 2] = t.z;
-              w[4 * c4 + 3] = t.w;
-            }
+            for (int c = 0; c < COUT; ++c) w[c] = wg[((ch * KS + kh) * KS + kw) * COUT + c];
 #pragma unroll
             for (int p = 0; p < PPT; ++p) {
               const float v = xs[(ch * IH + (row + 8 * p) * STRIDE + kh) * IWP + col * STRIDE + kw];
