@@ -14,8 +14,6 @@
 
 namespace {
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
 struct SmallGeom {
   int Cin, Hi, Wi, Ho, Wo, tiles_h, tiles_w, sps;
 };
@@ -52,13 +50,11 @@ __global__ __launch_bounds__(256) void conv2d_small_kernel(const float* __restri
     const int tw = item % g.tiles_w, th = item / g.tiles_w;
     const int oh0 = th * TR, ow0 = tw * TC;
     const int ih0 = oh0 * STRIDE - PAD, iw0 = ow0 * STRIDE - PAD;
-    // accumulators as float2 pairs of adjacent output channels: v_pk_fma_f32 does two FMAs per lane per
-    // instruction (SQ counters showed the scalar-FMA version VALU-bound for half of its run time)
-    f32x2 acc[PPT][COUT / 2];
+    float acc[PPT][COUT];
 #pragma unroll
     for (int p = 0; p < PPT; ++p)
 #pragma unroll
-      for (int c = 0; c < COUT / 2; ++c) acc[p][c] = (f32x2){0.0f, 0.0f};
+      for (int c = 0; c < COUT; ++c) acc[p][c] = 0.0f;
 
     // Staging issues U global loads back to back before their LDS stores: a one-load-one-store loop waits
     // out a full memory latency per element (10-37 of them per group; measured 42 us vs a 12 us HBM floor).
@@ -95,18 +91,14 @@ __global__ __launch_bounds__(256) void conv2d_small_kernel(const float* __restri
         for (int kh = 0; kh < KS; ++kh) {
 #pragma unroll
           for (int kw = 0; kw < KS; ++kw) {
-            f32x2 w[COUT / 2];
+            float w[COUT];
 #pragma unroll
-            for (int c = 0; c < COUT / 2; ++c) {
-              w[c].x = wg[((ch * KS + kh) * KS + kw) * COUT + 2 * c];
-              w[c].y = wg[((ch * KS + kh) * KS + kw) * COUT + 2 * c + 1];
-            }
+            for (int c = 0; c < COUT; ++c) w[c] = wg[((ch * KS + kh) * KS + kw) * COUT + c];
 #pragma unroll
             for (int p = 0; p < PPT; ++p) {
               const float v = xs[(ch * IH + (row + 8 * p) * STRIDE + kh) * IWP + col * STRIDE + kw];
-              const f32x2 vv = {v, v};
 #pragma unroll
-              for (int c = 0; c < COUT / 2; ++c) acc[p][c] = __builtin_elementwise_fma(vv, w[c], acc[p][c]);
+              for (int c = 0; c < COUT; ++c) acc[p][c] = fmaf(v, w[c], acc[p][c]);
             }
           }
         }
@@ -120,7 +112,7 @@ __global__ __launch_bounds__(256) void conv2d_small_kernel(const float* __restri
       if (oh < g.Ho && ow < g.Wo) {
 #pragma unroll
         for (int c = 0; c < COUT; ++c) {
-          const float v = (c & 1) ? acc[p][c >> 1].y : acc[p][c >> 1].x;
+          const float v = acc[p][c];
           yb[(int64_t)c * plane_o + (int64_t)oh * g.Wo + ow] = v;
           ssum[c] += v;
           ssq[c] += v * v;
