@@ -170,6 +170,7 @@ class PointMVSNet(nn.Module):
         )
         self._grid_cache = {}
         self._plan = None
+        self._side_stream = None
 
     # ------------------------------------------------------------------------------------------
     def _pixel_grid(self, h, w, device):
@@ -211,6 +212,22 @@ class PointMVSNet(nn.Module):
         dev = img_list.device
         preds = collections.OrderedDict()
 
+        # The flow tower depends only on the images: it runs on a second stream, concurrently with the whole
+        # coarse stage (tower, warp, VolumeConv, soft-argmin), and is joined before the first PointFlow
+        # iteration.  Most kernels here are far too small to fill 256 CUs alone; under hipGraph capture the
+        # fork/join becomes graph edges.
+        pyramids = None
+        main = torch.cuda.current_stream()
+        if isFlow:
+            if self._side_stream is None or self._side_stream.device != dev:
+                self._side_stream = torch.cuda.Stream(device=dev)
+            side = self._side_stream
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                pyramids = self.flow_img_conv.forward_views(img_list)
+                for p in pyramids.values():
+                    p.record_stream(main)
+
         # ---- coarse stage (reference model.py:71-130) -----------------------------------------
         feature_list = self.coarse_img_conv.forward_views(img_list)["conv3"].contiguous()   # (B,V,C,FH,FW)
         C, FH, FW = feature_list.shape[2:]
@@ -231,7 +248,7 @@ class PointMVSNet(nn.Module):
 
         # ---- flow stage (reference model.py:132-303) --------------------------------------------
         names = ("conv1", "conv2", "conv3")
-        pyramids = self.flow_img_conv.forward_views(img_list)
+        main.wait_stream(self._side_stream)
         for it, img_scale in enumerate(plan.img_scales):
             h, w = int(H * img_scale), int(W * img_scale)
             ratio = int(img_scale * 8) if (plan.is_test and img_scale != 0.125) else 1
