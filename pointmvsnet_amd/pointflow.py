@@ -91,6 +91,19 @@ def bn_affine(bn, partials, col0, C, count, unbias_n, G, groups_per_stat, scale,
               _lib.ptr(shift), int(scale.stride(0)), _lib.stream(), algo_bytes=16.0 * G * T * C)
 
 
+_side_streams = {}
+
+
+def side_stream(device, slot):
+    """A cached auxiliary stream (per device and slot) for independent kernel chains; fork with
+    ``s.wait_stream(current)``, join with ``current.wait_stream(s)`` -- graph edges under hipGraph capture."""
+    key = (str(device), slot)
+    st = _side_streams.get(key)
+    if st is None:
+        st = _side_streams[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 _pending_counters = []
 
 
@@ -351,7 +364,7 @@ def batch_norm_act_(x, bn, relu, samples_per_stat, partials=None):
 # EdgeConv (rows E0 / E1 / E2)
 # ---------------------------------------------------------------------------------------------
 def edge_conv_fused(X, point_major, ldx, K, G, Ng, idx, conv1_w, conv2_w, bn, concat, Y, ldy,
-                    groups_per_stat=1):
+                    groups_per_stat=1, join=None):
     """One EdgeConv / EdgeConvNoC layer on G groups of Ng points (reference networks.py:18-45, :56-81).
 
     X: channel-major (G,K,Ng) or point-major rows; idx (G,Ng,k) int64 group-local; Y: point-major view
@@ -368,6 +381,8 @@ def edge_conv_fused(X, point_major, ldx, K, G, Ng, idx, conv1_w, conv2_w, bn, co
     shift = torch.empty((S, cbn), dtype=_F32, device=dev)
     part_l = pointwise_gemm(X, point_major, ldx, Wt, LE, 2 * C, G, Ng, K, 2 * C,
                             groups_per_stat=groups_per_stat, want_stats=(concat and training))
+    if join is not None:                      # ``idx`` was produced on another stream (flow_chain)
+        torch.cuda.current_stream().wait_stream(join)
     if training:
         T = stat_blocks(G, Ng)
         part_d = torch.empty((G, T, C, 2), dtype=torch.float64, device=dev)
@@ -445,7 +460,13 @@ def flow_chain(feature, xyz, depth, interval, h, w, ratio, edge_convs, flow_mlp,
     dev = depth.device
     G, Cin, Ng = feature.shape
     hs, ws = h // ratio, w // ratio
-    idx = knn_lattice(xyz.view(G, 3, 5, hs, ws), 5, k)                     # (G, Ng, k), group-local
+    # the lattice kNN needs only xyz; the first EdgeConv GEMM needs only the features: run them concurrently
+    main = torch.cuda.current_stream()
+    aux = side_stream(dev, 1)
+    aux.wait_stream(main)
+    with torch.cuda.stream(aux):
+        idx = knn_lattice(xyz.view(G, 3, 5, hs, ws), 5, k)                 # (G, Ng, k), group-local
+        idx.record_stream(main)
 
     widths = []
     for m in edge_convs:
@@ -455,9 +476,10 @@ def flow_chain(feature, xyz, depth, interval, h, w, ratio, edge_convs, flow_mlp,
     edges = torch.empty((G * Ng, ctot), dtype=_F32, device=dev)            # the (N,224) concat buffer
     col = 0
     X, pm, ldx, K = feature, False, 0, Cin
-    for m, wdt in zip(edge_convs, widths):
+    for li, (m, wdt) in enumerate(zip(edge_convs, widths)):
         Y = edges[:, col:]
-        edge_conv_fused(X, pm, ldx, K, G, Ng, idx, m.conv1.weight, m.conv2.weight, m.bn, m.concat, Y, ctot)
+        edge_conv_fused(X, pm, ldx, K, G, Ng, idx, m.conv1.weight, m.conv2.weight, m.bn, m.concat, Y, ctot,
+                        join=(aux if li == 0 else None))
         X, pm, ldx, K = Y, True, ctot, wdt
         col += wdt
 
