@@ -218,7 +218,10 @@ class PointMVSNet(nn.Module):
         # fork/join becomes graph edges.
         pyramids = None
         main = torch.cuda.current_stream()
-        if isFlow:
+        side = None
+        if isFlow and pointflow.CONCURRENCY < 1:
+            pyramids = self.flow_img_conv.forward_views(img_list)
+        elif isFlow:
             if self._side_stream is None or self._side_stream.device != dev:
                 self._side_stream = torch.cuda.Stream(device=dev)
             side = self._side_stream
@@ -248,7 +251,8 @@ class PointMVSNet(nn.Module):
 
         # ---- flow stage (reference model.py:132-303) --------------------------------------------
         names = ("conv1", "conv2", "conv3")
-        main.wait_stream(self._side_stream)
+        if side is not None:
+            main.wait_stream(side)
         for it, img_scale in enumerate(plan.img_scales):
             h, w = int(H * img_scale), int(W * img_scale)
             ratio = int(img_scale * 8) if (plan.is_test and img_scale != 0.125) else 1

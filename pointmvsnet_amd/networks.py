@@ -212,12 +212,16 @@ class VolumeConv(nn.Module):
         f = lambda blk, t: _block_fused(blk, t, B)   # noqa: E731
         # the full-resolution branch (conv0_1, 69 % of the FLOPs) is independent of the encoder/decoder
         # chain of small layers until the final add: run it on an auxiliary stream
-        main = torch.cuda.current_stream()
-        aux = pointflow.side_stream(x.device, 2)
-        aux.wait_stream(main)
-        with torch.cuda.stream(aux):
+        aux = None
+        if pointflow.CONCURRENCY >= 3:
+            main = torch.cuda.current_stream()
+            aux = pointflow.side_stream(x.device, 2)
+            aux.wait_stream(main)
+            with torch.cuda.stream(aux):
+                full = f(self.conv0_1, x)
+                full.record_stream(main)
+        else:
             full = f(self.conv0_1, x)
-            full.record_stream(main)
         half = f(self.conv1_0, x)
         quarter = f(self.conv2_0, half)
         eighth = f(self.conv3_1, f(self.conv3_0, quarter))
@@ -226,7 +230,8 @@ class VolumeConv(nn.Module):
         up = f(self.conv4_0, eighth)
         up = f(self.conv5_0, up + quarter)
         up = f(self.conv6_0, up + half)
-        main.wait_stream(aux)
+        if aux is not None:
+            torch.cuda.current_stream().wait_stream(aux)
         return f(self.conv6_2, up + full)
 
     def forward(self, x):

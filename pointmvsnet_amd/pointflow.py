@@ -91,6 +91,12 @@ def bn_affine(bn, partials, col0, C, count, unbias_n, G, groups_per_stat, scale,
               _lib.ptr(shift), int(scale.stride(0)), _lib.stream(), algo_bytes=16.0 * G * T * C)
 
 
+import os as _os
+
+# Concurrency level (PF_CONCURRENCY): 0 = single stream; 1 = flow tower beside the coarse stage;
+# 2 = + lattice kNN beside the first EdgeConv GEMM; 3 = + conv0_1 beside the VolumeConv encoder/decoder.
+CONCURRENCY = int(_os.environ.get("PF_CONCURRENCY", "1"))
+
 _side_streams = {}
 
 
@@ -461,12 +467,16 @@ def flow_chain(feature, xyz, depth, interval, h, w, ratio, edge_convs, flow_mlp,
     G, Cin, Ng = feature.shape
     hs, ws = h // ratio, w // ratio
     # the lattice kNN needs only xyz; the first EdgeConv GEMM needs only the features: run them concurrently
-    main = torch.cuda.current_stream()
-    aux = side_stream(dev, 1)
-    aux.wait_stream(main)
-    with torch.cuda.stream(aux):
-        idx = knn_lattice(xyz.view(G, 3, 5, hs, ws), 5, k)                 # (G, Ng, k), group-local
-        idx.record_stream(main)
+    aux = None
+    if CONCURRENCY >= 2:
+        main = torch.cuda.current_stream()
+        aux = side_stream(dev, 1)
+        aux.wait_stream(main)
+        with torch.cuda.stream(aux):
+            idx = knn_lattice(xyz.view(G, 3, 5, hs, ws), 5, k)             # (G, Ng, k), group-local
+            idx.record_stream(main)
+    else:
+        idx = knn_lattice(xyz.view(G, 3, 5, hs, ws), 5, k)
 
     widths = []
     for m in edge_convs:
