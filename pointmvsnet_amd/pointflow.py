@@ -95,7 +95,7 @@ import os as _os
 
 # Concurrency level (PF_CONCURRENCY): 0 = single stream; 1 = flow tower beside the coarse stage;
 # 2 = + lattice kNN beside the first EdgeConv GEMM; 3 = + conv0_1 beside the VolumeConv encoder/decoder.
-CONCURRENCY = int(_os.environ.get("PF_CONCURRENCY", "1"))
+CONCURRENCY = int(_os.environ.get("PF_CONCURRENCY", "2"))
 
 _side_streams = {}
 
