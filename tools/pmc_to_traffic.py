@@ -3,19 +3,21 @@ profiles/pmc_traffic.json: measured HBM bytes per launch for every C-ABI entry p
 
     python tools/pmc_to_traffic.py gpurun_out/pmc_fetch.json gpurun_out/pmc_write.json profiles/pmc_traffic.json
 
-Units / corrections (/opt/skills/guides/MI355X_MICROARCH.md, section HBM): FETCH_SIZE and WRITE_SIZE are in
-KiB... the counters are reported in kilobytes (x1024 -> bytes).  The guide's gfx950 caveat -- FETCH_SIZE reads
-exactly half of a wide (16 B/lane) coalesced streaming read -- is applied to kernels whose read side is
-float4 streaming (listed in WIDE_READERS); kernels that read 4 B/lane are taken as reported, which the
-known byte counts confirm (fetch_variance: 6.98 MB reported vs 6.9 MB of maps+points; WRITE_SIZE 62.9 MB
-vs the 62.9 MB cost volume).
+Units / corrections (/opt/skills/guides/MI355X_MICROARCH.md, section HBM): rocprofv3 reports FETCH_SIZE and
+WRITE_SIZE in kilobytes (x1024 -> bytes).  The guide's gfx950 caveat -- FETCH_SIZE reads exactly half of a
+wide (16 B/lane) coalesced streaming read -- is applied to the kernels whose read side is a float4 stream
+(WIDE_READERS); the calibration on a known byte count that the guide asks for: channel_bn_apply reads and
+writes the same tensor and reports FETCH = 0.51 x WRITE.  Kernels that read 4 B/lane are taken as reported,
+which known byte counts confirm (fetch_variance: 6.98 MB reported vs 6.9 MB of maps + points; its WRITE_SIZE
+62.9 MB vs the 62.9 MB cost volume).  The 16-byte gathers of the EdgeConv passes are uncalibrated and taken
+as reported.
 """
 import json
 import sys
 
 ENTRY_KERNELS = {
     "pf_conv3d_k3_f32": "conv3d_k3_kernel", "pf_conv3d_k3_few_f32": "conv3d_k3_few_kernel",
-    "pf_conv2d_f32": "conv2d_kernel", "pf_pointwise_gemm_f32": "pointwise_gemm_kernel",
+    "pf_conv2d_f32": "conv2d_kernel", "pf_conv2d_small_f32": "conv2d_small_kernel", "pf_pointwise_gemm_f32": "pointwise_gemm_kernel",
     "pf_edge_apply_f32": "edge_apply_kernel", "pf_edge_stats_f32": "edge_stats_kernel",
     "pf_flow_features_f32": "flow_features_kernel", "pf_knn_lattice_f32": "knn_lattice_kernel",
     "pf_fetch_variance_f32": "fetch_variance_kernel", "pf_channel_bn_apply_f32": "channel_bn_apply_kernel",
@@ -23,8 +25,7 @@ ENTRY_KERNELS = {
     "pf_resize_bilinear_f32": "resize_bilinear_kernel", "pf_softargmin_prob_f32": "softargmin_prob_kernel",
     "pf_flow_head_f32": "flow_head_kernel", "pf_channel_affine_f32": "channel_affine_kernel",
 }
-WIDE_READERS = ("channel_stats_kernel", "channel_bn_apply_kernel", "channel_affine_kernel",
-                "edge_apply_kernel", "edge_stats_kernel")
+WIDE_READERS = ("channel_stats_kernel", "channel_bn_apply_kernel", "channel_affine_kernel")
 
 
 def main():
