@@ -202,3 +202,22 @@ def test_other_baseline_configs_run_and_hold_properties(dev, cfg):
         prev = cur
     from pointmvsnet_amd import _lib
     assert _lib.status() == 0
+
+
+def test_batch_of_two_scenes_vs_oracle(dev):
+    """B = 2: BatchNorm statistics of the towers / VolumeConv pool over the batch (one reference module call
+    sees both scenes), the PointFlow stage runs per scene.  Oracle on the same batch, CPU."""
+    data, img_scales, inter_scales = synthetic.make_scene(128, 192, 3, 8, seed=11, batch=2), (0.125, 0.25), (1.0, 0.75)
+    net = _model(dev)
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    with torch.no_grad():
+        preds = net(_to(data, dev), img_scales, inter_scales, isFlow=True, isTest=True)
+        ref = O.forward(sd, data, img_scales, inter_scales, True, True)
+    rel_c = float(((preds["coarse_depth_map"].cpu() - ref["coarse_depth_map"]).abs() / ref["coarse_depth_map"]).max())
+    report("batch2_coarse", rel_err=rel_c)
+    assert preds["coarse_depth_map"].shape == (2, 1, 16, 24) and rel_c < 1e-5
+    for key in ("flow1", "flow2"):
+        rel = (preds[key].cpu() - ref[key]).abs() / ref[key].abs()
+        report("batch2_" + key, rel_median=float(rel.median()), rel_max=float(rel.max()))
+        assert preds[key].shape == ref[key].shape
+        assert float(rel.median()) < 1e-4 and float(rel.max()) < 2e-2
