@@ -4,7 +4,7 @@
 // (profiles/r01c_last_step_dispatches.txt lines 41-49); an MFMA tile is half empty at 8 output channels and
 // instruction-bound (conv2d.hip).  So: plain float32 FMAs.
 //
-//   * one lane = one output column, PPT output rows; all C_out accumulators in registers;
+//   * one lane = one output column (30 per tile), PPT output rows; all C_out accumulators in registers;
 //   * the block's input patch is staged in LDS four channels at a time (the previous layer's
 //     BatchNorm+ReLU applied on the way in, zero outside the image); the group's weights are wave-uniform
 //     and come through the scalar cache ([ch][kh][kw][C_out], s_load into SGPRs), reused for the PPT rows;
@@ -18,21 +18,29 @@ struct SmallGeom {
   int Cin, Hi, Wi, Ho, Wo, tiles_h, tiles_w, sps;
 };
 
+constexpr int TC = 30;   // output columns per tile: the staged patch is then 32 (3x3/s1) or 63 (5x5/s2) floats wide
+
 template <int COUT, int KS, int STRIDE, int PPT>
 __global__ __launch_bounds__(256) void conv2d_small_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                            float* __restrict__ y, SmallGeom g,
                                                            const float* __restrict__ in_scale,
                                                            const float* __restrict__ in_shift,
                                                            double* __restrict__ partials) {
-  constexpr int TR = 8 * PPT, TC = 32;                 // output tile rows x cols
+  constexpr int TR = 8 * PPT;                          // output tile rows
   constexpr int IH = (TR - 1) * STRIDE + KS, IW = (TC - 1) * STRIDE + KS;
   constexpr int IWP = IW | 1;                          // odd row stride
   constexpr int PAD = KS / 2;
   constexpr int WSZ = 4 * KS * KS * COUT;
-  __shared__ __attribute__((aligned(16))) float xs[4 * IH * IWP];
+  constexpr int ROWS = 4 * IH;
+  constexpr int NXR = (ROWS + 7) / 8;                  // staged rows per lane-row (8 rows of 32 lanes per pass)
+  constexpr int XPASS = (IW + 31) / 32;
+  constexpr int XS = 4 * IH * IWP;
+  constexpr bool DB = 2 * XS * 4 <= 40 * 1024;         // double-buffer the patch when it is small enough
+  __shared__ __attribute__((aligned(16))) float xs[(DB ? 2 : 1) * XS];
   __shared__ double red[4][2 * COUT];
   const int tid = threadIdx.x;
   const int col = tid & 31, row = tid >> 5;            // 32 columns x 8 rows of lanes
+  const int ccol = col < TC ? col : 0;                 // lanes 30, 31 only help staging
   const int n = blockIdx.y;
   const int64_t plane_i = (int64_t)g.Hi * g.Wi, plane_o = (int64_t)g.Ho * g.Wo;
   const float* xb = x + (int64_t)n * g.Cin * plane_i;
@@ -45,46 +53,78 @@ __global__ __launch_bounds__(256) void conv2d_small_kernel(const float* __restri
 #pragma unroll
   for (int c = 0; c < COUT; ++c) ssum[c] = ssq[c] = 0.0f;
 
+  // Persistent block, flat sequence of (tile, channel group) steps; the NEXT step's patch is loaded into
+  // registers while the current one is computed, across tile boundaries too.  (SQ counters on the first
+  // version -- one tile per block, load / sync / compute / sync -- showed the VALU busy only 50 % of the
+  // time and 45 % of the wave cycles in s_waitcnt / barriers: profiles/r01d_conv2d_small_sq_counters_*.)
   const int total = g.tiles_h * g.tiles_w;
-  for (int item = blockIdx.x; item < total; item += gridDim.x) {
+  float rx[NXR * XPASS];
+  auto load_step = [&](int item, int cg) {
     const int tw = item % g.tiles_w, th = item / g.tiles_w;
-    const int oh0 = th * TR, ow0 = tw * TC;
-    const int ih0 = oh0 * STRIDE - PAD, iw0 = ow0 * STRIDE - PAD;
-    float acc[PPT][COUT];
+    const int ih0 = th * TR * STRIDE - PAD, iw0 = tw * TC * STRIDE - PAD;
 #pragma unroll
-    for (int p = 0; p < PPT; ++p)
-#pragma unroll
-      for (int c = 0; c < COUT; ++c) acc[p][c] = 0.0f;
-
-    // Staging issues U global loads back to back before their LDS stores: a one-load-one-store loop waits
-    // out a full memory latency per element (10-37 of them per group; measured 42 us vs a 12 us HBM floor).
-    constexpr int U = KS == 3 ? 5 : 8;
-    for (int cg = 0; cg < cgroups; ++cg) {
-      __syncthreads();                        // everyone is done reading the previous group from LDS
-      for (int e0 = tid; e0 < 4 * IH * IW; e0 += 256 * U) {
-        float v[U];
-        int lo[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int e = e0 + 256 * u;
-          const int ch = e / (IH * IW);
-          const int rem = e - ch * (IH * IW);
-          const int yy = rem / IW, xx = rem - yy * IW;
-          const int c = cg * 4 + ch, ih = ih0 + yy, iw = iw0 + xx;
-          const bool ok = e < 4 * IH * IW && c < g.Cin && ih >= 0 && ih < g.Hi && iw >= 0 && iw < g.Wi;
-          float t = ok ? xb[(int64_t)c * plane_i + (int64_t)ih * g.Wi + iw] : 0.0f;
-          if (sc != nullptr && ok) t = fmaxf(fmaf(t, sc[c], sh[c]), 0.0f);    // previous BatchNorm + ReLU
-          v[u] = t;
-          lo[u] = e < 4 * IH * IW ? (ch * IH + yy) * IWP + xx : -1;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-          if (lo[u] >= 0) xs[lo[u]] = v[u];
+    for (int r = 0; r < NXR; ++r) {
+      const int srow = r * 8 + row;
+      const int ch = srow / IH, yy = srow - ch * IH;
+      const int c = cg * 4 + ch, ih = ih0 + yy;
+      const bool rok = srow < ROWS && c < g.Cin && ih >= 0 && ih < g.Hi;
+      const float* src = xb + (int64_t)(rok ? c : 0) * plane_i + (int64_t)(rok ? ih : 0) * g.Wi;
+      float a = 1.0f, b = 0.0f;
+      if (sc != nullptr && rok) {
+        a = sc[c];
+        b = sh[c];
       }
-      __syncthreads();
-      // Weights are wave-uniform: read them through the scalar cache into SGPRs (s_load) instead of LDS
-      // broadcasts -- with them in LDS the kernel was LDS-bandwidth bound (12 LDS cycles per 16 FMAs x 4 SIMDs).
+#pragma unroll
+      for (int p = 0; p < XPASS; ++p) {
+        const int cc = col + 32 * p, iw = iw0 + cc;
+        const bool ok = rok && cc < IW && iw >= 0 && iw < g.Wi;
+        float v = ok ? src[iw] : 0.0f;
+        if (sc != nullptr && ok) v = fmaxf(fmaf(v, a, b), 0.0f);           // previous BatchNorm + ReLU
+        rx[r * XPASS + p] = v;
+      }
+    }
+  };
+  auto store_step = [&](int buf) {
+    float* dst = xs + buf * XS;
+#pragma unroll
+    for (int r = 0; r < NXR; ++r) {
+      const int srow = r * 8 + row;
+      if (srow < ROWS) {
+        const int ch = srow / IH, yy = srow - ch * IH;
+#pragma unroll
+        for (int p = 0; p < XPASS; ++p) {
+          const int cc = col + 32 * p;
+          if (cc < IW) dst[(ch * IH + yy) * IWP + cc] = rx[r * XPASS + p];
+        }
+      }
+    }
+  };
+
+  float acc[PPT][COUT];
+  int item = blockIdx.x, cg = 0, buf = 0;
+  if (item < total) {
+    load_step(item, 0);
+    store_step(0);
+  }
+  __syncthreads();
+  while (item < total) {
+    int n_item = item, n_cg = cg + 1;
+    if (n_cg == cgroups) {
+      n_cg = 0;
+      n_item = item + gridDim.x;
+    }
+    const bool has_next = n_item < total;
+    if (has_next) load_step(n_item, n_cg);               // in flight during the FMAs below
+    if (cg == 0) {
+#pragma unroll
+      for (int p = 0; p < PPT; ++p)
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) acc[p][c] = 0.0f;
+    }
+    {
+      // weights are wave-uniform: scalar cache -> SGPRs (in LDS the kernel was LDS-bandwidth bound)
       const float* __restrict__ wg = wp + (int64_t)cg * WSZ;
+      const float* xsb = xs + buf * XS;
 #pragma unroll
       for (int ch = 0; ch < 4; ++ch) {
 #pragma unroll
@@ -96,7 +136,7 @@ __global__ __launch_bounds__(256) void conv2d_small_kernel(const float* __restri
             for (int c = 0; c < COUT; ++c) w[c] = wg[((ch * KS + kh) * KS + kw) * COUT + c];
 #pragma unroll
             for (int p = 0; p < PPT; ++p) {
-              const float v = xs[(ch * IH + (row + 8 * p) * STRIDE + kh) * IWP + col * STRIDE + kw];
+              const float v = xsb[(ch * IH + (row + 8 * p) * STRIDE + kh) * IWP + ccol * STRIDE + kw];
 #pragma unroll
               for (int c = 0; c < COUT; ++c) acc[p][c] = fmaf(v, w[c], acc[p][c]);
             }
@@ -104,21 +144,29 @@ __global__ __launch_bounds__(256) void conv2d_small_kernel(const float* __restri
         }
       }
     }
-
-    const int ow = ow0 + col;
+    if (cg == cgroups - 1) {
+      const int tw = item % g.tiles_w, th = item / g.tiles_w;
+      const int ow = tw * TC + col;
 #pragma unroll
-    for (int p = 0; p < PPT; ++p) {
-      const int oh = oh0 + row + 8 * p;
-      if (oh < g.Ho && ow < g.Wo) {
+      for (int p = 0; p < PPT; ++p) {
+        const int oh = th * TR + row + 8 * p;
+        if (col < TC && oh < g.Ho && ow < g.Wo) {
 #pragma unroll
-        for (int c = 0; c < COUT; ++c) {
-          const float v = acc[p][c];
-          yb[(int64_t)c * plane_o + (int64_t)oh * g.Wo + ow] = v;
-          ssum[c] += v;
-          ssq[c] += v * v;
+          for (int c = 0; c < COUT; ++c) {
+            const float v = acc[p][c];
+            yb[(int64_t)c * plane_o + (int64_t)oh * g.Wo + ow] = v;
+            ssum[c] += v;
+            ssq[c] += v * v;
+          }
         }
       }
     }
+    if (!DB) __syncthreads();                             // single buffer: everyone is done reading it
+    if (has_next) store_step(DB ? (buf ^ 1) : 0);
+    __syncthreads();
+    item = n_item;
+    cg = n_cg;
+    if (DB) buf ^= 1;
   }
 
   if (partials != nullptr) {
@@ -144,9 +192,10 @@ __global__ __launch_bounds__(256) void conv2d_small_kernel(const float* __restri
   }
 }
 
+// Persistent blocks (about four per CU over the whole batch) so that every block streams several tiles.
 int small_blocks(int64_t Ho, int64_t Wo, int tr, int64_t N) {
-  const int64_t total = ((Ho + tr - 1) / tr) * ((Wo + 31) / 32);
-  int64_t cap = 2048 / (N < 1 ? 1 : N);
+  const int64_t total = ((Ho + tr - 1) / tr) * ((Wo + TC - 1) / TC);
+  int64_t cap = 1024 / (N < 1 ? 1 : N);
   cap = cap < 64 ? 64 : cap;
   return (int)(total < cap ? total : cap);
 }
@@ -156,7 +205,7 @@ int launch_small(const float* x, const float* wp, float* y, SmallGeom g, int64_t
                  const float* in_shift, double* partials, hipStream_t s) {
   constexpr int TR = 8 * PPT;
   g.tiles_h = (g.Ho + TR - 1) / TR;
-  g.tiles_w = (g.Wo + 31) / 32;
+  g.tiles_w = (g.Wo + TC - 1) / TC;
   dim3 grid((unsigned)small_blocks(g.Ho, g.Wo, TR, N), (unsigned)N);
   hipLaunchKernelGGL((conv2d_small_kernel<COUT, KS, STRIDE, PPT>), grid, dim3(256), 0, s, x, wp, y, g, in_scale,
                      in_shift, partials);
