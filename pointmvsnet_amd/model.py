@@ -196,9 +196,13 @@ class PointMVSNet(nn.Module):
         if not img_list.is_cuda:
             raise RuntimeError("pointmvsnet_amd.PointMVSNet runs on a GPU (HIP) device only; the CPU "
                                "restatement lives in oracle/ and is test infrastructure")
-        if self._needs_graph():
-            return self._forward_autograd(data_batch, img_scales, inter_scales, isFlow, isTest)
         B, V, _, H, W = img_list.shape
+        if self._needs_graph() or B > 1:
+            # The fused pipeline is built for one scene per call (the reference's test path asserts
+            # TEST.BATCH_SIZE == 1, test.py:116).  With B > 1 every BatchNorm of the PointFlow stage pools its
+            # statistics over the batch (networks.py:41,77; nn/conv.py:31-32); the composed path below does
+            # exactly that, with or without autograd.
+            return self._forward_autograd(data_batch, img_scales, inter_scales, isFlow, isTest)
         D = int(_host_cams(data_batch)[0, 0, 1, 3, 2].long())
         plan = self._plan
         if plan is None or not plan.matches(img_list.device, B, V, H, W, img_scales, inter_scales, isTest, D):
