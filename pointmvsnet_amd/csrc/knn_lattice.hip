@@ -136,6 +136,128 @@ __global__ __launch_bounds__(256) void knn_lattice_kernel(const float* __restric
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Split variant (knn <= 16): the four waves of a block scan one quarter of the window codes each for the
+// same 64 points (2 x 32 tile), then wave 0 merges the four sorted lists through LDS.  A PointFlow stage
+// has only 25 600-102 400 points: with one lane doing all 125 candidates the first iteration is 120 blocks
+// of serial work (42 us); splitting the scan gives 4x the blocks and ~1/3 of the per-lane work.  The merge
+// takes the smallest head, lower quarter first on equal distance == the (d2, code) order.
+// ------------------------------------------------------------------------------------------------
+constexpr int SW = 32, SH = 2;
+
+__global__ __launch_bounds__(256) void knn_lattice_split_kernel(const float* __restrict__ xyz, Strides5 st, int D,
+                                                                int H, int W, int ks, int knn,
+                                                                int64_t* __restrict__ idx_out,
+                                                                uint8_t* __restrict__ code_out) {
+  constexpr int CAP = 16;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int hk = ks >> 1;
+  const int LW = SW + 2 * hk, LH = SH + 2 * hk;
+  const int plane = LH * LW;
+  const int total = ks * plane;
+  float* lx = lds;
+  float* ly = lds + total;
+  float* lz = lds + 2 * total;
+  constexpr int LS = CAP + 1;                                // odd list stride: conflict-free LDS writes
+  float* ld = lds + 3 * total;                               // [4][64][17] distances
+  int* lc = reinterpret_cast<int*>(ld + 4 * 64 * LS);        // [4][64][17] codes
+
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int tx = lane & (SW - 1), ty = lane >> 5;
+  const int w0 = blockIdx.x * SW, h0 = blockIdx.y * SH;
+  const int b = blockIdx.z / D;
+  const int d = blockIdx.z - b * D;
+
+  for (int e = threadIdx.x; e < total; e += 256) {
+    const int pl = e / plane;
+    const int rem = e - pl * plane;
+    const int r = rem / LW;
+    const int cc = rem - r * LW;
+    const int dd = d - hk + pl, hh = h0 - hk + r, ww = w0 - hk + cc;
+    const bool in = (dd >= 0) && (dd < D) && (hh >= 0) && (hh < H) && (ww >= 0) && (ww < W);
+    float vx = 0.0f, vy = 0.0f, vz = 0.0f;
+    if (in) {
+      const int64_t off = b * st.b + dd * st.d + hh * st.h + ww * st.w;
+      vx = xyz[off];
+      vy = xyz[off + st.c];
+      vz = xyz[off + 2 * st.c];
+    }
+    lx[e] = vx;
+    ly[e] = vy;
+    lz[e] = vz;
+  }
+  __syncthreads();
+
+  const int h = h0 + ty, w = w0 + tx;
+  const bool valid = (h < H) && (w < W);
+  const int ce = (hk * LH + ty + hk) * LW + tx + hk;
+  const float cx = lx[ce], cy = ly[ce], cz = lz[ce];
+
+  float bd[CAP];
+  int bc[CAP];
+#pragma unroll
+  for (int j = 0; j < CAP; ++j) {
+    bd[j] = __builtin_huge_valf();
+    bc[j] = 0x7fffffff;
+  }
+  const int k3 = ks * ks * ks;
+  const int per = (k3 + 3) >> 2;
+  const int c0 = wave * per, c1 = min(k3, c0 + per);
+  const int ks2 = ks * ks;
+  for (int code = c0; code < c1; ++code) {
+    const int pl = code / ks2;
+    const int rem = code - pl * ks2;
+    const int r = rem / ks, cc = rem - r * ks;
+    const int e = (pl * LH + ty + r) * LW + tx + cc;
+    const float dx = cx - lx[e];
+    const float dy = cy - ly[e];
+    const float dz = cz - lz[e];
+    const float d2 = (dx * dx + dy * dy) + dz * dz;
+    if (d2 < bd[CAP - 1]) insert_sorted<CAP>(bd, bc, d2, code, std::make_integer_sequence<int, CAP>());
+  }
+#pragma unroll
+  for (int j = 0; j < CAP; ++j) {
+    ld[(wave * 64 + lane) * LS + j] = bd[j];
+    lc[(wave * 64 + lane) * LS + j] = bc[j];
+  }
+  __syncthreads();
+  if (wave != 0 || !valid) return;
+
+  // 4-way merge of the sorted lists (entries past a list's real length are +inf)
+  int pos[4] = {0, 0, 0, 0};
+  float hd[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) hd[q] = ld[(q * 64 + lane) * LS];
+  const int64_t HW = (int64_t)H * W;
+  const int64_t DHW = HW * D;
+  const int64_t n = (int64_t)d * HW + (int64_t)h * W + w;
+  int64_t* op = idx_out + ((int64_t)b * DHW + n) * knn;
+  uint8_t* cp = code_out ? code_out + ((int64_t)b * DHW + n) * knn : nullptr;
+  for (int j = 0; j < knn; ++j) {
+    int best = 0;
+    float bv = hd[0];
+#pragma unroll
+    for (int q = 1; q < 4; ++q) {
+      if (hd[q] < bv) {            // strict: on equal distance the lower quarter (smaller codes) wins
+        bv = hd[q];
+        best = q;
+      }
+    }
+    const int slot = (best * 64 + lane) * LS + pos[best];
+    const int code = lc[slot];
+    pos[best] += 1;
+    hd[best] = pos[best] < CAP ? ld[slot + 1] : __builtin_huge_valf();
+    const int pd = code / ks2;
+    const int rem = code - pd * ks2;
+    const int ph = rem / ks;
+    const int pw = rem - ph * ks;
+    int64_t v = n + (int64_t)(pd - hk) * HW + (int64_t)(ph - hk) * W + (pw - hk);
+    v = v < 0 ? 0 : (v > DHW - 1 ? DHW - 1 : v);
+    op[j] = v;
+    if (cp) cp[j] = (uint8_t)code;
+  }
+}
+
 }  // namespace
 
 extern "C" int pf_knn_lattice_f32(const float* xyz, const int64_t* strides_host, int64_t B, int64_t D, int64_t H,
@@ -157,7 +279,16 @@ extern "C" int pf_knn_lattice_f32(const float* xyz, const int64_t* strides_host,
   const size_t lds_bytes = (size_t)3 * kernel_size * (TH + 2 * hk) * (TW + 2 * hk) * sizeof(float);
   dim3 grid((unsigned)pf_cdiv(W, TW), (unsigned)pf_cdiv(H, TH), (unsigned)(B * D));
   hipStream_t s = (hipStream_t)stream;
-  if (knn <= 8) {
+  if (knn <= 16 && k3 >= 64) {
+    // split scan (see knn_lattice_split_kernel); every quarter holds >= 16 candidates, so the merged heads
+    // never run dry before knn picks
+    const size_t lds2 = (size_t)3 * kernel_size * (SH + 2 * hk) * (SW + 2 * hk) * sizeof(float) +
+                        (size_t)4 * 64 * 17 * (sizeof(float) + sizeof(int));
+    dim3 grid2((unsigned)pf_cdiv(W, SW), (unsigned)pf_cdiv(H, SH), (unsigned)(B * D));
+    PF_REQUIRE(pf_cdiv(H, SH) <= 65535);
+    hipLaunchKernelGGL(knn_lattice_split_kernel, grid2, dim3(256), lds2, s, xyz, st, (int)D, (int)H, (int)W,
+                       kernel_size, knn, idx_out, code_out);
+  } else if (knn <= 8) {
     hipLaunchKernelGGL(knn_lattice_kernel<8>, grid, dim3(256), lds_bytes, s, xyz, st, (int)D, (int)H, (int)W,
                        kernel_size, knn, idx_out, code_out);
   } else if (knn <= 16) {
