@@ -169,6 +169,25 @@ int pf_bn_finalize_f32(const double* partials, int T, int pcols, int col0, int C
                        float* running_var, float momentum, float eps, int G, int groups_per_stat,
                        float* scale, float* shift, int ld_affine, void* stream);
 
+/* The same, for 1..4 independent jobs in one launch (e.g. the central and the difference half of an
+ * EdgeConv BatchNorm, reference networks.py:33-36).  Fields = the arguments of pf_bn_finalize_f32; the
+ * jobs must write disjoint scale/shift/running-stat ranges. */
+typedef struct pf_bn_job {
+  const double* partials;
+  int32_t T, pcols, col0, C;
+  double count, unbias_n;
+  const float* gamma;
+  const float* beta;
+  float* running_mean;
+  float* running_var;
+  float momentum, eps;
+  int32_t G, groups_per_stat;
+  float* scale;
+  float* shift;
+  int32_t ld_affine;
+} pf_bn_job;
+int pf_bn_finalize_jobs_f32(const pf_bn_job* jobs, int njobs, void* stream);
+
 /* Pass B of EdgeConv (reference networks.py:37-43 / :74-79):
  *   concat != 0: Y[m, 0:C]  = relu(l*scale[0:C] + shift[0:C])                       (central half)
  *                Y[m, C:2C] = mean_j relu((e[idx_j]-l)*scale[C:2C] + shift[C:2C])

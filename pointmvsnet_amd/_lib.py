@@ -13,6 +13,17 @@ LIB_PATH = os.path.join(_HERE, "libpointflow_hip.so")
 
 _vp, _i, _i64, _f, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double
 
+
+
+class BnJob(ctypes.Structure):
+    """``pf_bn_job`` of include/pointflow_hip.h (one BatchNorm finalize job)."""
+    _fields_ = [("partials", _vp), ("T", ctypes.c_int32), ("pcols", ctypes.c_int32), ("col0", ctypes.c_int32),
+                ("C", ctypes.c_int32), ("count", _d), ("unbias_n", _d), ("gamma", _vp), ("beta", _vp),
+                ("running_mean", _vp), ("running_var", _vp), ("momentum", _f), ("eps", _f),
+                ("G", ctypes.c_int32), ("groups_per_stat", ctypes.c_int32), ("scale", _vp), ("shift", _vp),
+                ("ld_affine", ctypes.c_int32)]
+
+
 # name -> argtypes; every entry must exist in include/pointflow_hip.h (tests/test_abi.py checks both ways)
 PROTOTYPES = {
     "pf_version": ([], ctypes.c_char_p),
@@ -45,6 +56,7 @@ PROTOTYPES = {
     "pf_channel_bn_apply_f32": ([_vp, _vp, _vp, _i, _i64, _i64, _i64, _i, _d, _vp, _vp, _vp, _vp, _f, _f, _i, _vp], _i),
     "pf_edge_stats_f32": ([_vp, _i64, _i, _vp, _i, _i, _i, _vp, _vp], _i),
     "pf_bn_finalize_f32": ([_vp, _i, _i, _i, _i, _d, _d, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _i, _vp], _i),
+    "pf_bn_finalize_jobs_f32": ([ctypes.POINTER(BnJob), _i, _vp], _i),
     "pf_edge_apply_f32": ([_vp, _i64, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _i64, _vp], _i),
     "pf_flow_head_f32": ([_vp, _i64, _vp, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp], _i),
     "pf_softargmin_prob_f32": ([_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp], _i),

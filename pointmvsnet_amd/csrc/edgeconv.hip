@@ -379,39 +379,46 @@ __global__ __launch_bounds__(256) void edge_apply_kernel(const float* __restrict
 // ------------------------------------------------------------------------------------------------
 // BatchNorm finalize: one workgroup, stat groups in order (running statistics are sequential state)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void bn_finalize_kernel(const double* __restrict__ partials, int T, int pcols,
-                                                           int col0, int C, double count, double unbias_n,
-                                                           const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta,
-                                                           float* __restrict__ running_mean,
-                                                           float* __restrict__ running_var, float momentum,
-                                                           float eps, int S, int groups_per_stat,
-                                                           float* __restrict__ scale, float* __restrict__ shift,
-                                                           int ld_affine) {
+// One launch serves up to kBnJobs independent finalize jobs (blockIdx.y) and splits the channels of a job
+// over blocks of kBnCB channels (blockIdx.x): the partial sums of one layer are up to ~1 MB, which a single
+// workgroup pulls through one CU's L1 in 5-13 us; channels are independent, so 8-16 CUs share the read.
+constexpr int kBnJobs = 4;
+constexpr int kBnCB = 4;
+constexpr int kBnThreads = 256;
+struct BnJobs {
+  pf_bn_job j[kBnJobs];
+};
+
+__global__ __launch_bounds__(kBnThreads) void bn_finalize_kernel(BnJobs jobs) {
+  const pf_bn_job& J = jobs.j[blockIdx.y];
+  const int c_base = blockIdx.x * kBnCB;
+  if (c_base >= J.C) return;
+  const int Cl = min(kBnCB, J.C - c_base);
+  const int S = J.G / J.groups_per_stat;
   // Phase 1 (parallel): all (stat group, channel) pairs of a round are reduced at once -- one batch of
-  // independent loads for the whole launch instead of one global round trip per stat group.
+  // independent loads per round instead of one global round trip per stat group.
   // Phase 2 (sequential in s, from LDS): affine parameters + the running-statistics recurrence.
-  __shared__ double2 red[1024];
-  __shared__ double2 stat[1024];
+  __shared__ double2 red[kBnThreads];
+  __shared__ double2 stat[kBnThreads];
   const int tid = threadIdx.x;
-  const int entries = groups_per_stat * T;
-  const int64_t estride = (int64_t)pcols * 2;
-  const int Sc = max(1, 1024 / C);  // stat groups per round (C <= 256 checked on the host)
+  const int entries = J.groups_per_stat * J.T;
+  const int64_t estride = (int64_t)J.pcols * 2;
+  const int Sc = 64 / kBnCB;        // stat groups per round: at most 64 pairs, at least 4 slices each
   float rm = 0.0f, rv = 0.0f;
-  const bool track = running_mean != nullptr;
-  if (track && tid < C) {
-    rm = running_mean[tid];
-    rv = running_var[tid];
+  const bool track = J.running_mean != nullptr;
+  if (track && tid < Cl) {
+    rm = J.running_mean[c_base + tid];
+    rv = J.running_var[c_base + tid];
   }
   for (int s0 = 0; s0 < S; s0 += Sc) {
     const int ns = min(Sc, S - s0);
-    const int P = ns * C;
-    const int slices = max(1, 1024 / P);
+    const int P = ns * Cl;
+    const int slices = kBnThreads / P;
     double a = 0.0, b = 0.0;
     if (tid < P * slices) {
       const int pair = tid % P, sl = tid / P;
-      const int s = s0 + pair / C, c = pair % C;
-      const double* base = partials + ((int64_t)s * entries * pcols + col0 + c) * 2;
+      const int s = s0 + pair / Cl, c = c_base + pair % Cl;
+      const double* base = J.partials + ((int64_t)s * entries * J.pcols + J.col0 + c) * 2;
       int e = sl;
       for (; e + 7 * slices < entries; e += 8 * slices) {
         double2 v[8];
@@ -438,30 +445,30 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const double* __restr
         sum += red[i * P + tid].x;
         sq += red[i * P + tid].y;
       }
-      const double mean = sum / count;
-      double var = sq / count - mean * mean;
+      const double mean = sum / J.count;
+      double var = sq / J.count - mean * mean;
       stat[tid] = make_double2(mean, var < 0.0 ? 0.0 : var);
     }
     __syncthreads();
-    if (tid < C) {
-      const float g_ = gamma[tid], b_ = beta[tid];
+    if (tid < Cl) {
+      const float g_ = J.gamma[c_base + tid], b_ = J.beta[c_base + tid];
       for (int si = 0; si < ns; ++si) {
-        const double2 mv = stat[si * C + tid];
-        const float invstd = (float)(1.0 / sqrt(mv.y + (double)eps));
+        const double2 mv = stat[si * Cl + tid];
+        const float invstd = (float)(1.0 / sqrt(mv.y + (double)J.eps));
         const float a_ = invstd * g_;
-        scale[(int64_t)(s0 + si) * ld_affine + tid] = a_;
-        shift[(int64_t)(s0 + si) * ld_affine + tid] = b_ - (float)mv.x * a_;
+        J.scale[(int64_t)(s0 + si) * J.ld_affine + c_base + tid] = a_;
+        J.shift[(int64_t)(s0 + si) * J.ld_affine + c_base + tid] = b_ - (float)mv.x * a_;
         if (track) {
-          const double unbiased = unbias_n > 1.0 ? mv.y * (unbias_n / (unbias_n - 1.0)) : mv.y;
-          rm = (1.0f - momentum) * rm + momentum * (float)mv.x;
-          rv = (1.0f - momentum) * rv + momentum * (float)unbiased;
+          const double unbiased = J.unbias_n > 1.0 ? mv.y * (J.unbias_n / (J.unbias_n - 1.0)) : mv.y;
+          rm = (1.0f - J.momentum) * rm + J.momentum * (float)mv.x;
+          rv = (1.0f - J.momentum) * rv + J.momentum * (float)unbiased;
         }
       }
     }
   }
-  if (track && tid < C) {
-    running_mean[tid] = rm;
-    running_var[tid] = rv;
+  if (track && tid < Cl) {
+    J.running_mean[c_base + tid] = rm;
+    J.running_var[c_base + tid] = rv;
   }
 }
 
@@ -600,20 +607,49 @@ int pf_edge_stats_f32(const float* LE, int64_t ldle, int C, const int64_t* idx, 
   return pf_launch_status();
 }
 
+int pf_bn_finalize_jobs_f32(const pf_bn_job* jobs, int njobs, void* stream) {
+  PF_REQUIRE(jobs != nullptr && njobs >= 1 && njobs <= kBnJobs);
+  BnJobs packed;
+  int cmax = 0;
+  for (int i = 0; i < njobs; ++i) {
+    const pf_bn_job& j = jobs[i];
+    PF_REQUIRE(j.T >= 1 && j.pcols >= 1 && j.col0 >= 0 && j.C >= 1 && j.col0 + j.C <= j.pcols && j.count > 0.0);
+    PF_REQUIRE(j.G >= 1 && j.groups_per_stat >= 1 && (j.G % j.groups_per_stat) == 0 && j.ld_affine >= j.C);
+    PF_REQUIRE(j.partials && j.gamma && j.beta && j.scale && j.shift);
+    PF_REQUIRE((j.running_mean == nullptr) == (j.running_var == nullptr));
+    packed.j[i] = j;
+    cmax = j.C > cmax ? j.C : cmax;
+  }
+  for (int i = njobs; i < kBnJobs; ++i) packed.j[i] = jobs[0];   // never addressed (gridDim.y == njobs)
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)pf_cdiv(cmax, kBnCB), (unsigned)njobs), dim3(kBnThreads), 0,
+                     (hipStream_t)stream, packed);
+  return pf_launch_status();
+}
+
 int pf_bn_finalize_f32(const double* partials, int T, int pcols, int col0, int C, double count, double unbias_n,
                        const float* gamma, const float* beta, float* running_mean, float* running_var,
                        float momentum, float eps, int G, int groups_per_stat, float* scale, float* shift,
                        int ld_affine, void* stream) {
-  PF_REQUIRE(T >= 1 && pcols >= 1 && col0 >= 0 && C >= 1 && col0 + C <= pcols && count > 0.0);
-  PF_REQUIRE(G >= 1 && groups_per_stat >= 1 && (G % groups_per_stat) == 0 && ld_affine >= C);
-  if (C > 256) return PF_ERR_UNSUPPORTED;
-  PF_REQUIRE(partials && gamma && beta && scale && shift);
-  PF_REQUIRE((running_mean == nullptr) == (running_var == nullptr));
-  const int S = G / groups_per_stat;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, partials, T, pcols, col0, C,
-                     count, unbias_n, gamma, beta, running_mean, running_var, momentum, eps, S, groups_per_stat,
-                     scale, shift, ld_affine);
-  return pf_launch_status();
+  pf_bn_job j;
+  j.partials = partials;
+  j.T = T;
+  j.pcols = pcols;
+  j.col0 = col0;
+  j.C = C;
+  j.count = count;
+  j.unbias_n = unbias_n;
+  j.gamma = gamma;
+  j.beta = beta;
+  j.running_mean = running_mean;
+  j.running_var = running_var;
+  j.momentum = momentum;
+  j.eps = eps;
+  j.G = G;
+  j.groups_per_stat = groups_per_stat;
+  j.scale = scale;
+  j.shift = shift;
+  j.ld_affine = ld_affine;
+  return pf_bn_finalize_jobs_f32(&j, 1, stream);
 }
 
 int pf_edge_apply_f32(const float* LE, int64_t ldle, int C, const int64_t* idx, int k, int G, int Ng,

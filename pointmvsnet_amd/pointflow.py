@@ -74,21 +74,33 @@ def pointwise_gemm(X, point_major, ldx, Wt, Y, ldy, G, Ng, K, nc_store, in_affin
     return partials
 
 
-def bn_affine(bn, partials, col0, C, count, unbias_n, G, groups_per_stat, scale, shift, ch0=0):
-    """Train-mode BatchNorm statistics -> (scale, shift) rows, plus the running-stat update the module
-    would have made (one update per stat group, in order).  ``ch0`` selects the slice of the module's
-    channels (EdgeConv's BN covers [central | difference])."""
+def bn_job(bn, partials, col0, C, count, unbias_n, G, groups_per_stat, scale, shift, ch0=0):
+    """One ``pf_bn_job``: train-mode BatchNorm statistics -> (scale, shift) rows, plus the running-stat update
+    the module would have made (one update per stat group, in order).  ``ch0`` selects the slice of the
+    module's channels (EdgeConv's BN covers [central | difference])."""
     if bn.momentum is None:
         raise NotImplementedError("cumulative-average BatchNorm momentum is not supported")
     T, pcols = partials.shape[1], partials.shape[2]
     track = bn.track_running_stats and bn.running_mean is not None
+    dp = lambda t: None if t is None else t.data_ptr()   # noqa: E731
     rm = bn.running_mean[ch0:ch0 + C] if track else None
     rv = bn.running_var[ch0:ch0 + C] if track else None
-    _lib.call("pf_bn_finalize_f32",
-              _lib.ptr(partials), int(T), int(pcols), int(col0), int(C), float(count), float(unbias_n),
-              _lib.ptr(bn.weight.detach()[ch0:ch0 + C]), _lib.ptr(bn.bias.detach()[ch0:ch0 + C]), _lib.ptr(rm),
-              _lib.ptr(rv), float(bn.momentum), float(bn.eps), int(G), int(groups_per_stat), _lib.ptr(scale),
-              _lib.ptr(shift), int(scale.stride(0)), _lib.stream(), algo_bytes=16.0 * G * T * C)
+    return _lib.BnJob(dp(partials), int(T), int(pcols), int(col0), int(C), float(count), float(unbias_n),
+                      dp(bn.weight.detach()[ch0:ch0 + C]), dp(bn.bias.detach()[ch0:ch0 + C]), dp(rm), dp(rv),
+                      float(bn.momentum), float(bn.eps), int(G), int(groups_per_stat), dp(scale), dp(shift),
+                      int(scale.stride(0)))
+
+
+def bn_finalize_jobs(jobs):
+    """Up to four finalize jobs in one launch (pf_bn_finalize_jobs_f32)."""
+    arr = (_lib.BnJob * len(jobs))(*jobs)
+    _lib.call("pf_bn_finalize_jobs_f32", arr, len(jobs), _lib.stream(),
+              algo_bytes=sum(16.0 * j.G * j.T * j.C for j in jobs))
+
+
+def bn_affine(bn, partials, col0, C, count, unbias_n, G, groups_per_stat, scale, shift, ch0=0):
+    """A single finalize job (see bn_job)."""
+    bn_finalize_jobs([bn_job(bn, partials, col0, C, count, unbias_n, G, groups_per_stat, scale, shift, ch0)])
 
 
 import os as _os
@@ -396,9 +408,9 @@ def edge_conv_fused(X, point_major, ldx, K, G, Ng, idx, conv1_w, conv2_w, bn, co
                   _lib.stream(), algo_bytes=float(G) * Ng * (4.0 * C + 8.0 * k + 4.0 * C * k))
         n_pairs = float(groups_per_stat) * Ng * k
         if concat:
-            bn_affine(bn, part_l, 0, C, float(groups_per_stat) * Ng, n_pairs, G, groups_per_stat,
-                      scale, shift, ch0=0)
-            bn_affine(bn, part_d, 0, C, n_pairs, n_pairs, G, groups_per_stat, scale[:, C:], shift[:, C:], ch0=C)
+            bn_finalize_jobs([
+                bn_job(bn, part_l, 0, C, float(groups_per_stat) * Ng, n_pairs, G, groups_per_stat, scale, shift),
+                bn_job(bn, part_d, 0, C, n_pairs, n_pairs, G, groups_per_stat, scale[:, C:], shift[:, C:], ch0=C)])
         else:
             bn_affine(bn, part_d, 0, C, n_pairs, n_pairs, G, groups_per_stat, scale, shift, ch0=0)
         bump_counter(bn, S)

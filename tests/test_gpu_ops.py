@@ -586,3 +586,49 @@ def test_conv2d_small_vs_fp64(dev, N, Cin, Cout, H, W, ks, stride, affine):
     sums = part.sum(dim=1).cpu()
     assert torch.allclose(sums[..., 0], ref.sum(dim=(2, 3)), rtol=1e-5, atol=1e-4 * scale)
     assert torch.allclose(sums[..., 1], (ref ** 2).sum(dim=(2, 3)), rtol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------
+# BatchNorm finalize (shared by rows E*, M, I, R): multi-job launch against float64 first principles
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("C,G,gps,T", [(10, 6, 2, 7), (64, 4, 1, 200), (3, 1, 1, 1), (257, 5, 5, 9)])
+def test_bn_finalize_jobs_vs_first_principles(dev, C, G, gps, T):
+    torch.manual_seed(C + G)
+    S = G // gps
+    jobs, expect = [], []
+    for j in range(2):
+        pcols = C + 3 * j
+        col0 = 2 * j
+        part = torch.rand((G, T, pcols, 2), dtype=torch.float64) + 0.5
+        part[..., 1] += 40.0                                  # keep the variance positive
+        count = 37.0 + j
+        bn = torch.nn.BatchNorm1d(C).to(dev)
+        with torch.no_grad():
+            bn.weight.uniform_(-1.0, 1.0)
+            bn.bias.uniform_(-1.0, 1.0)
+            bn.running_mean.uniform_(-1.0, 1.0)
+            bn.running_var.uniform_(0.5, 2.0)
+        rm, rv = bn.running_mean.double().cpu().clone(), bn.running_var.double().cpu().clone()
+        scale = torch.full((S, C + 4), 7.0, device=dev)
+        shift = torch.full((S, C + 4), 7.0, device=dev)
+        pd = part.to(dev)
+        jobs.append((pointflow.bn_job(bn, pd, col0, C, count, count, G, gps, scale, shift), pd, bn, scale, shift))
+        sums = part[:, :, col0:col0 + C].reshape(S, gps * T, C, 2).sum(1)
+        mean = sums[..., 0] / count
+        var = (sums[..., 1] / count - mean * mean).clamp_min(0.0)
+        a = bn.weight.double().cpu() / torch.sqrt(var + bn.eps)
+        b = bn.bias.double().cpu() - mean * a
+        for s in range(S):                                    # one running-stat update per stat group, in order
+            rm = (1 - bn.momentum) * rm + bn.momentum * mean[s]
+            rv = (1 - bn.momentum) * rv + bn.momentum * var[s] * (count / (count - 1.0))
+        expect.append((a, b, rm, rv))
+    pointflow.bn_finalize_jobs([j[0] for j in jobs])
+    torch.cuda.synchronize()
+    for (_, _, bn, scale, shift), (a, b, rm, rv) in zip(jobs, expect):
+        # float32 outputs of a float64 reduction: tolerance = float32 rounding of the result
+        assert torch.allclose(scale[:, :C].double().cpu(), a, rtol=1e-6, atol=1e-7)
+        assert torch.allclose(shift[:, :C].double().cpu(), b, rtol=1e-6, atol=1e-6)
+        assert torch.all(scale[:, C:] == 7.0) and torch.all(shift[:, C:] == 7.0)   # ld_affine padding untouched
+        assert torch.allclose(bn.running_mean.double().cpu(), rm, rtol=1e-5, atol=1e-6)
+        assert torch.allclose(bn.running_var.double().cpu(), rv, rtol=1e-5, atol=1e-6)
+    assert _lib.status() == 0

@@ -21,7 +21,7 @@ ENTRY_KERNELS = {
     "pf_edge_apply_f32": "edge_apply_kernel", "pf_edge_stats_f32": "edge_stats_kernel",
     "pf_flow_features_f32": "flow_features_kernel", "pf_knn_lattice_f32": "knn_lattice_kernel",
     "pf_fetch_variance_f32": "fetch_variance_kernel", "pf_channel_bn_apply_f32": "channel_bn_apply_kernel",
-    "pf_channel_stats_f32": "channel_stats_kernel", "pf_bn_finalize_f32": "bn_finalize_kernel",
+    "pf_channel_stats_f32": "channel_stats_kernel", "pf_bn_finalize_f32": "bn_finalize_kernel", "pf_bn_finalize_jobs_f32": "bn_finalize_kernel",
     "pf_resize_bilinear_f32": "resize_bilinear_kernel", "pf_softargmin_prob_f32": "softargmin_prob_kernel",
     "pf_flow_head_f32": "flow_head_kernel", "pf_channel_affine_f32": "channel_affine_kernel",
 }
