@@ -15,7 +15,12 @@
 //   * K is walked in groups of 4 input channels.  For each group the block stages the input sub-volume
 //     it needs -- 4 x ((TD-1)s+3) x (3s+3) x (15s+3) voxels, zero-filled outside the tensor, so the
 //     compute loop has no boundary code -- and the group's 27 x 4 x 16NT weights into LDS, double
-//     buffered: group g+1 travels global -> registers while the matrix cores work on group g;
+//     buffered: group g+1 travels global -> registers while the matrix cores work on group g.  Wave w
+//     stages channel w of the group, its lanes walking the channel's sub-volume as one flat index (no lane
+//     idles on row padding; one 32-bit offset per element, computed once per tile, wave-uniform base);
+//     the sub-volume geometry is a compile-time function of (stride, TD), so every LDS address in the
+//     MFMA loop is one base register + an immediate (v3: 132 -> 42 us on the 64 -> 16 stride-2 layer,
+//     168 -> 131 us on 64 -> 8, profiles/r01g_microbench_conv3d.log);
 //   * v_mfma_f32_16x16x4_f32: lane l (row i = l&15, k = l>>4) reads A = xs[k][d*s+kd][h*s+kh][i*s+kw] and
 //     B = ws[tap][k][16t + i] from LDS (plane stride padded to 16 mod 32 banks: conflict-free); a B value
 //     is reused for the TD depth slices.  Exact float32: an fmaf chain over (channel group, tap, channel).
@@ -23,6 +28,8 @@
 //     one 64-byte segment, and per-channel sum / sum-of-squares are folded into float64 block partials
 //     (the (N, T, C, 2) layout pf_bn_finalize_f32 / pf_channel_bn_apply_f32 consume).
 // Bound: fp32 MFMA (2*27*C_in*C_out flop per voxel vs 4*(C_in + C_out) bytes).
+#include <stdlib.h>
+
 #include "pf_common.h"
 
 namespace {
@@ -35,102 +42,105 @@ struct ConvGeom {
   int tiles_d, tiles_h, tiles_w;
 };
 
-template <int NT, int STRIDE, int TD>
-__global__ __launch_bounds__(256) void conv3d_k3_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+// Staged sub-volume of one input channel for a TD x 4 x 16 output tile: compile-time so that every LDS
+// address of the MFMA loop is base register + immediate.
+template <int STRIDE, int TD>
+struct Stage {
+  static constexpr int ID = (TD - 1) * STRIDE + 3;
+  static constexpr int IH = 3 * STRIDE + 3;
+  static constexpr int IW = 15 * STRIDE + 3;
+  static constexpr int IWP = IW + 1;
+  static constexpr int RAW = ID * IH * IWP;
+  // channel planes 16 banks apart for unit-stride reads, 17 for stride-2 reads (the 16 lanes of a plane
+  // then use every other bank): the two planes of a 32-lane LDS group never collide
+  static constexpr int WANT = STRIDE == 1 ? 16 : 17;
+  static constexpr int PLANE = RAW + ((WANT - RAW % 32) + 32) % 32;
+  static constexpr int ELEMS = ID * IH * IW;        // floats of one channel's sub-volume
+  static constexpr int NXR = (ELEMS + 63) / 64;     // ... per lane of the wave that stages the channel
+};
+
+template <int NT, int STRIDE, int TD, int MINW>
+__global__ __launch_bounds__(256, MINW) void conv3d_k3_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                         float* __restrict__ y, ConvGeom g,
                                                         double* __restrict__ partials) {
+  using St = Stage<STRIDE, TD>;
+  constexpr int ID = St::ID, IH = St::IH, IW = St::IW, IWP = St::IWP, PLANE = St::PLANE;
+  constexpr int ELEMS = St::ELEMS, NXR = St::NXR;
   constexpr int NCP = NT * 16;
   constexpr int WSZ = 27 * 4 * NCP;                 // weights of one channel group
   constexpr int NWR = (WSZ + 255) / 256;            // weight floats staged per thread
-  constexpr int MAXROWS = 4 * ((TD - 1) * STRIDE + 3) * (3 * STRIDE + 3);
-  constexpr int NXR = (MAXROWS + 7) / 8;            // input rows staged per thread (8 rows of 32 lanes per pass)
-  constexpr int XPASS = STRIDE == 1 ? 1 : 2;        // a staged row has 18 (stride 1) or 33 (stride 2) floats
+  constexpr int XS = 4 * PLANE;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int xs_size = 4 * g.plane;
   float* xs0 = lds;
-  float* ws0 = lds + 2 * xs_size;
+  float* ws0 = lds + 2 * XS;
   // the epilogue buffers alias the staging buffers (all of a tile's MFMA reads are behind the last barrier
-  // of its channel loop): 35 KB instead of 41 KB for the 64 -> 8 layer, i.e. four resident blocks per CU
+  // of its channel loop)
   float* tile = lds;                                 // [4 waves][NCP][17]
   double* red = reinterpret_cast<double*>(tile + 4 * NCP * 17 + ((4 * NCP * 17) & 1));   // [4][NCP][2]
 
   const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int li = lane & 15, lk = lane >> 4;
   const int n = blockIdx.y;
-  const int64_t plane_i = (int64_t)g.Hi * g.Wi, vol_i = plane_i * g.Di;
+  const int plane_i = g.Hi * g.Wi, vol_i = plane_i * g.Di;       // Cin * vol_i < 2^31 (checked on the host)
   const int64_t plane_o = (int64_t)g.Ho * g.Wo, vol_o = plane_o * g.Do;
   const float* xb = x + (int64_t)n * g.Cin * vol_i;
   float* yb = y + (int64_t)n * g.Cout * vol_o;
   const int cgroups = g.Cin >> 2;
-  const int rows_total = 4 * g.ID * g.IH;
-  const int srow = tid >> 5, scol = tid & 31;        // staging: 8 rows x 32 columns per pass
 
   double ssum[NT], ssq[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) ssum[t] = ssq[t] = 0.0;
 
-  const int64_t total = (int64_t)g.tiles_d * g.tiles_h * g.tiles_w;
-  for (int64_t item = blockIdx.x; item < total; item += gridDim.x) {
-    const int tw = (int)(item % g.tiles_w);
-    const int64_t rest = item / g.tiles_w;
-    const int th = (int)(rest % g.tiles_h);
-    const int td = (int)(rest / g.tiles_h);
+  const int total = g.tiles_d * g.tiles_h * g.tiles_w;
+  for (int item = blockIdx.x; item < total; item += gridDim.x) {
+    const int tw = item % g.tiles_w;
+    const int rest = item / g.tiles_w;
+    const int th = rest % g.tiles_h;
+    const int td = rest / g.tiles_h;
     const int od0 = td * TD, oh0 = th * 4, ow0 = tw * 16;
     const int id0 = od0 * STRIDE - 1, ih0 = oh0 * STRIDE - 1, iw0 = ow0 * STRIDE - 1;
 
-    // staging plan of this tile: row = (ch * ID + dz) * IH + hy of the 4-channel sub-volume; the same for
-    // every channel group, so the index arithmetic is done once per tile
-    int gofs[NXR], lofs[NXR];
+    // Staging plan of this tile, the same for every channel group: wave w stages channel w of the group;
+    // lane l takes the elements e = l + 64 r of the channel's ID x IH x IW sub-volume (flat, so no lane is
+    // wasted on row padding).  Outside the tensor: offset 0 (a valid address) and a cleared mask bit.
+    unsigned gofs[NXR];
+    unsigned okmask = 0;
 #pragma unroll
     for (int r = 0; r < NXR; ++r) {
-      const int row = r * 8 + srow;
-      const int ch = row / (g.ID * g.IH);
-      const int rem = row - ch * g.ID * g.IH;
-      const int dz = rem / g.IH, hy = rem - dz * g.IH;
-      const int id = id0 + dz, ih = ih0 + hy;
-      const bool in = row < rows_total;
-      const bool rok = in && id >= 0 && id < g.Di && ih >= 0 && ih < g.Hi;
-      gofs[r] = rok ? (int)((int64_t)ch * vol_i + (int64_t)id * plane_i + (int64_t)ih * g.Wi) : -1;
-      lofs[r] = in ? ch * g.plane + rem * g.IWP : -1;
+      const int e = lane + 64 * r;
+      const int row = e / IW, col = e - row * IW;
+      const int dz = row / IH, hy = row - dz * IH;
+      const int id = id0 + dz, ih = ih0 + hy, iw = iw0 + col;
+      const bool ok = e < ELEMS && id >= 0 && id < g.Di && ih >= 0 && ih < g.Hi && iw >= 0 && iw < g.Wi;
+      gofs[r] = ok ? (unsigned)(id * plane_i + ih * g.Wi + iw) : 0u;
+      okmask |= (ok ? 1u : 0u) << r;
     }
 
-    float rx[NXR * XPASS], rw[NWR];
+    float rx[NXR], rw[NWR];
     auto load_group = [&](int cg) {
-      const float* src = xb + (int64_t)cg * 4 * vol_i;
+      const float* src = xb + (int64_t)(cg * 4 + wave) * vol_i;       // wave-uniform base
 #pragma unroll
-      for (int r = 0; r < NXR; ++r) {
-#pragma unroll
-        for (int p = 0; p < XPASS; ++p) {
-          const int col = scol + 32 * p;
-          const int iw = iw0 + col;
-          rx[r * XPASS + p] = (gofs[r] >= 0 && col < g.IW && iw >= 0 && iw < g.Wi) ? src[gofs[r] + iw] : 0.0f;
-        }
-      }
+      for (int r = 0; r < NXR; ++r) rx[r] = src[gofs[r]];
       const float* wsrc = wp + (int64_t)cg * WSZ;
 #pragma unroll
       for (int r = 0; r < NWR; ++r) {
         const int e = tid + 256 * r;
-        rw[r] = e < WSZ ? wsrc[e] : 0.0f;
+        rw[r] = (256 * (r + 1) <= WSZ || e < WSZ) ? wsrc[e] : 0.0f;
       }
     };
     auto store_group = [&](int buf) {
-      float* xs = xs0 + buf * xs_size;
+      float* xs = xs0 + buf * XS + wave * PLANE;
       float* ws = ws0 + buf * WSZ;
 #pragma unroll
       for (int r = 0; r < NXR; ++r) {
-        if (lofs[r] >= 0) {
-#pragma unroll
-          for (int p = 0; p < XPASS; ++p) {
-            const int col = scol + 32 * p;
-            if (col < g.IW) xs[lofs[r] + col] = rx[r * XPASS + p];
-          }
-        }
+        const int e = lane + 64 * r;
+        if (64 * (r + 1) <= ELEMS || e < ELEMS) xs[e + e / IW] = ((okmask >> r) & 1u) ? rx[r] : 0.0f;
       }
 #pragma unroll
       for (int r = 0; r < NWR; ++r) {
         const int e = tid + 256 * r;
-        if (e < WSZ) ws[e] = rw[r];
+        if (256 * (r + 1) <= WSZ || e < WSZ) ws[e] = rw[r];
       }
     };
 
@@ -140,14 +150,14 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(const float* __restrict_
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[d][t] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
 
-    __syncthreads();                       // the previous tile's last group has been consumed
+    __syncthreads();                       // the previous tile's epilogue / last group has been consumed
     load_group(0);
     store_group(0);
     __syncthreads();
     for (int cg = 0; cg < cgroups; ++cg) {
       const int buf = cg & 1;
       if (cg + 1 < cgroups) load_group(cg + 1);
-      const float* xs = xs0 + buf * xs_size + lk * g.plane + (wave * STRIDE) * g.IWP + li * STRIDE;
+      const float* xs = xs0 + buf * XS + lk * PLANE + (wave * STRIDE) * IWP + li * STRIDE;
       const float* ws = ws0 + buf * WSZ + lk * NCP + li;
 #pragma unroll
       for (int kd = 0; kd < 3; ++kd) {
@@ -161,7 +171,7 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(const float* __restrict_
             for (int t = 0; t < NT; ++t) b[t] = ws[tap * 4 * NCP + 16 * t];
 #pragma unroll
             for (int d = 0; d < TD; ++d) {
-              const float a = xs[((d * STRIDE + kd) * g.IH + kh) * g.IWP + kw];
+              const float a = xs[((d * STRIDE + kd) * IH + kh) * IWP + kw];
 #pragma unroll
               for (int t = 0; t < NT; ++t) acc[d][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[t], acc[d][t], 0, 0, 0);
             }
@@ -315,15 +325,26 @@ size_t lds_bytes_for(const ConvGeom& g, int NT) {
   return staging > epilogue ? staging : epilogue;
 }
 
-// Deepest tile (TD in {4,2,1}) whose LDS image fits 64 KiB and that still leaves >= 512 blocks of work
+// Tuning hook (microbenchmarks only): PF_CONV3D_VARIANT = 10*TD + MINW forces the tile depth and the
+// waves-per-SIMD target of the NT == 1 kernels.
+int variant_override() {
+  const char* e = getenv("PF_CONV3D_VARIANT");
+  return e ? atoi(e) : 0;
+}
+
+// Deepest admissible tile (TD in {4,2,1}) whose LDS image fits and that still leaves >= 512 blocks of work
 // (2 per CU); if none has 512 blocks, the shallowest that fits.
 int pick_td(int64_t Cin, int64_t Cout, int64_t Di, int64_t Hi, int64_t Wi, int stride) {
   const int NT = (int)((Cout + 15) / 16);
   int best = 0;
-  for (int td = stride == 1 ? 4 : 2; td >= 1; td >>= 1) {   // stride-2 TD=4 would need > 80 KiB of LDS
+  const int ov = variant_override() / 10;
+  // stride-2 TD=4 would need > 80 KiB of LDS; with <= 16 output channels TD=2 at twice the occupancy beats TD=4
+  for (int td = (stride == 1 && (NT > 1 || ov)) ? 4 : 2; td >= 1; td >>= 1) {
     const ConvGeom g = make_geom(Cin, Cout, Di, Hi, Wi, stride, td);
     if (lds_bytes_for(g, NT) > kMaxLds) continue;
+    if (ov && NT == 1 && td > ov) continue;
     best = td;
+    if (ov && NT == 1) return td;
     if ((int64_t)g.tiles_d * g.tiles_h * g.tiles_w >= 512) return td;
   }
   return best;
@@ -334,7 +355,7 @@ int blocks_for(const ConvGeom& g) {
   return (int)(total < 2048 ? total : 2048);
 }
 
-template <int NT, int STRIDE, int TD>
+template <int NT, int STRIDE, int TD, int MINW>
 int launch(const float* x, const float* wp, float* y, const ConvGeom& g, int64_t N, double* partials,
            hipStream_t s) {
   const size_t lds_bytes = lds_bytes_for(g, NT);
@@ -342,24 +363,39 @@ int launch(const float* x, const float* wp, float* y, const ConvGeom& g, int64_t
   if (lds_bytes > 64 * 1024) {           // opt in to more than the default 64 KiB of dynamic LDS (160 KiB per CU)
     static bool done = false;            // per instantiation
     if (!done) {
-      PF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_kernel<NT, STRIDE, TD>),
+      PF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_kernel<NT, STRIDE, TD, MINW>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
       done = true;
     }
   }
   dim3 grid((unsigned)blocks_for(g), (unsigned)N);
-  hipLaunchKernelGGL((conv3d_k3_kernel<NT, STRIDE, TD>), grid, dim3(256), lds_bytes, s, x, wp, y, g, partials);
+  hipLaunchKernelGGL((conv3d_k3_kernel<NT, STRIDE, TD, MINW>), grid, dim3(256), lds_bytes, s, x, wp, y, g, partials);
   return pf_launch_status();
+}
+
+template <int NT, int STRIDE, int TD>
+int launch_w(const float* x, const float* wp, float* y, const ConvGeom& g, int64_t N, double* partials,
+             hipStream_t s) {
+  // measured (profiles/r01g_microbench_conv3d.log): the 64 -> 8 layer runs 151 us at TD 4 / 2 waves per
+  // SIMD and 131 us at TD 2 / 4 waves per SIMD (124 VGPRs, no spills); the stride-2 tile is best left alone
+  constexpr int kDefault = (NT == 1 && STRIDE == 1 && TD == 2) ? 4 : 2;
+  if constexpr (NT == 1) {
+    const int minw = variant_override() % 10;
+    if (minw == 2) return launch<NT, STRIDE, TD, 2>(x, wp, y, g, N, partials, s);
+    if (minw == 4) return launch<NT, STRIDE, TD, 4>(x, wp, y, g, N, partials, s);
+    if (minw == 5) return launch<NT, STRIDE, TD, 5>(x, wp, y, g, N, partials, s);
+  }
+  return launch<NT, STRIDE, TD, kDefault>(x, wp, y, g, N, partials, s);
 }
 
 template <int NT, int STRIDE>
 int launch_td(int td, const float* x, const float* wp, float* y, const ConvGeom& g, int64_t N, double* partials,
               hipStream_t s) {
   if constexpr (STRIDE == 1) {
-    if (td == 4) return launch<NT, STRIDE, 4>(x, wp, y, g, N, partials, s);
+    if (td == 4) return launch_w<NT, STRIDE, 4>(x, wp, y, g, N, partials, s);
   }
-  if (td == 2) return launch<NT, STRIDE, 2>(x, wp, y, g, N, partials, s);
-  return launch<NT, STRIDE, 1>(x, wp, y, g, N, partials, s);
+  if (td == 2) return launch_w<NT, STRIDE, 2>(x, wp, y, g, N, partials, s);
+  return launch_w<NT, STRIDE, 1>(x, wp, y, g, N, partials, s);
 }
 
 }  // namespace
