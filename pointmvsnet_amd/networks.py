@@ -83,15 +83,38 @@ class EdgeConvNoC(_EdgeConvBase):
     concat = False
 
 
+def _deconv_fusable(block, x):
+    """pf_deconv3d_k3s2_f32 covers the decoder's ConvTranspose3d blocks; measured policy: from 2048 input
+    cells up (below that the layer is a handful of wavefronts either way and the library GEMM wins)."""
+    conv = getattr(block, "conv", None)
+    return (type(conv) is nn.ConvTranspose3d and conv.kernel_size == (3, 3, 3) and conv.stride == (2, 2, 2)
+            and conv.padding == (1, 1, 1) and conv.output_padding == (1, 1, 1) and conv.dilation == (1, 1, 1)
+            and conv.groups == 1 and conv.bias is None and x[0, 0].numel() >= 2048)
+
+
 def _block_fused(block, x, samples_per_stat):
     """conv (library) -> HIP BatchNorm statistics/finalize -> HIP affine+ReLU in place; ``block`` is one of
     the nn.conv blocks or a plain nn.ConvNd (no BN / ReLU)."""
+    skip = None
+    if isinstance(x, tuple):                  # decoder input "up + skip" (reference networks.py:163-165)
+        x, skip = x
+    if (skip is not None or hasattr(block, "bn")) and _deconv_fusable(block, x):
+        # transposed conv with the skip add on load and the BN batch statistics in the epilogue
+        training_bn = block.bn is not None and (block.bn.training or not block.bn.track_running_stats)
+        y, partials = pointflow.deconv3d_k3s2(x.contiguous(), None if skip is None else skip.contiguous(),
+                                              block.conv.weight, training_bn)
+        if block.bn is not None:
+            return pointflow.batch_norm_act_(y, block.bn, block.relu, samples_per_stat, partials=partials)
+        return F.relu(y, inplace=True) if block.relu else y
     if not hasattr(block, "bn"):
         if (type(block) is nn.Conv3d and block.kernel_size == (3, 3, 3) and block.padding == (1, 1, 1)
                 and block.stride == (1, 1, 1) and block.dilation == (1, 1, 1) and block.groups == 1
                 and block.bias is None and block.out_channels <= 4 and block.in_channels * block.out_channels <= 256):
-            return pointflow.conv3d_k3_few(x.contiguous(), block.weight)
-        return block(x)
+            return pointflow.conv3d_k3_few(x.contiguous(), block.weight,
+                                           None if skip is None else skip.contiguous())
+        return block(x if skip is None else x + skip)
+    if skip is not None:
+        x = x + skip
     conv = block.conv
     training_bn = block.bn is not None and (block.bn.training or not block.bn.track_running_stats)
     if (type(conv) is nn.Conv3d and conv.kernel_size == (3, 3, 3) and conv.padding == (1, 1, 1)
@@ -228,11 +251,11 @@ class VolumeConv(nn.Module):
         half = f(self.conv1_1, half)
         quarter = f(self.conv2_1, quarter)
         up = f(self.conv4_0, eighth)
-        up = f(self.conv5_0, up + quarter)
-        up = f(self.conv6_0, up + half)
+        up = f(self.conv5_0, (up, quarter))
+        up = f(self.conv6_0, (up, half))
         if aux is not None:
             torch.cuda.current_stream().wait_stream(aux)
-        return f(self.conv6_2, up + full)
+        return f(self.conv6_2, (up, full))
 
     def forward(self, x):
         full = self.conv0_1(x)

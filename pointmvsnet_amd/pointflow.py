@@ -171,6 +171,27 @@ def conv3d_k3(x, weight, stride, want_stats):
     return y, partials
 
 
+def deconv3d_k3s2(xa, xb, weight, want_stats):
+    """ConvTranspose3d 3x3x3 / stride 2 / padding 1 / output_padding 1 of ``xa (+ xb)`` (pf_deconv3d_k3s2_f32;
+    weight in nn.ConvTranspose3d's (Cin, Cout, 3, 3, 3) layout).  Returns (y, partials or None)."""
+    N, Cin, D, H, W = xa.shape
+    Cout = weight.shape[1]
+    w = weight.detach()
+    if w.dtype != _F32 or not w.is_contiguous():
+        w = w.to(_F32).contiguous()
+    y = torch.empty((N, Cout, 2 * D, 2 * H, 2 * W), dtype=_F32, device=xa.device)
+    partials = None
+    if want_stats:
+        T = int(_lib.load().pf_deconv3d_blocks(D, H, W))
+        partials = torch.empty((N, T, Cout, 2), dtype=torch.float64, device=xa.device)
+    vol = D * H * W
+    _lib.call("pf_deconv3d_k3s2_f32", _lib.ptr(xa), _lib.ptr(xb), _lib.ptr(w), _lib.ptr(y), N, Cin, Cout, D, H, W,
+              _lib.ptr(partials), _lib.stream(),
+              algo_bytes=4.0 * N * vol * (Cin * (2 if xb is not None else 1) + 8 * Cout) + 4.0 * 27 * Cin * Cout,
+              flops=2.0 * N * vol * 27 * Cin * Cout)
+    return y, partials
+
+
 def conv2d_supported(conv):
     """True for the two conv shapes of the feature towers that pf_conv2d_f32 implements."""
     if type(conv) is not torch.nn.Conv2d or conv.bias is not None or conv.groups != 1 or conv.out_channels > 64:
@@ -314,14 +335,14 @@ def bn_affine_rows(x, bn, samples_per_stat, partials=None):
     return sc.unsqueeze(0).expand(G, C).contiguous(), sh.unsqueeze(0).expand(G, C).contiguous()
 
 
-def conv3d_k3_few(x, weight):
-    """3x3x3 / pad 1 / stride 1 conv3d with <= 4 output channels (pf_conv3d_k3_few_f32)."""
+def conv3d_k3_few(x, weight, x2=None):
+    """3x3x3 / pad 1 / stride 1 conv3d of ``x (+ x2)`` with <= 4 output channels (pf_conv3d_k3_few_f32)."""
     N, Cin, D, H, W = x.shape
     Cout = weight.shape[0]
     y = torch.empty((N, Cout, D, H, W), dtype=_F32, device=x.device)
     w = weight.detach().to(_F32).contiguous()
-    _lib.call("pf_conv3d_k3_few_f32", _lib.ptr(x), _lib.ptr(w), _lib.ptr(y), N, Cin, Cout, D, H, W, _lib.stream(),
-              algo_bytes=4.0 * N * D * H * W * (Cin + Cout))
+    _lib.call("pf_conv3d_k3_few_f32", _lib.ptr(x), _lib.ptr(x2), _lib.ptr(w), _lib.ptr(y), N, Cin, Cout, D, H, W,
+              _lib.stream(), algo_bytes=4.0 * N * D * H * W * (Cin * (2 if x2 is not None else 1) + Cout))
     return y
 
 

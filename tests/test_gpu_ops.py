@@ -502,6 +502,35 @@ def test_conv3d_k3_few_vs_fp64(dev, N, Cin, Cout, D, H, W):
     err = _maxabs(y, ref)
     report("conv3d_few_%d_%d" % (Cin, Cout), err=err, scale=float(ref.abs().max()))
     assert err < 3e-6 * float(ref.abs().max())
+    # the decoder's last skip add, applied while loading: identical to adding first (one float32 add)
+    x2 = torch.randn(N, Cin, D, H, W, generator=gen)
+    ya = pointflow.conv3d_k3_few(x.to(dev), w.to(dev), x2.to(dev))
+    assert torch.equal(ya, pointflow.conv3d_k3_few((x + x2).to(dev), w.to(dev)))
+
+
+@pytest.mark.parametrize("N,Cin,Cout,D,H,W", [(1, 16, 8, 24, 32, 40), (2, 32, 16, 12, 16, 20), (1, 5, 3, 3, 5, 7),
+                                              (1, 4, 6, 1, 1, 1), (1, 64, 32, 6, 8, 10)])
+@pytest.mark.parametrize("skip", [False, True])
+def test_deconv3d_k3s2_vs_fp64(dev, N, Cin, Cout, D, H, W, skip):
+    # VolumeConv decoder rows (reference networks.py:141-143): float64 ConvTranspose3d of (xa + xb)
+    gen = torch.Generator().manual_seed(Cin * 100 + D * H * W + int(skip))
+    xa = torch.randn(N, Cin, D, H, W, generator=gen)
+    xb = torch.randn(N, Cin, D, H, W, generator=gen) if skip else None
+    w = torch.randn(Cin, Cout, 3, 3, 3, generator=gen) / (4 * Cin) ** 0.5
+    xin = xa + xb if skip else xa
+    ref = F.conv_transpose3d(xin.double(), w.double(), None, stride=2, padding=1, output_padding=1)
+    y, part = pointflow.deconv3d_k3s2(xa.to(dev), None if xb is None else xb.to(dev), w.to(dev), True)
+    assert y.shape == ref.shape == (N, Cout, 2 * D, 2 * H, 2 * W)
+    scale = float(ref.abs().max())
+    err = _maxabs(y, ref)
+    report("deconv3d_%d_%d_%d" % (Cin, Cout, int(skip)), err=err, scale=scale)
+    # float32 fmaf chain over <= 8*Cin products vs float64: a few ulp of the largest output
+    assert err < 3e-6 * scale
+    sums = part.sum(dim=1).cpu()
+    assert torch.allclose(sums[..., 0], ref.sum(dim=(2, 3, 4)), rtol=1e-4, atol=1e-3 * scale)
+    assert torch.allclose(sums[..., 1], (ref ** 2).sum(dim=(2, 3, 4)), rtol=1e-5)
+    y2, none = pointflow.deconv3d_k3s2(xa.to(dev), None if xb is None else xb.to(dev), w.to(dev), False)
+    assert none is None and torch.equal(y2, y)                           # deterministic
 
 
 @pytest.mark.parametrize("N,Cin,Cout,H,W,ks,stride", [(3, 3, 8, 64, 96, 3, 1), (3, 8, 8, 40, 56, 3, 1),
