@@ -144,12 +144,14 @@ def main():
     if not args.eager:
         try:
             from pointmvsnet_amd.graph import GraphedForward
+            n_graphs = int(os.environ.get("PF_BENCH_GRAPHS", "1"))             # diagnostic: alternate graph execs
             with torch.no_grad():
-                graphed = GraphedForward(net, scenes[0], img_scales, inter_scales, isFlow=True, isTest=True)
+                graphs = [GraphedForward(net, scenes[0], img_scales, inter_scales, isFlow=True, isTest=True)
+                          for _ in range(n_graphs)]
 
             def step(i):                                                       # noqa: F811
                 with torch.no_grad():
-                    return graphed(scenes[i % n_unique])
+                    return graphs[i % n_graphs](scenes[i % n_unique])
 
             for i in range(2):
                 step(i)
@@ -173,9 +175,23 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         preds = step(args.warmup + i)
+    issued = time.perf_counter() - t0            # host-side time to enqueue every step (diagnostic only)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    gap_probe = None
+    if execution != "eager" and os.environ.get("PF_BENCH_GAP"):      # diagnostic, outside the timed region
+        probe = []
+        for g in graphs:
+            g.probe = probe
+        for i in range(args.steps):
+            step(args.warmup + i)
+        torch.cuda.synchronize()
+        for g in graphs:
+            g.probe = None
+        inside = [a.elapsed_time(b) for a, b in probe]
+        between = [probe[i][1].elapsed_time(probe[i + 1][0]) for i in range(len(probe) - 1)]
+        gap_probe = {"graph_ms": statistics.median(inside), "between_graphs_ms": statistics.median(between)}
     _lib.set_timer(None)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -228,6 +244,8 @@ def main():
                    "parallelism": "scene-sharded replicas x%d (no data-path collective)" % world,
                    "mode": "PointMVSNet.forward(isFlow=True, isTest=True), BatchNorm in train mode (test.py:58)"},
         "execution": execution,
+        "host_issue_ms_per_step": issued / args.steps * 1e3,
+        "gap_probe": gap_probe,
         "roofline": roof,
         "kernels": kernels,
     }

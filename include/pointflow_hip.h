@@ -227,10 +227,9 @@ int pf_conv3d_blocks(int64_t Cin, int64_t Cout, int64_t Di, int64_t Hi, int64_t 
 int pf_conv3d_k3_f32(const float* x, const float* wp, float* y, int64_t N, int64_t Cin, int64_t Cout, int64_t Di,
                      int64_t Hi, int64_t Wi, int stride, double* partials, void* stream);
 /* 3x3x3 / pad 1 / stride 1 conv3d with Cout <= 4 (VolumeConv's 8 -> 1 output layer, networks.py:147);
- * w is the unpacked (Cout, Cin, 3, 3, 3) weight.  x2 != NULL: the layer input is x + x2 (the decoder's last
- * skip add, networks.py:166), added while loading. */
-int pf_conv3d_k3_few_f32(const float* x, const float* x2, const float* w, float* y, int64_t N, int64_t Cin,
-                         int64_t Cout, int64_t D, int64_t H, int64_t W, void* stream);
+ * w is the unpacked (Cout, Cin, 3, 3, 3) weight. */
+int pf_conv3d_k3_few_f32(const float* x, const float* w, float* y, int64_t N, int64_t Cin, int64_t Cout, int64_t D,
+                         int64_t H, int64_t W, void* stream);
 
 /* ConvTranspose3d 3x3x3, stride 2, padding 1, output_padding 1 (VolumeConv decoder, reference
  * networks.py:141-143 via nn/conv.py:189-216): y (N, Cout, 2D, 2H, 2W) from xa (+ xb when not NULL: the

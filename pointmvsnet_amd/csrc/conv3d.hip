@@ -249,10 +249,9 @@ __global__ __launch_bounds__(256, MINW) void conv3d_k3_kernel(const float* __res
 // Few output channels (VolumeConv's last layer, 8 -> 1: reference networks.py:147): no GEMM shape to speak
 // of -- 216 multiply-adds per voxel against 36 bytes moved -- so one lane per output voxel, weights in
 // LDS, taps served by L1 (neighbouring lanes share 2 of 3 taps along W, neighbouring rows/planes by L2).
-template <int COUT, bool ADD>
-__global__ __launch_bounds__(256) void conv3d_k3_few_kernel(const float* __restrict__ x, const float* __restrict__ x2,
-                                                            const float* __restrict__ w, float* __restrict__ y,
-                                                            int Cin, int D, int H, int W) {
+template <int COUT>
+__global__ __launch_bounds__(256) void conv3d_k3_few_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            float* __restrict__ y, int Cin, int D, int H, int W) {
   extern __shared__ __attribute__((aligned(16))) float wl[];     // [COUT][Cin][27]
   for (int e = threadIdx.x; e < COUT * Cin * 27; e += 256) wl[e] = w[e];
   __syncthreads();
@@ -267,10 +266,8 @@ __global__ __launch_bounds__(256) void conv3d_k3_few_kernel(const float* __restr
 #pragma unroll
   for (int c = 0; c < COUT; ++c) acc[c] = 0.0f;
   const float* xb = x + (int64_t)n * Cin * vol;
-  const float* xb2 = ADD ? x2 + (int64_t)n * Cin * vol : nullptr;
   for (int ci = 0; ci < Cin; ++ci) {
     const float* xc = xb + (int64_t)ci * vol;
-    const float* xc2 = ADD ? xb2 + (int64_t)ci * vol : nullptr;
 #pragma unroll
     for (int kd = 0; kd < 3; ++kd) {
       const int id = od + kd - 1;
@@ -279,12 +276,11 @@ __global__ __launch_bounds__(256) void conv3d_k3_few_kernel(const float* __restr
       for (int kh = 0; kh < 3; ++kh) {
         const int ih = oh + kh - 1;
         const bool hok = dok && ih >= 0 && ih < H;
-        const int64_t ro = (int64_t)id * plane + (int64_t)ih * W;
+        const float* row = xc + (int64_t)id * plane + (int64_t)ih * W;
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
           const int iw = ow + kw - 1;
-          float v = 0.0f;
-          if (hok && iw >= 0 && iw < W) v = ADD ? xc[ro + iw] + xc2[ro + iw] : xc[ro + iw];
+          const float v = (hok && iw >= 0 && iw < W) ? row[iw] : 0.0f;
 #pragma unroll
           for (int c = 0; c < COUT; ++c) acc[c] = fmaf(v, wl[(c * Cin + ci) * 27 + (kd * 3 + kh) * 3 + kw], acc[c]);
         }
@@ -431,8 +427,8 @@ int pf_conv3d_k3_f32(const float* x, const float* wp, float* y, int64_t N, int64
   return NT == 1 ? launch_td<1, 2>(td, x, wp, y, g, N, partials, s) : launch_td<2, 2>(td, x, wp, y, g, N, partials, s);
 }
 
-int pf_conv3d_k3_few_f32(const float* x, const float* x2, const float* w, float* y, int64_t N, int64_t Cin,
-                         int64_t Cout, int64_t D, int64_t H, int64_t W, void* stream) {
+int pf_conv3d_k3_few_f32(const float* x, const float* w, float* y, int64_t N, int64_t Cin, int64_t Cout, int64_t D,
+                         int64_t H, int64_t W, void* stream) {
   PF_REQUIRE(N >= 0 && Cin >= 1 && Cout >= 1 && D >= 1 && H >= 1 && W >= 1 && N <= 65535);
   if (Cout > 4 || Cout * Cin * 27 * sizeof(float) > 48 * 1024) return PF_ERR_UNSUPPORTED;
   PF_REQUIRE(H * W <= INT32_MAX);
@@ -441,20 +437,12 @@ int pf_conv3d_k3_few_f32(const float* x, const float* x2, const float* w, float*
   const size_t lds = sizeof(float) * (size_t)(Cout * Cin * 27);
   dim3 grid((unsigned)pf_cdiv(D * H * W, 256), (unsigned)N);
   hipStream_t s = (hipStream_t)stream;
-#define PF_FEW(CO)                                                                                               \
-  if (x2 != nullptr)                                                                                             \
-    hipLaunchKernelGGL((conv3d_k3_few_kernel<CO, true>), grid, dim3(256), lds, s, x, x2, w, y, (int)Cin, (int)D, \
-                       (int)H, (int)W);                                                                          \
-  else                                                                                                           \
-    hipLaunchKernelGGL((conv3d_k3_few_kernel<CO, false>), grid, dim3(256), lds, s, x, x2, w, y, (int)Cin, (int)D, \
-                       (int)H, (int)W)
   switch ((int)Cout) {
-    case 1: PF_FEW(1); break;
-    case 2: PF_FEW(2); break;
-    case 3: PF_FEW(3); break;
-    default: PF_FEW(4); break;
+    case 1: hipLaunchKernelGGL(conv3d_k3_few_kernel<1>, grid, dim3(256), lds, s, x, w, y, (int)Cin, (int)D, (int)H, (int)W); break;
+    case 2: hipLaunchKernelGGL(conv3d_k3_few_kernel<2>, grid, dim3(256), lds, s, x, w, y, (int)Cin, (int)D, (int)H, (int)W); break;
+    case 3: hipLaunchKernelGGL(conv3d_k3_few_kernel<3>, grid, dim3(256), lds, s, x, w, y, (int)Cin, (int)D, (int)H, (int)W); break;
+    default: hipLaunchKernelGGL(conv3d_k3_few_kernel<4>, grid, dim3(256), lds, s, x, w, y, (int)Cin, (int)D, (int)H, (int)W); break;
   }
-#undef PF_FEW
   return pf_launch_status();
 }
 

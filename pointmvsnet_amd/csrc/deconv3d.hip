@@ -11,17 +11,18 @@
 // k=1 of input i and an output of odd coordinate 2i+1 takes tap k=0 of input i+1 and tap k=2 of input i.
 // One lane owns one input cell (id, ih, iw): it reads the 2x2x2 input neighbourhood once per input channel
 // and produces the 2x2x2 output cell (1+2+2+4+2+4+4+8 = 27 taps) for CG output channels; the weights of
-// (input channel, channel group) are wave-uniform and come through the scalar cache.  Neighbour loads of
-// channel c+1 are issued before the FMAs of channel c.  Lanes are consecutive along W: loads coalesce and
-// each lane stores two adjacent floats per output row.
+// (input channel, channel group) are wave-uniform and come through the scalar cache.  The neighbour loads
+// of 8 input channels are issued together.  Lanes are consecutive along W: loads coalesce and each lane
+// stores two adjacent floats per output row.
 // Bound: latency / issue (tiny); algorithmic bytes 4*(Cin*vol*(1 or 2) + Cout*8*vol).
 #include "pf_common.h"
 
 namespace {
 
 constexpr int kDcThreads = 128;
+constexpr int kDcUnroll = 8;      // input channels whose loads are issued together
 
-template <int CG, bool ADD>
+template <int CG, bool ADD, int U>
 __global__ __launch_bounds__(kDcThreads) void deconv3d_k3s2_kernel(const float* __restrict__ xa,
                                                                    const float* __restrict__ xb,
                                                                    const float* __restrict__ w,
@@ -59,40 +60,47 @@ __global__ __launch_bounds__(kDcThreads) void deconv3d_k3s2_kernel(const float* 
 
   const float* xan = xa + (int64_t)n * Cin * vol;
   const float* xbn = ADD ? xb + (int64_t)n * Cin * vol : nullptr;
-  float nxt[8];
-  auto fetch = [&](int ci) {
-    const float* pa = xan + (int64_t)ci * vol;
+  // U input channels per round: all of a round's neighbour loads are in flight together (the layer is a
+  // chain of Cin dependent global-load latencies otherwise: 35 us for 32 channels)
+  for (int ci0 = 0; ci0 < Cin; ci0 += U) {
+    float v[U][8];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) nxt[s] = pa[off[s]];
-    if (ADD) {
-      const float* pb = xbn + (int64_t)ci * vol;
+    for (int u = 0; u < U; ++u) {
+      const int ci = min(ci0 + u, Cin - 1);                       // tail: reload the last channel, unused
+      const float* pa = xan + (int64_t)ci * vol;
 #pragma unroll
-      for (int s = 0; s < 8; ++s) nxt[s] += pb[off[s]];
+      for (int s = 0; s < 8; ++s) v[u][s] = pa[off[s]];
+      if (ADD) {
+        const float* pb = xbn + (int64_t)ci * vol;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) v[u][s] += pb[off[s]];
+      }
     }
-  };
-  fetch(0);
-  for (int ci = 0; ci < Cin; ++ci) {
-    float v[8];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) v[s] = nxt[s] * keep[s];
-    if (ci + 1 < Cin) fetch(ci + 1);
-    const float* __restrict__ wg = w + ((int64_t)ci * Cout + co0) * 27;     // wave-uniform: scalar loads
-    // per dimension: parity 0 -> (shift 0, tap 1); parity 1 -> (shift 1, tap 0), (shift 0, tap 2)
+    for (int u = 0; u < U; ++u) {
+      if (ci0 + u < Cin) {                                        // wave-uniform
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      const int pd = p >> 2, ph = (p >> 1) & 1, pw = p & 1;
+        for (int s = 0; s < 8; ++s) v[u][s] *= keep[s];
+        const float* __restrict__ wg = w + ((int64_t)(ci0 + u) * Cout + co0) * 27;   // wave-uniform: scalar loads
+        // per dimension: parity 0 -> (shift 0, tap 1); parity 1 -> (shift 1, tap 0), (shift 0, tap 2)
 #pragma unroll
-      for (int a = 0; a <= pd; ++a) {
-        const int sd = pd ? 1 - a : 0, kd = pd ? 2 * a : 1;
+        for (int p = 0; p < 8; ++p) {
+          const int pd = p >> 2, ph = (p >> 1) & 1, pw = p & 1;
 #pragma unroll
-        for (int b = 0; b <= ph; ++b) {
-          const int sh = ph ? 1 - b : 0, kh = ph ? 2 * b : 1;
+          for (int a = 0; a <= pd; ++a) {
+            const int sd = pd ? 1 - a : 0, kd = pd ? 2 * a : 1;
 #pragma unroll
-          for (int e = 0; e <= pw; ++e) {
-            const int sw = pw ? 1 - e : 0, kw = pw ? 2 * e : 1;
-            const float xv = v[(sd << 2) | (sh << 1) | sw];
+            for (int b = 0; b <= ph; ++b) {
+              const int sh = ph ? 1 - b : 0, kh = ph ? 2 * b : 1;
 #pragma unroll
-            for (int c = 0; c < CG; ++c) acc[p][c] = fmaf(xv, wg[c * 27 + (kd * 3 + kh) * 3 + kw], acc[p][c]);
+              for (int e = 0; e <= pw; ++e) {
+                const int sw = pw ? 1 - e : 0, kw = pw ? 2 * e : 1;
+                const float xv = v[u][(sd << 2) | (sh << 1) | sw];
+#pragma unroll
+                for (int c = 0; c < CG; ++c)
+                  acc[p][c] = fmaf(xv, wg[c * 27 + (kd * 3 + kh) * 3 + kw], acc[p][c]);
+              }
+            }
           }
         }
       }
@@ -149,10 +157,10 @@ int launch_dc(const float* xa, const float* xb, const float* w, float* y, int64_
               int W, double* partials, hipStream_t s) {
   dim3 grid((unsigned)pf_cdiv((int64_t)D * H * W, kDcThreads), (unsigned)(Cout / CG), (unsigned)N);
   if (xb != nullptr)
-    hipLaunchKernelGGL((deconv3d_k3s2_kernel<CG, true>), grid, dim3(kDcThreads), 0, s, xa, xb, w, y, Cin, Cout, D, H, W,
+    hipLaunchKernelGGL((deconv3d_k3s2_kernel<CG, true, kDcUnroll>), grid, dim3(kDcThreads), 0, s, xa, xb, w, y, Cin, Cout, D, H, W,
                        partials);
   else
-    hipLaunchKernelGGL((deconv3d_k3s2_kernel<CG, false>), grid, dim3(kDcThreads), 0, s, xa, xb, w, y, Cin, Cout, D, H,
+    hipLaunchKernelGGL((deconv3d_k3s2_kernel<CG, false, kDcUnroll>), grid, dim3(kDcThreads), 0, s, xa, xb, w, y, Cin, Cout, D, H,
                        W, partials);
   return pf_launch_status();
 }

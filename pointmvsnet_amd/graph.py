@@ -19,6 +19,7 @@ class GraphedForward(object):
             raise RuntimeError("GraphedForward captures the inference path; wrap the call in torch.no_grad()")
         self.model = model
         self.isFlow = isFlow
+        self.probe = None                                  # set to a list to collect (start, end) events per replay
         self.static_img = example_batch["img_list"].clone()
         self.plan = model.make_plan(example_batch, img_scales, inter_scales, isTest)
         side = torch.cuda.Stream()
@@ -28,6 +29,9 @@ class GraphedForward(object):
                 model.run(self.plan, self.static_img, isFlow)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        # One graph for the whole forward; the stream forks inside run() become graph edges.  (Three graphs
+        # -- coarse, flow tower on a side stream, flow iterations -- ordered by stream events were measured
+        # at 402 depth maps/s against 486: replays on different streams did not overlap, profiles/r01h_split_ab.log.)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.outputs = model.run(self.plan, self.static_img, isFlow)
@@ -37,5 +41,12 @@ class GraphedForward(object):
         img = data_batch["img_list"]
         if img.data_ptr() != self.static_img.data_ptr():
             self.static_img.copy_(img, non_blocking=True)
-        self.graph.replay()
+        if self.probe is not None:                         # diagnostic: GPU-side extent of each replay
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            self.graph.replay()
+            b.record()
+            self.probe.append((a, b))
+        else:
+            self.graph.replay()
         return self.outputs

@@ -18,6 +18,7 @@ the same ATen CPU calls the reference makes (model.py:54-61, :159-170) and uploa
 blocks; it is microseconds of work and keeps the geometry bit-identical to the reference's.
 """
 import collections
+import os
 
 import torch
 import torch.nn as nn
@@ -211,32 +212,48 @@ class PointMVSNet(nn.Module):
         return self.run(plan, img_list, isFlow)
 
     def run(self, plan, img_list, isFlow=True):
-        """Device-only inference forward (capturable in a hipGraph): fused HIP pipeline, SURVEY.md section 8."""
-        B, V, H, W, D = plan.B, plan.V, plan.H, plan.W, plan.D
-        dev = img_list.device
-        preds = collections.OrderedDict()
+        """Device-only inference forward (capturable in a hipGraph): fused HIP pipeline, SURVEY.md section 8.
 
-        # The flow tower depends only on the images: it runs on a second stream, concurrently with the whole
-        # coarse stage (tower, warp, VolumeConv, soft-argmin), and is joined before the first PointFlow
-        # iteration.  Most kernels here are far too small to fill 256 CUs alone; under hipGraph capture the
-        # fork/join becomes graph edges.
-        pyramids = None
+        The flow tower depends only on the images: it runs on a second stream, beside the coarse stage
+        (warp, VolumeConv, soft-argmin -- mostly kernels far too small to fill 256 CUs), and is joined
+        before the first PointFlow iteration; under hipGraph capture the fork/join becomes graph edges.
+        The fork sits AFTER the coarse tower: two towers side by side only slow each other down (same
+        kernels, each fills the chip) -- 474 -> 486 depth maps/s, profiles/r01h_fork_ab.log."""
+        dev = img_list.device
         main = torch.cuda.current_stream()
-        side = None
+        feature_list = self.run_coarse_tower(img_list)
+        pyramids, side = None, None
         if isFlow and pointflow.CONCURRENCY < 1:
-            pyramids = self.flow_img_conv.forward_views(img_list)
+            pyramids = self.run_flow_tower(img_list)
         elif isFlow:
             if self._side_stream is None or self._side_stream.device != dev:
                 self._side_stream = torch.cuda.Stream(device=dev)
             side = self._side_stream
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                pyramids = self.flow_img_conv.forward_views(img_list)
+                pyramids = self.run_flow_tower(img_list)
                 for p in pyramids.values():
                     p.record_stream(main)
+        preds = self.run_coarse_stage(plan, feature_list)
+        if not isFlow:
+            pointflow.flush_counters()
+            return preds
+        if side is not None:
+            main.wait_stream(side)
+        return self.run_flows(plan, pyramids, preds)
 
-        # ---- coarse stage (reference model.py:71-130) -----------------------------------------
-        feature_list = self.coarse_img_conv.forward_views(img_list)["conv3"].contiguous()   # (B,V,C,FH,FW)
+    # The four device-only stages of ``run`` (GraphedForward may capture them as separate graphs).
+    def run_coarse_tower(self, img_list):
+        return self.coarse_img_conv.forward_views(img_list)["conv3"].contiguous()           # (B,V,C,FH,FW)
+
+    def run_flow_tower(self, img_list):
+        return self.flow_img_conv.forward_views(img_list)
+
+    def run_coarse_stage(self, plan, feature_list):
+        """Coarse stage after the tower (reference model.py:79-130): warp, variance, VolumeConv, soft-argmin."""
+        B, D = plan.B, plan.D
+        dev = feature_list.device
+        preds = collections.OrderedDict()
         C, FH, FW = feature_list.shape[2:]
         grid = self._pixel_grid(FH, FW, dev).view(1, 1, 3, -1).expand(B, 1, 3, -1)
         uv = torch.matmul(plan.d("Kinv0"), grid)
@@ -249,14 +266,13 @@ class PointMVSNet(nn.Module):
         pred_depth, prob_map = pointflow.soft_argmin_params(filtered, plan.d("sa_params"))
         preds["coarse_depth_map"] = pred_depth
         preds["coarse_prob_map"] = prob_map
-        if not isFlow:
-            pointflow.flush_counters()
-            return preds
+        return preds
 
-        # ---- flow stage (reference model.py:132-303) --------------------------------------------
+    def run_flows(self, plan, pyramids, preds):
+        """Flow stage (reference model.py:132-303) on the coarse depth in ``preds``; flushes the BN counters."""
+        B, H, W = plan.B, plan.H, plan.W
+        pred_depth = preds["coarse_depth_map"]
         names = ("conv1", "conv2", "conv3")
-        if side is not None:
-            main.wait_stream(side)
         for it, img_scale in enumerate(plan.img_scales):
             h, w = int(H * img_scale), int(W * img_scale)
             ratio = int(img_scale * 8) if (plan.is_test and img_scale != 0.125) else 1

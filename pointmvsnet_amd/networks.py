@@ -110,8 +110,7 @@ def _block_fused(block, x, samples_per_stat):
         if (type(block) is nn.Conv3d and block.kernel_size == (3, 3, 3) and block.padding == (1, 1, 1)
                 and block.stride == (1, 1, 1) and block.dilation == (1, 1, 1) and block.groups == 1
                 and block.bias is None and block.out_channels <= 4 and block.in_channels * block.out_channels <= 256):
-            return pointflow.conv3d_k3_few(x.contiguous(), block.weight,
-                                           None if skip is None else skip.contiguous())
+            return pointflow.conv3d_k3_few((x if skip is None else x + skip).contiguous(), block.weight)
         return block(x if skip is None else x + skip)
     if skip is not None:
         x = x + skip
@@ -255,7 +254,9 @@ class VolumeConv(nn.Module):
         up = f(self.conv6_0, (up, half))
         if aux is not None:
             torch.cuda.current_stream().wait_stream(aux)
-        return f(self.conv6_2, (up, full))
+        # (the last skip add stays a separate elementwise launch: conv6_2's kernel is bound by its tap loads,
+        # and adding on load doubles them -- 63 us against 15 + 5, profiles/r01h_microbench_deconv3d.log)
+        return f(self.conv6_2, up + full)
 
     def forward(self, x):
         full = self.conv0_1(x)

@@ -335,14 +335,14 @@ def bn_affine_rows(x, bn, samples_per_stat, partials=None):
     return sc.unsqueeze(0).expand(G, C).contiguous(), sh.unsqueeze(0).expand(G, C).contiguous()
 
 
-def conv3d_k3_few(x, weight, x2=None):
-    """3x3x3 / pad 1 / stride 1 conv3d of ``x (+ x2)`` with <= 4 output channels (pf_conv3d_k3_few_f32)."""
+def conv3d_k3_few(x, weight):
+    """3x3x3 / pad 1 / stride 1 conv3d with <= 4 output channels (pf_conv3d_k3_few_f32)."""
     N, Cin, D, H, W = x.shape
     Cout = weight.shape[0]
     y = torch.empty((N, Cout, D, H, W), dtype=_F32, device=x.device)
     w = weight.detach().to(_F32).contiguous()
-    _lib.call("pf_conv3d_k3_few_f32", _lib.ptr(x), _lib.ptr(x2), _lib.ptr(w), _lib.ptr(y), N, Cin, Cout, D, H, W,
-              _lib.stream(), algo_bytes=4.0 * N * D * H * W * (Cin * (2 if x2 is not None else 1) + Cout))
+    _lib.call("pf_conv3d_k3_few_f32", _lib.ptr(x), _lib.ptr(w), _lib.ptr(y), N, Cin, Cout, D, H, W, _lib.stream(),
+              algo_bytes=4.0 * N * D * H * W * (Cin + Cout))
     return y
 
 
