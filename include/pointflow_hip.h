@@ -112,6 +112,15 @@ int pf_fetch_backward_f32(const float* grad_out, const float* pts, const float* 
 int pf_fetch_variance_f32(const float* maps, const float* pts, const float* K, const float* E, float* out,
                           int64_t B, int64_t V, int64_t C, int64_t H, int64_t W, int64_t N,
                           int ref_override, void* stream);
+/* The coarse stage's use of it (reference model.py:79-111): the points are the frustum of the reference view,
+ * generated in the kernel instead of read -- point n = d*H*W + y*W + x is
+ *   world = rinv[b] (depths[b,d] * kinv[b] (x+0.5, y+0.5, 1)^T - t[b])
+ * (kinv, rinv row-major 3x3: inverse coarse intrinsics and inverse rotation of view 0; t its translation),
+ * with ref_override semantics.  world != NULL also receives the points (B, 3, D*H*W), the model's
+ * "world_points" output.  out (B, C, D*H*W). */
+int pf_frustum_variance_f32(const float* maps, const float* kinv, const float* rinv, const float* t,
+                            const float* depths, const float* K, const float* E, float* out, float* world,
+                            int64_t B, int64_t V, int64_t C, int64_t H, int64_t W, int64_t D, void* stream);
 
 /* ---- bilinear resize (align_corners = False), the F.interpolate of model.py:184 -------------
  * in (P, IH, IW) -> out (P, OH, OW). */
@@ -214,6 +223,14 @@ int pf_channel_affine_f32(const float* x, float* y, const float* scale, const fl
 int pf_channel_bn_apply_f32(const float* x, float* y, const double* partials, int T, int64_t N, int64_t C, int64_t S,
                             int samples_per_stat, double count, const float* gamma, const float* beta,
                             float* running_mean, float* running_var, float momentum, float eps, int relu,
+                            void* stream);
+/* Statistics + finalize + normalise in ONE launch for small tensors (one 1024-thread block per channel walks
+ * the stat groups in order): y = act(BN_train(x)) with y == x allowed, and/or (y == NULL) only the affine
+ * rows scale/shift (N/samples_per_stat, ld_affine) for a consumer that applies them itself.  Same
+ * running-statistics semantics as pf_bn_finalize_f32. */
+int pf_channel_bn_fused_f32(const float* x, float* y, int64_t N, int64_t C, int64_t S, int samples_per_stat,
+                            const float* gamma, const float* beta, float* running_mean, float* running_var,
+                            float momentum, float eps, int relu, float* scale, float* shift, int ld_affine,
                             void* stream);
 
 /* ---- row R : 3x3x3 convolution of VolumeConv on the f32 matrix cores ---------------------------------

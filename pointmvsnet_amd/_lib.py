@@ -38,6 +38,7 @@ PROTOTYPES = {
     "pf_fetch_forward_f32": ([_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp], _i),
     "pf_fetch_backward_f32": ([_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp], _i),
     "pf_fetch_variance_f32": ([_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i, _vp], _i),
+    "pf_frustum_variance_f32": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp], _i),
     "pf_resize_bilinear_f32": ([_vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp], _i),
     "pf_flow_features_f32": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp], _i),
     "pf_stat_blocks": ([_i, _i], _i),
@@ -56,6 +57,7 @@ PROTOTYPES = {
     "pf_channel_stats_f32": ([_vp, _i64, _i64, _i64, _vp, _vp], _i),
     "pf_channel_affine_f32": ([_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _vp], _i),
     "pf_channel_bn_apply_f32": ([_vp, _vp, _vp, _i, _i64, _i64, _i64, _i, _d, _vp, _vp, _vp, _vp, _f, _f, _i, _vp], _i),
+    "pf_channel_bn_fused_f32": ([_vp, _vp, _i64, _i64, _i64, _i, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _i, _vp], _i),
     "pf_edge_stats_f32": ([_vp, _i64, _i, _vp, _i, _i, _i, _vp, _vp], _i),
     "pf_bn_finalize_f32": ([_vp, _i, _i, _i, _i, _d, _d, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _i, _vp], _i),
     "pf_bn_finalize_jobs_f32": ([ctypes.POINTER(BnJob), _i, _vp], _i),

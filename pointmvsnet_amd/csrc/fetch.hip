@@ -67,9 +67,20 @@ __global__ __launch_bounds__(256) void fetch_bwd_kernel(const float* __restrict_
 // ------------------------------------------------------------------------------------------------
 // W+V: fetch + variance over views (reference model.py:102-111 coarse, :187-190 flow)
 // ------------------------------------------------------------------------------------------------
-template <int V>
+// Frustum of the reference view (reference model.py:79-100): point n = d*H*W + y*W + x is the un-projection
+// of pixel centre (x+0.5, y+0.5) at depth hypothesis d,  world = Rinv (depth * Kinv (x+0.5, y+0.5, 1)^T - t).
+struct Frustum {
+  const float* kinv;     // (B, 9)
+  const float* rinv;     // (B, 9)
+  const float* t;        // (B, 3)
+  const float* depths;   // (B, D)
+  float* world;          // (B, 3, N) out, or nullptr
+  int D;
+};
+
+template <int V, bool FRUSTUM>
 __global__ __launch_bounds__(256) void fetch_variance_kernel(const float* __restrict__ maps,
-                                                             const float* __restrict__ pts,
+                                                             const float* __restrict__ pts, Frustum fr,
                                                              const float* __restrict__ Kmat,
                                                              const float* __restrict__ Emat,
                                                              float* __restrict__ out, int C, int H, int W,
@@ -77,8 +88,37 @@ __global__ __launch_bounds__(256) void fetch_variance_kernel(const float* __rest
   const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t b = blockIdx.y;
   if (n >= N) return;
-  const float* pb = pts + b * 3 * N;
-  const float X = pb[n], Y = pb[N + n], Z = pb[2 * N + n];
+  float X, Y, Z;
+  if (FRUSTUM) {
+    const int hw = H * W;
+    const int d = (int)(n / hw);
+    const int pix = (int)(n - (int64_t)d * hw);
+    const int py = pix / W, px = pix - py * W;
+    const float gx = (float)px + 0.5f, gy = (float)py + 0.5f;
+    const float* ki = fr.kinv + b * 9;
+    const float* ri = fr.rinv + b * 9;
+    const float* tt = fr.t + b * 3;
+    const float depth = fr.depths[b * fr.D + d];
+    // the dot products as fmaf chains in index order (the reference's are library matmuls of K = 3)
+    const float u0 = fmaf(ki[2], 1.0f, fmaf(ki[1], gy, ki[0] * gx));
+    const float u1 = fmaf(ki[5], 1.0f, fmaf(ki[4], gy, ki[3] * gx));
+    const float u2 = fmaf(ki[8], 1.0f, fmaf(ki[7], gy, ki[6] * gx));
+    const float c0 = u0 * depth - tt[0], c1 = u1 * depth - tt[1], c2 = u2 * depth - tt[2];
+    X = fmaf(ri[2], c2, fmaf(ri[1], c1, ri[0] * c0));
+    Y = fmaf(ri[5], c2, fmaf(ri[4], c1, ri[3] * c0));
+    Z = fmaf(ri[8], c2, fmaf(ri[7], c1, ri[6] * c0));
+    if (fr.world != nullptr) {
+      float* wb = fr.world + b * 3 * N;
+      wb[n] = X;
+      wb[N + n] = Y;
+      wb[2 * N + n] = Z;
+    }
+  } else {
+    const float* pb = pts + b * 3 * N;
+    X = pb[n];
+    Y = pb[N + n];
+    Z = pb[2 * N + n];
+  }
   PfTaps t[V];
 #pragma unroll
   for (int v = 0; v < V; ++v)
@@ -354,8 +394,33 @@ int pf_fetch_variance_f32(const float* maps, const float* pts, const float* K, c
   dim3 grid((unsigned)pf_cdiv(N, 256), (unsigned)B);
   return dispatch_views((int)V, [&](auto vtag) {
     constexpr int VV = decltype(vtag)::value;
-    hipLaunchKernelGGL(fetch_variance_kernel<VV>, grid, dim3(256), 0, (hipStream_t)stream, maps, pts, K, E, out,
-                       (int)C, (int)H, (int)W, N, ref_override);
+    hipLaunchKernelGGL((fetch_variance_kernel<VV, false>), grid, dim3(256), 0, (hipStream_t)stream, maps, pts,
+                       Frustum{}, K, E, out, (int)C, (int)H, (int)W, N, ref_override);
+    return pf_launch_status();
+  });
+}
+
+int pf_frustum_variance_f32(const float* maps, const float* kinv, const float* rinv, const float* t,
+                            const float* depths, const float* K, const float* E, float* out, float* world,
+                            int64_t B, int64_t V, int64_t C, int64_t H, int64_t W, int64_t D, void* stream) {
+  PF_REQUIRE(B >= 0 && V >= 1 && C >= 0 && H >= 1 && W >= 1 && D >= 0);
+  PF_REQUIRE(B <= 65535 && H * W <= INT32_MAX && C <= INT32_MAX && D <= INT32_MAX);
+  if (V > PF_MAX_VIEWS) return PF_ERR_UNSUPPORTED;
+  const int64_t N = D * H * W;
+  if (B == 0 || N == 0) return PF_OK;
+  PF_REQUIRE(maps && kinv && rinv && t && depths && K && out);
+  Frustum fr;
+  fr.kinv = kinv;
+  fr.rinv = rinv;
+  fr.t = t;
+  fr.depths = depths;
+  fr.world = world;
+  fr.D = (int)D;
+  dim3 grid((unsigned)pf_cdiv(N, 256), (unsigned)B);
+  return dispatch_views((int)V, [&](auto vtag) {
+    constexpr int VV = decltype(vtag)::value;
+    hipLaunchKernelGGL((fetch_variance_kernel<VV, true>), grid, dim3(256), 0, (hipStream_t)stream, maps, nullptr, fr,
+                       K, E, out, (int)C, (int)H, (int)W, N, 1);
     return pf_launch_status();
   });
 }

@@ -168,9 +168,137 @@ __global__ __launch_bounds__(256) void channel_bn_apply_kernel(
   affine_stream(x + ((int64_t)n * C + c) * S, y + ((int64_t)n * C + c) * S, S, a, b, relu);
 }
 
+// Small tensors (the encoder/decoder layers of VolumeConv and the deep tower stages: <= 256 KB per channel):
+// statistics, finalize and normalise in ONE launch.  A 1024-thread block owns a channel and walks its stat
+// groups in order (the running-statistics recurrence is sequential anyway): pass 1 reduces the group's
+// samples_per_stat x S elements (float per lane, float64 across lanes, fixed order), pass 2 re-reads them
+// (L2-resident) and writes y.  With y == nullptr only the affine rows scale/shift (G, ld) are produced
+// (the next conv applies them while staging).  Saves a 4-5 us dependent launch per layer.
+constexpr int kFusedThreads = 1024;
+
+__global__ __launch_bounds__(kFusedThreads) void channel_bn_fused_kernel(
+    const float* __restrict__ x, float* __restrict__ y, int C, int64_t S, int samples_per_stat, int G,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ running_mean,
+    float* __restrict__ running_var, float momentum, float eps, int relu, float* __restrict__ scale_out,
+    float* __restrict__ shift_out, int ld_affine) {
+  __shared__ double2 red[kFusedThreads / 64];
+  __shared__ double2 total;
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const double count = (double)samples_per_stat * (double)S;
+  const bool vec = ((((uintptr_t)x | (uintptr_t)y) & 15) == 0) && (S & 3) == 0;
+  float rm = 0.0f, rv = 0.0f;
+  const bool track = running_mean != nullptr;
+  if (track) {
+    rm = running_mean[c];
+    rv = running_var[c];
+  }
+  for (int g = 0; g < G; ++g) {
+    float s0 = 0.0f, q0 = 0.0f;
+    for (int j = 0; j < samples_per_stat; ++j) {
+      const float* p = x + ((int64_t)(g * samples_per_stat + j) * C + c) * S;
+      if (vec) {
+        const float4* p4 = reinterpret_cast<const float4*>(p);
+        for (int64_t i = tid; i < (S >> 2); i += kFusedThreads) {
+          const float4 a = p4[i];
+          s0 += (a.x + a.y) + (a.z + a.w);
+          q0 += (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
+        }
+      } else {
+        for (int64_t i = tid; i < S; i += kFusedThreads) {
+          const float v = p[i];
+          s0 += v;
+          q0 += v * v;
+        }
+      }
+    }
+    double ds = (double)s0, dq = (double)q0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      ds += __shfl_xor(ds, off);
+      dq += __shfl_xor(dq, off);
+    }
+    if ((tid & 63) == 0) red[tid >> 6] = make_double2(ds, dq);
+    __syncthreads();
+    if (tid == 0) {
+      double a = 0.0, b = 0.0;
+      for (int w = 0; w < kFusedThreads / 64; ++w) {
+        a += red[w].x;
+        b += red[w].y;
+      }
+      total = make_double2(a, b);
+    }
+    __syncthreads();
+    const double mean = total.x / count;
+    double var = total.y / count - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    const float a = (float)(1.0 / sqrt(var + (double)eps)) * gamma[c];
+    const float b = beta[c] - (float)mean * a;
+    if (track) {
+      const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
+      rm = (1.0f - momentum) * rm + momentum * (float)mean;
+      rv = (1.0f - momentum) * rv + momentum * (float)unbiased;
+    }
+    if (scale_out != nullptr && tid == 0) {
+      scale_out[(int64_t)g * ld_affine + c] = a;
+      shift_out[(int64_t)g * ld_affine + c] = b;
+    }
+    if (y != nullptr) {
+      for (int j = 0; j < samples_per_stat; ++j) {
+        const int64_t o = ((int64_t)(g * samples_per_stat + j) * C + c) * S;
+        if (vec) {
+          const float4* p4 = reinterpret_cast<const float4*>(x + o);
+          float4* o4 = reinterpret_cast<float4*>(y + o);
+          for (int64_t i = tid; i < (S >> 2); i += kFusedThreads) {
+            float4 v = p4[i];
+            v.x = fmaf(v.x, a, b);
+            v.y = fmaf(v.y, a, b);
+            v.z = fmaf(v.z, a, b);
+            v.w = fmaf(v.w, a, b);
+            if (relu) {
+              v.x = fmaxf(v.x, 0.0f);
+              v.y = fmaxf(v.y, 0.0f);
+              v.z = fmaxf(v.z, 0.0f);
+              v.w = fmaxf(v.w, 0.0f);
+            }
+            o4[i] = v;
+          }
+        } else {
+          for (int64_t i = tid; i < S; i += kFusedThreads) {
+            const float v = fmaf(x[o + i], a, b);
+            y[o + i] = relu ? fmaxf(v, 0.0f) : v;
+          }
+        }
+      }
+    }
+    // (red/total are rewritten only after the next group's first barrier; x may alias y: each element is
+    // read in pass 1 before any lane's pass 2 writes thanks to the barriers above)
+  }
+  if (track && tid == 0) {
+    running_mean[c] = rm;
+    running_var[c] = rv;
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int pf_channel_bn_fused_f32(const float* x, float* y, int64_t N, int64_t C, int64_t S, int samples_per_stat,
+                            const float* gamma, const float* beta, float* running_mean, float* running_var,
+                            float momentum, float eps, int relu, float* scale, float* shift, int ld_affine,
+                            void* stream) {
+  PF_REQUIRE(N >= 0 && C >= 0 && S >= 0 && N <= 65535 && C <= INT32_MAX && samples_per_stat >= 1);
+  PF_REQUIRE(N % samples_per_stat == 0);
+  PF_REQUIRE((running_mean == nullptr) == (running_var == nullptr) && (scale == nullptr) == (shift == nullptr));
+  PF_REQUIRE(y != nullptr || scale != nullptr);
+  PF_REQUIRE(scale == nullptr || ld_affine >= C);
+  if (N == 0 || C == 0 || S == 0) return PF_OK;
+  PF_REQUIRE(x && gamma && beta);
+  hipLaunchKernelGGL(channel_bn_fused_kernel, dim3((unsigned)C), dim3(kFusedThreads), 0, (hipStream_t)stream, x, y,
+                     (int)C, S, samples_per_stat, (int)(N / samples_per_stat), gamma, beta, running_mean, running_var,
+                     momentum, eps, relu, scale, shift, ld_affine);
+  return pf_launch_status();
+}
 
 int pf_norm_blocks(int64_t S) {
   if (S <= 0) return 0;

@@ -28,7 +28,7 @@ from . import pointflow
 from .functions.functions import get_pixel_grids, get_propability_map
 from .networks import EdgeConv, EdgeConvNoC, ImageConv, VolumeConv, MAELoss, Valid_MAELoss
 from .nn.mlp import SharedMLP
-from .utils.feature_fetcher import FeatureFetcher, fetch_variance
+from .utils.feature_fetcher import FeatureFetcher, frustum_variance
 from .utils.torch_utils import get_knn_3d
 
 _HYPOTHESES = (-2, -1, 0, 1, 2)
@@ -252,16 +252,12 @@ class PointMVSNet(nn.Module):
     def run_coarse_stage(self, plan, feature_list):
         """Coarse stage after the tower (reference model.py:79-130): warp, variance, VolumeConv, soft-argmin."""
         B, D = plan.B, plan.D
-        dev = feature_list.device
         preds = collections.OrderedDict()
         C, FH, FW = feature_list.shape[2:]
-        grid = self._pixel_grid(FH, FW, dev).view(1, 1, 3, -1).expand(B, 1, 3, -1)
-        uv = torch.matmul(plan.d("Kinv0"), grid)
-        cam_points = (uv.unsqueeze(3) * plan.d("depths").view(B, 1, 1, D, 1)).view(B, 1, 3, -1)
-        world_points = torch.matmul(plan.d("Rinv0"), cam_points - plan.d("t0")).transpose(1, 2).contiguous() \
-            .view(B, 3, -1)
+        # the frustum points (model.py:79-100) are generated inside the fetch+variance kernel
+        cost, world_points = frustum_variance(feature_list, plan.d("Kinv0"), plan.d("Rinv0"), plan.d("t0"),
+                                              plan.d("depths"), plan.d("K_coarse"), plan.d("ext"))
         preds["world_points"] = world_points
-        cost = fetch_variance(feature_list, world_points, plan.d("K_coarse"), plan.d("ext"), ref_override=True)
         filtered = self.coarse_vol_conv.forward_fused(cost.view(B, C, D, FH, FW)).squeeze(1)   # (B,D,FH,FW)
         pred_depth, prob_map = pointflow.soft_argmin_params(filtered, plan.d("sa_params"))
         preds["coarse_depth_map"] = pred_depth

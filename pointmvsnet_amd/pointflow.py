@@ -312,6 +312,23 @@ def channel_affine_(x, affine, relu, samples_per_stat):
     return x
 
 
+# one-launch BatchNorm (pf_channel_bn_fused_f32) when a channel's N*S elements fit one block's streaming budget
+FUSED_BN_MAX = 65536
+
+
+def _bn_fused(x, y, bn, relu, samples_per_stat, scale=None, shift=None):
+    N, C = x.shape[:2]
+    S = x[0, 0].numel()
+    if bn.momentum is None:
+        raise NotImplementedError("cumulative-average BatchNorm momentum is not supported")
+    track = bn.track_running_stats and bn.running_mean is not None
+    _lib.call("pf_channel_bn_fused_f32", _lib.ptr(x), _lib.ptr(y), N, C, S, int(samples_per_stat),
+              _lib.ptr(bn.weight.detach()), _lib.ptr(bn.bias.detach()), _lib.ptr(bn.running_mean if track else None),
+              _lib.ptr(bn.running_var if track else None), float(bn.momentum), float(bn.eps), int(bool(relu)),
+              _lib.ptr(scale), _lib.ptr(shift), int(scale.stride(0)) if scale is not None else 0, _lib.stream(),
+              algo_bytes=(8.0 if y is not None else 4.0) * N * C * S)
+
+
 def bn_affine_rows(x, bn, samples_per_stat, partials=None):
     """(scale, shift) rows (N/sps, C) of BatchNorm ``bn`` for the raw conv output x (N,C,*spatial): batch
     statistics from ``partials`` (or a statistics pass over x) in train mode, running statistics in eval."""
@@ -320,13 +337,17 @@ def bn_affine_rows(x, bn, samples_per_stat, partials=None):
     G = N // samples_per_stat
     dev = x.device
     if bn.training or not bn.track_running_stats:
+        scale = torch.empty((G, C), dtype=_F32, device=dev)
+        shift = torch.empty((G, C), dtype=_F32, device=dev)
+        if partials is None and N * S <= FUSED_BN_MAX:
+            _bn_fused(x, None, bn, False, samples_per_stat, scale, shift)
+            bump_counter(bn, G)
+            return scale, shift
         if partials is None:
             T = int(_lib.load().pf_norm_blocks(S))
             partials = torch.empty((N, T, C, 2), dtype=torch.float64, device=dev)
             _lib.call("pf_channel_stats_f32", _lib.ptr(x), N, C, S, _lib.ptr(partials), _lib.stream(),
                       algo_bytes=4.0 * N * C * S)
-        scale = torch.empty((G, C), dtype=_F32, device=dev)
-        shift = torch.empty((G, C), dtype=_F32, device=dev)
         n = float(samples_per_stat) * S
         bn_affine(bn, partials, 0, C, n, n, N, samples_per_stat, scale, shift)
         bump_counter(bn, G)
@@ -378,6 +399,10 @@ def batch_norm_act_(x, bn, relu, samples_per_stat, partials=None):
     if bn.training or not bn.track_running_stats:
         if bn.momentum is None:
             raise NotImplementedError("cumulative-average BatchNorm momentum is not supported")
+        if partials is None and N * S <= FUSED_BN_MAX:
+            _bn_fused(x, x, bn, relu, samples_per_stat)
+            bump_counter(bn, G)
+            return x
         if partials is None:
             T = int(_lib.load().pf_norm_blocks(S))
             partials = torch.empty((N, T, C, 2), dtype=torch.float64, device=dev)

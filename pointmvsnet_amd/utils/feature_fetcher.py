@@ -79,3 +79,28 @@ def fetch_variance(feature_maps, pts, cam_intrinsics, cam_extrinsics, ref_overri
                   B, V, C, H, W, N, int(bool(ref_override)), _lib.stream(),
                   algo_bytes=4.0 * B * (V * C * H * W + 3 * N + C * N))
     return out
+
+
+def frustum_variance(feature_maps, kinv, rinv, t, depths, cam_intrinsics, cam_extrinsics, want_points=True):
+    """Coarse cost volume (reference model.py:79-111) without materialising the frustum first: the world
+    points of the reference view's depth hypotheses are generated inside the fetch+variance kernel
+    (pf_frustum_variance_f32).  kinv/rinv (B,3,3), t (B,3), depths (B,D) float32 on the device.
+    Returns (cost (B,C,D*H*W), world_points (B,3,D*H*W) or None)."""
+    _lib.require_gpu(feature_maps, kinv, rinv, t, depths, cam_intrinsics, cam_extrinsics)
+    maps = feature_maps.detach().float().contiguous()
+    B, V, C, H, W = maps.shape
+    D = depths.shape[-1]
+    kinv = kinv.detach().float().reshape(B, 9).contiguous()
+    rinv = rinv.detach().float().reshape(B, 9).contiguous()
+    t = t.detach().float().reshape(B, 3).contiguous()
+    depths = depths.detach().float().reshape(B, D).contiguous()
+    K = cam_intrinsics.detach().float().reshape(B, V, 9).contiguous()
+    E = cam_extrinsics.detach().float().reshape(B, V, 12).contiguous()
+    N = D * H * W
+    out = torch.empty((B, C, N), dtype=torch.float32, device=maps.device)
+    world = torch.empty((B, 3, N), dtype=torch.float32, device=maps.device) if want_points else None
+    with torch.cuda.device(maps.device):
+        _lib.call("pf_frustum_variance_f32", _lib.ptr(maps), _lib.ptr(kinv), _lib.ptr(rinv), _lib.ptr(t),
+                  _lib.ptr(depths), _lib.ptr(K), _lib.ptr(E), _lib.ptr(out), _lib.ptr(world), B, V, C, H, W, D,
+                  _lib.stream(), algo_bytes=4.0 * B * (V * C * H * W + (3 * N if want_points else 0) + C * N))
+    return out, world

@@ -233,6 +233,41 @@ def test_fetch_variance_vs_oracle(dev, V, ref_override):
     assert err < 6e-5 * scale
 
 
+@pytest.mark.parametrize("B,V", [(1, 3), (2, 5)])
+def test_frustum_variance_vs_reference_composition(dev, B, V):
+    """Coarse-stage use (model.py:79-111): frustum points generated in the kernel == the reference's matmul
+    composition to float32 rounding, and the cost volume == fetch_variance on exactly those points."""
+    from pointmvsnet_amd.functions.functions import get_pixel_grids
+    from pointmvsnet_amd.utils.feature_fetcher import frustum_variance
+    gen = torch.Generator().manual_seed(10 * B + V)
+    C, H, W, D = 8, 16, 20, 6
+    data = synthetic.make_scene(128, 160, V, D, seed=V, batch=B)
+    cams = data["cam_params_list"]
+    K = cams[:, :, 1, :3, :3].clone()
+    K[:, :, :2, :3] /= 8.0
+    E = cams[:, :, 0, :3, :4].clone()
+    feats = torch.randn(B, V, C, H, W, generator=gen)
+    kinv = torch.inverse(K[:, 0])
+    rinv = torch.inverse(E[:, 0, :, :3])
+    t0 = E[:, 0, :, 3]
+    depths = torch.stack([torch.linspace(425.0 + 10 * b, 900.0 + 10 * b, D) for b in range(B)])
+    grid = get_pixel_grids(H, W).view(1, 3, -1).expand(B, 3, -1)
+    uv = torch.matmul(kinv, grid)
+    cam_points = (uv.unsqueeze(2) * depths.view(B, 1, D, 1)).view(B, 3, -1)
+    world_ref = torch.matmul(rinv, cam_points - t0.unsqueeze(2))
+    out, world = frustum_variance(feats.to(dev), kinv.to(dev), rinv.to(dev), t0.to(dev), depths.to(dev), K.to(dev),
+                                  E.to(dev))
+    err = _maxabs(world, world_ref)
+    report("frustum_points_B%d_V%d" % (B, V), err=err, scale=float(world_ref.abs().max()))
+    # float32 evaluation of a ~1000 mm coordinate in a different association order: a few ulp (6e-5 mm each)
+    assert err < 1e-3
+    same = fetch_variance(feats.to(dev), world, K.to(dev), E.to(dev), ref_override=True)
+    assert torch.equal(out, same)
+    out2, none = frustum_variance(feats.to(dev), kinv.to(dev), rinv.to(dev), t0.to(dev), depths.to(dev), K.to(dev),
+                                  E.to(dev), want_points=False)
+    assert none is None and torch.equal(out2, out)
+
+
 def test_fetch_errors(dev):
     f = FeatureFetcher()
     with pytest.raises(RuntimeError):
@@ -403,7 +438,8 @@ def test_volume_conv_vs_reference(dev):
 # BatchNorm kernels for the conv stacks, batched-view ImageConv, fused VolumeConv
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("shape,sps", [((3, 8, 64, 80), 1), ((6, 16, 7, 9), 2), ((1, 8, 6, 16, 20), 1),
-                                       ((2, 5, 3, 5, 7), 2), ((4, 3, 33), 1)])
+                                       ((2, 5, 3, 5, 7), 2), ((4, 3, 33), 1), ((3, 4, 160, 200), 1),
+                                       ((2, 3, 150, 250), 2)])       # the last two exceed the one-launch budget
 @pytest.mark.parametrize("relu", [True, False])
 def test_batch_norm_act_vs_torch_per_group(dev, shape, sps, relu):
     gen = torch.Generator().manual_seed(sum(shape))
@@ -428,6 +464,18 @@ def test_batch_norm_act_vs_torch_per_group(dev, shape, sps, relu):
     assert _maxabs(bn.running_mean, ref_bn.running_mean) < 1e-6
     assert float(((bn.running_var.cpu() - ref_bn.running_var).abs() / ref_bn.running_var).max()) < 1e-5
     assert int(bn.num_batches_tracked) == int(ref_bn.num_batches_tracked) == shape[0] // sps
+    # affine-rows form (the consumer normalises itself): same statistics, no pass over y
+    bn2 = bn_cls(C)
+    synthetic.seed_weights(bn2, 3)
+    bn2 = bn2.to(dev).train()
+    xd = x.to(dev).contiguous()
+    sc, sh = pointflow.bn_affine_rows(xd, bn2, sps)
+    pointflow.flush_counters()
+    G = shape[0] // sps
+    yy = xd.view(G, sps, C, -1) * sc.view(G, 1, C, 1) + sh.view(G, 1, C, 1)
+    yy = (F.relu(yy) if relu else yy).view(shape)
+    assert _maxabs(yy, ref) < 5e-6 * max(1.0, float(ref.abs().max()))
+    assert _maxabs(bn2.running_mean, ref_bn.running_mean) < 1e-6
 
 
 def test_image_conv_batched_views_equals_per_view_calls(dev):
