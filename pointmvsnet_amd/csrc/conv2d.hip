@@ -12,6 +12,8 @@
 //   * a 256-thread block owns (4*TR) x 16 output pixels; wave w owns TR rows; K is walked in groups of
 //     4 input channels (C_in = 3 is zero-padded to 4), double buffered through LDS.
 // Bound: fp32 MFMA for the wide layers, HBM (4*(C_in+C_out) B/pixel) for the 3->8 / 8->8 full-resolution ones.
+#include <stdlib.h>
+
 #include "pf_common.h"
 
 namespace {
@@ -24,6 +26,7 @@ struct Conv2Geom {
   int Cin, Cout, Hi, Wi, Ho, Wo, tiles_h, tiles_w, sps;
 };
 
+// Staged patch of one input channel for a (4*TR) x 16 output tile; compile-time (see conv3d.hip, v3).
 template <int STRIDE, int KS, int TR>
 struct Stage2 {
   static constexpr int IH = (4 * TR - 1) * STRIDE + KS;
@@ -32,48 +35,53 @@ struct Stage2 {
   static constexpr int RAW = IH * IWP;
   static constexpr int WANT = STRIDE == 1 ? 16 : 17;   // bank offset between channel planes (see conv3d.hip)
   static constexpr int PLANE = RAW + ((WANT - RAW % 32) + 32) % 32;
-  static constexpr int ROWS = 4 * IH;
-  static constexpr int NXR = (ROWS + 7) / 8;
-  static constexpr int XPASS = (IW + 31) / 32;
+  static constexpr int ELEMS = IH * IW;               // floats of one channel's patch
+  static constexpr int NXR = (ELEMS + 63) / 64;       // ... per lane of the wave that stages the channel
 };
 
-template <int NT, int STRIDE, int KS, int TR>
+template <int NT, int STRIDE, int KS, int TR, int KG>
 constexpr size_t lds_bytes_2d() {
   using S = Stage2<STRIDE, KS, TR>;
-  return sizeof(float) * (size_t)(2 * 4 * S::PLANE + 2 * KS * KS * 4 * NT * 16 + 4 * NT * 16 * 17) +
+  return sizeof(float) * (size_t)(2 * KG * 4 * S::PLANE + 2 * KG * KS * KS * 4 * NT * 16 + 4 * NT * 16 * 17) +
          sizeof(double) * (size_t)(4 * NT * 16 * 2);
 }
 
-template <int NT, int STRIDE, int KS, int TR>
-__global__ __launch_bounds__(256) void conv2d_kernel(const float* __restrict__ x, const float* __restrict__ wp,
-                                                     float* __restrict__ y, Conv2Geom g,
-                                                     const float* __restrict__ in_scale,
-                                                     const float* __restrict__ in_shift,
-                                                     double* __restrict__ partials) {
+// v3 (same moves as conv3d.hip v3): compile-time patch geometry, so every LDS address of the MFMA loop is a
+// base register + immediate; a step covers KG groups of 4 input channels (a 3x3 step of 4 channels is only
+// 9*TR*NT MFMAs -- shorter than one global-load latency -- so two groups share a barrier); wave w stages
+// channel w of each group, its lanes walking the channel's patch as one flat index (unconditional loads,
+// one 32-bit offset per element per tile, wave-uniform channel base and BatchNorm affine).
+template <int NT, int STRIDE, int KS, int TR, int KG, int MINW>
+__global__ __launch_bounds__(256, MINW) void conv2d_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                           float* __restrict__ y, Conv2Geom g,
+                                                           const float* __restrict__ in_scale,
+                                                           const float* __restrict__ in_shift,
+                                                           double* __restrict__ partials) {
   using S = Stage2<STRIDE, KS, TR>;
+  constexpr int IH = S::IH, IW = S::IW, IWP = S::IWP, PLANE = S::PLANE, ELEMS = S::ELEMS, NXR = S::NXR;
   constexpr int NCP = NT * 16;
   constexpr int KK = KS * KS;
   constexpr int PAD = KS / 2;
-  constexpr int WSZ = KK * 4 * NCP;
+  constexpr int WSZ4 = KK * 4 * NCP;                 // weights of one 4-channel group
+  constexpr int WSZ = KG * WSZ4;                     // ... of one step
   constexpr int NWR = (WSZ + 255) / 256;
-  constexpr int NXR = S::NXR, XPASS = S::XPASS;
+  constexpr int XS = KG * 4 * PLANE;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int XS = 4 * S::PLANE;
   float* xs0 = lds;
   float* ws0 = lds + 2 * XS;
   float* tile = ws0 + 2 * WSZ;
   double* red = reinterpret_cast<double*>(tile + 4 * NCP * 17);
 
   const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int li = lane & 15, lk = lane >> 4;
   const int n = blockIdx.y;
-  const int64_t plane_i = (int64_t)g.Hi * g.Wi;
+  const int plane_i = g.Hi * g.Wi;                   // Cin * plane_i < 2^31 (checked on the host)
   const int64_t plane_o = (int64_t)g.Ho * g.Wo;
   const float* xb = x + (int64_t)n * g.Cin * plane_i;
   float* yb = y + (int64_t)n * g.Cout * plane_o;
-  const int cgroups = (g.Cin + 3) >> 2;
-  const int srow = tid >> 5, scol = tid & 31;
+  const int groups4 = (g.Cin + 3) >> 2;
+  const int steps = (groups4 + KG - 1) / KG;
   const float* sc = in_scale ? in_scale + (int64_t)(n / g.sps) * g.Cin : nullptr;
   const float* sh = in_scale ? in_shift + (int64_t)(n / g.sps) * g.Cin : nullptr;
 
@@ -81,107 +89,101 @@ __global__ __launch_bounds__(256) void conv2d_kernel(const float* __restrict__ x
 #pragma unroll
   for (int t = 0; t < NT; ++t) ssum[t] = ssq[t] = 0.0;
 
-  // The block walks a flat sequence of (tile, channel group) steps with the NEXT step's global loads
-  // always in flight, across tile boundaries too: with C_in = 8 a tile has only two groups, so a per-tile
-  // prologue would expose one full memory latency per tile (measured: 58 us vs a 12 us HBM floor).
+  // The block walks a flat sequence of (tile, step) pairs with the NEXT pair's global loads always in
+  // flight, across tile boundaries too (a tile of an 8-channel layer is a single step).
   const int total = g.tiles_h * g.tiles_w;
-  int gofs[NXR], lofs[NXR];            // staging plan of the tile being LOADED (row = ch * IH + hy)
-  int l_iw0 = 0;
+  unsigned gofs[NXR];                  // staging plan of the tile being LOADED
+  unsigned okmask = 0;
   auto plan_tile = [&](int item) {
     const int tw = item % g.tiles_w, th = item / g.tiles_w;
-    const int ih0 = th * 4 * TR * STRIDE - PAD;
-    l_iw0 = tw * 16 * STRIDE - PAD;
+    const int ih0 = th * 4 * TR * STRIDE - PAD, iw0 = tw * 16 * STRIDE - PAD;
+    okmask = 0;
 #pragma unroll
     for (int r = 0; r < NXR; ++r) {
-      const int row = r * 8 + srow;
-      const int ch = row / S::IH, hy = row - ch * S::IH;
-      const int ih = ih0 + hy;
-      const bool in = row < S::ROWS;
-      gofs[r] = (in && ih >= 0 && ih < g.Hi) ? (int)((int64_t)ch * plane_i + (int64_t)ih * g.Wi) : -1;
-      lofs[r] = in ? ch * S::PLANE + hy * S::IWP : -1;
+      const int e = lane + 64 * r;
+      const int hy = e / IW, col = e - hy * IW;
+      const int ih = ih0 + hy, iw = iw0 + col;
+      const bool ok = e < ELEMS && ih >= 0 && ih < g.Hi && iw >= 0 && iw < g.Wi;
+      gofs[r] = ok ? (unsigned)(ih * g.Wi + iw) : 0u;
+      okmask |= (ok ? 1u : 0u) << r;
     }
   };
 
-  float rx[NXR * XPASS], rw[NWR];
-  auto load_group = [&](int cg) {
-    const float* src = xb + (int64_t)cg * 4 * plane_i;
+  float rx[KG][NXR], rw[NWR];
+  auto load_step = [&](int st) {
 #pragma unroll
-    for (int r = 0; r < NXR; ++r) {
-      const int c = cg * 4 + (r * 8 + srow) / S::IH;
-      const bool cok = gofs[r] >= 0 && c < g.Cin;
+    for (int kg = 0; kg < KG; ++kg) {
+      const int c = (st * KG + kg) * 4 + wave;                        // wave-uniform channel
+      const bool cok = c < g.Cin;
+      const float* src = xb + (int64_t)(cok ? c : 0) * plane_i;
       float a = 1.0f, b = 0.0f;
       if (sc != nullptr && cok) {
         a = sc[c];
         b = sh[c];
       }
 #pragma unroll
-      for (int p = 0; p < XPASS; ++p) {
-        const int col = scol + 32 * p;
-        const int iw = l_iw0 + col;
-        float v = 0.0f;
-        if (cok && col < S::IW && iw >= 0 && iw < g.Wi) {
-          v = src[gofs[r] + iw];
-          if (sc != nullptr) v = fmaxf(fmaf(v, a, b), 0.0f);         // previous layer's BatchNorm + ReLU
-        }
-        rx[r * XPASS + p] = v;
+      for (int r = 0; r < NXR; ++r) {
+        float v = src[gofs[r]];
+        if (sc != nullptr) v = fmaxf(fmaf(v, a, b), 0.0f);           // previous layer's BatchNorm + ReLU
+        rx[kg][r] = (cok && ((okmask >> r) & 1u)) ? v : 0.0f;         // zero padding applies AFTER it
       }
     }
-    const float* wsrc = wp + (int64_t)cg * WSZ;
+    const int valid = min(KG, groups4 - st * KG) * WSZ4;              // a last, partial step: zero weights
+    const float* wsrc = wp + (int64_t)st * WSZ;
 #pragma unroll
     for (int r = 0; r < NWR; ++r) {
       const int e = tid + 256 * r;
-      rw[r] = e < WSZ ? wsrc[e] : 0.0f;
+      rw[r] = e < valid ? wsrc[e] : 0.0f;
     }
   };
-  auto store_group = [&](int buf) {
-    float* xs = xs0 + buf * XS;
+  auto store_step = [&](int buf) {
     float* ws = ws0 + buf * WSZ;
 #pragma unroll
-    for (int r = 0; r < NXR; ++r) {
-      if (lofs[r] >= 0) {
+    for (int kg = 0; kg < KG; ++kg) {
+      float* xs = xs0 + buf * XS + (kg * 4 + wave) * PLANE;
 #pragma unroll
-        for (int p = 0; p < XPASS; ++p) {
-          const int col = scol + 32 * p;
-          if (col < S::IW) xs[lofs[r] + col] = rx[r * XPASS + p];
-        }
+      for (int r = 0; r < NXR; ++r) {
+        const int e = lane + 64 * r;
+        if (64 * (r + 1) <= ELEMS || e < ELEMS) xs[e + e / IW] = rx[kg][r];
       }
     }
 #pragma unroll
     for (int r = 0; r < NWR; ++r) {
       const int e = tid + 256 * r;
-      if (e < WSZ) ws[e] = rw[r];
+      if (256 * (r + 1) <= WSZ || e < WSZ) ws[e] = rw[r];
     }
   };
 
   f32x4 acc[TR][NT];
-  int item = blockIdx.x, cg = 0, buf = 0;
+  int item = blockIdx.x, st = 0, buf = 0;
   if (item < total) {
     plan_tile(item);
-    load_group(0);
-    store_group(0);
+    load_step(0);
+    store_step(0);
   }
   __syncthreads();
   while (item < total) {
-    // the step after (item, cg)
-    int n_item = item, n_cg = cg + 1;
-    if (n_cg == cgroups) {
-      n_cg = 0;
+    // the pair after (item, st)
+    int n_item = item, n_st = st + 1;
+    if (n_st == steps) {
+      n_st = 0;
       n_item = item + gridDim.x;
     }
     const bool has_next = n_item < total;
     if (has_next) {
-      if (n_cg == 0) plan_tile(n_item);
-      load_group(n_cg);
+      if (n_st == 0) plan_tile(n_item);
+      load_step(n_st);
     }
-    if (cg == 0) {
+    if (st == 0) {
 #pragma unroll
       for (int r = 0; r < TR; ++r)
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[r][t] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
     }
-    {
-      const float* xs = xs0 + buf * XS + lk * S::PLANE + (wave * TR * STRIDE) * S::IWP + li * STRIDE;
-      const float* ws = ws0 + buf * WSZ + lk * NCP + li;
+#pragma unroll
+    for (int kg = 0; kg < KG; ++kg) {
+      const float* xs = xs0 + buf * XS + (kg * 4 + lk) * PLANE + (wave * TR * STRIDE) * IWP + li * STRIDE;
+      const float* ws = ws0 + buf * WSZ + kg * WSZ4 + lk * NCP + li;
 #pragma unroll
       for (int kh = 0; kh < KS; ++kh) {
 #pragma unroll
@@ -191,14 +193,14 @@ __global__ __launch_bounds__(256) void conv2d_kernel(const float* __restrict__ x
           for (int t = 0; t < NT; ++t) b[t] = ws[(kh * KS + kw) * 4 * NCP + 16 * t];
 #pragma unroll
           for (int r = 0; r < TR; ++r) {
-            const float a = xs[(r * STRIDE + kh) * S::IWP + kw];
+            const float a = xs[(r * STRIDE + kh) * IWP + kw];
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[t], acc[r][t], 0, 0, 0);
           }
         }
       }
     }
-    if (cg == cgroups - 1) {
+    if (st == steps - 1) {
       // epilogue of tile `item`: per-wave LDS transpose -> 64-byte segments per channel, BN statistics
       const int tw = item % g.tiles_w, th = item / g.tiles_w;
       const int oh0 = th * 4 * TR, ow0 = tw * 16;
@@ -238,10 +240,10 @@ __global__ __launch_bounds__(256) void conv2d_kernel(const float* __restrict__ x
         __builtin_amdgcn_wave_barrier();
       }
     }
-    if (has_next) store_group(buf ^ 1);
+    if (has_next) store_step(buf ^ 1);
     __syncthreads();
     item = n_item;
-    cg = n_cg;
+    st = n_st;
     buf ^= 1;
   }
 
@@ -268,7 +270,23 @@ __global__ __launch_bounds__(256) void conv2d_kernel(const float* __restrict__ x
   }
 }
 
-int tr_for(int ks, int nt) { return (ks == 5 && nt == 4) ? 1 : 2; }
+// Tuning hook (microbenchmarks only): PF_CONV2D_VARIANT = 100*TR + 10*KG + MINW for the NT <= 2 kernels.
+int variant2d() {
+  const char* e = getenv("PF_CONV2D_VARIANT");
+  return e ? atoi(e) : 0;
+}
+
+// Rows per wave.  Measured (profiles/r01j_microbench_conv2d.log): 3x3 layers with <= 16 output channels run
+// best on 16 x 16 tiles (TR 4: an A operand is reused for one column tile only, so more rows per weight
+// read pay) when that still leaves >= 512 tiles; 32-channel layers and the 5x5/2 layers on 8 x 16 tiles;
+// 5x5 layers with 64 output channels only fit with TR = 1.
+int tr_for(int ks, int nt, int64_t Ho, int64_t Wo, int64_t N) {
+  const int ov = variant2d() / 100;
+  if (ov && nt <= 2) return (ks == 5) ? 2 : ov;
+  if (ks == 5) return nt == 4 ? 1 : 2;
+  if (nt == 1 && ((Ho + 15) / 16) * ((Wo + 15) / 16) * N >= 512) return 4;
+  return 2;
+}
 
 // Persistent blocks: ~6 per CU over the whole batch, so that every block streams several tiles through its
 // software pipeline (a block that owns a single tile cannot hide its first memory latency).
@@ -279,15 +297,15 @@ int blocks_2d(int64_t Ho, int64_t Wo, int tr, int64_t N) {
   return (int)(total < cap ? total : cap);
 }
 
-template <int NT, int STRIDE, int KS, int TR>
+template <int NT, int STRIDE, int KS, int TR, int KG, int MINW>
 int launch2d(const float* x, const float* wp, float* y, Conv2Geom g, int64_t N, const float* in_scale,
              const float* in_shift, double* partials, hipStream_t s) {
-  constexpr size_t lds_bytes = lds_bytes_2d<NT, STRIDE, KS, TR>();
+  constexpr size_t lds_bytes = lds_bytes_2d<NT, STRIDE, KS, TR, KG>();
   static_assert(lds_bytes <= kMaxLds2d, "conv2d tile does not fit the LDS budget");
   if (lds_bytes > 64 * 1024) {
     static bool done = false;
     if (!done) {
-      PF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_kernel<NT, STRIDE, KS, TR>),
+      PF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_kernel<NT, STRIDE, KS, TR, KG, MINW>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds2d));
       done = true;
     }
@@ -295,9 +313,34 @@ int launch2d(const float* x, const float* wp, float* y, Conv2Geom g, int64_t N, 
   g.tiles_h = (g.Ho + 4 * TR - 1) / (4 * TR);
   g.tiles_w = (g.Wo + 15) / 16;
   dim3 grid((unsigned)blocks_2d(g.Ho, g.Wo, TR, N), (unsigned)N);
-  hipLaunchKernelGGL((conv2d_kernel<NT, STRIDE, KS, TR>), grid, dim3(256), lds_bytes, s, x, wp, y, g, in_scale,
-                     in_shift, partials);
+  hipLaunchKernelGGL((conv2d_kernel<NT, STRIDE, KS, TR, KG, MINW>), grid, dim3(256), lds_bytes, s, x, wp, y, g,
+                     in_scale, in_shift, partials);
   return pf_launch_status();
+}
+
+// NT <= 2: the variants the tuning hook can select (TR in {2,4} for 3x3, KG in {1,2}, MINW in {2,3,4})
+template <int NT, int STRIDE, int KS>
+int launch_variant(int tr, const float* x, const float* wp, float* y, const Conv2Geom& g, int64_t N,
+                   const float* in_scale, const float* in_shift, double* partials, hipStream_t s) {
+  const int ov = variant2d();
+  const int kg = ov ? (ov / 10) % 10 : ((KS == 3 && NT == 2) ? 2 : 1);
+  const int minw = ov ? ov % 10 : 2;
+#define PF_L2(TRV, KGV, MW) return launch2d<NT, STRIDE, KS, TRV, KGV, MW>(x, wp, y, g, N, in_scale, in_shift, partials, s)
+  if constexpr (KS == 3) {
+    if (tr == 4) {
+      if (kg == 2) { if (minw == 3) PF_L2(4, 2, 3); PF_L2(4, 2, 2); }
+      if (minw == 3) PF_L2(4, 1, 3);
+      PF_L2(4, 1, 2);
+    }
+    if (kg == 2) { if (minw == 4) PF_L2(2, 2, 4); if (minw == 3) PF_L2(2, 2, 3); PF_L2(2, 2, 2); }
+    if (minw == 4) PF_L2(2, 1, 4);
+    if (minw == 3) PF_L2(2, 1, 3);
+    PF_L2(2, 1, 2);
+  } else {
+    if (minw == 3) PF_L2(2, 1, 3);
+    PF_L2(2, 1, 2);
+  }
+#undef PF_L2
 }
 
 }  // namespace
@@ -308,7 +351,7 @@ int pf_conv2d_blocks(int64_t N, int64_t Cout, int64_t Hi, int64_t Wi, int kernel
   if (Cout <= 0 || Hi <= 0 || Wi <= 0 || (stride != 1 && stride != 2)) return 0;
   const int nt = (int)((Cout + 15) / 16);
   const int64_t Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;
-  return blocks_2d(Ho, Wo, tr_for(kernel_size, nt == 3 ? 4 : nt), N);
+  return blocks_2d(Ho, Wo, tr_for(kernel_size, nt == 3 ? 4 : nt, Ho, Wo, N), N);
 }
 
 int pf_conv2d_f32(const float* x, const float* wp, float* y, int64_t N, int64_t Cin, int64_t Cout, int64_t Hi,
@@ -333,14 +376,15 @@ int pf_conv2d_f32(const float* x, const float* wp, float* y, int64_t N, int64_t 
   hipStream_t s = (hipStream_t)stream;
   int nt = (int)((Cout + 15) / 16);
   if (nt == 3) nt = 4;
+  const int tr = tr_for(kernel_size, nt, g.Ho, g.Wo, N);
   if (k3s1) {
-    if (nt == 1) return launch2d<1, 1, 3, 2>(x, wp, y, g, N, in_scale, in_shift, partials, s);
-    if (nt == 2) return launch2d<2, 1, 3, 2>(x, wp, y, g, N, in_scale, in_shift, partials, s);
-    return launch2d<4, 1, 3, 2>(x, wp, y, g, N, in_scale, in_shift, partials, s);
+    if (nt == 1) return launch_variant<1, 1, 3>(tr, x, wp, y, g, N, in_scale, in_shift, partials, s);
+    if (nt == 2) return launch_variant<2, 1, 3>(tr, x, wp, y, g, N, in_scale, in_shift, partials, s);
+    return launch2d<4, 1, 3, 2, 1, 2>(x, wp, y, g, N, in_scale, in_shift, partials, s);
   }
-  if (nt == 1) return launch2d<1, 2, 5, 2>(x, wp, y, g, N, in_scale, in_shift, partials, s);
-  if (nt == 2) return launch2d<2, 2, 5, 2>(x, wp, y, g, N, in_scale, in_shift, partials, s);
-  return launch2d<4, 2, 5, 1>(x, wp, y, g, N, in_scale, in_shift, partials, s);
+  if (nt == 1) return launch_variant<1, 2, 5>(tr, x, wp, y, g, N, in_scale, in_shift, partials, s);
+  if (nt == 2) return launch_variant<2, 2, 5>(tr, x, wp, y, g, N, in_scale, in_shift, partials, s);
+  return launch2d<4, 2, 5, 1, 1, 2>(x, wp, y, g, N, in_scale, in_shift, partials, s);
 }
 
 }  // extern "C"

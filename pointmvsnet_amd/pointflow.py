@@ -204,17 +204,24 @@ def conv2d_supported(conv):
 
 
 def conv2d_preferred(conv):
-    """Measured policy (profiles/r01c): the f32-MFMA conv2d beats the library's Winograd kernel plus the
-    separate BatchNorm statistics / normalise passes only for the 3x3 layers with 17..32 output channels
-    (36 us vs 40 + 14 us); at 8/16 channels the 16x16x4 tile is half empty and instruction-bound, and the
-    64-channel layers (64x80 maps) are too small to fill the chip with 128-pixel tiles.  Everything else
-    stays on the library convolution + the HIP BatchNorm kernels until those kernels are reworked."""
-    return conv2d_supported(conv) and conv.kernel_size == (3, 3) and 16 < conv.out_channels <= 32
+    """Measured policy (profiles/r01j_microbench_conv2d.log, cfg2 shapes, 3 views): the f32-MFMA conv2d (v3)
+    is the fastest path for every tower layer with 16..32 output channels -- 8->16 5x5/2: 43 us (direct FMA
+    kernel 67, library 62), 16->16 3x3: 25 us (40, 39), 16->32 5x5/2: 31 us (library 33.5 plus its separate
+    BatchNorm statistics and normalise passes), 32->32 3x3: 23 us (library 22 plus passes).  The 64-channel
+    layers (64x80 maps: too few 128-pixel tiles for 256 CUs) stay on the library convolution + the HIP
+    BatchNorm kernels; the 8-channel full-resolution layers on the direct kernel (see below)."""
+    return conv2d_supported(conv) and 16 <= conv.out_channels <= 32
+
+
+def conv2d_small_supported(conv):
+    """Shapes pf_conv2d_small_f32 is built for: the tower's conv shapes with 8 or 16 output and <= 16 input channels."""
+    return conv2d_supported(conv) and conv.out_channels in (8, 16) and conv.in_channels <= 16
 
 
 def conv2d_small_preferred(conv):
-    """The few-channel layers (C_out 8 or 16, C_in <= 16) are HBM-bound: plain-FMA kernel (conv2d_small.hip)."""
-    return conv2d_supported(conv) and conv.out_channels in (8, 16) and conv.in_channels <= 16
+    """The 8-channel full-resolution layers (3->8, 8->8: HBM-bound, half of a 16-wide MFMA tile would be
+    empty) run on the plain-FMA kernel (conv2d_small.hip): 25 / 37 us against 31 / 43 us on the matrix cores."""
+    return conv2d_supported(conv) and conv.out_channels == 8 and conv.in_channels <= 16
 
 
 def pack_conv2d_small_weight(weight):

@@ -648,7 +648,7 @@ def test_conv2d_small_vs_fp64(dev, N, Cin, Cout, H, W, ks, stride, affine):
         xin = torch.relu(xin * sc.double().view(N, Cin, 1, 1) + sh.double().view(N, Cin, 1, 1))
     ref = F.conv2d(xin, conv.weight.double(), None, stride, ks // 2)
     conv = conv.to(dev)
-    assert pointflow.conv2d_small_preferred(conv)
+    assert pointflow.conv2d_small_supported(conv)
     aff = (sc.to(dev), sh.to(dev)) if affine else None
     y, part = pointflow.conv2d_small(x.to(dev), conv, aff, 1, True)
     assert y.shape == ref.shape
