@@ -127,11 +127,19 @@ int pf_frustum_variance_f32(const float* maps, const float* kinv, const float* r
 int pf_resize_bilinear_f32(const float* in, float* out, int64_t P, int64_t IH, int64_t IW, int64_t OH,
                            int64_t OW, void* stream);
 
+/* The three pyramid levels of one flow iteration (model.py:180-186) in one launch: in_l (V, c_l, h_l, w_l)
+ * -> out_l (V, h, w, c_l) CHANNEL-LAST, bilinear align_corners = False (a level already at (h, w) is
+ * transposed only).  c_l % 4 == 0 (else PF_ERR_UNSUPPORTED); c_l == 0 skips a level. */
+int pf_flow_pyramid_f32(const float* in1, int c1, int h1, int w1, const float* in2, int c2, int h2, int w2,
+                        const float* in3, int c3, int h3, int w3, int V, int h, int w, float* out1, float* out2,
+                        float* out3, void* stream);
+
 /* ---- row F (+U, +T ordering) : flow feature assembly ------------------------------------------
  * One launch builds what reference model.py:153-204 builds with ~100 ATen calls, for batch item 0..0
  * (one scene): for the 5 hypotheses depth + i*interval, i=-2..2: un-project the pixel centres of the
  * (h,w) flow grid, project into every view, bilinear-fetch the three (already resized to (h,w)) pyramid
- * levels maps1/2/3 (V,c_l,h,w), variance over views, append (world-mean)/std repeated 8x.
+ * levels maps1/2/3 -- CHANNEL-LAST (V,h,w,c_l), c_l % 4 == 0, as pf_flow_pyramid_f32 writes them --
+ * variance over views, append (world-mean)/std repeated 8x.
  * depth_in (dh,dw) is nearest-resized to (h,w) on the fly (model.py:153-158).  `interval` is a DEVICE pointer
  * to the hypothesis spacing (one float): scene constants live in device memory so that a captured
  * hipGraph of the whole forward can be replayed on a new scene by refreshing small buffers.

@@ -40,6 +40,7 @@ PROTOTYPES = {
     "pf_fetch_variance_f32": ([_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i, _vp], _i),
     "pf_frustum_variance_f32": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp], _i),
     "pf_resize_bilinear_f32": ([_vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp], _i),
+    "pf_flow_pyramid_f32": ([_vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp], _i),
     "pf_flow_features_f32": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp], _i),
     "pf_stat_blocks": ([_i, _i], _i),
     "pf_gemm_blocks": ([_i, _i], _i),

@@ -185,6 +185,47 @@ __global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __res
   out[p * OH * OW + i] = v;
 }
 
+// The three pyramid levels of one flow iteration in ONE launch, written CHANNEL-LAST (V, OH, OW, C): the
+// consumer (flow_features_kernel) reads every bilinear tap of a point as 16-byte loads of 4 consecutive
+// channels instead of one scattered 4-byte load per (channel, view, tap) -- 4x fewer texture-address
+// operations in the kernel that was bound by them.  A level already at (OH, OW) is copied (transposed).
+struct PyramidLevel {
+  const float* in;
+  float* out;
+  int C, IH, IW;
+};
+struct Pyramid {
+  PyramidLevel l[3];
+};
+
+__global__ __launch_bounds__(256) void pyramid_resize_kernel(Pyramid py, int V, int OH, int OW, int cq_max) {
+  const PyramidLevel L = py.l[blockIdx.z];
+  const int v = blockIdx.y / cq_max, cq = blockIdx.y - v * cq_max;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (4 * cq >= L.C || i >= OH * OW) return;
+  const int oy = i / OW, ox = i - oy * OW;
+  const int plane = L.IH * L.IW;
+  const float* src = L.in + ((int64_t)v * L.C + 4 * cq) * plane;
+  float r[4];
+  if (L.IH == OH && L.IW == OW) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) r[c] = src[(int64_t)c * plane + i];
+  } else {
+    int y0, y1, x0, x1;
+    float ly0, ly1, lx0, lx1;
+    resize_axis(oy, (float)L.IH / (float)OH, L.IH, y0, y1, ly0, ly1);
+    resize_axis(ox, (float)L.IW / (float)OW, L.IW, x0, x1, lx0, lx1);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float* pc = src + (int64_t)c * plane;
+      const float a = pc[y0 * L.IW + x0], b = pc[y0 * L.IW + x1];
+      const float cc = pc[y1 * L.IW + x0], d = pc[y1 * L.IW + x1];
+      r[c] = ly0 * (lx0 * a + lx1 * b) + ly1 * (lx0 * cc + lx1 * d);
+    }
+  }
+  *reinterpret_cast<float4*>(L.out + ((int64_t)v * OH * OW + i) * L.C + 4 * cq) = make_float4(r[0], r[1], r[2], r[3]);
+}
+
 // ------------------------------------------------------------------------------------------------
 // F: flow feature assembly (reference model.py:153-204), sub-grid-major output (model.py:236-255)
 // ------------------------------------------------------------------------------------------------
@@ -252,25 +293,44 @@ __global__ __launch_bounds__(256) void flow_features_kernel(const float* __restr
   int ch = 0;
 #pragma unroll 1
   for (int level = 0; level < 3; ++level) {
+    // maps are channel-last (V, h, w, cl): a tap is cl consecutive floats
     const float* maps = level == 0 ? maps1 : (level == 1 ? maps2 : maps3);
     const int cl = level == 0 ? c1 : (level == 1 ? c2 : c3);
-#pragma unroll 4
-    for (int c = 0; c < cl; ++c, ++ch) {
-      float s = 0.0f, s2 = 0.0f;
+    int64_t tb[V][4];
+#pragma unroll
+    for (int v = 0; v < V; ++v)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) tb[v][k] = ((int64_t)v * hw + t[v].off[k]) * cl;
+#pragma unroll 2
+    for (int c = 0; c < cl; c += 4, ch += 4) {
+      float s[4], s2[4];
 #pragma unroll
       for (int v = 0; v < V; ++v) {
-        const float f = pf_sample(maps + ((int64_t)v * cl + c) * hw, t[v]);
-        if (v == 0) {
-          s = f;
-          s2 = f * f;
-        } else {
-          s = s + f;
-          s2 = s2 + f * f;
+        const float4 a = *reinterpret_cast<const float4*>(maps + tb[v][0] + c);
+        const float4 b = *reinterpret_cast<const float4*>(maps + tb[v][1] + c);
+        const float4 cc = *reinterpret_cast<const float4*>(maps + tb[v][2] + c);
+        const float4 d = *reinterpret_cast<const float4*>(maps + tb[v][3] + c);
+        const float w0 = t[v].wgt[0], w1 = t[v].wgt[1], w2 = t[v].wgt[2], w3 = t[v].wgt[3];
+        // the arithmetic of pf_sample, per channel
+        const float f[4] = {((a.x * w0 + b.x * w1) + cc.x * w2) + d.x * w3, ((a.y * w0 + b.y * w1) + cc.y * w2) + d.y * w3,
+                            ((a.z * w0 + b.z * w1) + cc.z * w2) + d.z * w3, ((a.w * w0 + b.w * w1) + cc.w * w2) + d.w * w3};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (v == 0) {
+            s[i] = f[i];
+            s2[i] = f[i] * f[i];
+          } else {
+            s[i] = s[i] + f[i];
+            s2[i] = s2[i] + f[i] * f[i];
+          }
         }
       }
-      const float m1 = s / (float)V;
-      const float m2 = s2 / (float)V;
-      fo[(int64_t)ch * Ng] = m2 - m1 * m1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float m1 = s[i] / (float)V;
+        const float m2 = s2[i] / (float)V;
+        fo[(int64_t)(ch + i) * Ng] = m2 - m1 * m1;
+      }
     }
   }
   // xyz.repeat(1, 8, 1): channel j of the 24 holds axis j % 3 (model.py:193-194)
@@ -438,10 +498,33 @@ int pf_resize_bilinear_f32(const float* in, float* out, int64_t P, int64_t IH, i
   return pf_launch_status();
 }
 
+int pf_flow_pyramid_f32(const float* in1, int c1, int h1, int w1, const float* in2, int c2, int h2, int w2,
+                        const float* in3, int c3, int h3, int w3, int V, int h, int w, float* out1, float* out2,
+                        float* out3, void* stream) {
+  PF_REQUIRE(V >= 1 && h >= 1 && w >= 1 && c1 >= 0 && c2 >= 0 && c3 >= 0);
+  PF_REQUIRE(h1 >= 1 && w1 >= 1 && h2 >= 1 && w2 >= 1 && h3 >= 1 && w3 >= 1);
+  if ((c1 % 4) != 0 || (c2 % 4) != 0 || (c3 % 4) != 0) return PF_ERR_UNSUPPORTED;
+  PF_REQUIRE((int64_t)h * w <= INT32_MAX && (int64_t)h1 * w1 <= INT32_MAX && (int64_t)h2 * w2 <= INT32_MAX &&
+             (int64_t)h3 * w3 <= INT32_MAX);
+  int cmax = c1 > c2 ? c1 : c2;
+  cmax = cmax > c3 ? cmax : c3;
+  if (cmax == 0) return PF_OK;
+  PF_REQUIRE((c1 == 0 || (in1 && out1)) && (c2 == 0 || (in2 && out2)) && (c3 == 0 || (in3 && out3)));
+  PF_REQUIRE((int64_t)V * (cmax / 4) <= 65535);
+  Pyramid py;
+  py.l[0] = PyramidLevel{in1, out1, c1, h1, w1};
+  py.l[1] = PyramidLevel{in2, out2, c2, h2, w2};
+  py.l[2] = PyramidLevel{in3, out3, c3, h3, w3};
+  dim3 grid((unsigned)pf_cdiv((int64_t)h * w, 256), (unsigned)(V * (cmax / 4)), 3);
+  hipLaunchKernelGGL(pyramid_resize_kernel, grid, dim3(256), 0, (hipStream_t)stream, py, V, h, w, cmax / 4);
+  return pf_launch_status();
+}
+
 int pf_flow_features_f32(const float* maps1, const float* maps2, const float* maps3, int c1, int c2, int c3,
                          int V, int h, int w, const float* depth_in, int dh, int dw, const float* interval,
                          const float* cam, int ratio, float* feature, float* xyz, void* stream) {
   PF_REQUIRE(c1 >= 0 && c2 >= 0 && c3 >= 0 && V >= 1 && h >= 1 && w >= 1 && dh >= 1 && dw >= 1 && ratio >= 1);
+  if ((c1 % 4) != 0 || (c2 % 4) != 0 || (c3 % 4) != 0) return PF_ERR_UNSUPPORTED;
   PF_REQUIRE(h % ratio == 0 && w % ratio == 0);
   PF_REQUIRE(ratio * ratio <= 65535);
   if (V > PF_MAX_VIEWS) return PF_ERR_UNSUPPORTED;

@@ -507,11 +507,25 @@ def resize_maps(maps, h, w):
     return out
 
 
+def flow_pyramid(pyramid, h, w):
+    """The three pyramid levels (V,c_l,h_l,w_l) of a scene resized to the flow grid (model.py:180-186) in one
+    launch, CHANNEL-LAST (V,h,w,c_l) -- the layout flow_features samples with 16-byte loads."""
+    V = pyramid[0].shape[0]
+    outs = [torch.empty((V, h, w, int(m.shape[1])), dtype=_F32, device=m.device) for m in pyramid]
+    args = []
+    for m in pyramid:
+        args += [_lib.ptr(m), int(m.shape[1]), int(m.shape[2]), int(m.shape[3])]
+    _lib.call("pf_flow_pyramid_f32", *args, V, h, w, _lib.ptr(outs[0]), _lib.ptr(outs[1]), _lib.ptr(outs[2]),
+              _lib.stream(), algo_bytes=sum(4.0 * m.numel() + 4.0 * o.numel() for m, o in zip(pyramid, outs)))
+    return outs
+
+
 def flow_features(levels, depth, interval, cam, h, w, ratio):
-    """Row F.  levels: three (V,c,h,w) maps; depth (dh,dw); interval: 1-element device tensor; cam: packed
-    camera block (device float32).  Returns feature (G, 136, Ng) and xyz (G, 3, Ng), sub-grid-major."""
+    """Row F.  levels: three channel-last (V,h,w,c) maps (flow_pyramid); depth (dh,dw); interval: 1-element
+    device tensor; cam: packed camera block (device float32).  Returns feature (G, 136, Ng) and xyz (G, 3, Ng),
+    sub-grid-major."""
     V = levels[0].shape[0]
-    c1, c2, c3 = (int(l.shape[1]) for l in levels)
+    c1, c2, c3 = (int(l.shape[3]) for l in levels)
     G = ratio * ratio
     Ng = 5 * (h // ratio) * (w // ratio)
     dev = depth.device
@@ -586,7 +600,7 @@ def flow_iteration(pyramid, depth, interval, cam, h, w, ratio, edge_convs, flow_
     pyramid: three contiguous (V,c,H_l,W_l) feature maps of this scene; depth: (dh,dw) prior depth map;
     interval: 1-element device tensor (hypothesis spacing); cam: packed camera block for this scale.
     Returns (depth_out (h,w), flow_prob (5,h,w))."""
-    levels = [resize_maps(m, h, w) for m in pyramid]
+    levels = flow_pyramid(pyramid, h, w)
     feature, xyz = flow_features(levels, depth, interval, cam, h, w, ratio)
     return flow_chain(feature, xyz, depth, interval, h, w, ratio, edge_convs, flow_mlp, k=k)
 

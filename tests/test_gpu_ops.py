@@ -290,6 +290,30 @@ def test_resize_bilinear_vs_interpolate(dev):
         assert err < 2e-6 * float(x.abs().max())
 
 
+def test_flow_pyramid_vs_interpolate(dev):
+    """One launch, three levels (down-sample, copy, up-sample), channel-last output == F.interpolate + permute."""
+    g = torch.Generator().manual_seed(5)
+    for V, (h, w), shapes in [(3, (16, 20), [(16, 32, 40), (32, 16, 20), (64, 8, 10)]),
+                              (2, (12, 18), [(8, 24, 36), (4, 7, 9), (12, 12, 18)]),
+                              (1, (5, 7), [(4, 5, 7), (0, 3, 3), (8, 2, 3)])]:
+        maps = [torch.randn(V, c, ih, iw, generator=g) for c, ih, iw in shapes]
+        outs = pointflow.flow_pyramid([m.to(dev) for m in maps], h, w)
+        for m, o in zip(maps, outs):
+            assert o.shape == (V, h, w, m.shape[1])
+            if m.shape[1] == 0:
+                continue
+            ref = F.interpolate(m, (h, w), mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+            err = _maxabs(o, ref)
+            report("pyramid_%dx%d_%dx%d" % (m.shape[2], m.shape[3], h, w), err=err)
+            assert err < 2e-6 * float(m.abs().max())
+            # same arithmetic as the planar resize kernel: bit-identical
+            assert torch.equal(o.permute(0, 3, 1, 2), pointflow.resize_maps(m.to(dev), h, w))
+    lib = _lib.load()
+    z = torch.zeros(64, device=dev)
+    assert lib.pf_flow_pyramid_f32(_lib.ptr(z), 6, 2, 2, _lib.ptr(z), 4, 2, 2, _lib.ptr(z), 4, 2, 2, 1, 2, 2,
+                                   _lib.ptr(z), _lib.ptr(z), _lib.ptr(z), _lib.stream()) == -2   # c % 4 != 0
+
+
 # ---------------------------------------------------------------------------------------------
 # row S
 # ---------------------------------------------------------------------------------------------

@@ -59,7 +59,7 @@ def test_flow_iteration_stagewise_vs_oracle(dev, cfg, it):
     # ---- stage F: feature assembly on the oracle's pyramids and prior depth -----------------------
     cam = _Cameras(cams, True)
     packed = cam.packed(cam.flow_intrinsics(s), data["mean"], data["std"], interval).to(dev)
-    levels = [pointflow.resize_maps(pyr[n][0].to(dev).contiguous(), h, w) for n in ("conv1", "conv2", "conv3")]
+    levels = pointflow.flow_pyramid([pyr[n][0].to(dev).contiguous() for n in ("conv1", "conv2", "conv3")], h, w)
     f_gpu, x_gpu = pointflow.flow_features(levels, prior[0, 0].to(dev).contiguous(), packed[0, -1:],
                                            packed[0], h, w, ratio)
     hs, ws = h // ratio, w // ratio
