@@ -146,7 +146,7 @@ int pf_flow_pyramid_f32(const float* in1, int c1, int h1, int w1, const float* i
  * Points are written in SUB-GRID-MAJOR order for the test-mode tiling of model.py:231-267
  * (ratio r, G = r*r groups, Ng = 5*(h/r)*(w/r) points each; group g=(y%r)*r+(x%r), local index
  * d*(h/r)*(w/r) + (y/r)*(w/r) + (x/r)); r = 1 gives the plain (5,h,w) lattice.
- *   feature (G, c1+c2+c3+24, Ng)    xyz (G, 3, Ng) */
+ *   feature (G*Ng, c1+c2+c3+24) POINT-major (the first EdgeConv GEMM's A operand)    xyz (G, 3, Ng) */
 int pf_flow_features_f32(const float* maps1, const float* maps2, const float* maps3, int c1, int c2, int c3,
                          int V, int h, int w, const float* depth_in, int dh, int dw, const float* interval,
                          const float* cam, int ratio, float* feature, float* xyz, void* stream);

@@ -229,6 +229,17 @@ __global__ __launch_bounds__(256) void pyramid_resize_kernel(Pyramid py, int V, 
 // ------------------------------------------------------------------------------------------------
 // F: flow feature assembly (reference model.py:153-204), sub-grid-major output (model.py:236-255)
 // ------------------------------------------------------------------------------------------------
+// Eight lanes share one point: lane q samples channels [32 p + 4 q, +4) of a level (p = pass), so one tap of
+// one point is read as 8 x 16 B = one full 128-byte line of the channel-last map.  (One lane per point with
+// a loop over channel quads -- the previous layout -- touches ~400 lines per wave and iteration and
+// comes back to each of them 8 times, long after a 32 KB L1 has dropped it.)  The per-point projection
+// setup is replicated on the 8 lanes (a few hundred VALU instructions against ~50 line fetches).
+// Output rows are POINT-major: feature (G*Ng, ctot), a point's ctot floats contiguous (the first
+// EdgeConv GEMM reads them as its A operand); xyz stays planar (G, 3, Ng) for the lattice kNN.
+constexpr int kFeatLanes = 8;
+constexpr int kFeatPY = 4, kFeatPX = 8;           // 32 points per 256-thread block
+static_assert(kFeatPY * kFeatPX * kFeatLanes == 256, "one point per 8 lanes");
+
 template <int V>
 __global__ __launch_bounds__(256) void flow_features_kernel(const float* __restrict__ maps1,
                                                             const float* __restrict__ maps2,
@@ -241,15 +252,21 @@ __global__ __launch_bounds__(256) void flow_features_kernel(const float* __restr
                                                             float* __restrict__ xyz) {
   const int hs = h / ratio, ws = w / ratio;
   const int64_t Ng = (int64_t)5 * hs * ws;
-  const int64_t loc = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int g = blockIdx.y;
-  if (loc >= Ng) return;
-  // local index -> (hypothesis d, sub-grid row/col) -> image pixel (y, x)
-  const int d = (int)(loc / ((int64_t)hs * ws));
-  const int rem = (int)(loc - (int64_t)d * hs * ws);
-  const int ysub = rem / ws, xsub = rem - ysub * ws;
-  const int y = ysub * ratio + g / ratio;
-  const int x = xsub * ratio + g % ratio;
+  const int q = threadIdx.x & (kFeatLanes - 1);
+  // A block owns a kFeatPY x kFeatPX patch of flow-grid pixels of one hypothesis plane, ACROSS the sub-grids:
+  // neighbouring pixels project to neighbouring source texels, so the patch's taps share cache lines in
+  // this CU's L1 (a run of 32 points of one sub-grid -- every ratio-th pixel of a row -- shares none).
+  const int tiles_x = (w + kFeatPX - 1) / kFeatPX, tiles_y = (h + kFeatPY - 1) / kFeatPY;
+  const int bx = blockIdx.x % tiles_x;
+  const int by = (blockIdx.x / tiles_x) % tiles_y;
+  const int d = blockIdx.x / (tiles_x * tiles_y);
+  const int pl = threadIdx.x / kFeatLanes;
+  const int y_raw = by * kFeatPY + pl / kFeatPX, x_raw = bx * kFeatPX + pl % kFeatPX;
+  const bool live = y_raw < h && x_raw < w;
+  const int y = live ? y_raw : h - 1, x = live ? x_raw : w - 1;     // dead lanes shadow a valid pixel, store nothing
+  // image pixel (y, x) -> sub-grid g, local index (hypothesis d, sub-grid row/col)
+  const int g = (y % ratio) * ratio + (x % ratio);
+  const int64_t loc = ((int64_t)d * hs + y / ratio) * ws + x / ratio;
 
   // nearest resize of the prior depth map (model.py:153-158)
   const float scy = (float)dh / (float)h, scx = (float)dw / (float)w;
@@ -275,10 +292,12 @@ __global__ __launch_bounds__(256) void flow_features_kernel(const float* __restr
   const float nx = (X - cam[PF_CAM_MEAN + 0]) / cam[PF_CAM_STD + 0];
   const float ny = (Y - cam[PF_CAM_MEAN + 1]) / cam[PF_CAM_STD + 1];
   const float nz = (Z - cam[PF_CAM_MEAN + 2]) / cam[PF_CAM_STD + 2];
-  float* xo = xyz + (int64_t)g * 3 * Ng + loc;
-  xo[0] = nx;
-  xo[Ng] = ny;
-  xo[2 * Ng] = nz;
+  if (live && q == 0) {
+    float* xo = xyz + (int64_t)g * 3 * Ng + loc;
+    xo[0] = nx;
+    xo[Ng] = ny;
+    xo[2 * Ng] = nz;
+  }
 
   PfTaps t[V];
 #pragma unroll
@@ -288,7 +307,7 @@ __global__ __launch_bounds__(256) void flow_features_kernel(const float* __restr
   }
 
   const int ctot = c1 + c2 + c3 + 24;
-  float* fo = feature + (int64_t)g * ctot * Ng + loc;
+  float* frow = feature + ((int64_t)g * Ng + loc) * ctot;
   const int64_t hw = (int64_t)h * w;
   int ch = 0;
 #pragma unroll 1
@@ -301,43 +320,55 @@ __global__ __launch_bounds__(256) void flow_features_kernel(const float* __restr
     for (int v = 0; v < V; ++v)
 #pragma unroll
       for (int k = 0; k < 4; ++k) tb[v][k] = ((int64_t)v * hw + t[v].off[k]) * cl;
-#pragma unroll 2
-    for (int c = 0; c < cl; c += 4, ch += 4) {
-      float s[4], s2[4];
+#pragma unroll 1
+    for (int c0 = 0; c0 < cl; c0 += 4 * kFeatLanes) {
+      const int c = c0 + 4 * q;
+      if (c < cl) {
+        float s[4], s2[4];
 #pragma unroll
-      for (int v = 0; v < V; ++v) {
-        const float4 a = *reinterpret_cast<const float4*>(maps + tb[v][0] + c);
-        const float4 b = *reinterpret_cast<const float4*>(maps + tb[v][1] + c);
-        const float4 cc = *reinterpret_cast<const float4*>(maps + tb[v][2] + c);
-        const float4 d = *reinterpret_cast<const float4*>(maps + tb[v][3] + c);
-        const float w0 = t[v].wgt[0], w1 = t[v].wgt[1], w2 = t[v].wgt[2], w3 = t[v].wgt[3];
-        // the arithmetic of pf_sample, per channel
-        const float f[4] = {((a.x * w0 + b.x * w1) + cc.x * w2) + d.x * w3, ((a.y * w0 + b.y * w1) + cc.y * w2) + d.y * w3,
-                            ((a.z * w0 + b.z * w1) + cc.z * w2) + d.z * w3, ((a.w * w0 + b.w * w1) + cc.w * w2) + d.w * w3};
+        for (int v = 0; v < V; ++v) {
+          const float4 a = *reinterpret_cast<const float4*>(maps + tb[v][0] + c);
+          const float4 b = *reinterpret_cast<const float4*>(maps + tb[v][1] + c);
+          const float4 cc = *reinterpret_cast<const float4*>(maps + tb[v][2] + c);
+          const float4 dd = *reinterpret_cast<const float4*>(maps + tb[v][3] + c);
+          const float w0 = t[v].wgt[0], w1 = t[v].wgt[1], w2 = t[v].wgt[2], w3 = t[v].wgt[3];
+          // the arithmetic of pf_sample, per channel
+          const float f[4] = {((a.x * w0 + b.x * w1) + cc.x * w2) + dd.x * w3,
+                              ((a.y * w0 + b.y * w1) + cc.y * w2) + dd.y * w3,
+                              ((a.z * w0 + b.z * w1) + cc.z * w2) + dd.z * w3,
+                              ((a.w * w0 + b.w * w1) + cc.w * w2) + dd.w * w3};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (v == 0) {
-            s[i] = f[i];
-            s2[i] = f[i] * f[i];
-          } else {
-            s[i] = s[i] + f[i];
-            s2[i] = s2[i] + f[i] * f[i];
+          for (int i = 0; i < 4; ++i) {
+            if (v == 0) {
+              s[i] = f[i];
+              s2[i] = f[i] * f[i];
+            } else {
+              s[i] = s[i] + f[i];
+              s2[i] = s2[i] + f[i] * f[i];
+            }
           }
         }
-      }
+        float o[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float m1 = s[i] / (float)V;
-        const float m2 = s2[i] / (float)V;
-        fo[(int64_t)(ch + i) * Ng] = m2 - m1 * m1;
+        for (int i = 0; i < 4; ++i) {
+          const float m1 = s[i] / (float)V;
+          const float m2 = s2[i] / (float)V;
+          o[i] = m2 - m1 * m1;
+        }
+        if (live) *reinterpret_cast<float4*>(frow + ch + c) = make_float4(o[0], o[1], o[2], o[3]);
       }
     }
+    ch += cl;
   }
-  // xyz.repeat(1, 8, 1): channel j of the 24 holds axis j % 3 (model.py:193-194)
+  // xyz.repeat(1, 8, 1): channel j of the 24 holds axis j % 3 (model.py:193-194); lanes 0..5 write 4 each
+  if (live && q < 6) {
+    float o[4];
 #pragma unroll
-  for (int j = 0; j < 24; ++j) {
-    const float val = (j % 3 == 0) ? nx : ((j % 3 == 1) ? ny : nz);
-    fo[(int64_t)(ch + j) * Ng] = val;
+    for (int i = 0; i < 4; ++i) {
+      const int j = 4 * q + i;
+      o[i] = (j % 3 == 0) ? nx : ((j % 3 == 1) ? ny : nz);
+    }
+    *reinterpret_cast<float4*>(frow + ch + 4 * q) = make_float4(o[0], o[1], o[2], o[3]);
   }
 }
 
@@ -530,7 +561,9 @@ int pf_flow_features_f32(const float* maps1, const float* maps2, const float* ma
   if (V > PF_MAX_VIEWS) return PF_ERR_UNSUPPORTED;
   PF_REQUIRE(maps1 && maps2 && maps3 && depth_in && interval && cam && feature && xyz);
   const int64_t Ng = (int64_t)5 * (h / ratio) * (w / ratio);
-  dim3 grid((unsigned)pf_cdiv(Ng, 256), (unsigned)(ratio * ratio));
+  (void)Ng;
+  PF_REQUIRE(pf_cdiv(h, kFeatPY) * pf_cdiv(w, kFeatPX) * 5 <= INT32_MAX);
+  dim3 grid((unsigned)(5 * pf_cdiv(h, kFeatPY) * pf_cdiv(w, kFeatPX)));
   return dispatch_views(V, [&](auto vtag) {
     constexpr int VV = decltype(vtag)::value;
     hipLaunchKernelGGL(flow_features_kernel<VV>, grid, dim3(256), 0, (hipStream_t)stream, maps1, maps2, maps3,

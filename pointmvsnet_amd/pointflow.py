@@ -522,14 +522,14 @@ def flow_pyramid(pyramid, h, w):
 
 def flow_features(levels, depth, interval, cam, h, w, ratio):
     """Row F.  levels: three channel-last (V,h,w,c) maps (flow_pyramid); depth (dh,dw); interval: 1-element
-    device tensor; cam: packed camera block (device float32).  Returns feature (G, 136, Ng) and xyz (G, 3, Ng),
-    sub-grid-major."""
+    device tensor; cam: packed camera block (device float32).  Returns feature (G, Ng, 136) -- point-major
+    rows -- and xyz (G, 3, Ng), points in sub-grid-major order."""
     V = levels[0].shape[0]
     c1, c2, c3 = (int(l.shape[3]) for l in levels)
     G = ratio * ratio
     Ng = 5 * (h // ratio) * (w // ratio)
     dev = depth.device
-    feature = torch.empty((G, c1 + c2 + c3 + 24, Ng), dtype=_F32, device=dev)
+    feature = torch.empty((G, Ng, c1 + c2 + c3 + 24), dtype=_F32, device=dev)
     xyz = torch.empty((G, 3, Ng), dtype=_F32, device=dev)
     _lib.call("pf_flow_features_f32",
               _lib.ptr(levels[0]), _lib.ptr(levels[1]), _lib.ptr(levels[2]), c1, c2, c3, V, h, w, _lib.ptr(depth),
@@ -539,11 +539,15 @@ def flow_features(levels, depth, interval, cam, h, w, ratio):
     return feature, xyz
 
 
-def flow_chain(feature, xyz, depth, interval, h, w, ratio, edge_convs, flow_mlp, k=16):
-    """Rows K, E0-E2, M, H, T on assembled point features: feature (G,136,Ng) / xyz (G,3,Ng) in
-    sub-grid-major order (see flow_features) -> (depth_out (h,w), flow_prob (5,h,w))."""
+def flow_chain(feature, xyz, depth, interval, h, w, ratio, edge_convs, flow_mlp, k=16, point_major=True):
+    """Rows K, E0-E2, M, H, T on assembled point features: feature (G,Ng,136) point-major rows (or
+    (G,136,Ng) with ``point_major=False``) / xyz (G,3,Ng), points in sub-grid-major order (see
+    flow_features) -> (depth_out (h,w), flow_prob (5,h,w))."""
     dev = depth.device
-    G, Cin, Ng = feature.shape
+    if point_major:
+        G, Ng, Cin = feature.shape
+    else:
+        G, Cin, Ng = feature.shape
     hs, ws = h // ratio, w // ratio
     # the lattice kNN needs only xyz; the first EdgeConv GEMM needs only the features: run them concurrently
     aux = None
@@ -564,7 +568,7 @@ def flow_chain(feature, xyz, depth, interval, h, w, ratio, edge_convs, flow_mlp,
     ctot = sum(widths)
     edges = torch.empty((G * Ng, ctot), dtype=_F32, device=dev)            # the (N,224) concat buffer
     col = 0
-    X, pm, ldx, K = feature, False, 0, Cin
+    X, pm, ldx, K = feature, bool(point_major), (Cin if point_major else 0), Cin
     for li, (m, wdt) in enumerate(zip(edge_convs, widths)):
         Y = edges[:, col:]
         edge_conv_fused(X, pm, ldx, K, G, Ng, idx, m.conv1.weight, m.conv2.weight, m.bn, m.concat, Y, ctot,

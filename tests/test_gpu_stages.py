@@ -68,6 +68,7 @@ def test_flow_iteration_stagewise_vs_oracle(dev, cfg, it):
     x_ref = xyz.view(3, 5, hs, ratio, ws, ratio).permute(3, 5, 0, 1, 2, 4).reshape(ratio * ratio, 3, -1)
     e_x = float((x_gpu.cpu() - x_ref).abs().max())
     var_scale = float(f_ref[:, :112].abs().max())
+    f_gpu = f_gpu.transpose(1, 2)                      # point-major rows (G,Ng,136) -> (G,136,Ng) for comparison
     e_f = float((f_gpu.cpu()[:, :112] - f_ref[:, :112]).abs().max())
     report("stage_F_%s_it%d" % (cfg, it), xyz_err=e_x, feat_err=e_f, feat_scale=var_scale)
     assert e_x < 2e-6                                  # normalised coordinates are O(1)
@@ -93,7 +94,10 @@ def test_flow_iteration_stagewise_vs_oracle(dev, cfg, it):
     net = net.to(dev).train()
     with torch.no_grad():
         d_gpu, p_gpu = pointflow.flow_chain(f_in, x_in, prior[0, 0].to(dev).contiguous(), packed[0, -1:], h, w,
-                                            ratio, net.flow_edge_conv, net.flow_mlp, k=16)
+                                            ratio, net.flow_edge_conv, net.flow_mlp, k=16, point_major=False)
+        # the point-major layout flow_features produces must give the very same result (same GEMM arithmetic)
+        d_pm, p_pm = pointflow.flow_chain(f_in.transpose(1, 2).contiguous(), x_in, prior[0, 0].to(dev).contiguous(),
+                                          packed[0, -1:], h, w, ratio, net.flow_edge_conv, net.flow_mlp, k=16)
         # the oracle on the same tensors (sub-grids sequential, model.py:231-267)
         flow = torch.zeros(1, 1, hs, ratio, ws, ratio)
         prob = torch.zeros(1, 5, hs, ratio, ws, ratio)
@@ -106,6 +110,7 @@ def test_flow_iteration_stagewise_vs_oracle(dev, cfg, it):
                 prob[:, :, :, i, :, j] = pij
         d_ref = cur + flow.view(1, 1, h, w)
         p_ref = prob.view(1, 5, h, w)
+    assert torch.allclose(d_pm, d_gpu, rtol=1e-6, atol=0.0) and torch.allclose(p_pm, p_gpu, rtol=0.0, atol=1e-6)
     rel = float(((d_gpu.cpu() - d_ref[0, 0]).abs() / d_ref[0, 0].abs()).max())
     e_p = float((p_gpu.cpu() - p_ref[0]).abs().max())
     report("stage_chain_%s_it%d" % (cfg, it), depth_rel=rel, prob_abs=e_p)
