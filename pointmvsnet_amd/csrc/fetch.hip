@@ -12,6 +12,8 @@
 // The reference moves V*C*N*4 for the fetched features alone and then makes four more passes over it.
 #include <type_traits>
 
+#include <stdlib.h>
+
 #include "pf_common.h"
 
 namespace {
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(256) void flow_features_kernel(const float* __restr
                                                             const float* __restrict__ interval_p,
                                                             const float* __restrict__ cam,
                                                             int ratio, float* __restrict__ feature,
-                                                            float* __restrict__ xyz) {
+                                                            float* __restrict__ xyz, int xcd_order) {
   const int hs = h / ratio, ws = w / ratio;
   const int64_t Ng = (int64_t)5 * hs * ws;
   const int q = threadIdx.x & (kFeatLanes - 1);
@@ -257,9 +259,22 @@ __global__ __launch_bounds__(256) void flow_features_kernel(const float* __restr
   // neighbouring pixels project to neighbouring source texels, so the patch's taps share cache lines in
   // this CU's L1 (a run of 32 points of one sub-grid -- every ratio-th pixel of a row -- shares none).
   const int tiles_x = (w + kFeatPX - 1) / kFeatPX, tiles_y = (h + kFeatPY - 1) / kFeatPY;
-  const int bx = blockIdx.x % tiles_x;
-  const int by = (blockIdx.x / tiles_x) % tiles_y;
-  const int d = blockIdx.x / (tiles_x * tiles_y);
+  // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): renumber so that consecutive logical
+  // blocks share an XCD, and make the 5 hypotheses of a patch consecutive -- they sample almost the same
+  // texels (neighbouring positions on the epipolar lines), which then come from that XCD's L2.
+  int d, patch;
+  if (xcd_order) {
+    const int nb = gridDim.x, per = nb / 8, extra = nb % 8;
+    const int xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
+    const int logical = (xcd < extra ? xcd * (per + 1) : extra * (per + 1) + (xcd - extra) * per) + slot;
+    d = logical % 5;
+    patch = logical / 5;
+  } else {
+    patch = blockIdx.x % (tiles_x * tiles_y);
+    d = blockIdx.x / (tiles_x * tiles_y);
+  }
+  const int bx = patch % tiles_x;
+  const int by = patch / tiles_x;
   const int pl = threadIdx.x / kFeatLanes;
   const int y_raw = by * kFeatPY + pl / kFeatPX, x_raw = bx * kFeatPX + pl % kFeatPX;
   const bool live = y_raw < h && x_raw < w;
@@ -564,10 +579,12 @@ int pf_flow_features_f32(const float* maps1, const float* maps2, const float* ma
   (void)Ng;
   PF_REQUIRE(pf_cdiv(h, kFeatPY) * pf_cdiv(w, kFeatPX) * 5 <= INT32_MAX);
   dim3 grid((unsigned)(5 * pf_cdiv(h, kFeatPY) * pf_cdiv(w, kFeatPX)));
+  const char* ord = getenv("PF_FEAT_ORDER");                 // tuning hook: 0 = plane-major blocks, 1 = XCD-aware
+  const int xcd_order = ord ? atoi(ord) : 1;
   return dispatch_views(V, [&](auto vtag) {
     constexpr int VV = decltype(vtag)::value;
     hipLaunchKernelGGL(flow_features_kernel<VV>, grid, dim3(256), 0, (hipStream_t)stream, maps1, maps2, maps3,
-                       c1, c2, c3, h, w, depth_in, dh, dw, interval, cam, ratio, feature, xyz);
+                       c1, c2, c3, h, w, depth_in, dh, dw, interval, cam, ratio, feature, xyz, xcd_order);
     return pf_launch_status();
   });
 }
