@@ -119,9 +119,10 @@ def _block_fused(block, x, samples_per_stat):
     if (type(conv) is nn.Conv3d and conv.kernel_size == (3, 3, 3) and conv.padding == (1, 1, 1)
             and conv.stride in ((1, 1, 1), (2, 2, 2)) and conv.dilation == (1, 1, 1) and conv.groups == 1
             and conv.bias is None and conv.in_channels % 4 == 0
-            and conv.out_channels <= (32 if conv.stride[0] == 1 else 16)
-            and x[0, 0].numel() // (conv.stride[0] ** 3) >= 16384):
-        # (small volumes do not fill the chip with one wave per 16 voxels: the library GEMM path is faster)
+            and conv.out_channels <= 32
+            and x[0, 0].numel() // (conv.stride[0] ** 3) >= 2048):
+        # (measured, profiles/r01l_microbench_conv3d.log: 16->32 /2 on 24x32x40: 14.5 us vs 23.4 us for the
+        # library's im2col + GEMM, 32->32 on 12x16x20: 19.6 vs 36.5 us; the 6x8x10 layers stay on the library)
         # row R on the f32 matrix cores; the BN batch statistics come out of the conv epilogue
         y, partials = pointflow.conv3d_k3(x.contiguous(), conv.weight, conv.stride[0], training_bn)
         if block.bn is not None:
