@@ -244,7 +244,7 @@ class PointMVSNet(nn.Module):
 
     # The four device-only stages of ``run`` (GraphedForward may capture them as separate graphs).
     def run_coarse_tower(self, img_list):
-        return self.coarse_img_conv.forward_views(img_list)["conv3"].contiguous()           # (B,V,C,FH,FW)
+        return self.coarse_img_conv.forward_views(img_list, need=("conv3",))["conv3"].contiguous()   # (B,V,C,FH,FW)
 
     def run_flow_tower(self, img_list):
         return self.flow_img_conv.forward_views(img_list)

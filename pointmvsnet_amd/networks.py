@@ -162,12 +162,13 @@ class ImageConv(nn.Module):
             out[name] = x
         return out
 
-    def forward_views(self, img_list):
+    def forward_views(self, img_list, need=("conv1", "conv2", "conv3")):
         """Inference fast path: all V views of (B,V,3,H,W) in ONE pass through the tower with per-view
         BatchNorm statistics -- numerically the reference's V separate calls (model.py:71-77).  Each layer is
         one pf_conv2d_f32 launch (previous BatchNorm+ReLU applied while staging, this layer's statistics in
-        the epilogue) plus the finalize; only the stage outputs the model consumes ("conv1".."conv3",
-        (B,V,c,h,w)) are materialised -- "conv0" is not returned."""
+        the epilogue) plus the finalize; only the stage outputs in ``need`` ((B,V,c,h,w); the coarse tower
+        needs "conv3" alone) are materialised, every other BatchNorm+ReLU stays an affine row pair that the
+        next convolution applies while staging -- "conv0" is never returned."""
         B, V = img_list.shape[:2]
         x = img_list.transpose(0, 1).reshape(V * B, *img_list.shape[2:]).float().contiguous()   # view-major
         pending = None                      # (scale, shift) of a BatchNorm+ReLU not yet applied to x
@@ -178,10 +179,11 @@ class ImageConv(nn.Module):
             nxt = blocks[i + 1][1] if i + 1 < len(blocks) else None
             # the BN+ReLU of this block can stay pending only if the next conv applies it while staging
             nconv = None if nxt is None else (nxt.conv if hasattr(nxt, "bn") else nxt)
-            defer = (not (stage_end and name != "conv0")) and nconv is not None and \
+            wanted = stage_end and name in need
+            defer = (not wanted) and nconv is not None and \
                 (pointflow.conv2d_preferred(nconv) or pointflow.conv2d_small_preferred(nconv))
             x, pending = _conv2d_block_fused(block, x, pending, B, defer)
-            if stage_end and name != "conv0":
+            if wanted:
                 out[name] = x.view(V, B, *x.shape[1:]).transpose(0, 1)
         return out
 
