@@ -279,7 +279,10 @@ extern "C" int pf_knn_lattice_f32(const float* xyz, const int64_t* strides_host,
   const size_t lds_bytes = (size_t)3 * kernel_size * (TH + 2 * hk) * (TW + 2 * hk) * sizeof(float);
   dim3 grid((unsigned)pf_cdiv(W, TW), (unsigned)pf_cdiv(H, TH), (unsigned)(B * D));
   hipStream_t s = (hipStream_t)stream;
-  if (knn <= 16 && k3 >= 64) {
+  // Measured (profiles/r01n_microbench_knn.log, window 5, k 16): the split scan wins while the lattice is too
+  // small to fill the chip with one lane per point (25 600 points: 27 vs 35 us); on 102 400 points the plain
+  // scan does the same work in a quarter of the waves without the merge (49 vs 82 us).
+  if (knn <= 16 && k3 >= 64 && B * D * H * W < 65536) {
     // split scan (see knn_lattice_split_kernel); every quarter holds >= 16 candidates, so the merged heads
     // never run dry before knn picks
     const size_t lds2 = (size_t)3 * kernel_size * (SH + 2 * hk) * (SW + 2 * hk) * sizeof(float) +
