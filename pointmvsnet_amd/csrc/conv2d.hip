@@ -294,7 +294,11 @@ int blocks_2d(int64_t Ho, int64_t Wo, int tr, int64_t N) {
   const int64_t total = ((Ho + 4 * tr - 1) / (4 * tr)) * ((Wo + 15) / 16);
   int64_t cap = 1536 / (N < 1 ? 1 : N);
   cap = cap < 64 ? 64 : cap;
-  return (int)(total < cap ? total : cap);
+  if (total <= cap) return (int)total;
+  // every block the same number of tiles: 640 tiles on 512 blocks would leave 3/4 of the chip idle in the
+  // second round (8->16 5x5/2 layer: 43.6 -> 36.1 us with 320 blocks, profiles/r01n_microbench_conv2d_cap.log)
+  const int64_t per = (total + cap - 1) / cap;
+  return (int)((total + per - 1) / per);
 }
 
 template <int NT, int STRIDE, int KS, int TR, int KG, int MINW>
