@@ -51,3 +51,37 @@ def test_header_cites_reference_interfaces():
     text = open(os.path.join(ROOT, "include", "pointflow_hip.h")).read()
     for cite in ("gather_knn_kernel.cu", "utils/torch_utils.py:16", "utils/feature_fetcher.py:13", "model.py"):
         assert cite in text
+
+
+def test_bn_job_struct_layout_matches_header(tmp_path):
+    """pf_bn_job crosses the ABI by value in an array: the ctypes mirror must have the C compiler's layout."""
+    import ctypes
+    from pointmvsnet_amd import _lib
+    fields = [name for name, _ in _lib.BnJob._fields_]
+    src = tmp_path / "layout.c"
+    prints = "\n".join('  printf("%%zu\\n", offsetof(pf_bn_job, %s));' % f for f in fields)
+    src.write_text('#include <stddef.h>\n#include <stdio.h>\n#include "pointflow_hip.h"\nint main(void) {\n'
+                   '  printf("%%zu\\n", sizeof(pf_bn_job));\n%s\n  return 0;\n}\n' % prints)
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    vals = [int(v) for v in subprocess.check_output([str(exe)]).decode().split()]
+    assert vals[0] == ctypes.sizeof(_lib.BnJob)
+    assert vals[1:] == [getattr(_lib.BnJob, f).offset for f in fields]
+    # the header is plain C: it compiled above with gcc (no C++-isms at the boundary)
+
+
+def test_conv_policies_are_disjoint_and_cover_the_towers():
+    """Every ImageConv layer has exactly one owner among {direct FMA kernel, MFMA kernel, library}."""
+    from pointmvsnet_amd import pointflow
+    from pointmvsnet_amd.networks import ImageConv
+    tower = ImageConv(8)
+    owners = {}
+    for name in ("conv0", "conv1", "conv2", "conv3"):
+        for i, blk in enumerate(getattr(tower, name)):
+            conv = blk.conv if hasattr(blk, "conv") else blk
+            small, mfma = pointflow.conv2d_small_preferred(conv), pointflow.conv2d_preferred(conv)
+            assert not (small and mfma)
+            owners["%s.%d" % (name, i)] = "small" if small else ("mfma" if mfma else "library")
+    assert owners == {"conv0.0": "small", "conv0.1": "small", "conv1.0": "mfma", "conv1.1": "mfma",
+                      "conv1.2": "mfma", "conv2.0": "mfma", "conv2.1": "mfma", "conv2.2": "mfma",
+                      "conv3.0": "library", "conv3.1": "library", "conv3.2": "library"}
