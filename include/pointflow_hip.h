@@ -227,11 +227,12 @@ int pf_channel_affine_f32(const float* x, float* y, const float* scale, const fl
 /* Finalize + normalise in one launch: every block reduces the partials (N, T, C, 2) of its own
  * (stat group, channel) in a fixed order, then streams y = act(gamma*(x-mean)*rsqrt(var+eps)+beta);
  * one block per channel applies the running-statistics recurrence over the N/samples_per_stat stat groups
- * in order.  count = elements per stat group (= samples_per_stat * S). */
+ * in order.  count = elements per stat group (= samples_per_stat * S).  addend != NULL (same shape as x):
+ * y = addend + act(...), the additive skip of VolumeConv's decoder (reference networks.py:166) in the same pass. */
 int pf_channel_bn_apply_f32(const float* x, float* y, const double* partials, int T, int64_t N, int64_t C, int64_t S,
                             int samples_per_stat, double count, const float* gamma, const float* beta,
                             float* running_mean, float* running_var, float momentum, float eps, int relu,
-                            void* stream);
+                            const float* addend, void* stream);
 /* Statistics + finalize + normalise in ONE launch for small tensors (one 1024-thread block per channel walks
  * the stat groups in order): y = act(BN_train(x)) with y == x allowed, and/or (y == NULL) only the affine
  * rows scale/shift (N/samples_per_stat, ld_affine) for a consumer that applies them itself.  Same

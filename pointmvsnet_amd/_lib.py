@@ -57,7 +57,7 @@ PROTOTYPES = {
     "pf_norm_blocks": ([_i64], _i),
     "pf_channel_stats_f32": ([_vp, _i64, _i64, _i64, _vp, _vp], _i),
     "pf_channel_affine_f32": ([_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _vp], _i),
-    "pf_channel_bn_apply_f32": ([_vp, _vp, _vp, _i, _i64, _i64, _i64, _i, _d, _vp, _vp, _vp, _vp, _f, _f, _i, _vp], _i),
+    "pf_channel_bn_apply_f32": ([_vp, _vp, _vp, _i, _i64, _i64, _i64, _i, _d, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp], _i),
     "pf_channel_bn_fused_f32": ([_vp, _vp, _i64, _i64, _i64, _i, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _i, _vp], _i),
     "pf_edge_stats_f32": ([_vp, _i64, _i, _vp, _i, _i, _i, _vp, _vp], _i),
     "pf_bn_finalize_f32": ([_vp, _i, _i, _i, _i, _d, _d, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _i, _vp], _i),

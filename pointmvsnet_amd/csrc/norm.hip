@@ -70,11 +70,12 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restr
 
 // y = act(x * scale[s, c] + shift[s, c]), s = n / samples_per_stat; grid = (blocks, C, N)
 __device__ __forceinline__ void affine_stream(const float* __restrict__ p, float* __restrict__ o, int64_t S,
-                                              float a, float b, int relu) {
+                                              float a, float b, int relu, const float* __restrict__ add = nullptr) {
   const int64_t stride = (int64_t)gridDim.x * 256;
-  if ((((uintptr_t)p | (uintptr_t)o) & 15) == 0 && (S & 3) == 0) {
+  if ((((uintptr_t)p | (uintptr_t)o | (uintptr_t)add) & 15) == 0 && (S & 3) == 0) {
     const int64_t n4 = S >> 2;
     const float4* p4 = reinterpret_cast<const float4*>(p);
+    const float4* a4 = reinterpret_cast<const float4*>(add);
     float4* o4 = reinterpret_cast<float4*>(o);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
       float4 v = p4[i];
@@ -88,12 +89,20 @@ __device__ __forceinline__ void affine_stream(const float* __restrict__ p, float
         v.z = fmaxf(v.z, 0.0f);
         v.w = fmaxf(v.w, 0.0f);
       }
+      if (add != nullptr) {                      // other + act(bn(x)): the operand order of the reference's add
+        const float4 u = a4[i];
+        v.x = u.x + v.x;
+        v.y = u.y + v.y;
+        v.z = u.z + v.z;
+        v.w = u.w + v.w;
+      }
       o4[i] = v;
     }
   } else {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < S; i += stride) {
       float v = fmaf(p[i], a, b);
-      o[i] = relu ? fmaxf(v, 0.0f) : v;
+      v = relu ? fmaxf(v, 0.0f) : v;
+      o[i] = add != nullptr ? add[i] + v : v;
     }
   }
 }
@@ -138,7 +147,8 @@ __device__ __forceinline__ double2 reduce_partials(const double* __restrict__ pa
 __global__ __launch_bounds__(256) void channel_bn_apply_kernel(
     const float* __restrict__ x, float* __restrict__ y, const double* __restrict__ partials, int T, int C, int64_t S,
     int samples_per_stat, int G, double count, const float* __restrict__ gamma, const float* __restrict__ beta,
-    float* __restrict__ running_mean, float* __restrict__ running_var, float momentum, float eps, int relu) {
+    float* __restrict__ running_mean, float* __restrict__ running_var, float momentum, float eps, int relu,
+    const float* __restrict__ addend) {
   __shared__ double2 red[256];
   const int c = blockIdx.y, n = blockIdx.z;
   const int s = n / samples_per_stat;
@@ -165,7 +175,8 @@ __global__ __launch_bounds__(256) void channel_bn_apply_kernel(
       running_var[c] = rv;
     }
   }
-  affine_stream(x + ((int64_t)n * C + c) * S, y + ((int64_t)n * C + c) * S, S, a, b, relu);
+  affine_stream(x + ((int64_t)n * C + c) * S, y + ((int64_t)n * C + c) * S, S, a, b, relu,
+                addend ? addend + ((int64_t)n * C + c) * S : nullptr);
 }
 
 // Small tensors (the encoder/decoder layers of VolumeConv and the deep tower stages: <= 256 KB per channel):
@@ -334,7 +345,7 @@ int pf_channel_affine_f32(const float* x, float* y, const float* scale, const fl
 int pf_channel_bn_apply_f32(const float* x, float* y, const double* partials, int T, int64_t N, int64_t C, int64_t S,
                             int samples_per_stat, double count, const float* gamma, const float* beta,
                             float* running_mean, float* running_var, float momentum, float eps, int relu,
-                            void* stream) {
+                            const float* addend, void* stream) {
   PF_REQUIRE(N >= 0 && C >= 0 && S >= 0 && N <= 65535 && C <= 65535 && samples_per_stat >= 1 && T >= 1);
   PF_REQUIRE(N % samples_per_stat == 0 && count > 0.0);
   PF_REQUIRE((running_mean == nullptr) == (running_var == nullptr));
@@ -345,7 +356,7 @@ int pf_channel_bn_apply_f32(const float* x, float* y, const double* partials, in
   dim3 grid((unsigned)blocks, (unsigned)C, (unsigned)N);
   hipLaunchKernelGGL(channel_bn_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, partials, T, (int)C, S,
                      samples_per_stat, (int)(N / samples_per_stat), count, gamma, beta, running_mean, running_var,
-                     momentum, eps, relu);
+                     momentum, eps, relu, addend);
   return pf_launch_status();
 }
 

@@ -92,6 +92,16 @@ def _deconv_fusable(block, x):
             and conv.groups == 1 and conv.bias is None and x[0, 0].numel() >= 2048)
 
 
+def _conv3d_fusable(conv, x):
+    """Layers pf_conv3d_k3_f32 takes (measured policy, profiles/r01l_microbench_conv3d.log: 16->32 /2 on
+    24x32x40: 14.5 us vs 23.4 us for the library's im2col + GEMM, 32->32 on 12x16x20: 19.6 vs 36.5 us; the
+    6x8x10 layers stay on the library)."""
+    return (type(conv) is nn.Conv3d and conv.kernel_size == (3, 3, 3) and conv.padding == (1, 1, 1)
+            and conv.stride in ((1, 1, 1), (2, 2, 2)) and conv.dilation == (1, 1, 1) and conv.groups == 1
+            and conv.bias is None and conv.in_channels % 4 == 0 and conv.out_channels <= 32
+            and x[0, 0].numel() // (conv.stride[0] ** 3) >= 2048)
+
+
 def _block_fused(block, x, samples_per_stat):
     """conv (library) -> HIP BatchNorm statistics/finalize -> HIP affine+ReLU in place; ``block`` is one of
     the nn.conv blocks or a plain nn.ConvNd (no BN / ReLU)."""
@@ -116,13 +126,7 @@ def _block_fused(block, x, samples_per_stat):
         x = x + skip
     conv = block.conv
     training_bn = block.bn is not None and (block.bn.training or not block.bn.track_running_stats)
-    if (type(conv) is nn.Conv3d and conv.kernel_size == (3, 3, 3) and conv.padding == (1, 1, 1)
-            and conv.stride in ((1, 1, 1), (2, 2, 2)) and conv.dilation == (1, 1, 1) and conv.groups == 1
-            and conv.bias is None and conv.in_channels % 4 == 0
-            and conv.out_channels <= 32
-            and x[0, 0].numel() // (conv.stride[0] ** 3) >= 2048):
-        # (measured, profiles/r01l_microbench_conv3d.log: 16->32 /2 on 24x32x40: 14.5 us vs 23.4 us for the
-        # library's im2col + GEMM, 32->32 on 12x16x20: 19.6 vs 36.5 us; the 6x8x10 layers stay on the library)
+    if _conv3d_fusable(conv, x):
         # row R on the f32 matrix cores; the BN batch statistics come out of the conv epilogue
         y, partials = pointflow.conv3d_k3(x.contiguous(), conv.weight, conv.stride[0], training_bn)
         if block.bn is not None:
@@ -246,7 +250,13 @@ class VolumeConv(nn.Module):
                 full = f(self.conv0_1, x)
                 full.record_stream(main)
         else:
-            full = f(self.conv0_1, x)
+            blk = self.conv0_1
+            training_bn = blk.bn is not None and (blk.bn.training or not blk.bn.track_running_stats)
+            if aux is None and training_bn and _conv3d_fusable(blk.conv, x):
+                # its BatchNorm+ReLU waits for the decoder: applied together with the last skip add below
+                full = pointflow.conv3d_k3(x.contiguous(), blk.conv.weight, 1, True)
+            else:
+                full = f(blk, x)
         half = f(self.conv1_0, x)
         quarter = f(self.conv2_0, half)
         eighth = f(self.conv3_1, f(self.conv3_0, quarter))
@@ -257,9 +267,16 @@ class VolumeConv(nn.Module):
         up = f(self.conv6_0, (up, half))
         if aux is not None:
             torch.cuda.current_stream().wait_stream(aux)
-        # (the last skip add stays a separate elementwise launch: conv6_2's kernel is bound by its tap loads,
-        # and adding on load doubles them -- 63 us against 15 + 5, profiles/r01h_microbench_deconv3d.log)
-        return f(self.conv6_2, up + full)
+        # (conv6_2 does not add on load: its kernel is bound by its tap loads and adding there doubles them --
+        # 63 us against 15 + 5, profiles/r01h_microbench_deconv3d.log; instead the add rides on conv0_1's
+        # BatchNorm+ReLU pass, which has to stream that tensor anyway)
+        if isinstance(full, tuple):
+            raw, partials = full
+            summed = pointflow.batch_norm_act_(raw, self.conv0_1.bn, self.conv0_1.relu, B, partials=partials,
+                                               addend=up.contiguous())
+        else:
+            summed = up + full
+        return f(self.conv6_2, summed)
 
     def forward(self, x):
         full = self.conv0_1(x)

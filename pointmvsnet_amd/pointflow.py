@@ -392,8 +392,9 @@ def pack_conv3d_weight(weight):
     return wp
 
 
-def batch_norm_act_(x, bn, relu, samples_per_stat, partials=None):
-    """In-place train/eval BatchNorm + optional ReLU on a contiguous (N,C,*spatial) conv output.
+def batch_norm_act_(x, bn, relu, samples_per_stat, partials=None, addend=None):
+    """In-place train/eval BatchNorm + optional ReLU on a contiguous (N,C,*spatial) conv output; with
+    ``addend`` (same shape) the result is ``addend + act(bn(x))`` (a decoder skip add in the same pass).
 
     ``samples_per_stat`` consecutive samples share one set of batch statistics == one reference module
     call (the reference runs each view through the tower separately, model.py:71-77, so views batched
@@ -409,26 +410,29 @@ def batch_norm_act_(x, bn, relu, samples_per_stat, partials=None):
         if partials is None and N * S <= FUSED_BN_MAX:
             _bn_fused(x, x, bn, relu, samples_per_stat)
             bump_counter(bn, G)
-            return x
+            return x if addend is None else x.add_(addend)
         if partials is None:
             T = int(_lib.load().pf_norm_blocks(S))
             partials = torch.empty((N, T, C, 2), dtype=torch.float64, device=dev)
             _lib.call("pf_channel_stats_f32", _lib.ptr(x), N, C, S, _lib.ptr(partials), _lib.stream(),
                       algo_bytes=4.0 * N * C * S)
         track = bn.track_running_stats and bn.running_mean is not None
+        if addend is not None and (addend.shape != x.shape or not addend.is_contiguous()):
+            raise RuntimeError("batch_norm_act_: addend must be contiguous and shaped like x")
         _lib.call("pf_channel_bn_apply_f32", _lib.ptr(x), _lib.ptr(x), _lib.ptr(partials), int(partials.shape[1]),
                   N, C, S, int(samples_per_stat), float(samples_per_stat) * S, _lib.ptr(bn.weight.detach()),
                   _lib.ptr(bn.bias.detach()), _lib.ptr(bn.running_mean if track else None),
                   _lib.ptr(bn.running_var if track else None), float(bn.momentum), float(bn.eps), int(bool(relu)),
-                  _lib.stream(), algo_bytes=8.0 * N * C * S)
+                  _lib.ptr(addend), _lib.stream(), algo_bytes=(8.0 if addend is None else 12.0) * N * C * S)
         bump_counter(bn, G)
+        return x
     else:
         sc, sh = eval_affine(bn, G, C)
         scale = sc.unsqueeze(0).expand(G, C).contiguous()
         shift = sh.unsqueeze(0).expand(G, C).contiguous()
         _lib.call("pf_channel_affine_f32", _lib.ptr(x), _lib.ptr(x), _lib.ptr(scale), _lib.ptr(shift), N, C, S,
                   int(samples_per_stat), int(bool(relu)), _lib.stream(), algo_bytes=8.0 * N * C * S)
-    return x
+    return x if addend is None else x.add_(addend)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -488,6 +488,14 @@ def test_batch_norm_act_vs_torch_per_group(dev, shape, sps, relu):
     assert _maxabs(bn.running_mean, ref_bn.running_mean) < 1e-6
     assert float(((bn.running_var.cpu() - ref_bn.running_var).abs() / ref_bn.running_var).max()) < 1e-5
     assert int(bn.num_batches_tracked) == int(ref_bn.num_batches_tracked) == shape[0] // sps
+    # decoder skip add in the same pass (VolumeConv's last add): addend + act(bn(x))
+    bn3 = bn_cls(C)
+    synthetic.seed_weights(bn3, 3)
+    bn3 = bn3.to(dev).train()
+    addend = torch.randn(shape, generator=gen)
+    y3 = pointflow.batch_norm_act_(x.to(dev).contiguous(), bn3, relu, sps, addend=addend.to(dev))
+    pointflow.flush_counters()
+    assert _maxabs(y3, ref + addend) < 5e-6 * max(1.0, float((ref + addend).abs().max()))
     # affine-rows form (the consumer normalises itself): same statistics, no pass over y
     bn2 = bn_cls(C)
     synthetic.seed_weights(bn2, 3)
