@@ -26,7 +26,7 @@ def test_header_library_and_bindings_agree(lib_built):
     lib = _lib.load()
     assert b"gfx950" in lib.pf_version()
     assert b"invalid argument" in lib.pf_error_string(-1)
-    assert lib.pf_stat_blocks(1, 25600) == 256 and lib.pf_stat_blocks(16, 96000) == 64
+    assert lib.pf_stat_blocks(1, 25600) == 400 and lib.pf_stat_blocks(16, 96000) == 250
     assert lib.pf_stat_blocks(1, 100) == 2 and lib.pf_stat_blocks(0, 5) == 0
 
 
