@@ -159,21 +159,6 @@ int pf_stat_blocks(int G, int Ng);
 /* Blocks per group used by pf_pointwise_gemm_f32 (128-point tiles); its partials are (G, Tg, Nc, 2). */
 int pf_gemm_blocks(int G, int Ng);
 
-/* Y[m, 0:Nc_store] = act(X[m, 0:K]) * Wt, m over G*Ng points.  Wt is (K, Nc) row-major, Nc in
- * {32, 64, 128}.  X is channel-major (G, K, Ng) when x_point_major == 0 (the reference (B,C,N) layout)
- * or point-major rows of ldx floats.  act = ReLU(x*in_scale[s,k] + in_shift[s,k]) when in_scale != NULL
- * (s = g / groups_per_stat) -- the previous layer's BatchNorm+ReLU fused into the load -- else identity.
- * col_partials (G, pf_gemm_blocks(G,Ng), Nc, 2) float64 or NULL receives per-block column sums of Y. */
-int pf_pointwise_gemm_f32(const float* X, int x_point_major, int64_t ldx, const float* Wt, float* Y,
-                          int64_t ldy, int G, int Ng, int K, int Nc, int Nc_store, const float* in_scale,
-                          const float* in_shift, int groups_per_stat, double* col_partials, void* stream);
-
-/* Pass A of EdgeConv: for rows LE = [l (C) | e (C)] (point-major, ldle floats per point) and local
- * neighbour indices idx (G, Ng, k): partial sums over all (point, neighbour) pairs of
- * d = e[idx] - l and d*d per channel -> partials (G, T, C, 2) float64.   C in {32, 64, 128}. */
-int pf_edge_stats_f32(const float* LE, int64_t ldle, int C, const int64_t* idx, int k, int G, int Ng,
-                      double* partials, void* stream);
-
 /* BatchNorm (training mode) statistics -> affine.  Reduces partials (G, T, pcols, 2) over the T blocks
  * of `groups_per_stat` consecutive groups, columns [col0, col0+C):  mean = S/count,
  * var = SS/count - mean^2 (biased, used to normalise), scale = gamma*rsqrt(var+eps),
@@ -204,6 +189,36 @@ typedef struct pf_bn_job {
   int32_t ld_affine;
 } pf_bn_job;
 int pf_bn_finalize_jobs_f32(const pf_bn_job* jobs, int njobs, void* stream);
+
+/* The finalize FOLDED INTO THE PRODUCER ("last block done", csrc/pf_bn_tail.h).  The kernels that write statistics
+ * rows -- pf_pointwise_gemm_f32, pf_edge_stats_f32, pf_conv2d_f32, pf_conv2d_small_f32 -- accept up to two
+ * pf_bn_job (host array `bn_jobs_host`, n_bn_jobs; the fields partials / T / pcols / G are filled in by the
+ * call from its own launch geometry) and then perform those jobs themselves: blocks publish their rows
+ * write-through, the last block of every cluster of rows reduces the cluster, the last cluster-reducer
+ * finalizes -- fixed summation order, bit-reproducible, no separate launch.  With n_bn_jobs > 0 the statistics
+ * buffer must hold pf_bn_tail_rows(G, T) extra rows after the (G, T, pcols, 2) block rows, and `tickets` must
+ * point to pf_bn_tail_tickets(G, T) zero-initialised unsigned counters that no concurrently running launch
+ * uses (the kernel leaves them zero again).  pcols must be 8/16/32/64/128 (else PF_ERR_UNSUPPORTED). */
+int pf_bn_tail_rows(int G, int T);
+int pf_bn_tail_tickets(int G, int T);
+
+/* Y[m, 0:Nc_store] = act(X[m, 0:K]) * Wt, m over G*Ng points.  Wt is (K, Nc) row-major, Nc in
+ * {32, 64, 128}.  X is channel-major (G, K, Ng) when x_point_major == 0 (the reference (B,C,N) layout)
+ * or point-major rows of ldx floats.  act = ReLU(x*in_scale[s,k] + in_shift[s,k]) when in_scale != NULL
+ * (s = g / groups_per_stat) -- the previous layer's BatchNorm+ReLU fused into the load -- else identity.
+ * col_partials (G, pf_gemm_blocks(G,Ng), Nc, 2) float64 or NULL receives per-block column sums of Y. */
+int pf_pointwise_gemm_f32(const float* X, int x_point_major, int64_t ldx, const float* Wt, float* Y,
+                          int64_t ldy, int G, int Ng, int K, int Nc, int Nc_store, const float* in_scale,
+                          const float* in_shift, int groups_per_stat, double* col_partials,
+                          const pf_bn_job* bn_jobs_host, int n_bn_jobs, unsigned* tickets, void* stream);
+
+/* Pass A of EdgeConv: for rows LE = [l (C) | e (C)] (point-major, ldle floats per point) and local
+ * neighbour indices idx (G, Ng, k): partial sums over all (point, neighbour) pairs of
+ * d = e[idx] - l and d*d per channel -> partials (G, T, C, 2) float64.   C in {32, 64, 128}. */
+int pf_edge_stats_f32(const float* LE, int64_t ldle, int C, const int64_t* idx, int k, int G, int Ng,
+                      double* partials, const pf_bn_job* bn_jobs_host, int n_bn_jobs, unsigned* tickets,
+                      void* stream);
+
 
 /* Pass B of EdgeConv (reference networks.py:37-43 / :74-79):
  *   concat != 0: Y[m, 0:C]  = relu(l*scale[0:C] + shift[0:C])                       (central half)
@@ -277,7 +292,8 @@ int pf_deconv3d_k3s2_f32(const float* xa, const float* xb, const float* w, float
 int pf_conv2d_blocks(int64_t N, int64_t Cout, int64_t Hi, int64_t Wi, int kernel_size, int stride);
 int pf_conv2d_f32(const float* x, const float* wp, float* y, int64_t N, int64_t Cin, int64_t Cout, int64_t Hi,
                   int64_t Wi, int kernel_size, int stride, const float* in_scale, const float* in_shift,
-                  int samples_per_stat, double* partials, void* stream);
+                  int samples_per_stat, double* partials, const pf_bn_job* bn_jobs_host, int n_bn_jobs,
+                  unsigned* tickets, void* stream);
 
 /* Same contract as pf_conv2d_f32 for the few-channel layers (Cin <= 16, Cout = 8 or 16; 3x3/s1 or 5x5/s2),
  * on plain float32 FMAs.  wp = weights packed as (ceil(Cin/4), 4, K, K, Cout), zero padded over channels.
@@ -285,7 +301,8 @@ int pf_conv2d_f32(const float* x, const float* wp, float* y, int64_t N, int64_t 
 int pf_conv2d_small_blocks(int64_t N, int64_t Hi, int64_t Wi, int kernel_size, int stride);
 int pf_conv2d_small_f32(const float* x, const float* wp, float* y, int64_t N, int64_t Cin, int64_t Cout, int64_t Hi,
                         int64_t Wi, int kernel_size, int stride, const float* in_scale, const float* in_shift,
-                        int samples_per_stat, double* partials, void* stream);
+                        int samples_per_stat, double* partials, const pf_bn_job* bn_jobs_host, int n_bn_jobs,
+                        unsigned* tickets, void* stream);
 
 /* ---- rows M (last layer) + H + T : flow head ---------------------------------------------------
  * Z (G*Ng, ldz) holds the pre-BN output of the 64->16 MLP layer.  Per pixel of the (h,w) grid:

@@ -43,7 +43,9 @@ def install_as_pointmvsnet():
 def load_reference_model(model_py_path):
     """Execute a reference ``pointmvsnet/model.py`` file, unmodified, on top of the aliased operators."""
     install_as_pointmvsnet()
-    spec = importlib.util.spec_from_file_location("pointmvsnet.model", model_py_path)
+    import importlib.machinery
+    loader = importlib.machinery.SourceFileLoader("pointmvsnet.model", model_py_path)   # any file name
+    spec = importlib.util.spec_from_loader("pointmvsnet.model", loader)
     module = importlib.util.module_from_spec(spec)
     sys.modules["pointmvsnet.model"] = module
     spec.loader.exec_module(module)

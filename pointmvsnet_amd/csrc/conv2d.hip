@@ -15,6 +15,7 @@
 #include <stdlib.h>
 
 #include "pf_common.h"
+#include "pf_bn_tail.h"
 
 namespace {
 
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(256, MINW) void conv2d_kernel(const float* __restri
                                                            float* __restrict__ y, Conv2Geom g,
                                                            const float* __restrict__ in_scale,
                                                            const float* __restrict__ in_shift,
-                                                           double* __restrict__ partials) {
+                                                           double* __restrict__ partials, PfTail tail) {
   using S = Stage2<STRIDE, KS, TR>;
   constexpr int IH = S::IH, IW = S::IW, IWP = S::IWP, PLANE = S::PLANE, ELEMS = S::ELEMS, NXR = S::NXR;
   constexpr int NCP = NT * 16;
@@ -264,9 +265,11 @@ __global__ __launch_bounds__(256, MINW) void conv2d_kernel(const float* __restri
         q += red[((w * NCP) + tid) * 2 + 1];
       }
       double* o = partials + (((int64_t)n * gridDim.x + blockIdx.x) * g.Cout + tid) * 2;
-      o[0] = s;
-      o[1] = q;
+      pf_row_store(o, s);
+      pf_row_store(o + 1, q);
     }
+    // this layer's BatchNorm finalize by the last block (pf_bn_tail.h); the staging buffers are free by now
+    if (tail.njobs > 0) pf_bn_tail<256>(tail, n, blockIdx.x, reinterpret_cast<double*>(lds));
   }
 }
 
@@ -301,9 +304,15 @@ int blocks_2d(int64_t Ho, int64_t Wo, int tr, int64_t N) {
   return (int)((total + per - 1) / per);
 }
 
+struct TailArgs {
+  const pf_bn_job* jobs;
+  int njobs;
+  unsigned* tickets;
+};
+
 template <int NT, int STRIDE, int KS, int TR, int KG, int MINW>
 int launch2d(const float* x, const float* wp, float* y, Conv2Geom g, int64_t N, const float* in_scale,
-             const float* in_shift, double* partials, hipStream_t s) {
+             const float* in_shift, double* partials, TailArgs ta, hipStream_t s) {
   constexpr size_t lds_bytes = lds_bytes_2d<NT, STRIDE, KS, TR, KG>();
   static_assert(lds_bytes <= kMaxLds2d, "conv2d tile does not fit the LDS budget");
   if (lds_bytes > 64 * 1024) {
@@ -316,20 +325,26 @@ int launch2d(const float* x, const float* wp, float* y, Conv2Geom g, int64_t N, 
   }
   g.tiles_h = (g.Ho + 4 * TR - 1) / (4 * TR);
   g.tiles_w = (g.Wo + 15) / 16;
+  static_assert(lds_bytes >= sizeof(double) * kTailSmemDoubles, "the BatchNorm tail borrows the staging LDS");
   dim3 grid((unsigned)blocks_2d(g.Ho, g.Wo, TR, N), (unsigned)N);
+  PfTail tail;
+  {
+    const int rc = pf_tail_setup(tail, ta.jobs, ta.njobs, partials, (int)N, (int)grid.x, g.Cout, ta.tickets);
+    if (rc != PF_OK) return rc;
+  }
   hipLaunchKernelGGL((conv2d_kernel<NT, STRIDE, KS, TR, KG, MINW>), grid, dim3(256), lds_bytes, s, x, wp, y, g,
-                     in_scale, in_shift, partials);
+                     in_scale, in_shift, partials, tail);
   return pf_launch_status();
 }
 
 // NT <= 2: the variants the tuning hook can select (TR in {2,4} for 3x3, KG in {1,2}, MINW in {2,3,4})
 template <int NT, int STRIDE, int KS>
 int launch_variant(int tr, const float* x, const float* wp, float* y, const Conv2Geom& g, int64_t N,
-                   const float* in_scale, const float* in_shift, double* partials, hipStream_t s) {
+                   const float* in_scale, const float* in_shift, double* partials, TailArgs ta, hipStream_t s) {
   const int ov = variant2d();
   const int kg = ov ? (ov / 10) % 10 : ((KS == 3 && NT == 2) ? 2 : 1);
   const int minw = ov ? ov % 10 : 2;
-#define PF_L2(TRV, KGV, MW) return launch2d<NT, STRIDE, KS, TRV, KGV, MW>(x, wp, y, g, N, in_scale, in_shift, partials, s)
+#define PF_L2(TRV, KGV, MW) return launch2d<NT, STRIDE, KS, TRV, KGV, MW>(x, wp, y, g, N, in_scale, in_shift, partials, ta, s)
   if constexpr (KS == 3) {
     if (tr == 4) {
       if (kg == 2) { if (minw == 3) PF_L2(4, 2, 3); PF_L2(4, 2, 2); }
@@ -360,8 +375,11 @@ int pf_conv2d_blocks(int64_t N, int64_t Cout, int64_t Hi, int64_t Wi, int kernel
 
 int pf_conv2d_f32(const float* x, const float* wp, float* y, int64_t N, int64_t Cin, int64_t Cout, int64_t Hi,
                   int64_t Wi, int kernel_size, int stride, const float* in_scale, const float* in_shift,
-                  int samples_per_stat, double* partials, void* stream) {
+                  int samples_per_stat, double* partials, const pf_bn_job* bn_jobs, int n_bn_jobs, unsigned* tickets,
+                  void* stream) {
   PF_REQUIRE(N >= 0 && Cin >= 1 && Cout >= 1 && Hi >= 1 && Wi >= 1 && N <= 65535 && samples_per_stat >= 1);
+  PF_REQUIRE(n_bn_jobs >= 0 && (n_bn_jobs == 0 || partials != nullptr));
+  const TailArgs ta{bn_jobs, n_bn_jobs, tickets};
   PF_REQUIRE((in_scale == nullptr) == (in_shift == nullptr));
   const bool k3s1 = kernel_size == 3 && stride == 1, k5s2 = kernel_size == 5 && stride == 2;
   if (!(k3s1 || k5s2) || Cout > 64) return PF_ERR_UNSUPPORTED;
@@ -382,13 +400,13 @@ int pf_conv2d_f32(const float* x, const float* wp, float* y, int64_t N, int64_t 
   if (nt == 3) nt = 4;
   const int tr = tr_for(kernel_size, nt, g.Ho, g.Wo, N);
   if (k3s1) {
-    if (nt == 1) return launch_variant<1, 1, 3>(tr, x, wp, y, g, N, in_scale, in_shift, partials, s);
-    if (nt == 2) return launch_variant<2, 1, 3>(tr, x, wp, y, g, N, in_scale, in_shift, partials, s);
-    return launch2d<4, 1, 3, 2, 1, 2>(x, wp, y, g, N, in_scale, in_shift, partials, s);
+    if (nt == 1) return launch_variant<1, 1, 3>(tr, x, wp, y, g, N, in_scale, in_shift, partials, ta, s);
+    if (nt == 2) return launch_variant<2, 1, 3>(tr, x, wp, y, g, N, in_scale, in_shift, partials, ta, s);
+    return launch2d<4, 1, 3, 2, 1, 2>(x, wp, y, g, N, in_scale, in_shift, partials, ta, s);
   }
-  if (nt == 1) return launch_variant<1, 2, 5>(tr, x, wp, y, g, N, in_scale, in_shift, partials, s);
-  if (nt == 2) return launch_variant<2, 2, 5>(tr, x, wp, y, g, N, in_scale, in_shift, partials, s);
-  return launch2d<4, 2, 5, 1, 1, 2>(x, wp, y, g, N, in_scale, in_shift, partials, s);
+  if (nt == 1) return launch_variant<1, 2, 5>(tr, x, wp, y, g, N, in_scale, in_shift, partials, ta, s);
+  if (nt == 2) return launch_variant<2, 2, 5>(tr, x, wp, y, g, N, in_scale, in_shift, partials, ta, s);
+  return launch2d<4, 2, 5, 1, 1, 2>(x, wp, y, g, N, in_scale, in_shift, partials, ta, s);
 }
 
 }  // extern "C"

@@ -11,6 +11,7 @@
 //   * stores are 128-byte row segments per channel straight from registers; per-channel sum / sum of
 //     squares are carried in registers across the block's tiles and reduced once (float64 partials).
 #include "pf_common.h"
+#include "pf_bn_tail.h"
 
 namespace {
 
@@ -25,7 +26,7 @@ __global__ __launch_bounds__(256) void conv2d_small_kernel(const float* __restri
                                                            float* __restrict__ y, SmallGeom g,
                                                            const float* __restrict__ in_scale,
                                                            const float* __restrict__ in_shift,
-                                                           double* __restrict__ partials) {
+                                                           double* __restrict__ partials, PfTail tail) {
   constexpr int TR = 8 * PPT;                          // output tile rows
   constexpr int IH = (TR - 1) * STRIDE + KS, IW = (TC - 1) * STRIDE + KS;
   constexpr int IWP = IW | 1;                          // odd row stride
@@ -187,8 +188,11 @@ __global__ __launch_bounds__(256) void conv2d_small_kernel(const float* __restri
     __syncthreads();
     if (tid < 2 * COUT) {
       const double v = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
-      partials[(((int64_t)n * gridDim.x + blockIdx.x) * COUT + (tid >> 1)) * 2 + (tid & 1)] = v;
+      pf_row_store(partials + (((int64_t)n * gridDim.x + blockIdx.x) * COUT + (tid >> 1)) * 2 + (tid & 1), v);
     }
+    // this layer's BatchNorm finalize by the last block (pf_bn_tail.h); the patch buffer is free by now
+    static_assert(sizeof(xs) >= sizeof(double) * kTailSmemDoubles, "the BatchNorm tail borrows the patch buffer");
+    if (tail.njobs > 0) pf_bn_tail<256>(tail, n, blockIdx.x, reinterpret_cast<double*>(xs));
   }
 }
 
@@ -202,13 +206,19 @@ int small_blocks(int64_t Ho, int64_t Wo, int tr, int64_t N) {
 
 template <int COUT, int KS, int STRIDE, int PPT>
 int launch_small(const float* x, const float* wp, float* y, SmallGeom g, int64_t N, const float* in_scale,
-                 const float* in_shift, double* partials, hipStream_t s) {
+                 const float* in_shift, double* partials, const pf_bn_job* jobs, int njobs, unsigned* tickets,
+                 hipStream_t s) {
   constexpr int TR = 8 * PPT;
   g.tiles_h = (g.Ho + TR - 1) / TR;
   g.tiles_w = (g.Wo + TC - 1) / TC;
   dim3 grid((unsigned)small_blocks(g.Ho, g.Wo, TR, N), (unsigned)N);
+  PfTail tail;
+  {
+    const int rc = pf_tail_setup(tail, jobs, njobs, partials, (int)N, (int)grid.x, COUT, tickets);
+    if (rc != PF_OK) return rc;
+  }
   hipLaunchKernelGGL((conv2d_small_kernel<COUT, KS, STRIDE, PPT>), grid, dim3(256), 0, s, x, wp, y, g, in_scale,
-                     in_shift, partials);
+                     in_shift, partials, tail);
   return pf_launch_status();
 }
 
@@ -224,8 +234,10 @@ int pf_conv2d_small_blocks(int64_t N, int64_t Hi, int64_t Wi, int kernel_size, i
 
 int pf_conv2d_small_f32(const float* x, const float* wp, float* y, int64_t N, int64_t Cin, int64_t Cout, int64_t Hi,
                         int64_t Wi, int kernel_size, int stride, const float* in_scale, const float* in_shift,
-                        int samples_per_stat, double* partials, void* stream) {
+                        int samples_per_stat, double* partials, const pf_bn_job* bn_jobs, int n_bn_jobs,
+                        unsigned* tickets, void* stream) {
   PF_REQUIRE(N >= 0 && Cin >= 1 && Cout >= 1 && Hi >= 1 && Wi >= 1 && N <= 65535 && samples_per_stat >= 1);
+  PF_REQUIRE(n_bn_jobs >= 0 && (n_bn_jobs == 0 || partials != nullptr));
   PF_REQUIRE((in_scale == nullptr) == (in_shift == nullptr));
   const bool k3s1 = kernel_size == 3 && stride == 1, k5s2 = kernel_size == 5 && stride == 2;
   if (!(k3s1 || k5s2) || (Cout != 8 && Cout != 16) || Cin > 16) return PF_ERR_UNSUPPORTED;
@@ -242,11 +254,11 @@ int pf_conv2d_small_f32(const float* x, const float* wp, float* y, int64_t N, in
   g.sps = samples_per_stat;
   hipStream_t s = (hipStream_t)stream;
   if (k3s1) {
-    if (Cout == 8) return launch_small<8, 3, 1, 2>(x, wp, y, g, N, in_scale, in_shift, partials, s);
-    return launch_small<16, 3, 1, 2>(x, wp, y, g, N, in_scale, in_shift, partials, s);
+    if (Cout == 8) return launch_small<8, 3, 1, 2>(x, wp, y, g, N, in_scale, in_shift, partials, bn_jobs, n_bn_jobs, tickets, s);
+    return launch_small<16, 3, 1, 2>(x, wp, y, g, N, in_scale, in_shift, partials, bn_jobs, n_bn_jobs, tickets, s);
   }
-  if (Cout == 8) return launch_small<8, 5, 2, 2>(x, wp, y, g, N, in_scale, in_shift, partials, s);
-  return launch_small<16, 5, 2, 2>(x, wp, y, g, N, in_scale, in_shift, partials, s);
+  if (Cout == 8) return launch_small<8, 5, 2, 2>(x, wp, y, g, N, in_scale, in_shift, partials, bn_jobs, n_bn_jobs, tickets, s);
+  return launch_small<16, 5, 2, 2>(x, wp, y, g, N, in_scale, in_shift, partials, bn_jobs, n_bn_jobs, tickets, s);
 }
 
 }  // extern "C"

@@ -27,6 +27,7 @@
 // Algorithmic HBM bytes per point: EdgeConv(C_in->C_out, out C'):
 // 4*C_in + 8*16 + 16*4*C_out + 4*C'.
 #include "pf_common.h"
+#include "pf_bn_tail.h"
 
 namespace {
 
@@ -52,7 +53,7 @@ template <bool POINT_MAJOR, int NT>
 __global__ __launch_bounds__(256, 2) void pointwise_gemm_kernel(
     const float* __restrict__ X, int64_t ldx, const float* __restrict__ Wt, float* __restrict__ Y, int64_t ldy,
     int Ng, int K, int Nc_store, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
-    int groups_per_stat, double* __restrict__ partials, int T) {
+    int groups_per_stat, double* __restrict__ partials, int T, PfTail tail) {
   constexpr int NC = NT * 32;
   constexpr int KC = NT == 4 ? 16 : 32;
   constexpr int NA = KC * GT / 256;   // A floats staged per thread per chunk (16 or 8)
@@ -205,9 +206,11 @@ __global__ __launch_bounds__(256, 2) void pointwise_gemm_kernel(
         q += red[((w * NC) + tid) * 2 + 1];
       }
       double* o = partials + (((int64_t)g * T + tb) * NC + tid) * 2;
-      o[0] = s;
-      o[1] = q;
+      pf_row_store(o, s);
+      pf_row_store(o + 1, q);
     }
+    // BatchNorm finalize by the last block (pf_bn_tail.h); the staging buffers are free by now
+    if (tail.njobs > 0) pf_bn_tail<256>(tail, g, tb, red);
   }
 }
 
@@ -246,7 +249,7 @@ template <int C, int K>   // K == 0: neighbour count known only at run time
 __global__ __launch_bounds__(256) void edge_stats_kernel(const float* __restrict__ LE, int64_t ldle,
                                                          const int64_t* __restrict__ idx, int k, int Ng,
                                                          double* __restrict__ partials, int T,
-                                                         unsigned* __restrict__ status) {
+                                                         unsigned* __restrict__ status, PfTail tail) {
   constexpr int Q = C / 4;         // lanes per point
   constexpr int PPB = 256 / Q;     // points per pass
   __shared__ double red[256 * 8];
@@ -303,8 +306,9 @@ __global__ __launch_bounds__(256) void edge_stats_kernel(const float* __restrict
     const int qq = tid / 8, comp = tid % 8;
     double acc = 0.0;
     for (int s = 0; s < PPB; ++s) acc += red[(s * Q + qq) * 8 + comp];
-    partials[(((int64_t)g * T + tb) * C + 4 * qq + (comp & 3)) * 2 + (comp >> 2)] = acc;
+    pf_row_store(partials + (((int64_t)g * T + tb) * C + 4 * qq + (comp & 3)) * 2 + (comp >> 2), acc);
   }
+  if (tail.njobs > 0) pf_bn_tail<256>(tail, g, tb, red);
 }
 
 template <int C, int K>
@@ -554,6 +558,16 @@ int pf_stat_blocks(int G, int Ng) {
   return (tiles + per - 1) / per;
 }
 
+int pf_bn_tail_rows(int G, int T) {
+  if (G <= 0 || T <= 0) return 0;
+  return pf_tail_fan(G, T) > 1 ? G * pf_tail_clusters(G, T) : 0;
+}
+
+int pf_bn_tail_tickets(int G, int T) {
+  if (G <= 0 || T <= 0) return 0;
+  return 1 + (pf_tail_fan(G, T) > 1 ? G * pf_tail_clusters(G, T) : 0);
+}
+
 int pf_gemm_blocks(int G, int Ng) {
   if (G <= 0 || Ng <= 0) return 0;
   const int tiles = (Ng + GT - 1) / GT;
@@ -564,8 +578,10 @@ int pf_gemm_blocks(int G, int Ng) {
 
 int pf_pointwise_gemm_f32(const float* X, int x_point_major, int64_t ldx, const float* Wt, float* Y, int64_t ldy,
                           int G, int Ng, int K, int Nc, int Nc_store, const float* in_scale,
-                          const float* in_shift, int groups_per_stat, double* col_partials, void* stream) {
+                          const float* in_shift, int groups_per_stat, double* col_partials, const pf_bn_job* bn_jobs,
+                          int n_bn_jobs, unsigned* tickets, void* stream) {
   PF_REQUIRE(G >= 0 && Ng >= 0 && K >= 1 && Nc >= 32 && Nc_store >= 1 && Nc_store <= Nc);
+  PF_REQUIRE(n_bn_jobs >= 0 && (n_bn_jobs == 0 || col_partials != nullptr));
   PF_REQUIRE(Nc % 32 == 0 && groups_per_stat >= 1);
   if (Nc != 32 && Nc != 64 && Nc != 128) return PF_ERR_UNSUPPORTED;
   PF_REQUIRE((in_scale == nullptr) == (in_shift == nullptr));
@@ -574,11 +590,16 @@ int pf_pointwise_gemm_f32(const float* X, int x_point_major, int64_t ldx, const 
   PF_REQUIRE(X && Wt && Y && ldy >= Nc_store);
   if (x_point_major) PF_REQUIRE(ldx >= K);
   const int T = pf_gemm_blocks(G, Ng);
+  PfTail tail;
+  {
+    const int rc = pf_tail_setup(tail, bn_jobs, n_bn_jobs, col_partials, G, T, Nc, tickets);
+    if (rc != PF_OK) return rc;
+  }
   dim3 grid((unsigned)T, (unsigned)G);
   hipStream_t s = (hipStream_t)stream;
 #define PF_GEMM_LAUNCH(PM, NTV)                                                                                  \
   hipLaunchKernelGGL((pointwise_gemm_kernel<PM, NTV>), grid, dim3(256), 0, s, X, ldx, Wt, Y, ldy, Ng, K, Nc_store, \
-                     in_scale, in_shift, groups_per_stat, col_partials, T)
+                     in_scale, in_shift, groups_per_stat, col_partials, T, tail)
   if (x_point_major) {
     if (Nc == 32) PF_GEMM_LAUNCH(true, 1);
     else if (Nc == 64) PF_GEMM_LAUNCH(true, 2);
@@ -593,7 +614,8 @@ int pf_pointwise_gemm_f32(const float* X, int x_point_major, int64_t ldx, const 
 }
 
 int pf_edge_stats_f32(const float* LE, int64_t ldle, int C, const int64_t* idx, int k, int G, int Ng,
-                      double* partials, void* stream) {
+                      double* partials, const pf_bn_job* bn_jobs, int n_bn_jobs, unsigned* tickets, void* stream) {
+  PF_REQUIRE(n_bn_jobs >= 0);
   PF_REQUIRE(G >= 0 && Ng >= 0 && k >= 1 && ldle >= 2 * (int64_t)C && (ldle % 4) == 0 && G <= 65535);
   if (C != 32 && C != 64 && C != 128) return PF_ERR_UNSUPPORTED;
   if (G == 0 || Ng == 0) return PF_OK;
@@ -601,9 +623,14 @@ int pf_edge_stats_f32(const float* LE, int64_t ldle, int C, const int64_t* idx, 
   unsigned* status = pf_status_ptr();
   PF_REQUIRE(status != nullptr);
   const int T = pf_stat_blocks(G, Ng);
+  PfTail tail;
+  {
+    const int rc = pf_tail_setup(tail, bn_jobs, n_bn_jobs, partials, G, T, C, tickets);
+    if (rc != PF_OK) return rc;
+  }
   dim3 grid((unsigned)T, (unsigned)G);
   hipStream_t s = (hipStream_t)stream;
-#define PF_ES(CV, KV) hipLaunchKernelGGL((edge_stats_kernel<CV, KV>), grid, dim3(256), 0, s, LE, ldle, idx, k, Ng, partials, T, status)
+#define PF_ES(CV, KV) hipLaunchKernelGGL((edge_stats_kernel<CV, KV>), grid, dim3(256), 0, s, LE, ldle, idx, k, Ng, partials, T, status, tail)
   if (k == 16) {
     if (C == 32) PF_ES(32, 16); else if (C == 64) PF_ES(64, 16); else PF_ES(128, 16);
   } else {

@@ -198,17 +198,26 @@ def _conv2d_block_fused(block, x, pending, samples_per_stat, defer):
     while staging; otherwise y is normalised in place (statistics + fused finalize/normalise)."""
     conv, bn, relu = (block.conv, block.bn, block.relu) if hasattr(block, "bn") else (block, None, False)
     training_bn = bn is not None and (bn.training or not bn.track_running_stats)
+    # a deferred train-mode BatchNorm is finalized by the convolution's own last block (csrc/pf_bn_tail.h)
+    tail_bn = bn if (pointflow.FUSED_BN and training_bn and defer and relu and bn.momentum is not None) else None
+    affine = None
     if pointflow.conv2d_small_preferred(conv):
-        y, partials = pointflow.conv2d_small(x, conv, pending, samples_per_stat, training_bn)
+        out = pointflow.conv2d_small(x, conv, pending, samples_per_stat, training_bn, bn=tail_bn)
     elif pointflow.conv2d_preferred(conv):
-        y, partials = pointflow.conv2d(x, conv, pending, samples_per_stat, training_bn)
+        out = pointflow.conv2d(x, conv, pending, samples_per_stat, training_bn, bn=tail_bn)
     else:
         if pending is not None:
             x = pointflow.channel_affine_(x, pending, True, samples_per_stat)
         y = block._crop(conv(x), x).contiguous() if hasattr(block, "_crop") else conv(x).contiguous()
-        partials = None
+        out = (y, None)
+    if len(out) == 3:
+        y, partials, affine = out
+    else:
+        y, partials = out
     if bn is None:
         return (F.relu(y, inplace=True) if relu else y), None
+    if affine is not None:
+        return y, affine
     if defer and relu:
         return y, pointflow.bn_affine_rows(y, bn, samples_per_stat, partials)
     return pointflow.batch_norm_act_(y, bn, relu, samples_per_stat, partials=partials), None

@@ -58,18 +58,44 @@ def _pack_weight_t(*convs):
     return wt.contiguous(), cout
 
 
+import os as _os
+
+# PF_FUSED_BN=0 restores the separate BatchNorm finalize launches (A/B measurements only; same results up to the
+# summation order of the float64 statistics).
+FUSED_BN = int(_os.environ.get("PF_FUSED_BN", "1"))
+
+
+def stat_rows(G, T, pcols, dev, tail):
+    """Statistics rows of one launch: the (G, T, pcols, 2) float64 block rows, followed -- when the launch
+    finalizes its own BatchNorm (``tail``) -- by the level-1 rows of csrc/pf_bn_tail.h.  Returns the view of
+    the block rows (the buffer behind it is what the kernel gets)."""
+    extra = int(_lib.load().pf_bn_tail_rows(int(G), int(T))) if tail else 0
+    buf = torch.empty((G * T + extra, pcols, 2), dtype=torch.float64, device=dev)
+    return buf[:G * T].view(G, T, pcols, 2)
+
+
+def tail_args(jobs, G, T, dev):
+    """ctypes arguments (jobs array, count, ticket pointer) for a producer that finalizes ``jobs`` itself."""
+    if not jobs:
+        return None, 0, None
+    arr = (_lib.BnJob * len(jobs))(*jobs)
+    return arr, len(jobs), _lib.tickets(dev, int(_lib.load().pf_bn_tail_tickets(int(G), int(T))))
+
+
 def pointwise_gemm(X, point_major, ldx, Wt, Y, ldy, G, Ng, K, nc_store, in_affine=None, groups_per_stat=1,
-                   want_stats=False):
+                   want_stats=False, bn_jobs=None):
     """Y[:, :nc_store] = act(X) @ Wt (see pf_pointwise_gemm_f32).  Returns the float64 column partials
-    (G, T, Nc, 2) when ``want_stats``."""
+    (G, T, Nc, 2) when ``want_stats``.  ``bn_jobs`` (bn_job(..., partials=None) entries over the columns of Y):
+    the BatchNorm finalize jobs the launch performs itself (last block done), no separate launch."""
     Nc = Wt.shape[1]
     T = int(_lib.load().pf_gemm_blocks(int(G), int(Ng)))
-    partials = torch.empty((G, T, Nc, 2), dtype=torch.float64, device=Wt.device) if want_stats else None
+    partials = stat_rows(G, T, Nc, Wt.device, bool(bn_jobs)) if (want_stats or bn_jobs) else None
     sc, sh = in_affine if in_affine is not None else (None, None)
+    jobs, njobs, tk = tail_args(bn_jobs, G, T, Wt.device)
     _lib.call("pf_pointwise_gemm_f32",
               _lib.ptr(X), int(bool(point_major)), int(ldx), _lib.ptr(Wt), _lib.ptr(Y), int(ldy), int(G), int(Ng),
               int(K), int(Nc), int(nc_store), _lib.ptr(sc), _lib.ptr(sh), int(groups_per_stat), _lib.ptr(partials),
-              _lib.stream(), algo_bytes=4.0 * G * Ng * (K + nc_store) + 4.0 * K * Nc,
+              jobs, njobs, tk, _lib.stream(), algo_bytes=4.0 * G * Ng * (K + nc_store) + 4.0 * K * Nc,
               flops=2.0 * G * Ng * K * nc_store)
     return partials
 
@@ -80,7 +106,8 @@ def bn_job(bn, partials, col0, C, count, unbias_n, G, groups_per_stat, scale, sh
     module's channels (EdgeConv's BN covers [central | difference])."""
     if bn.momentum is None:
         raise NotImplementedError("cumulative-average BatchNorm momentum is not supported")
-    T, pcols = partials.shape[1], partials.shape[2]
+    # partials None: a job for a producer's own tail (the call fills partials / T / pcols / G in)
+    T, pcols = (partials.shape[1], partials.shape[2]) if partials is not None else (0, 0)
     track = bn.track_running_stats and bn.running_mean is not None
     dp = lambda t: None if t is None else t.data_ptr()   # noqa: E731
     rm = bn.running_mean[ch0:ch0 + C] if track else None
@@ -102,8 +129,6 @@ def bn_affine(bn, partials, col0, C, count, unbias_n, G, groups_per_stat, scale,
     """A single finalize job (see bn_job)."""
     bn_finalize_jobs([bn_job(bn, partials, col0, C, count, unbias_n, G, groups_per_stat, scale, shift, ch0)])
 
-
-import os as _os
 
 # Concurrency level (PF_CONCURRENCY): 0 = single stream; 1 = flow tower beside the coarse stage;
 # 2 = + lattice kNN beside the first EdgeConv GEMM; 3 = + conv0_1 beside the VolumeConv encoder/decoder.
@@ -243,7 +268,18 @@ def pack_conv2d_small_weight(weight):
     return wp
 
 
-def conv2d_small(x, conv, in_affine, samples_per_stat, want_stats):
+def _conv_bn_tail(bn, N, Cout, S_out, samples_per_stat, dev):
+    """(jobs, (scale, shift)) for a tower convolution that finalizes its own train-mode BatchNorm."""
+    G = N // samples_per_stat
+    scale = torch.empty((G, Cout), dtype=_F32, device=dev)
+    shift = torch.empty((G, Cout), dtype=_F32, device=dev)
+    n = float(samples_per_stat) * S_out
+    job = bn_job(bn, None, 0, Cout, n, n, N, samples_per_stat, scale, shift)
+    bump_counter(bn, G)
+    return [job], (scale, shift)
+
+
+def conv2d_small(x, conv, in_affine, samples_per_stat, want_stats, bn=None):
     """Few-channel tower convolution (pf_conv2d_small_f32); same contract as conv2d()."""
     N, Cin, Hi, Wi = x.shape
     Cout = conv.out_channels
@@ -251,16 +287,20 @@ def conv2d_small(x, conv, in_affine, samples_per_stat, want_stats):
     Ho, Wo = (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
     wp = pack_conv2d_small_weight(conv.weight)
     y = torch.empty((N, Cout, Ho, Wo), dtype=_F32, device=x.device)
-    partials = None
-    if want_stats:
-        T = int(_lib.load().pf_conv2d_small_blocks(N, Hi, Wi, ks, stride))
-        partials = torch.empty((N, T, Cout, 2), dtype=torch.float64, device=x.device)
+    partials, jobs, affine = None, None, None
+    T = int(_lib.load().pf_conv2d_small_blocks(N, Hi, Wi, ks, stride))
+    if bn is not None:
+        jobs, affine = _conv_bn_tail(bn, N, Cout, Ho * Wo, samples_per_stat, x.device)
+    if want_stats or jobs:
+        partials = stat_rows(N, T, Cout, x.device, bool(jobs))
     sc, sh = in_affine if in_affine is not None else (None, None)
+    jarr, njobs, tk = tail_args(jobs, N, T, x.device)
     _lib.call("pf_conv2d_small_f32", _lib.ptr(x), _lib.ptr(wp), _lib.ptr(y), N, Cin, Cout, Hi, Wi, int(ks),
-              int(stride), _lib.ptr(sc), _lib.ptr(sh), int(samples_per_stat), _lib.ptr(partials), _lib.stream(),
+              int(stride), _lib.ptr(sc), _lib.ptr(sh), int(samples_per_stat), _lib.ptr(partials), jarr, njobs, tk,
+              _lib.stream(),
               algo_bytes=4.0 * N * (Cin * Hi * Wi + Cout * Ho * Wo) + 4.0 * ks * ks * Cin * Cout,
               flops=2.0 * N * Ho * Wo * ks * ks * Cin * Cout)
-    return y, partials
+    return (y, partials) if bn is None else (y, partials, affine)
 
 
 def _conv2d_ncp(cout):
@@ -289,25 +329,30 @@ def pack_conv2d_weight(weight):
     return wp
 
 
-def conv2d(x, conv, in_affine, samples_per_stat, want_stats):
+def conv2d(x, conv, in_affine, samples_per_stat, want_stats, bn=None):
     """One feature-tower convolution (pf_conv2d_f32).  ``in_affine`` = (scale, shift) rows (N/sps, Cin) of a
-    pending BatchNorm+ReLU to apply while staging x, or None.  Returns (raw y, statistics partials or None)."""
+    pending BatchNorm+ReLU to apply while staging x, or None.  Returns (raw y, statistics partials or None);
+    with ``bn`` (a train-mode BatchNorm module) the launch also finalizes that BatchNorm itself (last block
+    done, csrc/pf_bn_tail.h) and (y, partials, (scale, shift)) is returned."""
     N, Cin, Hi, Wi = x.shape
     Cout = conv.out_channels
     ks, stride = conv.kernel_size[0], conv.stride[0]
     Ho, Wo = (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
     wp = pack_conv2d_weight(conv.weight)
     y = torch.empty((N, Cout, Ho, Wo), dtype=_F32, device=x.device)
-    partials = None
-    if want_stats:
-        T = int(_lib.load().pf_conv2d_blocks(N, Cout, Hi, Wi, ks, stride))
-        partials = torch.empty((N, T, Cout, 2), dtype=torch.float64, device=x.device)
+    partials, jobs, affine = None, None, None
+    T = int(_lib.load().pf_conv2d_blocks(N, Cout, Hi, Wi, ks, stride))
+    if bn is not None:
+        jobs, affine = _conv_bn_tail(bn, N, Cout, Ho * Wo, samples_per_stat, x.device)
+    if want_stats or jobs:
+        partials = stat_rows(N, T, Cout, x.device, bool(jobs))
     sc, sh = in_affine if in_affine is not None else (None, None)
+    jarr, njobs, tk = tail_args(jobs, N, T, x.device)
     _lib.call("pf_conv2d_f32", _lib.ptr(x), _lib.ptr(wp), _lib.ptr(y), N, Cin, Cout, Hi, Wi, int(ks), int(stride),
-              _lib.ptr(sc), _lib.ptr(sh), int(samples_per_stat), _lib.ptr(partials), _lib.stream(),
+              _lib.ptr(sc), _lib.ptr(sh), int(samples_per_stat), _lib.ptr(partials), jarr, njobs, tk, _lib.stream(),
               algo_bytes=4.0 * N * (Cin * Hi * Wi + Cout * Ho * Wo) + 4.0 * ks * ks * Cin * Cout,
               flops=2.0 * N * Ho * Wo * ks * ks * Cin * Cout)
-    return y, partials
+    return (y, partials) if bn is None else (y, partials, affine)
 
 
 def channel_affine_(x, affine, relu, samples_per_stat):
@@ -454,17 +499,26 @@ def edge_conv_fused(X, point_major, ldx, K, G, Ng, idx, conv1_w, conv2_w, bn, co
     cbn = 2 * C if concat else C
     scale = torch.empty((S, cbn), dtype=_F32, device=dev)
     shift = torch.empty((S, cbn), dtype=_F32, device=dev)
-    part_l = pointwise_gemm(X, point_major, ldx, Wt, LE, 2 * C, G, Ng, K, 2 * C,
-                            groups_per_stat=groups_per_stat, want_stats=(concat and training))
+    n_pairs = float(groups_per_stat) * Ng * k
+    fused = bool(FUSED_BN) and training and 2 * C <= 128          # rows of 8..128 columns (pf_bn_tail.h)
+    central = [bn_job(bn, None, 0, C, float(groups_per_stat) * Ng, n_pairs, G, groups_per_stat, scale, shift)] \
+        if (fused and concat) else None
+    part_l = pointwise_gemm(X, point_major, ldx, Wt, LE, 2 * C, G, Ng, K, 2 * C, groups_per_stat=groups_per_stat,
+                            want_stats=(concat and training), bn_jobs=central)
     if join is not None:                      # ``idx`` was produced on another stream (flow_chain)
         torch.cuda.current_stream().wait_stream(join)
     if training:
         T = stat_blocks(G, Ng)
-        part_d = torch.empty((G, T, C, 2), dtype=torch.float64, device=dev)
+        part_d = stat_rows(G, T, C, dev, fused)
+        doff = C if concat else 0
+        diff = [bn_job(bn, None, 0, C, n_pairs, n_pairs, G, groups_per_stat, scale[:, doff:], shift[:, doff:],
+                       ch0=doff)] if fused else None
+        jarr, njobs, tk = tail_args(diff, G, T, dev)
         _lib.call("pf_edge_stats_f32", _lib.ptr(LE), 2 * C, C, _lib.ptr(idx), k, G, Ng, _lib.ptr(part_d),
-                  _lib.stream(), algo_bytes=float(G) * Ng * (4.0 * C + 8.0 * k + 4.0 * C * k))
-        n_pairs = float(groups_per_stat) * Ng * k
-        if concat:
+                  jarr, njobs, tk, _lib.stream(), algo_bytes=float(G) * Ng * (4.0 * C + 8.0 * k + 4.0 * C * k))
+        if fused:
+            pass                              # both halves were finalized by their producers
+        elif concat:
             bn_finalize_jobs([
                 bn_job(bn, part_l, 0, C, float(groups_per_stat) * Ng, n_pairs, G, groups_per_stat, scale, shift),
                 bn_job(bn, part_d, 0, C, n_pairs, n_pairs, G, groups_per_stat, scale[:, C:], shift[:, C:], ch0=C)])
@@ -543,10 +597,12 @@ def flow_features(levels, depth, interval, cam, h, w, ratio):
     return feature, xyz
 
 
-def flow_chain(feature, xyz, depth, interval, h, w, ratio, edge_convs, flow_mlp, k=16, point_major=True):
+def flow_chain(feature, xyz, depth, interval, h, w, ratio, edge_convs, flow_mlp, k=16, point_major=True, idx=None):
     """Rows K, E0-E2, M, H, T on assembled point features: feature (G,Ng,136) point-major rows (or
     (G,136,Ng) with ``point_major=False``) / xyz (G,3,Ng), points in sub-grid-major order (see
-    flow_features) -> (depth_out (h,w), flow_prob (5,h,w))."""
+    flow_features) -> (depth_out (h,w), flow_prob (5,h,w)).  ``idx`` (G,Ng,k) int64 group-local neighbour
+    indices replaces the lattice kNN of ``xyz`` (stage tests feed the oracle's own indices so that the
+    EdgeConv / MLP / head chain is compared on identical neighbour sets)."""
     dev = depth.device
     if point_major:
         G, Ng, Cin = feature.shape
@@ -555,7 +611,11 @@ def flow_chain(feature, xyz, depth, interval, h, w, ratio, edge_convs, flow_mlp,
     hs, ws = h // ratio, w // ratio
     # the lattice kNN needs only xyz; the first EdgeConv GEMM needs only the features: run them concurrently
     aux = None
-    if CONCURRENCY >= 2:
+    if idx is not None:
+        if tuple(idx.shape) != (G, Ng, k) or idx.dtype != torch.int64:
+            raise RuntimeError("flow_chain: idx must be int64 (G, Ng, k)")
+        idx = idx.contiguous()
+    elif CONCURRENCY >= 2:
         main = torch.cuda.current_stream()
         aux = side_stream(dev, 1)
         aux.wait_stream(main)
@@ -587,8 +647,18 @@ def flow_chain(feature, xyz, depth, interval, h, w, ratio, edge_convs, flow_mlp,
     for layer in shared:
         Wt, cout = pack_weight_t(layer.conv.weight)
         Z = torch.empty((G * Ng, cout), dtype=_F32, device=dev)
-        part = pointwise_gemm(X, True, ldx, Wt, Z, cout, G, Ng, K, cout, in_affine=affine, want_stats=True)
-        affine = _bn_affine_from_gemm(layer.bn, part, cout, G, Ng, 1, dev)
+        bn = layer.bn
+        training = bn.training or not bn.track_running_stats
+        if FUSED_BN and training:
+            scale = torch.empty((G, cout), dtype=_F32, device=dev)
+            shift = torch.empty((G, cout), dtype=_F32, device=dev)
+            job = bn_job(bn, None, 0, cout, float(Ng), float(Ng), G, 1, scale, shift)
+            pointwise_gemm(X, True, ldx, Wt, Z, cout, G, Ng, K, cout, in_affine=affine, bn_jobs=[job])
+            bump_counter(bn, G)
+            affine = (scale, shift)
+        else:
+            part = pointwise_gemm(X, True, ldx, Wt, Z, cout, G, Ng, K, cout, in_affine=affine, want_stats=True)
+            affine = _bn_affine_from_gemm(bn, part, cout, G, Ng, 1, dev)
         X, ldx, K = Z, cout, cout
     if K != 16 or last.weight.shape[0] != 1:
         raise NotImplementedError("flow head kernel is built for the reference widths (..., 16, 1)")

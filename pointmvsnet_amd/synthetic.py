@@ -33,6 +33,9 @@ CONFIGS = {
     # small legal shapes for fast parity tests (not BASELINE configs)
     "tiny": (128, 192, 3, 8, 4.24, (0.125, 0.25), (1.0, 0.75)),
     "small": (256, 320, 3, 16, 4.24, (0.125, 0.25, 0.5), (1.0, 0.75, 0.15)),
+    # BASELINE config 5's shape class at a size the CPU reference finishes in seconds: 7 views, 3 iterations
+    # including the 16-sub-grid scale 0.5 (golden: tests/golden/model_cfg5r_test.npz)
+    "cfg5r": (256, 320, 7, 16, 2.13, (0.125, 0.25, 0.5), (1.0, 0.75, 0.15)),
 }
 
 

@@ -1,0 +1,83 @@
+"""Measure the reference algorithm's OWN sensitivity to a 1-ulp perturbation of its coarse depth map.
+
+    python tests/golden/make_envelope.py [cfg ...]        # writes tests/golden/sensitivity_envelope.json
+
+PointFlow is discontinuous in its input: a nearly-tied kNN choice flips under a 1-ulp change of a point
+coordinate, and BatchNorm batch statistics couple every point to every other.  An implementation whose 3D
+convolutions accumulate in a different (legal) order than ATen's CPU kernels therefore cannot match the
+reference's refined depth maps in the max norm -- the reference does not match ITSELF under that change.
+This script quantifies it per configuration: the coarse depth of the oracle (bit-identical to the
+reference, tests/test_oracle_golden.py) is multiplied by (1 + 4e-7 * N(0,1)) -- the size of one float32
+rounding at these magnitudes -- for several noise seeds, and for every refined map the worst median, max
+and fraction of pixels moving by more than 1e-4 relative are recorded.  tests/test_gpu_model.py bounds the
+GPU-vs-golden deviation by THIS envelope (at most twice the reference's self-deviation fraction) instead of
+by a constant; tests/test_sensitivity.py re-measures one seed on CPU and checks it lies inside.
+"""
+import json
+import os
+import sys
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import pointflow_oracle as O  # noqa: E402
+from pointmvsnet_amd import synthetic  # noqa: E402
+from pointmvsnet_amd.model import PointMVSNet  # noqa: E402
+
+SEEDS = (1, 2, 3)
+EPS = 4e-7
+OUT = os.path.join(HERE, "sensitivity_envelope.json")
+
+
+def perturbed_forward(sd, data, scales, inters, seed, train_intrinsics=False):
+    orig = O.soft_argmin
+
+    def soft_argmin(*a, **k):
+        d, p = orig(*a, **k)
+        g = torch.Generator().manual_seed(seed)
+        return d * (1 + EPS * torch.randn(d.shape, generator=g)), p
+
+    O.soft_argmin = soft_argmin
+    try:
+        with torch.no_grad():
+            return O.forward(sd, data, scales, inters, True, not train_intrinsics)
+    finally:
+        O.soft_argmin = orig
+
+
+def measure(cfg, seeds=SEEDS, train_intrinsics=False):
+    net = PointMVSNet()
+    synthetic.seed_weights(net, 0)
+    sd = net.state_dict()
+    data, scales, inters = synthetic.make_config(cfg, train_intrinsics=train_intrinsics)
+    with torch.no_grad():
+        base = O.forward(sd, data, scales, inters, True, not train_intrinsics)
+    env = {}
+    for seed in seeds:
+        pert = perturbed_forward(sd, data, scales, inters, seed, train_intrinsics)
+        for it in range(1, len(scales) + 1):
+            key = "flow%d" % it
+            rel = (pert[key] - base[key]).abs() / base[key].abs()
+            cur = {"median": float(rel.median()), "max": float(rel.max()),
+                   "frac_gt_1e4": float((rel > 1e-4).float().mean())}
+            old = env.get(key)
+            env[key] = cur if old is None else {k: max(old[k], cur[k]) for k in cur}
+    return env
+
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or ["tiny", "small", "cfg5r", "cfg1", "cfg2", "cfg3"]
+    table = json.load(open(OUT)) if os.path.exists(OUT) else {}
+    for name in names:
+        seeds = SEEDS if name != "cfg3" else SEEDS[:1]        # cfg3: one minute per forward on 8 cores
+        table[name] = dict(measure(name, seeds), seeds=list(seeds), eps=EPS)
+        print(name, json.dumps(table[name]))
+        if name == "tiny":
+            table["tiny_train"] = dict(measure(name, seeds, train_intrinsics=True), seeds=list(seeds), eps=EPS)
+            print("tiny_train", json.dumps(table["tiny_train"]))
+    with open(OUT, "w") as f:
+        json.dump(table, f, indent=1, sort_keys=True)
+    print("wrote", OUT)
