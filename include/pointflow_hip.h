@@ -85,8 +85,9 @@ int pf_gather_knn_backward_f64(const double* grad_out, const int64_t* index, dou
  * model.py:251-252 need no copy.  Candidates are the kernel_size^3 window, zero outside the lattice;
  * d2 = (dx*dx + dy*dy) + dz*dz in float32 without contraction; ranking: smaller d2 first, ties by
  * smaller candidate code (the reference's tie order is unspecified).
- *   idx_out  (B, D*H*W, knn) int64: n + offsets, one global clamp to [0, DHW-1] (torch_utils.py:55-59)
- *   code_out (B, D*H*W, knn) uint8 or NULL: the window candidate code of each pick (kernel_size<=5)
+ *   idx_out  (B, D*H*W, knn) int64 or NULL: n + offsets, one global clamp to [0, DHW-1] (torch_utils.py:55-59)
+ *   code_out (B, D*H*W, knn) uint8 or NULL: the window candidate code of each pick (kernel_size<=5);
+ *            at least one of the two must be given
  * Limits: kernel_size odd, <= 7; knn <= min(32, kernel_size^3). */
 int pf_knn_lattice_f32(const float* xyz, const int64_t* strides_host, int64_t B, int64_t D, int64_t H,
                        int64_t W, int kernel_size, int knn, int64_t* idx_out, uint8_t* code_out,
@@ -121,6 +122,15 @@ int pf_fetch_variance_f32(const float* maps, const float* pts, const float* K, c
 int pf_frustum_variance_f32(const float* maps, const float* kinv, const float* rinv, const float* t,
                             const float* depths, const float* K, const float* E, float* out, float* world,
                             int64_t B, int64_t V, int64_t C, int64_t H, int64_t W, int64_t D, void* stream);
+
+/* The same on CHANNEL-LAST maps (B, V, H, W, C), C % 4 == 0 (pf_nchw_to_nhwc_f32 converts; a convolution may
+ * also write that layout directly): 16 lanes per point read every bilinear tap as one contiguous C-float run,
+ * the (C, D*H*W) volume is written in 256-byte rows through an LDS transpose.  Bit-identical results. */
+int pf_frustum_variance_cl_f32(const float* maps_cl, const float* kinv, const float* rinv, const float* t,
+                               const float* depths, const float* K, const float* E, float* out, float* world,
+                               int64_t B, int64_t V, int64_t C, int64_t H, int64_t W, int64_t D, void* stream);
+/* in (P, C, S) -> out (P, S, C): planar to channel-last for P images of S pixels. */
+int pf_nchw_to_nhwc_f32(const float* in, float* out, int64_t P, int64_t C, int64_t S, void* stream);
 
 /* ---- bilinear resize (align_corners = False), the F.interpolate of model.py:184 -------------
  * in (P, IH, IW) -> out (P, OH, OW). */
@@ -214,10 +224,16 @@ int pf_pointwise_gemm_f32(const float* X, int x_point_major, int64_t ldx, const 
 
 /* Pass A of EdgeConv: for rows LE = [l (C) | e (C)] (point-major, ldle floats per point) and local
  * neighbour indices idx (G, Ng, k): partial sums over all (point, neighbour) pairs of
- * d = e[idx] - l and d*d per channel -> partials (G, T, C, 2) float64.   C in {32, 64, 128}. */
+ * d = e[idx] - l and d*d per channel -> partials (G, T, C, 2) float64.   C in {32, 64, 128}.
+ * Neighbourhood, two forms (both passes): `idx` (G, Ng, k) int64 group-local indices -- the reference's
+ * tensor (functions/gather_knn.py:10-24) -- or, when `codes` != NULL (then idx may be NULL and k must be 16),
+ * the window codes pf_knn_lattice_f32 wrote, (G, Ng, 16) uint8: neighbour j of point n is
+ * clamp(n + (pd-hk)*lat_h*lat_w + (ph-hk)*lat_w + (pw-hk), 0, Ng-1) with code = (pd*lat_ks + ph)*lat_ks + pw,
+ * hk = lat_ks/2 -- get_knn_3d's own index arithmetic (utils/torch_utils.py:51-59) done on the fly, so the six
+ * gather passes of a PointFlow iteration read 16 instead of 128 index bytes per point.  lat_ks in {3, 5}. */
 int pf_edge_stats_f32(const float* LE, int64_t ldle, int C, const int64_t* idx, int k, int G, int Ng,
                       double* partials, const pf_bn_job* bn_jobs_host, int n_bn_jobs, unsigned* tickets,
-                      void* stream);
+                      const uint8_t* codes, int lat_ks, int lat_h, int lat_w, void* stream);
 
 
 /* Pass B of EdgeConv (reference networks.py:37-43 / :74-79):
@@ -227,7 +243,8 @@ int pf_edge_stats_f32(const float* LE, int64_t ldle, int C, const int64_t* idx, 
  * scale/shift are (S, ld_affine).  Y is point-major with ldy floats per point. */
 int pf_edge_apply_f32(const float* LE, int64_t ldle, int C, const int64_t* idx, int k, int G, int Ng,
                       const float* scale, const float* shift, int ld_affine, int groups_per_stat,
-                      int concat, float* Y, int64_t ldy, void* stream);
+                      int concat, float* Y, int64_t ldy, const uint8_t* codes, int lat_ks, int lat_h, int lat_w,
+                      void* stream);
 
 /* ---- train-mode BatchNorm for the conv stacks around the path (ImageConv / VolumeConv) ----------
  * x (N, C, S) contiguous (NCHW / NCDHW with S = spatial size).  pf_channel_stats_f32 writes float64

@@ -39,6 +39,8 @@ PROTOTYPES = {
     "pf_fetch_backward_f32": ([_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp], _i),
     "pf_fetch_variance_f32": ([_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i, _vp], _i),
     "pf_frustum_variance_f32": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp], _i),
+    "pf_frustum_variance_cl_f32": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp], _i),
+    "pf_nchw_to_nhwc_f32": ([_vp, _vp, _i64, _i64, _i64, _vp], _i),
     "pf_resize_bilinear_f32": ([_vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp], _i),
     "pf_flow_pyramid_f32": ([_vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp], _i),
     "pf_flow_features_f32": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp], _i),
@@ -64,10 +66,11 @@ PROTOTYPES = {
     "pf_channel_affine_f32": ([_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _vp], _i),
     "pf_channel_bn_apply_f32": ([_vp, _vp, _vp, _i, _i64, _i64, _i64, _i, _d, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp], _i),
     "pf_channel_bn_fused_f32": ([_vp, _vp, _i64, _i64, _i64, _i, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _i, _vp], _i),
-    "pf_edge_stats_f32": ([_vp, _i64, _i, _vp, _i, _i, _i, _vp, ctypes.POINTER(BnJob), _i, _vp, _vp], _i),
+    "pf_edge_stats_f32": ([_vp, _i64, _i, _vp, _i, _i, _i, _vp, ctypes.POINTER(BnJob), _i, _vp,
+                           _vp, _i, _i, _i, _vp], _i),
     "pf_bn_finalize_f32": ([_vp, _i, _i, _i, _i, _d, _d, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _i, _vp], _i),
     "pf_bn_finalize_jobs_f32": ([ctypes.POINTER(BnJob), _i, _vp], _i),
-    "pf_edge_apply_f32": ([_vp, _i64, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _i64, _vp], _i),
+    "pf_edge_apply_f32": ([_vp, _i64, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _i64, _vp, _i, _i, _i, _vp], _i),
     "pf_flow_head_f32": ([_vp, _i64, _vp, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp], _i),
     "pf_softargmin_prob_f32": ([_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp], _i),
 }

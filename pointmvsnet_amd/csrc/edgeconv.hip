@@ -245,14 +245,53 @@ __device__ __forceinline__ void gather_rows(const float* __restrict__ LE, int64_
   }
 }
 
+// The lattice form of the same gather: the neighbours of point n are n + offset(code_j) for the 16 window
+// codes the lattice kNN wrote (16 bytes per point instead of 128 bytes of int64 indices, read by six passes
+// per PointFlow iteration), clamped to the group like get_knn_3d clamps (reference utils/torch_utils.py:55-59).
+// `lut` (LDS) maps a code to its offset (pd-hk)*H*W + (ph-hk)*W + (pw-hk).
+struct Lattice {
+  int ks, H, W;     // window size and lattice plane shape; ks == 0: neighbours come from the int64 index tensor
+};
+
+__device__ __forceinline__ void build_code_lut(int* lut, const Lattice& lat) {
+  const int hk = lat.ks >> 1, k2 = lat.ks * lat.ks;
+  for (int c = threadIdx.x; c < 256; c += blockDim.x) {
+    int off = 0;
+    if (c < k2 * lat.ks) {
+      const int pd = c / k2, rem = c - pd * k2, ph = rem / lat.ks, pw = rem - ph * lat.ks;
+      off = (pd - hk) * lat.H * lat.W + (ph - hk) * lat.W + (pw - hk);
+    }
+    lut[c] = off;
+  }
+  __syncthreads();
+}
+
+template <int C>
+__device__ __forceinline__ void gather_rows_codes(const float* __restrict__ LE, int64_t ldle,
+                                                  const uint8_t* __restrict__ cp, const int* lut, int64_t gbase, int n,
+                                                  int Ng, int q, float4 (&e)[16]) {
+  const uint4 cw = *reinterpret_cast<const uint4*>(cp);
+  const unsigned w[4] = {cw.x, cw.y, cw.z, cw.w};
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int code = (int)((w[j >> 2] >> (8 * (j & 3))) & 255u);
+    int i = n + lut[code];
+    i = i < 0 ? 0 : (i > Ng - 1 ? Ng - 1 : i);
+    e[j] = ld4(LE + (gbase + i) * ldle + C + 4 * q);
+  }
+}
+
 template <int C, int K>   // K == 0: neighbour count known only at run time
 __global__ __launch_bounds__(256) void edge_stats_kernel(const float* __restrict__ LE, int64_t ldle,
                                                          const int64_t* __restrict__ idx, int k, int Ng,
                                                          double* __restrict__ partials, int T,
-                                                         unsigned* __restrict__ status, PfTail tail) {
+                                                         unsigned* __restrict__ status, PfTail tail,
+                                                         const uint8_t* __restrict__ codes, Lattice lat) {
   constexpr int Q = C / 4;         // lanes per point
   constexpr int PPB = 256 / Q;     // points per pass
   __shared__ double red[256 * 8];
+  __shared__ int lut[256];
+  if (K == 16 && codes != nullptr) build_code_lut(lut, lat);
   const int tid = threadIdx.x;
   const int q = tid % Q, pl = tid / Q;
   const int g = blockIdx.y, tb = blockIdx.x;
@@ -271,7 +310,12 @@ __global__ __launch_bounds__(256) void edge_stats_kernel(const float* __restrict
       float4 s = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
       if constexpr (K > 0) {
         float4 e[K > 0 ? K : 1];
-        gather_rows<C, (K > 0 ? K : 2)>(LE, ldle, ip, gbase, Ng, q, e, bad);
+        if constexpr (K == 16) {
+          if (codes != nullptr) gather_rows_codes<C>(LE, ldle, codes + row * 16, lut, gbase, n, Ng, q, e);
+          else gather_rows<C, 16>(LE, ldle, ip, gbase, Ng, q, e, bad);
+        } else {
+          gather_rows<C, (K > 0 ? K : 2)>(LE, ldle, ip, gbase, Ng, q, e, bad);
+        }
 #pragma unroll
         for (int j = 0; j < K; ++j) {
           const float dx = e[j].x - l.x, dy = e[j].y - l.y, dz = e[j].z - l.z, dw = e[j].w - l.w;
@@ -317,9 +361,12 @@ __global__ __launch_bounds__(256) void edge_apply_kernel(const float* __restrict
                                                          const float* __restrict__ scale,
                                                          const float* __restrict__ shift, int ld_affine,
                                                          int groups_per_stat, int concat, float* __restrict__ Y,
-                                                         int64_t ldy, int T) {
+                                                         int64_t ldy, int T, const uint8_t* __restrict__ codes,
+                                                         Lattice lat) {
   constexpr int Q = C / 4;
   constexpr int PPB = 256 / Q;
+  __shared__ int lut[256];
+  if (K == 16 && codes != nullptr) build_code_lut(lut, lat);
   const int tid = threadIdx.x;
   const int q = tid % Q, pl = tid / Q;
   const int g = blockIdx.y, tb = blockIdx.x;
@@ -346,7 +393,12 @@ __global__ __launch_bounds__(256) void edge_apply_kernel(const float* __restrict
       float4 a = {0, 0, 0, 0};
       if constexpr (K > 0) {
         float4 e[K > 0 ? K : 1];
-        gather_rows<C, (K > 0 ? K : 2)>(LE, ldle, ip, gbase, Ng, q, e, bad);
+        if constexpr (K == 16) {
+          if (codes != nullptr) gather_rows_codes<C>(LE, ldle, codes + row * 16, lut, gbase, n, Ng, q, e);
+          else gather_rows<C, 16>(LE, ldle, ip, gbase, Ng, q, e, bad);
+        } else {
+          gather_rows<C, (K > 0 ? K : 2)>(LE, ldle, ip, gbase, Ng, q, e, bad);
+        }
 #pragma unroll
         for (int j = 0; j < K; ++j) {
           a.x += fmaxf(fmaf(e[j].x - l.x, dsc.x, dsh.x), 0.0f);
@@ -613,13 +665,36 @@ int pf_pointwise_gemm_f32(const float* X, int x_point_major, int64_t ldx, const 
   return pf_launch_status();
 }
 
+// `codes` non-NULL selects the lattice form of the neighbourhood (see pf_edge_stats_f32 in the header).
+static int check_lattice(const int64_t* idx, const uint8_t* codes, int k, int Ng, int lat_ks, int lat_h, int lat_w,
+                         Lattice& lat) {
+  lat.ks = 0;
+  lat.H = lat.W = 1;
+  if (codes == nullptr) {
+    PF_REQUIRE(idx != nullptr);
+    return PF_OK;
+  }
+  PF_REQUIRE(k == 16 && (lat_ks == 3 || lat_ks == 5) && lat_h >= 1 && lat_w >= 1);
+  PF_REQUIRE(Ng % (lat_h * lat_w) == 0);
+  lat.ks = lat_ks;
+  lat.H = lat_h;
+  lat.W = lat_w;
+  return PF_OK;
+}
+
 int pf_edge_stats_f32(const float* LE, int64_t ldle, int C, const int64_t* idx, int k, int G, int Ng,
-                      double* partials, const pf_bn_job* bn_jobs, int n_bn_jobs, unsigned* tickets, void* stream) {
+                      double* partials, const pf_bn_job* bn_jobs, int n_bn_jobs, unsigned* tickets,
+                      const uint8_t* codes, int lat_ks, int lat_h, int lat_w, void* stream) {
   PF_REQUIRE(n_bn_jobs >= 0);
   PF_REQUIRE(G >= 0 && Ng >= 0 && k >= 1 && ldle >= 2 * (int64_t)C && (ldle % 4) == 0 && G <= 65535);
   if (C != 32 && C != 64 && C != 128) return PF_ERR_UNSUPPORTED;
   if (G == 0 || Ng == 0) return PF_OK;
-  PF_REQUIRE(LE && idx && partials);
+  PF_REQUIRE(LE && partials);
+  Lattice lat;
+  {
+    const int rc = check_lattice(idx, codes, k, Ng, lat_ks, lat_h, lat_w, lat);
+    if (rc != PF_OK) return rc;
+  }
   unsigned* status = pf_status_ptr();
   PF_REQUIRE(status != nullptr);
   const int T = pf_stat_blocks(G, Ng);
@@ -630,7 +705,7 @@ int pf_edge_stats_f32(const float* LE, int64_t ldle, int C, const int64_t* idx, 
   }
   dim3 grid((unsigned)T, (unsigned)G);
   hipStream_t s = (hipStream_t)stream;
-#define PF_ES(CV, KV) hipLaunchKernelGGL((edge_stats_kernel<CV, KV>), grid, dim3(256), 0, s, LE, ldle, idx, k, Ng, partials, T, status, tail)
+#define PF_ES(CV, KV) hipLaunchKernelGGL((edge_stats_kernel<CV, KV>), grid, dim3(256), 0, s, LE, ldle, idx, k, Ng, partials, T, status, tail, codes, lat)
   if (k == 16) {
     if (C == 32) PF_ES(32, 16); else if (C == 64) PF_ES(64, 16); else PF_ES(128, 16);
   } else {
@@ -687,19 +762,24 @@ int pf_bn_finalize_f32(const double* partials, int T, int pcols, int col0, int C
 
 int pf_edge_apply_f32(const float* LE, int64_t ldle, int C, const int64_t* idx, int k, int G, int Ng,
                       const float* scale, const float* shift, int ld_affine, int groups_per_stat, int concat,
-                      float* Y, int64_t ldy, void* stream) {
+                      float* Y, int64_t ldy, const uint8_t* codes, int lat_ks, int lat_h, int lat_w, void* stream) {
   PF_REQUIRE(G >= 0 && Ng >= 0 && k >= 1 && ldle >= 2 * (int64_t)C && (ldle % 4) == 0 && G <= 65535);
   PF_REQUIRE(groups_per_stat >= 1 && (ldy % 4) == 0 && ldy >= (concat ? 2 : 1) * (int64_t)C);
   PF_REQUIRE((ld_affine % 4) == 0 && ld_affine >= (concat ? 2 : 1) * C);
   if (C != 32 && C != 64 && C != 128) return PF_ERR_UNSUPPORTED;
   if (G == 0 || Ng == 0) return PF_OK;
-  PF_REQUIRE(LE && idx && scale && shift && Y);
+  PF_REQUIRE(LE && scale && shift && Y);
+  Lattice lat;
+  {
+    const int rc = check_lattice(idx, codes, k, Ng, lat_ks, lat_h, lat_w, lat);
+    if (rc != PF_OK) return rc;
+  }
   const int T = pf_stat_blocks(G, Ng);
   dim3 grid((unsigned)T, (unsigned)G);
   hipStream_t s = (hipStream_t)stream;
 #define PF_EA(CV, KV)                                                                                         \
   hipLaunchKernelGGL((edge_apply_kernel<CV, KV>), grid, dim3(256), 0, s, LE, ldle, idx, k, Ng, scale, shift, \
-                     ld_affine, groups_per_stat, concat, Y, ldy, T)
+                     ld_affine, groups_per_stat, concat, Y, ldy, T, codes, lat)
   if (k == 16) {
     if (C == 32) PF_EA(32, 16); else if (C == 64) PF_EA(64, 16); else PF_EA(128, 16);
   } else {

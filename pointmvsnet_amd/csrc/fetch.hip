@@ -151,6 +151,122 @@ __global__ __launch_bounds__(256) void fetch_variance_kernel(const float* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
+// W+V for the coarse cost volume, channel-last maps (reference model.py:79-111)
+// ------------------------------------------------------------------------------------------------
+// fetch_variance_kernel above walks the channels of NCHW maps with one lane per point: 4 scattered 4-byte
+// loads per (channel, view), 64 channels in sequence -- latency-bound at 16 % of the HBM roof on the write of
+// the cost volume (53 us for 70 MB at BASELINE config 2).  Here the maps are channel-last (B,V,H,W,C) and 16
+// lanes share a point, lane q owning channels [4q, 4q+4) of a 64-channel pass: a bilinear tap is one 256-byte
+// contiguous read per point, all V*4 taps of a point are in flight together, and there is no loop over
+// channels.  A block owns 64 consecutive points (consecutive x of one cost-volume row, so their taps are
+// neighbouring texels that stay in L1 between the four 16-point passes); the 64 x C variances are transposed
+// through LDS so that every channel row leaves as a 256-byte segment of the (C, D*H*W) volume.
+// Arithmetic per channel is that of fetch_variance_kernel (pf_sample's expression, sums in view order):
+// the two kernels are bit-identical (tests/test_gpu_ops.py).
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                           int C, int64_t S) {
+  __shared__ float tile[64][65];
+  const int64_t p = blockIdx.z;
+  const int64_t s0 = (int64_t)blockIdx.x * 64;
+  const int c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4) {
+    const int c = c0 + r;
+    const int64_t s = s0 + tx;
+    tile[r][tx] = (c < C && s < S) ? in[(p * C + c) * S + s] : 0.0f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 64; r += 4) {
+    const int64_t s = s0 + r;
+    const int c = c0 + tx;
+    if (s < S && c < C) out[(p * S + s) * C + c] = tile[tx][r];
+  }
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void frustum_variance_cl_kernel(const float* __restrict__ maps, Frustum fr,
+                                                                  const float* __restrict__ Kmat,
+                                                                  const float* __restrict__ Emat,
+                                                                  float* __restrict__ out, int C, int H, int W,
+                                                                  int64_t N) {
+  constexpr int PTS = 64;
+  __shared__ float tile[64 + 3][PTS + 1];
+  const int q = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  const int64_t b = blockIdx.y;
+  const int64_t n0 = (int64_t)blockIdx.x * PTS;
+  const int hw = H * W;
+  const float* ki = fr.kinv + b * 9;
+  const float* ri = fr.rinv + b * 9;
+  const float* tt = fr.t + b * 3;
+  const float* mb = maps + b * V * (int64_t)hw * C;
+  for (int c0 = 0; c0 < C; c0 += 64) {
+#pragma unroll 1
+    for (int pass = 0; pass < PTS / 16; ++pass) {
+      const int p = pass * 16 + pl;
+      int64_t n = n0 + p;
+      n = n < N ? n : N - 1;                               // lanes past the end shadow the last point
+      const int d = (int)(n / hw);
+      const int pix = (int)(n - (int64_t)d * hw);
+      const int py = pix / W, px = pix - py * W;
+      const float gx = (float)px + 0.5f, gy = (float)py + 0.5f;
+      const float depth = fr.depths[b * fr.D + d];
+      const float u0 = fmaf(ki[2], 1.0f, fmaf(ki[1], gy, ki[0] * gx));
+      const float u1 = fmaf(ki[5], 1.0f, fmaf(ki[4], gy, ki[3] * gx));
+      const float u2 = fmaf(ki[8], 1.0f, fmaf(ki[7], gy, ki[6] * gx));
+      const float q0 = u0 * depth - tt[0], q1 = u1 * depth - tt[1], q2 = u2 * depth - tt[2];
+      const float X = fmaf(ri[2], q2, fmaf(ri[1], q1, ri[0] * q0));
+      const float Y = fmaf(ri[5], q2, fmaf(ri[4], q1, ri[3] * q0));
+      const float Z = fmaf(ri[8], q2, fmaf(ri[7], q1, ri[6] * q0));
+      if (c0 == 0 && q < 3) tile[64 + q][p] = q == 0 ? X : (q == 1 ? Y : Z);
+      PfTaps t[V];
+#pragma unroll
+      for (int v = 1; v < V; ++v)
+        pf_project_taps(X, Y, Z, Kmat + (b * V + v) * 9, Emat ? Emat + (b * V + v) * 12 : nullptr, H, W, t[v]);
+      const int c = c0 + 4 * q;
+      if (c < C) {
+        // view 0 contributes its un-warped feature (model.py:103-106)
+        const float4 r0 = *reinterpret_cast<const float4*>(mb + (int64_t)pix * C + c);
+        float s[4] = {r0.x, r0.y, r0.z, r0.w};
+        float s2[4] = {r0.x * r0.x, r0.y * r0.y, r0.z * r0.z, r0.w * r0.w};
+#pragma unroll
+        for (int v = 1; v < V; ++v) {
+          const float* mv = mb + (int64_t)v * hw * C + c;
+          const float4 a = *reinterpret_cast<const float4*>(mv + (int64_t)t[v].off[0] * C);
+          const float4 bb = *reinterpret_cast<const float4*>(mv + (int64_t)t[v].off[1] * C);
+          const float4 cc = *reinterpret_cast<const float4*>(mv + (int64_t)t[v].off[2] * C);
+          const float4 dd = *reinterpret_cast<const float4*>(mv + (int64_t)t[v].off[3] * C);
+          const float w0 = t[v].wgt[0], w1 = t[v].wgt[1], w2 = t[v].wgt[2], w3 = t[v].wgt[3];
+          const float f[4] = {((a.x * w0 + bb.x * w1) + cc.x * w2) + dd.x * w3,
+                              ((a.y * w0 + bb.y * w1) + cc.y * w2) + dd.y * w3,
+                              ((a.z * w0 + bb.z * w1) + cc.z * w2) + dd.z * w3,
+                              ((a.w * w0 + bb.w * w1) + cc.w * w2) + dd.w * w3};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            s[i] = s[i] + f[i];
+            s2[i] = s2[i] + f[i] * f[i];
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float m1 = s[i] / (float)V;
+          const float m2 = s2[i] / (float)V;
+          tile[4 * q + i][p] = m2 - m1 * m1;
+        }
+      }
+    }
+    __syncthreads();
+    // rows of the tile -> 256-byte segments of the (C, N) volume; plus the three rows of world points once
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const bool inb = n0 + tx < N;
+    const int rows = min(64, C - c0);
+    for (int r = ty; r < rows; r += 4)
+      if (inb) out[(b * C + c0 + r) * N + n0 + tx] = tile[r][tx];
+    if (c0 == 0 && fr.world != nullptr && ty < 3 && inb) fr.world[(b * 3 + ty) * N + n0 + tx] = tile[64 + ty][tx];
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // bilinear resize, align_corners=False (F.interpolate at reference model.py:184)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void resize_axis(int o, float scale, int in_size, int& i0, int& i1, float& l0,
@@ -527,6 +643,41 @@ int pf_frustum_variance_f32(const float* maps, const float* kinv, const float* r
     constexpr int VV = decltype(vtag)::value;
     hipLaunchKernelGGL((fetch_variance_kernel<VV, true>), grid, dim3(256), 0, (hipStream_t)stream, maps, nullptr, fr,
                        K, E, out, (int)C, (int)H, (int)W, N, 1);
+    return pf_launch_status();
+  });
+}
+
+int pf_nchw_to_nhwc_f32(const float* in, float* out, int64_t P, int64_t C, int64_t S, void* stream) {
+  PF_REQUIRE(P >= 0 && C >= 1 && S >= 1 && P <= 65535 && C <= INT32_MAX && pf_cdiv(C, 64) <= 65535);
+  if (P == 0) return PF_OK;
+  PF_REQUIRE(in && out);
+  dim3 grid((unsigned)pf_cdiv(S, 64), (unsigned)pf_cdiv(C, 64), (unsigned)P);
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, out, (int)C, S);
+  return pf_launch_status();
+}
+
+int pf_frustum_variance_cl_f32(const float* maps_cl, const float* kinv, const float* rinv, const float* t,
+                               const float* depths, const float* K, const float* E, float* out, float* world,
+                               int64_t B, int64_t V, int64_t C, int64_t H, int64_t W, int64_t D, void* stream) {
+  PF_REQUIRE(B >= 0 && V >= 1 && C >= 0 && H >= 1 && W >= 1 && D >= 0);
+  PF_REQUIRE(B <= 65535 && H * W <= INT32_MAX && C <= INT32_MAX && D <= INT32_MAX);
+  if (V > PF_MAX_VIEWS || (C % 4) != 0) return PF_ERR_UNSUPPORTED;
+  const int64_t N = D * H * W;
+  if (B == 0 || N == 0 || C == 0) return PF_OK;
+  PF_REQUIRE(maps_cl && kinv && rinv && t && depths && K && out);
+  PF_REQUIRE(H * W * C <= (int64_t)INT32_MAX * 4);
+  Frustum fr;
+  fr.kinv = kinv;
+  fr.rinv = rinv;
+  fr.t = t;
+  fr.depths = depths;
+  fr.world = world;
+  fr.D = (int)D;
+  dim3 grid((unsigned)pf_cdiv(N, 64), (unsigned)B);
+  return dispatch_views((int)V, [&](auto vtag) {
+    constexpr int VV = decltype(vtag)::value;
+    hipLaunchKernelGGL((frustum_variance_cl_kernel<VV>), grid, dim3(256), 0, (hipStream_t)stream, maps_cl, fr, K, E,
+                       out, (int)C, (int)H, (int)W, N);
     return pf_launch_status();
   });
 }

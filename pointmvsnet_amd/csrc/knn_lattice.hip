@@ -11,6 +11,8 @@
 // Ranking: smaller d2 first, ties by smaller candidate code (the reference's tie order is unspecified,
 // SURVEY.md F10).  The top list is a sorted register array updated by one compare-exchange pass per
 // accepted candidate; everything is unrolled so nothing spills to scratch.
+#include <stdlib.h>
+
 #include <utility>
 
 #include "pf_common.h"
@@ -258,6 +260,186 @@ __global__ __launch_bounds__(256) void knn_lattice_split_kernel(const float* __r
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Sorting-network variant (window 3 or 5, knn <= 16): the path the PointFlow stage uses.
+//
+// The insertion lists above are data dependent: a wave executes the 16-deep insert whenever ANY of its 64
+// lanes accepts a candidate, i.e. for nearly all 125 candidates (68.7 us on the 102 400-point lattice of
+// BASELINE config 2, 2.6 % of the HBM roof for 14 MB of traffic).  Here a lane ranks its candidates with
+// branch-free compare-exchange networks on 64-bit keys (float bits of d2 << 32 | window code): d2 >= 0, so
+// the unsigned order of the bits is the order of the floats, and the code in the low word resolves equal
+// distances towards the smaller code -- exactly the (d2, code) order of the kernels above and of the NumPy
+// brute force.  The keys are held as DOUBLES with those bits: for sign-bit-clear, non-NaN patterns (the
+// float exponent lands in the double's exponent field below 0x7ff; d2 = 0 gives a denormal, and f64
+// denormals are not flushed) the double order IS the unsigned order, and a compare-exchange is then
+// v_min_f64 + v_max_f64 -- two instructions instead of a 64-bit compare and four conditional moves.  Candidates are taken 16 at a time (codes 16g .. 16g+15, every LDS address an immediate):
+// a bitonic sort of the 16 (80 exchanges), then a truncated bitonic merge with the running best 16
+// (min of list i and reversed list 15-i gives the 16 smallest as a bitonic sequence; 4 more stages sort it).
+// ~1000 exchanges of 5 VALU instructions per point, no divergence, nothing in scratch.
+// Outputs: the window codes as 16 bytes per point (what the EdgeConv gather passes consume) and/or the
+// int64 indices of the reference API.
+// ------------------------------------------------------------------------------------------------
+typedef double key64;
+
+__device__ __forceinline__ key64 make_key(float d2, int code) {
+  return __longlong_as_double(((long long)__float_as_uint(d2) << 32) | (long long)code);
+}
+__device__ __forceinline__ unsigned key_code(key64 k) { return (unsigned)__double_as_longlong(k) & 255u; }
+
+// plain v_min_f64 / v_max_f64 (no canonicalisation of the inputs: they are never NaN)
+__device__ __forceinline__ key64 kmin(key64 a, key64 b) {
+  key64 r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ key64 kmax(key64 a, key64 b) {
+  key64 r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ void cmpex(key64& a, key64& b) {   // afterwards a <= b
+  const key64 lo = kmin(a, b), hi = kmax(a, b);
+  a = lo;
+  b = hi;
+}
+
+// ascending bitonic sort of 16 keys (all indices compile-time after unrolling)
+__device__ __forceinline__ void sort16(key64 (&v)[16]) {
+#pragma unroll
+  for (int k = 2; k <= 16; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int l = i ^ j;
+        if (l > i) {
+          if ((i & k) == 0) cmpex(v[i], v[l]);
+          else cmpex(v[l], v[i]);
+        }
+      }
+    }
+  }
+}
+
+// best <- the 16 smallest of (best U v), ascending; both inputs ascending
+__device__ __forceinline__ void merge16(key64 (&best)[16], const key64 (&v)[16]) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    best[i] = kmin(best[i], v[15 - i]);
+  }
+#pragma unroll
+  for (int j = 8; j > 0; j >>= 1) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int l = i ^ j;
+      if (l > i) cmpex(best[i], best[l]);
+    }
+  }
+}
+
+template <int KS, int ROWS>   // block = ROWS x 32 points of one lattice plane, 32*ROWS threads
+__global__ __launch_bounds__(32 * ROWS) void knn_net_kernel(const float* __restrict__ xyz, Strides5 st, int D, int H,
+                                                            int W, int knn, int64_t* __restrict__ idx_out,
+                                                            uint8_t* __restrict__ code_out) {
+  constexpr int HK = KS / 2;
+  constexpr int LW = 32 + 2 * HK, LH = ROWS + 2 * HK;
+  constexpr int PLANE = LH * LW, TOTAL = KS * PLANE;
+  constexpr int K3 = KS * KS * KS;
+  constexpr int GROUPS = (K3 + 15) / 16;
+  __shared__ float lx[TOTAL], ly[TOTAL], lz[TOTAL];
+
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int w0 = blockIdx.x * 32, h0 = blockIdx.y * ROWS;
+  const int b = blockIdx.z / D;
+  const int d = blockIdx.z - b * D;
+
+  for (int e = threadIdx.x; e < TOTAL; e += 32 * ROWS) {
+    const int pl = e / PLANE;
+    const int rem = e - pl * PLANE;
+    const int r = rem / LW;
+    const int cc = rem - r * LW;
+    const int dd = d - HK + pl, hh = h0 - HK + r, ww = w0 - HK + cc;
+    const bool in = (dd >= 0) && (dd < D) && (hh >= 0) && (hh < H) && (ww >= 0) && (ww < W);
+    float vx = 0.0f, vy = 0.0f, vz = 0.0f;
+    if (in) {
+      const int64_t off = b * st.b + dd * st.d + hh * st.h + ww * st.w;
+      vx = xyz[off];
+      vy = xyz[off + st.c];
+      vz = xyz[off + 2 * st.c];
+    }
+    lx[e] = vx;
+    ly[e] = vy;
+    lz[e] = vz;
+  }
+  __syncthreads();
+
+  const int h = h0 + ty, w = w0 + tx;
+  if (h >= H || w >= W) return;
+  const int base = ty * LW + tx;                          // window origin of this lane
+  const int ce = base + (HK * LH + HK) * LW + HK;
+  const float cx = lx[ce], cy = ly[ce], cz = lz[ce];
+
+  key64 best[16];
+#pragma unroll
+  for (int g = 0; g < GROUPS; ++g) {
+    key64 v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int code = 16 * g + i;
+      if (code < K3) {
+        const int pl = code / (KS * KS), r = (code / KS) % KS, cc = code % KS;
+        const int e = base + (pl * LH + r) * LW + cc;
+        const float dx = cx - lx[e];
+        const float dy = cy - ly[e];
+        const float dz = cz - lz[e];
+        const float d2 = (dx * dx + dy * dy) + dz * dz;
+        v[i] = make_key(d2, code);
+      } else {
+        v[i] = make_key(__builtin_huge_valf(), 255);     // past the window: never among the 16 smallest
+      }
+    }
+    sort16(v);
+    if (g == 0) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) best[i] = v[i];
+    } else {
+      merge16(best, v);
+    }
+  }
+
+  const int64_t HW = (int64_t)H * W;
+  const int64_t DHW = HW * D;
+  const int64_t n = (int64_t)d * HW + (int64_t)h * W + w;
+  if (code_out != nullptr) {
+    uint8_t* cp = code_out + ((int64_t)b * DHW + n) * knn;
+    if (knn == 16) {
+      unsigned pk[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        pk[q] = key_code(best[4 * q]) | (key_code(best[4 * q + 1]) << 8) | (key_code(best[4 * q + 2]) << 16) |
+                (key_code(best[4 * q + 3]) << 24);
+      *reinterpret_cast<uint4*>(cp) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (j < knn) cp[j] = (uint8_t)key_code(best[j]);
+    }
+  }
+  if (idx_out != nullptr) {
+    int64_t* op = idx_out + ((int64_t)b * DHW + n) * knn;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      if (j < knn) {
+        const int code = (int)key_code(best[j]);
+        const int pd = code / (KS * KS), ph = (code / KS) % KS, pw = code % KS;
+        int64_t v = n + (int64_t)(pd - HK) * HW + (int64_t)(ph - HK) * W + (pw - HK);
+        v = v < 0 ? 0 : (v > DHW - 1 ? DHW - 1 : v);
+        op[j] = v;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int pf_knn_lattice_f32(const float* xyz, const int64_t* strides_host, int64_t B, int64_t D, int64_t H,
@@ -271,7 +453,7 @@ extern "C" int pf_knn_lattice_f32(const float* xyz, const int64_t* strides_host,
   if (knn > 32) return PF_ERR_UNSUPPORTED;
   if (code_out != nullptr && k3 > 256) return PF_ERR_UNSUPPORTED;
   if (B == 0 || D == 0 || H == 0 || W == 0) return PF_OK;
-  PF_REQUIRE(xyz != nullptr && strides_host != nullptr && idx_out != nullptr);
+  PF_REQUIRE(xyz != nullptr && strides_host != nullptr && (idx_out != nullptr || code_out != nullptr));
   PF_REQUIRE(B * D <= 65535 && pf_cdiv(H, TH) <= 65535);
   PF_REQUIRE(D * H * W <= (int64_t)INT32_MAX * 16);
   Strides5 st{strides_host[0], strides_host[1], strides_host[2], strides_host[3], strides_host[4]};
@@ -279,6 +461,25 @@ extern "C" int pf_knn_lattice_f32(const float* xyz, const int64_t* strides_host,
   const size_t lds_bytes = (size_t)3 * kernel_size * (TH + 2 * hk) * (TW + 2 * hk) * sizeof(float);
   dim3 grid((unsigned)pf_cdiv(W, TW), (unsigned)pf_cdiv(H, TH), (unsigned)(B * D));
   hipStream_t s = (hipStream_t)stream;
+  const char* legacy = getenv("PF_KNN_LEGACY");
+  if (knn <= 16 && (kernel_size == 3 || kernel_size == 5) && !(legacy && legacy[0] == '1')) {
+    // sorting-network kernel; 64-point blocks while the lattice is too small to fill the chip with 256-point ones
+    const bool small = B * D * H * W < 65536;
+    const int rows = small ? 2 : 8;
+    PF_REQUIRE(pf_cdiv(H, rows) <= 65535);
+    dim3 gridn((unsigned)pf_cdiv(W, 32), (unsigned)pf_cdiv(H, rows), (unsigned)(B * D));
+#define PF_KNN_NET(KSV, RV)                                                                                  \
+  hipLaunchKernelGGL((knn_net_kernel<KSV, RV>), gridn, dim3(32 * RV), 0, s, xyz, st, (int)D, (int)H, (int)W, knn, \
+                     idx_out, code_out)
+    if (kernel_size == 5) {
+      if (small) PF_KNN_NET(5, 2); else PF_KNN_NET(5, 8);
+    } else {
+      if (small) PF_KNN_NET(3, 2); else PF_KNN_NET(3, 8);
+    }
+#undef PF_KNN_NET
+    return pf_launch_status();
+  }
+  PF_REQUIRE(idx_out != nullptr);          // the insertion-list kernels below always write the indices
   // Measured (profiles/r01n_microbench_knn.log, window 5, k 16): the split scan wins while the lattice is too
   // small to fill the chip with one lane per point (25 600 points: 27 vs 35 us); on 102 400 points the plain
   // scan does the same work in a quarter of the waves without the merge (49 vs 82 us).

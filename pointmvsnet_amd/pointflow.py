@@ -63,6 +63,8 @@ import os as _os
 # PF_FUSED_BN=0 restores the separate BatchNorm finalize launches (A/B measurements only; same results up to the
 # summation order of the float64 statistics).
 FUSED_BN = int(_os.environ.get("PF_FUSED_BN", "1"))
+# PF_KNN_CODES=0: the PointFlow stage hands int64 neighbour indices to the EdgeConv passes (round-1 form)
+KNN_CODES = int(_os.environ.get("PF_KNN_CODES", "1"))
 
 
 def stat_rows(G, T, pcols, dev, tail):
@@ -484,13 +486,15 @@ def batch_norm_act_(x, bn, relu, samples_per_stat, partials=None, addend=None):
 # EdgeConv (rows E0 / E1 / E2)
 # ---------------------------------------------------------------------------------------------
 def edge_conv_fused(X, point_major, ldx, K, G, Ng, idx, conv1_w, conv2_w, bn, concat, Y, ldy,
-                    groups_per_stat=1, join=None):
+                    groups_per_stat=1, join=None, codes=None, lattice=None):
     """One EdgeConv / EdgeConvNoC layer on G groups of Ng points (reference networks.py:18-45, :56-81).
 
     X: channel-major (G,K,Ng) or point-major rows; idx (G,Ng,k) int64 group-local; Y: point-major view
-    with ``ldy`` floats per point receiving [central | diff] (concat) or diff (NoC)."""
+    with ``ldy`` floats per point receiving [central | diff] (concat) or diff (NoC).  Alternatively to ``idx``:
+    ``codes`` (G,Ng,16) uint8 window codes of the lattice kNN with ``lattice`` = (window, H, W)."""
     C = conv1_w.shape[0]
-    k = idx.shape[-1]
+    k = idx.shape[-1] if idx is not None else int(codes.shape[-1])
+    lat = (0, 1, 1) if codes is None else tuple(int(v) for v in lattice)
     dev = Y.device
     S = G // groups_per_stat
     training = bn.training or not bn.track_running_stats
@@ -515,7 +519,8 @@ def edge_conv_fused(X, point_major, ldx, K, G, Ng, idx, conv1_w, conv2_w, bn, co
                        ch0=doff)] if fused else None
         jarr, njobs, tk = tail_args(diff, G, T, dev)
         _lib.call("pf_edge_stats_f32", _lib.ptr(LE), 2 * C, C, _lib.ptr(idx), k, G, Ng, _lib.ptr(part_d),
-                  jarr, njobs, tk, _lib.stream(), algo_bytes=float(G) * Ng * (4.0 * C + 8.0 * k + 4.0 * C * k))
+                  jarr, njobs, tk, _lib.ptr(codes), lat[0], lat[1], lat[2], _lib.stream(),
+                  algo_bytes=float(G) * Ng * (4.0 * C + (1.0 if codes is not None else 8.0) * k + 4.0 * C * k))
         if fused:
             pass                              # both halves were finalized by their producers
         elif concat:
@@ -530,8 +535,9 @@ def edge_conv_fused(X, point_major, ldx, K, G, Ng, idx, conv1_w, conv2_w, bn, co
         scale.copy_(sc.unsqueeze(0).expand(S, cbn))
         shift.copy_(sh.unsqueeze(0).expand(S, cbn))
     _lib.call("pf_edge_apply_f32", _lib.ptr(LE), 2 * C, C, _lib.ptr(idx), k, G, Ng, _lib.ptr(scale),
-              _lib.ptr(shift), cbn, groups_per_stat, int(bool(concat)), _lib.ptr(Y), int(ldy), _lib.stream(),
-              algo_bytes=float(G) * Ng * (4.0 * C + 8.0 * k + 4.0 * C * k + 4.0 * cbn))
+              _lib.ptr(shift), cbn, groups_per_stat, int(bool(concat)), _lib.ptr(Y), int(ldy), _lib.ptr(codes),
+              lat[0], lat[1], lat[2], _lib.stream(),
+              algo_bytes=float(G) * Ng * (4.0 * C + (1.0 if codes is not None else 8.0) * k + 4.0 * C * k + 4.0 * cbn))
     return Y
 
 
@@ -610,20 +616,29 @@ def flow_chain(feature, xyz, depth, interval, h, w, ratio, edge_convs, flow_mlp,
         G, Cin, Ng = feature.shape
     hs, ws = h // ratio, w // ratio
     # the lattice kNN needs only xyz; the first EdgeConv GEMM needs only the features: run them concurrently
-    aux = None
+    aux, codes, lattice = None, None, None
     if idx is not None:
         if tuple(idx.shape) != (G, Ng, k) or idx.dtype != torch.int64:
             raise RuntimeError("flow_chain: idx must be int64 (G, Ng, k)")
         idx = idx.contiguous()
-    elif CONCURRENCY >= 2:
-        main = torch.cuda.current_stream()
-        aux = side_stream(dev, 1)
-        aux.wait_stream(main)
-        with torch.cuda.stream(aux):
-            idx = knn_lattice(xyz.view(G, 3, 5, hs, ws), 5, k)             # (G, Ng, k), group-local
-            idx.record_stream(main)
     else:
-        idx = knn_lattice(xyz.view(G, 3, 5, hs, ws), 5, k)
+        # window codes (16 bytes per point) instead of int64 indices when the kernels support it
+        use_codes = k == 16 and bool(KNN_CODES)
+        lattice = (5, hs, ws) if use_codes else None
+
+        def _knn():
+            out = knn_lattice(xyz.view(G, 3, 5, hs, ws), 5, k, with_codes=use_codes, with_idx=not use_codes)
+            return out if use_codes else (out, None)
+
+        if CONCURRENCY >= 2:
+            main = torch.cuda.current_stream()
+            aux = side_stream(dev, 1)
+            aux.wait_stream(main)
+            with torch.cuda.stream(aux):
+                idx, codes = _knn()                                        # (G, Ng, k), group-local
+                (codes if use_codes else idx).record_stream(main)
+        else:
+            idx, codes = _knn()
 
     widths = []
     for m in edge_convs:
@@ -636,7 +651,7 @@ def flow_chain(feature, xyz, depth, interval, h, w, ratio, edge_convs, flow_mlp,
     for li, (m, wdt) in enumerate(zip(edge_convs, widths)):
         Y = edges[:, col:]
         edge_conv_fused(X, pm, ldx, K, G, Ng, idx, m.conv1.weight, m.conv2.weight, m.bn, m.concat, Y, ctot,
-                        join=(aux if li == 0 else None))
+                        join=(aux if li == 0 else None), codes=codes, lattice=lattice)
         X, pm, ldx, K = Y, True, ctot, wdt
         col += wdt
 

@@ -81,7 +81,25 @@ def fetch_variance(feature_maps, pts, cam_intrinsics, cam_extrinsics, ref_overri
     return out
 
 
-def frustum_variance(feature_maps, kinv, rinv, t, depths, cam_intrinsics, cam_extrinsics, want_points=True):
+import os as _os
+
+# PF_FETCH_CL=0: the coarse warp reads the NCHW maps with one lane per point (round-1 kernel; A/B and tests)
+FETCH_CL = int(_os.environ.get("PF_FETCH_CL", "1"))
+
+
+def to_channel_last(maps):
+    """(..., C, H, W) contiguous -> (..., H, W, C) contiguous (pf_nchw_to_nhwc_f32)."""
+    C, H, W = maps.shape[-3:]
+    P = maps.numel() // (C * H * W)
+    out = torch.empty(tuple(maps.shape[:-3]) + (H, W, C), dtype=torch.float32, device=maps.device)
+    with torch.cuda.device(maps.device):
+        _lib.call("pf_nchw_to_nhwc_f32", _lib.ptr(maps), _lib.ptr(out), P, C, H * W, _lib.stream(),
+                  algo_bytes=8.0 * maps.numel())
+    return out
+
+
+def frustum_variance(feature_maps, kinv, rinv, t, depths, cam_intrinsics, cam_extrinsics, want_points=True,
+                     channel_last=None):
     """Coarse cost volume (reference model.py:79-111) without materialising the frustum first: the world
     points of the reference view's depth hypotheses are generated inside the fetch+variance kernel
     (pf_frustum_variance_f32).  kinv/rinv (B,3,3), t (B,3), depths (B,D) float32 on the device.
@@ -99,6 +117,15 @@ def frustum_variance(feature_maps, kinv, rinv, t, depths, cam_intrinsics, cam_ex
     N = D * H * W
     out = torch.empty((B, C, N), dtype=torch.float32, device=maps.device)
     world = torch.empty((B, 3, N), dtype=torch.float32, device=maps.device) if want_points else None
+    if channel_last is None:
+        channel_last = bool(FETCH_CL) and C % 4 == 0
+    if channel_last:
+        maps_cl = to_channel_last(maps)
+        with torch.cuda.device(maps.device):
+            _lib.call("pf_frustum_variance_cl_f32", _lib.ptr(maps_cl), _lib.ptr(kinv), _lib.ptr(rinv), _lib.ptr(t),
+                      _lib.ptr(depths), _lib.ptr(K), _lib.ptr(E), _lib.ptr(out), _lib.ptr(world), B, V, C, H, W, D,
+                      _lib.stream(), algo_bytes=4.0 * B * (V * C * H * W + (3 * N if want_points else 0) + C * N))
+        return out, world
     with torch.cuda.device(maps.device):
         _lib.call("pf_frustum_variance_f32", _lib.ptr(maps), _lib.ptr(kinv), _lib.ptr(rinv), _lib.ptr(t),
                   _lib.ptr(depths), _lib.ptr(K), _lib.ptr(E), _lib.ptr(out), _lib.ptr(world), B, V, C, H, W, D,

@@ -23,8 +23,9 @@ def set_random_seed(seed):
         torch.cuda.manual_seed_all(seed)
 
 
-def knn_lattice(xyz, kernel_size=5, knn=16, with_codes=False):
-    """HIP lattice kNN.  Returns idx, or (idx, codes uint8) when ``with_codes``."""
+def knn_lattice(xyz, kernel_size=5, knn=16, with_codes=False, with_idx=True):
+    """HIP lattice kNN.  Returns idx, or (idx, codes uint8) when ``with_codes`` (idx is None when
+    ``with_idx`` is False: the fused EdgeConv passes consume the 16-byte window codes directly)."""
     _lib.require_gpu(xyz)
     if xyz.dim() != 5 or xyz.size(1) != 3:
         raise RuntimeError("get_knn_3d: xyz must be (B,3,D,H,W)")
@@ -34,12 +35,15 @@ def knn_lattice(xyz, kernel_size=5, knn=16, with_codes=False):
     B, _, D, H, W = xyz.shape
     if knn > kernel_size ** 3:
         raise RuntimeError("get_knn_3d: knn larger than the window (topk would be out of range)")
-    idx = torch.empty((B, D * H * W, knn), dtype=torch.int64, device=xyz.device)
+    if not (with_idx or with_codes):
+        raise RuntimeError("knn_lattice: nothing to compute")
+    idx = torch.empty((B, D * H * W, knn), dtype=torch.int64, device=xyz.device) if with_idx else None
     codes = torch.empty((B, D * H * W, knn), dtype=torch.uint8, device=xyz.device) if with_codes else None
     strides = (ctypes.c_int64 * 5)(*xyz.stride())
     with torch.cuda.device(xyz.device):
         _lib.call("pf_knn_lattice_f32", _lib.ptr(xyz), strides, B, D, H, W, int(kernel_size), int(knn),
-                  _lib.ptr(idx), _lib.ptr(codes), _lib.stream(), algo_bytes=float(B * D * H * W) * (12.0 + 8.0 * knn))
+                  _lib.ptr(idx), _lib.ptr(codes), _lib.stream(),
+                  algo_bytes=float(B * D * H * W) * (12.0 + (8.0 * knn if with_idx else 0.0) + (knn if with_codes else 0.0)))
     return (idx, codes) if with_codes else idx
 
 

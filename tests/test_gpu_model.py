@@ -6,12 +6,16 @@ r*r sub-grids batched), in train mode, through autograd, and -- when the referen
 Contract (BASELINE.json north_star): depth maps within 1e-4 relative.  The coarse depth map meets it in
 the max norm.  After a PointFlow iteration the max norm is not a property the algorithm has: a 1-ulp
 change of the coarse depth flips nearly-tied kNN choices and moves the REFERENCE'S OWN output by up to
-6e-3 relative at up to ~10 % of the pixels (tests/test_sensitivity.py, measured on the reference code),
-and the GPU convolutions legally differ from the CPU ones by such ulps.  So: every stage is checked to
-float32 rounding on identical inputs in tests/test_gpu_stages.py, and here the refined maps must agree
-with the reference within its own self-sensitivity envelope: median <= 1e-4, at most 15 % of the pixels
-beyond 1e-4, none beyond 2e-2 (= two hypothesis intervals, the largest step a PointFlow iteration can take).
+6e-3 relative at up to ~10 % of the pixels, and the GPU convolutions legally differ from the CPU ones by
+such ulps.  So: every stage is checked to float32 rounding on identical inputs in tests/test_gpu_stages.py
+(unconditionally, on the oracle's own neighbour indices), and here the refined maps must agree with the
+reference within the reference's MEASURED self-sensitivity for the same configuration
+(tests/golden/sensitivity_envelope.json, produced by tests/golden/make_envelope.py, re-checked on CPU by
+tests/test_sensitivity.py): median <= 1e-4; the fraction of pixels beyond 1e-4 at most twice the
+reference's own fraction under a 1-ulp perturbation; the largest deviation at most three times the
+reference's own largest (and never more than two hypothesis intervals, the largest step an iteration takes).
 """
+import json
 import os
 
 import pytest
@@ -25,6 +29,15 @@ from pointmvsnet_amd.model import PointMVSNet
 pytestmark = pytest.mark.gpu
 
 DEPTH_RTOL = 1e-4
+ENVELOPE = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
+                                       "sensitivity_envelope.json")))
+
+
+def envelope_bounds(cfg, key):
+    """(max fraction of pixels beyond 1e-4, max relative deviation) the GPU result may show for ``key`` of
+    configuration ``cfg``: 2x / 3x what the reference itself shows under a 1-ulp perturbation of its coarse depth."""
+    e = ENVELOPE[cfg][key]
+    return 2.0 * e["frac_gt_1e4"] + 1e-3, min(3.0 * e["max"], 2e-2)
 
 
 def _to(data, dev):
@@ -34,7 +47,7 @@ def _to(data, dev):
     return out
 
 
-def _compare(preds, g, tag):
+def _compare(preds, g, tag, cfg):
     rel_c = float(((preds["coarse_depth_map"].cpu() - g["coarse_depth_map"]).abs() / g["coarse_depth_map"]).max())
     report("%s_coarse_depth_map" % tag, rel_err=rel_c)
     assert rel_c < 1e-5, "coarse depth map must match in the max norm"
@@ -44,8 +57,10 @@ def _compare(preds, g, tag):
             continue
         rel = (preds[key].cpu() - g[key]).abs() / g[key].abs()
         med, mx, frac = float(rel.median()), float(rel.max()), float((rel > 1e-4).float().mean())
-        report("%s_%s" % (tag, key), rel_median=med, rel_max=mx, frac_gt_1e4=frac)
-        assert mx < 2e-2 and frac < 0.15, (key, med, mx, frac)
+        frac_max, rel_max = envelope_bounds(cfg, key)
+        report("%s_%s" % (tag, key), rel_median=med, rel_max=mx, frac_gt_1e4=frac, frac_bound=frac_max,
+               max_bound=rel_max)
+        assert mx < rel_max and frac < frac_max, (key, med, mx, frac, rel_max, frac_max)
         worst = max(worst, med)
     for key in ("coarse_prob_map", "flow1_prob", "flow2_prob", "flow3_prob"):
         if key in g:
@@ -62,7 +77,8 @@ def _model(dev):
 
 
 @pytest.mark.parametrize("tag,cfg", [("model_tiny_test", "tiny"), ("model_small_test", "small"),
-                                     ("model_cfg2_test", "cfg2")])
+                                     ("model_cfg5r_test", "cfg5r"), ("model_cfg1_test", "cfg1"),
+                                     ("model_cfg2_test", "cfg2"), ("model_cfg3_test", "cfg3")])
 def test_forward_test_mode_vs_reference(dev, tag, cfg):
     g = load_golden(tag)
     data, img_scales, inter_scales = synthetic.make_config(cfg)
@@ -70,7 +86,7 @@ def test_forward_test_mode_vs_reference(dev, tag, cfg):
     with torch.no_grad():
         preds = net(_to(data, dev), img_scales, inter_scales, isFlow=True, isTest=True)
     assert list(preds.keys())[:3] == ["world_points", "coarse_depth_map", "coarse_prob_map"]
-    worst, err_wp = _compare(preds, g, tag)
+    worst, err_wp = _compare(preds, g, tag, cfg)
     assert err_wp < 1e-3                       # world points (mm) to float32 rounding of a ~650 mm value
     assert worst < DEPTH_RTOL
     for key in g:                              # BN running statistics mutate exactly like the reference's
@@ -89,7 +105,7 @@ def test_forward_train_mode_no_grad_vs_reference(dev):
     net = _model(dev)
     with torch.no_grad():
         preds = net(_to(data, dev), img_scales, inter_scales, isFlow=True, isTest=False)
-    worst, _ = _compare(preds, g, "model_tiny_train_fused")
+    worst, _ = _compare(preds, g, "model_tiny_train_fused", "tiny_train")
     assert worst < DEPTH_RTOL
 
 
@@ -98,7 +114,7 @@ def test_forward_autograd_path_vs_reference_and_backward(dev):
     data, img_scales, inter_scales = synthetic.make_config("tiny", train_intrinsics=True)
     net = _model(dev)
     preds = net(_to(data, dev), img_scales, inter_scales, isFlow=True, isTest=False)
-    worst, _ = _compare(preds, g, "model_tiny_train_autograd")
+    worst, _ = _compare(preds, g, "model_tiny_train_autograd", "tiny_train")
     assert worst < DEPTH_RTOL
     loss = preds["flow2"].mean() + preds["coarse_depth_map"].mean()
     loss.backward()
@@ -142,19 +158,35 @@ def test_cfg2_full_size_properties(dev):
     assert float(pm.min()) >= 0.0 and float(pm.max()) <= 2.0 + 1e-5
 
 
-@pytest.mark.skipif(not os.path.isdir(REFERENCE_DIR), reason="reference tree only exists in the build container")
-def test_reference_model_py_runs_unchanged_on_our_operators(dev):
+def _reference_model_file():
+    """The reference's own model.py: from /root/reference in the build container, else the byte-identical copy
+    oracle/make_ref.py staged under the git-ignored oracle/_ref/ at build time (it travels to the GPU box)."""
+    live = os.path.join(REFERENCE_DIR, "pointmvsnet", "model.py")
+    if os.path.isfile(live):
+        return live
+    staged = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref",
+                          "reference_model_py.txt")
+    assert os.path.isfile(staged), "oracle/_ref/reference_model_py.txt missing: run __graft_entry__.build() " \
+                                   "(oracle/make_ref.py) in the build container before shipping to the GPU box"
+    return staged
+
+
+@pytest.mark.parametrize("tag,cfg", [("model_tiny_test", "tiny"), ("model_cfg2_test", "cfg2")])
+def test_reference_model_py_runs_unchanged_on_our_operators(dev, tag, cfg):
+    """north_star: "pointmvsnet/model.py consumes the new ops unchanged".  The reference's model graph, executed
+    from its own source file, over pointmvsnet_amd's operator layer aliased under the reference's module names,
+    must reproduce the reference's golden depth maps within the same envelope as our own model graph."""
     from pointmvsnet_amd import compat
-    ref = compat.load_reference_model(os.path.join(REFERENCE_DIR, "pointmvsnet", "model.py"))
+    ref = compat.load_reference_model(_reference_model_file())
     net = ref.PointMVSNet()
     synthetic.seed_weights(net, seed=0)
     net = net.to(dev).train()
-    data, img_scales, inter_scales = synthetic.make_config("tiny")
-    g = load_golden("model_tiny_test")
+    data, img_scales, inter_scales = synthetic.make_config(cfg)
+    g = load_golden(tag)
     with torch.no_grad():
         preds = net({k: v.to(dev) for k, v in data.items()}, img_scales, inter_scales, isFlow=True, isTest=True)
-    rel = float(((preds["flow2"].cpu() - g["flow2"]).abs() / g["flow2"]).max())
-    assert rel < 1e-3      # modern grid_sample default differs from the pinned one (F7): loose bound only
+    worst, err_wp = _compare(preds, g, "refmodel_" + tag, cfg)
+    assert worst < DEPTH_RTOL and err_wp < 1e-3
 
 
 def test_graphed_forward_matches_eager_and_replays_on_new_scenes(dev):

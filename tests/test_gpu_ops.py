@@ -737,3 +737,212 @@ def test_bn_finalize_jobs_vs_first_principles(dev, C, G, gps, T):
         assert torch.allclose(bn.running_mean.double().cpu(), rm, rtol=1e-5, atol=1e-6)
         assert torch.allclose(bn.running_var.double().cpu(), rv, rtol=1e-5, atol=1e-6)
     assert _lib.status() == 0
+
+
+# ---------------------------------------------------------------------------------------------
+# BatchNorm finalize folded into the producer (csrc/pf_bn_tail.h)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("G,Ng,K,cout,gps", [(1, 64, 32, 64, 1), (4, 25600, 64, 64, 1), (16, 6000, 64, 16, 1),
+                                             (6, 1000, 224, 64, 2), (3, 1000, 64, 128, 3), (1, 102400, 136, 64, 1)])
+def test_gemm_fused_bn_tail_vs_separate_finalize(dev, G, Ng, K, cout, gps):
+    """The last-block-done finalize must give what the separate finalize launch gives on the same statistics rows
+    (same float64 sums up to their order: float32 scale/shift agree to rounding; the running statistics too),
+    for one-level (few rows) and two-level (many rows) trees, pooled stat groups, padded column tiles -- and it
+    must do so on every one of many back-to-back launches that reuse ticket counters while another stream keeps
+    the chip unevenly busy (the hand-off is placement- and timing-independent or it is wrong)."""
+    gen = torch.Generator().manual_seed(G + Ng + K)
+    w = torch.randn(cout, K, 1, generator=gen).to(dev)
+    x = torch.randn(G * Ng, K, generator=gen).to(dev)
+    Wt, _ = pointflow.pack_weight_t(w)
+    S = G // gps
+
+    def make_bn():
+        bn = torch.nn.BatchNorm1d(cout).to(dev)
+        g2 = torch.Generator().manual_seed(5)
+        with torch.no_grad():
+            bn.weight.copy_(torch.rand(cout, generator=g2) + 0.5)
+            bn.bias.copy_(torch.randn(cout, generator=g2))
+            bn.running_mean.copy_(torch.randn(cout, generator=g2))
+            bn.running_var.copy_(torch.rand(cout, generator=g2) + 0.5)
+        return bn
+
+    n = float(gps) * Ng
+    # separate finalize (the round-1 path)
+    bn_a = make_bn()
+    Y = torch.empty((G * Ng, cout), device=dev)
+    part = pointflow.pointwise_gemm(x, True, K, Wt, Y, cout, G, Ng, K, cout, groups_per_stat=gps, want_stats=True)
+    sc_a = torch.empty((S, cout), device=dev)
+    sh_a = torch.empty((S, cout), device=dev)
+    pointflow.bn_affine(bn_a, part, 0, cout, n, n, G, gps, sc_a, sh_a)
+    # fused tail, many launches, noise on a second stream
+    noise = torch.randn(1 << 22, device=dev)
+    side = torch.cuda.Stream()
+    reps = 20
+    results = []
+    for r in range(reps):
+        bn_b = make_bn()
+        sc_b = torch.full((S, cout + 4), 7.0, device=dev)
+        sh_b = torch.full((S, cout + 4), 7.0, device=dev)
+        job = pointflow.bn_job(bn_b, None, 0, cout, n, n, G, gps, sc_b, sh_b)
+        with torch.cuda.stream(side):
+            for _ in range(1 + r % 3):
+                noise.mul_(1.0000001)
+        pointflow.pointwise_gemm(x, True, K, Wt, Y, cout, G, Ng, K, cout, groups_per_stat=gps, bn_jobs=[job])
+        results.append((bn_b, sc_b, sh_b))
+    torch.cuda.synchronize()
+    for bn_b, sc_b, sh_b in results:
+        assert torch.allclose(sc_b[:, :cout], sc_a, rtol=1e-6, atol=1e-7)
+        assert torch.allclose(sh_b[:, :cout], sh_a, rtol=1e-6, atol=1e-6)
+        assert torch.all(sc_b[:, cout:] == 7.0) and torch.all(sh_b[:, cout:] == 7.0)
+        assert torch.allclose(bn_b.running_mean, bn_a.running_mean, rtol=1e-6, atol=1e-7)
+        assert torch.allclose(bn_b.running_var, bn_a.running_var, rtol=1e-6, atol=1e-7)
+        # bit-reproducible across launches (fixed summation order)
+        assert torch.equal(sc_b, results[0][1]) and torch.equal(sh_b, results[0][2])
+    # the ticket counters are back to zero
+    for buf, _ in _lib._ticket_pools.values():
+        assert int(buf.abs().sum()) == 0
+    assert _lib.status() == 0
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,ks,stride,sps", [(3, 3, 8, 128, 160, 3, 1, 1), (3, 8, 16, 128, 160, 5, 2, 1),
+                                                          (6, 16, 32, 64, 80, 5, 2, 2), (3, 32, 32, 32, 40, 3, 1, 1),
+                                                          (3, 8, 8, 512, 640, 3, 1, 1)])
+def test_conv2d_fused_bn_tail_vs_torch(dev, N, Cin, Cout, H, W, ks, stride, sps):
+    """A tower convolution that finalizes its own BatchNorm: (scale, shift) and running statistics against
+    nn.BatchNorm2d run per stat group on the float64 convolution output."""
+    gen = torch.Generator().manual_seed(N * Cin + Cout)
+    conv = torch.nn.Conv2d(Cin, Cout, ks, stride=stride, padding=ks // 2, bias=False)
+    x = torch.randn(N, Cin, H, W, generator=gen)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=gen) * 0.2)
+    ref = F.conv2d(x.double(), conv.weight.double(), None, stride, ks // 2)
+    bn_ref = torch.nn.BatchNorm2d(Cout).double().train()
+    bn = torch.nn.BatchNorm2d(Cout).to(dev).train()
+    with torch.no_grad():
+        for b in (bn_ref, bn):
+            b.weight.copy_(torch.linspace(0.5, 1.5, Cout))
+            b.bias.copy_(torch.linspace(-0.3, 0.3, Cout))
+    conv = conv.to(dev)
+    fn = pointflow.conv2d_small if pointflow.conv2d_small_preferred(conv) else pointflow.conv2d
+    y, part, (sc, sh) = fn(x.to(dev), conv, None, sps, True, bn=bn)
+    pointflow.flush_counters()
+    G = N // sps
+    got = torch.relu(y.double().cpu().view(G, sps, Cout, -1) * sc.double().cpu().view(G, 1, Cout, 1)
+                     + sh.double().cpu().view(G, 1, Cout, 1))
+    want = torch.stack([torch.relu(bn_ref(ref[g * sps:(g + 1) * sps])) for g in range(G)]).view(G, sps, Cout, -1)
+    err = float((got - want.detach()).abs().max())
+    report("conv2d_fused_bn_%d_%d_%d" % (Cin, Cout, ks), err=err)
+    assert err < 2e-5 * max(1.0, float(want.abs().max()))
+    assert torch.allclose(bn.running_mean.double().cpu(), bn_ref.running_mean, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(bn.running_var.double().cpu(), bn_ref.running_var, rtol=1e-5, atol=1e-6)
+    assert int(bn.num_batches_tracked) == G
+    assert _lib.status() == 0
+
+
+def test_image_conv_tower_vs_oracle(dev):
+    """The batched-views tower (own conv kernels, BatchNorm in the epilogues / tails) against the CPU oracle's
+    tower (reference networks.py:84-124 on ATen), per view, including the running statistics."""
+    from oracle import pointflow_oracle as O
+    from pointmvsnet_amd.networks import ImageConv
+    gen = torch.Generator().manual_seed(21)
+    imgs = torch.randn(1, 3, 3, 128, 160, generator=gen)
+    net = ImageConv(8)
+    synthetic.seed_weights(net, 3)
+    sd = {"t." + k: v.clone() for k, v in net.state_dict().items()}
+    net = net.to(dev).train()
+    with torch.no_grad():
+        got = net.forward_views(imgs.to(dev), need=("conv1", "conv2", "conv3"))
+        pointflow.flush_counters()
+        track = {}
+        want = [O.image_conv(imgs[:, v], sd, "t", track) for v in range(3)]
+    for name in ("conv1", "conv2", "conv3"):
+        w = torch.stack([o[name] for o in want], dim=1)
+        err = _maxabs(got[name], w)
+        report("image_conv_tower_vs_oracle_" + name, err=err, scale=float(w.abs().max()))
+        assert err < 2e-5 * max(1.0, float(w.abs().max()))
+    state = net.state_dict()
+    assert len(track) == 3 * 10                        # ten BatchNorms, (mean, var, counter) each
+    for key, val in track.items():                     # three sequential updates per module, like the reference
+        if key.endswith("num_batches_tracked"):
+            assert int(state[key[2:]]) == int(val), key
+        else:
+            assert torch.allclose(state[key[2:]].cpu(), val, rtol=1e-4, atol=1e-5), key
+
+
+# ---------------------------------------------------------------------------------------------
+# lattice kNN: sorting-network kernel, window codes as the neighbourhood of the EdgeConv passes
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(1, 5, 64, 80), (4, 5, 64, 80), (2, 5, 7, 33), (16, 5, 30, 40)])
+def test_knn_network_kernel_equals_insertion_kernels_and_codes_only_call(dev, shape, monkeypatch):
+    B, D, H, W = shape
+    g = torch.Generator().manual_seed(B * H)
+    base = torch.stack(torch.meshgrid(torch.arange(W).float(), torch.arange(H).float(), torch.arange(D).float(),
+                                      indexing="xy"), 0).permute(0, 3, 1, 2)
+    xyz = (base.unsqueeze(0).repeat(B, 1, 1, 1, 1) * 0.07 - 1.0 + 0.02 * torch.randn(B, 3, D, H, W, generator=g)).to(dev)
+    xyz[:, :, :, :2, :3] = xyz[:, :, :, 2:4, :3]                  # exact duplicates: ties resolved by the code order
+    idx, codes = knn_lattice(xyz, 5, 16, with_codes=True)
+    none, codes_only = knn_lattice(xyz, 5, 16, with_codes=True, with_idx=False)
+    assert none is None and torch.equal(codes_only, codes)
+    monkeypatch.setenv("PF_KNN_LEGACY", "1")                      # the round-1 insertion-list kernels
+    idx_old, codes_old = knn_lattice(xyz, 5, 16, with_codes=True)
+    monkeypatch.delenv("PF_KNN_LEGACY")
+    assert torch.equal(idx, idx_old) and torch.equal(codes, codes_old)
+    bf_idx, bf_code = BF.knn_window(xyz[0].cpu().numpy(), 5, 16)
+    assert np.array_equal(idx[0].cpu().numpy(), bf_idx) and np.array_equal(codes[0].cpu().numpy(), bf_code)
+
+
+@pytest.mark.parametrize("concat,C", [(False, 32), (True, 32), (True, 64)])
+def test_edgeconv_window_codes_equal_int64_indices(dev, concat, C):
+    """The EdgeConv passes fed with the 16-byte window codes must reproduce, bit for bit, what they give on the
+    int64 indices of the same kNN call (incl. the clamp at the ends of each group)."""
+    G, D, H, W, K = 3, 5, 9, 14, 40
+    Ng = D * H * W
+    gen = torch.Generator().manual_seed(C)
+    xyz = torch.randn(G, 3, D, H, W, generator=gen).to(dev)       # random cloud: neighbours all over the window
+    idx, codes = knn_lattice(xyz, 5, 16, with_codes=True)
+    X = torch.randn(G * Ng, K, generator=gen).to(dev)
+    outs = []
+    for use_codes in (False, True):
+        mod = (EdgeConv if concat else EdgeConvNoC)(K, C)
+        synthetic.seed_weights(mod, seed=2)
+        mod = mod.to(dev).train()
+        width = (2 if concat else 1) * C
+        Y = torch.empty((G * Ng, width), device=dev)
+        with torch.no_grad():
+            pointflow.edge_conv_fused(X, True, K, K, G, Ng, None if use_codes else idx, mod.conv1.weight,
+                                      mod.conv2.weight, mod.bn, concat, Y, width,
+                                      codes=codes if use_codes else None, lattice=(5, H, W) if use_codes else None)
+            pointflow.flush_counters()
+        outs.append((Y, mod.bn.running_mean.clone(), mod.bn.running_var.clone()))
+    torch.cuda.synchronize()
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    assert _lib.status() == 0
+
+
+# ---------------------------------------------------------------------------------------------
+# coarse warp on channel-last maps (csrc/fetch.hip, frustum_variance_cl_kernel)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,V,C,H,W,D", [(1, 3, 64, 64, 80, 48), (2, 5, 8, 16, 20, 6), (1, 7, 68, 9, 11, 3),
+                                         (1, 2, 4, 5, 7, 1)])
+def test_frustum_variance_channel_last_is_bit_identical(dev, B, V, C, H, W, D):
+    from pointmvsnet_amd.utils.feature_fetcher import frustum_variance, to_channel_last
+    gen = torch.Generator().manual_seed(C + H)
+    data = synthetic.make_scene(8 * H, 8 * W, V, D, seed=V, batch=B)
+    cams = data["cam_params_list"]
+    K = cams[:, :, 1, :3, :3].clone()
+    K[:, :, :2, :3] /= 8.0
+    E = cams[:, :, 0, :3, :4].clone()
+    feats = torch.randn(B, V, C, H, W, generator=gen).to(dev)
+    kinv = torch.inverse(K[:, 0]).to(dev)
+    rinv = torch.inverse(E[:, 0, :, :3]).to(dev)
+    t0 = E[:, 0, :, 3].to(dev)
+    depths = torch.stack([torch.linspace(425.0 + 10 * b, 900.0 + 10 * b, D) for b in range(B)]).to(dev)
+    cl = to_channel_last(feats)
+    assert cl.shape == (B, V, H, W, C) and torch.equal(cl, feats.permute(0, 1, 3, 4, 2).contiguous())
+    a, wa = frustum_variance(feats, kinv, rinv, t0, depths, K.to(dev), E.to(dev), channel_last=False)
+    b, wb = frustum_variance(feats, kinv, rinv, t0, depths, K.to(dev), E.to(dev), channel_last=True)
+    assert torch.equal(a, b) and torch.equal(wa, wb)
+    c, none = frustum_variance(feats, kinv, rinv, t0, depths, K.to(dev), E.to(dev), want_points=False,
+                               channel_last=True)
+    assert none is None and torch.equal(c, a)
