@@ -316,12 +316,10 @@ int launch2d(const float* x, const float* wp, float* y, Conv2Geom g, int64_t N, 
   constexpr size_t lds_bytes = lds_bytes_2d<NT, STRIDE, KS, TR, KG>();
   static_assert(lds_bytes <= kMaxLds2d, "conv2d tile does not fit the LDS budget");
   if (lds_bytes > 64 * 1024) {
-    static bool done = false;
-    if (!done) {
-      PF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_kernel<NT, STRIDE, KS, TR, KG, MINW>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds2d));
-      done = true;
-    }
+    static std::atomic<unsigned long long> done{0};   // per instantiation, one bit per device
+    const int rc = pf_allow_big_lds(reinterpret_cast<const void*>(&conv2d_kernel<NT, STRIDE, KS, TR, KG, MINW>),
+                                    (int)kMaxLds2d, done);
+    if (rc != PF_OK) return rc;
   }
   g.tiles_h = (g.Ho + 4 * TR - 1) / (4 * TR);
   g.tiles_w = (g.Wo + 15) / 16;

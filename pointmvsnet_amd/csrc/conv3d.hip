@@ -361,12 +361,10 @@ int launch(const float* x, const float* wp, float* y, const ConvGeom& g, int64_t
   const size_t lds_bytes = lds_bytes_for(g, NT);
   if (lds_bytes > kMaxLds) return PF_ERR_UNSUPPORTED;
   if (lds_bytes > 64 * 1024) {           // opt in to more than the default 64 KiB of dynamic LDS (160 KiB per CU)
-    static bool done = false;            // per instantiation
-    if (!done) {
-      PF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_k3_kernel<NT, STRIDE, TD, MINW>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
-      done = true;
-    }
+    static std::atomic<unsigned long long> done{0};   // per instantiation, one bit per device
+    const int rc = pf_allow_big_lds(reinterpret_cast<const void*>(&conv3d_k3_kernel<NT, STRIDE, TD, MINW>),
+                                    (int)kMaxLds, done);
+    if (rc != PF_OK) return rc;
   }
   dim3 grid((unsigned)blocks_for(g), (unsigned)N);
   hipLaunchKernelGGL((conv3d_k3_kernel<NT, STRIDE, TD, MINW>), grid, dim3(256), lds_bytes, s, x, wp, y, g, partials);

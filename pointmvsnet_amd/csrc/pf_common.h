@@ -29,6 +29,19 @@ static inline int pf_launch_status() {
 
 static inline int64_t pf_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per DEVICE: `flags` is one bit per device ordinal, owned by the
+// caller (one static word per kernel instantiation), so a process that drives several GPUs opts in on each of them.
+#include <atomic>
+static inline int pf_allow_big_lds(const void* kernel, int bytes, std::atomic<unsigned long long>& flags) {
+  int dev = 0;
+  PF_HIP(hipGetDevice(&dev));
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (flags.load(std::memory_order_acquire) & bit) return PF_OK;
+  PF_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  flags.fetch_or(bit, std::memory_order_release);
+  return PF_OK;
+}
+
 // ---- projection + bilinear taps shared by the fetch kernels -------------------------------------
 // Follows reference utils/feature_fetcher.py:36-55 on the arithmetic of ATen's CPU grid_sample with
 // align_corners=True (the oracle): un-normalise with (g + 1) * ((size - 1) / 2), weights

@@ -9,8 +9,17 @@ by construction, see ``ScenePlan`` -- once, then serves every scene of the same 
 BatchNorm running statistics and ``num_batches_tracked`` keep mutating on every replay exactly as in
 eager mode (the update kernels are part of the graph).  Outputs are static tensors, overwritten by the
 next replay.
+
+Weights: the graph reads the PACKED copies of the conv / GEMM weights (pointflow's pack cache).  The entries
+used during capture are pinned (never evicted while this object lives) and their source parameters are
+fingerprinted (version counter, storage address, device, dtype); a replay after ``load_state_dict``, an
+optimizer step, ``param.data = ...`` or ``model.to(...)`` re-captures instead of silently serving the old
+weights.  The warm-up forwards run on a snapshot of the BatchNorm buffers, which is restored before capture:
+constructing a GraphedForward does not advance running statistics or ``num_batches_tracked``.
 """
 import torch
+
+from . import pointflow
 
 
 class GraphedForward(object):
@@ -22,6 +31,9 @@ class GraphedForward(object):
         self.probe = None                                  # set to a list to collect (start, end) events per replay
         self.static_img = example_batch["img_list"].clone()
         self.plan = model.make_plan(example_batch, img_scales, inter_scales, isTest)
+        self._packs = []
+        self.recaptures = 0
+        buffers = [(b, b.clone()) for b in model.buffers()]          # warm-up must not advance BN statistics
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                      # library warm-up (MIOpen find, lazy allocations)
@@ -29,14 +41,35 @@ class GraphedForward(object):
                 model.run(self.plan, self.static_img, isFlow)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        with torch.no_grad():
+            for b, saved in buffers:
+                b.copy_(saved)
+        self._capture()
+
+    def _capture(self):
         # One graph for the whole forward; the stream forks inside run() become graph edges.  (Three graphs
         # -- coarse, flow tower on a side stream, flow iterations -- ordered by stream events were measured
         # at 402 depth maps/s against 486: replays on different streams did not overlap, profiles/r01h_split_ab.log.)
+        pointflow.pack_unpin(self._packs)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.outputs = model.run(self.plan, self.static_img, isFlow)
+        pointflow.pack_log_begin()
+        try:
+            with torch.cuda.graph(self.graph):
+                self.outputs = self.model.run(self.plan, self.static_img, self.isFlow)
+        finally:
+            self._packs = pointflow.pack_log_end(pin=True)
+
+    def __del__(self):
+        try:
+            pointflow.pack_unpin(self._packs)
+        except Exception:
+            pass
 
     def __call__(self, data_batch):
+        if pointflow.pack_entries_stale(self._packs):      # weights changed since capture: the graph holds old packs
+            torch.cuda.synchronize()
+            self._capture()
+            self.recaptures += 1
         self.plan.update_(data_batch)
         img = data_batch["img_list"]
         if img.data_ptr() != self.static_img.data_ptr():

@@ -35,9 +35,15 @@ _HYPOTHESES = (-2, -1, 0, 1, 2)
 
 
 def _host_cams(data_batch):
+    """Host copy of the camera block.  ``cam_params_list_host`` (optional) spares the D2H copy + sync; it must be
+    the same values as the device tensor -- PF_DEBUG=1 checks that on every call (a stale host copy would give
+    wrong geometry silently)."""
     cams = data_batch.get("cam_params_list_host")
     if cams is None:
         cams = data_batch["cam_params_list"].detach().cpu()   # one small D2H per forward
+    elif os.environ.get("PF_DEBUG") == "1":
+        if not torch.equal(cams.float(), data_batch["cam_params_list"].detach().cpu().float()):
+            raise RuntimeError("cam_params_list_host differs from cam_params_list")
     return cams.float()
 
 

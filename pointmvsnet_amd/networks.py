@@ -53,8 +53,6 @@ class _EdgeConvBase(nn.Module):
         B, cin, N = feature.shape
         cout = self.conv1.weight.shape[0]
         width = (2 if self.concat else 1) * cout
-        if cout not in (32, 64, 128):
-            raise NotImplementedError("fused EdgeConv kernels are built for 32/64/128 output channels")
         x = feature.detach().float().contiguous()
         idx = knn_inds.contiguous()
         out = torch.empty((B * N, width), dtype=torch.float32, device=x.device)
@@ -70,6 +68,11 @@ class _EdgeConvBase(nn.Module):
             raise RuntimeError("EdgeConv: expected feature (B,C,N) and int64 knn_inds (B,N,k)")
         if self._needs_graph(feature):
             return self._forward_autograd(feature, knn_inds)
+        if self.conv1.weight.shape[0] not in (32, 64) or knn_inds.shape[2] < 1:
+            # widths the fused kernels are not built for (their GEMM emits [l | e] = 2*C_out <= 128 columns):
+            # the composed operators give the same result, like the reference, instead of an error
+            with torch.no_grad():
+                return self._forward_autograd(feature, knn_inds)
         return self._forward_fused(feature, knn_inds)
 
 

@@ -24,29 +24,96 @@ def stat_blocks(G, Ng):
     return int(_lib.load().pf_stat_blocks(int(G), int(Ng)))
 
 
-_pack_cache = {}
+# ---------------------------------------------------------------------------------------------
+# packed-weight cache
+# ---------------------------------------------------------------------------------------------
+# An entry is valid only while every source tensor is the same OBJECT (weak reference), has the same version
+# counter, the same storage address, device and dtype: ``param.data = ...``, ``module.to()/cuda(1)/double()``,
+# ``vector_to_parameters`` and EMA swaps leave ``_version`` untouched but move the storage.  Entries a captured
+# hipGraph reads are pinned (graph.GraphedForward): eviction skips them, so the allocator can never hand the
+# memory a live graph reads to somebody else.
+import collections as _collections
+import weakref as _weakref
+
+_PACK_CAP = 256
+_pack_cache = _collections.OrderedDict()
+_pack_pins = {}            # key -> pin count
+_pack_log = None           # list collecting the keys used while a graph is being captured
+
+
+def _src_sig(t):
+    return (t._version, t.data_ptr(), str(t.device), t.dtype)
+
+
+def _cached_pack(key, sources, make):
+    hit = _pack_cache.get(key)
+    if hit is not None:
+        refs, sigs, out = hit
+        if all(r() is t for r, t in zip(refs, sources)) and sigs == tuple(_src_sig(t) for t in sources):
+            _pack_cache.move_to_end(key)
+            if _pack_log is not None:
+                _pack_log.append(key)
+            return out
+    out = make()
+    try:
+        _pack_cache[key] = (tuple(_weakref.ref(t) for t in sources), tuple(_src_sig(t) for t in sources), out)
+        _pack_cache.move_to_end(key)
+    except TypeError:
+        return out
+    if _pack_log is not None:
+        _pack_log.append(key)
+    if len(_pack_cache) > _PACK_CAP:                       # least recently used first, never a pinned entry
+        for k in list(_pack_cache.keys()):
+            if len(_pack_cache) <= _PACK_CAP:
+                break
+            if k not in _pack_pins and k != key:
+                del _pack_cache[k]
+    return out
+
+
+def pack_log_begin():
+    """Start recording which cache entries are used (graph capture)."""
+    global _pack_log
+    _pack_log = []
+
+
+def pack_log_end(pin=True):
+    """Stop recording; returns [(key, source weakrefs, signatures)] of the entries used, pinned against eviction."""
+    global _pack_log
+    keys, _pack_log = (_pack_log or []), None
+    out = []
+    for k in dict.fromkeys(keys):
+        if k in _pack_cache:
+            refs, sigs, _ = _pack_cache[k]
+            out.append((k, refs, sigs))
+            if pin:
+                _pack_pins[k] = _pack_pins.get(k, 0) + 1
+    return out
+
+
+def pack_unpin(entries):
+    for k, _, _ in entries:
+        n = _pack_pins.get(k, 0) - 1
+        if n <= 0:
+            _pack_pins.pop(k, None)
+        else:
+            _pack_pins[k] = n
+
+
+def pack_entries_stale(entries):
+    """True when a source tensor of a recorded entry changed (value, storage, device or dtype) or died."""
+    for _, refs, sigs in entries:
+        for r, sig in zip(refs, sigs):
+            t = r()
+            if t is None or _src_sig(t) != sig:
+                return True
+    return False
 
 
 def pack_weight_t(*convs):
     """Stack 1x1 conv weights (Cout_i, K, 1) along the output axis, transpose to (K, Nc) row-major and
-    zero-pad Nc to a multiple of 32 (MFMA column tiles).  Returns (Wt, Cout_total).  Cached per parameter
-    OBJECT (weak reference) and version counter, so inference re-packs nothing and a recycled address or
-    an optimizer step can never serve a stale pack."""
-    import weakref
-    key = tuple(id(c) for c in convs)
-    hit = _pack_cache.get(key)
-    if hit is not None:
-        refs, versions, out = hit
-        if all(r() is c for r, c in zip(refs, convs)) and versions == tuple(c._version for c in convs):
-            return out
-    if len(_pack_cache) > 256:
-        _pack_cache.clear()
-    out = _pack_weight_t(*convs)
-    try:
-        _pack_cache[key] = (tuple(weakref.ref(c) for c in convs), tuple(c._version for c in convs), out)
-    except TypeError:
-        pass
-    return out
+    zero-pad Nc to a multiple of 32 (MFMA column tiles).  Returns (Wt, Cout_total).  Cached (see above)."""
+    return _cached_pack(("wt",) + tuple(id(c) for c in convs), convs, lambda: _pack_weight_t(*convs))
 
 
 def _pack_weight_t(*convs):
@@ -149,24 +216,37 @@ def side_stream(device, slot):
     return st
 
 
-_pending_counters = []
+# Deferred ``num_batches_tracked`` updates, per (thread, device): the reference trains under nn.DataParallel
+# (train.py:177), which calls forward from one Python thread per GPU -- a shared list would let one replica
+# flush another replica's counters (tensors of several devices in one _foreach_add_).
+import threading as _threading
+
+_pending = _threading.local()
+
+
+def _pending_list(device):
+    table = getattr(_pending, "table", None)
+    if table is None:
+        table = _pending.table = {}
+    return table.setdefault(str(device), [])
 
 
 def bump_counter(bn, n):
     """``num_batches_tracked += n`` deferred to one fused launch (flush_counters) instead of one tiny
     elementwise kernel per BatchNorm module (82 of them per depth map in eager PyTorch)."""
     if bn.track_running_stats and bn.num_batches_tracked is not None:
-        _pending_counters.append((bn.num_batches_tracked, int(n)))
+        _pending_list(bn.num_batches_tracked.device).append((bn.num_batches_tracked, int(n)))
 
 
 def flush_counters():
-    if _pending_counters:
-        merged = {}
-        for t, n in _pending_counters:                 # a module may be bumped several times per forward
-            key = t.data_ptr()
-            merged[key] = (t, merged[key][1] + n) if key in merged else (t, n)
-        del _pending_counters[:]
-        torch._foreach_add_([t for t, _ in merged.values()], [n for _, n in merged.values()])
+    for pending in list(getattr(_pending, "table", {}).values()):
+        if pending:
+            merged = {}
+            for t, n in pending:                           # a module may be bumped several times per forward
+                key = t.data_ptr()
+                merged[key] = (t, merged[key][1] + n) if key in merged else (t, n)
+            del pending[:]
+            torch._foreach_add_([t for t, _ in merged.values()], [n for _, n in merged.values()])
 
 
 def eval_affine(bn, S, ld, ch0=0, C=None, out=None):
@@ -252,22 +332,14 @@ def conv2d_small_preferred(conv):
 
 
 def pack_conv2d_small_weight(weight):
-    """(Cout,Cin,K,K) -> (ceil(Cin/4), 4, K, K, Cout) zero padded; cached per parameter object."""
-    import weakref
-    key = ("c2s", id(weight))
-    hit = _pack_cache.get(key)
-    if hit is not None and hit[0]() is weight and hit[1] == weight._version:
-        return hit[2]
-    cout, cin, k, _ = weight.shape
-    groups = (cin + 3) // 4
-    full = torch.zeros((groups * 4, k, k, cout), dtype=_F32, device=weight.device)
-    full[:cin] = weight.detach().to(_F32).permute(1, 2, 3, 0)
-    wp = full.view(groups, 4, k, k, cout).contiguous()
-    try:
-        _pack_cache[key] = (weakref.ref(weight), weight._version, wp)
-    except TypeError:
-        pass
-    return wp
+    """(Cout,Cin,K,K) -> (ceil(Cin/4), 4, K, K, Cout) zero padded; cached per parameter."""
+    def make():
+        cout, cin, k, _ = weight.shape
+        groups = (cin + 3) // 4
+        full = torch.zeros((groups * 4, k, k, cout), dtype=_F32, device=weight.device)
+        full[:cin] = weight.detach().to(_F32).permute(1, 2, 3, 0)
+        return full.view(groups, 4, k, k, cout).contiguous()
+    return _cached_pack(("c2s", id(weight)), (weight,), make)
 
 
 def _conv_bn_tail(bn, N, Cout, S_out, samples_per_stat, dev):
@@ -311,24 +383,17 @@ def _conv2d_ncp(cout):
 
 
 def pack_conv2d_weight(weight):
-    """(Cout,Cin,K,K) -> (ceil(Cin/4), K*K, 4, NCP) zero padded; cached per parameter object."""
-    import weakref
-    key = ("c2", id(weight))
-    hit = _pack_cache.get(key)
-    if hit is not None and hit[0]() is weight and hit[1] == weight._version:
-        return hit[2]
-    cout, cin, k, _ = weight.shape
-    groups = (cin + 3) // 4
-    ncp = _conv2d_ncp(cout)
-    full = torch.zeros((groups * 4, k * k, cout), dtype=_F32, device=weight.device)
-    full[:cin] = weight.detach().to(_F32).permute(1, 2, 3, 0).reshape(cin, k * k, cout)
-    wp = torch.zeros((groups, k * k, 4, ncp), dtype=_F32, device=weight.device)
-    wp[..., :cout] = full.view(groups, 4, k * k, cout).transpose(1, 2)
-    try:
-        _pack_cache[key] = (weakref.ref(weight), weight._version, wp)
-    except TypeError:
-        pass
-    return wp
+    """(Cout,Cin,K,K) -> (ceil(Cin/4), K*K, 4, NCP) zero padded; cached per parameter."""
+    def make():
+        cout, cin, k, _ = weight.shape
+        groups = (cin + 3) // 4
+        ncp = _conv2d_ncp(cout)
+        full = torch.zeros((groups * 4, k * k, cout), dtype=_F32, device=weight.device)
+        full[:cin] = weight.detach().to(_F32).permute(1, 2, 3, 0).reshape(cin, k * k, cout)
+        wp = torch.zeros((groups, k * k, 4, ncp), dtype=_F32, device=weight.device)
+        wp[..., :cout] = full.view(groups, 4, k * k, cout).transpose(1, 2)
+        return wp
+    return _cached_pack(("c2", id(weight)), (weight,), make)
 
 
 def conv2d(x, conv, in_affine, samples_per_stat, want_stats, bn=None):
@@ -422,21 +487,14 @@ def conv3d_k3_few(x, weight):
 
 
 def pack_conv3d_weight(weight):
-    """(Cout,Cin,3,3,3) -> (Cin/4, 27, 4, 16*ceil(Cout/16)) zero padded; cached like pack_weight_t."""
-    import weakref
-    key = ("c3", id(weight))
-    hit = _pack_cache.get(key)
-    if hit is not None and hit[0]() is weight and hit[1] == weight._version:
-        return hit[2]
-    cout, cin = weight.shape[:2]
-    ncp = (cout + 15) // 16 * 16
-    wp = torch.zeros((cin // 4, 27, 4, ncp), dtype=_F32, device=weight.device)
-    wp[..., :cout] = weight.detach().to(_F32).permute(1, 2, 3, 4, 0).reshape(cin // 4, 4, 27, cout).transpose(1, 2)
-    try:
-        _pack_cache[key] = (weakref.ref(weight), weight._version, wp)
-    except TypeError:
-        pass
-    return wp
+    """(Cout,Cin,3,3,3) -> (Cin/4, 27, 4, 16*ceil(Cout/16)) zero padded; cached per parameter."""
+    def make():
+        cout, cin = weight.shape[:2]
+        ncp = (cout + 15) // 16 * 16
+        wp = torch.zeros((cin // 4, 27, 4, ncp), dtype=_F32, device=weight.device)
+        wp[..., :cout] = weight.detach().to(_F32).permute(1, 2, 3, 4, 0).reshape(cin // 4, 4, 27, cout).transpose(1, 2)
+        return wp
+    return _cached_pack(("c3", id(weight)), (weight,), make)
 
 
 def batch_norm_act_(x, bn, relu, samples_per_stat, partials=None, addend=None):

@@ -206,9 +206,20 @@ def test_graphed_forward_matches_eager_and_replays_on_new_scenes(dev):
         assert torch.equal(got_a[key], want_a[key]), key
         assert torch.equal(got_b[key], want_b[key]), key
     assert not torch.equal(got_a["flow2"], got_b["flow2"])
-    # warm-up (1) + capture (1: capture itself does not execute) + 2 replays worth of BN updates
+    # warm-up runs on a snapshot of the BN buffers and capture does not execute: 2 replays worth of updates
     nbt = int(graphed_net.flow_mlp[0][0].bn.num_batches_tracked)
-    assert nbt == (1 + 2) * 5, nbt
+    assert nbt == 2 * 5, nbt
+    # weights changed after capture (param.data swap, as EMA / load_state_dict do): the replay must not serve
+    # the packs baked into the graph -- it re-captures and matches eager on the new weights
+    with torch.no_grad():
+        for net in (eager, graphed_net):
+            w = net.flow_mlp[0][0].conv.weight
+            w.data = w.data * 1.5
+            net.flow_edge_conv[1].conv1.weight.mul_(0.5)
+        want_c = eager(_to(data_a, dev), img_scales, inter_scales, isFlow=True, isTest=True)
+        got_c = g(_to(data_a, dev))
+    assert g.recaptures == 1
+    assert torch.equal(got_c["flow2"], want_c["flow2"]) and not torch.equal(want_c["flow2"], want_a["flow2"])
 
 
 @pytest.mark.parametrize("cfg", ["cfg1", "cfg3"])

@@ -137,3 +137,36 @@ def test_reference_model_py_imports_unchanged_on_our_operator_layer():
     want = json.load(open(os.path.join(GOLDEN_DIR, "state_dict_keys.json")))
     assert {k: list(v.shape) for k, v in net.state_dict().items()} == want
     assert ref.get_knn_3d.__module__ == "pointmvsnet_amd.utils.torch_utils"
+
+
+def test_pack_cache_follows_data_swaps_and_pins():
+    """``param.data = ...`` / ``module.double()`` do not bump ``_version``; the cache must still miss."""
+    from pointmvsnet_amd import pointflow as pf
+    w = torch.nn.Parameter(torch.randn(16, 8, 1))
+    a, _ = pf.pack_weight_t(w)
+    assert pf.pack_weight_t(w)[0] is a
+    w.data = torch.randn(16, 8, 1)                        # version counter unchanged, storage moved
+    b, _ = pf.pack_weight_t(w)
+    assert b is not a and torch.equal(b[:, :16], w.detach()[:, :, 0].t())
+    with torch.no_grad():
+        w.add_(1.0)                                       # in-place update: version counter
+    c, _ = pf.pack_weight_t(w)
+    assert c is not b and torch.equal(c[:, :16], w.detach()[:, :, 0].t())
+    conv = torch.nn.Conv2d(8, 16, 3, bias=False)
+    p1 = pf.pack_conv2d_weight(conv.weight)
+    conv.double()                                         # dtype change through .data
+    p2 = pf.pack_conv2d_weight(conv.weight)
+    assert p2 is not p1 and p2.dtype == torch.float32
+    # pinned entries survive eviction pressure; unpinned least-recently-used ones go first
+    pf.pack_log_begin()
+    keep = torch.nn.Parameter(torch.randn(4, 4, 1))
+    pk, _ = pf.pack_weight_t(keep)
+    pins = pf.pack_log_end(pin=True)
+    junk = [torch.nn.Parameter(torch.randn(4, 4, 1)) for _ in range(300)]
+    for j in junk:
+        pf.pack_weight_t(j)
+    assert pf.pack_weight_t(keep)[0] is pk and len(pf._pack_cache) <= pf._PACK_CAP + 1
+    assert not pf.pack_entries_stale(pins)
+    keep.data = torch.zeros(4, 4, 1)
+    assert pf.pack_entries_stale(pins)
+    pf.pack_unpin(pins)
