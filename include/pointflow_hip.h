@@ -246,6 +246,28 @@ int pf_edge_apply_f32(const float* LE, int64_t ldle, int C, const int64_t* idx, 
                       int concat, float* Y, int64_t ldy, const uint8_t* codes, int lat_ks, int lat_h, int lat_w,
                       void* stream);
 
+/* ---- EdgeConv backward (training, BASELINE config 4) ------------------------------------------------
+ * Gradient of pf_edge_apply's output w.r.t. the rows LE = [l | e] through the train-mode BatchNorm, without
+ * the (N, k, C) edge tensor the reference's autograd keeps (networks.py:18-45; its scatter is
+ * functions/csrc/gather_knn_kernel.cu:50-89): both passes recompute d = e[idx] - l.
+ * grad_y (G*Ng, ldg) point-major: [G_central C | G_diff C] (concat) or [G_diff C]; scale/shift/mean/invstd
+ * rows (S, ld_affine) in the same column order (scale = gamma*invstd, shift = beta - mean*scale of the
+ * forward; mean / invstd = its batch statistics).
+ *   reduce: partials (G, pf_stat_blocks(G,Ng), cols, 2) float64, cols = 2C | C, per column
+ *           (sum g, sum g*xhat) with g = [u > 0] * G / k (central half: [u > 0] * G) -> dbeta, dgamma
+ *   apply : grad_le (G*Ng, ldle) = [dl | de]; c1 = dbeta/M, c2 = dgamma/M rows (S, ld_affine), M = elements
+ *           behind the statistics of that column (diff: gps*Ng*k; central: gps*Ng).  grad_le is zeroed by
+ *           the call; de rows are accumulated with float atomics (as the reference's scatter).
+ * C in {32, 64}. */
+int pf_edge_backward_reduce_f32(const float* LE, int64_t ldle, int C, const int64_t* idx, int k, int G, int Ng,
+                                const float* grad_y, int64_t ldg, const float* scale, const float* shift,
+                                const float* mean, const float* invstd, int ld_affine, int groups_per_stat,
+                                int concat, double* partials, void* stream);
+int pf_edge_backward_apply_f32(const float* LE, int64_t ldle, int C, const int64_t* idx, int k, int G, int Ng,
+                               const float* grad_y, int64_t ldg, const float* scale, const float* shift,
+                               const float* mean, const float* invstd, const float* c1, const float* c2,
+                               int ld_affine, int groups_per_stat, int concat, float* grad_le, void* stream);
+
 /* ---- train-mode BatchNorm for the conv stacks around the path (ImageConv / VolumeConv) ----------
  * x (N, C, S) contiguous (NCHW / NCDHW with S = spatial size).  pf_channel_stats_f32 writes float64
  * partial (sum, sum of squares) per (sample, block, channel): partials (N, pf_norm_blocks(S), C, 2), the

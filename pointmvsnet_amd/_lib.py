@@ -68,6 +68,9 @@ PROTOTYPES = {
     "pf_channel_bn_fused_f32": ([_vp, _vp, _i64, _i64, _i64, _i, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _i, _vp], _i),
     "pf_edge_stats_f32": ([_vp, _i64, _i, _vp, _i, _i, _i, _vp, ctypes.POINTER(BnJob), _i, _vp,
                            _vp, _i, _i, _i, _vp], _i),
+    "pf_edge_backward_reduce_f32": ([_vp, _i64, _i, _vp, _i, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp], _i),
+    "pf_edge_backward_apply_f32": ([_vp, _i64, _i, _vp, _i, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i,
+                                    _vp, _vp], _i),
     "pf_bn_finalize_f32": ([_vp, _i, _i, _i, _i, _d, _d, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _i, _vp], _i),
     "pf_bn_finalize_jobs_f32": ([ctypes.POINTER(BnJob), _i, _vp], _i),
     "pf_edge_apply_f32": ([_vp, _i64, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _i64, _vp, _i, _i, _i, _vp], _i),

@@ -265,8 +265,13 @@ __global__ __launch_bounds__(256, MINW) void conv2d_kernel(const float* __restri
         q += red[((w * NCP) + tid) * 2 + 1];
       }
       double* o = partials + (((int64_t)n * gridDim.x + blockIdx.x) * g.Cout + tid) * 2;
-      pf_row_store(o, s);
-      pf_row_store(o + 1, q);
+      if (tail.njobs > 0) {
+        pf_row_store(o, s);
+        pf_row_store(o + 1, q);
+      } else {
+        o[0] = s;
+        o[1] = q;
+      }
     }
     // this layer's BatchNorm finalize by the last block (pf_bn_tail.h); the staging buffers are free by now
     if (tail.njobs > 0) pf_bn_tail<256>(tail, n, blockIdx.x, reinterpret_cast<double*>(lds));

@@ -188,7 +188,9 @@ __global__ __launch_bounds__(256) void conv2d_small_kernel(const float* __restri
     __syncthreads();
     if (tid < 2 * COUT) {
       const double v = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
-      pf_row_store(partials + (((int64_t)n * gridDim.x + blockIdx.x) * COUT + (tid >> 1)) * 2 + (tid & 1), v);
+      double* o = partials + (((int64_t)n * gridDim.x + blockIdx.x) * COUT + (tid >> 1)) * 2 + (tid & 1);
+      if (tail.njobs > 0) pf_row_store(o, v);
+      else *o = v;
     }
     // this layer's BatchNorm finalize by the last block (pf_bn_tail.h); the patch buffer is free by now
     static_assert(sizeof(xs) >= sizeof(double) * kTailSmemDoubles, "the BatchNorm tail borrows the patch buffer");

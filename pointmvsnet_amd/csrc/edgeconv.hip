@@ -206,8 +206,13 @@ __global__ __launch_bounds__(256, 2) void pointwise_gemm_kernel(
         q += red[((w * NC) + tid) * 2 + 1];
       }
       double* o = partials + (((int64_t)g * T + tb) * NC + tid) * 2;
-      pf_row_store(o, s);
-      pf_row_store(o + 1, q);
+      if (tail.njobs > 0) {                // rows another CU reduces go out write-through (pf_bn_tail.h)
+        pf_row_store(o, s);
+        pf_row_store(o + 1, q);
+      } else {
+        o[0] = s;
+        o[1] = q;
+      }
     }
     // BatchNorm finalize by the last block (pf_bn_tail.h); the staging buffers are free by now
     if (tail.njobs > 0) pf_bn_tail<256>(tail, g, tb, red);
@@ -350,7 +355,9 @@ __global__ __launch_bounds__(256) void edge_stats_kernel(const float* __restrict
     const int qq = tid / 8, comp = tid % 8;
     double acc = 0.0;
     for (int s = 0; s < PPB; ++s) acc += red[(s * Q + qq) * 8 + comp];
-    pf_row_store(partials + (((int64_t)g * T + tb) * C + 4 * qq + (comp & 3)) * 2 + (comp >> 2), acc);
+    double* o = partials + (((int64_t)g * T + tb) * C + 4 * qq + (comp & 3)) * 2 + (comp >> 2);
+    if (tail.njobs > 0) pf_row_store(o, acc);
+    else *o = acc;
   }
   if (tail.njobs > 0) pf_bn_tail<256>(tail, g, tb, red);
 }
@@ -430,6 +437,225 @@ __global__ __launch_bounds__(256) void edge_apply_kernel(const float* __restrict
     }
   }
   (void)bad;
+}
+
+// ------------------------------------------------------------------------------------------------
+// EdgeConv backward (BASELINE config 4, training).  The reference differentiates the composition
+// conv1d / gather_knn / cat / BatchNorm2d / ReLU / mean (networks.py:18-45), which keeps the (B,2C,N,16)
+// edge tensor -- 839 MB at the 102 400-point lattice -- alive for backward and scatters through it with
+// atomicAdd (functions/csrc/gather_knn_kernel.cu:50-89).  Here nothing of size N*k is stored: both passes
+// recompute d = e[idx] - l from the saved (N, 2C) rows [l | e].
+//
+// With u = a*d + b (a = gamma*invstd, b = beta - mean*a), xhat = (d - mean)*invstd, y = mean_j relu(u_j)
+// and the upstream gradient G: g_j = [u_j > 0] * G / k;  dbeta = sum g;  dgamma = sum g*xhat;
+// dd_j = a * (g_j - dbeta/M - xhat_j * dgamma/M)  (M = elements behind the batch statistics);
+// dl = -sum_j dd_j,  de[idx_j] += dd_j.  The central half of EdgeConv (k identical copies of l through the
+// same BatchNorm) reduces to  dl += a_c * (g_c - dbeta_c/N - xhat_c * dgamma_c/N),  g_c = [u_c > 0] * G_c.
+//
+//   pass 1 (edge_bwd_reduce)  per-block float64 partial sums of (g, g*xhat) per channel -> dbeta, dgamma
+//   pass 2 (edge_bwd_apply)   dl rows (plain stores) and de rows (float atomics, like the reference)
+// The two GEMMs that follow (dX = [dl|de] W, dW = [dl|de]^T X) are plain library GEMMs on the host side.
+// ------------------------------------------------------------------------------------------------
+struct EdgeBwdAffine {
+  const float* scale;      // (S, ld) [central C | diff C] (concat) or [diff C]
+  const float* shift;
+  const float* mean;
+  const float* invstd;
+  const float* c1;         // pass 2: dbeta / M  (central columns: / N)
+  const float* c2;         // pass 2: dgamma / M
+  int ld, groups_per_stat, concat;
+};
+
+template <int C, int K>
+__global__ __launch_bounds__(256) void edge_bwd_reduce_kernel(const float* __restrict__ LE, int64_t ldle,
+                                                              const int64_t* __restrict__ idx, int k, int Ng,
+                                                              const float* __restrict__ Gy, int64_t ldg,
+                                                              EdgeBwdAffine A, double* __restrict__ partials, int T,
+                                                              unsigned* __restrict__ status) {
+  constexpr int Q = C / 4;
+  constexpr int PPB = 256 / Q;
+  __shared__ double red[256 * 16];
+  const int tid = threadIdx.x;
+  const int q = tid % Q, pl = tid / Q;
+  const int g = blockIdx.y, tb = blockIdx.x;
+  const int tiles = (Ng + TILE - 1) / TILE;
+  const int64_t gbase = (int64_t)g * Ng;
+  const int64_t so = (int64_t)(g / A.groups_per_stat) * A.ld;
+  const int doff = A.concat ? C : 0;
+  const float4 a = ld4(A.scale + so + doff + 4 * q), b = ld4(A.shift + so + doff + 4 * q);
+  const float4 mu = ld4(A.mean + so + doff + 4 * q), is = ld4(A.invstd + so + doff + 4 * q);
+  float4 ac = {0, 0, 0, 0}, bc = {0, 0, 0, 0}, muc = {0, 0, 0, 0}, isc = {0, 0, 0, 0};
+  if (A.concat) {
+    ac = ld4(A.scale + so + 4 * q);
+    bc = ld4(A.shift + so + 4 * q);
+    muc = ld4(A.mean + so + 4 * q);
+    isc = ld4(A.invstd + so + 4 * q);
+  }
+  const float kf = (float)k;
+  double acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.0;
+  bool bad = false;
+  for (int tile = tb; tile < tiles; tile += T) {
+    const int n0 = tile * TILE;
+    for (int p = pl; p < TILE; p += PPB) {
+      const int n = n0 + p;
+      if (n >= Ng) break;
+      const int64_t row = gbase + n;
+      const float4 l = ld4(LE + row * ldle + 4 * q);
+      const float4 gy = ld4(Gy + row * ldg + doff + 4 * q);
+      const float gd[4] = {gy.x / kf, gy.y / kf, gy.z / kf, gy.w / kf};
+      const float lv[4] = {l.x, l.y, l.z, l.w};
+      const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+      const float mv[4] = {mu.x, mu.y, mu.z, mu.w}, iv[4] = {is.x, is.y, is.z, is.w};
+      float sg[4] = {0, 0, 0, 0}, sx[4] = {0, 0, 0, 0};
+      const int64_t* ip = idx + row * k;
+      auto pair = [&](const float4& e) {
+        const float ev[4] = {e.x, e.y, e.z, e.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float d = ev[c] - lv[c];
+          const float u = fmaf(d, av[c], bv[c]);
+          const float gg = u > 0.0f ? gd[c] : 0.0f;
+          sg[c] += gg;
+          sx[c] += gg * ((d - mv[c]) * iv[c]);
+        }
+      };
+      if constexpr (K > 0) {
+        float4 e[K > 0 ? K : 1];
+        gather_rows<C, (K > 0 ? K : 2)>(LE, ldle, ip, gbase, Ng, q, e, bad);
+#pragma unroll
+        for (int j = 0; j < K; ++j) pair(e[j]);
+      } else {
+        for (int j = 0; j < k; ++j) {
+          int64_t i = ip[j];
+          if (i < 0 || i >= Ng) {
+            bad = true;
+            i = i < 0 ? 0 : Ng - 1;
+          }
+          pair(ld4(LE + (gbase + i) * ldle + C + 4 * q));
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        acc[c] += (double)sg[c];
+        acc[4 + c] += (double)sx[c];
+      }
+      if (A.concat) {
+        const float4 gc4 = ld4(Gy + row * ldg + 4 * q);
+        const float gcv[4] = {gc4.x, gc4.y, gc4.z, gc4.w};
+        const float acv[4] = {ac.x, ac.y, ac.z, ac.w}, bcv[4] = {bc.x, bc.y, bc.z, bc.w};
+        const float mcv[4] = {muc.x, muc.y, muc.z, muc.w}, icv[4] = {isc.x, isc.y, isc.z, isc.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float u = fmaf(lv[c], acv[c], bcv[c]);
+          const float gg = u > 0.0f ? gcv[c] : 0.0f;
+          acc[8 + c] += (double)gg;
+          acc[12 + c] += (double)(gg * ((lv[c] - mcv[c]) * icv[c]));
+        }
+      }
+    }
+  }
+  if (bad) atomicOr(status, PF_STATUS_BAD_INDEX);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) red[tid * 16 + i] = acc[i];
+  __syncthreads();
+  // partial row (cols = C or 2C, 2 doubles each): column order follows the BatchNorm channels
+  const int cols = A.concat ? 2 * C : C;
+  for (int o = tid; o < cols * 2; o += 256) {
+    const int col = o >> 1, comp = o & 1;                 // comp 0: sum g, 1: sum g*xhat
+    const bool central = A.concat && col < C;
+    const int ch = central ? col : col - doff;
+    const int qq = ch >> 2, cc = ch & 3;
+    const int slot = (central ? 8 : 0) + 4 * comp + cc;
+    double v = 0.0;
+    for (int s = 0; s < PPB; ++s) v += red[(s * Q + qq) * 16 + slot];
+    partials[(((int64_t)g * T + tb) * cols + col) * 2 + comp] = v;
+  }
+}
+
+template <int C, int K>
+__global__ __launch_bounds__(256) void edge_bwd_apply_kernel(const float* __restrict__ LE, int64_t ldle,
+                                                             const int64_t* __restrict__ idx, int k, int Ng,
+                                                             const float* __restrict__ Gy, int64_t ldg,
+                                                             EdgeBwdAffine A, float* __restrict__ dLE, int T) {
+  constexpr int Q = C / 4;
+  constexpr int PPB = 256 / Q;
+  const int tid = threadIdx.x;
+  const int q = tid % Q, pl = tid / Q;
+  const int g = blockIdx.y, tb = blockIdx.x;
+  const int tiles = (Ng + TILE - 1) / TILE;
+  const int64_t gbase = (int64_t)g * Ng;
+  const int64_t so = (int64_t)(g / A.groups_per_stat) * A.ld;
+  const int doff = A.concat ? C : 0;
+  const float4 a = ld4(A.scale + so + doff + 4 * q), b = ld4(A.shift + so + doff + 4 * q);
+  const float4 mu = ld4(A.mean + so + doff + 4 * q), is = ld4(A.invstd + so + doff + 4 * q);
+  const float4 k1 = ld4(A.c1 + so + doff + 4 * q), k2 = ld4(A.c2 + so + doff + 4 * q);
+  const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+  const float mv[4] = {mu.x, mu.y, mu.z, mu.w}, iv[4] = {is.x, is.y, is.z, is.w};
+  const float c1v[4] = {k1.x, k1.y, k1.z, k1.w}, c2v[4] = {k2.x, k2.y, k2.z, k2.w};
+  const float kf = (float)k;
+  for (int tile = tb; tile < tiles; tile += T) {
+    const int n0 = tile * TILE;
+    for (int p = pl; p < TILE; p += PPB) {
+      const int n = n0 + p;
+      if (n >= Ng) break;
+      const int64_t row = gbase + n;
+      const float4 l = ld4(LE + row * ldle + 4 * q);
+      const float4 gy = ld4(Gy + row * ldg + doff + 4 * q);
+      const float gd[4] = {gy.x / kf, gy.y / kf, gy.z / kf, gy.w / kf};
+      const float lv[4] = {l.x, l.y, l.z, l.w};
+      float dl[4] = {0, 0, 0, 0};
+      const int64_t* ip = idx + row * k;
+      auto pair = [&](const float4& e, int64_t i) {
+        const float ev[4] = {e.x, e.y, e.z, e.w};
+        float* de = dLE + (gbase + i) * ldle + C + 4 * q;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float d = ev[c] - lv[c];
+          const float u = fmaf(d, av[c], bv[c]);
+          const float gg = u > 0.0f ? gd[c] : 0.0f;
+          const float dd = av[c] * ((gg - c1v[c]) - ((d - mv[c]) * iv[c]) * c2v[c]);
+          dl[c] -= dd;
+          unsafeAtomicAdd(de + c, dd);
+        }
+      };
+      if constexpr (K > 0) {
+        float4 e[K > 0 ? K : 1];
+        bool bad = false;
+        gather_rows<C, (K > 0 ? K : 2)>(LE, ldle, ip, gbase, Ng, q, e, bad);
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+          int64_t i = ip[j];
+          i = i < 0 ? 0 : (i >= Ng ? Ng - 1 : i);
+          pair(e[j], i);
+        }
+      } else {
+        for (int j = 0; j < k; ++j) {
+          int64_t i = ip[j];
+          i = i < 0 ? 0 : (i >= Ng ? Ng - 1 : i);
+          pair(ld4(LE + (gbase + i) * ldle + C + 4 * q), i);
+        }
+      }
+      if (A.concat) {
+        const float4 gc4 = ld4(Gy + row * ldg + 4 * q);
+        const float gcv[4] = {gc4.x, gc4.y, gc4.z, gc4.w};
+        const float4 ac = ld4(A.scale + so + 4 * q), bc = ld4(A.shift + so + 4 * q);
+        const float4 muc = ld4(A.mean + so + 4 * q), isc = ld4(A.invstd + so + 4 * q);
+        const float4 k1c = ld4(A.c1 + so + 4 * q), k2c = ld4(A.c2 + so + 4 * q);
+        const float acv[4] = {ac.x, ac.y, ac.z, ac.w}, bcv[4] = {bc.x, bc.y, bc.z, bc.w};
+        const float mcv[4] = {muc.x, muc.y, muc.z, muc.w}, icv[4] = {isc.x, isc.y, isc.z, isc.w};
+        const float c1c[4] = {k1c.x, k1c.y, k1c.z, k1c.w}, c2c[4] = {k2c.x, k2c.y, k2c.z, k2c.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float u = fmaf(lv[c], acv[c], bcv[c]);
+          const float gg = u > 0.0f ? gcv[c] : 0.0f;
+          dl[c] += acv[c] * ((gg - c1c[c]) - ((lv[c] - mcv[c]) * icv[c]) * c2c[c]);
+        }
+      }
+      *reinterpret_cast<float4*>(dLE + row * ldle + 4 * q) = make_float4(dl[0], dl[1], dl[2], dl[3]);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -786,6 +1012,57 @@ int pf_edge_apply_f32(const float* LE, int64_t ldle, int C, const int64_t* idx, 
     if (C == 32) PF_EA(32, 0); else if (C == 64) PF_EA(64, 0); else PF_EA(128, 0);
   }
 #undef PF_EA
+  return pf_launch_status();
+}
+
+int pf_edge_backward_reduce_f32(const float* LE, int64_t ldle, int C, const int64_t* idx, int k, int G, int Ng,
+                                const float* grad_y, int64_t ldg, const float* scale, const float* shift,
+                                const float* mean, const float* invstd, int ld_affine, int groups_per_stat,
+                                int concat, double* partials, void* stream) {
+  PF_REQUIRE(G >= 0 && Ng >= 0 && k >= 1 && ldle >= 2 * (int64_t)C && (ldle % 4) == 0 && G <= 65535);
+  PF_REQUIRE(groups_per_stat >= 1 && (ldg % 4) == 0 && ldg >= (concat ? 2 : 1) * (int64_t)C);
+  PF_REQUIRE((ld_affine % 4) == 0 && ld_affine >= (concat ? 2 : 1) * C);
+  if (C != 32 && C != 64) return PF_ERR_UNSUPPORTED;
+  if (G == 0 || Ng == 0) return PF_OK;
+  PF_REQUIRE(LE && idx && grad_y && scale && shift && mean && invstd && partials);
+  unsigned* status = pf_status_ptr();
+  PF_REQUIRE(status != nullptr);
+  const EdgeBwdAffine A{scale, shift, mean, invstd, nullptr, nullptr, ld_affine, groups_per_stat, concat};
+  const int T = pf_stat_blocks(G, Ng);
+  dim3 grid((unsigned)T, (unsigned)G);
+  hipStream_t s = (hipStream_t)stream;
+#define PF_EBR(CV, KV) hipLaunchKernelGGL((edge_bwd_reduce_kernel<CV, KV>), grid, dim3(256), 0, s, LE, ldle, idx, k, Ng, grad_y, ldg, A, partials, T, status)
+  if (k == 16) {
+    if (C == 32) PF_EBR(32, 16); else PF_EBR(64, 16);
+  } else {
+    if (C == 32) PF_EBR(32, 0); else PF_EBR(64, 0);
+  }
+#undef PF_EBR
+  return pf_launch_status();
+}
+
+int pf_edge_backward_apply_f32(const float* LE, int64_t ldle, int C, const int64_t* idx, int k, int G, int Ng,
+                               const float* grad_y, int64_t ldg, const float* scale, const float* shift,
+                               const float* mean, const float* invstd, const float* c1, const float* c2,
+                               int ld_affine, int groups_per_stat, int concat, float* grad_le, void* stream) {
+  PF_REQUIRE(G >= 0 && Ng >= 0 && k >= 1 && ldle >= 2 * (int64_t)C && (ldle % 4) == 0 && G <= 65535);
+  PF_REQUIRE(groups_per_stat >= 1 && (ldg % 4) == 0 && ldg >= (concat ? 2 : 1) * (int64_t)C);
+  PF_REQUIRE((ld_affine % 4) == 0 && ld_affine >= (concat ? 2 : 1) * C);
+  if (C != 32 && C != 64) return PF_ERR_UNSUPPORTED;
+  if (G == 0 || Ng == 0) return PF_OK;
+  PF_REQUIRE(LE && idx && grad_y && scale && shift && mean && invstd && c1 && c2 && grad_le);
+  hipStream_t s = (hipStream_t)stream;
+  PF_HIP(hipMemsetAsync(grad_le, 0, sizeof(float) * (size_t)G * Ng * ldle, s));
+  const EdgeBwdAffine A{scale, shift, mean, invstd, c1, c2, ld_affine, groups_per_stat, concat};
+  const int T = pf_stat_blocks(G, Ng);
+  dim3 grid((unsigned)T, (unsigned)G);
+#define PF_EBA(CV, KV) hipLaunchKernelGGL((edge_bwd_apply_kernel<CV, KV>), grid, dim3(256), 0, s, LE, ldle, idx, k, Ng, grad_y, ldg, A, grad_le, T)
+  if (k == 16) {
+    if (C == 32) PF_EBA(32, 16); else PF_EBA(64, 16);
+  } else {
+    if (C == 32) PF_EBA(32, 0); else PF_EBA(64, 0);
+  }
+#undef PF_EBA
   return pf_launch_status();
 }
 

@@ -127,9 +127,13 @@ def _pack_weight_t(*convs):
 
 import os as _os
 
-# PF_FUSED_BN=0 restores the separate BatchNorm finalize launches (A/B measurements only; same results up to the
-# summation order of the float64 statistics).
-FUSED_BN = int(_os.environ.get("PF_FUSED_BN", "1"))
+# PF_FUSED_BN=1 folds every BatchNorm finalize into the kernel that produces its statistics (last block done,
+# csrc/pf_bn_tail.h) instead of a separate launch.  Measured on MI355X (profiles/r02a_fused_bn_ab.log, same box,
+# hipGraph replay of BASELINE config 2): 553 depth maps/s fused vs 570 with the 25 separate finalize launches --
+# the write-through publish, the ticket round trips of every block and the serial two-hop reduction by the last
+# block cost 5-10 us per launch (rocprofv3), more than the ~5.5 us a trivial dependent graph node costs.  So the
+# separate launch stays the default; the tail is kept, tested, for devices / drivers where a node costs more.
+FUSED_BN = int(_os.environ.get("PF_FUSED_BN", "0"))
 # PF_KNN_CODES=0: the PointFlow stage hands int64 neighbour indices to the EdgeConv passes (round-1 form)
 KNN_CODES = int(_os.environ.get("PF_KNN_CODES", "1"))
 

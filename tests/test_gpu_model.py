@@ -33,11 +33,13 @@ ENVELOPE = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)
                                        "sensitivity_envelope.json")))
 
 
-def envelope_bounds(cfg, key):
+def envelope_bounds(cfg, key, npix):
     """(max fraction of pixels beyond 1e-4, max relative deviation) the GPU result may show for ``key`` of
-    configuration ``cfg``: 2x / 3x what the reference itself shows under a 1-ulp perturbation of its coarse depth."""
+    configuration ``cfg``: 2x / 3x what the reference itself shows under a 1-ulp perturbation of its coarse depth.
+    The fraction gets a small-sample allowance of 4 pixels (a 16x24 map has 384 of them: one flipped neighbour
+    choice is 0.26 % there), at least 0.1 %."""
     e = ENVELOPE[cfg][key]
-    return 2.0 * e["frac_gt_1e4"] + 1e-3, min(3.0 * e["max"], 2e-2)
+    return 2.0 * e["frac_gt_1e4"] + max(1e-3, 4.0 / npix), min(3.0 * e["max"], 2e-2)
 
 
 def _to(data, dev):
@@ -57,7 +59,7 @@ def _compare(preds, g, tag, cfg):
             continue
         rel = (preds[key].cpu() - g[key]).abs() / g[key].abs()
         med, mx, frac = float(rel.median()), float(rel.max()), float((rel > 1e-4).float().mean())
-        frac_max, rel_max = envelope_bounds(cfg, key)
+        frac_max, rel_max = envelope_bounds(cfg, key, rel.numel())
         report("%s_%s" % (tag, key), rel_median=med, rel_max=mx, frac_gt_1e4=frac, frac_bound=frac_max,
                max_bound=rel_max)
         assert mx < rel_max and frac < frac_max, (key, med, mx, frac, rel_max, frac_max)

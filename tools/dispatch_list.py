@@ -6,7 +6,7 @@ import sys
 
 def main():
     db, out = sys.argv[1], sys.argv[2]
-    marker = sys.argv[3] if len(sys.argv) > 3 else "fetch_variance"
+    marker = sys.argv[3] if len(sys.argv) > 3 else "frustum_variance"
     con = sqlite3.connect(db)
     rows = con.execute("select name, start, duration/1000.0, grid_x, grid_y, grid_z, workgroup_x, vgpr_count, lds_size "
                        "from kernels order by start").fetchall()

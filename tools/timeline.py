@@ -7,7 +7,7 @@ import sys
 
 def main():
     db, out = sys.argv[1], sys.argv[2]
-    marker = sys.argv[3] if len(sys.argv) > 3 else "fetch_variance"
+    marker = sys.argv[3] if len(sys.argv) > 3 else "frustum_variance"
     con = sqlite3.connect(db)
     cols = [r[1] for r in con.execute("pragma table_info(kernels)")]
     qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else "0")
