@@ -55,6 +55,47 @@ def allreduce_gradients_sum(module, group=None):
     return int(flat.numel())
 
 
+class GradBucket(object):
+    """The single flat float32 gradient bucket of the data-parallel training step, kept for the life of the
+    model: every parameter's ``.grad`` is a VIEW into it, so backward accumulates straight into the bucket and
+    the step's gradient exchange is exactly one in-place ``all_reduce(SUM)`` (2.8 MB for PointMVSNet's 698 936
+    parameters) with no gather / scatter copies around it."""
+
+    def __init__(self, module):
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        if not self.params:
+            raise RuntimeError("GradBucket: the module has no trainable parameters")
+        dev = self.params[0].device
+        self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=torch.float32, device=dev)
+        offset = 0
+        for p in self.params:
+            if p.dtype != torch.float32 or p.device != dev:
+                raise RuntimeError("GradBucket: parameters must be float32 on one device")
+            n = p.numel()
+            p.grad = self.flat[offset:offset + n].view_as(p)
+            offset += n
+
+    def numel(self):
+        return int(self.flat.numel())
+
+    def zero_(self):
+        """Replaces optimizer.zero_grad(): the views stay attached to the bucket."""
+        self.flat.zero_()
+
+    def attached(self):
+        base = self.flat.untyped_storage().data_ptr()
+        return all(p.grad is not None and p.grad.untyped_storage().data_ptr() == base for p in self.params)
+
+    def allreduce_sum(self, group=None):
+        """One SUM all-reduce over RCCL/xGMI (gloo on CPU); a no-op for a single process."""
+        if not self.attached():
+            raise RuntimeError("GradBucket: a parameter's .grad was replaced (optimizer.zero_grad(set_to_none=True)?); "
+                               "use GradBucket.zero_()")
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+        return self.numel()
+
+
 def broadcast_parameters(module, src=0, group=None):
     """Make every replica start from rank ``src``'s parameters and buffers."""
     if not (dist.is_available() and dist.is_initialized()):

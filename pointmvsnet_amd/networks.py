@@ -24,6 +24,56 @@ from .nn.conv import *  # noqa: F401,F403  (the reference re-exports the conv bl
 from .nn.conv import Conv2d, Conv3d, Deconv3d
 
 
+class _EdgeConvTrain(torch.autograd.Function):
+    """EdgeConv / EdgeConvNoC with a train-mode BatchNorm as ONE autograd node on the fused HIP kernels.
+
+    Forward = the inference kernels (GEMM, pair statistics, apply); saved for backward: the input, the rows
+    [l | e] and per-channel statistics -- not the (B,2C,N,k) edge tensor the reference's autograd keeps
+    (networks.py:18-45: 839 MB for the 102 400-point lattice of BASELINE config 4).  Backward recomputes
+    d = e[idx] - l in two gather passes (BatchNorm reduction terms, then dl / scatter-added de), followed by
+    two plain GEMMs for dX and dW."""
+
+    @staticmethod
+    def forward(ctx, feature, knn_inds, w1, w2, gamma, beta, bn, concat):
+        B, cin, N = feature.shape
+        C = w1.shape[0]
+        k = knn_inds.shape[2]
+        width = (2 if concat else 1) * C
+        x = feature.detach().float().contiguous()
+        idx = knn_inds.contiguous()
+        out = torch.empty((B * N, width), dtype=torch.float32, device=x.device)
+        keep = {}
+        with torch.cuda.device(x.device):
+            pointflow.edge_conv_fused(x, False, 0, cin, B, N, idx, w1, w2, bn, concat, out, width,
+                                      groups_per_stat=B, keep=keep)
+            pointflow.flush_counters()
+        ctx.keep = keep
+        ctx.save_for_backward(x, idx, w1, w2)
+        ctx.meta = (bool(concat), C, k, B, N, cin)
+        return out.view(B, N, width).transpose(1, 2).contiguous()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, idx, w1, w2 = ctx.saved_tensors
+        concat, C, k, B, N, cin = ctx.meta
+        width = (2 if concat else 1) * C
+        gy = grad_out.float().transpose(1, 2).contiguous().view(B * N, width)        # point-major rows
+        with torch.cuda.device(x.device):
+            grad_le, grad_gamma, grad_beta = pointflow.edge_conv_backward(ctx.keep, idx, gy, C, k, B, N, B, concat)
+        ctx.keep = None
+        dle = grad_le.view(B, N, 2 * C)
+        wcat = torch.cat([w1.detach().reshape(C, cin), w2.detach().reshape(C, cin)], dim=0).float()   # (2C, K)
+        grad_x = torch.matmul(wcat.t(), dle.transpose(1, 2))                          # (B, K, N)
+        grad_w = torch.matmul(dle.transpose(1, 2), x.transpose(1, 2)).sum(dim=0)      # (2C, K)
+        return (grad_x, None, grad_w[:C].reshape(w1.shape), grad_w[C:].reshape(w2.shape), grad_gamma, grad_beta,
+                None, None)
+
+
+# PF_FUSED_TRAIN=0: training runs the reference's composition (gather_knn + BatchNorm2d + ...) instead
+import os as _os
+FUSED_TRAIN = int(_os.environ.get("PF_FUSED_TRAIN", "1"))
+
+
 class _EdgeConvBase(nn.Module):
     concat = True
 
@@ -67,6 +117,10 @@ class _EdgeConvBase(nn.Module):
         if feature.dim() != 3 or knn_inds.dim() != 3 or knn_inds.dtype != torch.int64:
             raise RuntimeError("EdgeConv: expected feature (B,C,N) and int64 knn_inds (B,N,k)")
         if self._needs_graph(feature):
+            if (FUSED_TRAIN and self.bn.training and self.bn.momentum is not None and self.bn.affine
+                    and self.conv1.weight.shape[0] in (32, 64) and knn_inds.shape[2] >= 1):
+                return _EdgeConvTrain.apply(feature, knn_inds, self.conv1.weight, self.conv2.weight,
+                                            self.bn.weight, self.bn.bias, self.bn, self.concat)
             return self._forward_autograd(feature, knn_inds)
         if self.conv1.weight.shape[0] not in (32, 64) or knn_inds.shape[2] < 1:
             # widths the fused kernels are not built for (their GEMM emits [l | e] = 2*C_out <= 128 columns):

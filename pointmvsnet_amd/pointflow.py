@@ -548,12 +548,14 @@ def batch_norm_act_(x, bn, relu, samples_per_stat, partials=None, addend=None):
 # EdgeConv (rows E0 / E1 / E2)
 # ---------------------------------------------------------------------------------------------
 def edge_conv_fused(X, point_major, ldx, K, G, Ng, idx, conv1_w, conv2_w, bn, concat, Y, ldy,
-                    groups_per_stat=1, join=None, codes=None, lattice=None):
+                    groups_per_stat=1, join=None, codes=None, lattice=None, keep=None):
     """One EdgeConv / EdgeConvNoC layer on G groups of Ng points (reference networks.py:18-45, :56-81).
 
     X: channel-major (G,K,Ng) or point-major rows; idx (G,Ng,k) int64 group-local; Y: point-major view
     with ``ldy`` floats per point receiving [central | diff] (concat) or diff (NoC).  Alternatively to ``idx``:
-    ``codes`` (G,Ng,16) uint8 window codes of the lattice kNN with ``lattice`` = (window, H, W)."""
+    ``codes`` (G,Ng,16) uint8 window codes of the lattice kNN with ``lattice`` = (window, H, W).
+    ``keep`` (a dict) receives what the backward pass recomputes from: the rows LE = [l | e], the BatchNorm
+    affine rows and the batch statistics (mean, invstd) in the BatchNorm's channel order."""
     C = conv1_w.shape[0]
     k = idx.shape[-1] if idx is not None else int(codes.shape[-1])
     lat = (0, 1, 1) if codes is None else tuple(int(v) for v in lattice)
@@ -596,11 +598,53 @@ def edge_conv_fused(X, point_major, ldx, K, G, Ng, idx, conv1_w, conv2_w, bn, co
         sc, sh = eval_affine(bn, S, cbn)
         scale.copy_(sc.unsqueeze(0).expand(S, cbn))
         shift.copy_(sh.unsqueeze(0).expand(S, cbn))
+    if keep is not None:
+        if not training:
+            raise RuntimeError("edge_conv_fused(keep=...) needs a train-mode BatchNorm")
+        sums_d = part_d.view(S, -1, C, 2).sum(dim=1)                       # float64 (S, C, 2)
+        mean = sums_d[..., 0] / n_pairs
+        var = (sums_d[..., 1] / n_pairs - mean * mean).clamp_min(0.0)
+        if concat:
+            n_pts = float(groups_per_stat) * Ng
+            sums_l = part_l.view(S, -1, part_l.shape[2], 2)[:, :, :C].sum(dim=1)
+            mean_l = sums_l[..., 0] / n_pts
+            var_l = (sums_l[..., 1] / n_pts - mean_l * mean_l).clamp_min(0.0)
+            mean, var = torch.cat([mean_l, mean], dim=1), torch.cat([var_l, var], dim=1)
+        keep.update(LE=LE, scale=scale, shift=shift, mean=mean.to(_F32).contiguous(),
+                    invstd=torch.rsqrt(var + bn.eps).to(_F32).contiguous())
     _lib.call("pf_edge_apply_f32", _lib.ptr(LE), 2 * C, C, _lib.ptr(idx), k, G, Ng, _lib.ptr(scale),
               _lib.ptr(shift), cbn, groups_per_stat, int(bool(concat)), _lib.ptr(Y), int(ldy), _lib.ptr(codes),
               lat[0], lat[1], lat[2], _lib.stream(),
               algo_bytes=float(G) * Ng * (4.0 * C + (1.0 if codes is not None else 8.0) * k + 4.0 * C * k + 4.0 * cbn))
     return Y
+
+
+def edge_conv_backward(keep, idx, grad_y, C, k, G, Ng, groups_per_stat, concat):
+    """Gradient of edge_conv_fused's output rows w.r.t. LE = [l | e] and the BatchNorm affine parameters
+    (pf_edge_backward_reduce_f32 / _apply_f32: d = e[idx] - l is recomputed, nothing of size N*k is stored).
+    grad_y: (G*Ng, cbn) point-major.  Returns (grad_LE (G*Ng, 2C), grad_gamma (cbn,), grad_beta (cbn,))."""
+    LE, scale, shift, mean, invstd = keep["LE"], keep["scale"], keep["shift"], keep["mean"], keep["invstd"]
+    dev = LE.device
+    cbn = 2 * C if concat else C
+    S = G // groups_per_stat
+    T = stat_blocks(G, Ng)
+    partials = torch.empty((G, T, cbn, 2), dtype=torch.float64, device=dev)
+    _lib.call("pf_edge_backward_reduce_f32", _lib.ptr(LE), 2 * C, C, _lib.ptr(idx), k, G, Ng, _lib.ptr(grad_y),
+              int(grad_y.stride(0)), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(mean), _lib.ptr(invstd), cbn,
+              groups_per_stat, int(bool(concat)), _lib.ptr(partials), _lib.stream(),
+              algo_bytes=float(G) * Ng * (4.0 * C + 8.0 * k + 4.0 * C * k + 4.0 * cbn))
+    red = partials.view(S, -1, cbn, 2).sum(dim=1)                          # (S, cbn, 2): (dbeta, dgamma)
+    m = torch.full((cbn,), float(groups_per_stat) * Ng * k, dtype=torch.float64, device=dev)
+    if concat:
+        m[:C] = float(groups_per_stat) * Ng
+    c1 = (red[..., 0] / m).to(_F32).contiguous()
+    c2 = (red[..., 1] / m).to(_F32).contiguous()
+    grad_le = torch.empty((G * Ng, 2 * C), dtype=_F32, device=dev)
+    _lib.call("pf_edge_backward_apply_f32", _lib.ptr(LE), 2 * C, C, _lib.ptr(idx), k, G, Ng, _lib.ptr(grad_y),
+              int(grad_y.stride(0)), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(c1),
+              _lib.ptr(c2), cbn, groups_per_stat, int(bool(concat)), _lib.ptr(grad_le), _lib.stream(),
+              algo_bytes=float(G) * Ng * (8.0 * C + 8.0 * k + 8.0 * C * k + 4.0 * cbn))
+    return grad_le, red[..., 1].sum(dim=0).to(_F32), red[..., 0].sum(dim=0).to(_F32)
 
 
 def _bn_affine_from_gemm(bn, partials, C, G, Ng, groups_per_stat, dev):

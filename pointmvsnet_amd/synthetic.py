@@ -30,6 +30,8 @@ CONFIGS = {
     "cfg2": (512, 640, 3, 48, 4.24, (0.125, 0.25), (1.0, 0.75)),
     "cfg3": (960, 1280, 5, 96, 2.13, (0.125, 0.25, 0.5), (1.0, 0.75, 0.15)),
     "cfg5": (1152, 1600, 7, 96, 2.13, (0.125, 0.25, 0.5), (1.0, 0.75, 0.15)),
+    # BASELINE config 4: the TRAINING step (one scene per GPU; reference config.py:61-63 train scales)
+    "cfg4": (512, 640, 3, 48, 4.24, (0.125, 0.25), (0.75, 0.375)),
     # small legal shapes for fast parity tests (not BASELINE configs)
     "tiny": (128, 192, 3, 8, 4.24, (0.125, 0.25), (1.0, 0.75)),
     "small": (256, 320, 3, 16, 4.24, (0.125, 0.25, 0.5), (1.0, 0.75, 0.15)),
@@ -95,6 +97,26 @@ def make_scene(height, width, num_view, num_depth, inter_scale=4.24, seed=0, bat
         "mean": mean,
         "std": std,
     }
+
+
+def make_gt_depth(data, scale=0.25, seed=0):
+    """Synthetic ground-truth depth (B, 1, H*scale, W*scale) for the training step (reference dataset.py:285-300
+    delivers it at the resolution of the finest flow stage): a smooth surface inside the hypothesis range with a
+    band of invalid (zero) pixels, which the masked losses must ignore (reference networks.py:170-207)."""
+    img, cams = data["img_list"], data["cam_params_list"]
+    B, _, _, H, W = img.shape
+    h, w = int(H * scale), int(W * scale)
+    g = torch.Generator().manual_seed(1000 + int(seed))
+    ys = torch.linspace(0.0, 1.0, h).view(1, 1, h, 1)
+    xs = torch.linspace(0.0, 1.0, w).view(1, 1, 1, w)
+    gt = torch.zeros(B, 1, h, w)
+    for b in range(B):
+        start, interval, D = float(cams[b, 0, 1, 3, 0]), float(cams[b, 0, 1, 3, 1]), float(cams[b, 0, 1, 3, 2])
+        a, c = torch.rand(2, generator=g).tolist()
+        surf = 0.3 + 0.25 * torch.sin(3.0 * xs + 6.0 * a) * torch.cos(2.0 * ys + 6.0 * c) + 0.15 * ys
+        gt[b] = start + interval * (D - 1) * surf[0]
+    gt[:, :, : max(1, h // 10)] = 0.0
+    return gt
 
 
 def make_config(name, seed=0, batch=1, train_intrinsics=False):

@@ -52,6 +52,51 @@ def test_flat_bucket_allreduce_sum_and_scene_sharding_world2():
     assert out[0][3] == out[1][3]                          # broadcast made the replicas identical
 
 
+def _bucket_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    D.init_from_env(backend="gloo")
+    from pointmvsnet_amd import synthetic
+    from pointmvsnet_amd.model import PointMVSNet
+    net = PointMVSNet()
+    synthetic.seed_weights(net, seed=rank)                # replicas start different on purpose
+    D.broadcast_parameters(net, src=0)
+    bucket = D.GradBucket(net)
+    g = torch.Generator().manual_seed(50 + rank)
+    local = []
+    for p in net.parameters():                            # what backward would do: accumulate into p.grad in place
+        val = torch.randn(p.shape, generator=g)
+        p.grad.add_(val)
+        local.append(val.reshape(-1))
+    local = torch.cat(local)
+    n = bucket.allreduce_sum()
+    gathered = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(gathered, local)
+    want = sum(gathered)
+    got = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+    first = float(next(net.parameters()).sum())
+    bucket.zero_()
+    zeroed = all(float(p.grad.abs().sum()) == 0.0 for p in net.parameters()) and bucket.attached()
+    out[rank] = (n, bool(torch.equal(got, want)), bool(torch.equal(bucket.flat, torch.zeros_like(bucket.flat))), zeroed,
+                 first)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pointmvsnet_gradient_bucket_allreduce_world2():
+    """The REAL bucket of BASELINE config 4: all 698 936 PointMVSNet parameters as views into one flat float32
+    buffer, one in-place SUM all-reduce (gloo here, RCCL on the node)."""
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_bucket_worker, args=(world, port, out), nprocs=world, join=True)
+    for r in range(world):
+        n, summed, flat_zero, zeroed, _ = out[r]
+        assert n == 698936 and summed and flat_zero and zeroed
+    assert out[0][4] == out[1][4]
+
+
 def test_single_process_is_a_noop():
     net = torch.nn.Linear(3, 2)
     net(torch.ones(1, 3)).sum().backward()

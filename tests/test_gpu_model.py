@@ -266,3 +266,73 @@ def test_batch_of_two_scenes_vs_oracle(dev):
         report("batch2_" + key, rel_median=float(rel.median()), rel_max=float(rel.max()))
         assert preds[key].shape == ref[key].shape
         assert float(rel.median()) < 1e-4 and float(rel.max()) < 2e-2
+
+
+def test_train_step_parameter_gradients_vs_oracle_autograd(dev, monkeypatch):
+    """BASELINE config 4's step on "tiny": forward (train mode) + PointMVSNetLoss + backward through the fused
+    EdgeConv node, the HIP fetch backward and ATen, against autograd of the CPU oracle (the reference's
+    composition).  Neighbour choices are discontinuous in the coarse depth (tests/test_sensitivity.py), so the
+    oracle's own kNN indices are injected: with identical neighbour sets every parameter gradient must agree to
+    2e-4 of its largest entry."""
+    import pointmvsnet_amd.model as M
+    from pointmvsnet_amd.model import PointMVSNetLoss
+    data, img_scales, inter_scales = synthetic.make_config("tiny", train_intrinsics=True)
+    gt = synthetic.make_gt_depth(data)
+    net = PointMVSNet()
+    synthetic.seed_weights(net, seed=0)
+    names = [k for k, _ in net.named_parameters()]
+    sd = {k: (v.detach().clone().requires_grad_(True) if k in names else v.clone()) for k, v in net.state_dict().items()}
+    recorded = []
+    orig_knn = O.knn_lattice
+
+    def recording_knn(xyz, kernel_size=5, knn=16, return_code=False):
+        out = orig_knn(xyz, kernel_size, knn, return_code)
+        recorded.append(out[0] if return_code else out)
+        return out
+
+    monkeypatch.setattr(O, "knn_lattice", recording_knn)
+    loss_fn = PointMVSNetLoss(8.0)
+    ref = O.forward(sd, data, img_scales, inter_scales, True, False)
+    loss_ref = sum(loss_fn(ref, {"gt_depth_img": gt, "cam_params_list": data["cam_params_list"]}, True).values())
+    loss_ref.backward()
+    monkeypatch.setattr(O, "knn_lattice", orig_knn)
+    assert len(recorded) == len(img_scales)
+
+    feed = iter(recorded)
+    monkeypatch.setattr(M, "get_knn_3d", lambda xyz, kernel_size=5, knn=16: next(feed).to(xyz.device))
+    net = net.to(dev).train()
+    batch = _to(data, dev)
+    batch["gt_depth_img"] = gt.to(dev)
+    preds = net(batch, img_scales, inter_scales, isFlow=True, isTest=False)
+    loss = sum(loss_fn(preds, batch, True).values())
+    loss.backward()
+    rel_loss = abs(float(loss) - float(loss_ref)) / abs(float(loss_ref))
+    worst, worst_name = 0.0, None
+    for name, p in net.named_parameters():
+        g_ref = sd[name].grad
+        assert p.grad is not None and g_ref is not None, name
+        err = float((p.grad.cpu() - g_ref).abs().max()) / max(float(g_ref.abs().max()), 1e-12)
+        if err > worst:
+            worst, worst_name = err, name
+    report("train_step_gradients_tiny", loss_rel=rel_loss, worst_grad_rel=worst, params=float(len(names)))
+    assert rel_loss < 1e-5
+    assert worst < 2e-4, (worst_name, worst)
+
+
+def test_train_step_runs_and_updates_through_the_bucket(dev):
+    """TrainStep = zero the bucket, forward, loss, backward, one (no-op here) all-reduce, RMSprop: parameters
+    move, gradients live in the flat bucket, the loss is finite, and a second step runs on the updated weights."""
+    from pointmvsnet_amd.train_step import TrainStep
+    data, img_scales, inter_scales = synthetic.make_config("tiny", train_intrinsics=True)
+    net = _model(dev)
+    step = TrainStep(net)
+    assert step.bucket.numel() == 698936 and step.bucket.attached()
+    batch = _to(data, dev)
+    batch["gt_depth_img"] = synthetic.make_gt_depth(data).to(dev)
+    before = net.flow_edge_conv[2].conv2.weight.detach().clone()
+    l1, parts, preds = step(batch, img_scales, inter_scales)
+    assert set(parts) == {"coarse_loss", "flow1_loss", "flow2_loss"} and torch.isfinite(l1)
+    assert step.bucket.attached() and float(step.bucket.flat.abs().sum()) > 0
+    assert not torch.equal(net.flow_edge_conv[2].conv2.weight.detach(), before)
+    l2, _, _ = step(batch, img_scales, inter_scales)
+    assert torch.isfinite(l2) and float(l2) != float(l1)

@@ -402,8 +402,14 @@ def test_edgeconv_fused_vs_reference(dev, name, concat):
         assert torch.equal(mod2(g["x"].to(dev), g["idx"].to(dev)), y)
 
 
-@pytest.mark.parametrize("name,concat", [("edgeconv_noc", False), ("edgeconv_32", True)])
-def test_edgeconv_autograd_path_vs_oracle(dev, name, concat):
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("name,concat", [("edgeconv_noc", False), ("edgeconv_32", True), ("edgeconv_64", True)])
+def test_edgeconv_autograd_path_vs_oracle(dev, name, concat, fused, monkeypatch):
+    """Training: gradients w.r.t. the input, both 1x1 convs and the BatchNorm affine parameters against the CPU
+    oracle's autograd (the reference's composition, networks.py:18-45) -- for the fused autograd node (recompute
+    backward kernels, csrc/edgeconv.hip) and for the composed path on the HIP gather_knn operator."""
+    from pointmvsnet_amd import networks
+    monkeypatch.setattr(networks, "FUSED_TRAIN", 1 if fused else 0)
     g = load_golden(name)
     cin = g["x"].shape[1]
     cout = g["y"].shape[1] // (2 if concat else 1)
@@ -421,10 +427,16 @@ def test_edgeconv_autograd_path_vs_oracle(dev, name, concat):
     y = mod(x, g["idx"].to(dev))
     assert _maxabs(y, g["y"]) < 2e-5 * max(1.0, float(g["y"].abs().max()))
     y.backward(go.to(dev))
-    e_x = _maxabs(x.grad, x_ref.grad) / float(x_ref.grad.abs().max())
-    e_w = _maxabs(mod.conv2.weight.grad, sd["m.conv2.weight"].grad) / float(sd["m.conv2.weight"].grad.abs().max())
-    report("edgeconv_autograd_" + name, dx_rel=e_x, dw_rel=e_w)
-    assert e_x < 2e-4 and e_w < 2e-4
+    errs = {"dx": _maxabs(x.grad, x_ref.grad) / float(x_ref.grad.abs().max())}
+    for pname, p in (("conv1.weight", mod.conv1.weight), ("conv2.weight", mod.conv2.weight),
+                     ("bn.weight", mod.bn.weight), ("bn.bias", mod.bn.bias)):
+        ref = sd["m." + pname].grad
+        assert p.grad is not None and p.grad.shape == ref.shape, pname
+        errs[pname.replace(".", "_")] = _maxabs(p.grad, ref) / float(ref.abs().max())
+    report("edgeconv_autograd_%s_fused%d" % (name, int(fused)), **errs)
+    assert max(errs.values()) < 2e-4, errs
+    assert int(mod.bn.num_batches_tracked) == 1
+    assert _maxabs(mod.bn.running_mean, g["running_mean"]) < 1e-5
 
 
 def test_edgeconv_eval_mode_uses_running_stats(dev):
