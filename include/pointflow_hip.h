@@ -360,6 +360,21 @@ int pf_flow_head_f32(const float* Z, int64_t ldz, const float* scale, const floa
 int pf_softargmin_prob_f32(const float* cost, const float* params, float* depth, float* prob, int64_t B,
                            int64_t D, int64_t HW, void* stream);
 
+/* ---- the step after the path: evaluation output + fusion pre-step -------------
+ * Device-side halves of reference utils/eval_file_logger.py:12-79 and tools/depthfusion.py:153-170, writing into a
+ * staging buffer in PFM row order (flip_rows != 0: bottom row first, the np.flipud of utils/io.py:124) so that one
+ * asynchronous D2H copy per depth map feeds the file writer.
+ *   pf_eval_pack_map_f32    src (h,w) -> dst (h,w) [row-flipped]
+ *   pf_eval_flow_prob_f32   prob (5,h,w) -> confidence p[floor(i)] + p[min(floor(i)+1,4)], i = sum_d p_d (d-2) + 2
+ *                           evaluated in float64 like NumPy does (eval_file_logger.py:48-62)
+ *   pf_eval_prob_filter_f32 depth (h,w) with depth := 0 where flow_conf (h,w) < flow_threshold or
+ *                           init_conf (ih,iw; nearest-resized, cv2.INTER_NEAREST's index rule) < init_threshold */
+int pf_eval_pack_map_f32(const float* src, float* dst, int h, int w, int flip_rows, void* stream);
+int pf_eval_flow_prob_f32(const float* prob, float* dst, int h, int w, int flip_rows, void* stream);
+int pf_eval_prob_filter_f32(const float* depth, const float* flow_conf, const float* init_conf, int h, int w, int ih,
+                            int iw, float flow_threshold, float init_threshold, float* dst, int flip_rows,
+                            void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -75,6 +75,9 @@ PROTOTYPES = {
     "pf_bn_finalize_jobs_f32": ([ctypes.POINTER(BnJob), _i, _vp], _i),
     "pf_edge_apply_f32": ([_vp, _i64, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _i64, _vp, _i, _i, _i, _vp], _i),
     "pf_flow_head_f32": ([_vp, _i64, _vp, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp], _i),
+    "pf_eval_pack_map_f32": ([_vp, _vp, _i, _i, _i, _vp], _i),
+    "pf_eval_flow_prob_f32": ([_vp, _vp, _i, _i, _i, _vp], _i),
+    "pf_eval_prob_filter_f32": ([_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _i, _vp], _i),
     "pf_softargmin_prob_f32": ([_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp], _i),
 }
 
