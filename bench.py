@@ -69,6 +69,8 @@ def parse_args():
     ap.add_argument("--eager", action="store_true", help="do not capture the forward in a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-repeats", type=int, default=3)
+    ap.add_argument("--train-cpu-baseline", action="store_true",
+                    help="cfg4 only: also time ONE oracle training step on the host (tens of seconds, ~15 GB of RAM)")
     return ap.parse_args()
 
 
@@ -355,7 +357,7 @@ def main():
         "roofline": roof,
         "kernels": kernels,
     }
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and (not training or args.train_cpu_baseline):
         data_cpu, _, _ = synthetic.make_config(args.config, seed=my_scenes[0], train_intrinsics=training)
         result["cpu_baseline"] = cpu_baseline(net, data_cpu, img_scales, inter_scales, args.cpu_repeats,
                                               WORKLOAD_TEXT[args.config], train=training)
