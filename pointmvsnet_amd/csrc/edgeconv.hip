@@ -26,6 +26,8 @@
 //
 // Algorithmic HBM bytes per point: EdgeConv(C_in->C_out, out C'):
 // 4*C_in + 8*16 + 16*4*C_out + 4*C'.
+#include <stdlib.h>
+
 #include "pf_common.h"
 #include "pf_bn_tail.h"
 
@@ -216,6 +218,212 @@ __global__ __launch_bounds__(256, 2) void pointwise_gemm_kernel(
     }
     // BatchNorm finalize by the last block (pf_bn_tail.h); the staging buffers are free by now
     if (tail.njobs > 0) pf_bn_tail<256>(tail, g, tb, red);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pointwise GEMM, "direct A" form for point-major rows (the PointFlow chain's six shapes)
+//
+// The kernel above stages BOTH operands through LDS in K chunks with a barrier per chunk; on these skinny
+// GEMMs (K <= 224, Nc <= 128) a chunk holds 0.4 us of MFMA work against ~2 us of load latency, so the matrix
+// cores idle (18-35 % of the f32 peak whatever the staging variant, profiles/r01l_microbench_gemm_*.log).
+// Here the A operand never touches LDS: the reduction index k may be assigned to (MFMA step, lane half) in any
+// order as long as A and B agree, so lane (row = lane & 31, half h = lane >> 5) loads its point's row straight
+// from global memory as 16-byte pieces  k = 8 j + 4 h + {0..3}  and feeds element i of piece j to step
+// (j, i) of v_mfma_f32_32x32x2_f32 -- every loaded byte is used, all of a tile's loads are in flight at once
+// (KJ independent dwordx4 per lane, the waits fall between the MFMA groups), waves never synchronise inside a
+// tile, and the whole W (K x Nc <= 16 384 floats) plus the fused BatchNorm affine of the previous layer sit in
+// LDS for the block's lifetime (one barrier per block instead of one per chunk).  The summation order differs
+// from the chunked kernel's (still one exact f32 fmaf chain per output), so results agree to rounding, not bits.
+// ------------------------------------------------------------------------------------------------
+template <int KJ, int NT, bool AFFINE>
+__global__ __launch_bounds__(256) void pointwise_gemm_direct_kernel(
+    const float* __restrict__ X, int64_t ldx, const float* __restrict__ Wt, float* __restrict__ Y, int64_t ldy,
+    int Ng, int K, int Nc_store, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
+    int groups_per_stat, double* __restrict__ partials, int T) {
+  constexpr int NC = NT * 32;
+  constexpr int KP = KJ * 8;                       // K rounded up to whole pieces
+  constexpr int J0 = (KJ + 1) / 2, J1 = KJ - J0;   // the two halves of a row's pieces (software pipeline below)
+  __shared__ __attribute__((aligned(16))) float Ws[KP * NC];
+  __shared__ __attribute__((aligned(16))) float Aff[2][AFFINE ? KP : 4];
+  constexpr bool kAlias = sizeof(float) * KP * NC >= sizeof(double) * (4 * NC * 2);
+  __shared__ double red_own[kAlias ? 1 : 4 * NC * 2];
+  double* red = kAlias ? reinterpret_cast<double*>(Ws) : red_own;      // W is dead once the tiles are done
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int hi = lane >> 5, lo = lane & 31;
+  const int g = blockIdx.y, tb = blockIdx.x;
+  const int tiles = (Ng + GT - 1) / GT;
+
+  {
+    // W -> LDS in 16-byte pieces, eight loads in flight per thread (a scalar copy loop is one dependent L2 round
+    // trip per element and costs more than the tile's matrix work)
+    const float4* W4 = reinterpret_cast<const float4*>(Wt);
+    float4* Ws4 = reinterpret_cast<float4*>(Ws);
+    constexpr int N4 = KP * NC / 4;
+    const int valid4 = K * NC / 4;                 // K*NC is a multiple of 4 (NC % 32 == 0)
+    for (int e0 = 0; e0 < N4; e0 += 256 * 8) {
+      float4 r[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + tid + 256 * u;
+        r[u] = e < valid4 ? W4[e] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + tid + 256 * u;
+        if (e < N4) Ws4[e] = r[u];
+      }
+    }
+  }
+  if (AFFINE) {
+    const float* sc = in_scale + (int64_t)(g / groups_per_stat) * K;
+    const float* sh = in_shift + (int64_t)(g / groups_per_stat) * K;
+    for (int e = tid; e < KP; e += 256) {
+      Aff[0][e] = e < K ? sc[e] : 0.0f;
+      Aff[1][e] = e < K ? sh[e] : 0.0f;
+    }
+  }
+  __syncthreads();
+
+  double csum[NT], csq[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) csum[t] = csq[t] = 0.0;
+
+  // this lane's row of tile `tile` (lanes past the end of the group shadow its last point; never stored)
+  auto row_ptr = [&](int tile) -> const float* {
+    int n = tile * GT + 32 * wave + lo;
+    n = n < Ng ? n : Ng - 1;
+    return X + ((int64_t)g * Ng + n) * ldx + 4 * hi;
+  };
+  // pieces [JB, JB+JN) of a row: 16-byte loads, all in flight together.  The last piece of the upper half may lie
+  // beyond K (K % 8 == 4): it re-reads the previous piece, its weights are zero.
+  auto load_half = [&](const float* xrow, float4* a, int jb, int jn) {
+#pragma unroll
+    for (int j = 0; j < (J0 > J1 ? J0 : J1); ++j)
+      if (j < jn) {
+        const int jj = jb + j;
+        int kb = 8 * jj;                                          // an immediate offset, except for the last piece
+        if (jj == KJ - 1 && 8 * jj + 4 * hi >= K) kb -= 4;
+        a[j] = *reinterpret_cast<const float4*>(xrow + kb);
+      }
+  };
+  const float* wbase = &Ws[(4 * hi) * NC + lo];
+  auto mma_half = [&](const float4* a, int jb, int jn, f32x16* acc) {
+    // B operands one piece ahead, and no further: left alone, the scheduler hoists a whole tile's LDS reads
+    // (4*NT*KJ registers) above the MFMAs and the kernel drops to one wave per SIMD
+    float bcur[4][NT], bnxt[4][NT];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) bcur[i][t] = wbase[(8 * jb + i) * NC + 32 * t];
+#pragma unroll
+    for (int j = 0; j < (J0 > J1 ? J0 : J1); ++j) {
+      if (j < jn) {
+        const int jj = jb + j;
+        if (j + 1 < jn) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) bnxt[i][t] = wbase[(8 * (jj + 1) + i) * NC + 32 * t];
+        }
+        float av[4] = {a[j].x, a[j].y, a[j].z, a[j].w};
+        if (AFFINE) {
+          const float4 s1 = *reinterpret_cast<const float4*>(&Aff[0][8 * jj + 4 * hi]);
+          const float4 s0 = *reinterpret_cast<const float4*>(&Aff[1][8 * jj + 4 * hi]);
+          av[0] = fmaxf(fmaf(av[0], s1.x, s0.x), 0.0f);
+          av[1] = fmaxf(fmaf(av[1], s1.y, s0.y), 0.0f);
+          av[2] = fmaxf(fmaf(av[2], s1.z, s0.z), 0.0f);
+          av[3] = fmaxf(fmaf(av[3], s1.w, s0.w), 0.0f);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bcur[i][t], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) bcur[i][t] = bnxt[i][t];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+
+  // Software pipeline over (tile, half): while the matrix cores work on one half of a row, the other half -- of
+  // this tile, then of the block's next tile -- is already in flight.
+  float4 a0[J0], a1[J1 > 0 ? J1 : 1];
+  if (tb < tiles) load_half(row_ptr(tb), a0, 0, J0);
+  for (int tile = tb; tile < tiles; tile += T) {
+    const int n0 = tile * GT + 32 * wave;
+    const int rows = min(32, Ng - n0);
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[t][q] = 0.0f;
+    if (J1 > 0) load_half(row_ptr(tile), a1, J0, J1);
+    mma_half(a0, 0, J0, acc);
+    if (tile + T < tiles) load_half(row_ptr(tile + T), a0, 0, J0);
+    if (J1 > 0) mma_half(a1, J0, J1, acc);
+    // epilogue: C/D layout col = lane&31, row = (q&3) + 8*(q>>2) + 4*(lane>>5)
+    if (rows > 0) {
+      float* yrow = Y + ((int64_t)g * Ng + n0 + 4 * hi) * ldy + lo;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int col = 32 * t + lo;
+        float cs = 0.0f, cq = 0.0f;
+        if (rows == 32) {                                // full tile: unconditional rows
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const float v = acc[t][q];
+            if (col < Nc_store) yrow[(int64_t)((q & 3) + 8 * (q >> 2)) * ldy + 32 * t] = v;
+            cs += v;
+            cq += v * v;
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const int row = (q & 3) + 8 * (q >> 2) + 4 * hi;
+            const float v = acc[t][q];
+            if (row < rows) {
+              if (col < Nc_store) yrow[(int64_t)((q & 3) + 8 * (q >> 2)) * ldy + 32 * t] = v;
+              cs += v;
+              cq += v * v;
+            }
+          }
+        }
+        csum[t] += (double)cs;
+        csq[t] += (double)cq;
+      }
+    }
+  }
+
+  if (partials != nullptr) {
+    __syncthreads();                                   // every wave is done reading W (red may alias it)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      double s = csum[t], q = csq[t];
+      s += __shfl_xor(s, 32);
+      q += __shfl_xor(q, 32);
+      if (lane < 32) {
+        red[((wave * NC) + 32 * t + lane) * 2 + 0] = s;
+        red[((wave * NC) + 32 * t + lane) * 2 + 1] = q;
+      }
+    }
+    __syncthreads();
+    if (tid < NC) {
+      double s = 0.0, q = 0.0;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        s += red[((w * NC) + tid) * 2 + 0];
+        q += red[((w * NC) + tid) * 2 + 1];
+      }
+      double* o = partials + (((int64_t)g * T + tb) * NC + tid) * 2;
+      o[0] = s;
+      o[1] = q;
+    }
   }
 }
 
@@ -846,12 +1054,17 @@ int pf_bn_tail_tickets(int G, int T) {
   return 1 + (pf_tail_fan(G, T) > 1 ? G * pf_tail_clusters(G, T) : 0);
 }
 
+// Blocks per group of the pointwise GEMM: about two persistent blocks per CU over the whole launch (the direct-A
+// kernel keeps W in LDS for a block's lifetime, so a block should own several tiles), every block the same number
+// of tiles; a launch with fewer tiles than that gives each tile its own block.
 int pf_gemm_blocks(int G, int Ng) {
   if (G <= 0 || Ng <= 0) return 0;
   const int tiles = (Ng + GT - 1) / GT;
-  int cap = 1024 / G;
-  cap = cap < 32 ? 32 : (cap > 256 ? 256 : cap);
-  return tiles < cap ? tiles : cap;
+  int cap = 512 / G;
+  cap = cap < 16 ? 16 : cap;
+  if (tiles <= cap) return tiles;
+  const int per = (tiles + cap - 1) / cap;
+  return (tiles + per - 1) / per;
 }
 
 int pf_pointwise_gemm_f32(const float* X, int x_point_major, int64_t ldx, const float* Wt, float* Y, int64_t ldy,
@@ -875,6 +1088,31 @@ int pf_pointwise_gemm_f32(const float* X, int x_point_major, int64_t ldx, const 
   }
   dim3 grid((unsigned)T, (unsigned)G);
   hipStream_t s = (hipStream_t)stream;
+  // the PointFlow chain's shapes (point-major rows, K a multiple of 4 that fits LDS with W): direct-A kernel
+  {
+    const char* legacy = getenv("PF_GEMM_LEGACY");
+    const int kj = (K + 7) / 8, nt = Nc / 32;
+    const bool direct = x_point_major && (K % 4) == 0 && (ldx % 4) == 0 && kj * 8 * Nc <= 16384 &&
+                        !(legacy && legacy[0] == '1') && (reinterpret_cast<uintptr_t>(X) % 16) == 0 &&
+                        tail.njobs == 0;      // (a launch that finalizes its own BatchNorm takes the chunked kernel)
+#define PF_GEMM_DIRECT(KJV, NTV)                                                                                   \
+  if (direct && kj == KJV && nt == NTV) {                                                                          \
+    if (in_scale != nullptr)                                                                                       \
+      hipLaunchKernelGGL((pointwise_gemm_direct_kernel<KJV, NTV, true>), grid, dim3(256), 0, s, X, ldx, Wt, Y, ldy, \
+                         Ng, K, Nc_store, in_scale, in_shift, groups_per_stat, col_partials, T);                    \
+    else                                                                                                           \
+      hipLaunchKernelGGL((pointwise_gemm_direct_kernel<KJV, NTV, false>), grid, dim3(256), 0, s, X, ldx, Wt, Y, ldy, \
+                         Ng, K, Nc_store, in_scale, in_shift, groups_per_stat, col_partials, T);                    \
+    return pf_launch_status();                                                                                     \
+  }
+    PF_GEMM_DIRECT(17, 2)   // EdgeConvNoC 136 -> [32 | 32]
+    PF_GEMM_DIRECT(4, 2)    // EdgeConv 32 -> [32 | 32]
+    PF_GEMM_DIRECT(8, 4)    // EdgeConv 64 -> [64 | 64]
+    PF_GEMM_DIRECT(28, 2)   // MLP 224 -> 64
+    PF_GEMM_DIRECT(8, 2)    // MLP 64 -> 64
+    PF_GEMM_DIRECT(8, 1)    // MLP 64 -> 16 (padded to 32 columns)
+#undef PF_GEMM_DIRECT
+  }
 #define PF_GEMM_LAUNCH(PM, NTV)                                                                                  \
   hipLaunchKernelGGL((pointwise_gemm_kernel<PM, NTV>), grid, dim3(256), 0, s, X, ldx, Wt, Y, ldy, Ng, K, Nc_store, \
                      in_scale, in_shift, groups_per_stat, col_partials, T, tail)

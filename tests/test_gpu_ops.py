@@ -958,3 +958,43 @@ def test_frustum_variance_channel_last_is_bit_identical(dev, B, V, C, H, W, D):
     c, none = frustum_variance(feats, kinv, rinv, t0, depths, K.to(dev), E.to(dev), want_points=False,
                                channel_last=True)
     assert none is None and torch.equal(c, a)
+
+
+# ---------------------------------------------------------------------------------------------
+# pointwise GEMM, direct-A kernel (the PointFlow chain's six shapes) against the chunked kernel and fp64
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("K,cout,ldx", [(136, 64, 136), (32, 64, 224), (64, 128, 224), (224, 64, 224), (64, 64, 64),
+                                        (64, 16, 64)])
+@pytest.mark.parametrize("G,Ng", [(1, 25600), (4, 1000), (3, 129), (2, 31)])
+def test_pointwise_gemm_direct_kernel(dev, K, cout, ldx, G, Ng, monkeypatch):
+    gen = torch.Generator().manual_seed(K + cout + Ng)
+    w = torch.randn(cout, K, 1, generator=gen)
+    x = torch.randn(G * Ng, ldx, generator=gen)
+    sc = torch.rand(G, K, generator=gen) + 0.5
+    sh = torch.randn(G, K, generator=gen) * 0.3
+    Wt, _ = pointflow.pack_weight_t(w.to(dev))
+    xd = x.to(dev)
+    for affine in (None, (sc.to(dev), sh.to(dev))):
+        a = x[:, :K].view(G, Ng, K).double()
+        if affine is not None:
+            a = torch.relu(a * sc.double().unsqueeze(1) + sh.double().unsqueeze(1))
+        ref = a @ w[:, :, 0].double().t()
+        outs = []
+        for legacy in ("1", "0"):
+            monkeypatch.setenv("PF_GEMM_LEGACY", legacy)
+            Y = torch.full((G * Ng, cout + 4), -7.0, device=dev)
+            part = pointflow.pointwise_gemm(xd, True, ldx, Wt, Y, cout + 4, G, Ng, K, cout, in_affine=affine,
+                                            want_stats=True)
+            torch.cuda.synchronize()
+            outs.append((Y, part))
+        monkeypatch.delenv("PF_GEMM_LEGACY")
+        scale = float(ref.abs().max())
+        for Y, part in outs:
+            assert _maxabs(Y[:, :cout].view(G, Ng, cout), ref) < 2e-6 * scale * max(1.0, (K / 32.0) ** 0.5)
+            assert float((Y[:, cout:] + 7.0).abs().max()) == 0.0
+            sums = part.sum(dim=1).cpu()
+            assert torch.allclose(sums[:, :cout, 0], ref.sum(dim=1), rtol=1e-5, atol=1e-4 * scale)
+            assert torch.allclose(sums[:, :cout, 1], (ref ** 2).sum(dim=1), rtol=1e-5)
+        # the two kernels order the K sum differently: equal to float32 rounding
+        assert _maxabs(outs[0][0], outs[1][0]) < 4e-6 * scale
+    assert _lib.status() == 0

@@ -1,5 +1,5 @@
 """Micro-benchmark of pf_pointwise_gemm_f32 on the six GEMM shapes of one flow iteration (cfg2: flow-1 G=1,
-flow-2 G=4, Ng=25600), every K-chunk / occupancy variant (PF_GEMM_VARIANT = 10*KC + MINW)."""
+flow-2 G=4, Ng=25600): the chunked-through-LDS kernel (PF_GEMM_LEGACY=1) against the direct-A kernel."""
 import os
 import sys
 
@@ -36,17 +36,16 @@ for G in (1, 4):
         aff = (torch.rand(G, K, device=dev) + 0.5, torch.randn(G, K, device=dev) * 0.1) if affine else None
         ref = None
         line = "G=%d %s K=%d Nc=%d:" % (G, name, K, Nc)
-        for v in (0, 162):
-            if v:
-                os.environ["PF_GEMM_VARIANT"] = str(v)
-            else:
-                os.environ.pop("PF_GEMM_VARIANT", None)
+        flops = 2.0 * G * Ng * K * Nc
+        for legacy in ("1", "0"):                          # chunked-through-LDS kernel, then the direct-A kernel
+            os.environ["PF_GEMM_LEGACY"] = legacy
             pointflow.pointwise_gemm(X, True, ldx, Wt, Y, Nc, G, Ng, K, Nc, in_affine=aff, want_stats=True)
             if ref is None:
                 ref = Y.clone()
-            same = torch.equal(Y, ref)
+            err = float((Y - ref).abs().max()) / float(ref.abs().max())
             t = timeit(lambda: pointflow.pointwise_gemm(X, True, ldx, Wt, Y, Nc, G, Ng, K, Nc, in_affine=aff,
                                                         want_stats=True))
-            line += "  [%d] %.1f%s" % (v, t, "" if same else " (DIFF)")
+            line += "  [%s] %.1f us %.1f TF (rel diff %.1e)" % ("chunked" if legacy == "1" else "direct", t,
+                                                                 flops / t / 1e6, err)
         print(line, flush=True)
-os.environ.pop("PF_GEMM_VARIANT", None)
+os.environ.pop("PF_GEMM_LEGACY", None)
