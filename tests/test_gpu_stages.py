@@ -115,7 +115,9 @@ def test_flow_iteration_stagewise_vs_oracle(dev, cfg, it):
                 prob[:, :, :, i, :, j] = pij
         d_ref = cur + flow.view(1, 1, h, w)
         p_ref = prob.view(1, 5, h, w)
-    assert torch.allclose(d_pm, d_gpu, rtol=1e-6, atol=0.0) and torch.allclose(p_pm, p_gpu, rtol=0.0, atol=1e-6)
+    # (channel-major input takes the chunked GEMM, point-major rows the direct-A GEMM: same products, different
+    # summation order of the exact float32 fmaf chains -> equal to rounding through the six layers, not bit-equal)
+    assert torch.allclose(d_pm, d_gpu, rtol=2e-6, atol=0.0) and torch.allclose(p_pm, p_gpu, rtol=0.0, atol=2e-5)
     rel = float(((d_gpu.cpu() - d_ref[0, 0]).abs() / d_ref[0, 0].abs()).max())
     e_p = float((p_gpu.cpu() - p_ref[0]).abs().max())
     rel_ix = float(((d_ix.cpu() - d_ref[0, 0]).abs() / d_ref[0, 0].abs()).max())
