@@ -17,17 +17,19 @@ import sys
 
 ENTRY_KERNELS = {
     "pf_conv3d_k3_f32": "conv3d_k3_kernel", "pf_conv3d_k3_few_f32": "conv3d_k3_few_kernel",
-    "pf_conv2d_f32": "conv2d_kernel", "pf_conv2d_small_f32": "conv2d_small_kernel", "pf_pointwise_gemm_f32": "pointwise_gemm_kernel",
+    "pf_conv2d_f32": "conv2d_kernel", "pf_conv2d_small_f32": "conv2d_small_kernel", "pf_pointwise_gemm_f32": "pointwise_gemm_",
     "pf_edge_apply_f32": "edge_apply_kernel", "pf_edge_stats_f32": "edge_stats_kernel",
     "pf_flow_features_f32": "flow_features_kernel", "pf_knn_lattice_f32": "knn_lattice",
     "pf_fetch_variance_f32": "fetch_variance_kernel", "pf_frustum_variance_f32": "fetch_variance_kernel",
+    "pf_frustum_variance_cl_f32": "frustum_variance_cl_kernel", "pf_nchw_to_nhwc_f32": "nchw_to_nhwc_kernel",
     "pf_flow_pyramid_f32": "pyramid_resize_kernel", "pf_deconv3d_k3s2_f32": "deconv3d_k3s2_kernel",
     "pf_channel_bn_fused_f32": "channel_bn_fused_kernel", "pf_channel_bn_apply_f32": "channel_bn_apply_kernel",
     "pf_channel_stats_f32": "channel_stats_kernel", "pf_bn_finalize_f32": "bn_finalize_kernel", "pf_bn_finalize_jobs_f32": "bn_finalize_kernel",
     "pf_resize_bilinear_f32": "resize_bilinear_kernel", "pf_softargmin_prob_f32": "softargmin_prob_kernel",
     "pf_flow_head_f32": "flow_head_kernel", "pf_channel_affine_f32": "channel_affine_kernel",
 }
-WIDE_READERS = ("channel_stats_kernel", "channel_bn_apply_kernel", "channel_affine_kernel")
+WIDE_READERS = ("channel_stats_kernel", "channel_bn_apply_kernel", "channel_affine_kernel", "pointwise_gemm_",
+                "frustum_variance_cl_kernel")      # 16-byte-per-lane streaming reads (the guide's x2)
 
 
 def main():
