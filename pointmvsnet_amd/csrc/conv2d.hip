@@ -349,6 +349,16 @@ int launch_variant(int tr, const float* x, const float* wp, float* y, const Conv
   const int minw = ov ? ov % 10 : 2;
 #define PF_L2(TRV, KGV, MW) return launch2d<NT, STRIDE, KS, TRV, KGV, MW>(x, wp, y, g, N, in_scale, in_shift, partials, ta, s)
   if constexpr (KS == 3) {
+    // kg == 4: all 16 input channels of a tile staged in ONE step (one barrier per tile instead of one per four
+    // channels); needs the > 64 KiB dynamic-LDS opt-in for the 16 x 16 tile
+    if (kg == 4) {
+      if constexpr (NT == 1) {
+        if (tr == 4) PF_L2(4, 4, 2);
+        PF_L2(2, 4, 2);
+      } else {
+        PF_L2(2, 4, 2);
+      }
+    }
     if (tr == 4) {
       if (kg == 2) { if (minw == 3) PF_L2(4, 2, 3); PF_L2(4, 2, 2); }
       if (minw == 3) PF_L2(4, 1, 3);
@@ -359,6 +369,9 @@ int launch_variant(int tr, const float* x, const float* wp, float* y, const Conv
     if (minw == 3) PF_L2(2, 1, 3);
     PF_L2(2, 1, 2);
   } else {
+    if constexpr (NT == 1) {
+      if (kg == 2) PF_L2(2, 2, 2);             // 8 -> 16, 5x5/2: both channel groups in one step
+    }
     if (minw == 3) PF_L2(2, 1, 3);
     PF_L2(2, 1, 2);
   }

@@ -229,18 +229,40 @@ class PointMVSNet(nn.Module):
         main = torch.cuda.current_stream()
         feature_list = self.run_coarse_tower(img_list)
         pyramids, side = None, None
+        mode = int(os.environ.get("PF_FORK_MODE", "0"))
         if isFlow and pointflow.CONCURRENCY < 1:
             pyramids = self.run_flow_tower(img_list)
+            preds = self.run_coarse_stage(plan, feature_list)
         elif isFlow:
             if self._side_stream is None or self._side_stream.device != dev:
                 self._side_stream = torch.cuda.Stream(device=dev)
             side = self._side_stream
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                pyramids = self.run_flow_tower(img_list)
-                for p in pyramids.values():
-                    p.record_stream(main)
-        preds = self.run_coarse_stage(plan, feature_list)
+
+            def tower():
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    out = self.run_flow_tower(img_list)
+                    for p in out.values():
+                        p.record_stream(main)
+                return out
+
+            if mode == 0:                      # flow tower captured first, coarse stage second
+                pyramids = tower()
+                preds = self.run_coarse_stage(plan, feature_list)
+            elif mode == 1:                    # coarse stage captured first
+                ev = torch.cuda.Event()
+                ev.record(main)
+                preds = self.run_coarse_stage(plan, feature_list)
+                side.wait_event(ev)
+                with torch.cuda.stream(side):
+                    pyramids = self.run_flow_tower(img_list)
+                    for p in pyramids.values():
+                        p.record_stream(main)
+            else:                              # fork after the warp: the flow tower's first node follows the fetch kernel
+                preds = self.run_coarse_stage(plan, feature_list, fork=tower)
+                pyramids = preds.pop("_forked")
+        else:
+            preds = self.run_coarse_stage(plan, feature_list)
         if not isFlow:
             pointflow.flush_counters()
             return preds
@@ -255,19 +277,23 @@ class PointMVSNet(nn.Module):
     def run_flow_tower(self, img_list):
         return self.flow_img_conv.forward_views(img_list)
 
-    def run_coarse_stage(self, plan, feature_list):
-        """Coarse stage after the tower (reference model.py:79-130): warp, variance, VolumeConv, soft-argmin."""
+    def run_coarse_stage(self, plan, feature_list, fork=None):
+        """Coarse stage after the tower (reference model.py:79-130): warp, variance, VolumeConv, soft-argmin.
+        ``fork`` (a callable) is invoked right after the warp has been enqueued (see run)."""
         B, D = plan.B, plan.D
         preds = collections.OrderedDict()
         C, FH, FW = feature_list.shape[2:]
         # the frustum points (model.py:79-100) are generated inside the fetch+variance kernel
         cost, world_points = frustum_variance(feature_list, plan.d("Kinv0"), plan.d("Rinv0"), plan.d("t0"),
                                               plan.d("depths"), plan.d("K_coarse"), plan.d("ext"))
+        forked = fork() if fork is not None else None
         preds["world_points"] = world_points
         filtered = self.coarse_vol_conv.forward_fused(cost.view(B, C, D, FH, FW)).squeeze(1)   # (B,D,FH,FW)
         pred_depth, prob_map = pointflow.soft_argmin_params(filtered, plan.d("sa_params"))
         preds["coarse_depth_map"] = pred_depth
         preds["coarse_prob_map"] = prob_map
+        if fork is not None:
+            preds["_forked"] = forked
         return preds
 
     def run_flows(self, plan, pyramids, preds):

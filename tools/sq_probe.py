@@ -1,0 +1,35 @@
+"""Workload for SQ-counter passes on single kernels: runs a few launches of selected entry points on the cfg2
+shapes (tower convs, the chain's GEMMs) so that `rocprofv3 --pmc ...` attributes counters to them."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from pointmvsnet_amd import pointflow  # noqa: E402
+
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+which = sys.argv[1:] or ["conv2d"]
+if "conv2d" in which:
+    for cin, cout, h, w, ks, stride in ((16, 16, 256, 320, 3, 1), (32, 32, 128, 160, 3, 1), (8, 16, 512, 640, 5, 2),
+                                        (16, 32, 256, 320, 5, 2)):
+        conv = torch.nn.Conv2d(cin, cout, ks, stride=stride, padding=ks // 2, bias=False).to(dev)
+        x = torch.randn(3, cin, h, w, device=dev)
+        sc = torch.rand(3, cin, device=dev) + 0.5
+        sh = torch.randn(3, cin, device=dev) * 0.1
+        for _ in range(4):
+            pointflow.conv2d(x, conv, (sc, sh), 1, True)
+if "gemm" in which:
+    for K, Nc, ldx in ((136, 64, 136), (224, 64, 224), (64, 128, 224)):
+        X = torch.randn(4 * 25600, ldx, device=dev)
+        Wt = torch.randn(K, Nc, device=dev) * 0.1
+        Y = torch.empty(4 * 25600, Nc, device=dev)
+        for _ in range(4):
+            pointflow.pointwise_gemm(X, True, ldx, Wt, Y, Nc, 4, 25600, K, Nc, want_stats=True)
+if "conv3d" in which:
+    w = torch.randn(8, 64, 3, 3, 3, device=dev) * 0.05
+    x = torch.randn(1, 64, 48, 64, 80, device=dev)
+    for _ in range(4):
+        pointflow.conv3d_k3(x, w, 1, True)
+torch.cuda.synchronize()
