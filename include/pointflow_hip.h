@@ -306,6 +306,14 @@ int pf_channel_bn_fused_f32(const float* x, float* y, int64_t N, int64_t C, int6
 int pf_conv3d_blocks(int64_t Cin, int64_t Cout, int64_t Di, int64_t Hi, int64_t Wi, int stride);
 int pf_conv3d_k3_f32(const float* x, const float* wp, float* y, int64_t N, int64_t Cin, int64_t Cout, int64_t Di,
                      int64_t Hi, int64_t Wi, int stride, double* partials, void* stream);
+/* The same convolution for stride 1 and Cout <= 8 (VolumeConv's conv0_1, networks.py:136: 64 -> 8 on the full cost
+ * volume) without the half-empty 16-wide tile: N = 8 channels x 2 adjacent output rows, which read the same four
+ * input rows, so K = 36 taps instead of 27 and 1.5x fewer MFMA cycles.  wp = weights packed as
+ * (Cin/4, 36 taps [kd][kh'][kw], 4, 16): wp[g][tap][k][c + 8 s] = W[c][4g+k][kd][kh' - s][kw] (zero where kh' - s
+ * is outside [0,2]).  partials (N, pf_conv3d_pair_blocks(...), Cout, 2) float64 or NULL as above. */
+int pf_conv3d_pair_blocks(int64_t Cin, int64_t Cout, int64_t D, int64_t H, int64_t W);
+int pf_conv3d_k3_pair_f32(const float* x, const float* wp, float* y, int64_t N, int64_t Cin, int64_t Cout, int64_t D,
+                          int64_t H, int64_t W, double* partials, void* stream);
 /* 3x3x3 / pad 1 / stride 1 conv3d with Cout <= 4 (VolumeConv's 8 -> 1 output layer, networks.py:147);
  * w is the unpacked (Cout, Cin, 3, 3, 3) weight. */
 int pf_conv3d_k3_few_f32(const float* x, const float* w, float* y, int64_t N, int64_t Cin, int64_t Cout, int64_t D,

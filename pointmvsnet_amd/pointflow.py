@@ -264,10 +264,41 @@ def eval_affine(bn, S, ld, ch0=0, C=None, out=None):
 # ---------------------------------------------------------------------------------------------
 # BatchNorm (+ReLU) for the conv stacks around the path (ImageConv / VolumeConv)
 # ---------------------------------------------------------------------------------------------
+# PF_CONV3D_PAIR=0: conv0_1 takes the 16-channel-wide tile of conv3d.hip (round-1 kernel)
+CONV3D_PAIR = int(_os.environ.get("PF_CONV3D_PAIR", "1"))
+
+
+def pack_conv3d_weight_pair(weight):
+    """(Cout<=8,Cin,3,3,3) -> (Cin/4, 36, 4, 16): column c + 8 s holds W[c] shifted by s along kh (see
+    csrc/conv3d_pair.hip); cached per parameter."""
+    def make():
+        cout, cin = weight.shape[:2]
+        w = weight.detach().to(_F32)
+        wp = torch.zeros((cin // 4, 3, 4, 3, 4, 16), dtype=_F32, device=weight.device)   # g, kd, kh', kw, k, col
+        src = w.permute(1, 2, 3, 4, 0).reshape(cin // 4, 4, 3, 3, 3, cout).permute(0, 2, 3, 4, 1, 5)   # g,kd,kh,kw,k,c
+        for s_ in (0, 1):
+            wp[:, :, s_:s_ + 3, :, :, 8 * s_:8 * s_ + cout] = src
+        return wp.reshape(cin // 4, 36, 4, 16).contiguous()
+    return _cached_pack(("c3p", id(weight)), (weight,), make)
+
+
 def conv3d_k3(x, weight, stride, want_stats):
-    """3x3x3 / pad 1 conv3d on the f32 matrix cores (pf_conv3d_k3_f32).  Returns (y, partials or None)."""
+    """3x3x3 / pad 1 conv3d on the f32 matrix cores (pf_conv3d_k3_f32; stride 1 with <= 8 output channels:
+    pf_conv3d_k3_pair_f32).  Returns (y, partials or None)."""
     N, Cin, Di, Hi, Wi = x.shape
     Cout = weight.shape[0]
+    if CONV3D_PAIR and stride == 1 and Cout <= 8 and Cin % 4 == 0:
+        wp = pack_conv3d_weight_pair(weight)
+        y = torch.empty((N, Cout, Di, Hi, Wi), dtype=_F32, device=x.device)
+        partials = None
+        if want_stats:
+            T = int(_lib.load().pf_conv3d_pair_blocks(Cin, Cout, Di, Hi, Wi))
+            partials = torch.empty((N, T, Cout, 2), dtype=torch.float64, device=x.device)
+        _lib.call("pf_conv3d_k3_pair_f32", _lib.ptr(x), _lib.ptr(wp), _lib.ptr(y), N, Cin, Cout, Di, Hi, Wi,
+                  _lib.ptr(partials), _lib.stream(),
+                  algo_bytes=4.0 * N * (Cin + Cout) * Di * Hi * Wi + 4.0 * 27 * Cin * Cout,
+                  flops=2.0 * N * Di * Hi * Wi * 27 * Cin * Cout)
+        return y, partials
     Do, Ho, Wo = (Di - 1) // stride + 1, (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
     wp = pack_conv3d_weight(weight)
     y = torch.empty((N, Cout, Do, Ho, Wo), dtype=_F32, device=x.device)

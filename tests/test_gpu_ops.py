@@ -565,7 +565,8 @@ def test_volume_conv_fused_vs_reference(dev):
                                                      (1, 4, 3, 3, 3, 3, 1), (1, 16, 16, 1, 1, 1, 1),
                                                      (1, 8, 20, 4, 6, 17, 1), (1, 64, 8, 48, 64, 80, 1),
                                                      (1, 64, 16, 48, 64, 80, 2), (1, 16, 16, 24, 32, 40, 1),
-                                                     (1, 8, 8, 96, 120, 160, 2)])
+                                                     (1, 8, 8, 96, 120, 160, 2), (2, 8, 5, 3, 7, 18, 1),
+                                                     (1, 12, 8, 5, 9, 33, 1), (1, 4, 1, 2, 1, 1, 1)])
 def test_conv3d_k3_vs_fp64(dev, N, Cin, Cout, D, H, W, stride):
     gen = torch.Generator().manual_seed(N * 1000 + Cin + Cout + D * H * W)
     x = torch.randn(N, Cin, D, H, W, generator=gen)
