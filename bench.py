@@ -230,10 +230,18 @@ def main():
     if not args.eager:
         try:
             from pointmvsnet_amd.graph import GraphedForward
-            n_graphs = int(os.environ.get("PF_BENCH_GRAPHS", "1"))             # diagnostic: alternate graph execs
+            # ONE captured graph whose static input the step's images are copied into (12 MB device-to-device, inside
+            # the timed region).  PF_BENCH_GRAPHS=<n_unique> keeps one graph per resident scene buffer instead (no image
+            # copy) -- measured SLOWER, 585 vs 598 depth maps/s (profiles/r02ae_graph_slots_ab.log): alternating graph
+            # executables costs more than the copy.
+            n_graphs = int(os.environ.get("PF_BENCH_GRAPHS", "1"))
             with torch.no_grad():
-                graphs = [GraphedForward(net, scenes[0], img_scales, inter_scales, isFlow=True, isTest=True)
-                          for _ in range(n_graphs)]
+                if n_graphs == n_unique and n_graphs > 1:
+                    graphs = [GraphedForward(net, scenes[j], img_scales, inter_scales, isFlow=True, isTest=True,
+                                             adopt_input=True) for j in range(n_unique)]
+                else:
+                    graphs = [GraphedForward(net, scenes[0], img_scales, inter_scales, isFlow=True, isTest=True)
+                              for _ in range(n_graphs)]
 
             def step(i):                                                       # noqa: F811
                 with torch.no_grad():
@@ -242,7 +250,9 @@ def main():
             for i in range(2):
                 step(i)
             torch.cuda.synchronize()
-            execution = "hipGraph replay (host camera algebra + 1 H2D + image copy + 1 graph launch per step)"
+            execution = ("hipGraph replay, one graph per resident input slot (host camera algebra + 1 H2D of the scene "
+                         "constants + 1 graph launch per step)") if (n_graphs == n_unique and n_graphs > 1) \
+                else "hipGraph replay (host camera algebra + image copy into the static input + 1 graph launch per step)"
         except Exception as exc:      # capture support varies with the library stack; say so, do not hide it
             sys.stderr.write("bench.py: hipGraph capture failed (%r); running eager\n" % (exc,))
             step = eager_step
@@ -284,6 +294,8 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     assert torch.isfinite(preds["flow%d" % len(img_scales)]).all()
+    from pointmvsnet_amd import pointflow as _pf
+    stage_timeline = _pf.timeline_report() if _pf.TIMELINE else None
 
     if rank != 0:
         return
@@ -354,6 +366,7 @@ def main():
         "execution": execution,
         "host_issue_ms_per_step": issued / args.steps * 1e3,
         "gap_probe": gap_probe,
+        "stage_timeline_us": stage_timeline,
         "roofline": roof,
         "kernels": kernels,
     }

@@ -61,6 +61,9 @@ const char* pf_version(void);
 const char* pf_error_string(int code);
 /* Number of compute units / LDS bytes of the current device, and its gcnArchName. */
 int pf_device_info(int* cu_count, int* lds_bytes_per_block, char* arch_host, int arch_len);
+/* Diagnostics: a one-thread kernel that writes the constant-rate device clock (100 MHz ticks) to *slot when it
+ * runs on `stream` -- a timestamp that can sit INSIDE a captured hipGraph, where events cannot (PF_TIMELINE=1). */
+int pf_debug_timestamp(long long* slot, void* stream);
 /* Synchronises `stream`, returns the sticky status bits in *status_host and clears them. */
 int pf_check_status(unsigned* status_host, void* stream);
 

@@ -29,6 +29,7 @@ PROTOTYPES = {
     "pf_version": ([], ctypes.c_char_p),
     "pf_error_string": ([_i], ctypes.c_char_p),
     "pf_device_info": ([ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.c_char_p, _i], _i),
+    "pf_debug_timestamp": ([_vp, _vp], _i),
     "pf_check_status": ([ctypes.POINTER(ctypes.c_uint), _vp], _i),
     "pf_gather_knn_forward_f32": ([_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp], _i),
     "pf_gather_knn_forward_f64": ([_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp], _i),

@@ -300,7 +300,8 @@ int tr_for(int ks, int nt, int64_t Ho, int64_t Wo, int64_t N) {
 // software pipeline (a block that owns a single tile cannot hide its first memory latency).
 int blocks_2d(int64_t Ho, int64_t Wo, int tr, int64_t N) {
   const int64_t total = ((Ho + 4 * tr - 1) / (4 * tr)) * ((Wo + 15) / 16);
-  int64_t cap = 1536 / (N < 1 ? 1 : N);
+  const char* ce = getenv("PF_CONV2D_CAP");          // tuning hook: total persistent blocks over the batch
+  int64_t cap = (ce ? atoi(ce) : 1536) / (N < 1 ? 1 : N);
   cap = cap < 64 ? 64 : cap;
   if (total <= cap) return (int)total;
   // every block the same number of tiles: 640 tiles on 512 blocks would leave 3/4 of the chip idle in the

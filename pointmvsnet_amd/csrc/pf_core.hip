@@ -20,7 +20,17 @@ unsigned* pf_status_ptr() {
   return g_status[dev];
 }
 
+namespace {
+__global__ void timestamp_kernel(long long* out) { *out = (long long)wall_clock64(); }
+}  // namespace
+
 extern "C" {
+
+int pf_debug_timestamp(long long* slot, void* stream) {
+  PF_REQUIRE(slot != nullptr);
+  hipLaunchKernelGGL(timestamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, slot);
+  return pf_launch_status();
+}
 
 const char* pf_version(void) { return "pointflow_hip 0.1 (gfx950)"; }
 

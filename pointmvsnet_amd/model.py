@@ -137,6 +137,20 @@ class ScenePlan(object):
                 and self.is_test == bool(is_test) and self.D == int(num_depth))
 
     def update_(self, data_batch):
+        """Host algebra into the pinned block, then one asynchronous H2D on the current stream."""
+        self.fill_host_(data_batch)
+        return self.upload_()
+
+    def upload_(self):
+        self.dev.copy_(self.host, non_blocking=True)
+        if self.dev.is_cuda:
+            self._copied = torch.cuda.Event()
+            self._copied.record()
+        return self
+
+    def fill_host_(self, data_batch):
+        """Only the host half: redo the camera algebra into the pinned block (a captured graph that contains the
+        H2D copy as its first node reads it at replay time; see graph.GraphedForward)."""
         cam = _Cameras(_host_cams(data_batch), self.is_test)
         if cam.num_depth != self.D:
             raise RuntimeError("ScenePlan: num_depth changed (%d -> %d); build a new plan" % (self.D, cam.num_depth))
@@ -155,10 +169,6 @@ class ScenePlan(object):
         self._h("sa_params").copy_(torch.stack([cam.depth_start, cam.depth_end, cam.depth_interval], dim=1))
         for i, (s, inter) in enumerate(zip(self.img_scales, self.inter_scales)):
             self._h("pack%d" % i).copy_(cam.packed(cam.flow_intrinsics(s), mean_h, std_h, inter * cam.depth_interval))
-        self.dev.copy_(self.host, non_blocking=True)
-        if self.dev.is_cuda:
-            self._copied = torch.cuda.Event()
-            self._copied.record()
         return self
 
 
@@ -227,7 +237,9 @@ class PointMVSNet(nn.Module):
         kernels, each fills the chip) -- 474 -> 486 depth maps/s, profiles/r01h_fork_ab.log."""
         dev = img_list.device
         main = torch.cuda.current_stream()
+        pointflow.stamp("start")
         feature_list = self.run_coarse_tower(img_list)
+        pointflow.stamp("coarse_tower_end")
         pyramids, side = None, None
         mode = int(os.environ.get("PF_FORK_MODE", "0"))
         if isFlow and pointflow.CONCURRENCY < 1:
@@ -242,6 +254,7 @@ class PointMVSNet(nn.Module):
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
                     out = self.run_flow_tower(img_list)
+                    pointflow.stamp("flow_tower_end")
                     for p in out.values():
                         p.record_stream(main)
                 return out
@@ -275,6 +288,8 @@ class PointMVSNet(nn.Module):
         return self.coarse_img_conv.forward_views(img_list, need=("conv3",))["conv3"].contiguous()   # (B,V,C,FH,FW)
 
     def run_flow_tower(self, img_list):
+        for _ in range(int(os.environ.get("PF_PROBE_REPEAT_TOWER", "0"))):     # critical-path probe (bench only)
+            self.flow_img_conv.forward_views(img_list, need=("conv1",))
         return self.flow_img_conv.forward_views(img_list)
 
     def run_coarse_stage(self, plan, feature_list, fork=None):
@@ -286,10 +301,14 @@ class PointMVSNet(nn.Module):
         # the frustum points (model.py:79-100) are generated inside the fetch+variance kernel
         cost, world_points = frustum_variance(feature_list, plan.d("Kinv0"), plan.d("Rinv0"), plan.d("t0"),
                                               plan.d("depths"), plan.d("K_coarse"), plan.d("ext"))
+        pointflow.stamp("warp_end")
         forked = fork() if fork is not None else None
         preds["world_points"] = world_points
         filtered = self.coarse_vol_conv.forward_fused(cost.view(B, C, D, FH, FW)).squeeze(1)   # (B,D,FH,FW)
+        for _ in range(int(os.environ.get("PF_PROBE_REPEAT_SOFTARGMIN", "0"))):   # critical-path probe (bench only)
+            pointflow.soft_argmin_params(filtered, plan.d("sa_params"))
         pred_depth, prob_map = pointflow.soft_argmin_params(filtered, plan.d("sa_params"))
+        pointflow.stamp("coarse_stage_end")
         preds["coarse_depth_map"] = pred_depth
         preds["coarse_prob_map"] = prob_map
         if fork is not None:
@@ -316,6 +335,7 @@ class PointMVSNet(nn.Module):
             flow_prob = torch.stack(probs, dim=0) if B > 1 else probs[0].unsqueeze(0)
             preds["flow{}_prob".format(it + 1)] = flow_prob
             preds["flow{}".format(it + 1)] = pred_depth
+            pointflow.stamp("flow%d_end" % (it + 1))
         pointflow.flush_counters()
         return preds
 

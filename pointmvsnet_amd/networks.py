@@ -320,15 +320,20 @@ class VolumeConv(nn.Module):
             training_bn = blk.bn is not None and (blk.bn.training or not blk.bn.track_running_stats)
             if aux is None and training_bn and _conv3d_fusable(blk.conv, x):
                 # its BatchNorm+ReLU waits for the decoder: applied together with the last skip add below
+                for _ in range(int(_os.environ.get("PF_PROBE_REPEAT_CONV0", "0"))):   # critical-path probe (bench only)
+                    pointflow.conv3d_k3(x.contiguous(), blk.conv.weight, 1, False)
                 full = pointflow.conv3d_k3(x.contiguous(), blk.conv.weight, 1, True)
             else:
                 full = f(blk, x)
+        pointflow.stamp("conv0_1_end")
         half = f(self.conv1_0, x)
         quarter = f(self.conv2_0, half)
         eighth = f(self.conv3_1, f(self.conv3_0, quarter))
         half = f(self.conv1_1, half)
         quarter = f(self.conv2_1, quarter)
+        pointflow.stamp("unet_encoder_end")
         up = f(self.conv4_0, eighth)
+        pointflow.stamp("unet_bottom_end")
         up = f(self.conv5_0, (up, quarter))
         up = f(self.conv6_0, (up, half))
         if aux is not None:

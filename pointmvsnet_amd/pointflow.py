@@ -127,6 +127,34 @@ def _pack_weight_t(*convs):
 
 import os as _os
 
+# PF_TIMELINE=1: one-thread timestamp kernels at the stage boundaries of PointMVSNet.run (they are graph nodes, so
+# they work under hipGraph replay where events cannot); read back with timeline_report().
+TIMELINE = int(_os.environ.get("PF_TIMELINE", "0"))
+_timeline = {"buf": None, "names": []}
+
+
+def stamp(name):
+    if not TIMELINE:
+        return
+    t = _timeline
+    if t["buf"] is None:
+        t["buf"] = torch.zeros(64, dtype=torch.int64, device=torch.cuda.current_device())
+    if name not in t["names"]:
+        t["names"].append(name)
+    i = t["names"].index(name)
+    _lib.call("pf_debug_timestamp", _lib.ptr(t["buf"][i:i + 1]), _lib.stream())
+
+
+def timeline_report():
+    """{name: microseconds since the first stamp} of the LAST forward (call after a synchronize)."""
+    t = _timeline
+    if t["buf"] is None:
+        return {}
+    vals = t["buf"].cpu().tolist()
+    t0 = min(vals[i] for i in range(len(t["names"])))
+    return {n: (vals[i] - t0) / 100.0 for i, n in enumerate(t["names"])}
+
+
 # PF_FUSED_BN=1 folds every BatchNorm finalize into the kernel that produces its statistics (last block done,
 # csrc/pf_bn_tail.h) instead of a separate launch.  Measured on MI355X (profiles/r02a_fused_bn_ab.log, same box,
 # hipGraph replay of BASELINE config 2): 553 depth maps/s fused vs 570 with the 25 separate finalize launches --

@@ -38,19 +38,17 @@ for name, cin, cout, h, w, ks, stride in LAYERS:
     xin = F.relu(x * sc.view(3, cin, 1, 1) + sh.view(3, cin, 1, 1))
     ref = F.conv2d(xin[:, :, :40, :56].double(), conv.weight.double(), None, stride, ks // 2)
     line = "%s %d->%d %dx%d k%d s%d:" % (name, cin, cout, h, w, ks, stride)
-    variants = [0, 212, 222, 242, 412, 422, 442] if ks == 3 else [0, 212, 222]
-    if cout > 32:
-        variants = [0]
+    variants = [0, 1536, 768, 512, 384, 256] if cout <= 32 else [0]
     for v in variants:
         if v:
-            os.environ["PF_CONV2D_VARIANT"] = str(v)
+            os.environ["PF_CONV2D_CAP"] = str(v)
         else:
-            os.environ.pop("PF_CONV2D_VARIANT", None)
+            os.environ.pop("PF_CONV2D_CAP", None)
         y, _ = pointflow.conv2d(x[:, :, :40, :56].contiguous(), conv, (sc, sh), 1, True)
         err = float((y.double() - ref).abs().max() / ref.abs().max())
         t = timeit(lambda: pointflow.conv2d(x, conv, (sc, sh), 1, True))
         line += "  mfma[%d] %.1f%s" % (v, t, "" if err < 1e-5 else " (ERR %.1e)" % err)
-    os.environ.pop("PF_CONV2D_VARIANT", None)
+    os.environ.pop("PF_CONV2D_CAP", None)
     if pointflow.conv2d_small_preferred(conv):
         line += "  | small %.1f" % timeit(lambda: pointflow.conv2d_small(x, conv, (sc, sh), 1, True))
     line += "  | library %.1f us" % timeit(lambda: conv(xin))
