@@ -328,12 +328,29 @@ class VolumeConv(nn.Module):
         pointflow.stamp("conv0_1_end")
         half = f(self.conv1_0, x)
         quarter = f(self.conv2_0, half)
+        # The skip branches conv1_1 / conv2_1 (+ their BatchNorms) are needed only by the decoder: with
+        # PF_VC_SIDE=1 they run on an auxiliary stream beside the bottom of the U-Net (dependent chain of small,
+        # latency-bound kernels: conv3_0, conv3_1, conv4_0)
+        side = None
+        if int(_os.environ.get("PF_VC_SIDE", "0")):
+            main = torch.cuda.current_stream()
+            side = pointflow.side_stream(x.device, 3)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                half_s = f(self.conv1_1, half)
+                quarter_s = f(self.conv2_1, quarter)
+                half_s.record_stream(main)
+                quarter_s.record_stream(main)
         eighth = f(self.conv3_1, f(self.conv3_0, quarter))
-        half = f(self.conv1_1, half)
-        quarter = f(self.conv2_1, quarter)
         pointflow.stamp("unet_encoder_end")
         up = f(self.conv4_0, eighth)
         pointflow.stamp("unet_bottom_end")
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+            half, quarter = half_s, quarter_s
+        else:
+            half = f(self.conv1_1, half)
+            quarter = f(self.conv2_1, quarter)
         up = f(self.conv5_0, (up, quarter))
         up = f(self.conv6_0, (up, half))
         if aux is not None:
