@@ -354,6 +354,17 @@ int pf_conv2d_small_f32(const float* x, const float* wp, float* y, int64_t N, in
                         int samples_per_stat, double* partials, const pf_bn_job* bn_jobs_host, int n_bn_jobs,
                         unsigned* tickets, void* stream);
 
+/* ImageConv's 32- and 64-channel layers (reference networks.py:95-110: 3x3/1 32->32 and 64->64, 5x5/2 16->32 and
+ * 32->64), the small-map mapping of pf_conv2d_f32's contract (csrc/conv2d_wide.hip): same x / y / in_scale /
+ * in_shift / samples_per_stat / partials meaning, partials (N, pf_conv2d_wide_blocks(...), Cout, 2).  wp is the
+ * weight packed (K, K, Cin/8, 2, Cout, 4): wp[kh][kw][kc][h][co][j] = w[co][8 kc + 4 h + j][kh][kw].
+ * PF_ERR_UNSUPPORTED for any other shape (pf_conv2d_wide_supported tells). */
+int pf_conv2d_wide_supported(int64_t Cin, int64_t Cout, int kernel_size, int stride);
+int pf_conv2d_wide_blocks(int64_t Cout, int64_t Hi, int64_t Wi, int stride);
+int pf_conv2d_wide_f32(const float* x, const float* wp, float* y, int64_t N, int64_t Cin, int64_t Cout, int64_t Hi,
+                       int64_t Wi, int kernel_size, int stride, const float* in_scale, const float* in_shift,
+                       int samples_per_stat, double* partials, void* stream);
+
 /* ---- rows M (last layer) + H + T : flow head ---------------------------------------------------
  * Z (G*Ng, ldz) holds the pre-BN output of the 64->16 MLP layer.  Per pixel of the (h,w) grid:
  * a = relu(Z*scale+shift); flow_d = sum_c w_out[c]*a_c for the 5 hypotheses; p = softmax(-flow);

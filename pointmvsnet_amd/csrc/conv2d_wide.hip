@@ -1,0 +1,309 @@
+// ImageConv, the 32- and 64-channel layers (reference networks.py:95-110): KxK conv2d
+// (3x3 stride 1 or 5x5 stride 2, pad K/2, no bias) as an implicit GEMM on v_mfma_f32_32x32x2_f32, with the previous
+// layer's BatchNorm+ReLU applied while the input patch is staged and this layer's BatchNorm batch statistics in
+// the epilogue -- the same contract as pf_conv2d_f32 (conv2d.hip), a different machine mapping for the layers
+// whose maps are SMALL (64 x 80 pixels x 3 views at 64 channels: 960 wave tiles of 32 pixels x 32 channels for
+// 1 024 SIMDs -- every SIMD gets ONE wave, so that wave has to keep its matrix pipe busy on its own):
+//
+//   * the staged input patch is channel-last in LDS ([pixel][C_in + 4]) and the reduction index is assigned to
+//     (MFMA step, lane half) as  c = 8 kc + 4 h + j : lane (pixel m, half h) reads the 16 bytes
+//     patch[pixel(m) + tap][8 kc + 4 h ..] with ONE ds_read_b128 and feeds element j to step (kc, j) -- a quarter
+//     of an LDS instruction per MFMA and, the patch geometry being compile-time, no address arithmetic at all
+//     (base register + immediate for every tap and chunk).  conv2d.hip's 16x16x4 loop issues 1.25 ds_read_b32
+//     and ~7 VALU per MFMA of half the size (SQ counters, profiles/r02r_sq_counters.md);
+//   * the weights are packed on the host in the matching order [kh][kw][kc][h][c_out][j], so a lane's B operand
+//     for four steps is one ds_read_b128 of consecutive 16-byte pieces (conflict-free); one kernel ROW of weights
+//     (K x C_in x C_out floats, 40-48 KB at 64 channels) is resident per stage, double buffered: the next row
+//     travels global -> registers while the matrix cores work, one barrier per kernel row (3 or 5 per tile);
+//   * a 256-thread block owns (2 * NWM) x 16 output pixels x C_out channels: wave (wm, wn) the two rows
+//     2 wm, 2 wm + 1 (32 pixels) x channels [32 wn, 32 wn + 32); C_out = 64: 2 x 2 waves (4 x 16 pixels), C_out = 32:
+//     4 x 1 (8 x 16 pixels).  The accumulator layout (lane = channel, 4 consecutive registers = 4 consecutive
+//     pixels of a row) stores straight to NCHW as 16-byte pieces -- no transpose through LDS;
+//   * statistics: per lane over its 16 outputs (float), the two lane halves by one shuffle, waves through LDS,
+//     one float64 partial row per block -- the layout pf_bn_finalize consumes from pf_conv2d_f32.
+//
+// Exact float32: every output is one fmaf chain over (kh, kw, kc, j, h); the order differs from conv2d.hip's and
+// from the library's Winograd kernels, so results agree with either to rounding (tests compare with float64).
+// Bound: the f32 matrix peak (157 TF): 2 K^2 C_in C_out flop per output pixel against 4 (C_in / S^2 + C_out) bytes.
+#include <stdlib.h>
+
+#include "pf_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));   // (HIP's float4 struct in a register ARRAY ends up in scratch)
+
+struct WideGeom {
+  int Hi, Wi, Ho, Wo, tiles_w, sps;
+};
+
+template <int KS, int STRIDE, int CIN, int COUT>
+struct WideCfg {
+  static constexpr int NWN = COUT / 32;                 // waves along the channels
+  static constexpr int NWM = 4 / NWN;                   // ... along the pixels (each: 2 rows x 16 columns)
+  static constexpr int TH = 2 * NWM, TW = 16;           // output tile of a block
+  static constexpr int PAD = KS / 2;
+  static constexpr int PH = (TH - 1) * STRIDE + KS, PW = (TW - 1) * STRIDE + KS;
+  static constexpr int NPIX = PH * PW;
+  static constexpr int RS = CIN + 4;                    // floats per staged pixel (+4: 16-byte reads of 16
+                                                        // consecutive pixels fall on 16 distinct bank quads)
+  static constexpr int PATCH = NPIX * RS;
+  static constexpr int KC = CIN / 8;
+  static constexpr int WROW = KS * CIN * COUT;          // floats of one kernel row of packed weights
+  static constexpr int WROW4 = WROW / 4;
+  static constexpr int NWR = (WROW4 + 255) / 256;       // 16-byte pieces per thread per row
+  static constexpr int ITEMS = NPIX * (CIN / 4);        // (pixel, channel quad) pairs of the patch
+  static constexpr int NIT = (ITEMS + 255) / 256;
+  static constexpr size_t LDS = sizeof(float) * (size_t)(PATCH + 2 * WROW + 2 * CIN) + sizeof(double) * 4 * 32 * 2;
+  static_assert(COUT == 32 || COUT == 64, "C_out is 32 or 64");
+  static_assert(CIN % 8 == 0 && PATCH % 4 == 0 && WROW % 4 == 0, "16-byte pieces");
+  static_assert(LDS <= 160 * 1024, "tile does not fit the LDS of a CU");
+};
+
+template <int KS, int STRIDE, int CIN, int COUT, bool AFFINE>
+__global__ __launch_bounds__(256) void conv2d_wide_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                          float* __restrict__ y, WideGeom g,
+                                                          const float* __restrict__ in_scale,
+                                                          const float* __restrict__ in_shift,
+                                                          double* __restrict__ partials) {
+  using C = WideCfg<KS, STRIDE, CIN, COUT>;
+  constexpr int PW = C::PW, RS = C::RS, NPIX = C::NPIX, WROW = C::WROW, WROW4 = C::WROW4, NWR = C::NWR;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* patch = lds;
+  float* wbuf = lds + C::PATCH;
+  float* aff = wbuf + 2 * WROW;                       // scale[CIN], shift[CIN] of the pending BatchNorm
+  double* red = reinterpret_cast<double*>(aff + 2 * CIN);
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int m = lane & 31, h = lane >> 5;
+  const int wm = wave / C::NWN, wn = wave % C::NWN;
+  const int n = blockIdx.y;
+  const int tw = blockIdx.x % g.tiles_w, th = blockIdx.x / g.tiles_w;
+  const int oh0 = th * C::TH, ow0 = tw * C::TW;
+  const int ih0 = oh0 * STRIDE - C::PAD, iw0 = ow0 * STRIDE - C::PAD;
+  const int plane_i = g.Hi * g.Wi;                    // CIN * plane_i < 2^31 (checked on the host)
+  const float* xb = x + (int64_t)n * CIN * plane_i;
+
+  // ---- kernel row 0 of the weights: global -> registers ------------------------------------------------------
+  f32x4 rw[NWR];
+  auto load_w = [&](int kh) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(wp + (int64_t)kh * WROW);
+#pragma unroll
+    for (int r = 0; r < NWR; ++r) {
+      const int e = tid + 256 * r;
+      rw[r] = src[e < WROW4 ? e : WROW4 - 1];
+    }
+  };
+  auto store_w = [&](int buf) {
+    f32x4* dst = reinterpret_cast<f32x4*>(wbuf + buf * WROW);
+#pragma unroll
+    for (int r = 0; r < NWR; ++r) {
+      const int e = tid + 256 * r;
+      if (256 * (r + 1) <= WROW4 || e < WROW4) dst[e] = rw[r];
+    }
+  };
+  load_w(0);
+
+  // ---- the input patch: NCHW planes -> [pixel][channel] in LDS, previous BatchNorm+ReLU on the way ---------------
+  // all of a thread's loads first (NIT x 4 independent dwords in flight), then the affine and the 16-byte LDS writes
+  float rx[C::NIT][4];
+  bool rok[C::NIT];
+#pragma unroll
+  for (int r = 0; r < C::NIT; ++r) {
+    const int it = tid + 256 * r;
+    const int itc = it < C::ITEMS ? it : C::ITEMS - 1;
+    const int q = itc / NPIX, p = itc - q * NPIX;       // lanes walk the patch's pixels: coalesced along a patch row
+    const int pr = p / PW, pc = p - pr * PW;
+    const int ih = ih0 + pr, iw = iw0 + pc;
+    rok[r] = ih >= 0 && ih < g.Hi && iw >= 0 && iw < g.Wi;
+    const float* src = xb + (int64_t)(4 * q) * plane_i + (rok[r] ? ih * g.Wi + iw : 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rx[r][j] = src[j * plane_i];
+  }
+  if (AFFINE) {
+    const float* sc = in_scale + (int64_t)(n / g.sps) * CIN;
+    const float* sh = in_shift + (int64_t)(n / g.sps) * CIN;
+    if (tid < CIN) aff[tid] = sc[tid];
+    else if (tid < 2 * CIN) aff[tid] = sh[tid - CIN];
+    __syncthreads();
+  }
+#pragma unroll
+  for (int r = 0; r < C::NIT; ++r) {
+    const int it = tid + 256 * r;
+    const int itc = it < C::ITEMS ? it : C::ITEMS - 1;
+    const int q = itc / NPIX, p = itc - q * NPIX;
+    f32x4 v = {rx[r][0], rx[r][1], rx[r][2], rx[r][3]};
+    if (AFFINE) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(aff + 4 * q);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(aff + CIN + 4 * q);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(v[j], a[j], b[j]), 0.0f);
+    }
+    if (!rok[r]) v = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};                       // zero padding applies AFTER it
+    if (256 * (r + 1) <= C::ITEMS || it < C::ITEMS) *reinterpret_cast<f32x4*>(patch + p * RS + 4 * q) = v;
+  }
+  store_w(0);
+  __syncthreads();
+
+  // ---- the MFMA loop: every LDS address below is (lane base) + (compile-time offset) ------------------------------
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+  const float* abase = patch + ((2 * wm + (m >> 4)) * STRIDE * PW + (m & 15) * STRIDE) * RS + 4 * h;
+  const float* bbase = wbuf + (h * COUT + wn * 32 + m) * 4;
+  // (operands of step t + 1 are read while the four MFMAs of step t run: a wave is alone on its SIMD here, so
+  // nobody else would cover the LDS latency; the sched_barriers keep the compiler from sinking the reads again)
+  constexpr int T = KS * C::KC;                        // 16-byte operand pairs per kernel row
+#pragma unroll
+  for (int kh = 0; kh < KS; ++kh) {
+    if (kh + 1 < KS) load_w(kh + 1);
+    const float* bb = bbase + (kh & 1) * WROW;
+    f32x4 a = *reinterpret_cast<const f32x4*>(abase + (kh * PW) * RS);
+    f32x4 b = *reinterpret_cast<const f32x4*>(bb);
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      f32x4 an = a, bn = b;
+      if (t + 1 < T) {
+        const int kw = (t + 1) / C::KC, kc = (t + 1) % C::KC;
+        an = *reinterpret_cast<const f32x4*>(abase + (kh * PW + kw) * RS + 8 * kc);
+        bn = *reinterpret_cast<const f32x4*>(bb + (t + 1) * 2 * COUT * 4);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      a = an;
+      b = bn;
+    }
+    if (kh + 1 < KS) {
+      store_w((kh + 1) & 1);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: C/D layout column (channel) = lane & 31, row (pixel) = (r & 3) + 8 (r >> 2) + 4 h -----------------
+  const int co = wn * 32 + m;
+  float* yb = y + ((int64_t)n * COUT + co) * ((int64_t)g.Ho * g.Wo);
+  const bool vec_ok = (g.Wo & 3) == 0;
+  float s = 0.0f, q = 0.0f;
+#pragma unroll
+  for (int rq = 0; rq < 4; ++rq) {
+    const int oh = oh0 + 2 * wm + (rq >> 1);
+    const int ow = ow0 + (rq & 1) * 8 + 4 * h;
+    if (oh < g.Ho) {
+      float* dst = yb + (int64_t)oh * g.Wo + ow;
+      if (vec_ok && ow + 3 < g.Wo) {
+        *reinterpret_cast<float4*>(dst) = make_float4(acc[4 * rq], acc[4 * rq + 1], acc[4 * rq + 2], acc[4 * rq + 3]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s += acc[4 * rq + e];
+          q += acc[4 * rq + e] * acc[4 * rq + e];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (ow + e < g.Wo) {
+            dst[e] = acc[4 * rq + e];
+            s += acc[4 * rq + e];
+            q += acc[4 * rq + e] * acc[4 * rq + e];
+          }
+        }
+      }
+    }
+  }
+  if (partials != nullptr) {
+    s += __shfl_xor(s, 32);
+    q += __shfl_xor(q, 32);
+    if (h == 0) {
+      red[(wave * 32 + m) * 2 + 0] = (double)s;
+      red[(wave * 32 + m) * 2 + 1] = (double)q;
+    }
+    __syncthreads();
+    if (tid < COUT) {
+      const int cn = tid >> 5, cm = tid & 31;
+      double ds = 0.0, dq = 0.0;
+#pragma unroll
+      for (int w = 0; w < C::NWM; ++w) {
+        ds += red[((w * C::NWN + cn) * 32 + cm) * 2 + 0];
+        dq += red[((w * C::NWN + cn) * 32 + cm) * 2 + 1];
+      }
+      double* o = partials + (((int64_t)n * gridDim.x + blockIdx.x) * COUT + tid) * 2;
+      o[0] = ds;
+      o[1] = dq;
+    }
+  }
+}
+
+template <int KS, int STRIDE, int CIN, int COUT>
+int launch_wide(const float* x, const float* wp, float* y, WideGeom g, int64_t N, const float* in_scale,
+                const float* in_shift, double* partials, hipStream_t s) {
+  using C = WideCfg<KS, STRIDE, CIN, COUT>;
+  if (C::LDS > 64 * 1024) {
+    static std::atomic<unsigned long long> done{0};   // per instantiation, one bit per device
+    const void* fn = in_scale ? reinterpret_cast<const void*>(&conv2d_wide_kernel<KS, STRIDE, CIN, COUT, true>)
+                              : reinterpret_cast<const void*>(&conv2d_wide_kernel<KS, STRIDE, CIN, COUT, false>);
+    static std::atomic<unsigned long long> done_plain{0};
+    const int rc = pf_allow_big_lds(fn, (int)C::LDS, in_scale ? done : done_plain);
+    if (rc != PF_OK) return rc;
+  }
+  g.tiles_w = (g.Wo + C::TW - 1) / C::TW;
+  const int tiles_h = (g.Ho + C::TH - 1) / C::TH;
+  dim3 grid((unsigned)(tiles_h * g.tiles_w), (unsigned)N);
+  if (in_scale)
+    hipLaunchKernelGGL((conv2d_wide_kernel<KS, STRIDE, CIN, COUT, true>), grid, dim3(256), C::LDS, s, x, wp, y, g,
+                       in_scale, in_shift, partials);
+  else
+    hipLaunchKernelGGL((conv2d_wide_kernel<KS, STRIDE, CIN, COUT, false>), grid, dim3(256), C::LDS, s, x, wp, y, g,
+                       in_scale, in_shift, partials);
+  return pf_launch_status();
+}
+
+int wide_tile_rows(int64_t Cout) { return Cout == 64 ? 4 : 8; }
+
+}  // namespace
+
+extern "C" {
+
+int pf_conv2d_wide_supported(int64_t Cin, int64_t Cout, int kernel_size, int stride) {
+  if (kernel_size == 3 && stride == 1) return (Cin == 64 && Cout == 64) || (Cin == 32 && Cout == 32);
+  if (kernel_size == 5 && stride == 2) return (Cin == 32 && Cout == 64) || (Cin == 16 && Cout == 32);
+  return 0;
+}
+
+int pf_conv2d_wide_blocks(int64_t Cout, int64_t Hi, int64_t Wi, int stride) {
+  if ((Cout != 32 && Cout != 64) || Hi <= 0 || Wi <= 0 || (stride != 1 && stride != 2)) return 0;
+  const int64_t Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;
+  const int th = wide_tile_rows(Cout);
+  return (int)(((Ho + th - 1) / th) * ((Wo + 15) / 16));
+}
+
+int pf_conv2d_wide_f32(const float* x, const float* wp, float* y, int64_t N, int64_t Cin, int64_t Cout, int64_t Hi,
+                       int64_t Wi, int kernel_size, int stride, const float* in_scale, const float* in_shift,
+                       int samples_per_stat, double* partials, void* stream) {
+  PF_REQUIRE(N >= 0 && Cin >= 1 && Cout >= 1 && Hi >= 1 && Wi >= 1 && N <= 65535 && samples_per_stat >= 1);
+  PF_REQUIRE((in_scale == nullptr) == (in_shift == nullptr));
+  if (!pf_conv2d_wide_supported(Cin, Cout, kernel_size, stride)) return PF_ERR_UNSUPPORTED;
+  PF_REQUIRE(Cin * Hi * Wi <= INT32_MAX);
+  if (N == 0) return PF_OK;
+  PF_REQUIRE(x && wp && y);
+  WideGeom g;
+  g.Hi = (int)Hi;
+  g.Wi = (int)Wi;
+  g.Ho = (int)((Hi - 1) / stride + 1);
+  g.Wo = (int)((Wi - 1) / stride + 1);
+  g.tiles_w = 0;
+  g.sps = samples_per_stat;
+  hipStream_t s = (hipStream_t)stream;
+  if (kernel_size == 3) {
+    if (Cin == 64) return launch_wide<3, 1, 64, 64>(x, wp, y, g, N, in_scale, in_shift, partials, s);
+    return launch_wide<3, 1, 32, 32>(x, wp, y, g, N, in_scale, in_shift, partials, s);
+  }
+  if (Cin == 32) return launch_wide<5, 2, 32, 64>(x, wp, y, g, N, in_scale, in_shift, partials, s);
+  return launch_wide<5, 2, 16, 32>(x, wp, y, g, N, in_scale, in_shift, partials, s);
+}
+
+}  // extern "C"

@@ -504,6 +504,167 @@ __global__ __launch_bounds__(256) void flow_features_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
+// F, second form: the five hypotheses of a pixel inside ONE block
+// ------------------------------------------------------------------------------------------------
+// flow_features_kernel gives every hypothesis plane its own block; SQ / PMC counters put it (and the coarse warp)
+// at ~10 TB/s of L2 -> L1 tap traffic (550 MB of 128-byte tap lines per launch at 4 x 25 600 points), not at HBM.
+// The five hypotheses of a pixel are 0.1-0.3 texels apart in every source view, i.e. they sample the SAME four
+// texels almost always.  Here a block owns a 4 x 8 pixel patch with all five hypotheses and walks
+// level -> 32-channel chunk -> view -> hypothesis: within one (level, view) the five hypotheses re-read lines
+// that are in L1 already (6 x 10 texels x 64-256 B per view and level), which cuts the L2 traffic ~5x.  The
+// 15 (view, hypothesis) projections of a point are computed once by its 8 lanes (two each) and parked in LDS.
+// Per (hypothesis, channel) the arithmetic and its order (views ascending) are those of flow_features_kernel:
+// the two kernels are bit-identical.
+template <int V, bool ROLLV>
+__global__ __launch_bounds__(256) void flow_features_hyp_kernel(const float* __restrict__ maps1,
+                                                                const float* __restrict__ maps2,
+                                                                const float* __restrict__ maps3, int c1, int c2,
+                                                                int c3, int h, int w,
+                                                                const float* __restrict__ depth_in, int dh, int dw,
+                                                                const float* __restrict__ interval_p,
+                                                                const float* __restrict__ cam, int ratio,
+                                                                float* __restrict__ feature, float* __restrict__ xyz) {
+  constexpr int PTS = kFeatPY * kFeatPX;                    // 32 points (pixels) per block
+  __shared__ int tap_off[PTS][V * 5][4];
+  __shared__ float tap_wgt[PTS][V * 5][4];
+  __shared__ float nxyz[PTS][5][4];
+  const int hs = h / ratio, ws = w / ratio;
+  const int64_t Ng = (int64_t)5 * hs * ws;
+  const int q = threadIdx.x & (kFeatLanes - 1);
+  const int pl = threadIdx.x / kFeatLanes;
+  const int tiles_x = (w + kFeatPX - 1) / kFeatPX;
+  const int bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
+  const int y_raw = by * kFeatPY + pl / kFeatPX, x_raw = bx * kFeatPX + pl % kFeatPX;
+  const bool live = y_raw < h && x_raw < w;
+  const int y = live ? y_raw : h - 1, x = live ? x_raw : w - 1;
+  const int g = (y % ratio) * ratio + (x % ratio);
+  const int64_t loc0 = (int64_t)(y / ratio) * ws + x / ratio;     // + d*hs*ws per hypothesis
+
+  const float scy = (float)dh / (float)h, scx = (float)dw / (float)w;
+  int sy = (int)floorf((float)y * scy);
+  int sx = (int)floorf((float)x * scx);
+  sy = sy > dh - 1 ? dh - 1 : sy;
+  sx = sx > dw - 1 ? dw - 1 : sx;
+  const float depth0 = depth_in[sy * dw + sx];
+  const float interval = interval_p[0];
+  const float* Ki = cam + PF_CAM_KREF_INV;
+  const float* Ri = cam + PF_CAM_RREF_INV;
+  const float* t0 = cam + PF_CAM_TREF;
+  const float px = (float)x + 0.5f, py = (float)y + 0.5f;
+  const float u0 = fmaf(Ki[2], 1.0f, fmaf(Ki[1], py, Ki[0] * px));
+  const float u1 = fmaf(Ki[5], 1.0f, fmaf(Ki[4], py, Ki[3] * px));
+  const float u2 = fmaf(Ki[8], 1.0f, fmaf(Ki[7], py, Ki[6] * px));
+  auto world = [&](int d, float& X, float& Y, float& Z) {
+    const float depth = depth0 + interval * (float)(d - 2);
+    const float q0 = u0 * depth - t0[0], q1 = u1 * depth - t0[1], q2 = u2 * depth - t0[2];
+    X = fmaf(Ri[2], q2, fmaf(Ri[1], q1, Ri[0] * q0));
+    Y = fmaf(Ri[5], q2, fmaf(Ri[4], q1, Ri[3] * q0));
+    Z = fmaf(Ri[8], q2, fmaf(Ri[7], q1, Ri[6] * q0));
+  };
+  // phase 0: the V*5 (view, hypothesis) projections of this point, spread over its 8 lanes
+  for (int p = q; p < V * 5; p += kFeatLanes) {
+    const int v = p / 5, d = p - v * 5;
+    float X, Y, Z;
+    world(d, X, Y, Z);
+    PfTaps t;
+    const float* cv = cam + PF_CAM_VIEWS + v * PF_CAM_VIEW_STRIDE;
+    pf_project_taps(X, Y, Z, cv, cv + 9, h, w, t);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      tap_off[pl][p][k] = t.off[k];
+      tap_wgt[pl][p][k] = t.wgt[k];
+    }
+  }
+  if (q < 5) {
+    float X, Y, Z;
+    world(q, X, Y, Z);
+    const float nx = (X - cam[PF_CAM_MEAN + 0]) / cam[PF_CAM_STD + 0];
+    const float ny = (Y - cam[PF_CAM_MEAN + 1]) / cam[PF_CAM_STD + 1];
+    const float nz = (Z - cam[PF_CAM_MEAN + 2]) / cam[PF_CAM_STD + 2];
+    nxyz[pl][q][0] = nx;
+    nxyz[pl][q][1] = ny;
+    nxyz[pl][q][2] = nz;
+    if (live) {
+      float* xo = xyz + (int64_t)g * 3 * Ng + (int64_t)q * hs * ws + loc0;
+      xo[0] = nx;
+      xo[Ng] = ny;
+      xo[2 * Ng] = nz;
+    }
+  }
+  __syncthreads();
+
+  const int ctot = c1 + c2 + c3 + 24;
+  float* frow0 = feature + ((int64_t)g * Ng + loc0) * ctot;       // + d*hs*ws*ctot per hypothesis
+  const int64_t dstride = (int64_t)hs * ws * ctot;
+  const int64_t hw = (int64_t)h * w;
+  int ch = 0;
+#pragma unroll 1
+  for (int level = 0; level < 3; ++level) {
+    const float* maps = level == 0 ? maps1 : (level == 1 ? maps2 : maps3);
+    const int cl = level == 0 ? c1 : (level == 1 ? c2 : c3);
+#pragma unroll 1
+    for (int c0 = 0; c0 < cl; c0 += 4 * kFeatLanes) {
+      const int c = c0 + 4 * q;
+      if (c < cl) {
+        float s[5][4], s2[5][4];
+        // (a zero start instead of "first view assigns" keeps every bit: 0 + f == f, and the sign of a zero sum
+        // cannot reach m2 - m1 * m1)
+#pragma unroll
+        for (int d = 0; d < 5; ++d)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) s[d][i] = s2[d][i] = 0.0f;
+#pragma unroll(ROLLV ? 1 : V)
+        for (int v = 0; v < V; ++v) {
+          const float* mv = maps + (int64_t)v * hw * cl + c;
+#pragma unroll
+          for (int d = 0; d < 5; ++d) {
+            const int4 o = *reinterpret_cast<const int4*>(&tap_off[pl][v * 5 + d][0]);
+            const float4 wg = *reinterpret_cast<const float4*>(&tap_wgt[pl][v * 5 + d][0]);
+            const float4 a = *reinterpret_cast<const float4*>(mv + (int64_t)o.x * cl);
+            const float4 b = *reinterpret_cast<const float4*>(mv + (int64_t)o.y * cl);
+            const float4 cc = *reinterpret_cast<const float4*>(mv + (int64_t)o.z * cl);
+            const float4 dd = *reinterpret_cast<const float4*>(mv + (int64_t)o.w * cl);
+            const float f[4] = {((a.x * wg.x + b.x * wg.y) + cc.x * wg.z) + dd.x * wg.w,
+                                ((a.y * wg.x + b.y * wg.y) + cc.y * wg.z) + dd.y * wg.w,
+                                ((a.z * wg.x + b.z * wg.y) + cc.z * wg.z) + dd.z * wg.w,
+                                ((a.w * wg.x + b.w * wg.y) + cc.w * wg.z) + dd.w * wg.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              s[d][i] = s[d][i] + f[i];
+              s2[d][i] = s2[d][i] + f[i] * f[i];
+            }
+          }
+        }
+        if (live) {
+#pragma unroll
+          for (int d = 0; d < 5; ++d) {
+            float o[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float m1 = s[d][i] / (float)V;
+              const float m2 = s2[d][i] / (float)V;
+              o[i] = m2 - m1 * m1;
+            }
+            *reinterpret_cast<float4*>(frow0 + d * dstride + ch + c) = make_float4(o[0], o[1], o[2], o[3]);
+          }
+        }
+      }
+    }
+    ch += cl;
+  }
+  // xyz.repeat(1, 8, 1): channel j of the 24 holds axis j % 3 (model.py:193-194); lanes 0..5 write 4 each
+  if (live && q < 6) {
+#pragma unroll
+    for (int d = 0; d < 5; ++d) {
+      float o[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = nxyz[pl][d][(4 * q + i) % 3];
+      *reinterpret_cast<float4*>(frow0 + d * dstride + ch + 4 * q) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // S: soft-argmin + probability map (reference model.py:117-130, functions/functions.py:141-175)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float linspace_at(float start, float end, float step, int k, int D) {
@@ -729,6 +890,20 @@ int pf_flow_features_f32(const float* maps1, const float* maps2, const float* ma
   const int64_t Ng = (int64_t)5 * (h / ratio) * (w / ratio);
   (void)Ng;
   PF_REQUIRE(pf_cdiv(h, kFeatPY) * pf_cdiv(w, kFeatPX) * 5 <= INT32_MAX);
+  const char* hyp = getenv("PF_FEAT_HYP");                   // 0: one block per hypothesis plane (round-1 kernel)
+  if (!(hyp && hyp[0] == '0')) {
+    dim3 gridh((unsigned)(pf_cdiv(h, kFeatPY) * pf_cdiv(w, kFeatPX)));
+    return dispatch_views(V, [&](auto vtag) {
+      constexpr int VV = decltype(vtag)::value;
+      if (hyp && hyp[0] == '2')
+        hipLaunchKernelGGL((flow_features_hyp_kernel<VV, true>), gridh, dim3(256), 0, (hipStream_t)stream, maps1, maps2,
+                           maps3, c1, c2, c3, h, w, depth_in, dh, dw, interval, cam, ratio, feature, xyz);
+      else
+        hipLaunchKernelGGL((flow_features_hyp_kernel<VV, false>), gridh, dim3(256), 0, (hipStream_t)stream, maps1,
+                           maps2, maps3, c1, c2, c3, h, w, depth_in, dh, dw, interval, cam, ratio, feature, xyz);
+      return pf_launch_status();
+    });
+  }
   dim3 grid((unsigned)(5 * pf_cdiv(h, kFeatPY) * pf_cdiv(w, kFeatPX)));
   const char* ord = getenv("PF_FEAT_ORDER");                 // tuning hook: 0 = plane-major blocks, 1 = XCD-aware
   const int xcd_order = ord ? atoi(ord) : 1;

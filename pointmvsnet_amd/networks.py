@@ -242,7 +242,8 @@ class ImageConv(nn.Module):
             nconv = None if nxt is None else (nxt.conv if hasattr(nxt, "bn") else nxt)
             wanted = stage_end and name in need
             defer = (not wanted) and nconv is not None and \
-                (pointflow.conv2d_preferred(nconv) or pointflow.conv2d_small_preferred(nconv))
+                (pointflow.conv2d_preferred(nconv) or pointflow.conv2d_small_preferred(nconv)
+                 or pointflow.conv2d_wide_preferred(nconv))
             x, pending = _conv2d_block_fused(block, x, pending, B, defer)
             if wanted:
                 out[name] = x.view(V, B, *x.shape[1:]).transpose(0, 1)
@@ -260,6 +261,8 @@ def _conv2d_block_fused(block, x, pending, samples_per_stat, defer):
     affine = None
     if pointflow.conv2d_small_preferred(conv):
         out = pointflow.conv2d_small(x, conv, pending, samples_per_stat, training_bn, bn=tail_bn)
+    elif pointflow.conv2d_wide_preferred(conv):
+        out = pointflow.conv2d_wide(x, conv, pending, samples_per_stat, training_bn)
     elif pointflow.conv2d_preferred(conv):
         out = pointflow.conv2d(x, conv, pending, samples_per_stat, training_bn, bn=tail_bn)
     else:

@@ -485,6 +485,51 @@ def conv2d(x, conv, in_affine, samples_per_stat, want_stats, bn=None):
     return (y, partials) if bn is None else (y, partials, affine)
 
 
+CONV2D_WIDE = int(_os.environ.get("PF_CONV2D_WIDE", "1"))     # 0: 64-channel tower layers on the library convolution
+
+
+def conv2d_wide_supported(conv):
+    """Shapes pf_conv2d_wide_f32 is built for: 3x3/1 32->32, 64->64 and 5x5/2 16->32, 32->64."""
+    return conv2d_supported(conv) and bool(_lib.load().pf_conv2d_wide_supported(
+        conv.in_channels, conv.out_channels, int(conv.kernel_size[0]), int(conv.stride[0])))
+
+
+def conv2d_wide_preferred(conv):
+    """Measured (profiles/r02ag_microbench_conv2d_wide.log, cfg2 shapes, 3 views; us): 16->32 5x5/2 25.1 (pf_conv2d_f32
+    31.0, library 34.7), 32->32 3x3 16.7 (22.8, 24.4), 32->64 5x5/2 21.0 (40.5, 31.9), 64->64 3x3 16.5 (38.0, 24.6) --
+    62-76 TF of exact f32: every 32- and 64-channel tower layer runs on csrc/conv2d_wide.hip."""
+    return bool(CONV2D_WIDE) and conv2d_wide_supported(conv)
+
+
+def pack_conv2d_wide_weight(weight):
+    """(Cout,Cin,K,K) -> (K, K, Cin/8, 2, Cout, 4): [kh][kw][kc][h][co][j] = w[co][8 kc + 4 h + j][kh][kw]."""
+    def make():
+        cout, cin, k, _ = weight.shape
+        w = weight.detach().to(_F32).permute(2, 3, 1, 0).reshape(k, k, cin // 8, 2, 4, cout)
+        return w.permute(0, 1, 2, 3, 5, 4).contiguous()
+    return _cached_pack(("c2w", id(weight)), (weight,), make)
+
+
+def conv2d_wide(x, conv, in_affine, samples_per_stat, want_stats):
+    """pf_conv2d_wide_f32: same contract as ``conv2d`` (raw y, statistics partials or None)."""
+    N, Cin, Hi, Wi = x.shape
+    Cout = conv.out_channels
+    ks, stride = conv.kernel_size[0], conv.stride[0]
+    Ho, Wo = (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
+    wp = pack_conv2d_wide_weight(conv.weight)
+    y = torch.empty((N, Cout, Ho, Wo), dtype=_F32, device=x.device)
+    partials = None
+    if want_stats:
+        T = int(_lib.load().pf_conv2d_wide_blocks(Cout, Hi, Wi, int(stride)))
+        partials = stat_rows(N, T, Cout, x.device, False)
+    sc, sh = in_affine if in_affine is not None else (None, None)
+    _lib.call("pf_conv2d_wide_f32", _lib.ptr(x), _lib.ptr(wp), _lib.ptr(y), N, Cin, Cout, Hi, Wi, int(ks), int(stride),
+              _lib.ptr(sc), _lib.ptr(sh), int(samples_per_stat), _lib.ptr(partials), _lib.stream(),
+              algo_bytes=4.0 * N * (Cin * Hi * Wi + Cout * Ho * Wo) + 4.0 * ks * ks * Cin * Cout,
+              flops=2.0 * N * Ho * Wo * ks * ks * Cin * Cout)
+    return y, partials
+
+
 def channel_affine_(x, affine, relu, samples_per_stat):
     """In place y = act(x*scale + shift) with (N/sps, C) affine rows."""
     N, C = x.shape[:2]

@@ -655,6 +655,58 @@ def test_conv2d_vs_fp64(dev, N, Cin, Cout, H, W, ks, stride, affine):
     assert torch.allclose(sums[..., 1], (ref ** 2).sum(dim=(2, 3)), rtol=1e-5)
 
 
+@pytest.mark.parametrize("N,Cin,Cout,H,W,ks,stride", [(3, 64, 64, 64, 80, 3, 1), (2, 64, 64, 19, 25, 3, 1),
+                                                       (3, 32, 64, 128, 160, 5, 2), (1, 32, 64, 37, 51, 5, 2),
+                                                       (3, 32, 32, 32, 48, 3, 1), (1, 32, 32, 13, 30, 3, 1),
+                                                       (2, 16, 32, 64, 80, 5, 2), (1, 16, 32, 27, 33, 5, 2),
+                                                       (1, 64, 64, 3, 5, 3, 1)])
+@pytest.mark.parametrize("affine", [False, True])
+def test_conv2d_wide_vs_fp64(dev, N, Cin, Cout, H, W, ks, stride, affine):
+    """csrc/conv2d_wide.hip (the 32x32x2-MFMA mapping for the towers' small maps) against a float64 convolution:
+    aligned maps, ragged edges in both directions (masked stores, masked statistics), maps smaller than a tile."""
+    gen = torch.Generator().manual_seed(N * 1000 + Cin + Cout + H * W)
+    x = torch.randn(N, Cin, H, W, generator=gen)
+    conv = torch.nn.Conv2d(Cin, Cout, ks, stride=stride, padding=ks // 2, bias=False)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=gen) / (ks * ks * Cin) ** 0.5)
+    sc = torch.rand(N, Cin, generator=gen) + 0.5
+    sh = torch.randn(N, Cin, generator=gen) * 0.3
+    xin = x.double()
+    if affine:
+        xin = torch.relu(xin * sc.double().view(N, Cin, 1, 1) + sh.double().view(N, Cin, 1, 1))
+    ref = F.conv2d(xin, conv.weight.double(), None, stride, ks // 2)
+    conv = conv.to(dev)
+    assert pointflow.conv2d_wide_supported(conv)
+    aff = (sc.to(dev), sh.to(dev)) if affine else None
+    y, part = pointflow.conv2d_wide(x.to(dev), conv, aff, 1, True)
+    assert y.shape == ref.shape
+    scale = float(ref.abs().max())
+    err = _maxabs(y, ref)
+    report("conv2d_wide_%d_%d_k%d_%dx%d_aff%d" % (Cin, Cout, ks, H, W, int(affine)), err=err, scale=scale)
+    assert err < 3e-6 * scale * max(1.0, (ks * ks * Cin / 256.0) ** 0.5)
+    sums = part.sum(dim=1).cpu()
+    assert torch.allclose(sums[..., 0], ref.sum(dim=(2, 3)), rtol=1e-5, atol=1e-4 * scale)
+    assert torch.allclose(sums[..., 1], (ref ** 2).sum(dim=(2, 3)), rtol=1e-5)
+    y2, none = pointflow.conv2d_wide(x.to(dev), conv, aff, 1, False)
+    assert none is None and torch.equal(y2, y)                           # deterministic
+    assert _lib.status() == 0
+
+
+def test_conv2d_wide_per_view_affine_rows(dev):
+    """samples_per_stat > 1: sample n takes affine row n // sps (the views of a scene batched along N)."""
+    gen = torch.Generator().manual_seed(5)
+    N, sps, C = 4, 2, 64
+    x = torch.randn(N, C, 12, 20, generator=gen)
+    conv = torch.nn.Conv2d(C, C, 3, padding=1, bias=False)
+    sc = torch.rand(N // sps, C, generator=gen) + 0.5
+    sh = torch.randn(N // sps, C, generator=gen) * 0.3
+    rows = torch.arange(N) // sps
+    xin = torch.relu(x.double() * sc.double()[rows].view(N, C, 1, 1) + sh.double()[rows].view(N, C, 1, 1))
+    ref = F.conv2d(xin, conv.weight.double(), None, 1, 1)
+    y, _ = pointflow.conv2d_wide(x.to(dev), conv.to(dev), (sc.to(dev), sh.to(dev)), sps, False)
+    assert _maxabs(y, ref) < 1e-5 * float(ref.abs().max())
+
+
 @pytest.mark.parametrize("concat,k", [(True, 5), (False, 8), (True, 16)])
 def test_edgeconv_fused_arbitrary_indices_vs_first_principles(dev, concat, k):
     """The module API takes ANY (B,N,k) int64 indices (not only lattice windows) and any k."""
