@@ -215,6 +215,16 @@ int pf_bn_finalize_jobs_f32(const pf_bn_job* jobs, int njobs, void* stream);
 int pf_bn_tail_rows(int G, int T);
 int pf_bn_tail_tickets(int G, int T);
 
+/* The finalize FOLDED INTO THE CONSUMER (`in_bn`, host pointer, of pf_pointwise_gemm_f32 / pf_conv2d_wide_f32 /
+ * pf_flow_head_f32; csrc/pf_bn_tail.h): instead of (in_scale, in_shift) rows the consumer gets the pf_bn_job of
+ * the pending BatchNorm -- finished statistics rows `partials` (G, T, pcols, 2) of the PRODUCER launch, count,
+ * gamma, beta, eps -- and every block computes the (scale, shift) of its statistic group itself while its first
+ * loads are in flight (fixed summation order: bit-reproducible).  The job's scale / shift rows and running
+ * statistics are NOT written by such a consumer: pf_bn_finalize_jobs_f32 on the same job, any time later and off
+ * the critical path, does that.  A consumer that cannot resolve (shape outside its fast path, more than 4096
+ * rows behind a statistic) runs the finalize itself, without the running-statistics update, into job.scale /
+ * job.shift (which must then be valid) and proceeds with those rows. */
+
 /* Y[m, 0:Nc_store] = act(X[m, 0:K]) * Wt, m over G*Ng points.  Wt is (K, Nc) row-major, Nc in
  * {32, 64, 128}.  X is channel-major (G, K, Ng) when x_point_major == 0 (the reference (B,C,N) layout)
  * or point-major rows of ldx floats.  act = ReLU(x*in_scale[s,k] + in_shift[s,k]) when in_scale != NULL
@@ -222,7 +232,7 @@ int pf_bn_tail_tickets(int G, int T);
  * col_partials (G, pf_gemm_blocks(G,Ng), Nc, 2) float64 or NULL receives per-block column sums of Y. */
 int pf_pointwise_gemm_f32(const float* X, int x_point_major, int64_t ldx, const float* Wt, float* Y,
                           int64_t ldy, int G, int Ng, int K, int Nc, int Nc_store, const float* in_scale,
-                          const float* in_shift, int groups_per_stat, double* col_partials,
+                          const float* in_shift, const pf_bn_job* in_bn, int groups_per_stat, double* col_partials,
                           const pf_bn_job* bn_jobs_host, int n_bn_jobs, unsigned* tickets, void* stream);
 
 /* Pass A of EdgeConv: for rows LE = [l (C) | e (C)] (point-major, ldle floats per point) and local
@@ -363,7 +373,7 @@ int pf_conv2d_wide_supported(int64_t Cin, int64_t Cout, int kernel_size, int str
 int pf_conv2d_wide_blocks(int64_t Cout, int64_t Hi, int64_t Wi, int stride);
 int pf_conv2d_wide_f32(const float* x, const float* wp, float* y, int64_t N, int64_t Cin, int64_t Cout, int64_t Hi,
                        int64_t Wi, int kernel_size, int stride, const float* in_scale, const float* in_shift,
-                       int samples_per_stat, double* partials, void* stream);
+                       const pf_bn_job* in_bn, int samples_per_stat, double* partials, void* stream);
 
 /* ---- rows M (last layer) + H + T : flow head ---------------------------------------------------
  * Z (G*Ng, ldz) holds the pre-BN output of the 64->16 MLP layer.  Per pixel of the (h,w) grid:
@@ -372,8 +382,9 @@ int pf_conv2d_wide_f32(const float* x, const float* wp, float* y, int64_t N, int
  * back in image order (undoing the sub-grid-major point order, model.py:256-266).
  * flow_prob (5,h,w), depth_out (h,w). */
 int pf_flow_head_f32(const float* Z, int64_t ldz, const float* scale, const float* shift, int ld_affine,
-                     const float* w_out, const float* depth_in, int dh, int dw, const float* interval, int h,
-                     int w, int ratio, float* flow_prob, float* depth_out, void* stream);
+                     const pf_bn_job* in_bn, const float* w_out, const float* depth_in, int dh, int dw,
+                     const float* interval, int h, int w, int ratio, float* flow_prob, float* depth_out,
+                     void* stream);
 
 /* ---- row S : soft-argmin + probability map -----------------------------------------------------
  * cost (B, D, HW) filtered cost volume; depth = sum_k linspace(start,end,D)[k] * softmax(-cost)[k]

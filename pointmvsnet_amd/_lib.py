@@ -49,8 +49,8 @@ PROTOTYPES = {
     "pf_gemm_blocks": ([_i, _i], _i),
     "pf_bn_tail_rows": ([_i, _i], _i),
     "pf_bn_tail_tickets": ([_i, _i], _i),
-    "pf_pointwise_gemm_f32": ([_vp, _i, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp,
-                               ctypes.POINTER(BnJob), _i, _vp, _vp], _i),
+    "pf_pointwise_gemm_f32": ([_vp, _i, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, ctypes.POINTER(BnJob), _i,
+                               _vp, ctypes.POINTER(BnJob), _i, _vp, _vp], _i),
     "pf_conv3d_blocks": ([_i64, _i64, _i64, _i64, _i64, _i], _i),
     "pf_conv3d_k3_f32": ([_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i, _vp, _vp], _i),
     "pf_conv3d_pair_blocks": ([_i64, _i64, _i64, _i64, _i64], _i),
@@ -63,7 +63,8 @@ PROTOTYPES = {
                        ctypes.POINTER(BnJob), _i, _vp, _vp], _i),
     "pf_conv2d_wide_supported": ([_i64, _i64, _i, _i], _i),
     "pf_conv2d_wide_blocks": ([_i64, _i64, _i64, _i], _i),
-    "pf_conv2d_wide_f32": ([_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i, _i, _vp, _vp, _i, _vp, _vp], _i),
+    "pf_conv2d_wide_f32": ([_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i, _i, _vp, _vp, ctypes.POINTER(BnJob), _i,
+                            _vp, _vp], _i),
     "pf_conv2d_small_blocks": ([_i64, _i64, _i64, _i, _i], _i),
     "pf_conv2d_small_f32": ([_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i, _i, _vp, _vp, _i, _vp,
                              ctypes.POINTER(BnJob), _i, _vp, _vp], _i),
@@ -80,7 +81,8 @@ PROTOTYPES = {
     "pf_bn_finalize_f32": ([_vp, _i, _i, _i, _i, _d, _d, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _i, _vp], _i),
     "pf_bn_finalize_jobs_f32": ([ctypes.POINTER(BnJob), _i, _vp], _i),
     "pf_edge_apply_f32": ([_vp, _i64, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _i64, _vp, _i, _i, _i, _vp], _i),
-    "pf_flow_head_f32": ([_vp, _i64, _vp, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp], _i),
+    "pf_flow_head_f32": ([_vp, _i64, _vp, _vp, _i, ctypes.POINTER(BnJob), _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp,
+                          _vp], _i),
     "pf_eval_pack_map_f32": ([_vp, _vp, _i, _i, _i, _vp], _i),
     "pf_eval_flow_prob_f32": ([_vp, _vp, _i, _i, _i, _vp], _i),
     "pf_eval_prob_filter_f32": ([_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _i, _vp], _i),

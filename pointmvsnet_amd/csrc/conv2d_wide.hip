@@ -28,6 +28,7 @@
 #include <stdlib.h>
 
 #include "pf_common.h"
+#include "pf_bn_tail.h"
 
 namespace {
 
@@ -61,12 +62,14 @@ struct WideCfg {
   static_assert(LDS <= 160 * 1024, "tile does not fit the LDS of a CU");
 };
 
-template <int KS, int STRIDE, int CIN, int COUT, bool AFFINE>
+// AFFINE: 0 = x is taken as is; 1 = relu(x * in_scale + in_shift), rows (N/sps, CIN); 2 = the same with the rows
+// computed here from the PRODUCER's statistics (pf_bn_resolve: the pending BatchNorm never gets its own launch)
+template <int KS, int STRIDE, int CIN, int COUT, int AFFINE>
 __global__ __launch_bounds__(256) void conv2d_wide_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                           float* __restrict__ y, WideGeom g,
                                                           const float* __restrict__ in_scale,
                                                           const float* __restrict__ in_shift,
-                                                          double* __restrict__ partials) {
+                                                          double* __restrict__ partials, pf_bn_job in_bn) {
   using C = WideCfg<KS, STRIDE, CIN, COUT>;
   constexpr int PW = C::PW, RS = C::RS, NPIX = C::NPIX, WROW = C::WROW, WROW4 = C::WROW4, NWR = C::NWR;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -122,13 +125,15 @@ __global__ __launch_bounds__(256) void conv2d_wide_kernel(const float* __restric
 #pragma unroll
     for (int j = 0; j < 4; ++j) rx[r][j] = src[j * plane_i];
   }
-  if (AFFINE) {
+  if (AFFINE == 1) {
     const float* sc = in_scale + (int64_t)(n / g.sps) * CIN;
     const float* sh = in_shift + (int64_t)(n / g.sps) * CIN;
     if (tid < CIN) aff[tid] = sc[tid];
     else if (tid < 2 * CIN) aff[tid] = sh[tid - CIN];
     __syncthreads();
   }
+  if (AFFINE == 2)   // (the weight buffers are still empty: 4 KB of them serve as the reduction scratch)
+    pf_bn_resolve<256>(in_bn, n / g.sps, aff, aff + CIN, reinterpret_cast<double*>(wbuf));
 #pragma unroll
   for (int r = 0; r < C::NIT; ++r) {
     const int it = tid + 256 * r;
@@ -238,28 +243,36 @@ __global__ __launch_bounds__(256) void conv2d_wide_kernel(const float* __restric
   }
 }
 
-template <int KS, int STRIDE, int CIN, int COUT>
-int launch_wide(const float* x, const float* wp, float* y, WideGeom g, int64_t N, const float* in_scale,
-                const float* in_shift, double* partials, hipStream_t s) {
+template <int KS, int STRIDE, int CIN, int COUT, int AFFINE>
+int launch_wide_mode(const float* x, const float* wp, float* y, WideGeom g, int64_t N, const float* in_scale,
+                     const float* in_shift, double* partials, const pf_bn_job& in_bn, hipStream_t s) {
   using C = WideCfg<KS, STRIDE, CIN, COUT>;
   if (C::LDS > 64 * 1024) {
     static std::atomic<unsigned long long> done{0};   // per instantiation, one bit per device
-    const void* fn = in_scale ? reinterpret_cast<const void*>(&conv2d_wide_kernel<KS, STRIDE, CIN, COUT, true>)
-                              : reinterpret_cast<const void*>(&conv2d_wide_kernel<KS, STRIDE, CIN, COUT, false>);
-    static std::atomic<unsigned long long> done_plain{0};
-    const int rc = pf_allow_big_lds(fn, (int)C::LDS, in_scale ? done : done_plain);
+    const int rc = pf_allow_big_lds(reinterpret_cast<const void*>(&conv2d_wide_kernel<KS, STRIDE, CIN, COUT, AFFINE>),
+                                    (int)C::LDS, done);
     if (rc != PF_OK) return rc;
   }
   g.tiles_w = (g.Wo + C::TW - 1) / C::TW;
   const int tiles_h = (g.Ho + C::TH - 1) / C::TH;
   dim3 grid((unsigned)(tiles_h * g.tiles_w), (unsigned)N);
-  if (in_scale)
-    hipLaunchKernelGGL((conv2d_wide_kernel<KS, STRIDE, CIN, COUT, true>), grid, dim3(256), C::LDS, s, x, wp, y, g,
-                       in_scale, in_shift, partials);
-  else
-    hipLaunchKernelGGL((conv2d_wide_kernel<KS, STRIDE, CIN, COUT, false>), grid, dim3(256), C::LDS, s, x, wp, y, g,
-                       in_scale, in_shift, partials);
+  hipLaunchKernelGGL((conv2d_wide_kernel<KS, STRIDE, CIN, COUT, AFFINE>), grid, dim3(256), C::LDS, s, x, wp, y, g,
+                     in_scale, in_shift, partials, in_bn);
   return pf_launch_status();
+}
+
+template <int KS, int STRIDE, int CIN, int COUT>
+int launch_wide(const float* x, const float* wp, float* y, WideGeom g, int64_t N, const float* in_scale,
+                const float* in_shift, double* partials, const pf_bn_job* in_bn, hipStream_t s) {
+  if (in_bn != nullptr) {
+    const int rc = pf_bn_in_check(in_bn, CIN, (int)(N / g.sps));
+    if (rc != PF_OK) return rc;
+    return launch_wide_mode<KS, STRIDE, CIN, COUT, 2>(x, wp, y, g, N, nullptr, nullptr, partials, *in_bn, s);
+  }
+  pf_bn_job none = {};
+  if (in_scale != nullptr)
+    return launch_wide_mode<KS, STRIDE, CIN, COUT, 1>(x, wp, y, g, N, in_scale, in_shift, partials, none, s);
+  return launch_wide_mode<KS, STRIDE, CIN, COUT, 0>(x, wp, y, g, N, nullptr, nullptr, partials, none, s);
 }
 
 int wide_tile_rows(int64_t Cout) { return Cout == 64 ? 4 : 8; }
@@ -283,9 +296,10 @@ int pf_conv2d_wide_blocks(int64_t Cout, int64_t Hi, int64_t Wi, int stride) {
 
 int pf_conv2d_wide_f32(const float* x, const float* wp, float* y, int64_t N, int64_t Cin, int64_t Cout, int64_t Hi,
                        int64_t Wi, int kernel_size, int stride, const float* in_scale, const float* in_shift,
-                       int samples_per_stat, double* partials, void* stream) {
+                       const pf_bn_job* in_bn, int samples_per_stat, double* partials, void* stream) {
   PF_REQUIRE(N >= 0 && Cin >= 1 && Cout >= 1 && Hi >= 1 && Wi >= 1 && N <= 65535 && samples_per_stat >= 1);
-  PF_REQUIRE((in_scale == nullptr) == (in_shift == nullptr));
+  PF_REQUIRE((in_scale == nullptr) == (in_shift == nullptr) && (in_bn == nullptr || in_scale == nullptr));
+  PF_REQUIRE(N % samples_per_stat == 0 || in_bn == nullptr);
   if (!pf_conv2d_wide_supported(Cin, Cout, kernel_size, stride)) return PF_ERR_UNSUPPORTED;
   PF_REQUIRE(Cin * Hi * Wi <= INT32_MAX);
   if (N == 0) return PF_OK;
@@ -299,11 +313,11 @@ int pf_conv2d_wide_f32(const float* x, const float* wp, float* y, int64_t N, int
   g.sps = samples_per_stat;
   hipStream_t s = (hipStream_t)stream;
   if (kernel_size == 3) {
-    if (Cin == 64) return launch_wide<3, 1, 64, 64>(x, wp, y, g, N, in_scale, in_shift, partials, s);
-    return launch_wide<3, 1, 32, 32>(x, wp, y, g, N, in_scale, in_shift, partials, s);
+    if (Cin == 64) return launch_wide<3, 1, 64, 64>(x, wp, y, g, N, in_scale, in_shift, partials, in_bn, s);
+    return launch_wide<3, 1, 32, 32>(x, wp, y, g, N, in_scale, in_shift, partials, in_bn, s);
   }
-  if (Cin == 32) return launch_wide<5, 2, 32, 64>(x, wp, y, g, N, in_scale, in_shift, partials, s);
-  return launch_wide<5, 2, 16, 32>(x, wp, y, g, N, in_scale, in_shift, partials, s);
+  if (Cin == 32) return launch_wide<5, 2, 32, 64>(x, wp, y, g, N, in_scale, in_shift, partials, in_bn, s);
+  return launch_wide<5, 2, 16, 32>(x, wp, y, g, N, in_scale, in_shift, partials, in_bn, s);
 }
 
 }  // extern "C"

@@ -236,11 +236,13 @@ __global__ __launch_bounds__(256, 2) void pointwise_gemm_kernel(
 // LDS for the block's lifetime (one barrier per block instead of one per chunk).  The summation order differs
 // from the chunked kernel's (still one exact f32 fmaf chain per output), so results agree to rounding, not bits.
 // ------------------------------------------------------------------------------------------------
-template <int KJ, int NT, bool AFFINE>
+// AFFINE: 0 = rows as they are; 1 = relu(x * in_scale + in_shift); 2 = the same, the rows computed by every block
+// from the producer's statistics (pf_bn_resolve, pf_bn_tail.h: the pending BatchNorm gets no launch of its own)
+template <int KJ, int NT, int AFFINE>
 __global__ __launch_bounds__(256) void pointwise_gemm_direct_kernel(
     const float* __restrict__ X, int64_t ldx, const float* __restrict__ Wt, float* __restrict__ Y, int64_t ldy,
     int Ng, int K, int Nc_store, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
-    int groups_per_stat, double* __restrict__ partials, int T) {
+    int groups_per_stat, double* __restrict__ partials, int T, pf_bn_job in_bn) {
   constexpr int NC = NT * 32;
   constexpr int KP = KJ * 8;                       // K rounded up to whole pieces
   constexpr int J0 = (KJ + 1) / 2, J1 = KJ - J0;   // the two halves of a row's pieces (software pipeline below)
@@ -249,6 +251,7 @@ __global__ __launch_bounds__(256) void pointwise_gemm_direct_kernel(
   constexpr bool kAlias = sizeof(float) * KP * NC >= sizeof(double) * (4 * NC * 2);
   __shared__ double red_own[kAlias ? 1 : 4 * NC * 2];
   double* red = kAlias ? reinterpret_cast<double*>(Ws) : red_own;      // W is dead once the tiles are done
+  __shared__ double bn_red[AFFINE == 2 ? 512 : 1];
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
@@ -277,13 +280,17 @@ __global__ __launch_bounds__(256) void pointwise_gemm_direct_kernel(
       }
     }
   }
-  if (AFFINE) {
+  if (AFFINE == 1) {
     const float* sc = in_scale + (int64_t)(g / groups_per_stat) * K;
     const float* sh = in_shift + (int64_t)(g / groups_per_stat) * K;
     for (int e = tid; e < KP; e += 256) {
       Aff[0][e] = e < K ? sc[e] : 0.0f;
       Aff[1][e] = e < K ? sh[e] : 0.0f;
     }
+  }
+  if (AFFINE == 2) {
+    if (tid < KP - K) Aff[0][K + tid] = Aff[1][K + tid] = 0.0f;
+    pf_bn_resolve<256>(in_bn, g / groups_per_stat, Aff[0], Aff[1], bn_red);   // (its W loads are in flight meanwhile)
   }
   __syncthreads();
 
@@ -872,7 +879,7 @@ __global__ __launch_bounds__(256) void edge_bwd_apply_kernel(const float* __rest
 // One launch serves up to kBnJobs independent finalize jobs (blockIdx.y) and splits the channels of a job
 // over blocks of kBnCB channels (blockIdx.x): the partial sums of one layer are up to ~1 MB, which a single
 // workgroup pulls through one CU's L1 in 5-13 us; channels are independent, so 8-16 CUs share the read.
-constexpr int kBnJobs = 4;
+constexpr int kBnJobs = 32;   // (3.3 KB of kernel arguments)
 constexpr int kBnCB = 4;
 constexpr int kBnThreads = 256;
 struct BnJobs {
@@ -965,6 +972,10 @@ __global__ __launch_bounds__(kBnThreads) void bn_finalize_kernel(BnJobs jobs) {
 // ------------------------------------------------------------------------------------------------
 // flow head
 // ------------------------------------------------------------------------------------------------
+// LAZY: the last BatchNorm of the MLP is resolved here (pf_bn_tail.h, consumer side): a block's pixels belong to
+// all ratio^2 sub-grids, so every block reduces the statistics rows of all S = G groups x 16 channels (one
+// (group, channel) pair per thread, S * 16 <= 256) -- the rows of the persistent GEMM blocks, 32-128 per group.
+template <bool LAZY>
 __global__ __launch_bounds__(256) void flow_head_kernel(const float* __restrict__ Z, int64_t ldz,
                                                         const float* __restrict__ scale,
                                                         const float* __restrict__ shift, int ld_affine,
@@ -973,7 +984,51 @@ __global__ __launch_bounds__(256) void flow_head_kernel(const float* __restrict_
                                                         const float* __restrict__ interval_p, int h, int w,
                                                         int ratio,
                                                         float* __restrict__ flow_prob,
-                                                        float* __restrict__ depth_out) {
+                                                        float* __restrict__ depth_out, pf_bn_job J) {
+  __shared__ float aff_s[2][LAZY ? 256 : 1];
+  __shared__ double red_s[LAZY ? 512 : 1];
+  if (LAZY) {
+    const int tid = threadIdx.x;
+    const int P = J.G * 16;                                  // (group, channel) pairs; groups_per_stat == 1
+    int slices = 256 / P;
+    if (slices > J.T) slices = J.T;
+    const int per = (J.T + slices - 1) / slices;
+    const int pair = tid % P, sl = tid / P;
+    double a = 0.0, b = 0.0;
+    if (sl < slices) {
+      const int sg = pair >> 4, c = pair & 15;
+      const double2* base = reinterpret_cast<const double2*>(J.partials) + (int64_t)sg * J.T * J.pcols + J.col0 + c;
+      const int r0 = sl * per, r1 = min(J.T, r0 + per);
+      for (int r = r0; r < r1; r += 16) {
+        double2 v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = base[(int64_t)min(r + u, r1 - 1) * J.pcols];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          a += (r + u < r1) ? v[u].x : 0.0;
+          b += (r + u < r1) ? v[u].y : 0.0;
+        }
+      }
+    }
+    red_s[2 * tid + 0] = a;
+    red_s[2 * tid + 1] = b;
+    __syncthreads();
+    if (tid < P) {
+      double sum = 0.0, sq = 0.0;
+      for (int q = 0; q < slices; ++q) {
+        sum += red_s[2 * (q * P + tid) + 0];
+        sq += red_s[2 * (q * P + tid) + 1];
+      }
+      const double mean = sum / J.count;
+      double var = sq / J.count - mean * mean;
+      var = var < 0.0 ? 0.0 : var;
+      const float invstd = (float)(1.0 / sqrt(var + (double)J.eps));
+      const float a_ = invstd * J.gamma[tid & 15];
+      aff_s[0][tid] = a_;
+      aff_s[1][tid] = J.beta[tid & 15] - (float)mean * a_;
+    }
+    __syncthreads();
+  }
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= h * w) return;
   const int y = i / w, x = i - y * w;
@@ -981,8 +1036,8 @@ __global__ __launch_bounds__(256) void flow_head_kernel(const float* __restrict_
   const int g = (y % ratio) * ratio + (x % ratio);
   const int64_t Ng = (int64_t)5 * hs * ws;
   const int64_t loc0 = (int64_t)(y / ratio) * ws + (x / ratio);
-  const float* sc = scale + (int64_t)g * ld_affine;
-  const float* sh = shift + (int64_t)g * ld_affine;
+  const float* sc = LAZY ? &aff_s[0][g * 16] : scale + (int64_t)g * ld_affine;
+  const float* sh = LAZY ? &aff_s[1][g * 16] : shift + (int64_t)g * ld_affine;
   float f[5];
 #pragma unroll
   for (int d = 0; d < 5; ++d) {
@@ -1067,10 +1122,40 @@ int pf_gemm_blocks(int G, int Ng) {
   return (tiles + per - 1) / per;
 }
 
+// A pending BatchNorm whose consumer cannot resolve it in its prologue: the ordinary finalize launch, minus the
+// running statistics (those belong to the one pf_bn_finalize_jobs_f32 call the owner of the job makes anyway).
+static int bn_materialize_rows(const pf_bn_job* in_bn, hipStream_t s) {
+  PF_REQUIRE(in_bn->scale != nullptr && in_bn->shift != nullptr && in_bn->ld_affine >= in_bn->C);
+  pf_bn_job j = *in_bn;
+  j.running_mean = j.running_var = nullptr;
+  return pf_bn_finalize_jobs_f32(&j, 1, s);
+}
+
 int pf_pointwise_gemm_f32(const float* X, int x_point_major, int64_t ldx, const float* Wt, float* Y, int64_t ldy,
                           int G, int Ng, int K, int Nc, int Nc_store, const float* in_scale,
-                          const float* in_shift, int groups_per_stat, double* col_partials, const pf_bn_job* bn_jobs,
-                          int n_bn_jobs, unsigned* tickets, void* stream) {
+                          const float* in_shift, const pf_bn_job* in_bn, int groups_per_stat, double* col_partials,
+                          const pf_bn_job* bn_jobs, int n_bn_jobs, unsigned* tickets, void* stream) {
+  PF_REQUIRE(in_bn == nullptr || in_scale == nullptr);
+  if (in_bn != nullptr && G > 0 && Ng > 0) {
+    PF_REQUIRE(groups_per_stat >= 1 && G % groups_per_stat == 0);
+    const int rc = pf_bn_in_check(in_bn, K, G / groups_per_stat);
+    if (rc != PF_OK && rc != PF_ERR_UNSUPPORTED) return rc;
+    const char* legacy = getenv("PF_GEMM_LEGACY");
+    const int kj = (K + 7) / 8, nt = Nc / 32;
+    const bool shape = (kj == 17 && nt == 2) || (kj == 4 && nt == 2) || (kj == 8 && nt == 4) || (kj == 28 && nt == 2) ||
+                       (kj == 8 && nt == 2) || (kj == 8 && nt == 1);
+    const bool direct = rc == PF_OK && shape && x_point_major && (K % 4) == 0 && (ldx % 4) == 0 &&
+                        kj * 8 * Nc <= 16384 && !(legacy && legacy[0] == '1') &&
+                        (reinterpret_cast<uintptr_t>(X) % 16) == 0 && n_bn_jobs == 0 && K <= 256;
+    if (!direct) {
+      const int rc2 = bn_materialize_rows(in_bn, (hipStream_t)stream);
+      if (rc2 != PF_OK) return rc2;
+      PF_REQUIRE(in_bn->ld_affine == K);
+      return pf_pointwise_gemm_f32(X, x_point_major, ldx, Wt, Y, ldy, G, Ng, K, Nc, Nc_store, in_bn->scale,
+                                   in_bn->shift, nullptr, groups_per_stat, col_partials, bn_jobs, n_bn_jobs, tickets,
+                                   stream);
+    }
+  }
   PF_REQUIRE(G >= 0 && Ng >= 0 && K >= 1 && Nc >= 32 && Nc_store >= 1 && Nc_store <= Nc);
   PF_REQUIRE(n_bn_jobs >= 0 && (n_bn_jobs == 0 || col_partials != nullptr));
   PF_REQUIRE(Nc % 32 == 0 && groups_per_stat >= 1);
@@ -1090,6 +1175,7 @@ int pf_pointwise_gemm_f32(const float* X, int x_point_major, int64_t ldx, const 
   hipStream_t s = (hipStream_t)stream;
   // the PointFlow chain's shapes (point-major rows, K a multiple of 4 that fits LDS with W): direct-A kernel
   {
+    const pf_bn_job no_bn = {};
     const char* legacy = getenv("PF_GEMM_LEGACY");
     const int kj = (K + 7) / 8, nt = Nc / 32;
     const bool direct = x_point_major && (K % 4) == 0 && (ldx % 4) == 0 && kj * 8 * Nc <= 16384 &&
@@ -1097,12 +1183,15 @@ int pf_pointwise_gemm_f32(const float* X, int x_point_major, int64_t ldx, const 
                         tail.njobs == 0;      // (a launch that finalizes its own BatchNorm takes the chunked kernel)
 #define PF_GEMM_DIRECT(KJV, NTV)                                                                                   \
   if (direct && kj == KJV && nt == NTV) {                                                                          \
-    if (in_scale != nullptr)                                                                                       \
-      hipLaunchKernelGGL((pointwise_gemm_direct_kernel<KJV, NTV, true>), grid, dim3(256), 0, s, X, ldx, Wt, Y, ldy, \
-                         Ng, K, Nc_store, in_scale, in_shift, groups_per_stat, col_partials, T);                    \
+    if (in_bn != nullptr)                                                                                          \
+      hipLaunchKernelGGL((pointwise_gemm_direct_kernel<KJV, NTV, 2>), grid, dim3(256), 0, s, X, ldx, Wt, Y, ldy,   \
+                         Ng, K, Nc_store, in_scale, in_shift, groups_per_stat, col_partials, T, *in_bn);           \
+    else if (in_scale != nullptr)                                                                                  \
+      hipLaunchKernelGGL((pointwise_gemm_direct_kernel<KJV, NTV, 1>), grid, dim3(256), 0, s, X, ldx, Wt, Y, ldy,   \
+                         Ng, K, Nc_store, in_scale, in_shift, groups_per_stat, col_partials, T, no_bn);            \
     else                                                                                                           \
-      hipLaunchKernelGGL((pointwise_gemm_direct_kernel<KJV, NTV, false>), grid, dim3(256), 0, s, X, ldx, Wt, Y, ldy, \
-                         Ng, K, Nc_store, in_scale, in_shift, groups_per_stat, col_partials, T);                    \
+      hipLaunchKernelGGL((pointwise_gemm_direct_kernel<KJV, NTV, 0>), grid, dim3(256), 0, s, X, ldx, Wt, Y, ldy,   \
+                         Ng, K, Nc_store, in_scale, in_shift, groups_per_stat, col_partials, T, no_bn);            \
     return pf_launch_status();                                                                                     \
   }
     PF_GEMM_DIRECT(17, 2)   // EdgeConvNoC 136 -> [32 | 32]
@@ -1305,14 +1394,35 @@ int pf_edge_backward_apply_f32(const float* LE, int64_t ldle, int C, const int64
 }
 
 int pf_flow_head_f32(const float* Z, int64_t ldz, const float* scale, const float* shift, int ld_affine,
-                     const float* w_out, const float* depth_in, int dh, int dw, const float* interval, int h,
-                     int w, int ratio, float* flow_prob, float* depth_out, void* stream) {
+                     const pf_bn_job* in_bn, const float* w_out, const float* depth_in, int dh, int dw,
+                     const float* interval, int h, int w, int ratio, float* flow_prob, float* depth_out,
+                     void* stream) {
   PF_REQUIRE(h >= 1 && w >= 1 && dh >= 1 && dw >= 1 && ratio >= 1 && h % ratio == 0 && w % ratio == 0);
-  PF_REQUIRE(ldz >= 16 && (ldz % 4) == 0 && ld_affine >= 16 && (int64_t)h * w <= INT32_MAX);
-  PF_REQUIRE(Z && scale && shift && w_out && depth_in && interval && flow_prob && depth_out);
+  PF_REQUIRE(ldz >= 16 && (ldz % 4) == 0 && (int64_t)h * w <= INT32_MAX);
+  PF_REQUIRE(Z && w_out && depth_in && interval && flow_prob && depth_out);
+  PF_REQUIRE((in_bn != nullptr) != (scale != nullptr) && (scale == nullptr) == (shift == nullptr));
   dim3 grid((unsigned)pf_cdiv((int64_t)h * w, 256));
-  hipLaunchKernelGGL(flow_head_kernel, grid, dim3(256), 0, (hipStream_t)stream, Z, ldz, scale, shift, ld_affine,
-                     w_out, depth_in, dh, dw, interval, h, w, ratio, flow_prob, depth_out);
+  hipStream_t s = (hipStream_t)stream;
+  if (in_bn != nullptr) {
+    const int rc = pf_bn_in_check(in_bn, 16, in_bn->G / (in_bn->groups_per_stat > 0 ? in_bn->groups_per_stat : 1));
+    if (rc != PF_OK && rc != PF_ERR_UNSUPPORTED) return rc;
+    PF_REQUIRE(in_bn->G == ratio * ratio);
+    if (rc == PF_OK && in_bn->groups_per_stat == 1 && in_bn->G * 16 <= 256) {
+      hipLaunchKernelGGL(flow_head_kernel<true>, grid, dim3(256), 0, s, Z, ldz, nullptr, nullptr, 0, w_out, depth_in,
+                         dh, dw, interval, h, w, ratio, flow_prob, depth_out, *in_bn);
+      return pf_launch_status();
+    }
+    PF_REQUIRE(in_bn->groups_per_stat == 1);     // (the kernel indexes its affine rows by sub-grid)
+    const int rc2 = bn_materialize_rows(in_bn, s);
+    if (rc2 != PF_OK) return rc2;
+    scale = in_bn->scale;
+    shift = in_bn->shift;
+    ld_affine = in_bn->ld_affine;
+  }
+  PF_REQUIRE(ld_affine >= 16);
+  const pf_bn_job no_bn = {};
+  hipLaunchKernelGGL(flow_head_kernel<false>, grid, dim3(256), 0, s, Z, ldz, scale, shift, ld_affine, w_out, depth_in,
+                     dh, dw, interval, h, w, ratio, flow_prob, depth_out, no_bn);
   return pf_launch_status();
 }
 

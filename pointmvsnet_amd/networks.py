@@ -244,13 +244,14 @@ class ImageConv(nn.Module):
             defer = (not wanted) and nconv is not None and \
                 (pointflow.conv2d_preferred(nconv) or pointflow.conv2d_small_preferred(nconv)
                  or pointflow.conv2d_wide_preferred(nconv))
-            x, pending = _conv2d_block_fused(block, x, pending, B, defer)
+            lazy = bool(defer) and pointflow.conv2d_wide_preferred(nconv)   # the next conv resolves this BatchNorm
+            x, pending = _conv2d_block_fused(block, x, pending, B, defer, lazy)
             if wanted:
                 out[name] = x.view(V, B, *x.shape[1:]).transpose(0, 1)
         return out
 
 
-def _conv2d_block_fused(block, x, pending, samples_per_stat, defer):
+def _conv2d_block_fused(block, x, pending, samples_per_stat, defer, lazy=False):
     """One tower block.  ``pending``: BN+ReLU affine rows not yet applied to x.  Returns (y, pending'): with
     ``defer`` the block's own BatchNorm+ReLU is returned as affine rows for the next (custom) conv to apply
     while staging; otherwise y is normalised in place (statistics + fused finalize/normalise)."""
@@ -279,7 +280,7 @@ def _conv2d_block_fused(block, x, pending, samples_per_stat, defer):
     if affine is not None:
         return y, affine
     if defer and relu:
-        return y, pointflow.bn_affine_rows(y, bn, samples_per_stat, partials)
+        return y, pointflow.bn_affine_rows(y, bn, samples_per_stat, partials, lazy=lazy)
     return pointflow.batch_norm_act_(y, bn, relu, samples_per_stat, partials=partials), None
 
 

@@ -9,6 +9,8 @@ its own kNN and its own BatchNorm batch statistics (reference model.py:231-267);
 groups of one batched launch (G = r*r, one stat group per group).  The nn.Module API of EdgeConv uses
 G = batch size with all groups pooled into one stat group (BatchNorm2d pools over the batch).
 """
+import ctypes
+
 import torch
 
 from . import _lib
@@ -186,18 +188,19 @@ def tail_args(jobs, G, T, dev):
 def pointwise_gemm(X, point_major, ldx, Wt, Y, ldy, G, Ng, K, nc_store, in_affine=None, groups_per_stat=1,
                    want_stats=False, bn_jobs=None):
     """Y[:, :nc_store] = act(X) @ Wt (see pf_pointwise_gemm_f32).  Returns the float64 column partials
-    (G, T, Nc, 2) when ``want_stats``.  ``bn_jobs`` (bn_job(..., partials=None) entries over the columns of Y):
-    the BatchNorm finalize jobs the launch performs itself (last block done), no separate launch."""
+    (G, T, Nc, 2) when ``want_stats``.  ``in_affine``: (scale, shift) rows, or a LazyAffine (the pending BatchNorm
+    is resolved by the GEMM's own blocks, no finalize launch).  ``bn_jobs`` (bn_job(..., partials=None) entries over
+    the columns of Y): the BatchNorm finalize jobs the launch performs itself (last block done), no separate launch."""
     Nc = Wt.shape[1]
     T = int(_lib.load().pf_gemm_blocks(int(G), int(Ng)))
     partials = stat_rows(G, T, Nc, Wt.device, bool(bn_jobs)) if (want_stats or bn_jobs) else None
-    sc, sh = in_affine if in_affine is not None else (None, None)
+    sc, sh, in_bn = _split_affine(in_affine)
     jobs, njobs, tk = tail_args(bn_jobs, G, T, Wt.device)
     _lib.call("pf_pointwise_gemm_f32",
               _lib.ptr(X), int(bool(point_major)), int(ldx), _lib.ptr(Wt), _lib.ptr(Y), int(ldy), int(G), int(Ng),
-              int(K), int(Nc), int(nc_store), _lib.ptr(sc), _lib.ptr(sh), int(groups_per_stat), _lib.ptr(partials),
-              jobs, njobs, tk, _lib.stream(), algo_bytes=4.0 * G * Ng * (K + nc_store) + 4.0 * K * Nc,
-              flops=2.0 * G * Ng * K * nc_store)
+              int(K), int(Nc), int(nc_store), _lib.ptr(sc), _lib.ptr(sh), in_bn, int(groups_per_stat),
+              _lib.ptr(partials), jobs, njobs, tk, _lib.stream(),
+              algo_bytes=4.0 * G * Ng * (K + nc_store) + 4.0 * K * Nc, flops=2.0 * G * Ng * K * nc_store)
     return partials
 
 
@@ -220,7 +223,7 @@ def bn_job(bn, partials, col0, C, count, unbias_n, G, groups_per_stat, scale, sh
 
 
 def bn_finalize_jobs(jobs):
-    """Up to four finalize jobs in one launch (pf_bn_finalize_jobs_f32)."""
+    """Up to 32 finalize jobs in one launch (pf_bn_finalize_jobs_f32)."""
     arr = (_lib.BnJob * len(jobs))(*jobs)
     _lib.call("pf_bn_finalize_jobs_f32", arr, len(jobs), _lib.stream(),
               algo_bytes=sum(16.0 * j.G * j.T * j.C for j in jobs))
@@ -229,6 +232,92 @@ def bn_finalize_jobs(jobs):
 def bn_affine(bn, partials, col0, C, count, unbias_n, G, groups_per_stat, scale, shift, ch0=0):
     """A single finalize job (see bn_job)."""
     bn_finalize_jobs([bn_job(bn, partials, col0, C, count, unbias_n, G, groups_per_stat, scale, shift, ch0)])
+
+
+# PF_LAZY_BN=1 (default): a train-mode BatchNorm whose statistics rows are few (persistent GEMM blocks, the small
+# maps of conv2d_wide) and whose consumer can resolve it (pf_bn_resolve, csrc/pf_bn_tail.h) gets NO finalize launch
+# on the critical path: the consumer's blocks compute (scale, shift) themselves, and the running statistics are
+# updated by batched finalize launches on a side stream (flush_lazy_stats / join at flush_counters).
+LAZY_BN = int(_os.environ.get("PF_LAZY_BN", "1"))
+LAZY_MAX_ROWS = 256            # rows behind one statistic that a consumer block is asked to re-reduce
+
+
+class LazyAffine(object):
+    """A pending train-mode BatchNorm(+ReLU): the finished statistics rows of its producer and everything the
+    finalize needs (one pf_bn_job).  Consumers with an ``in_bn`` slot take ``job_ptr()``; everybody else calls
+    ``rows()``, which runs the ordinary finalize launch (once) and returns the (scale, shift) rows."""
+
+    def __init__(self, job, keep, scale, shift):
+        self.job, self.keep, self.scale, self.shift = job, keep, scale, shift
+        self.done = False                 # finalize launched (rows valid, running statistics updated)
+        self.queued = False
+
+    def job_ptr(self):
+        if not (self.done or self.queued):
+            self.queued = True
+            _lazy_list(self.scale.device).append(self)
+        return ctypes.pointer(self.job)
+
+    def rows(self):
+        if not self.done:
+            bn_finalize_jobs([self.job])
+            self.done = True
+        return self.scale, self.shift
+
+
+def _split_affine(in_affine):
+    """(scale, shift, in_bn pointer) for a kernel with both kinds of input-affine slots."""
+    if in_affine is None:
+        return None, None, None
+    if isinstance(in_affine, LazyAffine):
+        if in_affine.done:
+            return in_affine.scale, in_affine.shift, None
+        return None, None, in_affine.job_ptr()
+    return in_affine[0], in_affine[1], None
+
+
+def affine_rows(in_affine):
+    """(scale, shift) rows of ``in_affine`` (a tuple, a LazyAffine or None) for consumers without an in_bn slot."""
+    if isinstance(in_affine, LazyAffine):
+        return in_affine.rows()
+    return in_affine
+
+
+def _lazy_list(device):
+    table = getattr(_pending, "lazy", None)
+    if table is None:
+        table = _pending.lazy = {}
+    return table.setdefault(str(device), [])
+
+
+def flush_lazy_stats(device=None):
+    """Running statistics (and the scale/shift rows) of every BatchNorm that was resolved by its consumer since
+    the last call: ONE batched finalize launch (<= 32 jobs each) on the current stream.  ``flush_counters`` calls
+    it at the end of a forward -- the only place where it is off every consumer's critical path without a
+    stream of its own (a further side stream made hipGraph serialise the coarse stage behind the flow tower:
+    profiles/r02ah_lazy_bn_side_stream_timeline.txt)."""
+    table = getattr(_pending, "lazy", {})
+    for dev in list(table.keys()):
+        if device is not None and str(device) != dev:
+            continue
+        lazy = [z for z in table[dev] if not z.done]
+        del table[dev][:]
+        # the jobs of one launch run concurrently: a module that was called several times (the flow MLP, once per
+        # PointFlow iteration) gets its running-statistics updates in call order, one launch per call
+        layers, seen = [], {}
+        for z in lazy:
+            k = seen.get(z.job.running_mean, 0) if z.job.running_mean else 0
+            if z.job.running_mean:
+                seen[z.job.running_mean] = k + 1
+            while len(layers) <= k:
+                layers.append([])
+            layers[k].append(z)
+        with torch.cuda.device(torch.device(dev)):
+            for layer in layers:
+                for i in range(0, len(layer), 32):
+                    bn_finalize_jobs([z.job for z in layer[i:i + 32]])
+        for z in lazy:
+            z.done = True
 
 
 # Concurrency level (PF_CONCURRENCY): 0 = single stream; 1 = flow tower beside the coarse stage;
@@ -271,6 +360,7 @@ def bump_counter(bn, n):
 
 
 def flush_counters():
+    flush_lazy_stats()
     for pending in list(getattr(_pending, "table", {}).values()):
         if pending:
             merged = {}
@@ -430,7 +520,7 @@ def conv2d_small(x, conv, in_affine, samples_per_stat, want_stats, bn=None):
         jobs, affine = _conv_bn_tail(bn, N, Cout, Ho * Wo, samples_per_stat, x.device)
     if want_stats or jobs:
         partials = stat_rows(N, T, Cout, x.device, bool(jobs))
-    sc, sh = in_affine if in_affine is not None else (None, None)
+    sc, sh = affine_rows(in_affine) or (None, None)
     jarr, njobs, tk = tail_args(jobs, N, T, x.device)
     _lib.call("pf_conv2d_small_f32", _lib.ptr(x), _lib.ptr(wp), _lib.ptr(y), N, Cin, Cout, Hi, Wi, int(ks),
               int(stride), _lib.ptr(sc), _lib.ptr(sh), int(samples_per_stat), _lib.ptr(partials), jarr, njobs, tk,
@@ -476,7 +566,7 @@ def conv2d(x, conv, in_affine, samples_per_stat, want_stats, bn=None):
         jobs, affine = _conv_bn_tail(bn, N, Cout, Ho * Wo, samples_per_stat, x.device)
     if want_stats or jobs:
         partials = stat_rows(N, T, Cout, x.device, bool(jobs))
-    sc, sh = in_affine if in_affine is not None else (None, None)
+    sc, sh = affine_rows(in_affine) or (None, None)
     jarr, njobs, tk = tail_args(jobs, N, T, x.device)
     _lib.call("pf_conv2d_f32", _lib.ptr(x), _lib.ptr(wp), _lib.ptr(y), N, Cin, Cout, Hi, Wi, int(ks), int(stride),
               _lib.ptr(sc), _lib.ptr(sh), int(samples_per_stat), _lib.ptr(partials), jarr, njobs, tk, _lib.stream(),
@@ -511,7 +601,8 @@ def pack_conv2d_wide_weight(weight):
 
 
 def conv2d_wide(x, conv, in_affine, samples_per_stat, want_stats):
-    """pf_conv2d_wide_f32: same contract as ``conv2d`` (raw y, statistics partials or None)."""
+    """pf_conv2d_wide_f32: same contract as ``conv2d`` (raw y, statistics partials or None); ``in_affine`` may be
+    a LazyAffine (resolved by the launch's own blocks)."""
     N, Cin, Hi, Wi = x.shape
     Cout = conv.out_channels
     ks, stride = conv.kernel_size[0], conv.stride[0]
@@ -522,9 +613,9 @@ def conv2d_wide(x, conv, in_affine, samples_per_stat, want_stats):
     if want_stats:
         T = int(_lib.load().pf_conv2d_wide_blocks(Cout, Hi, Wi, int(stride)))
         partials = stat_rows(N, T, Cout, x.device, False)
-    sc, sh = in_affine if in_affine is not None else (None, None)
+    sc, sh, in_bn = _split_affine(in_affine)
     _lib.call("pf_conv2d_wide_f32", _lib.ptr(x), _lib.ptr(wp), _lib.ptr(y), N, Cin, Cout, Hi, Wi, int(ks), int(stride),
-              _lib.ptr(sc), _lib.ptr(sh), int(samples_per_stat), _lib.ptr(partials), _lib.stream(),
+              _lib.ptr(sc), _lib.ptr(sh), in_bn, int(samples_per_stat), _lib.ptr(partials), _lib.stream(),
               algo_bytes=4.0 * N * (Cin * Hi * Wi + Cout * Ho * Wo) + 4.0 * ks * ks * Cin * Cout,
               flops=2.0 * N * Ho * Wo * ks * ks * Cin * Cout)
     return y, partials
@@ -532,6 +623,7 @@ def conv2d_wide(x, conv, in_affine, samples_per_stat, want_stats):
 
 def channel_affine_(x, affine, relu, samples_per_stat):
     """In place y = act(x*scale + shift) with (N/sps, C) affine rows."""
+    affine = affine_rows(affine)
     N, C = x.shape[:2]
     S = x[0, 0].numel()
     _lib.call("pf_channel_affine_f32", _lib.ptr(x), _lib.ptr(x), _lib.ptr(affine[0]), _lib.ptr(affine[1]), N, C, S,
@@ -556,9 +648,10 @@ def _bn_fused(x, y, bn, relu, samples_per_stat, scale=None, shift=None):
               algo_bytes=(8.0 if y is not None else 4.0) * N * C * S)
 
 
-def bn_affine_rows(x, bn, samples_per_stat, partials=None):
+def bn_affine_rows(x, bn, samples_per_stat, partials=None, lazy=False):
     """(scale, shift) rows (N/sps, C) of BatchNorm ``bn`` for the raw conv output x (N,C,*spatial): batch
-    statistics from ``partials`` (or a statistics pass over x) in train mode, running statistics in eval."""
+    statistics from ``partials`` (or a statistics pass over x) in train mode, running statistics in eval.
+    ``lazy``: the consumer has an ``in_bn`` slot -- with few statistics rows a LazyAffine is returned instead."""
     N, C = x.shape[:2]
     S = x[0, 0].numel()
     G = N // samples_per_stat
@@ -576,8 +669,11 @@ def bn_affine_rows(x, bn, samples_per_stat, partials=None):
             _lib.call("pf_channel_stats_f32", _lib.ptr(x), N, C, S, _lib.ptr(partials), _lib.stream(),
                       algo_bytes=4.0 * N * C * S)
         n = float(samples_per_stat) * S
-        bn_affine(bn, partials, 0, C, n, n, N, samples_per_stat, scale, shift)
         bump_counter(bn, G)
+        if lazy and LAZY_BN and samples_per_stat * partials.shape[1] <= LAZY_MAX_ROWS:
+            job = bn_job(bn, partials, 0, C, n, n, N, samples_per_stat, scale, shift)
+            return LazyAffine(job, (partials, scale, shift), scale, shift)
+        bn_affine(bn, partials, 0, C, n, n, N, samples_per_stat, scale, shift)
         return scale, shift
     sc, sh = eval_affine(bn, G, C)
     return sc.unsqueeze(0).expand(G, C).contiguous(), sh.unsqueeze(0).expand(G, C).contiguous()
@@ -751,15 +847,20 @@ def edge_conv_backward(keep, idx, grad_y, C, k, G, Ng, groups_per_stat, concat):
     return grad_le, red[..., 1].sum(dim=0).to(_F32), red[..., 0].sum(dim=0).to(_F32)
 
 
-def _bn_affine_from_gemm(bn, partials, C, G, Ng, groups_per_stat, dev):
-    """BatchNorm1d after a pointwise GEMM: statistics over the points of a stat group."""
+def _bn_affine_from_gemm(bn, partials, C, G, Ng, groups_per_stat, dev, lazy=False):
+    """BatchNorm1d after a pointwise GEMM: statistics over the points of a stat group.  ``lazy``: the caller's
+    next kernel has an ``in_bn`` slot -- return a LazyAffine instead of launching the finalize (train mode, few
+    statistics rows)."""
     S = G // groups_per_stat
     scale = torch.empty((S, C), dtype=_F32, device=dev)
     shift = torch.empty((S, C), dtype=_F32, device=dev)
     if bn.training or not bn.track_running_stats:
         n = float(groups_per_stat) * Ng
-        bn_affine(bn, partials, 0, C, n, n, G, groups_per_stat, scale, shift)
         bump_counter(bn, S)
+        if lazy and LAZY_BN and groups_per_stat * partials.shape[1] <= LAZY_MAX_ROWS:
+            job = bn_job(bn, partials, 0, C, n, n, G, groups_per_stat, scale, shift)
+            return LazyAffine(job, (partials, scale, shift), scale, shift)
+        bn_affine(bn, partials, 0, C, n, n, G, groups_per_stat, scale, shift)
     else:
         sc, sh = eval_affine(bn, S, C)
         scale.copy_(sc.unsqueeze(0).expand(S, C))
@@ -883,14 +984,15 @@ def flow_chain(feature, xyz, depth, interval, h, w, ratio, edge_convs, flow_mlp,
             affine = (scale, shift)
         else:
             part = pointwise_gemm(X, True, ldx, Wt, Z, cout, G, Ng, K, cout, in_affine=affine, want_stats=True)
-            affine = _bn_affine_from_gemm(bn, part, cout, G, Ng, 1, dev)
+            affine = _bn_affine_from_gemm(bn, part, cout, G, Ng, 1, dev, lazy=True)
         X, ldx, K = Z, cout, cout
     if K != 16 or last.weight.shape[0] != 1:
         raise NotImplementedError("flow head kernel is built for the reference widths (..., 16, 1)")
     depth_out = torch.empty((h, w), dtype=_F32, device=dev)
     flow_prob = torch.empty((5, h, w), dtype=_F32, device=dev)
     w_out = last.weight.detach().reshape(-1).to(_F32).contiguous()
-    _lib.call("pf_flow_head_f32", _lib.ptr(X), ldx, _lib.ptr(affine[0]), _lib.ptr(affine[1]), 16,
+    sc, sh, in_bn = _split_affine(affine)
+    _lib.call("pf_flow_head_f32", _lib.ptr(X), ldx, _lib.ptr(sc), _lib.ptr(sh), 16, in_bn,
               _lib.ptr(w_out), _lib.ptr(depth), int(depth.shape[-2]), int(depth.shape[-1]), _lib.ptr(interval), h, w,
               ratio, _lib.ptr(flow_prob), _lib.ptr(depth_out), _lib.stream(),
               algo_bytes=4.0 * G * Ng * 16 + 4.0 * h * w * 7)

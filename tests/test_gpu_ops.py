@@ -1051,3 +1051,92 @@ def test_pointwise_gemm_direct_kernel(dev, K, cout, ldx, G, Ng, monkeypatch):
         # the two kernels order the K sum differently: equal to float32 rounding
         assert _maxabs(outs[0][0], outs[1][0]) < 4e-6 * scale
     assert _lib.status() == 0
+
+
+# ---------------------------------------------------------------------------------------------
+# BatchNorm finalize folded into the CONSUMER (pf_bn_resolve, csrc/pf_bn_tail.h): same numbers as the separate
+# finalize launch, running statistics from the deferred batched finalize
+# ---------------------------------------------------------------------------------------------
+def _bn_pair(C, dev):
+    a, b = torch.nn.BatchNorm1d(C).to(dev).train(), torch.nn.BatchNorm1d(C).to(dev).train()
+    with torch.no_grad():
+        for m in (a, b):
+            m.weight.copy_(torch.linspace(0.5, 1.5, C))
+            m.bias.copy_(torch.linspace(-0.3, 0.3, C))
+    return a, b
+
+
+@pytest.mark.parametrize("G,Ng", [(16, 1600), (4, 6400), (3, 129), (1, 25600)])
+@pytest.mark.parametrize("K,cout", [(64, 64), (64, 16)])
+def test_gemm_resolves_pending_batchnorm_like_the_finalize_launch(dev, G, Ng, K, cout, monkeypatch):
+    gen = torch.Generator().manual_seed(G * 7 + Ng + cout)
+    w0 = torch.randn(K, 40, 1, generator=gen).to(dev)
+    w1 = torch.randn(cout, K, 1, generator=gen).to(dev)
+    x = torch.randn(G * Ng, 40, generator=gen).to(dev)
+    W0, _ = pointflow.pack_weight_t(w0)
+    W1, _ = pointflow.pack_weight_t(w1)
+    Z = torch.empty((G * Ng, K), device=dev)
+    part = pointflow.pointwise_gemm(x, True, 40, W0, Z, K, G, Ng, 40, K, want_stats=True)
+    bn_rows, bn_lazy = _bn_pair(K, dev)
+    rows = pointflow._bn_affine_from_gemm(bn_rows, part, K, G, Ng, 1, dev)
+    lazy = pointflow._bn_affine_from_gemm(bn_lazy, part, K, G, Ng, 1, dev, lazy=True)
+    assert isinstance(lazy, pointflow.LazyAffine) and not isinstance(rows, pointflow.LazyAffine)
+    outs = []
+    for aff in (rows, lazy):
+        Y = torch.empty((G * Ng, cout), device=dev)
+        pointflow.pointwise_gemm(Z, True, K, W1, Y, cout, G, Ng, K, cout, in_affine=aff)
+        outs.append(Y)
+    scale = float(outs[0].abs().max())
+    assert _maxabs(outs[0], outs[1]) < 2e-6 * scale          # (scale, shift) agree to float rounding
+    # the chunked kernel has no in_bn slot: the call materialises the rows itself (no running-stat update)
+    monkeypatch.setenv("PF_GEMM_LEGACY", "1")
+    bn_c, _ = _bn_pair(K, dev)
+    lazy2 = pointflow._bn_affine_from_gemm(bn_c, part, K, G, Ng, 1, dev, lazy=True)
+    Y2 = torch.empty((G * Ng, cout), device=dev)
+    pointflow.pointwise_gemm(Z, True, K, W1, Y2, cout, G, Ng, K, cout, in_affine=lazy2)
+    monkeypatch.delenv("PF_GEMM_LEGACY")
+    assert _maxabs(Y2, outs[0]) < 6e-6 * scale
+    # running statistics: untouched until the deferred finalize, then exactly the separate launch's
+    assert float(bn_lazy.running_mean.abs().max()) == 0.0
+    pointflow.flush_lazy_stats(dev)
+    pointflow.flush_counters()
+    torch.cuda.synchronize()
+    for b in (bn_lazy, bn_c):
+        assert torch.equal(b.running_mean, bn_rows.running_mean) and torch.equal(b.running_var, bn_rows.running_var)
+        assert int(b.num_batches_tracked) == G
+    assert torch.equal(lazy.scale, rows[0]) and torch.equal(lazy.shift, rows[1])
+    assert _lib.status() == 0
+
+
+@pytest.mark.parametrize("N,sps,Cin,Cout,H,W,ks,stride", [(3, 1, 32, 32, 128, 160, 3, 1), (4, 2, 64, 64, 23, 37, 3, 1),
+                                                           (3, 1, 32, 64, 64, 80, 5, 2)])
+def test_conv2d_wide_resolves_pending_batchnorm(dev, N, sps, Cin, Cout, H, W, ks, stride):
+    """producer conv (wide kernel, 3x3 Cin -> Cin, statistics in its epilogue) -> BatchNorm pending -> the consumer
+    conv resolves it in its prologue."""
+    gen = torch.Generator().manual_seed(N + Cin + H)
+    prod = torch.nn.Conv2d(Cin, Cin, 3, padding=1, bias=False).to(dev)
+    cons = torch.nn.Conv2d(Cin, Cout, ks, stride=stride, padding=ks // 2, bias=False).to(dev)
+    x = torch.randn(N, Cin, H, W, generator=gen).to(dev)
+    y0, part = pointflow.conv2d_wide(x, prod, None, sps, True)
+    bn_rows, bn_lazy = torch.nn.BatchNorm2d(Cin).to(dev).train(), torch.nn.BatchNorm2d(Cin).to(dev).train()
+    with torch.no_grad():
+        for m in (bn_rows, bn_lazy):
+            m.weight.copy_(torch.linspace(0.5, 1.5, Cin))
+            m.bias.copy_(torch.linspace(-0.3, 0.3, Cin))
+    rows = pointflow.bn_affine_rows(y0, bn_rows, sps, part)
+    lazy = pointflow.bn_affine_rows(y0, bn_lazy, sps, part, lazy=True)
+    assert isinstance(lazy, pointflow.LazyAffine)
+    ya, _ = pointflow.conv2d_wide(y0, cons, rows, sps, False)
+    yb, pb = pointflow.conv2d_wide(y0, cons, lazy, sps, True)
+    assert _maxabs(ya, yb) < 2e-6 * float(ya.abs().max())
+    # against torch: BatchNorm per stat group on the producer's output, ReLU, float64 convolution
+    G = N // sps
+    ref_in = torch.cat([torch.relu(F.batch_norm(y0[g * sps:(g + 1) * sps].double(), None, None, bn_rows.weight.double(),
+                                                bn_rows.bias.double(), True, 0.0, bn_rows.eps)) for g in range(G)])
+    ref = F.conv2d(ref_in, cons.weight.double(), None, stride, ks // 2)
+    assert _maxabs(yb, ref) < 2e-5 * float(ref.abs().max())
+    pointflow.flush_lazy_stats(dev)
+    pointflow.flush_counters()
+    torch.cuda.synchronize()
+    assert torch.equal(bn_lazy.running_mean, bn_rows.running_mean) and torch.equal(bn_lazy.running_var, bn_rows.running_var)
+    assert _lib.status() == 0
