@@ -364,10 +364,12 @@ int pf_conv2d_small_f32(const float* x, const float* wp, float* y, int64_t N, in
                         int samples_per_stat, double* partials, const pf_bn_job* bn_jobs_host, int n_bn_jobs,
                         unsigned* tickets, void* stream);
 
-/* ImageConv's 32- and 64-channel layers (reference networks.py:95-110: 3x3/1 32->32 and 64->64, 5x5/2 16->32 and
- * 32->64), the small-map mapping of pf_conv2d_f32's contract (csrc/conv2d_wide.hip): same x / y / in_scale /
- * in_shift / samples_per_stat / partials meaning, partials (N, pf_conv2d_wide_blocks(...), Cout, 2).  wp is the
- * weight packed (K, K, Cin/8, 2, Cout, 4): wp[kh][kw][kc][h][co][j] = w[co][8 kc + 4 h + j][kh][kw].
+/* ImageConv's 16-, 32- and 64-channel layers (reference networks.py:95-110: 3x3/1 16->16, 32->32, 64->64 and
+ * 5x5/2 8->16, 16->32, 32->64), the small-tile mapping of pf_conv2d_f32's contract (csrc/conv2d_wide.hip): same
+ * x / y / in_scale / in_shift / samples_per_stat / partials meaning, partials (N, pf_conv2d_wide_blocks(...),
+ * Cout, 2); in_bn: see "the finalize folded into the consumer" above.  wp is the weight packed
+ * (K, K, Cin/8, 2, Cout, 4): wp[kh][kw][kc][h][co][j] = w[co][8 kc + 4 h + j][kh][kw] for Cout 32 / 64, and
+ * (K, K, 4, 16, Cin/4): wp[kh][kw][kq][co][j] = w[co][(Cin/4) kq + j][kh][kw] for Cout 16.
  * PF_ERR_UNSUPPORTED for any other shape (pf_conv2d_wide_supported tells). */
 int pf_conv2d_wide_supported(int64_t Cin, int64_t Cout, int kernel_size, int stride);
 int pf_conv2d_wide_blocks(int64_t Cout, int64_t Hi, int64_t Wi, int stride);

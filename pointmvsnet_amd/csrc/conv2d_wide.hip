@@ -62,6 +62,57 @@ struct WideCfg {
   static_assert(LDS <= 160 * 1024, "tile does not fit the LDS of a CU");
 };
 
+// The input patch of a block: NCHW planes -> [pixel][channel] in LDS, the previous BatchNorm+ReLU on the way.
+// All of a thread's loads first (NIT x 4 independent dwords in flight), then the affine and the 16-byte LDS writes.
+// AFFINE: 0 = x as it is; 1 = relu(x * in_scale + in_shift), rows (N/sps, CIN); 2 = the same, the rows computed
+// here from the PRODUCER's statistics (pf_bn_resolve; `scratch`: 4 KB of LDS nobody uses yet).
+template <int CIN, int NPIX, int PW, int RS, int AFFINE>
+__device__ __forceinline__ void wide_stage_patch(const float* __restrict__ xb, int plane_i, int ih0, int iw0, int Hi,
+                                                 int Wi, float* patch, float* aff, const float* __restrict__ in_scale,
+                                                 const float* __restrict__ in_shift, int stat, const pf_bn_job& in_bn,
+                                                 double* scratch) {
+  constexpr int ITEMS = NPIX * (CIN / 4);             // (pixel, channel quad) pairs of the patch
+  constexpr int NIT = (ITEMS + 255) / 256;
+  const int tid = threadIdx.x;
+  float rx[NIT][4];
+  bool rok[NIT];
+#pragma unroll
+  for (int r = 0; r < NIT; ++r) {
+    const int it = tid + 256 * r;
+    const int itc = it < ITEMS ? it : ITEMS - 1;
+    const int q = itc / NPIX, p = itc - q * NPIX;       // lanes walk the patch's pixels: coalesced along a patch row
+    const int pr = p / PW, pc = p - pr * PW;
+    const int ih = ih0 + pr, iw = iw0 + pc;
+    rok[r] = ih >= 0 && ih < Hi && iw >= 0 && iw < Wi;
+    const float* src = xb + (int64_t)(4 * q) * plane_i + (rok[r] ? ih * Wi + iw : 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rx[r][j] = src[j * plane_i];
+  }
+  if (AFFINE == 1) {
+    const float* sc = in_scale + (int64_t)stat * CIN;
+    const float* sh = in_shift + (int64_t)stat * CIN;
+    if (tid < CIN) aff[tid] = sc[tid];
+    else if (tid < 2 * CIN) aff[tid] = sh[tid - CIN];
+    __syncthreads();
+  }
+  if (AFFINE == 2) pf_bn_resolve<256>(in_bn, stat, aff, aff + CIN, scratch);
+#pragma unroll
+  for (int r = 0; r < NIT; ++r) {
+    const int it = tid + 256 * r;
+    const int itc = it < ITEMS ? it : ITEMS - 1;
+    const int q = itc / NPIX, p = itc - q * NPIX;
+    f32x4 v = {rx[r][0], rx[r][1], rx[r][2], rx[r][3]};
+    if (AFFINE) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(aff + 4 * q);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(aff + CIN + 4 * q);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(v[j], a[j], b[j]), 0.0f);
+    }
+    if (!rok[r]) v = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};                       // zero padding applies AFTER it
+    if (256 * (r + 1) <= ITEMS || it < ITEMS) *reinterpret_cast<f32x4*>(patch + p * RS + 4 * q) = v;
+  }
+}
+
 // AFFINE: 0 = x is taken as is; 1 = relu(x * in_scale + in_shift), rows (N/sps, CIN); 2 = the same with the rows
 // computed here from the PRODUCER's statistics (pf_bn_resolve: the pending BatchNorm never gets its own launch)
 template <int KS, int STRIDE, int CIN, int COUT, int AFFINE>
@@ -109,46 +160,8 @@ __global__ __launch_bounds__(256) void conv2d_wide_kernel(const float* __restric
   };
   load_w(0);
 
-  // ---- the input patch: NCHW planes -> [pixel][channel] in LDS, previous BatchNorm+ReLU on the way ---------------
-  // all of a thread's loads first (NIT x 4 independent dwords in flight), then the affine and the 16-byte LDS writes
-  float rx[C::NIT][4];
-  bool rok[C::NIT];
-#pragma unroll
-  for (int r = 0; r < C::NIT; ++r) {
-    const int it = tid + 256 * r;
-    const int itc = it < C::ITEMS ? it : C::ITEMS - 1;
-    const int q = itc / NPIX, p = itc - q * NPIX;       // lanes walk the patch's pixels: coalesced along a patch row
-    const int pr = p / PW, pc = p - pr * PW;
-    const int ih = ih0 + pr, iw = iw0 + pc;
-    rok[r] = ih >= 0 && ih < g.Hi && iw >= 0 && iw < g.Wi;
-    const float* src = xb + (int64_t)(4 * q) * plane_i + (rok[r] ? ih * g.Wi + iw : 0);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) rx[r][j] = src[j * plane_i];
-  }
-  if (AFFINE == 1) {
-    const float* sc = in_scale + (int64_t)(n / g.sps) * CIN;
-    const float* sh = in_shift + (int64_t)(n / g.sps) * CIN;
-    if (tid < CIN) aff[tid] = sc[tid];
-    else if (tid < 2 * CIN) aff[tid] = sh[tid - CIN];
-    __syncthreads();
-  }
-  if (AFFINE == 2)   // (the weight buffers are still empty: 4 KB of them serve as the reduction scratch)
-    pf_bn_resolve<256>(in_bn, n / g.sps, aff, aff + CIN, reinterpret_cast<double*>(wbuf));
-#pragma unroll
-  for (int r = 0; r < C::NIT; ++r) {
-    const int it = tid + 256 * r;
-    const int itc = it < C::ITEMS ? it : C::ITEMS - 1;
-    const int q = itc / NPIX, p = itc - q * NPIX;
-    f32x4 v = {rx[r][0], rx[r][1], rx[r][2], rx[r][3]};
-    if (AFFINE) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(aff + 4 * q);
-      const f32x4 b = *reinterpret_cast<const f32x4*>(aff + CIN + 4 * q);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(v[j], a[j], b[j]), 0.0f);
-    }
-    if (!rok[r]) v = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};                       // zero padding applies AFTER it
-    if (256 * (r + 1) <= C::ITEMS || it < C::ITEMS) *reinterpret_cast<f32x4*>(patch + p * RS + 4 * q) = v;
-  }
+  wide_stage_patch<CIN, NPIX, PW, RS, AFFINE>(xb, plane_i, ih0, iw0, g.Hi, g.Wi, patch, aff, in_scale, in_shift,
+                                              n / g.sps, in_bn, reinterpret_cast<double*>(wbuf));
   store_w(0);
   __syncthreads();
 
@@ -275,20 +288,204 @@ int launch_wide(const float* x, const float* wp, float* y, WideGeom g, int64_t N
   return launch_wide_mode<KS, STRIDE, CIN, COUT, 0>(x, wp, y, g, N, nullptr, nullptr, partials, none, s);
 }
 
-int wide_tile_rows(int64_t Cout) { return Cout == 64 ? 4 : 8; }
+// ------------------------------------------------------------------------------------------------
+// C_out = 16 (conv1.x of the towers: 8 -> 16 5x5/2 and 16 -> 16 3x3 on 256 x 320 maps): the same idea on
+// v_mfma_f32_16x16x4_f32 -- lane (i = lane & 15, kq = lane >> 4) is pixel i of a 16-pixel output row for the A
+// operand and output channel i for B; its reduction slice is  c = (C_in / 4) kq + j : one 16-byte (C_in = 16) or
+// 8-byte (C_in = 8) LDS read feeds C_in / 4 MFMA steps of a tap.  A block owns 16 x 16 output pixels, wave w the
+// rows 4 w .. 4 w + 3 (four M tiles that share every B read); ALL weights (9-13 KB) stay in LDS, no barrier inside
+// the tile.  960 blocks of 26-72 KB LDS on the cfg2 maps: 2-4 blocks per CU cover each other's latencies.
+// ------------------------------------------------------------------------------------------------
+template <int KS, int STRIDE, int CIN>
+struct Wide16Cfg {
+  static constexpr int TH = 16, TW = 16, COUT = 16;
+  static constexpr int PAD = KS / 2;
+  static constexpr int PH = (TH - 1) * STRIDE + KS, PW = (TW - 1) * STRIDE + KS;
+  static constexpr int NPIX = PH * PW;
+  static constexpr int RS = CIN + 4;
+  static constexpr int PATCH = NPIX * RS;
+  static constexpr int CPL = CIN / 4;                  // channels per lane and tap (4: one b128 read, 2: one b64)
+  static constexpr int WALL = KS * KS * CIN * COUT;    // packed weights [tap][kq][c_out][CPL]
+  static constexpr size_t LDS = sizeof(float) * (size_t)(PATCH + WALL + 2 * CIN) + sizeof(double) * 4 * 16 * 2;
+  static_assert(CIN == 8 || CIN == 16, "C_in is 8 or 16");
+  static_assert(PATCH % 4 == 0 && WALL % 4 == 0 && sizeof(float) * WALL >= 4096, "16-byte pieces, 4 KB of scratch");
+  static_assert(LDS <= 80 * 1024, "two blocks per CU");
+};
+
+template <int KS, int STRIDE, int CIN, int AFFINE>
+__global__ __launch_bounds__(256) void conv2d_wide16_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                            float* __restrict__ y, WideGeom g,
+                                                            const float* __restrict__ in_scale,
+                                                            const float* __restrict__ in_shift,
+                                                            double* __restrict__ partials, pf_bn_job in_bn) {
+  using C = Wide16Cfg<KS, STRIDE, CIN>;
+  constexpr int PW = C::PW, RS = C::RS, NPIX = C::NPIX, CPL = C::CPL, COUT = 16;
+  typedef float opv __attribute__((ext_vector_type(CPL)));
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* patch = lds;
+  float* wl = lds + C::PATCH;
+  float* aff = wl + C::WALL;
+  double* red = reinterpret_cast<double*>(aff + 2 * CIN);
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int li = lane & 15, kq = lane >> 4;
+  const int n = blockIdx.y;
+  const int tw = blockIdx.x % g.tiles_w, th = blockIdx.x / g.tiles_w;
+  const int oh0 = th * C::TH, ow0 = tw * C::TW;
+  const int ih0 = oh0 * STRIDE - C::PAD, iw0 = ow0 * STRIDE - C::PAD;
+  const int plane_i = g.Hi * g.Wi;
+  const float* xb = x + (int64_t)n * CIN * plane_i;
+
+  // all weights: global -> registers now, -> LDS after the patch (the resolve borrows the space until then)
+  constexpr int W4 = C::WALL / 4, NWR = (W4 + 255) / 256;
+  f32x4 rw[NWR];
+#pragma unroll
+  for (int r = 0; r < NWR; ++r) {
+    const int e = tid + 256 * r;
+    rw[r] = reinterpret_cast<const f32x4*>(wp)[e < W4 ? e : W4 - 1];
+  }
+  wide_stage_patch<CIN, NPIX, PW, RS, AFFINE>(xb, plane_i, ih0, iw0, g.Hi, g.Wi, patch, aff, in_scale, in_shift,
+                                              n / g.sps, in_bn, reinterpret_cast<double*>(wl));
+#pragma unroll
+  for (int r = 0; r < NWR; ++r) {
+    const int e = tid + 256 * r;
+    if (256 * (r + 1) <= W4 || e < W4) reinterpret_cast<f32x4*>(wl)[e] = rw[r];
+  }
+  __syncthreads();
+
+  f32x4 acc[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+  const float* abase = patch + ((4 * wave) * STRIDE * PW + li * STRIDE) * RS + CPL * kq;
+  const float* bbase = wl + (kq * COUT + li) * CPL;
+  constexpr int TAPS = KS * KS;
+  auto read_a = [&](int t, opv* a) {
+    const int kh = t / KS, kw = t - kh * KS;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a[r] = *reinterpret_cast<const opv*>(abase + ((r * STRIDE + kh) * PW + kw) * RS);
+  };
+  opv a[4], b;
+  read_a(0, a);
+  b = *reinterpret_cast<const opv*>(bbase);
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t) {
+    opv an[4], bn = b;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) an[r] = a[r];
+    if (t + 1 < TAPS) {
+      read_a(t + 1, an);
+      bn = *reinterpret_cast<const opv*>(bbase + (t + 1) * 4 * COUT * CPL);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < CPL; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][j], b[j], acc[r], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a[r] = an[r];
+    b = bn;
+  }
+
+  // ---- epilogue: C/D layout column (channel) = lane & 15, rows (pixels of the output row) 4 kq + {0..3} -------------
+  float* yb = y + ((int64_t)n * COUT + li) * ((int64_t)g.Ho * g.Wo);
+  const bool vec_ok = (g.Wo & 3) == 0;
+  float s = 0.0f, q = 0.0f;
+  const int ow = ow0 + 4 * kq;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int oh = oh0 + 4 * wave + r;
+    if (oh < g.Ho) {
+      float* dst = yb + (int64_t)oh * g.Wo + ow;
+      if (vec_ok && ow + 3 < g.Wo) {
+        *reinterpret_cast<f32x4*>(dst) = acc[r];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s += acc[r][e];
+          q += acc[r][e] * acc[r][e];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (ow + e < g.Wo) {
+            dst[e] = acc[r][e];
+            s += acc[r][e];
+            q += acc[r][e] * acc[r][e];
+          }
+        }
+      }
+    }
+  }
+  if (partials != nullptr) {
+    s += __shfl_xor(s, 16);
+    q += __shfl_xor(q, 16);
+    s += __shfl_xor(s, 32);
+    q += __shfl_xor(q, 32);
+    if (lane < 16) {
+      red[(wave * 16 + lane) * 2 + 0] = (double)s;
+      red[(wave * 16 + lane) * 2 + 1] = (double)q;
+    }
+    __syncthreads();
+    if (tid < COUT) {
+      double ds = 0.0, dq = 0.0;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        ds += red[(w * 16 + tid) * 2 + 0];
+        dq += red[(w * 16 + tid) * 2 + 1];
+      }
+      double* o = partials + (((int64_t)n * gridDim.x + blockIdx.x) * COUT + tid) * 2;
+      o[0] = ds;
+      o[1] = dq;
+    }
+  }
+}
+
+template <int KS, int STRIDE, int CIN, int AFFINE>
+int launch_wide16_mode(const float* x, const float* wp, float* y, WideGeom g, int64_t N, const float* in_scale,
+                       const float* in_shift, double* partials, const pf_bn_job& in_bn, hipStream_t s) {
+  using C = Wide16Cfg<KS, STRIDE, CIN>;
+  if (C::LDS > 64 * 1024) {
+    static std::atomic<unsigned long long> done{0};
+    const int rc = pf_allow_big_lds(reinterpret_cast<const void*>(&conv2d_wide16_kernel<KS, STRIDE, CIN, AFFINE>),
+                                    (int)C::LDS, done);
+    if (rc != PF_OK) return rc;
+  }
+  g.tiles_w = (g.Wo + C::TW - 1) / C::TW;
+  const int tiles_h = (g.Ho + C::TH - 1) / C::TH;
+  dim3 grid((unsigned)(tiles_h * g.tiles_w), (unsigned)N);
+  hipLaunchKernelGGL((conv2d_wide16_kernel<KS, STRIDE, CIN, AFFINE>), grid, dim3(256), C::LDS, s, x, wp, y, g, in_scale,
+                     in_shift, partials, in_bn);
+  return pf_launch_status();
+}
+
+template <int KS, int STRIDE, int CIN>
+int launch_wide16(const float* x, const float* wp, float* y, WideGeom g, int64_t N, const float* in_scale,
+                  const float* in_shift, double* partials, const pf_bn_job* in_bn, hipStream_t s) {
+  if (in_bn != nullptr) {
+    const int rc = pf_bn_in_check(in_bn, CIN, (int)(N / g.sps));
+    if (rc != PF_OK) return rc;
+    return launch_wide16_mode<KS, STRIDE, CIN, 2>(x, wp, y, g, N, nullptr, nullptr, partials, *in_bn, s);
+  }
+  pf_bn_job none = {};
+  if (in_scale != nullptr) return launch_wide16_mode<KS, STRIDE, CIN, 1>(x, wp, y, g, N, in_scale, in_shift, partials, none, s);
+  return launch_wide16_mode<KS, STRIDE, CIN, 0>(x, wp, y, g, N, nullptr, nullptr, partials, none, s);
+}
+
+int wide_tile_rows(int64_t Cout) { return Cout == 64 ? 4 : (Cout == 32 ? 8 : 16); }
 
 }  // namespace
 
 extern "C" {
 
 int pf_conv2d_wide_supported(int64_t Cin, int64_t Cout, int kernel_size, int stride) {
-  if (kernel_size == 3 && stride == 1) return (Cin == 64 && Cout == 64) || (Cin == 32 && Cout == 32);
-  if (kernel_size == 5 && stride == 2) return (Cin == 32 && Cout == 64) || (Cin == 16 && Cout == 32);
+  if (kernel_size == 3 && stride == 1) return (Cin == 64 && Cout == 64) || (Cin == 32 && Cout == 32) || (Cin == 16 && Cout == 16);
+  if (kernel_size == 5 && stride == 2) return (Cin == 32 && Cout == 64) || (Cin == 16 && Cout == 32) || (Cin == 8 && Cout == 16);
   return 0;
 }
 
 int pf_conv2d_wide_blocks(int64_t Cout, int64_t Hi, int64_t Wi, int stride) {
-  if ((Cout != 32 && Cout != 64) || Hi <= 0 || Wi <= 0 || (stride != 1 && stride != 2)) return 0;
+  if ((Cout != 16 && Cout != 32 && Cout != 64) || Hi <= 0 || Wi <= 0 || (stride != 1 && stride != 2)) return 0;
   const int64_t Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;
   const int th = wide_tile_rows(Cout);
   return (int)(((Ho + th - 1) / th) * ((Wo + 15) / 16));
@@ -312,6 +509,10 @@ int pf_conv2d_wide_f32(const float* x, const float* wp, float* y, int64_t N, int
   g.tiles_w = 0;
   g.sps = samples_per_stat;
   hipStream_t s = (hipStream_t)stream;
+  if (Cout == 16) {
+    if (kernel_size == 3) return launch_wide16<3, 1, 16>(x, wp, y, g, N, in_scale, in_shift, partials, in_bn, s);
+    return launch_wide16<5, 2, 8>(x, wp, y, g, N, in_scale, in_shift, partials, in_bn, s);
+  }
   if (kernel_size == 3) {
     if (Cin == 64) return launch_wide<3, 1, 64, 64>(x, wp, y, g, N, in_scale, in_shift, partials, in_bn, s);
     return launch_wide<3, 1, 32, 32>(x, wp, y, g, N, in_scale, in_shift, partials, in_bn, s);

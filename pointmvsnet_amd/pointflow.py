@@ -576,10 +576,11 @@ def conv2d(x, conv, in_affine, samples_per_stat, want_stats, bn=None):
 
 
 CONV2D_WIDE = int(_os.environ.get("PF_CONV2D_WIDE", "1"))     # 0: 64-channel tower layers on the library convolution
+CONV2D_WIDE_MIN = int(_os.environ.get("PF_CONV2D_WIDE_MIN", "16"))   # 32: the 16-channel layers stay on pf_conv2d_f32
 
 
 def conv2d_wide_supported(conv):
-    """Shapes pf_conv2d_wide_f32 is built for: 3x3/1 32->32, 64->64 and 5x5/2 16->32, 32->64."""
+    """Shapes pf_conv2d_wide_f32 is built for: 3x3/1 16->16, 32->32, 64->64 and 5x5/2 8->16, 16->32, 32->64."""
     return conv2d_supported(conv) and bool(_lib.load().pf_conv2d_wide_supported(
         conv.in_channels, conv.out_channels, int(conv.kernel_size[0]), int(conv.stride[0])))
 
@@ -588,13 +589,18 @@ def conv2d_wide_preferred(conv):
     """Measured (profiles/r02ag_microbench_conv2d_wide.log, cfg2 shapes, 3 views; us): 16->32 5x5/2 25.1 (pf_conv2d_f32
     31.0, library 34.7), 32->32 3x3 16.7 (22.8, 24.4), 32->64 5x5/2 21.0 (40.5, 31.9), 64->64 3x3 16.5 (38.0, 24.6) --
     62-76 TF of exact f32: every 32- and 64-channel tower layer runs on csrc/conv2d_wide.hip."""
-    return bool(CONV2D_WIDE) and conv2d_wide_supported(conv)
+    return bool(CONV2D_WIDE) and conv.out_channels >= CONV2D_WIDE_MIN and conv2d_wide_supported(conv)
 
 
 def pack_conv2d_wide_weight(weight):
-    """(Cout,Cin,K,K) -> (K, K, Cin/8, 2, Cout, 4): [kh][kw][kc][h][co][j] = w[co][8 kc + 4 h + j][kh][kw]."""
+    """(Cout,Cin,K,K) -> (K, K, Cin/8, 2, Cout, 4): [kh][kw][kc][h][co][j] = w[co][8 kc + 4 h + j][kh][kw]
+    (Cout 32 / 64: 32x32x2 MFMA), or, for Cout = 16 (16x16x4 MFMA), (K, K, 4, 16, Cin/4):
+    [kh][kw][kq][co][j] = w[co][(Cin/4) kq + j][kh][kw]."""
     def make():
         cout, cin, k, _ = weight.shape
+        if cout == 16:
+            w = weight.detach().to(_F32).permute(2, 3, 1, 0).reshape(k, k, 4, cin // 4, cout)
+            return w.permute(0, 1, 2, 4, 3).contiguous()
         w = weight.detach().to(_F32).permute(2, 3, 1, 0).reshape(k, k, cin // 8, 2, 4, cout)
         return w.permute(0, 1, 2, 3, 5, 4).contiguous()
     return _cached_pack(("c2w", id(weight)), (weight,), make)

@@ -659,7 +659,9 @@ def test_conv2d_vs_fp64(dev, N, Cin, Cout, H, W, ks, stride, affine):
                                                        (3, 32, 64, 128, 160, 5, 2), (1, 32, 64, 37, 51, 5, 2),
                                                        (3, 32, 32, 32, 48, 3, 1), (1, 32, 32, 13, 30, 3, 1),
                                                        (2, 16, 32, 64, 80, 5, 2), (1, 16, 32, 27, 33, 5, 2),
-                                                       (1, 64, 64, 3, 5, 3, 1)])
+                                                       (1, 64, 64, 3, 5, 3, 1), (3, 16, 16, 64, 96, 3, 1),
+                                                       (2, 16, 16, 33, 47, 3, 1), (2, 8, 16, 128, 160, 5, 2),
+                                                       (1, 8, 16, 61, 75, 5, 2), (1, 16, 16, 5, 3, 3, 1)])
 @pytest.mark.parametrize("affine", [False, True])
 def test_conv2d_wide_vs_fp64(dev, N, Cin, Cout, H, W, ks, stride, affine):
     """csrc/conv2d_wide.hip (the 32x32x2-MFMA mapping for the towers' small maps) against a float64 convolution:
