@@ -369,7 +369,8 @@ int pf_conv2d_small_f32(const float* x, const float* wp, float* y, int64_t N, in
  * x / y / in_scale / in_shift / samples_per_stat / partials meaning, partials (N, pf_conv2d_wide_blocks(...),
  * Cout, 2); in_bn: see "the finalize folded into the consumer" above.  wp is the weight packed
  * (K, K, Cin/8, 2, Cout, 4): wp[kh][kw][kc][h][co][j] = w[co][8 kc + 4 h + j][kh][kw] for Cout 32 / 64, and
- * (K, K, 4, 16, Cin/4): wp[kh][kw][kq][co][j] = w[co][(Cin/4) kq + j][kh][kw] for Cout 16.
+ * (K, K, 4, 16, Cin'/4), Cin' = Cin rounded up to 4: wp[kh][kw][kq][co][j] = w[co][(Cin'/4) kq + j][kh][kw] for
+ * Cout 8 / 16 (zero where co >= Cout or the channel does not exist; shapes 3x3/1 3->8 and 8->8 as well).
  * PF_ERR_UNSUPPORTED for any other shape (pf_conv2d_wide_supported tells). */
 int pf_conv2d_wide_supported(int64_t Cin, int64_t Cout, int kernel_size, int stride);
 int pf_conv2d_wide_blocks(int64_t Cout, int64_t Hi, int64_t Wi, int stride);

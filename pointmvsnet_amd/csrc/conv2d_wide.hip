@@ -33,7 +33,8 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));   // (HIP's float4 struct in a register ARRAY ends up in scratch)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));   // (HIP's float4 struct in a register ARRAY ends up in scratch)
 
 struct WideGeom {
   int Hi, Wi, Ho, Wo, tiles_w, sps;
@@ -66,13 +67,14 @@ struct WideCfg {
 // All of a thread's loads first (NIT x 4 independent dwords in flight), then the affine and the 16-byte LDS writes.
 // AFFINE: 0 = x as it is; 1 = relu(x * in_scale + in_shift), rows (N/sps, CIN); 2 = the same, the rows computed
 // here from the PRODUCER's statistics (pf_bn_resolve; `scratch`: 4 KB of LDS nobody uses yet).
-template <int CIN, int NPIX, int PW, int RS, int AFFINE>
+template <int CIN, int NPIX, int PW, int RS, int AFFINE>   // (CIN % 4 != 0: the last quad is zero-padded)
 __device__ __forceinline__ void wide_stage_patch(const float* __restrict__ xb, int plane_i, int ih0, int iw0, int Hi,
                                                  int Wi, float* patch, float* aff, const float* __restrict__ in_scale,
                                                  const float* __restrict__ in_shift, int stat, const pf_bn_job& in_bn,
                                                  double* scratch) {
-  constexpr int ITEMS = NPIX * (CIN / 4);             // (pixel, channel quad) pairs of the patch
+  constexpr int ITEMS = NPIX * ((CIN + 3) / 4);       // (pixel, channel quad) pairs of the patch
   constexpr int NIT = (ITEMS + 255) / 256;
+  static_assert(CIN % 4 == 0 || (AFFINE == 0 && CIN < 4), "a padded quad: one quad only, and it takes no affine");
   const int tid = threadIdx.x;
   float rx[NIT][4];
   bool rok[NIT];
@@ -86,7 +88,7 @@ __device__ __forceinline__ void wide_stage_patch(const float* __restrict__ xb, i
     rok[r] = ih >= 0 && ih < Hi && iw >= 0 && iw < Wi;
     const float* src = xb + (int64_t)(4 * q) * plane_i + (rok[r] ? ih * Wi + iw : 0);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) rx[r][j] = src[j * plane_i];
+    for (int j = 0; j < 4; ++j) rx[r][j] = (CIN % 4 == 0 || j < CIN) ? src[j * plane_i] : 0.0f;
   }
   if (AFFINE == 1) {
     const float* sc = in_scale + (int64_t)stat * CIN;
@@ -296,36 +298,38 @@ int launch_wide(const float* x, const float* wp, float* y, WideGeom g, int64_t N
 // rows 4 w .. 4 w + 3 (four M tiles that share every B read); ALL weights (9-13 KB) stay in LDS, no barrier inside
 // the tile.  960 blocks of 26-72 KB LDS on the cfg2 maps: 2-4 blocks per CU cover each other's latencies.
 // ------------------------------------------------------------------------------------------------
-template <int KS, int STRIDE, int CIN>
+template <int KS, int STRIDE, int CIN, int COUT>
 struct Wide16Cfg {
-  static constexpr int TH = 16, TW = 16, COUT = 16;
+  static constexpr int TH = 16, TW = 16, NCOL = 16;    // NCOL: columns of the MFMA tile (COUT = 8: half of them zero)
   static constexpr int PAD = KS / 2;
   static constexpr int PH = (TH - 1) * STRIDE + KS, PW = (TW - 1) * STRIDE + KS;
   static constexpr int NPIX = PH * PW;
-  static constexpr int RS = CIN + 4;
+  static constexpr int CINP = (CIN + 3) / 4 * 4;        // 3 -> 4
+  static constexpr int RS = CINP + 4;
   static constexpr int PATCH = NPIX * RS;
-  static constexpr int CPL = CIN / 4;                  // channels per lane and tap (4: one b128 read, 2: one b64)
-  static constexpr int WALL = KS * KS * CIN * COUT;    // packed weights [tap][kq][c_out][CPL]
-  static constexpr size_t LDS = sizeof(float) * (size_t)(PATCH + WALL + 2 * CIN) + sizeof(double) * 4 * 16 * 2;
-  static_assert(CIN == 8 || CIN == 16, "C_in is 8 or 16");
-  static_assert(PATCH % 4 == 0 && WALL % 4 == 0 && sizeof(float) * WALL >= 4096, "16-byte pieces, 4 KB of scratch");
+  static constexpr int CPL = CINP / 4;                 // channels per lane and tap (4: b128 read, 2: b64, 1: b32)
+  static constexpr int WALL = KS * KS * CINP * NCOL;   // packed weights [tap][kq][column][CPL]
+  static constexpr int WSPACE = WALL > 1024 ? WALL : 1024;   // (>= 4 KB: pf_bn_resolve's scratch before W lands)
+  static constexpr size_t LDS = sizeof(float) * (size_t)(PATCH + WSPACE + 2 * CINP) + sizeof(double) * 4 * 16 * 2;
+  static_assert(CIN == 3 || CIN == 8 || CIN == 16, "C_in is 3, 8 or 16");
+  static_assert(COUT == 8 || COUT == 16, "C_out is 8 or 16");
+  static_assert(PATCH % 4 == 0 && WALL % 4 == 0, "16-byte pieces");
   static_assert(LDS <= 80 * 1024, "two blocks per CU");
 };
 
-template <int KS, int STRIDE, int CIN, int AFFINE>
+template <int KS, int STRIDE, int CIN, int COUT, int AFFINE>
 __global__ __launch_bounds__(256) void conv2d_wide16_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                             float* __restrict__ y, WideGeom g,
                                                             const float* __restrict__ in_scale,
                                                             const float* __restrict__ in_shift,
                                                             double* __restrict__ partials, pf_bn_job in_bn) {
-  using C = Wide16Cfg<KS, STRIDE, CIN>;
-  constexpr int PW = C::PW, RS = C::RS, NPIX = C::NPIX, CPL = C::CPL, COUT = 16;
-  typedef float opv __attribute__((ext_vector_type(CPL)));
+  using C = Wide16Cfg<KS, STRIDE, CIN, COUT>;
+  constexpr int PW = C::PW, RS = C::RS, NPIX = C::NPIX, CPL = C::CPL, NCOL = 16;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* patch = lds;
   float* wl = lds + C::PATCH;
-  float* aff = wl + C::WALL;
-  double* red = reinterpret_cast<double*>(aff + 2 * CIN);
+  float* aff = wl + C::WSPACE;
+  double* red = reinterpret_cast<double*>(aff + 2 * C::CINP);
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -358,30 +362,50 @@ __global__ __launch_bounds__(256) void conv2d_wide16_kernel(const float* __restr
 #pragma unroll
   for (int r = 0; r < 4; ++r) acc[r] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
   const float* abase = patch + ((4 * wave) * STRIDE * PW + li * STRIDE) * RS + CPL * kq;
-  const float* bbase = wl + (kq * COUT + li) * CPL;
+  const float* bbase = wl + (kq * NCOL + li) * CPL;
   constexpr int TAPS = KS * KS;
-  auto read_a = [&](int t, opv* a) {
+  struct Op {
+    float v[CPL];
+  };
+  auto read_op = [&](const float* p) {
+    Op o;
+    if (CPL == 4) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+      o.v[0] = t[0];
+      o.v[1 % CPL] = t[1];
+      o.v[2 % CPL] = t[2];
+      o.v[3 % CPL] = t[3];
+    } else if (CPL == 2) {
+      const f32x2 t = *reinterpret_cast<const f32x2*>(p);
+      o.v[0] = t[0];
+      o.v[1 % CPL] = t[1];
+    } else {
+      o.v[0] = p[0];
+    }
+    return o;
+  };
+  auto read_a = [&](int t, Op* a) {
     const int kh = t / KS, kw = t - kh * KS;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) a[r] = *reinterpret_cast<const opv*>(abase + ((r * STRIDE + kh) * PW + kw) * RS);
+    for (int r = 0; r < 4; ++r) a[r] = read_op(abase + ((r * STRIDE + kh) * PW + kw) * RS);
   };
-  opv a[4], b;
+  Op a[4], b;
   read_a(0, a);
-  b = *reinterpret_cast<const opv*>(bbase);
+  b = read_op(bbase);
 #pragma unroll
   for (int t = 0; t < TAPS; ++t) {
-    opv an[4], bn = b;
+    Op an[4], bn = b;
 #pragma unroll
     for (int r = 0; r < 4; ++r) an[r] = a[r];
     if (t + 1 < TAPS) {
       read_a(t + 1, an);
-      bn = *reinterpret_cast<const opv*>(bbase + (t + 1) * 4 * COUT * CPL);
+      bn = read_op(bbase + (t + 1) * 4 * NCOL * CPL);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < CPL; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][j], b[j], acc[r], 0, 0, 0);
+      for (int r = 0; r < 4; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r].v[j], b.v[j], acc[r], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int r = 0; r < 4; ++r) a[r] = an[r];
@@ -391,12 +415,13 @@ __global__ __launch_bounds__(256) void conv2d_wide16_kernel(const float* __restr
   // ---- epilogue: C/D layout column (channel) = lane & 15, rows (pixels of the output row) 4 kq + {0..3} -------------
   float* yb = y + ((int64_t)n * COUT + li) * ((int64_t)g.Ho * g.Wo);
   const bool vec_ok = (g.Wo & 3) == 0;
+  const bool col_ok = li < COUT;
   float s = 0.0f, q = 0.0f;
   const int ow = ow0 + 4 * kq;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int oh = oh0 + 4 * wave + r;
-    if (oh < g.Ho) {
+    if (oh < g.Ho && col_ok) {
       float* dst = yb + (int64_t)oh * g.Wo + ow;
       if (vec_ok && ow + 3 < g.Wo) {
         *reinterpret_cast<f32x4*>(dst) = acc[r];
@@ -441,51 +466,58 @@ __global__ __launch_bounds__(256) void conv2d_wide16_kernel(const float* __restr
   }
 }
 
-template <int KS, int STRIDE, int CIN, int AFFINE>
+template <int KS, int STRIDE, int CIN, int COUT, int AFFINE>
 int launch_wide16_mode(const float* x, const float* wp, float* y, WideGeom g, int64_t N, const float* in_scale,
                        const float* in_shift, double* partials, const pf_bn_job& in_bn, hipStream_t s) {
-  using C = Wide16Cfg<KS, STRIDE, CIN>;
+  using C = Wide16Cfg<KS, STRIDE, CIN, COUT>;
   if (C::LDS > 64 * 1024) {
     static std::atomic<unsigned long long> done{0};
-    const int rc = pf_allow_big_lds(reinterpret_cast<const void*>(&conv2d_wide16_kernel<KS, STRIDE, CIN, AFFINE>),
-                                    (int)C::LDS, done);
+    const int rc = pf_allow_big_lds(
+        reinterpret_cast<const void*>(&conv2d_wide16_kernel<KS, STRIDE, CIN, COUT, AFFINE>), (int)C::LDS, done);
     if (rc != PF_OK) return rc;
   }
   g.tiles_w = (g.Wo + C::TW - 1) / C::TW;
   const int tiles_h = (g.Ho + C::TH - 1) / C::TH;
   dim3 grid((unsigned)(tiles_h * g.tiles_w), (unsigned)N);
-  hipLaunchKernelGGL((conv2d_wide16_kernel<KS, STRIDE, CIN, AFFINE>), grid, dim3(256), C::LDS, s, x, wp, y, g, in_scale,
-                     in_shift, partials, in_bn);
+  hipLaunchKernelGGL((conv2d_wide16_kernel<KS, STRIDE, CIN, COUT, AFFINE>), grid, dim3(256), C::LDS, s, x, wp, y, g,
+                     in_scale, in_shift, partials, in_bn);
   return pf_launch_status();
 }
 
-template <int KS, int STRIDE, int CIN>
+template <int KS, int STRIDE, int CIN, int COUT>
 int launch_wide16(const float* x, const float* wp, float* y, WideGeom g, int64_t N, const float* in_scale,
                   const float* in_shift, double* partials, const pf_bn_job* in_bn, hipStream_t s) {
-  if (in_bn != nullptr) {
-    const int rc = pf_bn_in_check(in_bn, CIN, (int)(N / g.sps));
-    if (rc != PF_OK) return rc;
-    return launch_wide16_mode<KS, STRIDE, CIN, 2>(x, wp, y, g, N, nullptr, nullptr, partials, *in_bn, s);
-  }
   pf_bn_job none = {};
-  if (in_scale != nullptr) return launch_wide16_mode<KS, STRIDE, CIN, 1>(x, wp, y, g, N, in_scale, in_shift, partials, none, s);
-  return launch_wide16_mode<KS, STRIDE, CIN, 0>(x, wp, y, g, N, nullptr, nullptr, partials, none, s);
+  if constexpr (CIN % 4 == 0) {
+    if (in_bn != nullptr) {
+      const int rc = pf_bn_in_check(in_bn, CIN, (int)(N / g.sps));
+      if (rc != PF_OK) return rc;
+      return launch_wide16_mode<KS, STRIDE, CIN, COUT, 2>(x, wp, y, g, N, nullptr, nullptr, partials, *in_bn, s);
+    }
+    if (in_scale != nullptr)
+      return launch_wide16_mode<KS, STRIDE, CIN, COUT, 1>(x, wp, y, g, N, in_scale, in_shift, partials, none, s);
+  } else {
+    if (in_bn != nullptr || in_scale != nullptr) return PF_ERR_UNSUPPORTED;   // (the image layer has no pending BatchNorm)
+  }
+  return launch_wide16_mode<KS, STRIDE, CIN, COUT, 0>(x, wp, y, g, N, nullptr, nullptr, partials, none, s);
 }
 
-int wide_tile_rows(int64_t Cout) { return Cout == 64 ? 4 : (Cout == 32 ? 8 : 16); }
+int wide_tile_rows(int64_t Cout) { return Cout == 64 ? 4 : (Cout == 32 ? 8 : 16); }   // 8 and 16 channels: 16 x 16 tiles
 
 }  // namespace
 
 extern "C" {
 
 int pf_conv2d_wide_supported(int64_t Cin, int64_t Cout, int kernel_size, int stride) {
-  if (kernel_size == 3 && stride == 1) return (Cin == 64 && Cout == 64) || (Cin == 32 && Cout == 32) || (Cin == 16 && Cout == 16);
+  if (kernel_size == 3 && stride == 1)
+    return (Cin == 64 && Cout == 64) || (Cin == 32 && Cout == 32) || (Cin == 16 && Cout == 16) || (Cin == 8 && Cout == 8) ||
+           (Cin == 3 && Cout == 8);
   if (kernel_size == 5 && stride == 2) return (Cin == 32 && Cout == 64) || (Cin == 16 && Cout == 32) || (Cin == 8 && Cout == 16);
   return 0;
 }
 
 int pf_conv2d_wide_blocks(int64_t Cout, int64_t Hi, int64_t Wi, int stride) {
-  if ((Cout != 16 && Cout != 32 && Cout != 64) || Hi <= 0 || Wi <= 0 || (stride != 1 && stride != 2)) return 0;
+  if ((Cout != 8 && Cout != 16 && Cout != 32 && Cout != 64) || Hi <= 0 || Wi <= 0 || (stride != 1 && stride != 2)) return 0;
   const int64_t Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;
   const int th = wide_tile_rows(Cout);
   return (int)(((Ho + th - 1) / th) * ((Wo + 15) / 16));
@@ -509,9 +541,13 @@ int pf_conv2d_wide_f32(const float* x, const float* wp, float* y, int64_t N, int
   g.tiles_w = 0;
   g.sps = samples_per_stat;
   hipStream_t s = (hipStream_t)stream;
+  if (Cout == 8) {
+    if (Cin == 3) return launch_wide16<3, 1, 3, 8>(x, wp, y, g, N, in_scale, in_shift, partials, in_bn, s);
+    return launch_wide16<3, 1, 8, 8>(x, wp, y, g, N, in_scale, in_shift, partials, in_bn, s);
+  }
   if (Cout == 16) {
-    if (kernel_size == 3) return launch_wide16<3, 1, 16>(x, wp, y, g, N, in_scale, in_shift, partials, in_bn, s);
-    return launch_wide16<5, 2, 8>(x, wp, y, g, N, in_scale, in_shift, partials, in_bn, s);
+    if (kernel_size == 3) return launch_wide16<3, 1, 16, 16>(x, wp, y, g, N, in_scale, in_shift, partials, in_bn, s);
+    return launch_wide16<5, 2, 8, 16>(x, wp, y, g, N, in_scale, in_shift, partials, in_bn, s);
   }
   if (kernel_size == 3) {
     if (Cin == 64) return launch_wide<3, 1, 64, 64>(x, wp, y, g, N, in_scale, in_shift, partials, in_bn, s);

@@ -481,7 +481,7 @@ def conv2d_small_supported(conv):
 def conv2d_small_preferred(conv):
     """The 8-channel full-resolution layers (3->8, 8->8: HBM-bound, half of a 16-wide MFMA tile would be
     empty) run on the plain-FMA kernel (conv2d_small.hip): 25 / 37 us against 31 / 43 us on the matrix cores."""
-    return conv2d_supported(conv) and conv.out_channels == 8 and conv.in_channels <= 16
+    return conv2d_supported(conv) and conv.out_channels == 8 and conv.in_channels <= 16 and not conv2d_wide_preferred(conv)
 
 
 def pack_conv2d_small_weight(weight):
@@ -580,7 +580,7 @@ CONV2D_WIDE_MIN = int(_os.environ.get("PF_CONV2D_WIDE_MIN", "16"))   # 32: the 1
 
 
 def conv2d_wide_supported(conv):
-    """Shapes pf_conv2d_wide_f32 is built for: 3x3/1 16->16, 32->32, 64->64 and 5x5/2 8->16, 16->32, 32->64."""
+    """Shapes pf_conv2d_wide_f32 is built for: 3x3/1 3->8, 8->8, 16->16, 32->32, 64->64; 5x5/2 8->16, 16->32, 32->64."""
     return conv2d_supported(conv) and bool(_lib.load().pf_conv2d_wide_supported(
         conv.in_channels, conv.out_channels, int(conv.kernel_size[0]), int(conv.stride[0])))
 
@@ -594,13 +594,16 @@ def conv2d_wide_preferred(conv):
 
 def pack_conv2d_wide_weight(weight):
     """(Cout,Cin,K,K) -> (K, K, Cin/8, 2, Cout, 4): [kh][kw][kc][h][co][j] = w[co][8 kc + 4 h + j][kh][kw]
-    (Cout 32 / 64: 32x32x2 MFMA), or, for Cout = 16 (16x16x4 MFMA), (K, K, 4, 16, Cin/4):
-    [kh][kw][kq][co][j] = w[co][(Cin/4) kq + j][kh][kw]."""
+    (Cout 32 / 64: 32x32x2 MFMA), or, for Cout = 8 / 16 (16x16x4 MFMA), (K, K, 4, 16, Cin'/4) with Cin' = Cin
+    rounded up to 4: [kh][kw][kq][co][j] = w[co][(Cin'/4) kq + j][kh][kw], zero where co >= Cout or the channel
+    does not exist."""
     def make():
         cout, cin, k, _ = weight.shape
-        if cout == 16:
-            w = weight.detach().to(_F32).permute(2, 3, 1, 0).reshape(k, k, 4, cin // 4, cout)
-            return w.permute(0, 1, 2, 4, 3).contiguous()
+        if cout <= 16:
+            cinp = (cin + 3) // 4 * 4
+            full = torch.zeros((k, k, cinp, 16), dtype=_F32, device=weight.device)
+            full[:, :, :cin, :cout] = weight.detach().to(_F32).permute(2, 3, 1, 0)
+            return full.view(k, k, 4, cinp // 4, 16).permute(0, 1, 2, 4, 3).contiguous()
         w = weight.detach().to(_F32).permute(2, 3, 1, 0).reshape(k, k, cin // 8, 2, 4, cout)
         return w.permute(0, 1, 2, 3, 5, 4).contiguous()
     return _cached_pack(("c2w", id(weight)), (weight,), make)

@@ -661,7 +661,9 @@ def test_conv2d_vs_fp64(dev, N, Cin, Cout, H, W, ks, stride, affine):
                                                        (2, 16, 32, 64, 80, 5, 2), (1, 16, 32, 27, 33, 5, 2),
                                                        (1, 64, 64, 3, 5, 3, 1), (3, 16, 16, 64, 96, 3, 1),
                                                        (2, 16, 16, 33, 47, 3, 1), (2, 8, 16, 128, 160, 5, 2),
-                                                       (1, 8, 16, 61, 75, 5, 2), (1, 16, 16, 5, 3, 3, 1)])
+                                                       (1, 8, 16, 61, 75, 5, 2), (1, 16, 16, 5, 3, 3, 1),
+                                                       (3, 3, 8, 64, 96, 3, 1), (1, 3, 8, 37, 51, 3, 1),
+                                                       (2, 8, 8, 64, 80, 3, 1), (1, 8, 8, 19, 21, 3, 1)])
 @pytest.mark.parametrize("affine", [False, True])
 def test_conv2d_wide_vs_fp64(dev, N, Cin, Cout, H, W, ks, stride, affine):
     """csrc/conv2d_wide.hip (the 32x32x2-MFMA mapping for the towers' small maps) against a float64 convolution:
@@ -679,6 +681,8 @@ def test_conv2d_wide_vs_fp64(dev, N, Cin, Cout, H, W, ks, stride, affine):
     ref = F.conv2d(xin, conv.weight.double(), None, stride, ks // 2)
     conv = conv.to(dev)
     assert pointflow.conv2d_wide_supported(conv)
+    if affine and Cin == 3:
+        pytest.skip("the image layer has no pending BatchNorm (PF_ERR_UNSUPPORTED by contract)")
     aff = (sc.to(dev), sh.to(dev)) if affine else None
     y, part = pointflow.conv2d_wide(x.to(dev), conv, aff, 1, True)
     assert y.shape == ref.shape

@@ -27,7 +27,7 @@ def timeit(fn, reps=100):
     return e0.elapsed_time(e1) * 1000 / reps
 
 
-LAYERS = [("conv1.0", 8, 16, 512, 640, 5, 2), ("conv1.1", 16, 16, 256, 320, 3, 1), ("conv2.0", 16, 32, 256, 320, 5, 2), ("conv2.1", 32, 32, 128, 160, 3, 1),
+LAYERS = [("conv0.0", 3, 8, 512, 640, 3, 1), ("conv0.1", 8, 8, 512, 640, 3, 1), ("conv1.0", 8, 16, 512, 640, 5, 2), ("conv1.1", 16, 16, 256, 320, 3, 1), ("conv2.0", 16, 32, 256, 320, 5, 2), ("conv2.1", 32, 32, 128, 160, 3, 1),
           ("conv3.0", 32, 64, 128, 160, 5, 2), ("conv3.1", 64, 64, 64, 80, 3, 1)]
 for views in (3, 5):
     for name, cin, cout, h, w, ks, stride in LAYERS:
@@ -37,11 +37,16 @@ for views in (3, 5):
         sh = torch.randn(views, cin, device=dev) * 0.1
         xin = F.relu(x * sc.view(views, cin, 1, 1) + sh.view(views, cin, 1, 1))
         ref = F.conv2d(xin.double(), conv.weight.double(), None, stride, ks // 2)
-        y, _ = pointflow.conv2d_wide(x, conv, (sc, sh), 1, True)
+        aff = None if cin == 3 else (sc, sh)
+        if cin == 3:
+            xin = x
+            ref = F.conv2d(xin.double(), conv.weight.double(), None, stride, ks // 2)
+        y, _ = pointflow.conv2d_wide(x, conv, aff, 1, True)
         err = float((y.double() - ref).abs().max() / ref.abs().max())
         flops = 2.0 * ref.numel() * ks * ks * cin
-        tw = timeit(lambda: pointflow.conv2d_wide(x, conv, (sc, sh), 1, True))
-        tm = timeit(lambda: pointflow.conv2d(x, conv, (sc, sh), 1, True))
+        tw = timeit(lambda: pointflow.conv2d_wide(x, conv, aff, 1, True))
+        fn = pointflow.conv2d_small if cout == 8 else pointflow.conv2d
+        tm = timeit(lambda: fn(x, conv, aff, 1, True))
         tl = timeit(lambda: conv(xin))
         print("%d views %s %d->%d %dx%d k%d s%d: wide %.1f us (%.1f TF, rel err %.1e) | conv2d %.1f | library %.1f"
               % (views, name, cin, cout, h, w, ks, stride, tw, flops / tw * 1e-6, err, tm, tl), flush=True)
