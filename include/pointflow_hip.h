@@ -364,6 +364,27 @@ int pf_conv2d_small_f32(const float* x, const float* wp, float* y, int64_t N, in
                         int samples_per_stat, double* partials, const pf_bn_job* bn_jobs_host, int n_bn_jobs,
                         unsigned* tickets, void* stream);
 
+/* The bottom of VolumeConv's U-Net (reference networks.py:136-141) on volumes of a few thousand voxels, one launch
+ * per layer (csrc/conv3d_bottom.hip): 3x3x3 / pad 1 convolutions 32 -> 64 stride 2 and 64 -> 64 stride 1, and the
+ * ConvTranspose3d 64 -> 32 (3x3x3, stride 2, pad 1, output_padding 1: output = twice the input per dimension).
+ * x (N, Cin, Di, Hi, Wi) -> y (N, Cout, Do, Ho, Wo); in_scale / in_shift / in_bn / samples_per_stat: the pending
+ * BatchNorm + ReLU of the input as in pf_conv2d_wide_f32; partials (N, *_blocks(...), Cout, 2) float64 or NULL:
+ * per-block sums of y and y*y.  Weights packed for the f32 matrix cores:
+ *   conv   wp (3, 3, 3, Cin/16, 4, 64, 4):  wp[kd][kh][kw][kc][kq][co][j] = w[co][16 kc + 4 kq + j][kd][kh][kw]
+ *   deconv wp (27, 4, 4, 32, 4):            wp[tap][kc][kq][co][j] = w[16 kc + 4 kq + j][co][tap]   (Cin-major
+ *                                           weight of ConvTranspose3d, tap = (kd*3 + kh)*3 + kw)
+ * PF_ERR_UNSUPPORTED for other channel counts (the *_supported functions tell). */
+int pf_conv3d_bottom_supported(int64_t Cin, int64_t Cout, int stride);
+int pf_conv3d_bottom_blocks(int64_t Di, int64_t Hi, int64_t Wi, int stride);
+int pf_conv3d_bottom_f32(const float* x, const float* wp, float* y, int64_t N, int64_t Cin, int64_t Cout, int64_t Di,
+                         int64_t Hi, int64_t Wi, int stride, const float* in_scale, const float* in_shift,
+                         const pf_bn_job* in_bn, int samples_per_stat, double* partials, void* stream);
+int pf_deconv3d_bottom_supported(int64_t Cin, int64_t Cout);
+int pf_deconv3d_bottom_blocks(int64_t Di, int64_t Hi, int64_t Wi);
+int pf_deconv3d_bottom_f32(const float* x, const float* wp, float* y, int64_t N, int64_t Cin, int64_t Cout, int64_t Di,
+                           int64_t Hi, int64_t Wi, const float* in_scale, const float* in_shift, const pf_bn_job* in_bn,
+                           int samples_per_stat, double* partials, void* stream);
+
 /* ImageConv's 16-, 32- and 64-channel layers (reference networks.py:95-110: 3x3/1 16->16, 32->32, 64->64 and
  * 5x5/2 8->16, 16->32, 32->64), the small-tile mapping of pf_conv2d_f32's contract (csrc/conv2d_wide.hip): same
  * x / y / in_scale / in_shift / samples_per_stat / partials meaning, partials (N, pf_conv2d_wide_blocks(...),

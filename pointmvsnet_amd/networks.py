@@ -305,8 +305,16 @@ class VolumeConv(nn.Module):
         self.conv6_0 = Deconv3d(2 * b, b, 3, 2, padding=1, output_padding=1)
         self.conv6_2 = nn.Conv3d(b, 1, 3, padding=1, bias=False)
 
+    def _bottom_fusable(self):
+        blocks = (self.conv3_0, self.conv3_1, self.conv4_0)
+        return (bool(pointflow.UNET_BOTTOM) and all(b.bn is not None and b.relu for b in blocks)
+                and pointflow.conv3d_bottom_supported(self.conv3_0.conv)
+                and pointflow.conv3d_bottom_supported(self.conv3_1.conv)
+                and pointflow.deconv3d_bottom_supported(self.conv4_0.conv))
+
     def forward_fused(self, x):
-        """Inference fast path: library convs + HIP BatchNorm/ReLU kernels (statistics pooled over the batch)."""
+        """Inference fast path: own conv / deconv kernels + HIP BatchNorm/ReLU kernels (statistics pooled over the
+        batch); the library convolution only for shapes none of the kernels is built for."""
         B = x.shape[0]
         f = lambda blk, t: _block_fused(blk, t, B)   # noqa: E731
         # the full-resolution branch (conv0_1, 69 % of the FLOPs) is independent of the encoder/decoder
@@ -345,9 +353,21 @@ class VolumeConv(nn.Module):
                 quarter_s = f(self.conv2_1, quarter)
                 half_s.record_stream(main)
                 quarter_s.record_stream(main)
-        eighth = f(self.conv3_1, f(self.conv3_0, quarter))
-        pointflow.stamp("unet_encoder_end")
-        up = f(self.conv4_0, eighth)
+        if self._bottom_fusable():
+            # the three smallest layers, one launch each (csrc/conv3d_bottom.hip): every BatchNorm + ReLU between
+            # them is applied -- and, with few statistics rows, finalized -- by the NEXT layer while it stages
+            b0, b1, b2 = self.conv3_0, self.conv3_1, self.conv4_0
+            y0, p0 = pointflow.conv3d_bottom(quarter.contiguous(), b0.conv, None, B, True)
+            a0 = pointflow.bn_affine_rows(y0, b0.bn, B, p0, lazy=True)
+            y1, p1 = pointflow.conv3d_bottom(y0, b1.conv, a0, B, True)
+            a1 = pointflow.bn_affine_rows(y1, b1.bn, B, p1, lazy=True)
+            pointflow.stamp("unet_encoder_end")
+            y2, p2 = pointflow.deconv3d_bottom(y1, b2.conv, a1, B, True)
+            up = pointflow.batch_norm_act_(y2, b2.bn, b2.relu, B, partials=p2)
+        else:
+            eighth = f(self.conv3_1, f(self.conv3_0, quarter))
+            pointflow.stamp("unet_encoder_end")
+            up = f(self.conv4_0, eighth)
         pointflow.stamp("unet_bottom_end")
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)

@@ -688,6 +688,81 @@ def bn_affine_rows(x, bn, samples_per_stat, partials=None, lazy=False):
     return sc.unsqueeze(0).expand(G, C).contiguous(), sh.unsqueeze(0).expand(G, C).contiguous()
 
 
+# PF_UNET_BOTTOM=0: the three smallest VolumeConv layers go back to the library convolution (round-1 path)
+UNET_BOTTOM = int(_os.environ.get("PF_UNET_BOTTOM", "1"))
+
+
+def conv3d_bottom_supported(conv):
+    """nn.Conv3d shapes of pf_conv3d_bottom_f32: 3x3x3 / pad 1, 32 -> 64 stride 2 or 64 -> 64 stride 1, no bias."""
+    return (type(conv) is torch.nn.Conv3d and conv.kernel_size == (3, 3, 3) and conv.padding == (1, 1, 1)
+            and conv.stride in ((1, 1, 1), (2, 2, 2)) and conv.dilation == (1, 1, 1) and conv.groups == 1
+            and conv.bias is None and bool(_lib.load().pf_conv3d_bottom_supported(
+                conv.in_channels, conv.out_channels, int(conv.stride[0]))))
+
+
+def deconv3d_bottom_supported(conv):
+    """nn.ConvTranspose3d shape of pf_deconv3d_bottom_f32: 3x3x3, stride 2, pad 1, output_padding 1, 64 -> 32."""
+    return (type(conv) is torch.nn.ConvTranspose3d and conv.kernel_size == (3, 3, 3) and conv.stride == (2, 2, 2)
+            and conv.padding == (1, 1, 1) and conv.output_padding == (1, 1, 1) and conv.dilation == (1, 1, 1)
+            and conv.groups == 1 and conv.bias is None
+            and bool(_lib.load().pf_deconv3d_bottom_supported(conv.in_channels, conv.out_channels)))
+
+
+def pack_conv3d_bottom_weight(weight):
+    """(64,Cin,3,3,3) -> (3,3,3,Cin/16,4,64,4): [kd][kh][kw][kc][kq][co][j] = w[co][16 kc + 4 kq + j][kd][kh][kw]."""
+    def make():
+        cout, cin = weight.shape[:2]
+        w = weight.detach().to(_F32).permute(2, 3, 4, 1, 0).reshape(3, 3, 3, cin // 16, 4, 4, cout)
+        return w.permute(0, 1, 2, 3, 4, 6, 5).contiguous()
+    return _cached_pack(("c3b", id(weight)), (weight,), make)
+
+
+def pack_deconv3d_bottom_weight(weight):
+    """ConvTranspose3d weight (64,32,3,3,3) -> (27,4,4,32,4): [tap][kc][kq][co][j] = w[16 kc + 4 kq + j][co][tap]."""
+    def make():
+        cin, cout = weight.shape[:2]
+        w = weight.detach().to(_F32).permute(2, 3, 4, 0, 1).reshape(27, cin // 16, 4, 4, cout)
+        return w.permute(0, 1, 2, 4, 3).contiguous()
+    return _cached_pack(("d3b", id(weight)), (weight,), make)
+
+
+def conv3d_bottom(x, conv, in_affine, samples_per_stat, want_stats):
+    """pf_conv3d_bottom_f32 -> (raw y, statistics partials (N, T, 64, 2) or None); ``in_affine``: (scale, shift)
+    rows, a LazyAffine (resolved by the launch) or None."""
+    N, Cin, Di, Hi, Wi = x.shape
+    stride = int(conv.stride[0])
+    Do, Ho, Wo = (Di - 1) // stride + 1, (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
+    wp = pack_conv3d_bottom_weight(conv.weight)
+    y = torch.empty((N, 64, Do, Ho, Wo), dtype=_F32, device=x.device)
+    partials = None
+    if want_stats:
+        T = int(_lib.load().pf_conv3d_bottom_blocks(Di, Hi, Wi, stride))
+        partials = torch.empty((N, T, 64, 2), dtype=torch.float64, device=x.device)
+    sc, sh, in_bn = _split_affine(in_affine)
+    _lib.call("pf_conv3d_bottom_f32", _lib.ptr(x), _lib.ptr(wp), _lib.ptr(y), N, Cin, 64, Di, Hi, Wi, stride,
+              _lib.ptr(sc), _lib.ptr(sh), in_bn, int(samples_per_stat), _lib.ptr(partials), _lib.stream(),
+              algo_bytes=4.0 * N * (Cin * Di * Hi * Wi + 64 * Do * Ho * Wo) + 4.0 * 27 * Cin * 64,
+              flops=2.0 * N * Do * Ho * Wo * 27 * Cin * 64)
+    return y, partials
+
+
+def deconv3d_bottom(x, conv, in_affine, samples_per_stat, want_stats):
+    """pf_deconv3d_bottom_f32 -> (raw y (N,32,2D,2H,2W), statistics partials (N, T, 32, 2) or None)."""
+    N, Cin, Di, Hi, Wi = x.shape
+    wp = pack_deconv3d_bottom_weight(conv.weight)
+    y = torch.empty((N, 32, 2 * Di, 2 * Hi, 2 * Wi), dtype=_F32, device=x.device)
+    partials = None
+    if want_stats:
+        T = int(_lib.load().pf_deconv3d_bottom_blocks(Di, Hi, Wi))
+        partials = torch.empty((N, T, 32, 2), dtype=torch.float64, device=x.device)
+    sc, sh, in_bn = _split_affine(in_affine)
+    _lib.call("pf_deconv3d_bottom_f32", _lib.ptr(x), _lib.ptr(wp), _lib.ptr(y), N, Cin, 32, Di, Hi, Wi,
+              _lib.ptr(sc), _lib.ptr(sh), in_bn, int(samples_per_stat), _lib.ptr(partials), _lib.stream(),
+              algo_bytes=4.0 * N * Di * Hi * Wi * (Cin + 8 * 32) + 4.0 * 27 * Cin * 32,
+              flops=2.0 * N * Di * Hi * Wi * 27 * Cin * 32)
+    return y, partials
+
+
 def conv3d_k3_few(x, weight):
     """3x3x3 / pad 1 / stride 1 conv3d with <= 4 output channels (pf_conv3d_k3_few_f32)."""
     N, Cin, D, H, W = x.shape

@@ -1146,3 +1146,86 @@ def test_conv2d_wide_resolves_pending_batchnorm(dev, N, sps, Cin, Cout, H, W, ks
     torch.cuda.synchronize()
     assert torch.equal(bn_lazy.running_mean, bn_rows.running_mean) and torch.equal(bn_lazy.running_var, bn_rows.running_var)
     assert _lib.status() == 0
+
+
+# ---------------------------------------------------------------------------------------------
+# the bottom of VolumeConv's U-Net (csrc/conv3d_bottom.hip) against float64 convolutions
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,Cin,stride,D,H,W", [(1, 32, 2, 12, 32, 40), (2, 32, 2, 5, 7, 9), (1, 64, 1, 6, 16, 20),
+                                                (2, 64, 1, 3, 5, 7), (1, 64, 1, 6, 8, 10)])
+@pytest.mark.parametrize("affine", ["none", "rows", "lazy"])
+def test_conv3d_bottom_vs_fp64(dev, N, Cin, stride, D, H, W, affine):
+    gen = torch.Generator().manual_seed(N + Cin + D * H * W)
+    conv = torch.nn.Conv3d(Cin, 64, 3, stride=stride, padding=1, bias=False)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=gen) / (27 * Cin) ** 0.5)
+    x = torch.randn(N, Cin, D, H, W, generator=gen)
+    assert pointflow.conv3d_bottom_supported(conv)
+    xin, aff = x.double(), None
+    if affine == "rows":
+        sc = torch.rand(1, Cin, generator=gen) + 0.5
+        sh = torch.randn(1, Cin, generator=gen) * 0.3
+        xin = torch.relu(x.double() * sc.double().view(1, Cin, 1, 1, 1) + sh.double().view(1, Cin, 1, 1, 1))
+        aff = (sc.to(dev), sh.to(dev))
+    xd = x.to(dev)
+    if affine == "lazy":
+        # x is the raw output of a producer with statistics rows: here a statistics pass over x itself
+        bn = torch.nn.BatchNorm3d(Cin).to(dev).train()
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(0.5, 1.5, Cin))
+            bn.bias.copy_(torch.linspace(-0.3, 0.3, Cin))
+        S = D * H * W
+        T = 7
+        part = torch.zeros((N, T, Cin, 2), dtype=torch.float64, device=dev)
+        chunks = torch.chunk(xd.double().reshape(N, Cin, S), T, dim=2)
+        for t, ch in enumerate(chunks):
+            part[:, t, :, 0] = ch.sum(dim=2)
+            part[:, t, :, 1] = (ch * ch).sum(dim=2)
+        aff = pointflow.bn_affine_rows(xd, bn, N, part, lazy=True)
+        assert isinstance(aff, pointflow.LazyAffine)
+        xin = torch.relu(F.batch_norm(x.double(), None, None, bn.weight.double().cpu(), bn.bias.double().cpu(), True, 0.0,
+                                      bn.eps))
+    ref = F.conv3d(xin, conv.weight.double(), None, stride, 1)
+    y, part_y = pointflow.conv3d_bottom(xd, conv.to(dev), aff, N, True)
+    assert y.shape == ref.shape
+    scale = float(ref.abs().max())
+    err = _maxabs(y, ref)
+    report("conv3d_bottom_%d_s%d_%dx%dx%d_%s" % (Cin, stride, D, H, W, affine), err=err, scale=scale)
+    assert err < (2e-5 if affine == "lazy" else 4e-6) * scale * max(1.0, (27 * Cin / 256.0) ** 0.5)
+    sums = part_y.sum(dim=1).cpu()
+    assert torch.allclose(sums[..., 0], ref.sum(dim=(2, 3, 4)), rtol=1e-4, atol=2e-4 * scale * ref[0, 0].numel() ** 0.5)
+    assert torch.allclose(sums[..., 1], (ref ** 2).sum(dim=(2, 3, 4)), rtol=1e-4)
+    y2, none = pointflow.conv3d_bottom(xd, conv, aff if affine != "lazy" else aff.rows(), N, False)
+    assert none is None and (affine == "lazy" or torch.equal(y2, y))
+    pointflow.flush_counters()
+    assert _lib.status() == 0
+
+
+@pytest.mark.parametrize("N,D,H,W", [(1, 6, 16, 20), (2, 3, 5, 7), (1, 1, 4, 4), (1, 6, 8, 10)])
+@pytest.mark.parametrize("affine", [False, True])
+def test_deconv3d_bottom_vs_fp64(dev, N, D, H, W, affine):
+    gen = torch.Generator().manual_seed(N + D * H * W)
+    conv = torch.nn.ConvTranspose3d(64, 32, 3, stride=2, padding=1, output_padding=1, bias=False)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=gen) / (27 * 64 / 8) ** 0.5)
+    x = torch.randn(N, 64, D, H, W, generator=gen)
+    assert pointflow.deconv3d_bottom_supported(conv)
+    xin, aff = x.double(), None
+    if affine:
+        sc = torch.rand(1, 64, generator=gen) + 0.5
+        sh = torch.randn(1, 64, generator=gen) * 0.3
+        xin = torch.relu(x.double() * sc.double().view(1, 64, 1, 1, 1) + sh.double().view(1, 64, 1, 1, 1))
+        aff = (sc.to(dev), sh.to(dev))
+    ref = F.conv_transpose3d(xin, conv.weight.double(), None, 2, 1, 1)
+    y, part = pointflow.deconv3d_bottom(x.to(dev), conv.to(dev), aff, N, True)
+    assert y.shape == ref.shape
+    scale = float(ref.abs().max())
+    err = _maxabs(y, ref)
+    report("deconv3d_bottom_%dx%dx%d_aff%d" % (D, H, W, int(affine)), err=err, scale=scale)
+    assert err < 4e-6 * scale
+    sums = part.sum(dim=1).cpu()
+    assert torch.allclose(sums[..., 0], ref.sum(dim=(2, 3, 4)), rtol=1e-4, atol=2e-4 * scale * ref[0, 0].numel() ** 0.5)
+    assert torch.allclose(sums[..., 1], (ref ** 2).sum(dim=(2, 3, 4)), rtol=1e-4)
+    y2, none = pointflow.deconv3d_bottom(x.to(dev), conv, aff, N, False)
+    assert none is None and torch.equal(y2, y)
+    assert _lib.status() == 0
