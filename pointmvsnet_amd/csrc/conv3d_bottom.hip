@@ -10,8 +10,9 @@
 //     output is one exact f32 fmaf chain, and still a wave for half of the chip's SIMDs;
 //   * the input patch (3 depths x 6 x 6 or 9 x 9 voxels, channel-last, <= 36 KB) sits in LDS with the PREVIOUS
 //     layer's BatchNorm + ReLU applied while it is staged -- from (scale, shift) rows or resolved by the block itself
-//     from the producer's statistics rows (pf_bn_resolve, pf_bn_tail.h); one (kd, kh) row of weights (3 x C_in x 64
-//     floats) is resident per stage, double buffered, one barrier per row (9 per block);
+//     from the producer's statistics rows (pf_bn_resolve, pf_bn_tail.h); the weights never touch LDS: each is used by
+//     one wave of a block only, so every lane streams its own 16-byte pieces from L2 through a ring of 32 registers
+//     (the kernels are bound by that stream's latency, not by the 0.1 GFLOP of matrix work);
 //   * the transposed convolution is the same GEMM with the 2 x 2 x 2 input neighbourhood as reduction index and
 //     (output parity class, channel) as columns; only the 27 non-zero (neighbour, class) blocks are executed, the
 //     classes are dealt to the four waves by work (8 | 4+2 | 4+2 | 4+2+1 neighbour blocks), and the weights -- used
@@ -93,12 +94,18 @@ struct BottomCfg {
   static constexpr int RS = CIN + 4;
   static constexpr int PATCH = 3 * PH * PW * RS;
   static constexpr int KC = CIN / 16;
-  static constexpr int WROW = 3 * CIN * COUT;          // one (kd, kh) row: [kw][kc][kq][c_out][4]
-  static constexpr int WROW4 = WROW / 4, NWR = (WROW4 + 255) / 256;
-  static constexpr size_t LDS = sizeof(float) * (size_t)(PATCH + 2 * WROW + 2 * CIN) + sizeof(double) * 64 * 2;
-  static_assert(CIN % 16 == 0 && LDS <= 160 * 1024, "shape");
+  static constexpr int STEPS = 27 * KC;                // 16-byte operand pairs of a wave: [tap][kc]
+  static constexpr int PF = 32;                        // weight pieces in flight per lane (~2 us of L2 latency)
+  static constexpr size_t LDS = sizeof(float) * (size_t)(PATCH + 1024 + 2 * CIN);
+  static_assert(CIN % 16 == 0 && LDS <= 64 * 1024 && STEPS > PF, "shape");
 };
 
+// Every weight is used by exactly ONE wave of a block (wave w owns output channels 16 w .. 16 w + 15), so the B
+// operands never touch LDS: each lane streams its own 16-byte pieces from L2 through a ring of PF registers, the
+// load of step s + PF issued when step s is consumed -- no barrier after the patch is staged.  (A first version
+// staged one (kd, kh) row of weights per barrier through LDS, double buffered: 18 us for conv3_1 on 6 x 8 x 10,
+// each of the 9 rows waiting ~1.8 us for 49 KB per block against 0.6 us of MFMA work,
+// profiles/r02ai_unet_bottom.txt.)
 template <int STRIDE, int CIN, int AFFINE>
 __global__ __launch_bounds__(256) void conv3d_bottom_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                             float* __restrict__ y, BottomGeom g,
@@ -106,12 +113,11 @@ __global__ __launch_bounds__(256) void conv3d_bottom_kernel(const float* __restr
                                                             const float* __restrict__ in_shift,
                                                             double* __restrict__ partials, pf_bn_job in_bn) {
   using C = BottomCfg<STRIDE, CIN>;
-  constexpr int PH = C::PH, PW = C::PW, RS = C::RS, WROW = C::WROW, WROW4 = C::WROW4, NWR = C::NWR, COUT = 64;
+  constexpr int PH = C::PH, PW = C::PW, RS = C::RS, COUT = 64, KC = C::KC, STEPS = C::STEPS, PF = C::PF;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* patch = lds;
-  float* wbuf = lds + C::PATCH;
-  float* aff = wbuf + 2 * WROW;
-  double* red = reinterpret_cast<double*>(aff + 2 * CIN);
+  double* scratch = reinterpret_cast<double*>(lds + C::PATCH);
+  float* aff = lds + C::PATCH + 1024;
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -123,61 +129,35 @@ __global__ __launch_bounds__(256) void conv3d_bottom_kernel(const float* __restr
   const int64_t plane_c = (int64_t)g.Di * plane_d;
   const float* xb = x + (int64_t)n * CIN * plane_c;
 
-  f32x4 rw[NWR];
-  auto load_w = [&](int row) {
-    const f32x4* src = reinterpret_cast<const f32x4*>(wp + (int64_t)row * WROW);
+  // packed weights [kd][kh][kw][kc][kq][c_out][4]: step s = (tap, kc) of this lane is piece wg[s * 4 * COUT]
+  const f32x4* wg = reinterpret_cast<const f32x4*>(wp) + kq * COUT + 16 * wave + li;
+  f32x4 ring[PF];
 #pragma unroll
-    for (int r = 0; r < NWR; ++r) {
-      const int e = tid + 256 * r;
-      rw[r] = src[e < WROW4 ? e : WROW4 - 1];
-    }
-  };
-  auto store_w = [&](int buf) {
-    f32x4* dst = reinterpret_cast<f32x4*>(wbuf + buf * WROW);
-#pragma unroll
-    for (int r = 0; r < NWR; ++r) {
-      const int e = tid + 256 * r;
-      if (256 * (r + 1) <= WROW4 || e < WROW4) dst[e] = rw[r];
-    }
-  };
-  load_w(0);
+  for (int s = 0; s < PF; ++s) ring[s] = wg[s * 4 * COUT];
+
   stage_patch3d<CIN, 3, PH, PW, RS, AFFINE>(xb, plane_c, plane_d, od * STRIDE - 1, oh0 * STRIDE - 1, ow0 * STRIDE - 1, 1,
-                                            g.Di, g.Hi, g.Wi, patch, aff, in_scale, in_shift, n / g.sps, in_bn,
-                                            reinterpret_cast<double*>(wbuf));
-  store_w(0);
+                                            g.Di, g.Hi, g.Wi, patch, aff, in_scale, in_shift, n / g.sps, in_bn, scratch);
   __syncthreads();
 
   f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
   const float* abase = patch + (((li >> 2) * STRIDE) * PW + (li & 3) * STRIDE) * RS + 4 * kq;
-  const float* bbase = wbuf + (kq * COUT + 16 * wave + li) * 4;
-  constexpr int T = 3 * C::KC;                          // operand pairs per (kd, kh) row
+  auto a_ptr = [&](int s) {
+    const int tap = s / KC, kc = s - tap * KC;
+    const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+    return abase + ((kd * PH + kh) * PW + kw) * RS + 16 * kc;
+  };
+  f32x4 a = *reinterpret_cast<const f32x4*>(a_ptr(0));
 #pragma unroll
-  for (int row = 0; row < 9; ++row) {
-    const int kd = row / 3, kh = row - 3 * kd;
-    if (row + 1 < 9) load_w(row + 1);
-    const float* ar = abase + ((kd * PH + kh) * PW) * RS;
-    const float* bb = bbase + (row & 1) * WROW;
-    f32x4 a = *reinterpret_cast<const f32x4*>(ar);
-    f32x4 b = *reinterpret_cast<const f32x4*>(bb);
+  for (int s = 0; s < STEPS; ++s) {
+    const f32x4 b = ring[s % PF];
+    if (s + PF < STEPS) ring[s % PF] = wg[(s + PF) * 4 * COUT];
+    f32x4 an = a;
+    if (s + 1 < STEPS) an = *reinterpret_cast<const f32x4*>(a_ptr(s + 1));
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
-      f32x4 an = a, bn = b;
-      if (t + 1 < T) {
-        const int kw = (t + 1) / C::KC, kc = (t + 1) % C::KC;
-        an = *reinterpret_cast<const f32x4*>(ar + kw * RS + 16 * kc);
-        bn = *reinterpret_cast<const f32x4*>(bb + (t + 1) * 4 * COUT * 4);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc, 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      a = an;
-      b = bn;
-    }
-    if (row + 1 < 9) {
-      store_w((row + 1) & 1);
-      __syncthreads();
-    }
+    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    a = an;
   }
 
   // C/D layout: column (channel) = lane & 15, rows (voxels of the 4 x 4 patch) 4 kq + {0..3} = row kq, columns 0..3
@@ -214,7 +194,6 @@ __global__ __launch_bounds__(256) void conv3d_bottom_kernel(const float* __restr
       o[1] = (double)q;
     }
   }
-  (void)red;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -227,6 +206,18 @@ struct DeconvCfg {
   static constexpr int PATCH = 2 * 5 * 5 * RS;
   static constexpr size_t LDS = sizeof(float) * (size_t)(PATCH + 1024 + 2 * CIN);
 };
+
+// The (class, neighbour) blocks of each wave, in execution order: class bits (pd ph pw), neighbour bits (sd sh sw)
+// and "the class is complete after this item".  8 | 4+2 | 4+2 | 4+2+1 items.
+struct DcItem {
+  unsigned char cls, nb, end;
+};
+__constant__ DcItem kDcItems[4][8] = {
+    {{7, 0, 0}, {7, 1, 0}, {7, 2, 0}, {7, 3, 0}, {7, 4, 0}, {7, 5, 0}, {7, 6, 0}, {7, 7, 1}},
+    {{3, 0, 0}, {3, 1, 0}, {3, 2, 0}, {3, 3, 1}, {1, 0, 0}, {1, 1, 1}, {0, 0, 0}, {0, 0, 0}},
+    {{5, 0, 0}, {5, 1, 0}, {5, 4, 0}, {5, 5, 1}, {2, 0, 0}, {2, 2, 1}, {0, 0, 0}, {0, 0, 0}},
+    {{6, 0, 0}, {6, 2, 0}, {6, 4, 0}, {6, 6, 1}, {4, 0, 0}, {4, 4, 1}, {0, 0, 1}, {0, 0, 0}}};
+__constant__ int kDcCount[4] = {8, 6, 6, 7};
 
 __device__ __forceinline__ int deconv_tap(int parity, int offset) { return parity == 0 ? 1 : (offset == 1 ? 0 : 2); }
 
@@ -252,65 +243,78 @@ __global__ __launch_bounds__(256) void deconv3d_bottom_kernel(const float* __res
   const int plane_d = g.Hi * g.Wi;
   const int64_t plane_c = (int64_t)g.Di * plane_d;
   const float* xb = x + (int64_t)n * CIN * plane_c;
+
+  // weights of an item: [tap][kc][kq][c_out 32][4] floats, straight from L2 (used once per block), two items ahead
+  const f32x4* w4 = reinterpret_cast<const f32x4*>(wp) + kq * COUT + li;
+  const int nitems = kDcCount[wave];
+  auto item_tap = [&](int it) {
+    const DcItem d = kDcItems[wave][it];
+    const int pd = d.cls >> 2, ph = (d.cls >> 1) & 1, pw = d.cls & 1;
+    const int sd = d.nb >> 2, sh = (d.nb >> 1) & 1, sw = d.nb & 1;
+    return (deconv_tap(pd, sd) * 3 + deconv_tap(ph, sh)) * 3 + deconv_tap(pw, sw);
+  };
+  f32x4 bring[3][KC][2];
+  auto load_b = [&](int it, f32x4 (*b)[2]) {
+    const f32x4* wt = w4 + (int64_t)item_tap(it) * KC * 4 * COUT;
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+      b[kc][0] = wt[kc * 4 * COUT];
+      b[kc][1] = wt[kc * 4 * COUT + 16];
+    }
+  };
+  load_b(0, bring[0]);
+  load_b(1, bring[1]);
+
   stage_patch3d<CIN, 2, 5, 5, RS, AFFINE>(xb, plane_c, plane_d, id, ih0, iw0, 1, g.Di, g.Hi, g.Wi, patch, aff, in_scale,
                                           in_shift, n / g.sps, in_bn, scratch);
   __syncthreads();
 
-  // the wave's classes (bit 2 = pd, bit 1 = ph, bit 0 = pw): 8 | 4+2 | 4+2 | 4+2+1 neighbour blocks
-  const int ncls = wave == 0 ? 1 : (wave == 3 ? 3 : 2);
-  const int cls0 = wave == 0 ? 7 : (wave == 1 ? 3 : (wave == 2 ? 5 : 6));
-  const int cls1 = wave == 1 ? 1 : (wave == 2 ? 2 : 4);
   const float* abase = patch + ((li >> 2) * 5 + (li & 3)) * RS + 4 * kq;
-  const f32x4* w4 = reinterpret_cast<const f32x4*>(wp);
   const int64_t Vo = (int64_t)g.Do * g.Ho * g.Wo;
   const int ih = ih0 + kq;                                          // the lane's output rows come from input row ih
   double ssum[2] = {0.0, 0.0}, ssq[2] = {0.0, 0.0};
-#pragma unroll 1
-  for (int ci = 0; ci < ncls; ++ci) {
-    const int cls = ci == 0 ? cls0 : (ci == 1 ? cls1 : 0);
-    const int pd = cls >> 2, ph = (cls >> 1) & 1, pw = cls & 1;
-    f32x4 acc[2];
-    acc[0] = acc[1] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll 1
-    for (int sd = 0; sd <= pd; ++sd)
-#pragma unroll 1
-      for (int sh = 0; sh <= ph; ++sh)
-#pragma unroll 1
-        for (int sw = 0; sw <= pw; ++sw) {
-          const int tap = (deconv_tap(pd, sd) * 3 + deconv_tap(ph, sh)) * 3 + deconv_tap(pw, sw);
-          const float* ap = abase + ((sd * 5 + sh) * 5 + sw) * RS;
-          // weights of this tap: [tap][kc][kq][c_out 32][4] floats, straight from L2 (used once per block)
-          const f32x4* wt = w4 + ((int64_t)tap * KC * 4 + kq) * COUT + li;
-          f32x4 b[KC][2], a[KC];
+  f32x4 acc[2];
+  acc[0] = acc[1] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-          for (int kc = 0; kc < KC; ++kc) {
-            b[kc][0] = wt[(int64_t)kc * 4 * COUT];
-            b[kc][1] = wt[(int64_t)kc * 4 * COUT + 16];
-            a[kc] = *reinterpret_cast<const f32x4*>(ap + 16 * kc);
-          }
+  for (int it = 0; it < 8; ++it) {
+    if (it < nitems) {
+      if (it + 2 < nitems) load_b(it + 2, bring[(it + 2) % 3]);
+      const DcItem d = kDcItems[wave][it];
+      const int sd = d.nb >> 2, sh = (d.nb >> 1) & 1, sw = d.nb & 1;
+      const float* ap = abase + ((sd * 5 + sh) * 5 + sw) * RS;
+      f32x4 a[KC];
 #pragma unroll
-          for (int kc = 0; kc < KC; ++kc)
+      for (int kc = 0; kc < KC; ++kc) a[kc] = *reinterpret_cast<const f32x4*>(ap + 16 * kc);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kc][j], b[kc][0][j], acc[0], 0, 0, 0);
-              acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kc][j], b[kc][1][j], acc[1], 0, 0, 0);
-            }
+      for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kc][j], bring[it % 3][kc][0][j], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kc][j], bring[it % 3][kc][1][j], acc[1], 0, 0, 0);
         }
-    // lane: channel li (+16), input cells (row kq, columns 0..3) -> outputs (2 id + pd, 2 ih + ph, 2 (iw0 + e) + pw)
-    if (ih < g.Hi) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (d.end) {
+        // lane: channel li (+16), input cells (row kq, columns 0..3) -> outputs (2 id + pd, 2 ih + ph, 2 iw + pw)
+        const int pd = d.cls >> 2, ph = (d.cls >> 1) & 1, pw = d.cls & 1;
+        if (ih < g.Hi) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        float* dst = y + ((int64_t)n * COUT + 16 * t + li) * Vo + ((int64_t)(2 * id + pd) * g.Ho + 2 * ih + ph) * g.Wo + pw;
-        float s = 0.0f, q = 0.0f;
+          for (int t = 0; t < 2; ++t) {
+            float* dst =
+                y + ((int64_t)n * COUT + 16 * t + li) * Vo + ((int64_t)(2 * id + pd) * g.Ho + 2 * ih + ph) * g.Wo + pw;
+            float s = 0.0f, q = 0.0f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (iw0 + e < g.Wi) {
-            dst[2 * (iw0 + e)] = acc[t][e];
-            s += acc[t][e];
-            q += acc[t][e] * acc[t][e];
+            for (int e = 0; e < 4; ++e)
+              if (iw0 + e < g.Wi) {
+                dst[2 * (iw0 + e)] = acc[t][e];
+                s += acc[t][e];
+                q += acc[t][e] * acc[t][e];
+              }
+            ssum[t] += (double)s;
+            ssq[t] += (double)q;
           }
-        ssum[t] += (double)s;
-        ssq[t] += (double)q;
+        }
+        acc[0] = acc[1] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
       }
     }
   }
@@ -349,10 +353,6 @@ template <int STRIDE, int CIN, int AFFINE>
 int launch_bottom_mode(const float* x, const float* wp, float* y, BottomGeom g, int64_t N, const float* in_scale,
                        const float* in_shift, double* partials, const pf_bn_job& in_bn, hipStream_t s) {
   using C = BottomCfg<STRIDE, CIN>;
-  static std::atomic<unsigned long long> done{0};
-  const int rc = pf_allow_big_lds(reinterpret_cast<const void*>(&conv3d_bottom_kernel<STRIDE, CIN, AFFINE>), (int)C::LDS,
-                                  done);
-  if (rc != PF_OK) return rc;
   g.tiles_w = (g.Wo + 3) / 4;
   dim3 grid((unsigned)(((g.Ho + 3) / 4) * g.tiles_w), (unsigned)g.Do, (unsigned)N);
   hipLaunchKernelGGL((conv3d_bottom_kernel<STRIDE, CIN, AFFINE>), grid, dim3(256), C::LDS, s, x, wp, y, g, in_scale,
