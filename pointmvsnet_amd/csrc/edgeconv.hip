@@ -880,13 +880,21 @@ __global__ __launch_bounds__(256) void edge_bwd_apply_kernel(const float* __rest
 // over blocks of kBnCB channels (blockIdx.x): the partial sums of one layer are up to ~1 MB, which a single
 // workgroup pulls through one CU's L1 in 5-13 us; channels are independent, so 8-16 CUs share the read.
 constexpr int kBnJobs = 32;   // (3.3 KB of kernel arguments)
-constexpr int kBnCB = 4;
 constexpr int kBnThreads = 256;
+// Channels per block: the kernel is a chain of dependent L2 round trips (rows -> LDS -> statistics), so the more
+// blocks share the rows of a job the fewer batches each thread walks through -- in principle; measured
+// (profiles/r02aj_small_ab.txt) 4 channels per block beat 2 and 1 (646 / 645 / 642 depth maps/s): the fixed
+// launch + round-trip latency dominates, not the row batches.  PF_BN_CB: tuning hook.
+static int bn_channels_per_block() {
+  const char* e = getenv("PF_BN_CB");
+  const int v = e ? atoi(e) : 4;
+  return (v == 1 || v == 2 || v == 4) ? v : 4;
+}
 struct BnJobs {
   pf_bn_job j[kBnJobs];
 };
 
-__global__ __launch_bounds__(kBnThreads) void bn_finalize_kernel(BnJobs jobs) {
+__global__ __launch_bounds__(kBnThreads) void bn_finalize_kernel(BnJobs jobs, int kBnCB) {
   const pf_bn_job& J = jobs.j[blockIdx.y];
   const int c_base = blockIdx.x * kBnCB;
   if (c_base >= J.C) return;
@@ -1282,8 +1290,9 @@ int pf_bn_finalize_jobs_f32(const pf_bn_job* jobs, int njobs, void* stream) {
     cmax = j.C > cmax ? j.C : cmax;
   }
   for (int i = njobs; i < kBnJobs; ++i) packed.j[i] = jobs[0];   // never addressed (gridDim.y == njobs)
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)pf_cdiv(cmax, kBnCB), (unsigned)njobs), dim3(kBnThreads), 0,
-                     (hipStream_t)stream, packed);
+  const int cb = bn_channels_per_block();
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)pf_cdiv(cmax, cb), (unsigned)njobs), dim3(kBnThreads), 0,
+                     (hipStream_t)stream, packed, cb);
   return pf_launch_status();
 }
 

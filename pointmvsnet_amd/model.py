@@ -238,11 +238,24 @@ class PointMVSNet(nn.Module):
         dev = img_list.device
         main = torch.cuda.current_stream()
         pointflow.stamp("start")
+        mode = int(os.environ.get("PF_FORK_MODE", "0"))
+        early = None
+        if isFlow and pointflow.CONCURRENCY >= 1 and mode == 3:      # both towers side by side from the first kernel
+            if self._side_stream is None or self._side_stream.device != dev:
+                self._side_stream = torch.cuda.Stream(device=dev)
+            self._side_stream.wait_stream(main)
+            with torch.cuda.stream(self._side_stream):
+                early = self.run_flow_tower(img_list)
+                pointflow.stamp("flow_tower_end")
+                for p in early.values():
+                    p.record_stream(main)
         feature_list = self.run_coarse_tower(img_list)
         pointflow.stamp("coarse_tower_end")
         pyramids, side = None, None
-        mode = int(os.environ.get("PF_FORK_MODE", "0"))
-        if isFlow and pointflow.CONCURRENCY < 1:
+        if early is not None:
+            pyramids, side = early, self._side_stream
+            preds = self.run_coarse_stage(plan, feature_list)
+        elif isFlow and pointflow.CONCURRENCY < 1:
             pyramids = self.run_flow_tower(img_list)
             preds = self.run_coarse_stage(plan, feature_list)
         elif isFlow:

@@ -239,7 +239,10 @@ def bn_affine(bn, partials, col0, C, count, unbias_n, G, groups_per_stat, scale,
 # on the critical path: the consumer's blocks compute (scale, shift) themselves, and the running statistics are
 # updated by batched finalize launches on a side stream (flush_lazy_stats / join at flush_counters).
 LAZY_BN = int(_os.environ.get("PF_LAZY_BN", "1"))
-LAZY_MAX_ROWS = 256            # rows behind one statistic that a consumer block is asked to re-reduce
+# What a consumer block is asked to re-reduce: rows behind one statistic x channels (16 bytes each).  Measured
+# (profiles/r02aj_small_ab.txt): 4000 / 5120 / 16384 / 65536 -> 641 / 646 / 654 / 653 depth maps/s on config 2; the
+# largest job there is the flow MLP at 25 600 points per group (200 rows x 64 channels = 205 KB per GEMM block).
+LAZY_MAX_ELEMS = int(_os.environ.get("PF_LAZY_MAX", "16384"))
 
 
 class LazyAffine(object):
@@ -679,7 +682,7 @@ def bn_affine_rows(x, bn, samples_per_stat, partials=None, lazy=False):
                       algo_bytes=4.0 * N * C * S)
         n = float(samples_per_stat) * S
         bump_counter(bn, G)
-        if lazy and LAZY_BN and samples_per_stat * partials.shape[1] <= LAZY_MAX_ROWS:
+        if lazy and LAZY_BN and samples_per_stat * partials.shape[1] * C <= LAZY_MAX_ELEMS:
             job = bn_job(bn, partials, 0, C, n, n, N, samples_per_stat, scale, shift)
             return LazyAffine(job, (partials, scale, shift), scale, shift)
         bn_affine(bn, partials, 0, C, n, n, N, samples_per_stat, scale, shift)
@@ -941,7 +944,7 @@ def _bn_affine_from_gemm(bn, partials, C, G, Ng, groups_per_stat, dev, lazy=Fals
     if bn.training or not bn.track_running_stats:
         n = float(groups_per_stat) * Ng
         bump_counter(bn, S)
-        if lazy and LAZY_BN and groups_per_stat * partials.shape[1] <= LAZY_MAX_ROWS:
+        if lazy and LAZY_BN and groups_per_stat * partials.shape[1] * C <= LAZY_MAX_ELEMS:
             job = bn_job(bn, partials, 0, C, n, n, G, groups_per_stat, scale, shift)
             return LazyAffine(job, (partials, scale, shift), scale, shift)
         bn_affine(bn, partials, 0, C, n, n, G, groups_per_stat, scale, shift)
