@@ -37,7 +37,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));   // (HIP's float4 struct in a register ARRAY ends up in scratch)
 
 struct WideGeom {
-  int Hi, Wi, Ho, Wo, tiles_w, sps;
+  int Hi, Wi, Ho, Wo, tiles_w, tiles_h, sps;
 };
 
 template <int KS, int STRIDE, int CIN, int COUT>
@@ -64,32 +64,64 @@ struct WideCfg {
 };
 
 // The input patch of a block: NCHW planes -> [pixel][channel] in LDS, the previous BatchNorm+ReLU on the way.
-// All of a thread's loads first (NIT x 4 independent dwords in flight), then the affine and the 16-byte LDS writes.
-// AFFINE: 0 = x as it is; 1 = relu(x * in_scale + in_shift), rows (N/sps, CIN); 2 = the same, the rows computed
-// here from the PRODUCER's statistics (pf_bn_resolve; `scratch`: 4 KB of LDS nobody uses yet).
-template <int CIN, int NPIX, int PW, int RS, int AFFINE>   // (CIN % 4 != 0: the last quad is zero-padded)
-__device__ __forceinline__ void wide_stage_patch(const float* __restrict__ xb, int plane_i, int ih0, int iw0, int Hi,
-                                                 int Wi, float* patch, float* aff, const float* __restrict__ in_scale,
-                                                 const float* __restrict__ in_shift, int stat, const pf_bn_job& in_bn,
-                                                 double* scratch) {
-  constexpr int ITEMS = NPIX * ((CIN + 3) / 4);       // (pixel, channel quad) pairs of the patch
-  constexpr int NIT = (ITEMS + 255) / 256;
-  static_assert(CIN % 4 == 0 || (AFFINE == 0 && CIN < 4), "a padded quad: one quad only, and it takes no affine");
-  const int tid = threadIdx.x;
+// Two phases so that a block can have the NEXT tile's loads in flight while it works on the current one: load()
+// issues all of a thread's loads (NIT x 4 independent dwords), commit() applies the affine and writes 16-byte pieces.
+template <int CIN, int NPIX, int PW, int RS>   // (CIN % 4 != 0: the last quad is zero-padded)
+struct PatchStager {
+  static constexpr int ITEMS = NPIX * ((CIN + 3) / 4);   // (pixel, channel quad) pairs of the patch
+  static constexpr int NIT = (ITEMS + 255) / 256;
+  static_assert(CIN % 4 == 0 || CIN < 4, "a padded quad: one quad only");
   float rx[NIT][4];
-  bool rok[NIT];
+  unsigned okmask;
+
+  __device__ __forceinline__ void load(const float* __restrict__ xb, int plane_i, int ih0, int iw0, int Hi, int Wi) {
+    const int tid = threadIdx.x;
+    okmask = 0;
 #pragma unroll
-  for (int r = 0; r < NIT; ++r) {
-    const int it = tid + 256 * r;
-    const int itc = it < ITEMS ? it : ITEMS - 1;
-    const int q = itc / NPIX, p = itc - q * NPIX;       // lanes walk the patch's pixels: coalesced along a patch row
-    const int pr = p / PW, pc = p - pr * PW;
-    const int ih = ih0 + pr, iw = iw0 + pc;
-    rok[r] = ih >= 0 && ih < Hi && iw >= 0 && iw < Wi;
-    const float* src = xb + (int64_t)(4 * q) * plane_i + (rok[r] ? ih * Wi + iw : 0);
+    for (int r = 0; r < NIT; ++r) {
+      const int it = tid + 256 * r;
+      const int itc = it < ITEMS ? it : ITEMS - 1;
+      const int q = itc / NPIX, p = itc - q * NPIX;     // lanes walk the patch's pixels: coalesced along a patch row
+      const int pr = p / PW, pc = p - pr * PW;
+      const int ih = ih0 + pr, iw = iw0 + pc;
+      const bool ok = ih >= 0 && ih < Hi && iw >= 0 && iw < Wi;
+      okmask |= (ok ? 1u : 0u) << r;
+      const float* src = xb + (int64_t)(4 * q) * plane_i + (ok ? ih * Wi + iw : 0);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) rx[r][j] = (CIN % 4 == 0 || j < CIN) ? src[j * plane_i] : 0.0f;
+      for (int j = 0; j < 4; ++j) rx[r][j] = (CIN % 4 == 0 || j < CIN) ? src[j * plane_i] : 0.0f;
+    }
   }
+
+  template <bool AFF>
+  __device__ __forceinline__ void commit(float* patch, const float* aff) const {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int r = 0; r < NIT; ++r) {
+      const int it = tid + 256 * r;
+      const int itc = it < ITEMS ? it : ITEMS - 1;
+      const int q = itc / NPIX, p = itc - q * NPIX;
+      f32x4 v = {rx[r][0], rx[r][1], rx[r][2], rx[r][3]};
+      if (AFF) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(aff + 4 * q);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(aff + CIN + 4 * q);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(v[j], a[j], b[j]), 0.0f);
+      }
+      if (!((okmask >> r) & 1u)) v = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};       // zero padding applies AFTER it
+      if (256 * (r + 1) <= ITEMS || it < ITEMS) *reinterpret_cast<f32x4*>(patch + p * RS + 4 * q) = v;
+    }
+  }
+};
+
+// The pending BatchNorm of the input -> aff[0..CIN) scale, aff[CIN..2 CIN) shift (LDS).  AFFINE: 0 = none;
+// 1 = rows (N/sps, CIN) from memory; 2 = computed here from the PRODUCER's statistics (pf_bn_resolve; `scratch`:
+// 4 KB of LDS nobody uses yet).  Ends with a barrier when AFFINE != 0.
+template <int CIN, int AFFINE>
+__device__ __forceinline__ void wide_affine_prologue(float* aff, const float* __restrict__ in_scale,
+                                                     const float* __restrict__ in_shift, int stat,
+                                                     const pf_bn_job& in_bn, double* scratch) {
+  static_assert(CIN % 4 == 0 || AFFINE == 0, "a padded channel quad takes no affine");
+  const int tid = threadIdx.x;
   if (AFFINE == 1) {
     const float* sc = in_scale + (int64_t)stat * CIN;
     const float* sh = in_shift + (int64_t)stat * CIN;
@@ -98,21 +130,17 @@ __device__ __forceinline__ void wide_stage_patch(const float* __restrict__ xb, i
     __syncthreads();
   }
   if (AFFINE == 2) pf_bn_resolve<256>(in_bn, stat, aff, aff + CIN, scratch);
-#pragma unroll
-  for (int r = 0; r < NIT; ++r) {
-    const int it = tid + 256 * r;
-    const int itc = it < ITEMS ? it : ITEMS - 1;
-    const int q = itc / NPIX, p = itc - q * NPIX;
-    f32x4 v = {rx[r][0], rx[r][1], rx[r][2], rx[r][3]};
-    if (AFFINE) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(aff + 4 * q);
-      const f32x4 b = *reinterpret_cast<const f32x4*>(aff + CIN + 4 * q);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(v[j], a[j], b[j]), 0.0f);
-    }
-    if (!rok[r]) v = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};                       // zero padding applies AFTER it
-    if (256 * (r + 1) <= ITEMS || it < ITEMS) *reinterpret_cast<f32x4*>(patch + p * RS + 4 * q) = v;
-  }
+}
+
+template <int CIN, int NPIX, int PW, int RS, int AFFINE>
+__device__ __forceinline__ void wide_stage_patch(const float* __restrict__ xb, int plane_i, int ih0, int iw0, int Hi,
+                                                 int Wi, float* patch, float* aff, const float* __restrict__ in_scale,
+                                                 const float* __restrict__ in_shift, int stat, const pf_bn_job& in_bn,
+                                                 double* scratch) {
+  PatchStager<CIN, NPIX, PW, RS> st;
+  st.load(xb, plane_i, ih0, iw0, Hi, Wi);
+  wide_affine_prologue<CIN, AFFINE>(aff, in_scale, in_shift, stat, in_bn, scratch);
+  st.template commit<(AFFINE != 0)>(patch, aff);
 }
 
 // AFFINE: 0 = x is taken as is; 1 = relu(x * in_scale + in_shift), rows (N/sps, CIN); 2 = the same with the rows
@@ -335,13 +363,12 @@ __global__ __launch_bounds__(256) void conv2d_wide16_kernel(const float* __restr
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int li = lane & 15, kq = lane >> 4;
   const int n = blockIdx.y;
-  const int tw = blockIdx.x % g.tiles_w, th = blockIdx.x / g.tiles_w;
-  const int oh0 = th * C::TH, ow0 = tw * C::TW;
-  const int ih0 = oh0 * STRIDE - C::PAD, iw0 = ow0 * STRIDE - C::PAD;
   const int plane_i = g.Hi * g.Wi;
   const float* xb = x + (int64_t)n * CIN * plane_i;
+  const int tiles = g.tiles_h * g.tiles_w;
+  const int nb = gridDim.x;
 
-  // all weights: global -> registers now, -> LDS after the patch (the resolve borrows the space until then)
+  // all weights: global -> registers now, -> LDS after the affine prologue (the resolve borrows the space until then)
   constexpr int W4 = C::WALL / 4, NWR = (W4 + 255) / 256;
   f32x4 rw[NWR];
 #pragma unroll
@@ -349,18 +376,28 @@ __global__ __launch_bounds__(256) void conv2d_wide16_kernel(const float* __restr
     const int e = tid + 256 * r;
     rw[r] = reinterpret_cast<const f32x4*>(wp)[e < W4 ? e : W4 - 1];
   }
-  wide_stage_patch<CIN, NPIX, PW, RS, AFFINE>(xb, plane_i, ih0, iw0, g.Hi, g.Wi, patch, aff, in_scale, in_shift,
-                                              n / g.sps, in_bn, reinterpret_cast<double*>(wl));
+  // A block walks its tiles (blockIdx.x, + gridDim.x, ...) with the NEXT tile's patch loads in flight while the
+  // matrix cores work on the current one: with one tile per block every block of the launch is resident at once and
+  // they all load, then all multiply, then all store -- each phase leaving the other units idle.
+  PatchStager<CIN, NPIX, PW, RS> st;
+  int tile = blockIdx.x;
+  auto tile_origin = [&](int t, int& oh0, int& ow0) {
+    const int th = t / g.tiles_w;
+    oh0 = th * C::TH;
+    ow0 = (t - th * g.tiles_w) * C::TW;
+  };
+  {
+    int oh0, ow0;
+    tile_origin(tile, oh0, ow0);
+    st.load(xb, plane_i, oh0 * STRIDE - C::PAD, ow0 * STRIDE - C::PAD, g.Hi, g.Wi);
+  }
+  wide_affine_prologue<CIN, AFFINE>(aff, in_scale, in_shift, n / g.sps, in_bn, reinterpret_cast<double*>(wl));
 #pragma unroll
   for (int r = 0; r < NWR; ++r) {
     const int e = tid + 256 * r;
     if (256 * (r + 1) <= W4 || e < W4) reinterpret_cast<f32x4*>(wl)[e] = rw[r];
   }
-  __syncthreads();
 
-  f32x4 acc[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) acc[r] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
   const float* abase = patch + ((4 * wave) * STRIDE * PW + li * STRIDE) * RS + CPL * kq;
   const float* bbase = wl + (kq * NCOL + li) * CPL;
   constexpr int TAPS = KS * KS;
@@ -389,81 +426,111 @@ __global__ __launch_bounds__(256) void conv2d_wide16_kernel(const float* __restr
 #pragma unroll
     for (int r = 0; r < 4; ++r) a[r] = read_op(abase + ((r * STRIDE + kh) * PW + kw) * RS);
   };
-  Op a[4], b;
-  read_a(0, a);
-  b = read_op(bbase);
-#pragma unroll
-  for (int t = 0; t < TAPS; ++t) {
-    Op an[4], bn = b;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) an[r] = a[r];
-    if (t + 1 < TAPS) {
-      read_a(t + 1, an);
-      bn = read_op(bbase + (t + 1) * 4 * NCOL * CPL);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int j = 0; j < CPL; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r].v[j], b.v[j], acc[r], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) a[r] = an[r];
-    b = bn;
-  }
-
-  // ---- epilogue: C/D layout column (channel) = lane & 15, rows (pixels of the output row) 4 kq + {0..3} -------------
-  float* yb = y + ((int64_t)n * COUT + li) * ((int64_t)g.Ho * g.Wo);
   const bool vec_ok = (g.Wo & 3) == 0;
   const bool col_ok = li < COUT;
-  float s = 0.0f, q = 0.0f;
-  const int ow = ow0 + 4 * kq;
+  double ds = 0.0, dq = 0.0;
+#pragma unroll 1
+  for (; tile < tiles; tile += nb) {
+    int oh0, ow0;
+    tile_origin(tile, oh0, ow0);
+    st.template commit<(AFFINE != 0)>(patch, aff);
+    __syncthreads();
+    if (tile + nb < tiles) {
+      int noh0, now0;
+      tile_origin(tile + nb, noh0, now0);
+      st.load(xb, plane_i, noh0 * STRIDE - C::PAD, now0 * STRIDE - C::PAD, g.Hi, g.Wi);
+    }
+    f32x4 acc[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int oh = oh0 + 4 * wave + r;
-    if (oh < g.Ho && col_ok) {
-      float* dst = yb + (int64_t)oh * g.Wo + ow;
-      if (vec_ok && ow + 3 < g.Wo) {
-        *reinterpret_cast<f32x4*>(dst) = acc[r];
+    for (int r = 0; r < 4; ++r) acc[r] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    Op a[4], b;
+    read_a(0, a);
+    b = read_op(bbase);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          s += acc[r][e];
-          q += acc[r][e] * acc[r][e];
-        }
-      } else {
+    for (int t = 0; t < TAPS; ++t) {
+      Op an[4], bn = b;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (ow + e < g.Wo) {
-            dst[e] = acc[r][e];
+      for (int r = 0; r < 4; ++r) an[r] = a[r];
+      if (t + 1 < TAPS) {
+        read_a(t + 1, an);
+        bn = read_op(bbase + (t + 1) * 4 * NCOL * CPL);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < CPL; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r].v[j], b.v[j], acc[r], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a[r] = an[r];
+      b = bn;
+    }
+    // epilogue: C/D layout column (channel) = lane & 15, rows (pixels of the output row) 4 kq + {0..3}
+    float* yb = y + ((int64_t)n * COUT + li) * ((int64_t)g.Ho * g.Wo);
+    float s = 0.0f, q = 0.0f;
+    const int ow = ow0 + 4 * kq;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int oh = oh0 + 4 * wave + r;
+      if (oh < g.Ho && col_ok) {
+        float* dst = yb + (int64_t)oh * g.Wo + ow;
+        if (vec_ok && ow + 3 < g.Wo) {
+          *reinterpret_cast<f32x4*>(dst) = acc[r];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
             s += acc[r][e];
             q += acc[r][e] * acc[r][e];
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (ow + e < g.Wo) {
+              dst[e] = acc[r][e];
+              s += acc[r][e];
+              q += acc[r][e] * acc[r][e];
+            }
           }
         }
       }
     }
+    ds += (double)s;
+    dq += (double)q;
+    __syncthreads();                                   // every wave is done with the patch: the next commit may land
   }
   if (partials != nullptr) {
-    s += __shfl_xor(s, 16);
-    q += __shfl_xor(q, 16);
-    s += __shfl_xor(s, 32);
-    q += __shfl_xor(q, 32);
+    ds += __shfl_xor(ds, 16);
+    dq += __shfl_xor(dq, 16);
+    ds += __shfl_xor(ds, 32);
+    dq += __shfl_xor(dq, 32);
     if (lane < 16) {
-      red[(wave * 16 + lane) * 2 + 0] = (double)s;
-      red[(wave * 16 + lane) * 2 + 1] = (double)q;
+      red[(wave * 16 + lane) * 2 + 0] = ds;
+      red[(wave * 16 + lane) * 2 + 1] = dq;
     }
     __syncthreads();
     if (tid < COUT) {
-      double ds = 0.0, dq = 0.0;
+      double ts = 0.0, tq = 0.0;
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
-        ds += red[(w * 16 + tid) * 2 + 0];
-        dq += red[(w * 16 + tid) * 2 + 1];
+        ts += red[(w * 16 + tid) * 2 + 0];
+        tq += red[(w * 16 + tid) * 2 + 1];
       }
       double* o = partials + (((int64_t)n * gridDim.x + blockIdx.x) * COUT + tid) * 2;
-      o[0] = ds;
-      o[1] = dq;
+      o[0] = ts;
+      o[1] = tq;
     }
   }
+}
+
+// Blocks per sample of the 16-wide kernel: PF_WIDE16_TPB tiles per block (default 2), walked with a stride of the
+// block count so that neighbouring blocks stay on neighbouring tiles.
+int wide16_tiles_per_block() {
+  const char* e = getenv("PF_WIDE16_TPB");
+  const int v = e ? atoi(e) : 2;
+  return v >= 1 && v <= 8 ? v : 2;
+}
+int wide16_blocks(int tiles) {
+  const int tpb = wide16_tiles_per_block();
+  return (tiles + tpb - 1) / tpb;
 }
 
 template <int KS, int STRIDE, int CIN, int COUT, int AFFINE>
@@ -477,8 +544,8 @@ int launch_wide16_mode(const float* x, const float* wp, float* y, WideGeom g, in
     if (rc != PF_OK) return rc;
   }
   g.tiles_w = (g.Wo + C::TW - 1) / C::TW;
-  const int tiles_h = (g.Ho + C::TH - 1) / C::TH;
-  dim3 grid((unsigned)(tiles_h * g.tiles_w), (unsigned)N);
+  g.tiles_h = (g.Ho + C::TH - 1) / C::TH;
+  dim3 grid((unsigned)wide16_blocks(g.tiles_h * g.tiles_w), (unsigned)N);
   hipLaunchKernelGGL((conv2d_wide16_kernel<KS, STRIDE, CIN, COUT, AFFINE>), grid, dim3(256), C::LDS, s, x, wp, y, g,
                      in_scale, in_shift, partials, in_bn);
   return pf_launch_status();
@@ -520,7 +587,8 @@ int pf_conv2d_wide_blocks(int64_t Cout, int64_t Hi, int64_t Wi, int stride) {
   if ((Cout != 8 && Cout != 16 && Cout != 32 && Cout != 64) || Hi <= 0 || Wi <= 0 || (stride != 1 && stride != 2)) return 0;
   const int64_t Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;
   const int th = wide_tile_rows(Cout);
-  return (int)(((Ho + th - 1) / th) * ((Wo + 15) / 16));
+  const int tiles = (int)(((Ho + th - 1) / th) * ((Wo + 15) / 16));
+  return Cout <= 16 ? wide16_blocks(tiles) : tiles;
 }
 
 int pf_conv2d_wide_f32(const float* x, const float* wp, float* y, int64_t N, int64_t Cin, int64_t Cout, int64_t Hi,
@@ -538,7 +606,7 @@ int pf_conv2d_wide_f32(const float* x, const float* wp, float* y, int64_t N, int
   g.Wi = (int)Wi;
   g.Ho = (int)((Hi - 1) / stride + 1);
   g.Wo = (int)((Wi - 1) / stride + 1);
-  g.tiles_w = 0;
+  g.tiles_w = g.tiles_h = 0;
   g.sps = samples_per_stat;
   hipStream_t s = (hipStream_t)stream;
   if (Cout == 8) {

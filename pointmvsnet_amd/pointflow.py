@@ -579,7 +579,10 @@ def conv2d(x, conv, in_affine, samples_per_stat, want_stats, bn=None):
 
 
 CONV2D_WIDE = int(_os.environ.get("PF_CONV2D_WIDE", "1"))     # 0: 64-channel tower layers on the library convolution
-CONV2D_WIDE_MIN = int(_os.environ.get("PF_CONV2D_WIDE_MIN", "16"))   # 32: the 16-channel layers stay on pf_conv2d_f32
+# smallest C_out that goes to pf_conv2d_wide_f32: 8 = every tower layer (default; equal to 16 within noise, but the
+# 8-channel layers then resolve their input BatchNorm themselves); 16: the 8-channel layers on the FMA kernel
+# (conv2d_small.hip); 32: the 16-channel layers on pf_conv2d_f32 as well (-2 %)
+CONV2D_WIDE_MIN = int(_os.environ.get("PF_CONV2D_WIDE_MIN", "8"))
 
 
 def conv2d_wide_supported(conv):

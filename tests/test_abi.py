@@ -71,8 +71,8 @@ def test_bn_job_struct_layout_matches_header(tmp_path):
 
 
 def test_conv_policies_are_disjoint_and_cover_the_towers():
-    """Every ImageConv layer has exactly one owner, and since round 2 none of them is the library: the direct FMA
-    kernel (8 channels) or pf_conv2d_wide_f32 (16, 32 and 64 channels); pf_conv2d_f32 keeps the odd shapes."""
+    """Every ImageConv layer has exactly one owner, and since round 2 none of them is the library: all eleven run on
+    pf_conv2d_wide_f32; the FMA kernel (conv2d_small.hip) and pf_conv2d_f32 keep the other shapes and the knobs."""
     from pointmvsnet_amd import pointflow
     from pointmvsnet_amd.networks import ImageConv
     tower = ImageConv(8)
@@ -84,6 +84,6 @@ def test_conv_policies_are_disjoint_and_cover_the_towers():
             mfma = pointflow.conv2d_preferred(conv) and not wide          # the dispatch order of networks.py
             assert not (small and (mfma or wide))
             owners["%s.%d" % (name, i)] = "small" if small else ("wide" if wide else ("mfma" if mfma else "library"))
-    assert owners == {"conv0.0": "small", "conv0.1": "small", "conv1.0": "wide", "conv1.1": "wide",
+    assert owners == {"conv0.0": "wide", "conv0.1": "wide", "conv1.0": "wide", "conv1.1": "wide",
                       "conv1.2": "wide", "conv2.0": "wide", "conv2.1": "wide", "conv2.2": "wide",
                       "conv3.0": "wide", "conv3.1": "wide", "conv3.2": "wide"}
