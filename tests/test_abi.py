@@ -87,3 +87,26 @@ def test_conv_policies_are_disjoint_and_cover_the_towers():
     assert owners == {"conv0.0": "wide", "conv0.1": "wide", "conv1.0": "wide", "conv1.1": "wide",
                       "conv1.2": "wide", "conv2.0": "wide", "conv2.1": "wide", "conv2.2": "wide",
                       "conv3.0": "wide", "conv3.1": "wide", "conv3.2": "wide"}
+
+
+def test_no_default_path_kernel_uses_scratch_memory():
+    """hipcc's per-kernel resource usage, recorded by the build (build/resource_usage.json): a register array that
+    the compiler leaves in scratch (e.g. an array of HIP's float4 struct) serialises every access behind a memory
+    round trip and is invisible in the source.  Only the register-starved tuning variants (conv3d with >= 4 waves
+    per SIMD requested; never selected by default) may spill."""
+    import json
+    import re
+    from pointmvsnet_amd import build
+    if not os.path.exists(build.USAGE_FILE):
+        build.build(verbose=False)
+    usage = json.load(open(build.USAGE_FILE))
+    assert set(usage) == set(build.SOURCES)
+    allowed = re.compile(r"conv3d_k3_kernelILi\d+ELi\d+ELi\d+ELi[45]EE|conv3d_k3_pair_kernelILi2ELi4EE")
+    kernels = 0
+    for src, table in usage.items():
+        for name, u in table.items():
+            kernels += 1
+            if u.get("scratch_bytes_per_lane", 0) > 0:
+                assert allowed.search(name), "%s: %s uses %d bytes of scratch per lane" % (
+                    src, name, u["scratch_bytes_per_lane"])
+    assert kernels > 150
