@@ -197,10 +197,22 @@ def main():
     if training:
         from pointmvsnet_amd.train_step import TrainStep
         trainer = TrainStep(net)
-        args.eager = True                                                       # autograd: no graph capture
+        graphed_train = None
+        if not args.eager:
+            try:
+                from pointmvsnet_amd.train_step import GraphedTrainStep
+                graphed_train = GraphedTrainStep(trainer, scenes[0], img_scales, inter_scales)
+            except Exception as exc:          # say so, do not hide it
+                sys.stderr.write("bench.py: hipGraph capture of the training step failed (%r); running eager\n" % (exc,))
+        train_execution = "eager autograd" if graphed_train is None else \
+            "hipGraph replay of zero_grad + forward + loss + backward; all-reduce + RMSprop step eager"
+        args.eager = True                                                       # (no GraphedForward below)
 
         def eager_step(i):
-            loss, _, preds = trainer(scenes[i % n_unique], img_scales, inter_scales)
+            if graphed_train is not None:
+                loss, _, preds = graphed_train(scenes[i % n_unique])
+            else:
+                loss, _, preds = trainer(scenes[i % n_unique], img_scales, inter_scales)
             return preds
     else:
         def eager_step(i):
@@ -363,7 +375,7 @@ def main():
                    "mode": "train step: forward(isTest=False) + PointMVSNetLoss + backward + RMSprop (train.py:46-112)"
                    if training else
                    "PointMVSNet.forward(isFlow=True, isTest=True), BatchNorm in train mode (test.py:58)"},
-        "execution": execution,
+        "execution": train_execution if training else execution,
         "host_issue_ms_per_step": issued / args.steps * 1e3,
         "gap_probe": gap_probe,
         "stage_timeline_us": stage_timeline,

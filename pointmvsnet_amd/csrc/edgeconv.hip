@@ -1388,7 +1388,10 @@ int pf_edge_backward_apply_f32(const float* LE, int64_t ldle, int C, const int64
   if (G == 0 || Ng == 0) return PF_OK;
   PF_REQUIRE(LE && idx && grad_y && scale && shift && mean && invstd && c1 && c2 && grad_le);
   hipStream_t s = (hipStream_t)stream;
-  PF_HIP(hipMemsetAsync(grad_le, 0, sizeof(float) * (size_t)G * Ng * ldle, s));
+  {
+    const int zrc = pf_zero_async(grad_le, sizeof(float) * (size_t)G * Ng * ldle, s);
+    if (zrc != PF_OK) return zrc;
+  }
   const EdgeBwdAffine A{scale, shift, mean, invstd, c1, c2, ld_affine, groups_per_stat, concat};
   const int T = pf_stat_blocks(G, Ng);
   dim3 grid((unsigned)T, (unsigned)G);

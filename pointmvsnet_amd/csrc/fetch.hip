@@ -757,7 +757,10 @@ int pf_fetch_backward_f32(const float* grad_out, const float* pts, const float* 
   PF_REQUIRE(B <= 65535 && V <= 65535 && H * W <= INT32_MAX && C <= INT32_MAX);
   if (B == 0 || V == 0 || C == 0) return PF_OK;
   PF_REQUIRE(grad_maps != nullptr);
-  PF_HIP(hipMemsetAsync(grad_maps, 0, sizeof(float) * (size_t)(B * V * C * H * W), (hipStream_t)stream));
+  {
+    const int zrc = pf_zero_async(grad_maps, sizeof(float) * (size_t)(B * V * C * H * W), (hipStream_t)stream);
+    if (zrc != PF_OK) return zrc;
+  }
   if (N == 0) return PF_OK;
   PF_REQUIRE(grad_out && pts && K);
   dim3 grid((unsigned)pf_cdiv(N, 256), (unsigned)V, (unsigned)B);

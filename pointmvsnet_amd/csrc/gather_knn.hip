@@ -80,7 +80,10 @@ int gather_backward(const T* grad_out, const int64_t* index, T* grad_in, int64_t
   PF_REQUIRE(B <= 65535 && C <= INT32_MAX);
   if (B == 0 || C == 0 || N == 0) return PF_OK;
   PF_REQUIRE(grad_in != nullptr);
-  PF_HIP(hipMemsetAsync(grad_in, 0, sizeof(T) * (size_t)(B * C * N), (hipStream_t)stream));
+  {
+    const int zrc = pf_zero_async(grad_in, sizeof(T) * (size_t)(B * C * N), (hipStream_t)stream);
+    if (zrc != PF_OK) return zrc;
+  }
   if (K == 0) return PF_OK;
   PF_REQUIRE(grad_out != nullptr && index != nullptr);
   unsigned* status = pf_status_ptr();

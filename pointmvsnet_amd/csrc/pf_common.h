@@ -42,6 +42,26 @@ static inline int pf_allow_big_lds(const void* kernel, int bytes, std::atomic<un
   return PF_OK;
 }
 
+// Zero `bytes` bytes (a multiple of 4, 4-byte aligned) with a KERNEL.  The scatter-add backward passes need their output
+// cleared first; hipMemsetAsync did that until the training step was captured in a hipGraph: memset nodes recorded
+// from the autograd thread were not replayed reliably (the cleared buffers kept the previous replay's sums and the
+// gradients grew from replay to replay, tools/dbg_train.py), a kernel node is.
+#if defined(__HIPCC__)
+static __global__ __launch_bounds__(256) void pf_zero_kernel(unsigned* __restrict__ p, size_t words) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += stride) p[i] = 0u;
+}
+static inline int pf_zero_async(void* p, size_t bytes, hipStream_t s) {
+  if (bytes == 0) return PF_OK;
+  const size_t words = bytes / 4;
+  size_t blocks = (words + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(pf_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<unsigned*>(p), words);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? PF_OK : (int)e;
+}
+#endif
+
 // ---- projection + bilinear taps shared by the fetch kernels -------------------------------------
 // Follows reference utils/feature_fetcher.py:36-55 on the arithmetic of ATen's CPU grid_sample with
 // align_corners=True (the oracle): un-normalise with (g + 1) * ((size - 1) / 2), weights

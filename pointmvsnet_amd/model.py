@@ -172,6 +172,84 @@ class ScenePlan(object):
         return self
 
 
+class TrainPlan(object):
+    """The host-derived constants of one forward of the AUTOGRAD path (reference model.py:45-305), in one pinned
+    host block mirrored by one device block -- ScenePlan's idea for the training step: the forward touches device
+    tensors only (no per-call H2D copies, no ``.cpu()`` round trip for the flow intrinsics), so forward + loss +
+    backward can be captured in a hipGraph and replayed on the next scene (train_step.GraphedTrainStep)."""
+
+    def __init__(self, device, B, V, num_depth, img_scales, inter_scales, is_test):
+        self.device, self.B, self.V, self.D = device, B, V, int(num_depth)
+        self.img_scales, self.inter_scales = tuple(img_scales), tuple(inter_scales)
+        self.is_test = bool(is_test)
+        entries = [("K_coarse", (B, V, 3, 3)), ("ext", (B, V, 3, 4)), ("Kinv0", (B, 1, 3, 3)), ("Rinv0", (B, 1, 3, 3)),
+                   ("t0", (B, 1, 3, 1)), ("depths", (B, self.D)), ("d_start", (B,)), ("d_int", (B,)),
+                   ("mean", (B, 3, 1)), ("std", (B, 3, 1))]
+        for i in range(len(self.img_scales)):
+            entries += [("interval%d" % i, (B,)), ("K_flow%d" % i, (B, V, 3, 3)), ("Kinv_flow%d" % i, (B, 1, 3, 3))]
+        self._layout, off = {}, 0
+        for name, shape in entries:
+            n = 1
+            for d in shape:
+                n *= d
+            self._layout[name] = (off, n, shape)
+            off += (n + 3) // 4 * 4
+        self.host = torch.zeros(off, dtype=torch.float32)
+        if torch.cuda.is_available():
+            self.host = self.host.pin_memory()
+        self.dev = torch.zeros(off, dtype=torch.float32, device=device)
+        self._copied = None
+
+    def _h(self, name):
+        off, n, shape = self._layout[name]
+        return self.host[off:off + n].view(shape)
+
+    def d(self, name):
+        off, n, shape = self._layout[name]
+        return self.dev[off:off + n].view(shape)
+
+    def matches(self, device, B, V, num_depth, img_scales, inter_scales, is_test):
+        return (self.device == device and (self.B, self.V, self.D) == (B, V, int(num_depth))
+                and self.img_scales == tuple(img_scales) and self.inter_scales == tuple(inter_scales)
+                and self.is_test == bool(is_test))
+
+    def fill_host_(self, data_batch):
+        cam = _Cameras(_host_cams(data_batch), self.is_test)
+        if cam.num_depth != self.D:
+            raise RuntimeError("TrainPlan: num_depth changed (%d -> %d); build a new plan" % (self.D, cam.num_depth))
+        mean_h = data_batch["mean_host"] if "mean_host" in data_batch else data_batch["mean"].detach().cpu()
+        std_h = data_batch["std_host"] if "std_host" in data_batch else data_batch["std"].detach().cpu()
+        if self._copied is not None:
+            self._copied.synchronize()
+        self._h("K_coarse").copy_(cam.K_coarse)
+        self._h("ext").copy_(cam.ext)
+        self._h("Kinv0").copy_(torch.inverse(cam.K_coarse[:, 0]).unsqueeze(1))
+        self._h("Rinv0").copy_(cam.R_inv[:, 0:1])
+        self._h("t0").copy_(cam.t[:, 0:1])
+        for b in range(self.B):
+            self._h("depths")[b].copy_(torch.linspace(float(cam.depth_start[b]), float(cam.depth_end[b]), self.D))
+        self._h("d_start").copy_(cam.depth_start)
+        self._h("d_int").copy_(cam.depth_interval)
+        self._h("mean").copy_(mean_h.float().reshape(self.B, 3, 1))
+        self._h("std").copy_(std_h.float().reshape(self.B, 3, 1))
+        for i, (s, inter) in enumerate(zip(self.img_scales, self.inter_scales)):
+            K_flow = cam.flow_intrinsics(s)
+            self._h("interval%d" % i).copy_(inter * cam.depth_interval)
+            self._h("K_flow%d" % i).copy_(K_flow)
+            self._h("Kinv_flow%d" % i).copy_(torch.inverse(K_flow[:, 0]).unsqueeze(1))
+        return self
+
+    def upload_(self):
+        self.dev.copy_(self.host, non_blocking=True)
+        if self.dev.is_cuda:
+            self._copied = torch.cuda.Event()
+            self._copied.record()
+        return self
+
+    def update_(self, data_batch):
+        return self.fill_host_(data_batch).upload_()
+
+
 class PointMVSNet(nn.Module):
     def __init__(self, img_base_channels=8, vol_base_channels=8, flow_channels=(64, 64, 16, 1), k=16):
         super(PointMVSNet, self).__init__()
@@ -187,6 +265,7 @@ class PointMVSNet(nn.Module):
         )
         self._grid_cache = {}
         self._plan = None
+        self._tplan = None
         self._side_stream = None
 
     # ------------------------------------------------------------------------------------------
@@ -194,6 +273,12 @@ class PointMVSNet(nn.Module):
         key = (h, w, str(device))
         if key not in self._grid_cache:
             self._grid_cache[key] = get_pixel_grids(h, w).to(device)
+        return self._grid_cache[key]
+
+    def _hypotheses(self, device):
+        key = ("hyp", str(device))                       # cached: a host -> device copy cannot sit inside a hipGraph
+        if key not in self._grid_cache:
+            self._grid_cache[key] = torch.tensor(_HYPOTHESES, dtype=torch.float32, device=device)
         return self._grid_cache[key]
 
     def _needs_graph(self):
@@ -353,27 +438,46 @@ class PointMVSNet(nn.Module):
         return preds
 
     # ------------------------------------------------------------------------------------------
-    def _forward_autograd(self, data_batch, img_scales, inter_scales, isFlow, isTest):
-        """Training path: the reference composition on differentiable HIP operators (model.py:45-305)."""
+    def make_train_plan(self, data_batch, img_scales, inter_scales, isTest=False):
         img_list = data_batch["img_list"]
-        cam = _Cameras(_host_cams(data_batch), isTest)
+        B, V = img_list.shape[:2]
+        D = int(_host_cams(data_batch)[0, 0, 1, 3, 2].long())
+        return TrainPlan(img_list.device, B, V, D, img_scales, inter_scales, isTest).update_(data_batch)
+
+    def _forward_autograd(self, data_batch, img_scales, inter_scales, isFlow, isTest, tplan=None):
+        """Training path: the reference composition on differentiable HIP operators (model.py:45-305).  Every
+        host-derived constant comes from ``tplan`` (a TrainPlan; built and uploaded here when None), so with a
+        caller-owned plan the whole pass is device-only and capturable."""
+        img_list = data_batch["img_list"]
         dev = img_list.device
         B, V, _, H, W = img_list.shape
+        if tplan is None:
+            D = int(_host_cams(data_batch)[0, 0, 1, 3, 2].long())
+            tplan = self._tplan
+            if tplan is None or not tplan.matches(dev, B, V, D, img_scales, inter_scales, isTest):
+                tplan = self._tplan = TrainPlan(dev, B, V, D, img_scales, inter_scales, isTest)
+            tplan.update_(data_batch)
+        return self.run_autograd(tplan, img_list, isFlow)
+
+    def run_autograd(self, tplan, img_list, isFlow=True):
+        """Device-only autograd forward on the constants of ``tplan`` (capturable together with its backward)."""
+        dev = img_list.device
+        B, V, _, H, W = img_list.shape
+        isTest, img_scales = tplan.is_test, tplan.img_scales
         preds = collections.OrderedDict()
-        K_coarse = cam.K_coarse.to(dev)
-        ext = cam.ext.to(dev)
+        K_coarse = tplan.d("K_coarse")
+        ext = tplan.d("ext")
 
         coarse_maps = [self.coarse_img_conv(img_list[:, v])["conv3"] for v in range(V)]
         feature_list = torch.stack(coarse_maps, dim=1)                       # (B,V,C,FH,FW)
         C, FH, FW = feature_list.shape[2:]
-        D = cam.num_depth
-        depths = torch.stack([torch.linspace(float(cam.depth_start[b]), float(cam.depth_end[b]), D)
-                              for b in range(B)], dim=0).to(dev)            # (B,D)
+        D = tplan.D
+        depths = tplan.d("depths")                                           # (B,D)
         grid = self._pixel_grid(FH, FW, dev).view(1, 1, 3, -1).expand(B, 1, 3, -1)
-        uv = torch.matmul(torch.inverse(cam.K_coarse[:, 0]).to(dev).unsqueeze(1), grid)
+        uv = torch.matmul(tplan.d("Kinv0"), grid)
         cam_points = (uv.unsqueeze(3) * depths.view(B, 1, 1, D, 1)).view(B, 1, 3, -1)
-        R_inv0 = cam.R_inv[:, 0:1].to(dev)
-        t0 = cam.t[:, 0:1].to(dev)
+        R_inv0 = tplan.d("Rinv0")
+        t0 = tplan.d("t0")
         world_points = torch.matmul(R_inv0, cam_points - t0).transpose(1, 2).contiguous().view(B, 3, -1)
         preds["world_points"] = world_points
 
@@ -384,8 +488,8 @@ class PointMVSNet(nn.Module):
         cost = (point_features ** 2).mean(dim=1) - avg ** 2
         filtered = self.coarse_vol_conv(cost.view(B, C, D, FH, FW)).squeeze(1)
 
-        d_start = cam.depth_start.to(dev)
-        d_int = cam.depth_interval.to(dev)
+        d_start = tplan.d("d_start")
+        d_int = tplan.d("d_int")
         prob_volume = F.softmax(-filtered, dim=1)
         pred_depth = torch.sum(depths.view(B, D, 1, 1) * prob_volume, dim=1).unsqueeze(1)
         preds["coarse_depth_map"] = pred_depth
@@ -398,17 +502,14 @@ class PointMVSNet(nn.Module):
         pyramids = {n: torch.stack([pv[n] for pv in per_view], dim=1) for n in names}   # (B,V,c,h_l,w_l)
         if isTest:
             pyramids = {n: p.detach() for n, p in pyramids.items()}
-        for it, (img_scale, inter_scale) in enumerate(zip(img_scales, inter_scales)):
+        for it, img_scale in enumerate(img_scales):
             if isTest:
                 pred_depth = pred_depth.detach()
                 if img_scale not in (0.125, 0.25, 0.5, 1.0):
                     raise NotImplementedError
-            interval = (inter_scale * cam.depth_interval).to(dev)
             h, w = int(H * img_scale), int(W * img_scale)
             ratio = int(img_scale * 8) if (isTest and img_scale != 0.125) else 1
-            pred_depth, flow_prob = self._point_flow_autograd(
-                pyramids, pred_depth, interval, cam.flow_intrinsics(img_scale).to(dev), ext, cam, data_batch, h, w,
-                ratio)
+            pred_depth, flow_prob = self._point_flow_autograd(pyramids, pred_depth, tplan, it, h, w, ratio)
             preds["flow{}_prob".format(it + 1)] = flow_prob
             preds["flow{}".format(it + 1)] = pred_depth
         pointflow.flush_counters()
@@ -427,21 +528,21 @@ class PointMVSNet(nn.Module):
             edges.append(x)
         flow = self.flow_mlp(torch.cat(edges, dim=1)).contiguous().view(B, D, hs, ws)
         prob = F.softmax(-flow, dim=1)
-        length = torch.tensor(_HYPOTHESES, dtype=torch.float32, device=xyz.device).view(1, -1, 1, 1) \
-            * interval.view(-1, 1, 1, 1)
+        length = self._hypotheses(xyz.device).view(1, -1, 1, 1) * interval.view(-1, 1, 1, 1)
         return torch.sum(prob * length, dim=1, keepdim=True), prob
 
-    def _point_flow_autograd(self, pyramids, depth_map, interval, K_flow, ext, cam, data_batch, h, w, ratio):
+    def _point_flow_autograd(self, pyramids, depth_map, tplan, it, h, w, ratio):
         dev = depth_map.device
         B = depth_map.shape[0]
+        interval, K_flow, ext = tplan.d("interval%d" % it), tplan.d("K_flow%d" % it), tplan.d("ext")
         if depth_map.shape[2] != h:
             depth_map = F.interpolate(depth_map, (h, w), mode="nearest")
-        mean = data_batch["mean"].to(dev).unsqueeze(-1)
-        std = data_batch["std"].to(dev).unsqueeze(-1)
+        mean = tplan.d("mean")
+        std = tplan.d("std")
         grid = self._pixel_grid(h, w, dev).view(1, 1, 3, -1).expand(B, 1, 3, -1)
-        uv = torch.matmul(torch.inverse(K_flow[:, 0].cpu()).to(dev).unsqueeze(1), grid)
-        R_inv0 = cam.R_inv[:, 0:1].to(dev)
-        t0 = cam.t[:, 0:1].to(dev)
+        uv = torch.matmul(tplan.d("Kinv_flow%d" % it), grid)
+        R_inv0 = tplan.d("Rinv0")
+        t0 = tplan.d("t0")
         resized = {}
         for name, fm in pyramids.items():
             V, c, fh, fw = fm.shape[1:]

@@ -47,7 +47,28 @@ def _src_sig(t):
     return (t._version, t.data_ptr(), str(t.device), t.dtype)
 
 
+_pack_bypass = 0
+
+
+class no_pack_cache(object):
+    """Context: every packed-weight request re-packs (``make()``) instead of consulting the cache.  A hipGraph that
+    contains a TRAINING step must hold the packing kernels themselves -- its parameters change between replays, so
+    a pack cached at capture time would be stale at the first replay (train_step.GraphedTrainStep)."""
+
+    def __enter__(self):
+        global _pack_bypass
+        _pack_bypass += 1
+        return self
+
+    def __exit__(self, *exc):
+        global _pack_bypass
+        _pack_bypass -= 1
+        return False
+
+
 def _cached_pack(key, sources, make):
+    if _pack_bypass:
+        return make()
     hit = _pack_cache.get(key)
     if hit is not None:
         refs, sigs, out = hit

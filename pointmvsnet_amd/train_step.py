@@ -9,7 +9,7 @@ no (B,2C,N,k) tensor), the HIP FeatureFetcher forward/backward and stock ATen fo
 """
 import torch
 
-from . import distributed
+from . import distributed, pointflow
 from .model import PointMVSNetLoss
 
 
@@ -41,3 +41,66 @@ class TrainStep(object):
         self.bucket.allreduce_sum(self.group)                      # SUM: the loss sums over the batch (networks.py:176-179)
         self.optimizer.step()
         return total.detach(), losses, preds
+
+
+class GraphedTrainStep(object):
+    """The same step with  zero_grad + forward + loss + backward  captured ONCE in a hipGraph and replayed per scene.
+
+    Eager, config 4 spends ~100 of its 117 ms per step in Python / ATen launch overhead (autograd over ~1 500 small
+    kernels); the GPU work itself is a fraction of that.  What makes the pass capturable: every host-derived constant
+    lives in a TrainPlan (model.py; one pinned block, one H2D per step, OUTSIDE the graph), the images / ground
+    truth / camera block are static device buffers the step's batch is copied into, the gradients already live in
+    the flat bucket (GradBucket: ``.grad`` views, zeroed by one memset inside the graph), and the packed weights of
+    the fused EdgeConv node are re-packed inside the graph (pointflow.no_pack_cache) because the parameters change
+    between replays.  The gradient all-reduce (one collective) and the RMSprop step (a handful of foreach kernels)
+    run after the replay, eagerly -- RCCL calls are kept out of the graph on purpose.
+
+    Warm-up forwards/backwards run on a side stream before the capture (library autotuning, allocator); the
+    BatchNorm buffers are restored afterwards, the parameters are not touched (no optimizer step during warm-up)."""
+
+    def __init__(self, trainer, batch, img_scales, inter_scales, is_flow=True, warmup=3):
+        self.t = trainer
+        self.is_flow = bool(is_flow)
+        model = trainer.model
+        model.train()
+        self.img = batch["img_list"].detach().clone()
+        self.gt = batch["gt_depth_img"].detach().clone()
+        self.cams = batch["cam_params_list"].detach().clone()
+        self.plan = model.make_train_plan(batch, img_scales, inter_scales, isTest=False)
+        buffers = [(b, b.detach().clone()) for b in model.buffers()]
+        main = torch.cuda.current_stream()
+        side = torch.cuda.Stream(device=self.img.device)
+        side.wait_stream(main)
+        with pointflow.no_pack_cache():
+            with torch.cuda.stream(side):
+                for _ in range(int(warmup)):
+                    self._forward_backward()
+            main.wait_stream(side)
+            torch.cuda.synchronize()
+            with torch.no_grad():
+                for b, saved in buffers:
+                    b.copy_(saved)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.total, self.losses, self.preds = self._forward_backward()
+
+    def _forward_backward(self):
+        self.t.bucket.zero_()
+        preds = self.t.model.run_autograd(self.plan, self.img, self.is_flow)
+        labels = {"gt_depth_img": self.gt, "cam_params_list": self.cams}
+        losses = self.t.loss_fn(preds, labels, self.is_flow)
+        total = sum(losses.values())
+        total.backward()
+        return total.detach(), {k: v.detach() for k, v in losses.items()}, {k: v.detach() for k, v in preds.items()}
+
+    def __call__(self, batch):
+        """One step on ``batch`` (same shapes as the capture batch).  Returns (total loss, loss dict, preds) -- static
+        tensors that the next call overwrites."""
+        self.plan.update_(batch)                                    # host camera algebra + one H2D
+        self.img.copy_(batch["img_list"], non_blocking=True)
+        self.gt.copy_(batch["gt_depth_img"], non_blocking=True)
+        self.cams.copy_(batch["cam_params_list"], non_blocking=True)
+        self.graph.replay()
+        self.t.bucket.allreduce_sum(self.t.group)
+        self.t.optimizer.step()
+        return self.total, self.losses, self.preds

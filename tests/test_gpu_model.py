@@ -356,6 +356,43 @@ def test_train_step_runs_and_updates_through_the_bucket(dev):
     assert torch.isfinite(l2) and float(l2) != float(l1)
 
 
+def test_graphed_train_step_matches_the_eager_step(dev):
+    """GraphedTrainStep (zero_grad + forward + loss + backward replayed from ONE hipGraph, packs re-packed inside
+    it) against the eager TrainStep: same losses and the same 698 936 gradients on four consecutive steps over two
+    alternating scenes, the parameters changing between the replays -- the later steps only agree if a replay really
+    runs on the UPDATED parameters and on the new scene's constants."""
+    from pointmvsnet_amd.train_step import GraphedTrainStep, TrainStep
+    batches = []
+    for seed in (0, 1):
+        data, img_scales, inter_scales = synthetic.make_config("tiny", seed=seed, train_intrinsics=True)
+        b = _to(data, dev)
+        b["gt_depth_img"] = synthetic.make_gt_depth(data, seed=seed).to(dev)
+        batches.append(b)
+    net_e, net_g = _model(dev), _model(dev)
+    eager = TrainStep(net_e)
+    graphed = GraphedTrainStep(TrainStep(net_g), batches[0], img_scales, inter_scales)
+    # the capture and its warm-up must not have changed the module: same parameters AND BatchNorm buffers
+    for (k, a), (_, b) in zip(net_e.state_dict().items(), net_g.state_dict().items()):
+        assert torch.equal(a, b), k
+    for i in range(4):
+        # same weights and BatchNorm buffers on both sides before every step (RMSprop's 1/sqrt(v) turns the float-atomics
+        # noise of near-zero gradients into O(lr) parameter differences, so the two runs may not be left to drift):
+        # load_state_dict copies IN PLACE, i.e. the graph must pick the new values up from the same storage
+        net_g.load_state_dict(net_e.state_dict())
+        le, parts_e, _ = eager(batches[i % 2], img_scales, inter_scales)
+        ge = eager.bucket.flat.detach().clone()
+        lg, parts_g, _ = graphed(batches[i % 2])
+        gg = graphed.t.bucket.flat.detach().clone()
+        rel = abs(float(le) - float(lg)) / max(abs(float(le)), 1e-6)
+        l2 = float((ge - gg).norm() / ge.norm())
+        report("graphed_train_step_%d" % i, loss_eager=float(le), loss_graphed=float(lg), grad_rel_l2=l2)
+        assert rel < 1e-4, (i, float(le), float(lg))
+        assert torch.isfinite(gg).all() and l2 < 1e-3, (i, l2)           # 698 936 gradients, relative L2
+        for k in parts_e:
+            assert abs(float(parts_e[k]) - float(parts_g[k])) < 1e-4 * max(1.0, abs(float(parts_e[k])))
+    assert int(net_g.flow_mlp[0][0].bn.num_batches_tracked) == int(net_e.flow_mlp[0][0].bn.num_batches_tracked)
+
+
 def test_train_step_fused_edgeconv_node_vs_composed_path_on_gpu(dev, monkeypatch):
     """Same model, same inputs, same GPU libraries for everything around it: the fused EdgeConv autograd node
     (recompute backward kernels) against the reference's composition on the HIP gather_knn operator.  This isolates
