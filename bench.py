@@ -196,6 +196,10 @@ def main():
 
     if training:
         from pointmvsnet_amd.train_step import TrainStep
+        # PF_MIOPEN_FIND=1: let the library time its convolution solvers (torch.backends.cudnn.benchmark) instead of
+        # taking its immediate-mode pick, which for the 3-D weight gradients of VolumeConv is a naive reference kernel
+        if os.environ.get("PF_MIOPEN_FIND", "1") == "1":
+            torch.backends.cudnn.benchmark = True
         trainer = TrainStep(net)
         graphed_train = None
         if not args.eager:
