@@ -82,6 +82,49 @@ def test_scene_plan_blocks_are_one_aligned_buffer():
     assert torch.equal(plan.d("ext"), _Cameras(other["cam_params_list"], True).ext)
 
 
+def test_train_plan_holds_every_host_constant_of_the_autograd_forward():
+    """TrainPlan (the constants of the training forward in one block, what makes the step capturable): the same
+    values the reference's forward derives on the host (model.py:59-61, :87-100, :162-178), train-mode intrinsics."""
+    from pointmvsnet_amd.model import TrainPlan
+    data, scales, inters = synthetic.make_config("tiny", train_intrinsics=True)
+    plan = TrainPlan(torch.device("cpu"), 1, 3, 8, scales, inters, False).update_(data)
+    cam = _Cameras(data["cam_params_list"], False)
+    assert torch.equal(plan.d("K_coarse"), cam.K_coarse) and torch.equal(plan.d("ext"), cam.ext)
+    assert torch.equal(plan.d("Kinv0")[:, 0], torch.inverse(cam.K_coarse[:, 0]))
+    assert torch.equal(plan.d("Rinv0"), cam.R_inv[:, 0:1]) and torch.equal(plan.d("t0"), cam.t[:, 0:1])
+    assert torch.equal(plan.d("depths")[0], torch.linspace(float(cam.depth_start[0]), float(cam.depth_end[0]), 8))
+    assert torch.equal(plan.d("d_start"), cam.depth_start) and torch.equal(plan.d("d_int"), cam.depth_interval)
+    assert torch.equal(plan.d("mean")[:, :, 0], data["mean"].float()) and torch.equal(plan.d("std")[:, :, 0], data["std"].float())
+    for i, (s_, inter) in enumerate(zip(scales, inters)):
+        K_flow = cam.flow_intrinsics(s_)
+        assert torch.equal(plan.d("K_flow%d" % i), K_flow)
+        assert torch.equal(plan.d("Kinv_flow%d" % i)[:, 0], torch.inverse(K_flow[:, 0]))
+        assert torch.equal(plan.d("interval%d" % i), inter * cam.depth_interval)
+        for name in ("K_flow%d" % i, "Kinv_flow%d" % i, "interval%d" % i):
+            assert plan.d(name).data_ptr() % 16 == 0
+    assert plan.matches(torch.device("cpu"), 1, 3, 8, scales, inters, False)
+    assert not plan.matches(torch.device("cpu"), 1, 3, 8, scales, inters, True)
+    other, _, _ = synthetic.make_config("tiny", seed=4, train_intrinsics=True)
+    plan.update_(other)
+    assert torch.equal(plan.d("ext"), _Cameras(other["cam_params_list"], False).ext)
+
+
+def test_no_pack_cache_context_bypasses_and_restores_the_cache():
+    from pointmvsnet_amd import pointflow
+    w = torch.nn.Parameter(torch.randn(8, 4, 1))
+    a, _ = pointflow.pack_weight_t(w)
+    b, _ = pointflow.pack_weight_t(w)
+    assert a is b                                           # cached
+    with pointflow.no_pack_cache():
+        c, _ = pointflow.pack_weight_t(w)
+        with pointflow.no_pack_cache():
+            d, _ = pointflow.pack_weight_t(w)
+        e, _ = pointflow.pack_weight_t(w)
+    assert c is not a and d is not c and e is not d and torch.equal(c, a)
+    f, _ = pointflow.pack_weight_t(w)
+    assert f is a                                           # the cache itself was not touched
+
+
 def test_operators_fail_loudly_without_gpu():
     from pointmvsnet_amd.functions.gather_knn import gather_knn
     from pointmvsnet_amd.networks import EdgeConv
