@@ -392,12 +392,15 @@ int pf_deconv3d_bottom_f32(const float* x, const float* wp, float* y, int64_t N,
  * (K, K, Cin/8, 2, Cout, 4): wp[kh][kw][kc][h][co][j] = w[co][8 kc + 4 h + j][kh][kw] for Cout 32 / 64, and
  * (K, K, 4, 16, Cin'/4), Cin' = Cin rounded up to 4: wp[kh][kw][kq][co][j] = w[co][(Cin'/4) kq + j][kh][kw] for
  * Cout 8 / 16 (zero where co >= Cout or the channel does not exist; shapes 3x3/1 3->8 and 8->8 as well).
+ * out_channel_last != 0 (Cout 32 / 64 only): y is written (N, Ho, Wo, Cout) -- the coarse tower's last layer
+ * feeds pf_frustum_variance_cl_f32 directly, without the pf_nchw_to_nhwc_f32 pass.
  * PF_ERR_UNSUPPORTED for any other shape (pf_conv2d_wide_supported tells). */
 int pf_conv2d_wide_supported(int64_t Cin, int64_t Cout, int kernel_size, int stride);
 int pf_conv2d_wide_blocks(int64_t Cout, int64_t Hi, int64_t Wi, int stride);
 int pf_conv2d_wide_f32(const float* x, const float* wp, float* y, int64_t N, int64_t Cin, int64_t Cout, int64_t Hi,
                        int64_t Wi, int kernel_size, int stride, const float* in_scale, const float* in_shift,
-                       const pf_bn_job* in_bn, int samples_per_stat, double* partials, void* stream);
+                       const pf_bn_job* in_bn, int samples_per_stat, double* partials, int out_channel_last,
+                       void* stream);
 
 /* ---- rows M (last layer) + H + T : flow head ---------------------------------------------------
  * Z (G*Ng, ldz) holds the pre-BN output of the 64->16 MLP layer.  Per pixel of the (h,w) grid:

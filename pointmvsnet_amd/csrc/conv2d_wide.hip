@@ -37,7 +37,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));   // (HIP's float4 struct in a register ARRAY ends up in scratch)
 
 struct WideGeom {
-  int Hi, Wi, Ho, Wo, tiles_w, tiles_h, sps;
+  int Hi, Wi, Ho, Wo, tiles_w, tiles_h, sps, cl_out;   // cl_out: y is (N, Ho, Wo, C_out) instead of (N, C_out, Ho, Wo)
 };
 
 template <int KS, int STRIDE, int CIN, int COUT>
@@ -238,6 +238,26 @@ __global__ __launch_bounds__(256) void conv2d_wide_kernel(const float* __restric
   float* yb = y + ((int64_t)n * COUT + co) * ((int64_t)g.Ho * g.Wo);
   const bool vec_ok = (g.Wo & 3) == 0;
   float s = 0.0f, q = 0.0f;
+  if (g.cl_out) {
+    // channel-last output (the coarse tower's last layer feeds the warp, which samples channel-last maps): for one
+    // accumulator element the 32 lanes of a half-wave hold 32 consecutive channels of one pixel = one 128-byte row
+    float* ycl = y + (int64_t)n * g.Ho * g.Wo * COUT + co;
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      const int oh = oh0 + 2 * wm + (rq >> 1);
+      const int ow = ow0 + (rq & 1) * 8 + 4 * h;
+      if (oh < g.Ho) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (ow + e < g.Wo) {
+            ycl[((int64_t)oh * g.Wo + ow + e) * COUT] = acc[4 * rq + e];
+            s += acc[4 * rq + e];
+            q += acc[4 * rq + e] * acc[4 * rq + e];
+          }
+        }
+      }
+    }
+  } else
 #pragma unroll
   for (int rq = 0; rq < 4; ++rq) {
     const int oh = oh0 + 2 * wm + (rq >> 1);
@@ -593,8 +613,10 @@ int pf_conv2d_wide_blocks(int64_t Cout, int64_t Hi, int64_t Wi, int stride) {
 
 int pf_conv2d_wide_f32(const float* x, const float* wp, float* y, int64_t N, int64_t Cin, int64_t Cout, int64_t Hi,
                        int64_t Wi, int kernel_size, int stride, const float* in_scale, const float* in_shift,
-                       const pf_bn_job* in_bn, int samples_per_stat, double* partials, void* stream) {
+                       const pf_bn_job* in_bn, int samples_per_stat, double* partials, int out_channel_last,
+                       void* stream) {
   PF_REQUIRE(N >= 0 && Cin >= 1 && Cout >= 1 && Hi >= 1 && Wi >= 1 && N <= 65535 && samples_per_stat >= 1);
+  if (out_channel_last && Cout < 32) return PF_ERR_UNSUPPORTED;     // (built for the 32x32x2 kernels only)
   PF_REQUIRE((in_scale == nullptr) == (in_shift == nullptr) && (in_bn == nullptr || in_scale == nullptr));
   PF_REQUIRE(N % samples_per_stat == 0 || in_bn == nullptr);
   if (!pf_conv2d_wide_supported(Cin, Cout, kernel_size, stride)) return PF_ERR_UNSUPPORTED;
@@ -608,6 +630,7 @@ int pf_conv2d_wide_f32(const float* x, const float* wp, float* y, int64_t N, int
   g.Wo = (int)((Wi - 1) / stride + 1);
   g.tiles_w = g.tiles_h = 0;
   g.sps = samples_per_stat;
+  g.cl_out = out_channel_last ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;
   if (Cout == 8) {
     if (Cin == 3) return launch_wide16<3, 1, 3, 8>(x, wp, y, g, N, in_scale, in_shift, partials, in_bn, s);

@@ -28,7 +28,7 @@ from . import pointflow
 from .functions.functions import get_pixel_grids, get_propability_map
 from .networks import EdgeConv, EdgeConvNoC, ImageConv, VolumeConv, MAELoss, Valid_MAELoss
 from .nn.mlp import SharedMLP
-from .utils.feature_fetcher import FeatureFetcher, frustum_variance
+from .utils.feature_fetcher import ChannelLast, FeatureFetcher, frustum_variance
 from .utils.torch_utils import get_knn_3d
 
 _HYPOTHESES = (-2, -1, 0, 1, 2)
@@ -383,7 +383,12 @@ class PointMVSNet(nn.Module):
 
     # The four device-only stages of ``run`` (GraphedForward may capture them as separate graphs).
     def run_coarse_tower(self, img_list):
-        return self.coarse_img_conv.forward_views(img_list, need=("conv3",))["conv3"].contiguous()   # (B,V,C,FH,FW)
+        """(B,V,C,FH,FW) coarse features -- or, when the tower's last layer could write them channel-last for the
+        warp, a ``ChannelLast`` wrapper around (B,V,FH,FW,C)."""
+        out = self.coarse_img_conv.forward_views(img_list, need=("conv3",), channel_last=("conv3",))
+        if "conv3_cl" in out:
+            return ChannelLast(out["conv3_cl"].contiguous())
+        return out["conv3"].contiguous()
 
     def run_flow_tower(self, img_list):
         for _ in range(int(os.environ.get("PF_PROBE_REPEAT_TOWER", "0"))):     # critical-path probe (bench only)
@@ -395,7 +400,10 @@ class PointMVSNet(nn.Module):
         ``fork`` (a callable) is invoked right after the warp has been enqueued (see run)."""
         B, D = plan.B, plan.D
         preds = collections.OrderedDict()
-        C, FH, FW = feature_list.shape[2:]
+        if isinstance(feature_list, ChannelLast):
+            FH, FW, C = feature_list.maps.shape[2:]
+        else:
+            C, FH, FW = feature_list.shape[2:]
         # the frustum points (model.py:79-100) are generated inside the fetch+variance kernel
         cost, world_points = frustum_variance(feature_list, plan.d("Kinv0"), plan.d("Rinv0"), plan.d("t0"),
                                               plan.d("depths"), plan.d("K_coarse"), plan.d("ext"))

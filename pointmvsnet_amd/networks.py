@@ -223,13 +223,15 @@ class ImageConv(nn.Module):
             out[name] = x
         return out
 
-    def forward_views(self, img_list, need=("conv1", "conv2", "conv3")):
+    def forward_views(self, img_list, need=("conv1", "conv2", "conv3"), channel_last=()):
         """Inference fast path: all V views of (B,V,3,H,W) in ONE pass through the tower with per-view
         BatchNorm statistics -- numerically the reference's V separate calls (model.py:71-77).  Each layer is
         one pf_conv2d_f32 launch (previous BatchNorm+ReLU applied while staging, this layer's statistics in
         the epilogue) plus the finalize; only the stage outputs in ``need`` ((B,V,c,h,w); the coarse tower
         needs "conv3" alone) are materialised, every other BatchNorm+ReLU stays an affine row pair that the
-        next convolution applies while staging -- "conv0" is never returned."""
+        next convolution applies while staging -- "conv0" is never returned.  Stage names in ``channel_last`` come
+        back as (B,V,h,w,c) under the key name + "_cl" when the stage's last layer is a plain convolution on the
+        wide kernel (the coarse tower's "conv3" feeds the channel-last warp: no transposition pass), else as usual."""
         B, V = img_list.shape[:2]
         x = img_list.transpose(0, 1).reshape(V * B, *img_list.shape[2:]).float().contiguous()   # view-major
         pending = None                      # (scale, shift) of a BatchNorm+ReLU not yet applied to x
@@ -245,13 +247,16 @@ class ImageConv(nn.Module):
                 (pointflow.conv2d_preferred(nconv) or pointflow.conv2d_small_preferred(nconv)
                  or pointflow.conv2d_wide_preferred(nconv))
             lazy = bool(defer) and pointflow.conv2d_wide_preferred(nconv)   # the next conv resolves this BatchNorm
-            x, pending = _conv2d_block_fused(block, x, pending, B, defer, lazy)
+            conv = block.conv if hasattr(block, "bn") else block
+            cl = (wanted and name in channel_last and not hasattr(block, "bn") and conv.out_channels >= 32
+                  and pointflow.conv2d_wide_preferred(conv) and bool(pointflow.TOWER_CL_OUT))
+            x, pending = _conv2d_block_fused(block, x, pending, B, defer, lazy, channel_last_out=cl)
             if wanted:
-                out[name] = x.view(V, B, *x.shape[1:]).transpose(0, 1)
+                out[name + "_cl" if cl else name] = x.view(V, B, *x.shape[1:]).transpose(0, 1)
         return out
 
 
-def _conv2d_block_fused(block, x, pending, samples_per_stat, defer, lazy=False):
+def _conv2d_block_fused(block, x, pending, samples_per_stat, defer, lazy=False, channel_last_out=False):
     """One tower block.  ``pending``: BN+ReLU affine rows not yet applied to x.  Returns (y, pending'): with
     ``defer`` the block's own BatchNorm+ReLU is returned as affine rows for the next (custom) conv to apply
     while staging; otherwise y is normalised in place (statistics + fused finalize/normalise)."""
@@ -263,7 +268,7 @@ def _conv2d_block_fused(block, x, pending, samples_per_stat, defer, lazy=False):
     if pointflow.conv2d_small_preferred(conv):
         out = pointflow.conv2d_small(x, conv, pending, samples_per_stat, training_bn, bn=tail_bn)
     elif pointflow.conv2d_wide_preferred(conv):
-        out = pointflow.conv2d_wide(x, conv, pending, samples_per_stat, training_bn)
+        out = pointflow.conv2d_wide(x, conv, pending, samples_per_stat, training_bn, channel_last_out=channel_last_out)
     elif pointflow.conv2d_preferred(conv):
         out = pointflow.conv2d(x, conv, pending, samples_per_stat, training_bn, bn=tail_bn)
     else:

@@ -600,6 +600,8 @@ def conv2d(x, conv, in_affine, samples_per_stat, want_stats, bn=None):
 
 
 CONV2D_WIDE = int(_os.environ.get("PF_CONV2D_WIDE", "1"))     # 0: 64-channel tower layers on the library convolution
+# PF_TOWER_CL_OUT=0: the coarse tower's last layer writes NCHW and pf_nchw_to_nhwc_f32 transposes it for the warp
+TOWER_CL_OUT = int(_os.environ.get("PF_TOWER_CL_OUT", "1"))
 # smallest C_out that goes to pf_conv2d_wide_f32: 8 = every tower layer (default; equal to 16 within noise, but the
 # 8-channel layers then resolve their input BatchNorm themselves); 16: the 8-channel layers on the FMA kernel
 # (conv2d_small.hip); 32: the 16-channel layers on pf_conv2d_f32 as well (-2 %)
@@ -636,23 +638,23 @@ def pack_conv2d_wide_weight(weight):
     return _cached_pack(("c2w", id(weight)), (weight,), make)
 
 
-def conv2d_wide(x, conv, in_affine, samples_per_stat, want_stats):
+def conv2d_wide(x, conv, in_affine, samples_per_stat, want_stats, channel_last_out=False):
     """pf_conv2d_wide_f32: same contract as ``conv2d`` (raw y, statistics partials or None); ``in_affine`` may be
-    a LazyAffine (resolved by the launch's own blocks)."""
+    a LazyAffine (resolved by the launch's own blocks).  ``channel_last_out``: y is (N, Ho, Wo, Cout)."""
     N, Cin, Hi, Wi = x.shape
     Cout = conv.out_channels
     ks, stride = conv.kernel_size[0], conv.stride[0]
     Ho, Wo = (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
     wp = pack_conv2d_wide_weight(conv.weight)
-    y = torch.empty((N, Cout, Ho, Wo), dtype=_F32, device=x.device)
+    y = torch.empty((N, Ho, Wo, Cout) if channel_last_out else (N, Cout, Ho, Wo), dtype=_F32, device=x.device)
     partials = None
     if want_stats:
         T = int(_lib.load().pf_conv2d_wide_blocks(Cout, Hi, Wi, int(stride)))
         partials = stat_rows(N, T, Cout, x.device, False)
     sc, sh, in_bn = _split_affine(in_affine)
     _lib.call("pf_conv2d_wide_f32", _lib.ptr(x), _lib.ptr(wp), _lib.ptr(y), N, Cin, Cout, Hi, Wi, int(ks), int(stride),
-              _lib.ptr(sc), _lib.ptr(sh), in_bn, int(samples_per_stat), _lib.ptr(partials), _lib.stream(),
-              algo_bytes=4.0 * N * (Cin * Hi * Wi + Cout * Ho * Wo) + 4.0 * ks * ks * Cin * Cout,
+              _lib.ptr(sc), _lib.ptr(sh), in_bn, int(samples_per_stat), _lib.ptr(partials), int(bool(channel_last_out)),
+              _lib.stream(), algo_bytes=4.0 * N * (Cin * Hi * Wi + Cout * Ho * Wo) + 4.0 * ks * ks * Cin * Cout,
               flops=2.0 * N * Ho * Wo * ks * ks * Cin * Cout)
     return y, partials
 

@@ -87,6 +87,13 @@ import os as _os
 FETCH_CL = int(_os.environ.get("PF_FETCH_CL", "1"))
 
 
+class ChannelLast(object):
+    """Feature maps that already are channel-last: ``maps`` is (B, V, H, W, C) contiguous float32."""
+
+    def __init__(self, maps):
+        self.maps = maps
+
+
 def to_channel_last(maps):
     """(..., C, H, W) contiguous -> (..., H, W, C) contiguous (pf_nchw_to_nhwc_f32)."""
     C, H, W = maps.shape[-3:]
@@ -104,9 +111,16 @@ def frustum_variance(feature_maps, kinv, rinv, t, depths, cam_intrinsics, cam_ex
     points of the reference view's depth hypotheses are generated inside the fetch+variance kernel
     (pf_frustum_variance_f32).  kinv/rinv (B,3,3), t (B,3), depths (B,D) float32 on the device.
     Returns (cost (B,C,D*H*W), world_points (B,3,D*H*W) or None)."""
-    _lib.require_gpu(feature_maps, kinv, rinv, t, depths, cam_intrinsics, cam_extrinsics)
-    maps = feature_maps.detach().float().contiguous()
-    B, V, C, H, W = maps.shape
+    maps_cl = None
+    if isinstance(feature_maps, ChannelLast):                 # produced channel-last by the tower's last layer
+        maps_cl = feature_maps.maps.detach().float().contiguous()
+        _lib.require_gpu(maps_cl, kinv, rinv, t, depths, cam_intrinsics, cam_extrinsics)
+        B, V, H, W, C = maps_cl.shape
+        maps, channel_last = maps_cl, True
+    else:
+        _lib.require_gpu(feature_maps, kinv, rinv, t, depths, cam_intrinsics, cam_extrinsics)
+        maps = feature_maps.detach().float().contiguous()
+        B, V, C, H, W = maps.shape
     D = depths.shape[-1]
     kinv = kinv.detach().float().reshape(B, 9).contiguous()
     rinv = rinv.detach().float().reshape(B, 9).contiguous()
@@ -120,7 +134,8 @@ def frustum_variance(feature_maps, kinv, rinv, t, depths, cam_intrinsics, cam_ex
     if channel_last is None:
         channel_last = bool(FETCH_CL) and C % 4 == 0
     if channel_last:
-        maps_cl = to_channel_last(maps)
+        if maps_cl is None:
+            maps_cl = to_channel_last(maps)
         with torch.cuda.device(maps.device):
             _lib.call("pf_frustum_variance_cl_f32", _lib.ptr(maps_cl), _lib.ptr(kinv), _lib.ptr(rinv), _lib.ptr(t),
                       _lib.ptr(depths), _lib.ptr(K), _lib.ptr(E), _lib.ptr(out), _lib.ptr(world), B, V, C, H, W, D,

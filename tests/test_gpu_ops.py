@@ -695,6 +695,10 @@ def test_conv2d_wide_vs_fp64(dev, N, Cin, Cout, H, W, ks, stride, affine):
     assert torch.allclose(sums[..., 1], (ref ** 2).sum(dim=(2, 3)), rtol=1e-5)
     y2, none = pointflow.conv2d_wide(x.to(dev), conv, aff, 1, False)
     assert none is None and torch.equal(y2, y)                           # deterministic
+    if Cout >= 32:                                                       # channel-last output: the same numbers
+        ycl, pcl = pointflow.conv2d_wide(x.to(dev), conv, aff, 1, True, channel_last_out=True)
+        assert ycl.shape == (N, y.shape[2], y.shape[3], Cout)
+        assert torch.equal(ycl.permute(0, 3, 1, 2), y) and torch.equal(pcl, part)
     assert _lib.status() == 0
 
 
