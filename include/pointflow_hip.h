@@ -315,10 +315,14 @@ int pf_channel_bn_fused_f32(const float* x, float* y, int64_t N, int64_t C, int6
  * wp = weights packed on the host as (Cin/4, 27 taps [kd][kh][kw], 4, 16*ceil(Cout/16)), zero padded:
  * wp[g][tap][k][co] = W[co][4g+k][kd][kh][kw];  y (N,Cout,Do,Ho,Wo).
  * partials (N, pf_conv3d_blocks(...), Cout, 2) float64 or NULL receives the per-block (sum, sum of
- * squares) of y per channel -- the BatchNorm batch statistics for free. */
+ * squares) of y per channel -- the BatchNorm batch statistics for free.
+ * in_scale / in_shift (N / samples_per_stat, Cin) or in_bn: the pending BatchNorm + ReLU of x, applied while a
+ * channel is staged (zero padding after it) -- rows, or resolved by the launch itself ("the finalize folded into
+ * the consumer" above); all NULL: x is taken as it is. */
 int pf_conv3d_blocks(int64_t Cin, int64_t Cout, int64_t Di, int64_t Hi, int64_t Wi, int stride);
 int pf_conv3d_k3_f32(const float* x, const float* wp, float* y, int64_t N, int64_t Cin, int64_t Cout, int64_t Di,
-                     int64_t Hi, int64_t Wi, int stride, double* partials, void* stream);
+                     int64_t Hi, int64_t Wi, int stride, const float* in_scale, const float* in_shift,
+                     const pf_bn_job* in_bn, int samples_per_stat, double* partials, void* stream);
 /* The same convolution for stride 1 and Cout <= 8 (VolumeConv's conv0_1, networks.py:136: 64 -> 8 on the full cost
  * volume) without the half-empty 16-wide tile: N = 8 channels x 2 adjacent output rows, which read the same four
  * input rows, so K = 36 taps instead of 27 and 1.5x fewer MFMA cycles.  wp = weights packed as

@@ -52,7 +52,8 @@ PROTOTYPES = {
     "pf_pointwise_gemm_f32": ([_vp, _i, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, ctypes.POINTER(BnJob), _i,
                                _vp, ctypes.POINTER(BnJob), _i, _vp, _vp], _i),
     "pf_conv3d_blocks": ([_i64, _i64, _i64, _i64, _i64, _i], _i),
-    "pf_conv3d_k3_f32": ([_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i, _vp, _vp], _i),
+    "pf_conv3d_k3_f32": ([_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i, _vp, _vp, ctypes.POINTER(BnJob), _i,
+                          _vp, _vp], _i),
     "pf_conv3d_pair_blocks": ([_i64, _i64, _i64, _i64, _i64], _i),
     "pf_conv3d_k3_pair_f32": ([_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp], _i),
     "pf_conv3d_k3_few_f32": ([_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp], _i),

@@ -31,6 +31,7 @@
 #include <stdlib.h>
 
 #include "pf_common.h"
+#include "pf_bn_tail.h"
 
 namespace {
 
@@ -40,6 +41,13 @@ struct ConvGeom {
   int Cin, Cout, Di, Hi, Wi, Do, Ho, Wo;
   int ID, IH, IW, IWP, plane;   // staged sub-volume: depth, height, width, padded row, padded channel stride
   int tiles_d, tiles_h, tiles_w;
+  // the pending BatchNorm + ReLU of the INPUT, applied while a channel is staged (zero padding after it):
+  // aff_mode 0 = none, 1 = (scale, shift) rows (N / sps, Cin), 2 = resolved by every block from the producer's
+  // statistics rows (pf_bn_resolve, pf_bn_tail.h).  aff_off: float offset of the 2 * Cin affine values in LDS.
+  int aff_mode, sps, aff_off;
+  const float* in_scale;
+  const float* in_shift;
+  pf_bn_job in_bn;
 };
 
 // Staged sub-volume of one input channel for a TD x 4 x 16 output tile: compile-time so that every LDS
@@ -92,6 +100,15 @@ __global__ __launch_bounds__(256, MINW) void conv3d_k3_kernel(const float* __res
 #pragma unroll
   for (int t = 0; t < NT; ++t) ssum[t] = ssq[t] = 0.0;
 
+  float* aff = lds + g.aff_off;                      // [scale Cin | shift Cin] of the input's pending BatchNorm
+  if (g.aff_mode == 1) {
+    const int stat = n / g.sps;
+    for (int e = tid; e < 2 * g.Cin; e += 256)
+      aff[e] = e < g.Cin ? g.in_scale[(int64_t)stat * g.Cin + e] : g.in_shift[(int64_t)stat * g.Cin + e - g.Cin];
+  } else if (g.aff_mode == 2) {
+    pf_bn_resolve<256>(g.in_bn, n / g.sps, aff, aff + g.Cin, reinterpret_cast<double*>(lds));
+  }
+
   const int total = g.tiles_d * g.tiles_h * g.tiles_w;
   for (int item = blockIdx.x; item < total; item += gridDim.x) {
     const int tw = item % g.tiles_w;
@@ -129,13 +146,20 @@ __global__ __launch_bounds__(256, MINW) void conv3d_k3_kernel(const float* __res
         rw[r] = (256 * (r + 1) <= WSZ || e < WSZ) ? wsrc[e] : 0.0f;
       }
     };
-    auto store_group = [&](int buf) {
+    auto store_group = [&](int buf, int cg) {
       float* xs = xs0 + buf * XS + wave * PLANE;
       float* ws = ws0 + buf * WSZ;
+      float sa = 1.0f, sb = 0.0f;
+      if (g.aff_mode) {                                // wave-uniform: this wave stages channel 4 cg + wave
+        sa = aff[cg * 4 + wave];
+        sb = aff[g.Cin + cg * 4 + wave];
+      }
 #pragma unroll
       for (int r = 0; r < NXR; ++r) {
         const int e = lane + 64 * r;
-        if (64 * (r + 1) <= ELEMS || e < ELEMS) xs[e + e / IW] = ((okmask >> r) & 1u) ? rx[r] : 0.0f;
+        float v = rx[r];
+        if (g.aff_mode) v = fmaxf(fmaf(v, sa, sb), 0.0f);
+        if (64 * (r + 1) <= ELEMS || e < ELEMS) xs[e + e / IW] = ((okmask >> r) & 1u) ? v : 0.0f;
       }
 #pragma unroll
       for (int r = 0; r < NWR; ++r) {
@@ -152,7 +176,7 @@ __global__ __launch_bounds__(256, MINW) void conv3d_k3_kernel(const float* __res
 
     __syncthreads();                       // the previous tile's epilogue / last group has been consumed
     load_group(0);
-    store_group(0);
+    store_group(0, 0);
     __syncthreads();
     for (int cg = 0; cg < cgroups; ++cg) {
       const int buf = cg & 1;
@@ -178,7 +202,7 @@ __global__ __launch_bounds__(256, MINW) void conv3d_k3_kernel(const float* __res
           }
         }
       }
-      if (cg + 1 < cgroups) store_group(buf ^ 1);
+      if (cg + 1 < cgroups) store_group(buf ^ 1, cg + 1);
       __syncthreads();
     }
 
@@ -313,16 +337,25 @@ ConvGeom make_geom(int64_t Cin, int64_t Cout, int64_t Di, int64_t Hi, int64_t Wi
   g.tiles_d = (g.Do + td - 1) / td;
   g.tiles_h = (g.Ho + 3) / 4;
   g.tiles_w = (g.Wo + 15) / 16;
+  g.aff_mode = 0;
+  g.sps = 1;
+  g.aff_off = 0;
+  g.in_scale = g.in_shift = nullptr;
+  g.in_bn = pf_bn_job{};
   return g;
 }
 
 constexpr size_t kMaxLds = 80 * 1024;    // two blocks per CU still fit in the 160 KiB of a CU
 
-size_t lds_bytes_for(const ConvGeom& g, int NT) {
+size_t lds_work_bytes(const ConvGeom& g, int NT) {
   const int NCP = NT * 16;
   const size_t staging = sizeof(float) * (size_t)(2 * 4 * g.plane + 2 * 27 * 4 * NCP);
   const size_t epilogue = sizeof(float) * (size_t)(4 * NCP * 17 + 1) + sizeof(double) * (size_t)(4 * NCP * 2);
-  return staging > epilogue ? staging : epilogue;
+  const size_t m = staging > epilogue ? staging : epilogue;
+  return (m + 15) / 16 * 16;
+}
+size_t lds_bytes_for(const ConvGeom& g, int NT) {      // + the input BatchNorm's [scale | shift] behind the work area
+  return lds_work_bytes(g, NT) + sizeof(float) * 2 * (size_t)g.Cin;
 }
 
 // Tuning hook (microbenchmarks only): PF_CONV3D_VARIANT = 10*TD + MINW forces the tile depth and the
@@ -360,6 +393,8 @@ int launch(const float* x, const float* wp, float* y, const ConvGeom& g, int64_t
            hipStream_t s) {
   const size_t lds_bytes = lds_bytes_for(g, NT);
   if (lds_bytes > kMaxLds) return PF_ERR_UNSUPPORTED;
+  ConvGeom gk = g;
+  gk.aff_off = (int)(lds_work_bytes(g, NT) / sizeof(float));
   if (lds_bytes > 64 * 1024) {           // opt in to more than the default 64 KiB of dynamic LDS (160 KiB per CU)
     static std::atomic<unsigned long long> done{0};   // per instantiation, one bit per device
     const int rc = pf_allow_big_lds(reinterpret_cast<const void*>(&conv3d_k3_kernel<NT, STRIDE, TD, MINW>),
@@ -367,7 +402,7 @@ int launch(const float* x, const float* wp, float* y, const ConvGeom& g, int64_t
     if (rc != PF_OK) return rc;
   }
   dim3 grid((unsigned)blocks_for(g), (unsigned)N);
-  hipLaunchKernelGGL((conv3d_k3_kernel<NT, STRIDE, TD, MINW>), grid, dim3(256), lds_bytes, s, x, wp, y, g, partials);
+  hipLaunchKernelGGL((conv3d_k3_kernel<NT, STRIDE, TD, MINW>), grid, dim3(256), lds_bytes, s, x, wp, y, gk, partials);
   return pf_launch_status();
 }
 
@@ -408,16 +443,29 @@ int pf_conv3d_blocks(int64_t Cin, int64_t Cout, int64_t Di, int64_t Hi, int64_t 
 }
 
 int pf_conv3d_k3_f32(const float* x, const float* wp, float* y, int64_t N, int64_t Cin, int64_t Cout, int64_t Di,
-                     int64_t Hi, int64_t Wi, int stride, double* partials, void* stream) {
+                     int64_t Hi, int64_t Wi, int stride, const float* in_scale, const float* in_shift,
+                     const pf_bn_job* in_bn, int samples_per_stat, double* partials, void* stream) {
   PF_REQUIRE(N >= 0 && Cin >= 4 && Cout >= 1 && Di >= 1 && Hi >= 1 && Wi >= 1 && N <= 65535);
   PF_REQUIRE(stride == 1 || stride == 2);
+  PF_REQUIRE(samples_per_stat >= 1 && (in_scale == nullptr) == (in_shift == nullptr));
+  PF_REQUIRE(in_bn == nullptr || in_scale == nullptr);
+  if (in_bn != nullptr && N > 0) {
+    PF_REQUIRE(N % samples_per_stat == 0);
+    const int rc = pf_bn_in_check(in_bn, (int)Cin, (int)(N / samples_per_stat));
+    if (rc != PF_OK) return rc;
+  }
   if ((Cin % 4) != 0 || Cout > 32) return PF_ERR_UNSUPPORTED;
   PF_REQUIRE(Cin * Di * Hi * Wi <= INT32_MAX);
   if (N == 0) return PF_OK;
   PF_REQUIRE(x && wp && y);
   const int td = pick_td(Cin, Cout, Di, Hi, Wi, stride);
   if (td == 0) return PF_ERR_UNSUPPORTED;
-  const ConvGeom g = make_geom(Cin, Cout, Di, Hi, Wi, stride, td);
+  ConvGeom g = make_geom(Cin, Cout, Di, Hi, Wi, stride, td);
+  g.aff_mode = in_bn ? 2 : (in_scale ? 1 : 0);
+  g.sps = samples_per_stat;
+  g.in_scale = in_scale;
+  g.in_shift = in_shift;
+  if (in_bn) g.in_bn = *in_bn;
   hipStream_t s = (hipStream_t)stream;
   const int NT = (int)((Cout + 15) / 16);
   if (stride == 1)

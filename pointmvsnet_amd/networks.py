@@ -317,6 +317,25 @@ class VolumeConv(nn.Module):
                 and pointflow.conv3d_bottom_supported(self.conv3_1.conv)
                 and pointflow.deconv3d_bottom_supported(self.conv4_0.conv))
 
+    def _encoder_lazy(self, x):
+        if not int(_os.environ.get("PF_VC_LAZY", "0")) or not self._bottom_fusable():
+            return False
+        blocks = (self.conv1_0, self.conv2_0, self.conv1_1, self.conv2_1)
+        if not all(b.bn is not None and b.relu and (b.bn.training or not b.bn.track_running_stats) for b in blocks):
+            return False
+        D, H, W = x.shape[2:]
+        h = ((D - 1) // 2 + 1, (H - 1) // 2 + 1, (W - 1) // 2 + 1)
+        q = ((h[0] - 1) // 2 + 1, (h[1] - 1) // 2 + 1, (h[2] - 1) // 2 + 1)
+
+        def ok(conv, vol):
+            out = vol if conv.stride == (1, 1, 1) else tuple((v - 1) // 2 + 1 for v in vol)
+            return (type(conv) is nn.Conv3d and conv.kernel_size == (3, 3, 3) and conv.padding == (1, 1, 1)
+                    and conv.stride in ((1, 1, 1), (2, 2, 2)) and conv.dilation == (1, 1, 1) and conv.groups == 1
+                    and conv.bias is None and conv.in_channels % 4 == 0 and 8 < conv.out_channels <= 32
+                    and out[0] * out[1] * out[2] >= 2048)
+        return (ok(self.conv1_0.conv, (D, H, W)) and ok(self.conv2_0.conv, h) and ok(self.conv1_1.conv, h)
+                and ok(self.conv2_1.conv, q))
+
     def forward_fused(self, x):
         """Inference fast path: own conv / deconv kernels + HIP BatchNorm/ReLU kernels (statistics pooled over the
         batch); the library convolution only for shapes none of the kernels is built for."""
@@ -343,13 +362,27 @@ class VolumeConv(nn.Module):
             else:
                 full = f(blk, x)
         pointflow.stamp("conv0_1_end")
-        half = f(self.conv1_0, x)
-        quarter = f(self.conv2_0, half)
+        # Encoder with its BatchNorms left PENDING: conv1_0 / conv2_0 write raw outputs, and each of their consumers
+        # (conv2_0, conv1_1 / conv3_0, conv2_1) applies -- and with few statistics rows finalizes -- that BatchNorm +
+        # ReLU while staging: two normalise passes (and their graph nodes) less on the chain.  Measured equal
+        # (659 / 657 / 660 vs 659 / 659 depth maps/s, profiles/r02aj_small_ab.txt: four consumers pay the resolve,
+        # and the chain runs beside the flow tower), so it is OFF by default: PF_VC_LAZY=1 turns it on.
+        lazy_enc = self._encoder_lazy(x)
+        a_half = a_quarter = None
+        if lazy_enc:
+            half, p_half = pointflow.conv3d_k3(x.contiguous(), self.conv1_0.conv.weight, 2, True)
+            a_half = pointflow.bn_affine_rows(half, self.conv1_0.bn, B, p_half, lazy=True)
+            quarter, p_quarter = pointflow.conv3d_k3(half, self.conv2_0.conv.weight, 2, True, in_affine=a_half,
+                                                     samples_per_stat=B)
+            a_quarter = pointflow.bn_affine_rows(quarter, self.conv2_0.bn, B, p_quarter, lazy=True)
+        else:
+            half = f(self.conv1_0, x)
+            quarter = f(self.conv2_0, half)
         # The skip branches conv1_1 / conv2_1 (+ their BatchNorms) are needed only by the decoder: with
         # PF_VC_SIDE=1 they run on an auxiliary stream beside the bottom of the U-Net (dependent chain of small,
         # latency-bound kernels: conv3_0, conv3_1, conv4_0)
         side = None
-        if int(_os.environ.get("PF_VC_SIDE", "0")):
+        if int(_os.environ.get("PF_VC_SIDE", "0")) and not lazy_enc:
             main = torch.cuda.current_stream()
             side = pointflow.side_stream(x.device, 3)
             side.wait_stream(main)
@@ -362,7 +395,7 @@ class VolumeConv(nn.Module):
             # the three smallest layers, one launch each (csrc/conv3d_bottom.hip): every BatchNorm + ReLU between
             # them is applied -- and, with few statistics rows, finalized -- by the NEXT layer while it stages
             b0, b1, b2 = self.conv3_0, self.conv3_1, self.conv4_0
-            y0, p0 = pointflow.conv3d_bottom(quarter.contiguous(), b0.conv, None, B, True)
+            y0, p0 = pointflow.conv3d_bottom(quarter.contiguous(), b0.conv, a_quarter, B, True)
             a0 = pointflow.bn_affine_rows(y0, b0.bn, B, p0, lazy=True)
             y1, p1 = pointflow.conv3d_bottom(y0, b1.conv, a0, B, True)
             a1 = pointflow.bn_affine_rows(y1, b1.bn, B, p1, lazy=True)
@@ -377,6 +410,12 @@ class VolumeConv(nn.Module):
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
             half, quarter = half_s, quarter_s
+        elif lazy_enc:
+            y, p = pointflow.conv3d_k3(half, self.conv1_1.conv.weight, 1, True, in_affine=a_half, samples_per_stat=B)
+            half = pointflow.batch_norm_act_(y, self.conv1_1.bn, self.conv1_1.relu, B, partials=p)
+            y, p = pointflow.conv3d_k3(quarter, self.conv2_1.conv.weight, 1, True, in_affine=a_quarter,
+                                       samples_per_stat=B)
+            quarter = pointflow.batch_norm_act_(y, self.conv2_1.bn, self.conv2_1.relu, B, partials=p)
         else:
             half = f(self.conv1_1, half)
             quarter = f(self.conv2_1, quarter)

@@ -424,12 +424,13 @@ def pack_conv3d_weight_pair(weight):
     return _cached_pack(("c3p", id(weight)), (weight,), make)
 
 
-def conv3d_k3(x, weight, stride, want_stats):
+def conv3d_k3(x, weight, stride, want_stats, in_affine=None, samples_per_stat=1):
     """3x3x3 / pad 1 conv3d on the f32 matrix cores (pf_conv3d_k3_f32; stride 1 with <= 8 output channels:
-    pf_conv3d_k3_pair_f32).  Returns (y, partials or None)."""
+    pf_conv3d_k3_pair_f32).  ``in_affine``: the pending BatchNorm + ReLU of x -- (scale, shift) rows
+    (N/samples_per_stat, Cin) or a LazyAffine -- applied while x is staged.  Returns (y, partials or None)."""
     N, Cin, Di, Hi, Wi = x.shape
     Cout = weight.shape[0]
-    if CONV3D_PAIR and stride == 1 and Cout <= 8 and Cin % 4 == 0:
+    if CONV3D_PAIR and stride == 1 and Cout <= 8 and Cin % 4 == 0 and in_affine is None:
         wp = pack_conv3d_weight_pair(weight)
         y = torch.empty((N, Cout, Di, Hi, Wi), dtype=_F32, device=x.device)
         partials = None
@@ -448,8 +449,9 @@ def conv3d_k3(x, weight, stride, want_stats):
     if want_stats:
         T = int(_lib.load().pf_conv3d_blocks(Cin, Cout, Di, Hi, Wi, int(stride)))
         partials = torch.empty((N, T, Cout, 2), dtype=torch.float64, device=x.device)
+    sc, sh, in_bn = _split_affine(in_affine)
     _lib.call("pf_conv3d_k3_f32", _lib.ptr(x), _lib.ptr(wp), _lib.ptr(y), N, Cin, Cout, Di, Hi, Wi, int(stride),
-              _lib.ptr(partials), _lib.stream(),
+              _lib.ptr(sc), _lib.ptr(sh), in_bn, int(samples_per_stat), _lib.ptr(partials), _lib.stream(),
               algo_bytes=4.0 * N * (Cin * Di * Hi * Wi + Cout * Do * Ho * Wo) + 4.0 * 27 * Cin * Cout,
               flops=2.0 * N * Do * Ho * Wo * 27 * Cin * Cout)
     return y, partials

@@ -1233,3 +1233,45 @@ def test_deconv3d_bottom_vs_fp64(dev, N, D, H, W, affine):
     y2, none = pointflow.deconv3d_bottom(x.to(dev), conv, aff, N, False)
     assert none is None and torch.equal(y2, y)
     assert _lib.status() == 0
+
+
+@pytest.mark.parametrize("N,Cin,Cout,stride,D,H,W", [(1, 16, 32, 2, 24, 32, 40), (2, 16, 16, 1, 7, 9, 21), (1, 32, 32, 1, 12, 16, 20)])
+@pytest.mark.parametrize("affine", ["rows", "lazy"])
+def test_conv3d_k3_applies_pending_batchnorm_while_staging(dev, N, Cin, Cout, stride, D, H, W, affine):
+    """pf_conv3d_k3_f32 with the input's BatchNorm + ReLU pending (rows, or resolved by the launch from statistics
+    rows) against BatchNorm -> ReLU -> float64 convolution; zero padding applies AFTER the activation."""
+    gen = torch.Generator().manual_seed(N + Cin + Cout + D * H * W)
+    w = torch.randn(Cout, Cin, 3, 3, 3, generator=gen) / (27 * Cin) ** 0.5
+    x = torch.randn(N, Cin, D, H, W, generator=gen)
+    xd = x.to(dev)
+    if affine == "rows":
+        sc = torch.rand(1, Cin, generator=gen) + 0.5
+        sh = torch.randn(1, Cin, generator=gen) * 0.3
+        xin = torch.relu(x.double() * sc.double().view(1, Cin, 1, 1, 1) + sh.double().view(1, Cin, 1, 1, 1))
+        aff = (sc.to(dev), sh.to(dev))
+    else:
+        bn = torch.nn.BatchNorm3d(Cin).to(dev).train()
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(0.5, 1.5, Cin))
+            bn.bias.copy_(torch.linspace(-0.3, 0.3, Cin))
+        T = 5
+        part = torch.zeros((N, T, Cin, 2), dtype=torch.float64, device=dev)
+        for t, ch in enumerate(torch.chunk(xd.double().reshape(N, Cin, -1), T, dim=2)):
+            part[:, t, :, 0] = ch.sum(dim=2)
+            part[:, t, :, 1] = (ch * ch).sum(dim=2)
+        aff = pointflow.bn_affine_rows(xd, bn, N, part, lazy=True)
+        assert isinstance(aff, pointflow.LazyAffine)
+        xin = torch.relu(F.batch_norm(x.double(), None, None, bn.weight.double().cpu(), bn.bias.double().cpu(), True, 0.0,
+                                      bn.eps))
+    ref = F.conv3d(xin, w.double(), None, stride, 1)
+    y, part_y = pointflow.conv3d_k3(xd, w.to(dev), stride, True, in_affine=aff, samples_per_stat=N)
+    scale = float(ref.abs().max())
+    err = _maxabs(y, ref)
+    report("conv3d_k3_affine_%d_%d_s%d_%s" % (Cin, Cout, stride, affine), err=err, scale=scale)
+    assert err < (2e-5 if affine == "lazy" else 4e-6) * scale * max(1.0, (27 * Cin / 256.0) ** 0.5)
+    sums = part_y.sum(dim=1).cpu()
+    assert torch.allclose(sums[..., 0], ref.sum(dim=(2, 3, 4)), rtol=1e-4, atol=2e-4 * scale * ref[0, 0].numel() ** 0.5)
+    y_plain, _ = pointflow.conv3d_k3(xd, w.to(dev), stride, False)          # no affine: the plain convolution still
+    assert _maxabs(y_plain, F.conv3d(x.double(), w.double(), None, stride, 1)) < 4e-6 * scale * max(1.0, (27 * Cin / 256.0) ** 0.5) * 3
+    pointflow.flush_counters()
+    assert _lib.status() == 0
