@@ -340,10 +340,13 @@ int pf_conv3d_k3_few_f32(const float* x, const float* w, float* y, int64_t N, in
  * networks.py:141-143 via nn/conv.py:189-216): y (N, Cout, 2D, 2H, 2W) from xa (+ xb when not NULL: the
  * decoder's skip add, networks.py:163-165) (N, Cin, D, H, W) and w (Cin, Cout, 3, 3, 3) in
  * nn.ConvTranspose3d's own layout.  partials != NULL: float64 (sum, sum of squares) per (sample, block,
- * channel), (N, pf_deconv3d_blocks(D, H, W), Cout, 2), the layout pf_channel_bn_apply_f32 consumes. */
+ * channel), (N, pf_deconv3d_blocks(D, H, W), Cout, 2), the layout pf_channel_bn_apply_f32 consumes.  * in_scale / in_shift (N / samples_per_stat, Cin) or in_bn: the pending BatchNorm + ReLU of xa (the previous
+ * layer's raw output; Cin <= 64), applied to every loaded value BEFORE the skip add -- rows, or resolved by the
+ * launch itself; all NULL: xa is taken as it is. */
 int pf_deconv3d_blocks(int64_t D, int64_t H, int64_t W);
 int pf_deconv3d_k3s2_f32(const float* xa, const float* xb, const float* w, float* y, int64_t N, int64_t Cin,
-                         int64_t Cout, int64_t D, int64_t H, int64_t W, double* partials, void* stream);
+                         int64_t Cout, int64_t D, int64_t H, int64_t W, const float* in_scale, const float* in_shift,
+                         const pf_bn_job* in_bn, int samples_per_stat, double* partials, void* stream);
 
 /* ---- ImageConv: conv2d on the f32 matrix cores ------------------------
  * Replaces the nn.Conv2d of the Conv2d blocks of reference networks.py:89-110 (nn/conv.py:62-77) for the

@@ -58,7 +58,8 @@ PROTOTYPES = {
     "pf_conv3d_k3_pair_f32": ([_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp], _i),
     "pf_conv3d_k3_few_f32": ([_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp], _i),
     "pf_deconv3d_blocks": ([_i64, _i64, _i64], _i),
-    "pf_deconv3d_k3s2_f32": ([_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp], _i),
+    "pf_deconv3d_k3s2_f32": ([_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, ctypes.POINTER(BnJob), _i,
+                              _vp, _vp], _i),
     "pf_conv3d_bottom_supported": ([_i64, _i64, _i], _i),
     "pf_conv3d_bottom_blocks": ([_i64, _i64, _i64, _i], _i),
     "pf_conv3d_bottom_f32": ([_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i, _vp, _vp, ctypes.POINTER(BnJob), _i,

@@ -16,19 +16,41 @@
 // stores two adjacent floats per output row.
 // Bound: latency / issue (tiny); algorithmic bytes 4*(Cin*vol*(1 or 2) + Cout*8*vol).
 #include "pf_common.h"
+#include "pf_bn_tail.h"
 
 namespace {
 
 constexpr int kDcThreads = 128;
 constexpr int kDcUnroll = 8;      // input channels whose loads are issued together
 
+// The pending BatchNorm + ReLU of xa (the previous decoder layer's raw output), applied to every loaded value BEFORE
+// the skip add: mode 0 none, 1 rows (N / sps, Cin), 2 resolved by the block from the producer's statistics rows.
+struct DcAffine {
+  int mode, sps;
+  const float* scale;
+  const float* shift;
+  pf_bn_job bn;
+};
+constexpr int kDcAffMax = 64;       // input channels with a pending BatchNorm
+
 template <int CG, bool ADD, int U>
 __global__ __launch_bounds__(kDcThreads) void deconv3d_k3s2_kernel(const float* __restrict__ xa,
                                                                    const float* __restrict__ xb,
                                                                    const float* __restrict__ w,
                                                                    float* __restrict__ y, int Cin, int Cout, int D,
-                                                                   int H, int W, double* __restrict__ partials) {
+                                                                   int H, int W, double* __restrict__ partials,
+                                                                   DcAffine A) {
   __shared__ double red[kDcThreads / 64][2 * CG];
+  __shared__ float aff[2 * kDcAffMax];
+  __shared__ double aff_red[2 * kDcThreads];
+  if (A.mode == 1) {
+    const int stat = blockIdx.z / A.sps;
+    for (int e = threadIdx.x; e < 2 * Cin; e += kDcThreads)
+      aff[e < Cin ? e : kDcAffMax + e - Cin] = e < Cin ? A.scale[(int64_t)stat * Cin + e] : A.shift[(int64_t)stat * Cin + e - Cin];
+    __syncthreads();
+  } else if (A.mode == 2) {
+    pf_bn_resolve<kDcThreads>(A.bn, blockIdx.z / A.sps, aff, aff + kDcAffMax, aff_red);
+  }
   const int tid = threadIdx.x;
   const int co0 = blockIdx.y * CG;
   const int n = blockIdx.z;
@@ -70,6 +92,11 @@ __global__ __launch_bounds__(kDcThreads) void deconv3d_k3s2_kernel(const float* 
       const float* pa = xan + (int64_t)ci * vol;
 #pragma unroll
       for (int s = 0; s < 8; ++s) v[u][s] = pa[off[s]];
+      if (A.mode) {                                               // block-uniform
+        const float sa = aff[ci], sb = aff[kDcAffMax + ci];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) v[u][s] = fmaxf(fmaf(v[u][s], sa, sb), 0.0f);
+      }
       if (ADD) {
         const float* pb = xbn + (int64_t)ci * vol;
 #pragma unroll
@@ -154,14 +181,14 @@ __global__ __launch_bounds__(kDcThreads) void deconv3d_k3s2_kernel(const float* 
 
 template <int CG>
 int launch_dc(const float* xa, const float* xb, const float* w, float* y, int64_t N, int Cin, int Cout, int D, int H,
-              int W, double* partials, hipStream_t s) {
+              int W, double* partials, const DcAffine& A, hipStream_t s) {
   dim3 grid((unsigned)pf_cdiv((int64_t)D * H * W, kDcThreads), (unsigned)(Cout / CG), (unsigned)N);
   if (xb != nullptr)
     hipLaunchKernelGGL((deconv3d_k3s2_kernel<CG, true, kDcUnroll>), grid, dim3(kDcThreads), 0, s, xa, xb, w, y, Cin, Cout, D, H, W,
-                       partials);
+                       partials, A);
   else
     hipLaunchKernelGGL((deconv3d_k3s2_kernel<CG, false, kDcUnroll>), grid, dim3(kDcThreads), 0, s, xa, xb, w, y, Cin, Cout, D, H,
-                       W, partials);
+                       W, partials, A);
   return pf_launch_status();
 }
 
@@ -175,19 +202,35 @@ int pf_deconv3d_blocks(int64_t D, int64_t H, int64_t W) {
 }
 
 int pf_deconv3d_k3s2_f32(const float* xa, const float* xb, const float* w, float* y, int64_t N, int64_t Cin,
-                         int64_t Cout, int64_t D, int64_t H, int64_t W, double* partials, void* stream) {
+                         int64_t Cout, int64_t D, int64_t H, int64_t W, const float* in_scale, const float* in_shift,
+                         const pf_bn_job* in_bn, int samples_per_stat, double* partials, void* stream) {
   PF_REQUIRE(N >= 0 && Cin >= 1 && Cout >= 1 && D >= 1 && H >= 1 && W >= 1 && N <= 65535);
   PF_REQUIRE(Cin * D * H * W <= INT32_MAX && Cout <= 65535 * 4);
+  PF_REQUIRE(samples_per_stat >= 1 && (in_scale == nullptr) == (in_shift == nullptr));
+  PF_REQUIRE(in_bn == nullptr || in_scale == nullptr);
+  if ((in_bn != nullptr || in_scale != nullptr) && Cin > kDcAffMax) return PF_ERR_UNSUPPORTED;
   if (N == 0) return PF_OK;
   PF_REQUIRE(xa && w && y);
+  DcAffine A;
+  A.mode = in_bn ? 2 : (in_scale ? 1 : 0);
+  A.sps = samples_per_stat;
+  A.scale = in_scale;
+  A.shift = in_shift;
+  A.bn = pf_bn_job{};
+  if (in_bn != nullptr) {
+    PF_REQUIRE(N % samples_per_stat == 0);
+    const int rc = pf_bn_in_check(in_bn, (int)Cin, (int)(N / samples_per_stat));
+    if (rc != PF_OK) return rc;
+    A.bn = *in_bn;
+  }
   hipStream_t s = (hipStream_t)stream;
   // channel group: 4 when that still leaves >= 2 blocks per CU, else 2 / 1 (more, smaller work items)
   const int64_t cell_blocks = pf_cdiv(D * H * W, kDcThreads);
   if ((Cout % 4) == 0 && cell_blocks * (Cout / 4) * N >= 512)
-    return launch_dc<4>(xa, xb, w, y, N, (int)Cin, (int)Cout, (int)D, (int)H, (int)W, partials, s);
+    return launch_dc<4>(xa, xb, w, y, N, (int)Cin, (int)Cout, (int)D, (int)H, (int)W, partials, A, s);
   if ((Cout % 2) == 0 && cell_blocks * (Cout / 2) * N >= 512)
-    return launch_dc<2>(xa, xb, w, y, N, (int)Cin, (int)Cout, (int)D, (int)H, (int)W, partials, s);
-  return launch_dc<1>(xa, xb, w, y, N, (int)Cin, (int)Cout, (int)D, (int)H, (int)W, partials, s);
+    return launch_dc<2>(xa, xb, w, y, N, (int)Cin, (int)Cout, (int)D, (int)H, (int)W, partials, A, s);
+  return launch_dc<1>(xa, xb, w, y, N, (int)Cin, (int)Cout, (int)D, (int)H, (int)W, partials, A, s);
 }
 
 }  // extern "C"

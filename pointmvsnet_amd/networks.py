@@ -140,13 +140,17 @@ class EdgeConvNoC(_EdgeConvBase):
     concat = False
 
 
-def _deconv_fusable(block, x):
-    """pf_deconv3d_k3s2_f32 covers the decoder's ConvTranspose3d blocks; measured policy: from 2048 input
-    cells up (below that the layer is a handful of wavefronts either way and the library GEMM wins)."""
+def _deconv_block_ok(block):
     conv = getattr(block, "conv", None)
     return (type(conv) is nn.ConvTranspose3d and conv.kernel_size == (3, 3, 3) and conv.stride == (2, 2, 2)
             and conv.padding == (1, 1, 1) and conv.output_padding == (1, 1, 1) and conv.dilation == (1, 1, 1)
-            and conv.groups == 1 and conv.bias is None and x[0, 0].numel() >= 2048)
+            and conv.groups == 1 and conv.bias is None)
+
+
+def _deconv_fusable(block, x):
+    """pf_deconv3d_k3s2_f32 covers the decoder's ConvTranspose3d blocks; measured policy: from 2048 input
+    cells up (below that the layer is a handful of wavefronts either way and the library GEMM wins)."""
+    return _deconv_block_ok(block) and x[0, 0].numel() >= 2048
 
 
 def _conv3d_fusable(conv, x):
@@ -336,6 +340,17 @@ class VolumeConv(nn.Module):
         return (ok(self.conv1_0.conv, (D, H, W)) and ok(self.conv2_0.conv, h) and ok(self.conv1_1.conv, h)
                 and ok(self.conv2_1.conv, q))
 
+    def _decoder_lazy(self, x):
+        if not int(_os.environ.get("PF_DEC_LAZY", "0")) or not self._bottom_fusable():
+            return False
+        blocks = (self.conv4_0, self.conv5_0, self.conv6_0)
+        if not all(b.bn is not None and b.relu and (b.bn.training or not b.bn.track_running_stats) for b in blocks):
+            return False
+        D, H, W = x.shape[2:]
+        q = tuple((((v - 1) // 2 + 1) - 1) // 2 + 1 for v in (D, H, W))
+        return (q[0] * q[1] * q[2] >= 2048 and self.conv5_0.conv.in_channels <= 64
+                and self.conv6_0.conv.in_channels <= 64 and all(_deconv_block_ok(b) for b in blocks[1:]))
+
     def forward_fused(self, x):
         """Inference fast path: own conv / deconv kernels + HIP BatchNorm/ReLU kernels (statistics pooled over the
         batch); the library convolution only for shapes none of the kernels is built for."""
@@ -368,7 +383,8 @@ class VolumeConv(nn.Module):
         # (659 / 657 / 660 vs 659 / 659 depth maps/s, profiles/r02aj_small_ab.txt: four consumers pay the resolve,
         # and the chain runs beside the flow tower), so it is OFF by default: PF_VC_LAZY=1 turns it on.
         lazy_enc = self._encoder_lazy(x)
-        a_half = a_quarter = None
+        dec_lazy = self._decoder_lazy(x)
+        a_half = a_quarter = a_up = None
         if lazy_enc:
             half, p_half = pointflow.conv3d_k3(x.contiguous(), self.conv1_0.conv.weight, 2, True)
             a_half = pointflow.bn_affine_rows(half, self.conv1_0.bn, B, p_half, lazy=True)
@@ -401,7 +417,10 @@ class VolumeConv(nn.Module):
             a1 = pointflow.bn_affine_rows(y1, b1.bn, B, p1, lazy=True)
             pointflow.stamp("unet_encoder_end")
             y2, p2 = pointflow.deconv3d_bottom(y1, b2.conv, a1, B, True)
-            up = pointflow.batch_norm_act_(y2, b2.bn, b2.relu, B, partials=p2)
+            if dec_lazy:
+                up, a_up = y2, pointflow.bn_affine_rows(y2, b2.bn, B, p2, lazy=True)   # applied by conv5_0's loads
+            else:
+                up = pointflow.batch_norm_act_(y2, b2.bn, b2.relu, B, partials=p2)
         else:
             eighth = f(self.conv3_1, f(self.conv3_0, quarter))
             pointflow.stamp("unet_encoder_end")
@@ -419,8 +438,20 @@ class VolumeConv(nn.Module):
         else:
             half = f(self.conv1_1, half)
             quarter = f(self.conv2_1, quarter)
-        up = f(self.conv5_0, (up, quarter))
-        up = f(self.conv6_0, (up, half))
+        if dec_lazy:
+            # decoder with the BatchNorms of conv4_0 / conv5_0 pending: the next transposed convolution applies (and
+            # resolves) them on its loads, before the skip add -- two normalise passes and graph nodes less.  Measured
+            # equal or slightly slower (656.7 / 656.1 vs 657.9 / 661.3 depth maps/s: 960 small blocks each pay the
+            # resolve), so OFF by default (PF_DEC_LAZY=1 turns it on)
+            y5, p5 = pointflow.deconv3d_k3s2(up, quarter.contiguous(), self.conv5_0.conv.weight, True, in_affine=a_up,
+                                             samples_per_stat=B)
+            a5 = pointflow.bn_affine_rows(y5, self.conv5_0.bn, B, p5, lazy=True)
+            y6, p6 = pointflow.deconv3d_k3s2(y5, half.contiguous(), self.conv6_0.conv.weight, True, in_affine=a5,
+                                             samples_per_stat=B)
+            up = pointflow.batch_norm_act_(y6, self.conv6_0.bn, self.conv6_0.relu, B, partials=p6)
+        else:
+            up = f(self.conv5_0, (up, quarter))
+            up = f(self.conv6_0, (up, half))
         if aux is not None:
             torch.cuda.current_stream().wait_stream(aux)
         # (conv6_2 does not add on load: its kernel is bound by its tap loads and adding there doubles them --

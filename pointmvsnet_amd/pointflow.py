@@ -457,9 +457,10 @@ def conv3d_k3(x, weight, stride, want_stats, in_affine=None, samples_per_stat=1)
     return y, partials
 
 
-def deconv3d_k3s2(xa, xb, weight, want_stats):
-    """ConvTranspose3d 3x3x3 / stride 2 / padding 1 / output_padding 1 of ``xa (+ xb)`` (pf_deconv3d_k3s2_f32;
-    weight in nn.ConvTranspose3d's (Cin, Cout, 3, 3, 3) layout).  Returns (y, partials or None)."""
+def deconv3d_k3s2(xa, xb, weight, want_stats, in_affine=None, samples_per_stat=1):
+    """ConvTranspose3d 3x3x3 / stride 2 / padding 1 / output_padding 1 of ``act(xa) (+ xb)`` (pf_deconv3d_k3s2_f32;
+    weight in nn.ConvTranspose3d's (Cin, Cout, 3, 3, 3) layout).  ``in_affine``: the pending BatchNorm + ReLU of
+    xa (rows or a LazyAffine; None: xa as it is).  Returns (y, partials or None)."""
     N, Cin, D, H, W = xa.shape
     Cout = weight.shape[1]
     w = weight.detach()
@@ -471,8 +472,9 @@ def deconv3d_k3s2(xa, xb, weight, want_stats):
         T = int(_lib.load().pf_deconv3d_blocks(D, H, W))
         partials = torch.empty((N, T, Cout, 2), dtype=torch.float64, device=xa.device)
     vol = D * H * W
+    sc, sh, in_bn = _split_affine(in_affine)
     _lib.call("pf_deconv3d_k3s2_f32", _lib.ptr(xa), _lib.ptr(xb), _lib.ptr(w), _lib.ptr(y), N, Cin, Cout, D, H, W,
-              _lib.ptr(partials), _lib.stream(),
+              _lib.ptr(sc), _lib.ptr(sh), in_bn, int(samples_per_stat), _lib.ptr(partials), _lib.stream(),
               algo_bytes=4.0 * N * vol * (Cin * (2 if xb is not None else 1) + 8 * Cout) + 4.0 * 27 * Cin * Cout,
               flops=2.0 * N * vol * 27 * Cin * Cout)
     return y, partials

@@ -1275,3 +1275,43 @@ def test_conv3d_k3_applies_pending_batchnorm_while_staging(dev, N, Cin, Cout, st
     assert _maxabs(y_plain, F.conv3d(x.double(), w.double(), None, stride, 1)) < 4e-6 * scale * max(1.0, (27 * Cin / 256.0) ** 0.5) * 3
     pointflow.flush_counters()
     assert _lib.status() == 0
+
+
+@pytest.mark.parametrize("skip", [False, True])
+@pytest.mark.parametrize("affine", ["rows", "lazy"])
+def test_deconv3d_k3s2_applies_pending_batchnorm_before_the_skip_add(dev, skip, affine):
+    """pf_deconv3d_k3s2_f32 with the BatchNorm + ReLU of xa pending: y = deconv(relu(bn(xa)) + xb)."""
+    gen = torch.Generator().manual_seed(7 + int(skip))
+    N, Cin, Cout, D, H, W = 1, 32, 16, 6, 8, 10
+    conv = torch.nn.ConvTranspose3d(Cin, Cout, 3, stride=2, padding=1, output_padding=1, bias=False)
+    xa = torch.randn(N, Cin, D, H, W, generator=gen)
+    xb = torch.randn(N, Cin, D, H, W, generator=gen) if skip else None
+    xd = xa.to(dev)
+    if affine == "rows":
+        sc = torch.rand(1, Cin, generator=gen) + 0.5
+        sh = torch.randn(1, Cin, generator=gen) * 0.3
+        act = torch.relu(xa.double() * sc.double().view(1, Cin, 1, 1, 1) + sh.double().view(1, Cin, 1, 1, 1))
+        aff = (sc.to(dev), sh.to(dev))
+    else:
+        bn = torch.nn.BatchNorm3d(Cin).to(dev).train()
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(0.5, 1.5, Cin))
+            bn.bias.copy_(torch.linspace(-0.3, 0.3, Cin))
+        T = 4
+        part = torch.zeros((N, T, Cin, 2), dtype=torch.float64, device=dev)
+        for t, ch in enumerate(torch.chunk(xd.double().reshape(N, Cin, -1), T, dim=2)):
+            part[:, t, :, 0] = ch.sum(dim=2)
+            part[:, t, :, 1] = (ch * ch).sum(dim=2)
+        aff = pointflow.bn_affine_rows(xd, bn, N, part, lazy=True)
+        assert isinstance(aff, pointflow.LazyAffine)
+        act = torch.relu(F.batch_norm(xa.double(), None, None, bn.weight.double().cpu(), bn.bias.double().cpu(), True, 0.0,
+                                      bn.eps))
+    ref = F.conv_transpose3d(act + (xb.double() if skip else 0.0), conv.weight.double(), None, 2, 1, 1)
+    y, part_y = pointflow.deconv3d_k3s2(xd, xb.to(dev) if skip else None, conv.weight.to(dev), True, in_affine=aff,
+                                        samples_per_stat=N)
+    scale = float(ref.abs().max())
+    assert _maxabs(y, ref) < (2e-5 if affine == "lazy" else 4e-6) * scale
+    sums = part_y.sum(dim=1).cpu()
+    assert torch.allclose(sums[..., 0], ref.sum(dim=(2, 3, 4)), rtol=1e-4, atol=2e-4 * scale * ref[0, 0].numel() ** 0.5)
+    pointflow.flush_counters()
+    assert _lib.status() == 0
