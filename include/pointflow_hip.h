@@ -300,6 +300,14 @@ int pf_channel_bn_apply_f32(const float* x, float* y, const double* partials, in
                             int samples_per_stat, double count, const float* gamma, const float* beta,
                             float* running_mean, float* running_var, float momentum, float eps, int relu,
                             const float* addend, void* stream);
+/* The same for TWO convolution outputs at once: y = relu(bn2(x2)) + relu(bn1(x1)) (train-mode statistics from
+ * partials1 / partials2, running statistics of both updated), y may alias x1 or x2 -- the last skip add of
+ * VolumeConv's decoder (reference networks.py:166) as one pass over three streams. */
+int pf_channel_bn_apply2_f32(const float* x1, const double* partials1, int T1, const float* gamma1, const float* beta1,
+                             float* running_mean1, float* running_var1, float momentum1, float eps1, const float* x2,
+                             const double* partials2, int T2, const float* gamma2, const float* beta2,
+                             float* running_mean2, float* running_var2, float momentum2, float eps2, float* y, int64_t N,
+                             int64_t C, int64_t S, int samples_per_stat, double count, void* stream);
 /* Statistics + finalize + normalise in ONE launch for small tensors (one 1024-thread block per channel walks
  * the stat groups in order): y = act(BN_train(x)) with y == x allowed, and/or (y == NULL) only the affine
  * rows scale/shift (N/samples_per_stat, ld_affine) for a consumer that applies them itself.  Same
@@ -340,7 +348,8 @@ int pf_conv3d_k3_few_f32(const float* x, const float* w, float* y, int64_t N, in
  * networks.py:141-143 via nn/conv.py:189-216): y (N, Cout, 2D, 2H, 2W) from xa (+ xb when not NULL: the
  * decoder's skip add, networks.py:163-165) (N, Cin, D, H, W) and w (Cin, Cout, 3, 3, 3) in
  * nn.ConvTranspose3d's own layout.  partials != NULL: float64 (sum, sum of squares) per (sample, block,
- * channel), (N, pf_deconv3d_blocks(D, H, W), Cout, 2), the layout pf_channel_bn_apply_f32 consumes.  * in_scale / in_shift (N / samples_per_stat, Cin) or in_bn: the pending BatchNorm + ReLU of xa (the previous
+ * channel), (N, pf_deconv3d_blocks(D, H, W), Cout, 2), the layout pf_channel_bn_apply_f32 consumes.
+ * in_scale / in_shift (N / samples_per_stat, Cin) or in_bn: the pending BatchNorm + ReLU of xa (the previous
  * layer's raw output; Cin <= 64), applied to every loaded value BEFORE the skip add -- rows, or resolved by the
  * launch itself; all NULL: xa is taken as it is. */
 int pf_deconv3d_blocks(int64_t D, int64_t H, int64_t W);

@@ -82,6 +82,8 @@ PROTOTYPES = {
     "pf_channel_stats_f32": ([_vp, _i64, _i64, _i64, _vp, _vp], _i),
     "pf_channel_affine_f32": ([_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _vp], _i),
     "pf_channel_bn_apply_f32": ([_vp, _vp, _vp, _i, _i64, _i64, _i64, _i, _d, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp], _i),
+    "pf_channel_bn_apply2_f32": ([_vp, _vp, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _i, _vp, _vp, _vp, _vp, _f, _f, _vp,
+                                  _i64, _i64, _i64, _i, _d, _vp], _i),
     "pf_channel_bn_fused_f32": ([_vp, _vp, _i64, _i64, _i64, _i, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _i, _vp], _i),
     "pf_edge_stats_f32": ([_vp, _i64, _i, _vp, _i, _i, _i, _vp, ctypes.POINTER(BnJob), _i, _vp,
                            _vp, _i, _i, _i, _vp], _i),

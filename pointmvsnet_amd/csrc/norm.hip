@@ -179,6 +179,78 @@ __global__ __launch_bounds__(256) void channel_bn_apply_kernel(
                 addend ? addend + ((int64_t)n * C + c) * S : nullptr);
 }
 
+// Two BatchNorms in one pass: y = relu(bn2(x2)) + relu(bn1(x1)) -- the last skip add of VolumeConv's decoder
+// (reference networks.py:166: conv6_0's output + conv0_1's output, both straight out of their convolutions): one
+// launch and 3 streams instead of two launches and 5.  Same prologue as above, once per side.
+struct BnSide {
+  const double* partials;
+  int T;
+  const float* gamma;
+  const float* beta;
+  float* running_mean;
+  float* running_var;
+  float momentum, eps;
+};
+
+__device__ __forceinline__ void bn_side_affine(const BnSide& B, int C, int c, int n, int samples_per_stat, int G,
+                                               double count, double2* red, float& a, float& b) {
+  const int s = n / samples_per_stat;
+  const int entries = samples_per_stat * B.T;
+  const double2 sums = reduce_partials(B.partials, (int64_t)s * entries, entries, C, c, red);
+  const double mean = sums.x / count;
+  double var = sums.y / count - mean * mean;
+  var = var < 0.0 ? 0.0 : var;
+  a = (float)(1.0 / sqrt(var + (double)B.eps)) * B.gamma[c];
+  b = B.beta[c] - (float)mean * a;
+  if (B.running_mean != nullptr && blockIdx.x == 0 && n == 0) {
+    float rm = B.running_mean[c], rv = B.running_var[c];
+    for (int g = 0; g < G; ++g) {
+      const double2 sg = reduce_partials(B.partials, (int64_t)g * entries, entries, C, c, red);
+      const double m = sg.x / count;
+      double v = sg.y / count - m * m;
+      v = v < 0.0 ? 0.0 : v;
+      const double unbiased = count > 1.0 ? v * (count / (count - 1.0)) : v;
+      rm = (1.0f - B.momentum) * rm + B.momentum * (float)m;
+      rv = (1.0f - B.momentum) * rv + B.momentum * (float)unbiased;
+    }
+    if (threadIdx.x == 0) {
+      B.running_mean[c] = rm;
+      B.running_var[c] = rv;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void channel_bn_apply2_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
+                                                                float* __restrict__ y, BnSide B1, BnSide B2, int C,
+                                                                int64_t S, int samples_per_stat, int G, double count) {
+  __shared__ double2 red[256];
+  const int c = blockIdx.y, n = blockIdx.z;
+  float a1, b1, a2, b2;
+  bn_side_affine(B1, C, c, n, samples_per_stat, G, count, red, a1, b1);
+  bn_side_affine(B2, C, c, n, samples_per_stat, G, count, red, a2, b2);
+  const float* p1 = x1 + ((int64_t)n * C + c) * S;
+  const float* p2 = x2 + ((int64_t)n * C + c) * S;
+  float* o = y + ((int64_t)n * C + c) * S;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  if ((((uintptr_t)p1 | (uintptr_t)p2 | (uintptr_t)o) & 15) == 0 && (S & 3) == 0) {
+    const float4* q1 = reinterpret_cast<const float4*>(p1);
+    const float4* q2 = reinterpret_cast<const float4*>(p2);
+    float4* o4 = reinterpret_cast<float4*>(o);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (S >> 2); i += stride) {
+      const float4 v = q1[i], u = q2[i];
+      float4 r;
+      r.x = fmaxf(fmaf(u.x, a2, b2), 0.0f) + fmaxf(fmaf(v.x, a1, b1), 0.0f);
+      r.y = fmaxf(fmaf(u.y, a2, b2), 0.0f) + fmaxf(fmaf(v.y, a1, b1), 0.0f);
+      r.z = fmaxf(fmaf(u.z, a2, b2), 0.0f) + fmaxf(fmaf(v.z, a1, b1), 0.0f);
+      r.w = fmaxf(fmaf(u.w, a2, b2), 0.0f) + fmaxf(fmaf(v.w, a1, b1), 0.0f);
+      o4[i] = r;
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < S; i += stride)
+      o[i] = fmaxf(fmaf(p2[i], a2, b2), 0.0f) + fmaxf(fmaf(p1[i], a1, b1), 0.0f);
+  }
+}
+
 // Small tensors (the encoder/decoder layers of VolumeConv and the deep tower stages: <= 256 KB per channel):
 // statistics, finalize and normalise in ONE launch.  A 1024-thread block owns a channel and walks its stat
 // groups in order (the running-statistics recurrence is sequential anyway): pass 1 reduces the group's
@@ -357,6 +429,27 @@ int pf_channel_bn_apply_f32(const float* x, float* y, const double* partials, in
   hipLaunchKernelGGL(channel_bn_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, partials, T, (int)C, S,
                      samples_per_stat, (int)(N / samples_per_stat), count, gamma, beta, running_mean, running_var,
                      momentum, eps, relu, addend);
+  return pf_launch_status();
+}
+
+int pf_channel_bn_apply2_f32(const float* x1, const double* partials1, int T1, const float* gamma1, const float* beta1,
+                             float* running_mean1, float* running_var1, float momentum1, float eps1, const float* x2,
+                             const double* partials2, int T2, const float* gamma2, const float* beta2,
+                             float* running_mean2, float* running_var2, float momentum2, float eps2, float* y, int64_t N,
+                             int64_t C, int64_t S, int samples_per_stat, double count, void* stream) {
+  PF_REQUIRE(N >= 0 && C >= 0 && S >= 0 && N <= 65535 && C <= 65535 && samples_per_stat >= 1 && T1 >= 1 && T2 >= 1);
+  PF_REQUIRE(N % samples_per_stat == 0 && count > 0.0);
+  PF_REQUIRE((running_mean1 == nullptr) == (running_var1 == nullptr));
+  PF_REQUIRE((running_mean2 == nullptr) == (running_var2 == nullptr));
+  if (N == 0 || C == 0 || S == 0) return PF_OK;
+  PF_REQUIRE(x1 && x2 && y && partials1 && partials2 && gamma1 && beta1 && gamma2 && beta2);
+  const BnSide B1{partials1, T1, gamma1, beta1, running_mean1, running_var1, momentum1, eps1};
+  const BnSide B2{partials2, T2, gamma2, beta2, running_mean2, running_var2, momentum2, eps2};
+  int64_t blocks = (S / 4 + 1023) / 1024;
+  blocks = blocks < 1 ? 1 : (blocks > 64 ? 64 : blocks);
+  dim3 grid((unsigned)blocks, (unsigned)C, (unsigned)N);
+  hipLaunchKernelGGL(channel_bn_apply2_kernel, grid, dim3(256), 0, (hipStream_t)stream, x1, x2, y, B1, B2, (int)C, S,
+                     samples_per_stat, (int)(N / samples_per_stat), count);
   return pf_launch_status();
 }
 

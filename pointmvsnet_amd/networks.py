@@ -451,6 +451,15 @@ class VolumeConv(nn.Module):
             up = pointflow.batch_norm_act_(y6, self.conv6_0.bn, self.conv6_0.relu, B, partials=p6)
         else:
             up = f(self.conv5_0, (up, quarter))
+            blk6, blk0 = self.conv6_0, self.conv0_1
+            if (isinstance(full, tuple) and aux is None and int(_os.environ.get("PF_VC_DUAL_BN", "1"))
+                    and _deconv_fusable(blk6, up) and blk6.bn is not None and blk6.relu and blk0.relu
+                    and (blk6.bn.training or not blk6.bn.track_running_stats)):
+                # conv6_0's BatchNorm + ReLU, conv0_1's BatchNorm + ReLU and the add of the two: ONE pass
+                y6, p6 = pointflow.deconv3d_k3s2(up.contiguous(), half.contiguous(), blk6.conv.weight, True)
+                raw0, p0 = full
+                summed = pointflow.batch_norm_act2_(raw0, blk0.bn, p0, y6, blk6.bn, p6, B)
+                return f(self.conv6_2, summed)
             up = f(self.conv6_0, (up, half))
         if aux is not None:
             torch.cuda.current_stream().wait_stream(aux)

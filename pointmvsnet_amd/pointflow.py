@@ -289,6 +289,12 @@ class LazyAffine(object):
         return self.scale, self.shift
 
 
+def _bn_tensors(bn):
+    """Everything a pf_bn_job of ``bn`` points to: a queued LazyAffine keeps these alive until its deferred finalize
+    has been launched (the job holds raw device pointers; the module may be gone by then)."""
+    return tuple(t for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var) if t is not None)
+
+
 def _split_affine(in_affine):
     """(scale, shift, in_bn pointer) for a kernel with both kinds of input-affine slots."""
     if in_affine is None:
@@ -714,7 +720,7 @@ def bn_affine_rows(x, bn, samples_per_stat, partials=None, lazy=False):
         bump_counter(bn, G)
         if lazy and LAZY_BN and samples_per_stat * partials.shape[1] * C <= LAZY_MAX_ELEMS:
             job = bn_job(bn, partials, 0, C, n, n, N, samples_per_stat, scale, shift)
-            return LazyAffine(job, (partials, scale, shift), scale, shift)
+            return LazyAffine(job, (partials, scale, shift) + _bn_tensors(bn), scale, shift)
         bn_affine(bn, partials, 0, C, n, n, N, samples_per_stat, scale, shift)
         return scale, shift
     sc, sh = eval_affine(bn, G, C)
@@ -861,6 +867,31 @@ def batch_norm_act_(x, bn, relu, samples_per_stat, partials=None, addend=None):
     return x if addend is None else x.add_(addend)
 
 
+def batch_norm_act2_(x1, bn1, partials1, x2, bn2, partials2, samples_per_stat):
+    """relu(bn2(x2)) + relu(bn1(x1)) in ONE pass, written into x1 (pf_channel_bn_apply2_f32): both inputs are raw
+    convolution outputs with their statistics partials, both BatchNorms in train mode with ReLU (VolumeConv's last
+    skip add, reference networks.py:166)."""
+    N, C = x1.shape[:2]
+    S = x1[0, 0].numel()
+    if x2.shape != x1.shape or not (x1.is_contiguous() and x2.is_contiguous()):
+        raise RuntimeError("batch_norm_act2_: the two tensors must be contiguous and of one shape")
+    for bn in (bn1, bn2):
+        if bn.momentum is None:
+            raise NotImplementedError("cumulative-average BatchNorm momentum is not supported")
+    def side(bn):
+        track = bn.track_running_stats and bn.running_mean is not None
+        return (_lib.ptr(bn.weight.detach()), _lib.ptr(bn.bias.detach()), _lib.ptr(bn.running_mean if track else None),
+                _lib.ptr(bn.running_var if track else None), float(bn.momentum), float(bn.eps))
+    a, b = side(bn1), side(bn2)
+    _lib.call("pf_channel_bn_apply2_f32", _lib.ptr(x1), _lib.ptr(partials1), int(partials1.shape[1]), *a,
+              _lib.ptr(x2), _lib.ptr(partials2), int(partials2.shape[1]), *b, _lib.ptr(x1), N, C, S,
+              int(samples_per_stat), float(samples_per_stat) * S, _lib.stream(), algo_bytes=12.0 * N * C * S)
+    G = N // samples_per_stat
+    bump_counter(bn1, G)
+    bump_counter(bn2, G)
+    return x1
+
+
 # ---------------------------------------------------------------------------------------------
 # EdgeConv (rows E0 / E1 / E2)
 # ---------------------------------------------------------------------------------------------
@@ -976,7 +1007,7 @@ def _bn_affine_from_gemm(bn, partials, C, G, Ng, groups_per_stat, dev, lazy=Fals
         bump_counter(bn, S)
         if lazy and LAZY_BN and groups_per_stat * partials.shape[1] * C <= LAZY_MAX_ELEMS:
             job = bn_job(bn, partials, 0, C, n, n, G, groups_per_stat, scale, shift)
-            return LazyAffine(job, (partials, scale, shift), scale, shift)
+            return LazyAffine(job, (partials, scale, shift) + _bn_tensors(bn), scale, shift)
         bn_affine(bn, partials, 0, C, n, n, G, groups_per_stat, scale, shift)
     else:
         sc, sh = eval_affine(bn, S, C)

@@ -1315,3 +1315,39 @@ def test_deconv3d_k3s2_applies_pending_batchnorm_before_the_skip_add(dev, skip, 
     assert torch.allclose(sums[..., 0], ref.sum(dim=(2, 3, 4)), rtol=1e-4, atol=2e-4 * scale * ref[0, 0].numel() ** 0.5)
     pointflow.flush_counters()
     assert _lib.status() == 0
+
+
+@pytest.mark.parametrize("N,C,D,H,W,T1,T2", [(1, 8, 6, 8, 20, 5, 3), (2, 8, 3, 5, 7, 4, 4)])
+def test_batch_norm_act2_two_batchnorms_and_their_sum_in_one_pass(dev, N, C, D, H, W, T1, T2):
+    gen = torch.Generator().manual_seed(N + D * H * W)
+    x1 = torch.randn(N, C, D, H, W, generator=gen) * 1.5 + 0.3
+    x2 = torch.randn(N, C, D, H, W, generator=gen) * 0.7 - 0.2
+    mods, refs = [], []
+    for seed in (1, 2):
+        m = torch.nn.BatchNorm3d(C).to(dev).train()
+        r = torch.nn.BatchNorm3d(C).double().train()
+        with torch.no_grad():
+            for b in (m, r):
+                b.weight.copy_(torch.linspace(0.5, 1.5, C) * seed)
+                b.bias.copy_(torch.linspace(-0.3, 0.3, C))
+        mods.append(m)
+        refs.append(r)
+
+    def partials(x, T):
+        xd = x.to(dev).double().reshape(N, C, -1)
+        part = torch.zeros((N, T, C, 2), dtype=torch.float64, device=dev)
+        for t, ch in enumerate(torch.chunk(xd, T, dim=2)):
+            part[:, t, :, 0] = ch.sum(dim=2)
+            part[:, t, :, 1] = (ch * ch).sum(dim=2)
+        return part
+    want = torch.relu(refs[1](x2.double())) + torch.relu(refs[0](x1.double()))
+    a = x1.to(dev).clone()
+    out = pointflow.batch_norm_act2_(a, mods[0], partials(x1, T1), x2.to(dev), mods[1], partials(x2, T2), N)
+    pointflow.flush_counters()
+    assert out.data_ptr() == a.data_ptr()
+    assert _maxabs(out, want.detach()) < 2e-5 * float(want.abs().max())
+    for m, r in zip(mods, refs):
+        assert torch.allclose(m.running_mean.double().cpu(), r.running_mean, rtol=1e-5, atol=1e-6)
+        assert torch.allclose(m.running_var.double().cpu(), r.running_var, rtol=1e-5, atol=1e-6)
+        assert int(m.num_batches_tracked) == 1
+    assert _lib.status() == 0
