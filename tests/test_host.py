@@ -213,3 +213,33 @@ def test_pack_cache_follows_data_swaps_and_pins():
     keep.data = torch.zeros(4, 4, 1)
     assert pf.pack_entries_stale(pins)
     pf.pack_unpin(pins)
+
+
+def test_deferred_batchnorm_jobs_are_layered_by_module_call_order(monkeypatch):
+    """pointflow.flush_lazy_stats: the jobs of one finalize launch run concurrently, so two deferred jobs of the SAME
+    BatchNorm module (the flow MLP is called once per PointFlow iteration) must go to consecutive launches, in call
+    order -- a shared launch would apply only one of the two running-statistics updates."""
+    import contextlib
+    from pointmvsnet_amd import _lib, pointflow
+
+    launches = []
+    monkeypatch.setattr(pointflow, "bn_finalize_jobs", lambda jobs: launches.append([j.T for j in jobs]))
+    monkeypatch.setattr(pointflow.torch.cuda, "device", lambda d: contextlib.nullcontext())
+
+    def lazy(tag, running_mean_ptr):
+        job = _lib.BnJob(1, tag, 1, 0, 1, 1.0, 1.0, 2, 3, running_mean_ptr, running_mean_ptr, 0.1, 1e-5, 1, 1, 4, 5, 1)
+        z = pointflow.LazyAffine(job, (), torch.zeros(1), torch.zeros(1))
+        z.job_ptr()                                             # queues it (device key "cpu")
+        return z
+
+    a1, b1, c1 = lazy(11, 1000), lazy(21, 2000), lazy(31, None)   # three modules (one without running statistics)
+    a2, b2 = lazy(12, 1000), lazy(22, 2000)                       # the first two again (second iteration)
+    a3 = lazy(13, 1000)
+    done = lazy(99, 3000)
+    done.done = True                                              # materialised meanwhile: must not be launched again
+    pointflow.flush_lazy_stats()
+    assert launches == [[11, 21, 31], [12, 22], [13]]
+    assert all(z.done for z in (a1, b1, c1, a2, b2, a3))
+    launches.clear()
+    pointflow.flush_lazy_stats()                                  # nothing left
+    assert launches == []
