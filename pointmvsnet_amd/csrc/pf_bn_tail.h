@@ -88,6 +88,10 @@ static inline int pf_tail_setup(PfTail& t, const pf_bn_job* jobs, int njobs, dou
 
 // A pending BatchNorm handed to its CONSUMER (`in_bn` of pf_conv2d_wide_f32 / pf_pointwise_gemm_f32 /
 // pf_flow_head_f32, resolved per block by pf_bn_resolve below): the job must describe finished statistics rows.
+#ifndef PF_RESOLVE_BATCH
+#define PF_RESOLVE_BATCH 20
+#endif
+constexpr int kResolveBatch = PF_RESOLVE_BATCH;
 constexpr int kResolveMaxRows = 4096;   // rows behind one statistic; beyond that the re-reduction per block is absurd
 static inline int pf_bn_in_check(const pf_bn_job* j, int C, int stat_groups) {
   PF_REQUIRE(j != nullptr && j->partials != nullptr && j->gamma != nullptr && j->beta != nullptr);
@@ -157,12 +161,14 @@ __device__ __forceinline__ void pf_bn_resolve(const pf_bn_job& J, int s, float* 
   if (sl < slices) {
     const double2* base = reinterpret_cast<const double2*>(J.partials) + (int64_t)s * per_stat * J.pcols + J.col0 + c;
     const int r0 = sl * per, r1 = min(per_stat, r0 + per);
-    for (int r = r0; r < r1; r += 16) {
-      double2 v[16];
+    // kResolveBatch rows in flight: the tower layers hand every slice exactly 20 rows (80 / 160 / 320 / 640 rows for
+    // 64 / 32 / 16 / 8 channels), i.e. ONE round trip instead of two
+    for (int r = r0; r < r1; r += kResolveBatch) {
+      double2 v[kResolveBatch];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) v[u] = base[(int64_t)min(r + u, r1 - 1) * J.pcols];   // unconditional loads
+      for (int u = 0; u < kResolveBatch; ++u) v[u] = base[(int64_t)min(r + u, r1 - 1) * J.pcols];   // unconditional loads
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
+      for (int u = 0; u < kResolveBatch; ++u) {
         a += (r + u < r1) ? v[u].x : 0.0;
         b += (r + u < r1) ? v[u].y : 0.0;
       }
