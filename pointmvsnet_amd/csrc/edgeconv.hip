@@ -1123,7 +1123,9 @@ int pf_bn_tail_tickets(int G, int T) {
 int pf_gemm_blocks(int G, int Ng) {
   if (G <= 0 || Ng <= 0) return 0;
   const int tiles = (Ng + GT - 1) / GT;
-  int cap = 512 / G;
+  const char* e = getenv("PF_GEMM_CAP");              // tuning hook: persistent GEMM blocks over all groups
+  const int total = e ? atoi(e) : 512;
+  int cap = (total > 0 ? total : 512) / G;
   cap = cap < 16 ? 16 : cap;
   if (tiles <= cap) return tiles;
   const int per = (tiles + cap - 1) / cap;
