@@ -69,11 +69,12 @@ def build(force=False, verbose=True):
         objs.append(o)
         u = o.replace(".o", ".usage.json")
         if force or _stale(o, [s] + headers) or not os.path.exists(u):
-            cmd = [hipcc] + FLAGS + [USAGE_FLAG, "-c", s, "-o", o]
+            cmd = [hipcc] + FLAGS + [USAGE_FLAG, "-fno-caret-diagnostics", "-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             proc = subprocess.run(cmd, stderr=subprocess.PIPE, universal_newlines=True)
-            rest = [ln for ln in proc.stderr.splitlines() if "remark:" not in ln and ln.strip()]
+            rest = [ln for ln in proc.stderr.splitlines()
+                    if "remark:" not in ln and ln.strip() and not ln.startswith("In file included from")]
             if rest:
                 sys.stderr.write("\n".join(rest) + "\n")
             if proc.returncode != 0:

@@ -525,6 +525,7 @@ __global__ __launch_bounds__(256) void flow_features_hyp_kernel(const float* __r
                                                                 const float* __restrict__ cam, int ratio,
                                                                 float* __restrict__ feature, float* __restrict__ xyz) {
   constexpr int PTS = kFeatPY * kFeatPX;                    // 32 points (pixels) per block
+  constexpr int kUnrollV = ROLLV ? 1 : V;                   // view loop: rolled (fewer registers) or unrolled
   __shared__ int tap_off[PTS][V * 5][4];
   __shared__ float tap_wgt[PTS][V * 5][4];
   __shared__ float nxyz[PTS][5][4];
@@ -613,7 +614,7 @@ __global__ __launch_bounds__(256) void flow_features_hyp_kernel(const float* __r
         for (int d = 0; d < 5; ++d)
 #pragma unroll
           for (int i = 0; i < 4; ++i) s[d][i] = s2[d][i] = 0.0f;
-#pragma unroll(ROLLV ? 1 : V)
+#pragma unroll kUnrollV
         for (int v = 0; v < V; ++v) {
           const float* mv = maps + (int64_t)v * hw * cl + c;
 #pragma unroll
