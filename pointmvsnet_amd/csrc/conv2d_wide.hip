@@ -1,4 +1,6 @@
-// ImageConv, the 32- and 64-channel layers (reference networks.py:95-110): KxK conv2d
+// ImageConv, all eleven layers of a tower (reference networks.py:84-124).  First the
+// 32- and 64-channel layers (conv2d_wide_kernel); the 8- and 16-channel ones follow further down
+// (conv2d_wide16_kernel, the same idea on the 16x16x4 MFMA).  KxK conv2d
 // (3x3 stride 1 or 5x5 stride 2, pad K/2, no bias) as an implicit GEMM on v_mfma_f32_32x32x2_f32, with the previous
 // layer's BatchNorm+ReLU applied while the input patch is staged and this layer's BatchNorm batch statistics in
 // the epilogue -- the same contract as pf_conv2d_f32 (conv2d.hip), a different machine mapping for the layers
@@ -18,7 +20,8 @@
 //   * a 256-thread block owns (2 * NWM) x 16 output pixels x C_out channels: wave (wm, wn) the two rows
 //     2 wm, 2 wm + 1 (32 pixels) x channels [32 wn, 32 wn + 32); C_out = 64: 2 x 2 waves (4 x 16 pixels), C_out = 32:
 //     4 x 1 (8 x 16 pixels).  The accumulator layout (lane = channel, 4 consecutive registers = 4 consecutive
-//     pixels of a row) stores straight to NCHW as 16-byte pieces -- no transpose through LDS;
+//     pixels of a row) stores straight to NCHW as 16-byte pieces -- no transpose through LDS; with cl_out the same
+//     registers go out channel-last (a half-wave = 32 consecutive channels of one pixel) for the coarse warp;
 //   * statistics: per lane over its 16 outputs (float), the two lane halves by one shuffle, waves through LDS,
 //     one float64 partial row per block -- the layout pf_bn_finalize consumes from pf_conv2d_f32.
 //
@@ -55,8 +58,6 @@ struct WideCfg {
   static constexpr int WROW = KS * CIN * COUT;          // floats of one kernel row of packed weights
   static constexpr int WROW4 = WROW / 4;
   static constexpr int NWR = (WROW4 + 255) / 256;       // 16-byte pieces per thread per row
-  static constexpr int ITEMS = NPIX * (CIN / 4);        // (pixel, channel quad) pairs of the patch
-  static constexpr int NIT = (ITEMS + 255) / 256;
   static constexpr size_t LDS = sizeof(float) * (size_t)(PATCH + 2 * WROW + 2 * CIN) + sizeof(double) * 4 * 32 * 2;
   static_assert(COUT == 32 || COUT == 64, "C_out is 32 or 64");
   static_assert(CIN % 8 == 0 && PATCH % 4 == 0 && WROW % 4 == 0, "16-byte pieces");
