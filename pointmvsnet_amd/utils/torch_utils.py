@@ -5,6 +5,7 @@
 (reference model.py:251-252) without a copy: the five strides are handed to the HIP kernel.
 """
 import ctypes
+import os
 import random
 
 import numpy as np
@@ -37,13 +38,18 @@ def knn_lattice(xyz, kernel_size=5, knn=16, with_codes=False, with_idx=True):
         raise RuntimeError("get_knn_3d: knn larger than the window (topk would be out of range)")
     if not (with_idx or with_codes):
         raise RuntimeError("knn_lattice: nothing to compute")
-    idx = torch.empty((B, D * H * W, knn), dtype=torch.int64, device=xyz.device) if with_idx else None
+    # (the insertion-list kernels of PF_KNN_LEGACY=1 -- and windows / k the network kernel is not built for --
+    # always write the int64 indices: give them a buffer even when only the codes are wanted)
+    need_idx = with_idx or os.environ.get("PF_KNN_LEGACY") == "1" or knn > 16 or kernel_size not in (3, 5)
+    idx = torch.empty((B, D * H * W, knn), dtype=torch.int64, device=xyz.device) if need_idx else None
     codes = torch.empty((B, D * H * W, knn), dtype=torch.uint8, device=xyz.device) if with_codes else None
     strides = (ctypes.c_int64 * 5)(*xyz.stride())
     with torch.cuda.device(xyz.device):
         _lib.call("pf_knn_lattice_f32", _lib.ptr(xyz), strides, B, D, H, W, int(kernel_size), int(knn),
                   _lib.ptr(idx), _lib.ptr(codes), _lib.stream(),
                   algo_bytes=float(B * D * H * W) * (12.0 + (8.0 * knn if with_idx else 0.0) + (knn if with_codes else 0.0)))
+    if not with_idx:
+        idx = None
     return (idx, codes) if with_codes else idx
 
 
