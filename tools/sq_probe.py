@@ -20,6 +20,15 @@ if "conv2d" in which:
         sh = torch.randn(3, cin, device=dev) * 0.1
         for _ in range(4):
             pointflow.conv2d(x, conv, (sc, sh), 1, True)
+if "wide" in which:
+    for cin, cout, h, w, ks, stride in ((16, 16, 256, 320, 3, 1), (32, 32, 128, 160, 3, 1), (32, 64, 128, 160, 5, 2),
+                                        (64, 64, 64, 80, 3, 1)):
+        conv = torch.nn.Conv2d(cin, cout, ks, stride=stride, padding=ks // 2, bias=False).to(dev)
+        x = torch.randn(3, cin, h, w, device=dev)
+        sc = torch.rand(3, cin, device=dev) + 0.5
+        sh = torch.randn(3, cin, device=dev) * 0.1
+        for _ in range(4):
+            pointflow.conv2d_wide(x, conv, (sc, sh), 1, True)
 if "gemm" in which:
     for K, Nc, ldx in ((136, 64, 136), (224, 64, 224), (64, 128, 224)):
         X = torch.randn(4 * 25600, ldx, device=dev)
