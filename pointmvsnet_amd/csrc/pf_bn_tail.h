@@ -1,3 +1,7 @@
+// BatchNorm finalize WITHOUT its own launch, two ways: folded into the kernel that produces the statistics ("last block
+// done", first half of this file; measured slower than the separate launch, off by default) and folded into the kernel
+// that CONSUMES the normalised tensor (pf_bn_resolve, second half; on by default where the statistics rows are few).
+//
 // BatchNorm finalize folded into the kernel that produces the statistics ("last block done").
 //
 // Every BatchNorm on the path runs in training mode (reference test.py:58, networks.py:41,77, nn/conv.py:29-35):
