@@ -62,9 +62,21 @@ WORKLOAD_TEXT = {
 
 def parse_args():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1,
+                    help="GPUs of this node; N > 1 without a torchrun environment re-launches this command under "
+                         "torch.distributed.run with N ranks (one process per GPU, RCCL)")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scenes-per-step", type=int, default=None,
+                    help="depth maps per step (default: 64 for cfg1/cfg2, 8 for cfg3/cfg5, 1 for the training step): a "
+                         "step is one pass over a batch of that many synthetic scenes, one scene per forward like "
+                         "the reference's test.py (TEST.BATCH_SIZE 1), so that the default 20 steps time seconds, "
+                         "not 30 ms")
+    ap.add_argument("--calibration-steps", type=int, default=10,
+                    help="instrumented eager forwards (HIP events around every entry point) before the timed region")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only initialise the process group, count the ranks with an all-reduce of ones, print and "
+                         "exit (gloo when no GPU is visible: the N > 1 launch path is testable on CPU)")
     ap.add_argument("--config", default="cfg2", choices=sorted(synthetic.CONFIGS))
     ap.add_argument("--eager", action="store_true", help="do not capture the forward in a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -72,6 +84,52 @@ def parse_args():
     ap.add_argument("--train-cpu-baseline", action="store_true",
                     help="cfg4 only: also time ONE oracle training step on the host (tens of seconds, ~15 GB of RAM)")
     return ap.parse_args()
+
+
+def free_port():
+    import socket
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    return port
+
+
+def launch_command(n, argv):
+    """The command ``--gpus N`` re-launches itself as: one process per GPU on this node, rendezvous on 127.0.0.1
+    (the form the driver uses; reference: one process driving N GPUs through nn.DataParallel, train.py:177)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(n)),
+            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+
+
+def maybe_relaunch(args):
+    """``python bench.py --gpus N`` with N > 1 and no torchrun environment: become the launcher.  Under torchrun the
+    flag must agree with WORLD_SIZE -- a silent mismatch would print a line for the wrong N."""
+    world = os.environ.get("WORLD_SIZE")
+    if world is not None:
+        if int(world) != args.gpus:
+            raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%s; launch with --nproc-per-node %d"
+                             % (args.gpus, world, args.gpus))
+        return
+    if args.gpus <= 1:
+        return
+    if torch.cuda.is_available() and torch.cuda.device_count() < args.gpus:
+        raise SystemExit("bench.py: --gpus %d but only %d visible" % (args.gpus, torch.cuda.device_count()))
+    if not torch.cuda.is_available() and not args.launch_check:
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")            # dmabuf IPC: RCCL needs it on this driver
+    raise SystemExit(subprocess.call(launch_command(args.gpus, sys.argv[1:]), env=env))
+
+
+def count_ranks(dev):
+    """World size as the COLLECTIVE sees it: an all-reduce(SUM) of ones over RCCL (gloo on CPU)."""
+    if not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+        return 1
+    one = torch.ones(1, dtype=torch.float32, device=dev)
+    torch.distributed.all_reduce(one, op=torch.distributed.ReduceOp.SUM)
+    return int(round(float(one.item())))
 
 
 def to_device(data, dev):
@@ -161,20 +219,47 @@ def cpu_baseline(net, data, img_scales, inter_scales, repeats, text, train=False
 GATHER_PATH = ("pf_frustum_variance_f32", "pf_frustum_variance_cl_f32", "pf_nchw_to_nhwc_f32", "pf_flow_pyramid_f32",
                "pf_flow_features_f32", "pf_knn_lattice_f32", "pf_pointwise_gemm_f32", "pf_edge_stats_f32",
                "pf_bn_finalize_jobs_f32", "pf_bn_finalize_f32", "pf_edge_apply_f32", "pf_flow_head_f32")
+VOLUME_CONV = ("pf_conv3d_k3_f32", "pf_conv3d_k3_pair_f32", "pf_deconv3d_k3s2_f32", "pf_conv3d_k3_few_f32",
+               "pf_conv3d_bottom_f32", "pf_deconv3d_bottom_f32")
+VOLUME_CONV_BN = ("pf_channel_bn_apply_f32", "pf_channel_bn_apply2_f32", "pf_channel_stats_f32", "pf_channel_bn_fused_f32")
+TOWERS = ("pf_conv2d_wide_f32", "pf_conv2d_f32", "pf_conv2d_small_f32")
 GATHER_PATH_MB = {"cfg1": 404.1, "cfg2": 1658.8, "cfg3": 25194.4, "cfg5": 38116.0}
 
 
 def main():
     args = parse_args()
-    rank, world, local = distributed.init_from_env()
+    maybe_relaunch(args)
+    if args.launch_check:
+        rank, world, local = distributed.init_from_env()
+        dev = torch.device("cuda", local) if torch.cuda.is_available() else torch.device("cpu")
+        if dev.type == "cuda":
+            torch.cuda.set_device(local)
+        ranks = count_ranks(dev)
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "rccl_ranks": ranks,
+                              "backend": torch.distributed.get_backend() if world > 1 else None}))
+        if world > 1:
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs a GPU: the hot path has no CPU fallback")
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if local >= torch.cuda.device_count():
+        raise SystemExit("bench.py: LOCAL_RANK %d but only %d GPUs visible" % (local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
+    rank, world, local = distributed.init_from_env()
     dev = torch.device("cuda", local)
     _lib.load()
+    rccl_ranks = count_ranks(dev)
+    assert rccl_ranks == world == args.gpus, (rccl_ranks, world, args.gpus)
 
     h, w, V, D, _, img_scales, inter_scales = synthetic.CONFIGS[args.config]
-    total_steps = args.warmup + args.steps
+    training = args.config == "cfg4"
+    sps = args.scenes_per_step or {"cfg1": 64, "cfg2": 64, "cfg3": 8, "cfg5": 8, "cfg4": 1}.get(args.config, 8)
+    if training:
+        sps = 1                                       # a training step is one scene per GPU (BASELINE configs[3])
+    total_steps = (args.warmup + args.steps) * sps
     # every rank owns its own scenes (weak scaling: per-GPU work fixed as N grows)
     my_scenes = distributed.shard_scenes(world * total_steps, rank, world)
     n_unique = min(4, len(my_scenes))
@@ -182,7 +267,6 @@ def main():
     for i in range(n_unique):
         data, _, _ = synthetic.make_config(args.config, seed=my_scenes[i])
         scenes.append(to_device(data, dev))
-    training = args.config == "cfg4"
     if training:                                                                # train intrinsics + ground truth
         scenes = []
         for i in range(n_unique):
@@ -229,14 +313,19 @@ def main():
         if world > 1:
             torch.distributed.barrier()
 
-    # ---- warm-up, then a calibration pass that times every hand-written entry point --------------
-    for i in range(args.warmup):
-        step(i)
+    # ---- eager warm-up, then a calibration pass that times every hand-written entry point --------------
+    # HIP events (torch.cuda.Event on the stream the kernels are launched on) around every C-ABI call of
+    # ``--calibration-steps`` eager forwards over the same scenes.  This is THE clock of ``roofline`` and ``kernels``:
+    # raw event-pair times, nothing subtracted (an empty pair measures ``event_pair_floor_us``, reported beside them;
+    # rocprofv3's kernel durations of the same command are committed under profiles/ and are shorter by about that).
+    for i in range(min(max(args.warmup, 1), 3)):
+        eager_step(i)
     torch.cuda.synchronize()
+    ncal = max(1, int(args.calibration_steps)) if not training else 2
     cal = _lib.KernelTimer()
     _lib.set_timer(cal)
-    for i in range(2):
-        step(i)
+    for i in range(ncal):
+        eager_step(i)
     _lib.set_timer(None)
     split = cal.summary()
     dominant = max(split.items(), key=lambda kv: kv[1]["ms"])[0] if split else None
@@ -263,9 +352,6 @@ def main():
                 with torch.no_grad():
                     return graphs[i % n_graphs](scenes[i % n_unique])
 
-            for i in range(2):
-                step(i)
-            torch.cuda.synchronize()
             execution = ("hipGraph replay, one graph per resident input slot (host camera algebra + 1 H2D of the scene "
                          "constants + 1 graph launch per step)") if (n_graphs == n_unique and n_graphs > 1) \
                 else "hipGraph replay (host camera algebra + image copy into the static input + 1 graph launch per step)"
@@ -273,31 +359,42 @@ def main():
             sys.stderr.write("bench.py: hipGraph capture failed (%r); running eager\n" % (exc,))
             step = eager_step
 
-    # ---- timed region ------------------------------------------------------------------------------
-    # Event records cannot live inside a replayed graph: in graph mode the dominant kernel's HIP-event
-    # timing comes from an instrumented eager pass over the same scenes right before the timed region.
-    timer = _lib.KernelTimer(only=dominant)
-    _lib.set_timer(timer)
-    if execution != "eager":
-        for i in range(min(args.steps, 5)):
-            eager_step(i)
-        _lib.set_timer(None)
+    # ---- W untimed warm-up steps in the final execution mode, then the timed region: EXACTLY K steps ------------
+    # (event records cannot live inside a replayed graph, so the per-kernel clock is the calibration pass above)
+    def run_step(k):
+        out = None
+        for j in range(sps):
+            out = step(k * sps + j)
+        return out
+
+    for k in range(args.warmup):
+        run_step(k)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        preds = step(args.warmup + i)
+    for k in range(args.steps):
+        preds = run_step(args.warmup + k)
     issued = time.perf_counter() - t0            # host-side time to enqueue every step (diagnostic only)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    allreduce_us = None
+    if training and world > 1:                   # the step's one collective on its own: 2.8 MB SUM all-reduce over RCCL
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(22)]
+        for e0 in ev[:1]:
+            e0.record()
+        for j in range(21):
+            trainer.bucket.allreduce_sum()
+            ev[j + 1].record()
+        torch.cuda.synchronize()
+        allreduce_us = statistics.median(ev[j].elapsed_time(ev[j + 1]) for j in range(1, 21)) * 1e3
     gap_probe = None
     if execution != "eager" and os.environ.get("PF_BENCH_GAP"):      # diagnostic, outside the timed region
         probe = []
         for g in graphs:
             g.probe = probe
-        for i in range(args.steps):
-            step(args.warmup + i)
+        for i in range(min(args.steps * sps, 200)):
+            step(i)
         torch.cuda.synchronize()
         for g in graphs:
             g.probe = None
@@ -317,7 +414,7 @@ def main():
         return
     roof = None
     if dominant is not None:
-        s = timer.summary()[dominant]
+        s = split[dominant]
         avg_s = s["ms"] / 1e3 / s["launches"]
         avg_bytes = s["bytes"] / s["launches"]
         avg_flops = s["flops"] / s["launches"]
@@ -333,12 +430,28 @@ def main():
                     "frac": achieved / HBM_PEAK_GBS}
         roof.update({"traffic": measured_traffic(dominant), "avg_launch_us": avg_s * 1e6,
                      "launches": s["launches"], "algorithmic_bytes_per_launch": avg_bytes,
-                     "timed_in": "timed region" if execution == "eager"
-                     else "instrumented eager pass before the timed region"})
+                     "event_pair_floor_us": s["event_floor_ms"] * 1e3,
+                     "clock": "HIP events around every launch of the entry point in %d instrumented eager forwards "
+                              "before the timed region (raw pair times, floor not subtracted)" % ncal})
+        # north_star: "MFMA utilisation on the 3D-conv path against chip peak" -- VolumeConv's convolution entry
+        # points and the two towers' convolutions as groups, same clock (BatchNorm / normalise passes listed apart)
+        for tag, entries, bn in (("volume_conv", VOLUME_CONV, VOLUME_CONV_BN), ("towers", TOWERS, ())):
+            grp = [split[k] for k in entries if k in split]
+            if grp:
+                us = sum(v["ms"] for v in grp) * 1e3 / ncal
+                fl = sum(v["flops"] for v in grp) / ncal
+                roof[tag] = {"flops_per_depth_map": fl, "kernel_us_per_depth_map": us,
+                             "launches_per_depth_map": sum(v["launches"] for v in grp) / float(ncal),
+                             "TFLOPs": fl / us / 1e6 if us > 0 else None,
+                             "frac_of_f32_mfma_peak": fl / us / 1e6 / MFMA_F32_PEAK_TF if us > 0 else None}
+                if bn:      # every stand-alone BatchNorm pass of the forward (the towers' materialised stage outputs too)
+                    roof[tag]["batchnorm_pass_us_per_depth_map_all"] = sum(
+                        split[k]["ms"] for k in bn if k in split) * 1e3 / ncal
     kernels = {}
     for k, v in sorted(split.items(), key=lambda kv: -kv[1]["ms"]):
         gbps = (v["bytes"] / (v["ms"] / 1e3) / 1e9) if v["ms"] > 0 else None
-        kernels[k] = {"launches_per_step": v["launches"] / 2.0, "us_per_step": v["ms"] * 1e3 / 2.0, "algo_GBps": gbps,
+        kernels[k] = {"launches_per_depth_map": v["launches"] / float(ncal), "us_per_depth_map": v["ms"] * 1e3 / ncal,
+                      "algo_GBps": gbps,
                       "algo_TFLOPs": (v["flops"] / (v["ms"] / 1e3) / 1e12) if v["ms"] > 0 and v["flops"] > 0 else None}
         if gbps is not None and gbps > HBM_PEAK_GBS:
             # SURVEY 8(d) counts the k-neighbour gather at k*C*4 B per point; those rows are L2 hits (PMC traffic is
@@ -347,25 +460,29 @@ def main():
             kernels[k]["hbm_traffic_bytes_per_launch"] = measured_traffic(k)
     # the gather path as a whole (north_star: "achieved HBM GB/s on the gather path"): SURVEY 8(d)'s algorithmic
     # bytes per depth map over the summed HIP-event time of the PointFlow entry points in the calibration pass
-    gather_ms = sum(v["ms"] for k, v in split.items() if k in GATHER_PATH) / 2.0
+    gather_ms = sum(v["ms"] for k, v in split.items() if k in GATHER_PATH) / float(ncal)
     if roof is not None and args.config in GATHER_PATH_MB and gather_ms > 0:
         gb = GATHER_PATH_MB[args.config] / 1e3
         roof["gather_path"] = {"algorithmic_MB_per_depth_map": GATHER_PATH_MB[args.config],
                                "kernel_time_ms_per_depth_map": gather_ms,
                                "achieved_GBps": gb / (gather_ms / 1e3),
                                "frac_of_hbm_peak": gb / (gather_ms / 1e3) / HBM_PEAK_GBS,
-                               "whole_step_GBps": gb / (elapsed / args.steps),
-                               "whole_step_frac": gb / (elapsed / args.steps) / HBM_PEAK_GBS}
+                               "whole_step_GBps": gb / (elapsed / (args.steps * sps)),
+                               "whole_step_frac": gb / (elapsed / (args.steps * sps)) / HBM_PEAK_GBS}
     result = {
         "metric": "depth-maps/sec (DTU 640x512, 3 src views, 2 flow iters)" if args.config == "cfg2"
         else ("train-scenes/sec (DTU 640x512, 3 views, 1 scene per GPU, forward+loss+backward+RMSprop+all-reduce)"
               if training else "depth-maps/sec (%s)" % args.config),
-        "value": world * args.steps / elapsed,
+        "value": world * args.steps * sps / elapsed,
         "unit": "train-scenes/s" if training else "depth-maps/s",
         "n_gpus": world,
+        "rccl_ranks": rccl_ranks,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
+        "scenes_per_step": sps,
+        "ms_per_depth_map": elapsed / (args.steps * sps) * 1e3,
+        "allreduce_us": allreduce_us,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -373,6 +490,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": WORKLOAD_TEXT[args.config], "height": h, "width": w, "views": V, "depth_planes": D,
                    "img_scales": list(img_scales), "inter_scales": list(inter_scales), "batch_per_gpu": 1,
+                   "scenes_per_step": sps,
                    "parallelism": ("data parallel x%d, one flat 698 936-float gradient bucket, one SUM all-reduce per step"
                                    % world) if training
                    else "scene-sharded replicas x%d (no data-path collective)" % world,
@@ -380,7 +498,7 @@ def main():
                    if training else
                    "PointMVSNet.forward(isFlow=True, isTest=True), BatchNorm in train mode (test.py:58)"},
         "execution": train_execution if training else execution,
-        "host_issue_ms_per_step": issued / args.steps * 1e3,
+        "host_issue_ms_per_depth_map": issued / (args.steps * sps) * 1e3,
         "gap_probe": gap_probe,
         "stage_timeline_us": stage_timeline,
         "roofline": roof,

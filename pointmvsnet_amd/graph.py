@@ -18,7 +18,10 @@ Weights: the graph reads the PACKED copies of the conv / GEMM weights (pointflow
 used during capture are pinned (never evicted while this object lives) and their source parameters are
 fingerprinted (version counter, storage address, device, dtype); a replay after ``load_state_dict``, an
 optimizer step, ``param.data = ...`` or ``model.to(...)`` re-captures instead of silently serving the old
-weights.  The warm-up forwards run on a snapshot of the BatchNorm buffers, which is restored before capture:
+weights.  Everything else the kernels read through RAW pointers baked into the graph (BatchNorm gamma / beta / running
+statistics inside the pf_bn_job blocks, the flow head's weight) is watched by storage address: rebinding one of those
+tensors (``bn.weight.data = ...``, a swapped buffer) re-captures too; in-place updates need nothing, the pointer sees
+them.  The warm-up forwards run on a snapshot of the BatchNorm buffers, which is restored before capture:
 constructing a GraphedForward does not advance running statistics or ``num_batches_tracked``.
 """
 import torch
@@ -63,6 +66,13 @@ class GraphedForward(object):
                 self.outputs = self.model.run(self.plan, self.static_img, self.isFlow)
         finally:
             self._packs = pointflow.pack_log_end(pin=True)
+        self._watched = [t for t in list(self.model.parameters()) + list(self.model.buffers())]
+        self._addresses = [t.data_ptr() for t in self._watched]
+
+    def _rebound(self):
+        """A parameter / buffer was re-bound to other storage since capture (the graph holds its old address)."""
+        now = list(self.model.parameters()) + list(self.model.buffers())
+        return len(now) != len(self._watched) or [t.data_ptr() for t in now] != self._addresses
 
     def __del__(self):
         try:
@@ -71,7 +81,7 @@ class GraphedForward(object):
             pass
 
     def __call__(self, data_batch):
-        if pointflow.pack_entries_stale(self._packs):      # weights changed since capture: the graph holds old packs
+        if pointflow.pack_entries_stale(self._packs) or self._rebound():   # the graph holds old packs / addresses
             torch.cuda.synchronize()
             self._capture()
             self.recaptures += 1

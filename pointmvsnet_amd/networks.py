@@ -47,20 +47,21 @@ class _EdgeConvTrain(torch.autograd.Function):
             pointflow.edge_conv_fused(x, False, 0, cin, B, N, idx, w1, w2, bn, concat, out, width,
                                       groups_per_stat=B, keep=keep)
             pointflow.flush_counters()
-        ctx.keep = keep
-        ctx.save_for_backward(x, idx, w1, w2)
+        # everything the backward recomputes from goes through save_for_backward (in-place modification checks, and a
+        # second backward -- retain_graph, checkpoint re-entrance -- finds the tensors again)
+        ctx.save_for_backward(x, idx, w1, w2, keep["LE"], keep["scale"], keep["shift"], keep["mean"], keep["invstd"])
         ctx.meta = (bool(concat), C, k, B, N, cin)
         return out.view(B, N, width).transpose(1, 2).contiguous()
 
     @staticmethod
     def backward(ctx, grad_out):
-        x, idx, w1, w2 = ctx.saved_tensors
+        x, idx, w1, w2, LE, scale, shift, mean, invstd = ctx.saved_tensors
+        keep = {"LE": LE, "scale": scale, "shift": shift, "mean": mean, "invstd": invstd}
         concat, C, k, B, N, cin = ctx.meta
         width = (2 if concat else 1) * C
         gy = grad_out.float().transpose(1, 2).contiguous().view(B * N, width)        # point-major rows
         with torch.cuda.device(x.device):
-            grad_le, grad_gamma, grad_beta = pointflow.edge_conv_backward(ctx.keep, idx, gy, C, k, B, N, B, concat)
-        ctx.keep = None
+            grad_le, grad_gamma, grad_beta = pointflow.edge_conv_backward(keep, idx, gy, C, k, B, N, B, concat)
         dle = grad_le.view(B, N, 2 * C)
         wcat = torch.cat([w1.detach().reshape(C, cin), w2.detach().reshape(C, cin)], dim=0).float()   # (2C, K)
         grad_x = torch.matmul(wcat.t(), dle.transpose(1, 2))                          # (B, K, N)

@@ -138,11 +138,17 @@ class AsyncEvalWriter(object):
                     _lib.call("pf_eval_prob_filter_f32", _lib.ptr(depth), _lib.ptr(conf_dev[k]), _lib.ptr(init_conf), h, w,
                               int(init_conf.shape[0]), int(init_conf.shape[1]), float(flow_thr), float(init_thr),
                               _lib.ptr(staging[o:o + h * w]), 1, _lib.stream())
+            # every read of ``preds`` is enqueued: the producer stream must not overwrite them before these packs ran
+            # (GraphedForward / GraphedTrainStep hand out STATIC buffers that the next replay writes; record_stream only
+            # talks to the allocator).  The packs take microseconds; the D2H copy below reads the staging buffer only.
+            packed = torch.cuda.Event()
+            packed.record(side)
             host = torch.empty(staging.shape, dtype=torch.float32, pin_memory=True)
             host.copy_(staging, non_blocking=True)
             staging.record_stream(side)
             job.event = torch.cuda.Event()
             job.event.record(side)
+        torch.cuda.current_stream(dev).wait_event(packed)
         cams = data_batch.get("cam_params_list_host")
         if cams is None:
             cams = data_batch["cam_params_list"].detach().cpu()

@@ -56,7 +56,9 @@ def load_pfm(file):
         width, height = int(dims.group(1)), int(dims.group(2))
         scale = float(f.readline().decode("ascii").rstrip())
         endian = "<" if scale < 0 else ">"
-        data = np.frombuffer(f.read(), dtype=endian + "f4")
+        # np.fromfile like the reference (utils/io.py:96): the caller gets a WRITABLE array -- depthfusion.py's
+        # probability_filter masks the loaded depth map in place (tools/depthfusion.py:165-168)
+        data = np.fromfile(f, dtype=endian + "f4")
     shape = (height, width, 3) if kind == "PF" else (height, width)
     return np.flipud(data.reshape(shape)), abs(scale)
 

@@ -72,12 +72,12 @@ if __name__ == "__main__":
     names = sys.argv[1:] or ["tiny", "small", "cfg5r", "cfg1", "cfg2", "cfg3"]
     table = json.load(open(OUT)) if os.path.exists(OUT) else {}
     for name in names:
-        seeds = SEEDS if name != "cfg3" else SEEDS[:1]        # cfg3: one minute per forward on 8 cores
+        seeds = SEEDS if name not in ("cfg3", "cfg5") else SEEDS[:1]   # cfg3 / cfg5: minutes per forward on 8 cores
         table[name] = dict(measure(name, seeds), seeds=list(seeds), eps=EPS)
         print(name, json.dumps(table[name]))
-        if name == "tiny":
-            table["tiny_train"] = dict(measure(name, seeds, train_intrinsics=True), seeds=list(seeds), eps=EPS)
-            print("tiny_train", json.dumps(table["tiny_train"]))
+        if name in ("tiny", "cfg4"):                          # training-mode forward (one lattice per iteration)
+            table[name + "_train"] = dict(measure(name, seeds, train_intrinsics=True), seeds=list(seeds), eps=EPS)
+            print(name + "_train", json.dumps(table[name + "_train"]))
     with open(OUT, "w") as f:
         json.dump(table, f, indent=1, sort_keys=True)
     print("wrote", OUT)

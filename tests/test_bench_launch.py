@@ -1,0 +1,61 @@
+"""bench.py --gpus N is a real launcher: with N > 1 and no torchrun environment it re-launches itself under
+torch.distributed.run with one process per GPU (the reference fans out inside one command through nn.DataParallel,
+train.py:177 / test.py:84).  CPU: the launch path with 2 gloo ranks (--launch-check stops after the rank count).
+GPU: 2 RCCL ranks end to end when the box has 2 GPUs."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra)
+    return env
+
+
+def _last_json(text):
+    lines = [l for l in text.splitlines() if l.startswith("{")]
+    assert lines, text[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_gpus_flag_spawns_that_many_ranks_world2_gloo():
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--launch-check"], env=_env(CUDA_VISIBLE_DEVICES="",
+                       HIP_VISIBLE_DEVICES=""), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = _last_json(p.stdout)
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["backend"] == "gloo"
+
+
+def test_gpus_flag_must_agree_with_the_torchrun_environment():
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "4", "--launch-check"], env=_env(WORLD_SIZE="2", RANK="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "WORLD_SIZE=2" in (p.stderr + p.stdout)
+
+
+def test_launch_command_is_the_drivers_form():
+    sys.path.insert(0, ROOT)
+    import bench
+    cmd = bench.launch_command(8, ["--gpus", "8", "--steps", "5"])
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-5] == BENCH and cmd[-4:] == ["--gpus", "8", "--steps", "5"]
+
+
+@pytest.mark.gpu
+def test_two_rccl_ranks_end_to_end_when_two_gpus_are_visible():
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU on this box; the 2-rank RCCL run needs two (the gloo test above covers the launcher)")
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1", "--scenes-per-step", "4",
+                        "--calibration-steps", "2", "--no-cpu-baseline"], env=_env(), capture_output=True, text=True,
+                       timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = _last_json(p.stdout)
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["value"] > 0 and out["cpu_baseline"] is None

@@ -53,6 +53,9 @@ def test_pfm_and_cam_round_trip(tmp_path):
     IO.write_pfm(str(tmp_path / "a.pfm"), img)
     back, scale = IO.load_pfm(str(tmp_path / "a.pfm"))
     assert np.array_equal(back, img) and scale == 1.0
+    # writable like the reference's np.fromfile result: depthfusion.py masks the loaded depth map in place
+    back[back < 2.0] = 0.0
+    assert float(back.max()) == 0.0
     IO.write_pfm_body(str(tmp_path / "b.pfm"), np.ascontiguousarray(img[::-1]).tobytes(), 5, 7)
     assert open(str(tmp_path / "a.pfm"), "rb").read() == open(str(tmp_path / "b.pfm"), "rb").read()
     with pytest.raises(Exception):
@@ -86,3 +89,28 @@ def test_device_packing_and_async_writer_write_the_reference_bytes(dev, tmp_path
     # the synchronous entry point takes the device path too
     E.eval_file_logger(batch_dev, preds_dev, str(tmp_path / "E2" / "Rectified" / "scan9" / "rect_004_3_r5000.png"), "o")
     _check_logger_files(str(tmp_path / "E2" / "o" / "scan9"), files)
+
+
+@pytest.mark.gpu
+def test_async_writer_orders_the_producer_behind_its_packs(dev, tmp_path):
+    """GraphedForward hands out STATIC prediction buffers that the next replay overwrites: ``submit`` must make the
+    producer stream wait for the pack kernels that still read them.  The writer's side stream is stalled with a long
+    sleep kernel, the maps are submitted and then immediately overwritten on the producer stream -- the files must
+    still hold the submitted values."""
+    preds, files, batch = _golden()
+    static = {k: v.to(dev).clone() for k, v in preds.items()}
+    batch_dev = {"cam_params_list": batch["cam_params_list"].to(dev), "img_list": batch["img_list"],
+                 "cam_params_list_host": batch["cam_params_list"]}
+    ref_path = str(tmp_path / "Eval" / "Rectified" / "scan9" / "rect_004_3_r5000.png")
+    w = E.AsyncEvalWriter(filter_thresholds=(0.2, 0.1))
+    w.submit(batch_dev, static, ref_path, "warm")                 # creates the side stream
+    with torch.cuda.stream(w._stream):
+        torch.cuda._sleep(400 * 1000 * 1000)                      # ~0.2 s: the packs of the next submit queue behind it
+    w.submit(batch_dev, static, ref_path, "out")
+    for v in static.values():                                      # "the next replay": same stream as the producer
+        v.fill_(123.0)
+    w.close()
+    scene = str(tmp_path / "Eval" / "out" / "scan9")
+    os.remove(os.path.join(scene, "00000003_flow2_prob_filtered.pfm"))
+    os.remove(os.path.join(scene, "00000003_flow1_prob_filtered.pfm"))
+    _check_logger_files(scene, files)

@@ -1,0 +1,123 @@
+"""Backward kernels at BASELINE config 4's size (the training step: 640x512, flow-2 as ONE 102 400-point lattice).
+
+tests/test_gpu_ops.py pins the backward operators against the CPU oracle's autograd at golden-fixture sizes (a few
+hundred points); the reference's own expand + gather backward allocates (B,C,N,N) and cannot run at N = 102 400
+(functions/functions.py:65-67).  Here the same operators run at the real size against a float64 torch composition
+that gathers with ``index_select`` (ATen on the GPU in double precision: an independent implementation of the same
+math; its scatter is a float64 atomic add, i.e. order-independent to ~1e-16).
+
+Tolerances are relative to the largest entry of each gradient: our scatters add float32 values in arrival order
+(the reference's kernel does too, gather_knn_kernel.cu:50-89), which is the error floor measured here.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import report
+from pointmvsnet_amd import synthetic
+from pointmvsnet_amd.networks import EdgeConv, EdgeConvNoC
+from pointmvsnet_amd.utils.feature_fetcher import FeatureFetcher
+from pointmvsnet_amd.utils.torch_utils import get_knn_3d
+
+pytestmark = pytest.mark.gpu
+
+LATTICE = (5, 128, 160)                 # config 4, PointFlow iteration 2: 5 hypotheses x 128 x 160 = 102 400 points
+
+
+def _lattice_xyz(dev, seed=5):
+    D, H, W = LATTICE
+    g = torch.Generator().manual_seed(seed)
+    zs = torch.linspace(-0.2, 0.2, D).view(1, 1, D, 1, 1)
+    ys = torch.linspace(-1.0, 1.0, H).view(1, 1, 1, H, 1)
+    xs = torch.linspace(-1.25, 1.25, W).view(1, 1, 1, 1, W)
+    xyz = torch.cat([xs.expand(1, 1, D, H, W), ys.expand(1, 1, D, H, W), zs.expand(1, 1, D, H, W)], dim=1)
+    xyz = xyz + 0.004 * torch.randn(1, 3, D, H, W, generator=g) + torch.tensor([0.3, -0.2, 4.0]).view(1, 3, 1, 1, 1)
+    return xyz.contiguous().to(dev)
+
+
+def _edgeconv_f64(x, idx, w1, w2, gamma, beta, concat, eps=1e-5):
+    """mean_k relu(BN(cat[l, e[idx] - l])) with batch statistics over (N, k), float64, gather by index_select
+    (reference networks.py:18-45 / :56-81, CUDA branch)."""
+    N, k = idx.shape[1], idx.shape[2]
+    l = torch.matmul(w1, x[0])                                                     # (C, N)
+    e = torch.matmul(w2, x[0])
+    nb = e.index_select(1, idx.reshape(-1)).view(-1, N, k)
+    cen = l.unsqueeze(-1).expand(-1, -1, k)
+    t = torch.cat([cen, nb - cen], dim=0) if concat else nb - cen
+    mean = t.mean(dim=(1, 2), keepdim=True)
+    var = t.var(dim=(1, 2), unbiased=False, keepdim=True)
+    y = (t - mean) / torch.sqrt(var + eps) * gamma.view(-1, 1, 1) + beta.view(-1, 1, 1)
+    return F.relu(y).mean(dim=2).unsqueeze(0)
+
+
+@pytest.mark.parametrize("cls,cin,cout", [(EdgeConvNoC, 136, 32), (EdgeConv, 32, 32), (EdgeConv, 64, 64)])
+def test_edgeconv_backward_at_cfg4_size_vs_float64(dev, cls, cin, cout):
+    D, H, W = LATTICE
+    N = D * H * W
+    idx = get_knn_3d(_lattice_xyz(dev), 5, knn=16)                                  # (1, N, 16) int64
+    mod = cls(cin, cout)
+    synthetic.seed_weights(mod, seed=1)
+    mod = mod.to(dev).train()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, cin, N, generator=g).to(dev).requires_grad_(True)
+    go = torch.randn(1, (2 if mod.concat else 1) * cout, N, generator=g).to(dev)
+    y = mod(x, idx)                                                                # the fused autograd node
+    y.backward(go)
+    # float64 composition, same device
+    p64 = {n: p.detach().double().requires_grad_(True) for n, p in mod.named_parameters()}
+    x64 = x.detach().double().requires_grad_(True)
+    y64 = _edgeconv_f64(x64, idx, p64["conv1.weight"][:, :, 0], p64["conv2.weight"][:, :, 0], p64["bn.weight"],
+                        p64["bn.bias"], mod.concat)
+    y64.backward(go.double())
+    errs = {"y": float((y.detach().double() - y64.detach()).abs().max() / y64.detach().abs().max()),
+            "dx": float((x.grad.double() - x64.grad).abs().max() / x64.grad.abs().max())}
+    for n, p in mod.named_parameters():
+        errs[n.replace(".", "_")] = float((p.grad.double() - p64[n].grad).abs().max() / p64[n].grad.abs().max())
+    report("cfg4size_edgeconv_backward_%s_%d" % (cls.__name__, cout), **errs)
+    assert errs["y"] < 1e-5, errs
+    assert max(errs.values()) < 2e-4, errs
+
+
+@pytest.mark.parametrize("C,h,w", [(16, 256, 320), (32, 128, 160), (64, 64, 80)])
+def test_fetch_backward_at_cfg4_size_vs_float64(dev, C, h, w):
+    """pf_fetch_backward_f32 on 102 400 points x 3 views against autograd of a float64 bilinear fetch (projection and
+    taps in double precision; the gradient w.r.t. the maps is continuous in the sample position, so the float32
+    projection of the kernel costs ~1e-5 of a texel, not a different answer)."""
+    data, _, _ = synthetic.make_config("cfg4", train_intrinsics=True)
+    cams = data["cam_params_list"]
+    V = cams.shape[1]
+    s = w / 640.0
+    K = cams[:, :, 1, :3, :3].clone()
+    K[:, :, :2, :3] *= s * 4.0                                     # train intrinsics are given at 1/4 resolution
+    E = cams[:, :, 0, :3, :4].clone()
+    g = torch.Generator().manual_seed(11)
+    n = LATTICE[0] * LATTICE[1] * LATTICE[2]
+    # points in front of the reference camera, spread over (and a little beyond) its image
+    uv = torch.stack([torch.rand(n, generator=g) * (w + 8) - 4, torch.rand(n, generator=g) * (h + 8) - 4,
+                      torch.ones(n)], dim=0)
+    depth = 425.0 + 500.0 * torch.rand(n, generator=g)
+    cam_pts = torch.matmul(torch.inverse(K[0, 0].double()), uv.double()) * depth.double()
+    R, t = E[0, 0, :, :3].double(), E[0, 0, :, 3:].double()
+    pts = torch.matmul(torch.inverse(R), cam_pts - t).float().unsqueeze(0)             # (1, 3, n)
+    maps = torch.randn(1, V, C, h, w, generator=g)
+    go = torch.randn(1, V, C, n, generator=g)
+
+    m = maps.to(dev).requires_grad_(True)
+    out = FeatureFetcher()(m, pts.to(dev), K.to(dev), E.to(dev))
+    out.backward(go.to(dev))
+
+    m64 = maps.to(dev).double().requires_grad_(True)
+    p = torch.matmul(E.to(dev).double()[0, :, :, :3], pts.to(dev).double()) + E.to(dev).double()[0, :, :, 3:]   # (V,3,n)
+    nuv = torch.stack([p[:, 0] / p[:, 2], p[:, 1] / p[:, 2], torch.ones_like(p[:, 0])], dim=1)     # (V,3,n)
+    pix = torch.matmul(K.to(dev).double()[0], nuv)[:, :2]                                                 # (V,2,n)
+    grid = (pix - 0.5).transpose(1, 2).reshape(V, n, 1, 2).clone()
+    grid[..., 0] = grid[..., 0] / float(w - 1) * 2 - 1.0
+    grid[..., 1] = grid[..., 1] / float(h - 1) * 2 - 1.0
+    ref = F.grid_sample(m64[0], grid, mode="bilinear", padding_mode="zeros", align_corners=True).squeeze(3)
+    ref.backward(go.to(dev).double()[0])
+    scale = float(m64.grad.abs().max())
+    e_out = float((out.detach().double()[0] - ref.detach()).abs().max() / ref.detach().abs().max())
+    e_grad = float((m.grad.double() - m64.grad).abs().max() / scale)
+    report("cfg4size_fetch_backward_C%d" % C, out_rel=e_out, grad_rel=e_grad, grad_scale=scale)
+    assert e_out < 1e-3                       # float32 projection: ~1e-4 of a texel on maps with O(1) texel contrast
+    assert e_grad < 1e-3

@@ -81,8 +81,11 @@ def _model(dev):
 
 @pytest.mark.parametrize("tag,cfg", [("model_tiny_test", "tiny"), ("model_small_test", "small"),
                                      ("model_cfg5r_test", "cfg5r"), ("model_cfg1_test", "cfg1"),
-                                     ("model_cfg2_test", "cfg2"), ("model_cfg3_test", "cfg3")])
+                                     ("model_cfg2_test", "cfg2"), ("model_cfg3_test", "cfg3"),
+                                     ("model_cfg5_test", "cfg5")])
 def test_forward_test_mode_vs_reference(dev, tag, cfg):
+    """Golden depth maps of the reference itself; "cfg5" is BASELINE configs[4] at FULL size (1600x1152, 7 views, 96
+    planes, 3 iterations, variance aggregation -- there is no reference code for the visibility-aware variant)."""
     g = load_golden(tag)
     data, img_scales, inter_scales = synthetic.make_config(cfg)
     net = _model(dev)
@@ -102,22 +105,26 @@ def test_forward_test_mode_vs_reference(dev, tag, cfg):
             assert torch.allclose(got, g[key], rtol=2e-2, atol=1e-3), key
 
 
-def test_forward_train_mode_no_grad_vs_reference(dev):
-    g = load_golden("model_tiny_train")
-    data, img_scales, inter_scales = synthetic.make_config("tiny", train_intrinsics=True)
+@pytest.mark.parametrize("cfg", ["tiny", "cfg4"])
+def test_forward_train_mode_no_grad_vs_reference(dev, cfg):
+    """isTest=False: training intrinsics, every PointFlow iteration on ONE lattice; "cfg4" = BASELINE configs[3]'s
+    per-GPU scene at full size (640x512, flow-2 on 102 400 points)."""
+    g = load_golden("model_%s_train" % cfg)
+    data, img_scales, inter_scales = synthetic.make_config(cfg, train_intrinsics=True)
     net = _model(dev)
     with torch.no_grad():
         preds = net(_to(data, dev), img_scales, inter_scales, isFlow=True, isTest=False)
-    worst, _ = _compare(preds, g, "model_tiny_train_fused", "tiny_train")
+    worst, _ = _compare(preds, g, "model_%s_train_fused" % cfg, cfg + "_train")
     assert worst < DEPTH_RTOL
 
 
-def test_forward_autograd_path_vs_reference_and_backward(dev):
-    g = load_golden("model_tiny_train")
-    data, img_scales, inter_scales = synthetic.make_config("tiny", train_intrinsics=True)
+@pytest.mark.parametrize("cfg", ["tiny", "cfg4"])
+def test_forward_autograd_path_vs_reference_and_backward(dev, cfg):
+    g = load_golden("model_%s_train" % cfg)
+    data, img_scales, inter_scales = synthetic.make_config(cfg, train_intrinsics=True)
     net = _model(dev)
     preds = net(_to(data, dev), img_scales, inter_scales, isFlow=True, isTest=False)
-    worst, _ = _compare(preds, g, "model_tiny_train_autograd", "tiny_train")
+    worst, _ = _compare(preds, g, "model_%s_train_autograd" % cfg, cfg + "_train")
     assert worst < DEPTH_RTOL
     loss = preds["flow2"].mean() + preds["coarse_depth_map"].mean()
     loss.backward()

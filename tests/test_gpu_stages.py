@@ -43,8 +43,47 @@ def _oracle_flow_inputs(cfg, it):
     return net, sd, data, pyr, prior, s, inter, h, w
 
 
-@pytest.mark.parametrize("cfg,it", [("tiny", 0), ("tiny", 1), ("small", 2), ("cfg5r", 2), ("cfg2", 0), ("cfg2", 1)])
+def _flow_variances_f64(pyr, cur, interval, Kf, ext, R_inv, t):
+    """Stage F's 112 variance channels evaluated in float64 from the same float32 inputs (model.py:165-190 with every
+    intermediate in double precision): the yardstick that says how much of a float32-vs-float32 difference is the
+    conditioning of the stage itself (world coordinates of ~600 mm projected to 1e-4 of a texel, then
+    E[x^2] - E[x]^2 of the samples) and how much would be an implementation error."""
+    B, _, h, w = cur.shape
+    dd = lambda x: x.double()   # noqa: E731
+    grid = dd(O.pixel_grid(h, w)).view(1, 1, 3, -1).expand(B, 1, 3, -1)
+    uv = torch.matmul(torch.inverse(dd(Kf[:, 0])).unsqueeze(1), grid)
+    V = Kf.shape[1]
+    resized = []
+    for name in ("conv1", "conv2", "conv3"):
+        fm = dd(pyr[name])
+        c, fh, fw = fm.shape[2:]
+        resized.append(F.interpolate(fm.reshape(-1, c, fh, fw), (h, w), mode="bilinear", align_corners=False))
+    planes = []
+    for i in (-2, -1, 0, 1, 2):
+        d = dd(cur) + dd(interval).view(-1, 1, 1, 1) * i
+        world = torch.matmul(dd(R_inv[:, 0:1]), uv * d.view(B, 1, 1, -1) - dd(t[:, 0:1]))[:, 0]         # (B,3,N)
+        p = torch.matmul(dd(ext[:, :, :, :3]), world.unsqueeze(1)) + dd(ext[:, :, :, 3:])                  # (B,V,3,N)
+        nuv = torch.stack([p[:, :, 0] / p[:, :, 2], p[:, :, 1] / p[:, :, 2], torch.ones_like(p[:, :, 0])], dim=2)
+        pix = torch.matmul(dd(Kf), nuv)[:, :, :2]                                                          # (B,V,2,N)
+        g = (pix - 0.5).permute(0, 1, 3, 2).reshape(B * V, -1, 1, 2).clone()
+        g[..., 0] = g[..., 0] / float(w - 1) * 2 - 1.0
+        g[..., 1] = g[..., 1] / float(h - 1) * 2 - 1.0
+        chunks = []
+        for fm in resized:
+            f = F.grid_sample(fm, g, mode="bilinear", padding_mode="zeros", align_corners=True).squeeze(3)
+            f = f.view(B, V, fm.shape[1], -1)
+            chunks.append((f ** 2).mean(dim=1) - f.mean(dim=1) ** 2)
+        planes.append(torch.cat(chunks, dim=1))
+    return torch.stack(planes, dim=2)                                                                      # (B,112,5,N)
+
+
+# ("cfg3", 2): BASELINE configs[2]'s last iteration at full size -- 16 sub-grids x 96 000 points (about two CPU minutes
+# of oracle on the GPU box; the float64 yardstick is skipped there)
+@pytest.mark.parametrize("cfg,it", [("tiny", 0), ("tiny", 1), ("small", 2), ("cfg5r", 2), ("cfg2", 0), ("cfg2", 1),
+                                    ("cfg3", 2)])
 def test_flow_iteration_stagewise_vs_oracle(dev, cfg, it):
+    if cfg == "cfg3":
+        torch.set_num_threads(max(1, min(16, __import__("os").cpu_count() or 1)))
     net, sd, data, pyr, prior, s, inter, h, w = _oracle_flow_inputs(cfg, it)
     cams = data["cam_params_list"]
     ext, R, t, R_inv = O.split_cameras(cams)
@@ -83,7 +122,20 @@ def test_flow_iteration_stagewise_vs_oracle(dev, cfg, it):
     assert e_x < 2e-6                                  # normalised coordinates are O(1)
     assert torch.equal(f_gpu[:, 112:115].cpu(), x_gpu.cpu())             # xyz.repeat(1,8,1) layout
     assert torch.equal(f_gpu[:, 133:136].cpu(), x_gpu.cpu())
-    assert e_f < 1e-4 * max(var_scale, 1e-3)           # variance of bilinear samples (cancellation-limited)
+    # SURVEY 8(c) asks <= 1e-5 relative per operator; this stage cannot be held to it against ANOTHER float32
+    # evaluation: the oracle's own features are this far from the float64 value of the same expression (measured
+    # below), because the projection of ~600 mm float32 world coordinates moves a tap by ~1e-4 texel and the variance
+    # E[x^2] - E[x]^2 cancels.  So: (1) GPU vs oracle within 1e-4 of the feature scale, and (2) the GPU no farther
+    # from the float64 value than twice the oracle is (+ 2e-6 of the scale) -- i.e. as accurate as the reference.
+    assert e_f < 1e-4 * max(var_scale, 1e-3)
+    if cfg != "cfg3":
+        with torch.no_grad():
+            f64 = _flow_variances_f64(pyr, cur, interval, Kf, ext, R_inv, t)
+        f64 = f64.view(112, 5, hs, ratio, ws, ratio).permute(3, 5, 0, 1, 2, 4).reshape(ratio * ratio, 112, -1)
+        e_gpu64 = float((f_gpu.cpu()[:, :112].double() - f64).abs().max())
+        e_ref64 = float((f_ref[:, :112].double() - f64).abs().max())
+        report("stage_F64_%s_it%d" % (cfg, it), gpu_vs_f64=e_gpu64, oracle_vs_f64=e_ref64, feat_scale=var_scale)
+        assert e_gpu64 <= 2.0 * e_ref64 + 2e-6 * max(var_scale, 1e-3), (e_gpu64, e_ref64)
 
     # ---- stages K..H on the ORACLE's features: identical inputs => identical neighbour sets ----------
     f_in, x_in = f_ref.to(dev).contiguous(), x_ref.to(dev).contiguous()

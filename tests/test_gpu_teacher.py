@@ -1,0 +1,163 @@
+"""Teacher-forced end-to-end parity: every PointFlow iteration of the GPU pipeline against the ORACLE'S iteration
+on the GPU's own inputs (north_star: "depth maps within 1e-4 relative").
+
+tests/test_gpu_model.py compares whole forwards with the reference's golden maps and has to bound the result by the
+reference's measured self-sensitivity, because an iteration is discontinuous in its prior depth (a nearly tied 16th
+neighbour flips under a 1-ulp change).  This file removes the envelope from the argument.  For BASELINE configs 2
+and 3 at full size, after ONE GPU forward, for every iteration i:
+
+  prior   = the GPU's own coarse_depth_map / flow_i        (copied to the host)
+  pyramid = the GPU flow tower's own three levels           (copied to the host)
+
+(A) the oracle's iteration (flow_point_features + kNN + EdgeConv x3 + MLP + head, oracle/pointflow_oracle.py) runs on
+    that prior and pyramid with the GPU's own neighbour indices fed to it.  Both sides then evaluate the same
+    continuous function on the same inputs: the GPU's flow_{i+1} must match in the MAX norm, every pixel, no envelope.
+(B) the neighbour indices themselves: the GPU's kNN (on the GPU's xyz) against the oracle's kNN (on the oracle's xyz
+    of the same prior).  Rows whose neighbour SETS differ must be near-ties: with eps = max |xyz_gpu - xyz_oracle|
+    (float32 rounding of the un-projection, asserted < 2e-6), a squared distance moves by at most
+    4*sqrt(3*d2)*eps + 12*eps^2 (+ its own float32 rounding), and the 16th / 17th ranked candidates of such a row
+    must be closer than that.  The kernel's exactness on ITS OWN input is pinned bit for bit by
+    tests/test_gpu_ops.py (NumPy brute force including order).
+(C) cfg 2 only (a second oracle chain per iteration costs CPU minutes at cfg 3): the oracle's iteration with ITS OWN
+    neighbours.  Every pixel that deviates by more than the bound of (A) must lie in the receptive field of a row
+    of (B) -- EdgeConv x3 over 5x5x5 windows: a changed row reaches the E2 output of points up to 4 lattice steps away
+    in its own sub-grid -- and every pixel outside those fields must meet the bound.
+
+(A) + (B) together say: on the same prior the GPU differs from the reference algorithm ONLY by the neighbour choice in
+rows where the choice is undetermined at float32 resolution of the inputs.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import report
+from oracle import bruteforce as BF
+from oracle import pointflow_oracle as O
+from pointmvsnet_amd import pointflow, synthetic
+from pointmvsnet_amd.model import PointMVSNet, _Cameras
+from pointmvsnet_amd.utils.torch_utils import knn_lattice
+
+pytestmark = pytest.mark.gpu
+
+# max-norm bound of (A): the contract is 1e-4 relative; measured values are in profiles/*parity_report.jsonl
+TEACHER_RTOL = 1e-5
+XYZ_EPS_MAX = 2e-6
+
+
+def _to(data, dev):
+    out = {k: v.to(dev) for k, v in data.items()}
+    out["cam_params_list_host"] = data["cam_params_list"]
+    out["mean_host"], out["std_host"] = data["mean"], data["std"]
+    return out
+
+
+def _subgrid_major(t, C, hs, ws, r):
+    """(1,C,5,h,w) / (1,C,5,h*w) oracle layout -> (r*r, C, 5*hs*ws) sub-grid-major (pointflow's group order)."""
+    return t.reshape(C, 5, hs, r, ws, r).permute(3, 5, 0, 1, 2, 4).reshape(r * r, C, -1)
+
+
+def _oracle_iteration(feature, xyz, cur, interval, sd, r, feed=None):
+    """The flow stage after feature assembly, sub-grids sequential (model.py:231-267); ``feed``: an iterator of
+    (1,Ng,16) index tensors that replaces the oracle's kNN, one per sub-flow call in (i, j) order."""
+    _, _, _, h, w = xyz.shape
+    hs, ws = h // r, w // r
+    orig = O.knn_lattice
+    if feed is not None:
+        O.knn_lattice = lambda x, kernel_size=5, knn=16, return_code=False: next(feed)
+    try:
+        flow = torch.zeros(1, 1, hs, r, ws, r)
+        f7 = feature.view(1, 136, 5, hs, r, ws, r)
+        x7 = xyz.view(1, 3, 5, hs, r, ws, r)
+        for i in range(r):
+            for j in range(r):
+                fij, _ = O.sub_flow(x7[:, :, :, :, i, :, j], f7[:, :, :, :, i, :, j], interval, sd, 16)
+                flow[:, :, :, i, :, j] = fij
+    finally:
+        O.knn_lattice = orig
+    return cur + flow.view(1, 1, h, w)
+
+
+@pytest.mark.parametrize("cfg,with_own_knn", [("cfg2", True), ("cfg3", False)])
+def test_teacher_forced_iterations_vs_oracle(dev, cfg, with_own_knn):
+    threads = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))      # the oracle's small operators oversubscribe
+    try:
+        _run(dev, cfg, with_own_knn)
+    finally:
+        torch.set_num_threads(threads)
+
+
+def _run(dev, cfg, with_own_knn):
+    data, img_scales, inter_scales = synthetic.make_config(cfg)
+    net = PointMVSNet()
+    synthetic.seed_weights(net, seed=0)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    net = net.to(dev).train()
+    batch = _to(data, dev)
+    with torch.no_grad():
+        preds = net(batch, img_scales, inter_scales, isFlow=True, isTest=True)
+        pyr_dev = net.run_flow_tower(batch["img_list"])                # the same bits the forward used
+        pointflow.flush_counters()
+    pyr = {n: pyr_dev[n].cpu() for n in ("conv1", "conv2", "conv3")}
+    cams = data["cam_params_list"]
+    ext, R, t, R_inv = O.split_cameras(cams)
+    cam = _Cameras(cams, True)
+    H, W = data["img_list"].shape[3:]
+    prior_dev = preds["coarse_depth_map"]
+    for it, (s, inter) in enumerate(zip(img_scales, inter_scales)):
+        h, w = int(H * s), int(W * s)
+        r = 1 if s == 0.125 else int(s * 8)
+        hs, ws = h // r, w // r
+        interval = inter * cams[:, 0, 1, 3, 1]
+        Kf = cams[:, :, 1, :3, :3].clone()
+        Kf[:, :, :2, :3] *= s
+        prior = prior_dev.cpu()
+        got = preds["flow%d" % (it + 1)].cpu()
+        with torch.no_grad():
+            cur = prior if prior.shape[2] == h else F.interpolate(prior, (h, w), mode="nearest")
+            feature, xyz = O.flow_point_features(pyr, cur, interval, Kf, ext, R_inv, t, data["mean"], data["std"])
+            # the GPU's own neighbour choice for this prior (deterministic kernels: what the forward used)
+            packed = cam.packed(cam.flow_intrinsics(s), data["mean"], data["std"], interval).to(dev)
+            levels = pointflow.flow_pyramid([pyr_dev[n][0].contiguous() for n in ("conv1", "conv2", "conv3")], h, w)
+            _, x_gpu = pointflow.flow_features(levels, prior_dev[0, 0].contiguous(), packed[0, -1:], packed[0], h, w, r)
+            idx_gpu = knn_lattice(x_gpu.view(r * r, 3, 5, hs, ws), 5, 16).cpu()            # (G, Ng, 16)
+            # ---- (A) same prior, same pyramid, same neighbours: max norm, every pixel -------------------------
+            want_a = _oracle_iteration(feature, xyz, cur, interval, sd, r,
+                                       feed=iter([idx_gpu[g:g + 1] for g in range(r * r)]))
+        rel_a = ((got - want_a).abs() / want_a.abs())
+        # ---- (B) the neighbour rows that differ from the oracle's own choice are near-ties -----------------------
+        x_ref = _subgrid_major(xyz, 3, hs, ws, r)
+        eps = float((x_gpu.cpu() - x_ref).abs().max())
+        idx_ref = torch.stack([O.knn_lattice(x_ref[g].reshape(1, 3, 5, hs, ws), 5, 16)[0] for g in range(r * r)])
+        differ = ~(idx_gpu.sort(dim=2)[0] == idx_ref.sort(dim=2)[0]).all(dim=2)        # (G, Ng)
+        worst_gap = 0.0
+        for g in torch.nonzero(differ.any(dim=1)).flatten().tolist():
+            d2 = np.sort(BF.knn_window_d2(x_ref[g].reshape(3, 5, hs, ws).numpy(), 5).astype(np.float64), axis=0)
+            for n in torch.nonzero(differ[g]).flatten().tolist():
+                d16, d17 = d2[15, n], d2[16, n]
+                slack = sum(4.0 * np.sqrt(3.0 * d) * eps + 12.0 * eps * eps + 4.0 * 6e-8 * d for d in (d16, d17))
+                worst_gap = max(worst_gap, (d17 - d16) / max(slack, 1e-30))
+                assert d17 - d16 <= slack, ("neighbour sets differ without a near-tie", cfg, it, g, n, d16, d17, slack)
+        report("teacher_%s_it%d" % (cfg, it), rel_max_same_knn=float(rel_a.max()), rel_median=float(rel_a.median()),
+               xyz_eps=eps, rows_differing=float(differ.sum()), rows=float(differ.numel()),
+               worst_gap_over_slack=worst_gap)
+        assert eps < XYZ_EPS_MAX
+        assert float(rel_a.max()) < TEACHER_RTOL, (cfg, it, float(rel_a.max()))
+        assert float(differ.float().mean()) < 5e-3
+        # ---- (C) the oracle with its own neighbours: deviations only inside the fields of the rows of (B) -------
+        if with_own_knn:
+            with torch.no_grad():
+                want_c = _oracle_iteration(feature, xyz, cur, interval, sd, r)
+            rel_c = ((got - want_c).abs() / want_c.abs())[0, 0]                          # (h, w)
+            pix = differ.view(r, r, 5, hs, ws).any(dim=2).float()                         # rows -> pixels of a sub-grid
+            field = F.max_pool2d(pix.view(1, r * r, hs, ws), 9, stride=1, padding=4).view(r, r, hs, ws)
+            field = field.permute(2, 0, 3, 1).reshape(h, w) > 0                           # back to image order
+            outside = rel_c[~field]
+            report("teacher_own_knn_%s_it%d" % (cfg, it), rel_max=float(rel_c.max()),
+                   frac_gt_1e4=float((rel_c > 1e-4).float().mean()), field_frac=float(field.float().mean()),
+                   rel_max_outside_fields=float(outside.max()) if outside.numel() else 0.0)
+            assert not bool(((rel_c > TEACHER_RTOL) & ~field).any()), "a pixel outside every flipped row's field deviates"
+        prior_dev = preds["flow%d" % (it + 1)]

@@ -127,7 +127,8 @@ def test_volume_conv_vs_reference():
 
 
 @pytest.mark.parametrize("tag,cfg,is_test", [("model_tiny_test", "tiny", True), ("model_tiny_train", "tiny", False),
-                                             ("model_small_test", "small", True)])
+                                             ("model_small_test", "small", True),
+                                             ("model_cfg4_train", "cfg4", False)])
 def test_whole_forward_vs_reference(tag, cfg, is_test):
     g = load_golden(tag)
     data, img_scales, inter_scales = synthetic.make_config(cfg, train_intrinsics=not is_test)
