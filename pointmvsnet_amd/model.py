@@ -266,7 +266,6 @@ class PointMVSNet(nn.Module):
         self._grid_cache = {}
         self._plan = None
         self._tplan = None
-        self._side_stream = None
 
     # ------------------------------------------------------------------------------------------
     def _pixel_grid(self, h, w, device):
@@ -323,62 +322,27 @@ class PointMVSNet(nn.Module):
         dev = img_list.device
         main = torch.cuda.current_stream()
         pointflow.stamp("start")
-        mode = int(os.environ.get("PF_FORK_MODE", "0"))
-        early = None
-        if isFlow and pointflow.CONCURRENCY >= 1 and mode == 3:      # both towers side by side from the first kernel
-            if self._side_stream is None or self._side_stream.device != dev:
-                self._side_stream = torch.cuda.Stream(device=dev)
-            self._side_stream.wait_stream(main)
-            with torch.cuda.stream(self._side_stream):
-                early = self.run_flow_tower(img_list)
-                pointflow.stamp("flow_tower_end")
-                for p in early.values():
-                    p.record_stream(main)
         feature_list = self.run_coarse_tower(img_list)
         pointflow.stamp("coarse_tower_end")
-        pyramids, side = None, None
-        if early is not None:
-            pyramids, side = early, self._side_stream
-            preds = self.run_coarse_stage(plan, feature_list)
-        elif isFlow and pointflow.CONCURRENCY < 1:
-            pyramids = self.run_flow_tower(img_list)
-            preds = self.run_coarse_stage(plan, feature_list)
-        elif isFlow:
-            if self._side_stream is None or self._side_stream.device != dev:
-                self._side_stream = torch.cuda.Stream(device=dev)
-            side = self._side_stream
-
-            def tower():
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    out = self.run_flow_tower(img_list)
-                    pointflow.stamp("flow_tower_end")
-                    for p in out.values():
-                        p.record_stream(main)
-                return out
-
-            if mode == 0:                      # flow tower captured first, coarse stage second
-                pyramids = tower()
-                preds = self.run_coarse_stage(plan, feature_list)
-            elif mode == 1:                    # coarse stage captured first
-                ev = torch.cuda.Event()
-                ev.record(main)
-                preds = self.run_coarse_stage(plan, feature_list)
-                side.wait_event(ev)
-                with torch.cuda.stream(side):
-                    pyramids = self.run_flow_tower(img_list)
-                    for p in pyramids.values():
-                        p.record_stream(main)
-            else:                              # fork after the warp: the flow tower's first node follows the fetch kernel
-                preds = self.run_coarse_stage(plan, feature_list, fork=tower)
-                pyramids = preds.pop("_forked")
-        else:
-            preds = self.run_coarse_stage(plan, feature_list)
         if not isFlow:
+            preds = self.run_coarse_stage(plan, feature_list)
             pointflow.flush_counters()
             return preds
-        if side is not None:
-            main.wait_stream(side)
+        if pointflow.CONCURRENCY < 1:
+            pyramids = self.run_flow_tower(img_list)
+            preds = self.run_coarse_stage(plan, feature_list)
+            return self.run_flows(plan, pyramids, preds)
+        # (fork structure measured in round 2, profiles/r02p_fork_mode_ab.log: flow tower captured first / coarse stage
+        # first / fork after the warp / both towers side by side from the first kernel: 598 / 594 / 596 / within 0.3 %)
+        side = pointflow.side_stream(dev, 0)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            pyramids = self.run_flow_tower(img_list)
+            pointflow.stamp("flow_tower_end")
+            for p in pyramids.values():
+                p.record_stream(main)
+        preds = self.run_coarse_stage(plan, feature_list)
+        main.wait_stream(side)
         return self.run_flows(plan, pyramids, preds)
 
     # The four device-only stages of ``run`` (GraphedForward may capture them as separate graphs).
@@ -391,13 +355,10 @@ class PointMVSNet(nn.Module):
         return out["conv3"].contiguous()
 
     def run_flow_tower(self, img_list):
-        for _ in range(int(os.environ.get("PF_PROBE_REPEAT_TOWER", "0"))):     # critical-path probe (bench only)
-            self.flow_img_conv.forward_views(img_list, need=("conv1",))
         return self.flow_img_conv.forward_views(img_list)
 
-    def run_coarse_stage(self, plan, feature_list, fork=None):
-        """Coarse stage after the tower (reference model.py:79-130): warp, variance, VolumeConv, soft-argmin.
-        ``fork`` (a callable) is invoked right after the warp has been enqueued (see run)."""
+    def run_coarse_stage(self, plan, feature_list):
+        """Coarse stage after the tower (reference model.py:79-130): warp, variance, VolumeConv, soft-argmin."""
         B, D = plan.B, plan.D
         preds = collections.OrderedDict()
         if isinstance(feature_list, ChannelLast):
@@ -408,17 +369,12 @@ class PointMVSNet(nn.Module):
         cost, world_points = frustum_variance(feature_list, plan.d("Kinv0"), plan.d("Rinv0"), plan.d("t0"),
                                               plan.d("depths"), plan.d("K_coarse"), plan.d("ext"))
         pointflow.stamp("warp_end")
-        forked = fork() if fork is not None else None
         preds["world_points"] = world_points
         filtered = self.coarse_vol_conv.forward_fused(cost.view(B, C, D, FH, FW)).squeeze(1)   # (B,D,FH,FW)
-        for _ in range(int(os.environ.get("PF_PROBE_REPEAT_SOFTARGMIN", "0"))):   # critical-path probe (bench only)
-            pointflow.soft_argmin_params(filtered, plan.d("sa_params"))
         pred_depth, prob_map = pointflow.soft_argmin_params(filtered, plan.d("sa_params"))
         pointflow.stamp("coarse_stage_end")
         preds["coarse_depth_map"] = pred_depth
         preds["coarse_prob_map"] = prob_map
-        if fork is not None:
-            preds["_forked"] = forked
         return preds
 
     def run_flows(self, plan, pyramids, preds):

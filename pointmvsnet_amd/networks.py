@@ -317,160 +317,57 @@ class VolumeConv(nn.Module):
 
     def _bottom_fusable(self):
         blocks = (self.conv3_0, self.conv3_1, self.conv4_0)
-        return (bool(pointflow.UNET_BOTTOM) and all(b.bn is not None and b.relu for b in blocks)
+        return (all(b.bn is not None and b.relu for b in blocks)
                 and pointflow.conv3d_bottom_supported(self.conv3_0.conv)
                 and pointflow.conv3d_bottom_supported(self.conv3_1.conv)
                 and pointflow.deconv3d_bottom_supported(self.conv4_0.conv))
 
-    def _encoder_lazy(self, x):
-        if not int(_os.environ.get("PF_VC_LAZY", "0")) or not self._bottom_fusable():
-            return False
-        blocks = (self.conv1_0, self.conv2_0, self.conv1_1, self.conv2_1)
-        if not all(b.bn is not None and b.relu and (b.bn.training or not b.bn.track_running_stats) for b in blocks):
-            return False
-        D, H, W = x.shape[2:]
-        h = ((D - 1) // 2 + 1, (H - 1) // 2 + 1, (W - 1) // 2 + 1)
-        q = ((h[0] - 1) // 2 + 1, (h[1] - 1) // 2 + 1, (h[2] - 1) // 2 + 1)
-
-        def ok(conv, vol):
-            out = vol if conv.stride == (1, 1, 1) else tuple((v - 1) // 2 + 1 for v in vol)
-            return (type(conv) is nn.Conv3d and conv.kernel_size == (3, 3, 3) and conv.padding == (1, 1, 1)
-                    and conv.stride in ((1, 1, 1), (2, 2, 2)) and conv.dilation == (1, 1, 1) and conv.groups == 1
-                    and conv.bias is None and conv.in_channels % 4 == 0 and 8 < conv.out_channels <= 32
-                    and out[0] * out[1] * out[2] >= 2048)
-        return (ok(self.conv1_0.conv, (D, H, W)) and ok(self.conv2_0.conv, h) and ok(self.conv1_1.conv, h)
-                and ok(self.conv2_1.conv, q))
-
-    def _decoder_lazy(self, x):
-        if not int(_os.environ.get("PF_DEC_LAZY", "0")) or not self._bottom_fusable():
-            return False
-        blocks = (self.conv4_0, self.conv5_0, self.conv6_0)
-        if not all(b.bn is not None and b.relu and (b.bn.training or not b.bn.track_running_stats) for b in blocks):
-            return False
-        D, H, W = x.shape[2:]
-        q = tuple((((v - 1) // 2 + 1) - 1) // 2 + 1 for v in (D, H, W))
-        return (q[0] * q[1] * q[2] >= 2048 and self.conv5_0.conv.in_channels <= 64
-                and self.conv6_0.conv.in_channels <= 64 and all(_deconv_block_ok(b) for b in blocks[1:]))
-
     def forward_fused(self, x):
         """Inference fast path: own conv / deconv kernels + HIP BatchNorm/ReLU kernels (statistics pooled over the
-        batch); the library convolution only for shapes none of the kernels is built for."""
+        batch); the library convolution only for shapes none of the kernels is built for.  (Variants measured equal
+        or slower in round 2 and removed in round 3 -- encoder / decoder BatchNorms resolved by the consuming
+        kernels, the skip branches or conv0_1 on streams of their own: DESIGN.md section 6.)"""
         B = x.shape[0]
         f = lambda blk, t: _block_fused(blk, t, B)   # noqa: E731
-        # the full-resolution branch (conv0_1, 69 % of the FLOPs) is independent of the encoder/decoder
-        # chain of small layers until the final add: run it on an auxiliary stream
-        aux = None
-        if pointflow.CONCURRENCY >= 3:
-            main = torch.cuda.current_stream()
-            aux = pointflow.side_stream(x.device, 2)
-            aux.wait_stream(main)
-            with torch.cuda.stream(aux):
-                full = f(self.conv0_1, x)
-                full.record_stream(main)
+        blk0, blk6 = self.conv0_1, self.conv6_0
+        train0 = blk0.bn is not None and blk0.relu and (blk0.bn.training or not blk0.bn.track_running_stats)
+        if train0 and _conv3d_fusable(blk0.conv, x):
+            # raw output + statistics: its BatchNorm + ReLU waits for the decoder and rides on the last skip add
+            full = pointflow.conv3d_k3(x.contiguous(), blk0.conv.weight, 1, True)
         else:
-            blk = self.conv0_1
-            training_bn = blk.bn is not None and (blk.bn.training or not blk.bn.track_running_stats)
-            if aux is None and training_bn and _conv3d_fusable(blk.conv, x):
-                # its BatchNorm+ReLU waits for the decoder: applied together with the last skip add below
-                for _ in range(int(_os.environ.get("PF_PROBE_REPEAT_CONV0", "0"))):   # critical-path probe (bench only)
-                    pointflow.conv3d_k3(x.contiguous(), blk.conv.weight, 1, False)
-                full = pointflow.conv3d_k3(x.contiguous(), blk.conv.weight, 1, True)
-            else:
-                full = f(blk, x)
+            full = f(blk0, x)
         pointflow.stamp("conv0_1_end")
-        # Encoder with its BatchNorms left PENDING: conv1_0 / conv2_0 write raw outputs, and each of their consumers
-        # (conv2_0, conv1_1 / conv3_0, conv2_1) applies -- and with few statistics rows finalizes -- that BatchNorm +
-        # ReLU while staging: two normalise passes (and their graph nodes) less on the chain.  Measured equal
-        # (659 / 657 / 660 vs 659 / 659 depth maps/s, profiles/r02aj_small_ab.txt: four consumers pay the resolve,
-        # and the chain runs beside the flow tower), so it is OFF by default: PF_VC_LAZY=1 turns it on.
-        lazy_enc = self._encoder_lazy(x)
-        dec_lazy = self._decoder_lazy(x)
-        a_half = a_quarter = a_up = None
-        if lazy_enc:
-            half, p_half = pointflow.conv3d_k3(x.contiguous(), self.conv1_0.conv.weight, 2, True)
-            a_half = pointflow.bn_affine_rows(half, self.conv1_0.bn, B, p_half, lazy=True)
-            quarter, p_quarter = pointflow.conv3d_k3(half, self.conv2_0.conv.weight, 2, True, in_affine=a_half,
-                                                     samples_per_stat=B)
-            a_quarter = pointflow.bn_affine_rows(quarter, self.conv2_0.bn, B, p_quarter, lazy=True)
-        else:
-            half = f(self.conv1_0, x)
-            quarter = f(self.conv2_0, half)
-        # The skip branches conv1_1 / conv2_1 (+ their BatchNorms) are needed only by the decoder: with
-        # PF_VC_SIDE=1 they run on an auxiliary stream beside the bottom of the U-Net (dependent chain of small,
-        # latency-bound kernels: conv3_0, conv3_1, conv4_0)
-        side = None
-        if int(_os.environ.get("PF_VC_SIDE", "0")) and not lazy_enc:
-            main = torch.cuda.current_stream()
-            side = pointflow.side_stream(x.device, 3)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                half_s = f(self.conv1_1, half)
-                quarter_s = f(self.conv2_1, quarter)
-                half_s.record_stream(main)
-                quarter_s.record_stream(main)
+        half = f(self.conv1_0, x)
+        quarter = f(self.conv2_0, half)
         if self._bottom_fusable():
             # the three smallest layers, one launch each (csrc/conv3d_bottom.hip): every BatchNorm + ReLU between
             # them is applied -- and, with few statistics rows, finalized -- by the NEXT layer while it stages
             b0, b1, b2 = self.conv3_0, self.conv3_1, self.conv4_0
-            y0, p0 = pointflow.conv3d_bottom(quarter.contiguous(), b0.conv, a_quarter, B, True)
-            a0 = pointflow.bn_affine_rows(y0, b0.bn, B, p0, lazy=True)
-            y1, p1 = pointflow.conv3d_bottom(y0, b1.conv, a0, B, True)
-            a1 = pointflow.bn_affine_rows(y1, b1.bn, B, p1, lazy=True)
+            y0, p0 = pointflow.conv3d_bottom(quarter.contiguous(), b0.conv, None, B, True)
+            y1, p1 = pointflow.conv3d_bottom(y0, b1.conv, pointflow.bn_affine_rows(y0, b0.bn, B, p0, lazy=True), B, True)
             pointflow.stamp("unet_encoder_end")
-            y2, p2 = pointflow.deconv3d_bottom(y1, b2.conv, a1, B, True)
-            if dec_lazy:
-                up, a_up = y2, pointflow.bn_affine_rows(y2, b2.bn, B, p2, lazy=True)   # applied by conv5_0's loads
-            else:
-                up = pointflow.batch_norm_act_(y2, b2.bn, b2.relu, B, partials=p2)
+            y2, p2 = pointflow.deconv3d_bottom(y1, b2.conv, pointflow.bn_affine_rows(y1, b1.bn, B, p1, lazy=True), B, True)
+            up = pointflow.batch_norm_act_(y2, b2.bn, b2.relu, B, partials=p2)
         else:
             eighth = f(self.conv3_1, f(self.conv3_0, quarter))
             pointflow.stamp("unet_encoder_end")
             up = f(self.conv4_0, eighth)
         pointflow.stamp("unet_bottom_end")
-        if side is not None:
-            torch.cuda.current_stream().wait_stream(side)
-            half, quarter = half_s, quarter_s
-        elif lazy_enc:
-            y, p = pointflow.conv3d_k3(half, self.conv1_1.conv.weight, 1, True, in_affine=a_half, samples_per_stat=B)
-            half = pointflow.batch_norm_act_(y, self.conv1_1.bn, self.conv1_1.relu, B, partials=p)
-            y, p = pointflow.conv3d_k3(quarter, self.conv2_1.conv.weight, 1, True, in_affine=a_quarter,
-                                       samples_per_stat=B)
-            quarter = pointflow.batch_norm_act_(y, self.conv2_1.bn, self.conv2_1.relu, B, partials=p)
-        else:
-            half = f(self.conv1_1, half)
-            quarter = f(self.conv2_1, quarter)
-        if dec_lazy:
-            # decoder with the BatchNorms of conv4_0 / conv5_0 pending: the next transposed convolution applies (and
-            # resolves) them on its loads, before the skip add -- two normalise passes and graph nodes less.  Measured
-            # equal or slightly slower (656.7 / 656.1 vs 657.9 / 661.3 depth maps/s: 960 small blocks each pay the
-            # resolve), so OFF by default (PF_DEC_LAZY=1 turns it on)
-            y5, p5 = pointflow.deconv3d_k3s2(up, quarter.contiguous(), self.conv5_0.conv.weight, True, in_affine=a_up,
-                                             samples_per_stat=B)
-            a5 = pointflow.bn_affine_rows(y5, self.conv5_0.bn, B, p5, lazy=True)
-            y6, p6 = pointflow.deconv3d_k3s2(y5, half.contiguous(), self.conv6_0.conv.weight, True, in_affine=a5,
-                                             samples_per_stat=B)
-            up = pointflow.batch_norm_act_(y6, self.conv6_0.bn, self.conv6_0.relu, B, partials=p6)
-        else:
-            up = f(self.conv5_0, (up, quarter))
-            blk6, blk0 = self.conv6_0, self.conv0_1
-            if (isinstance(full, tuple) and aux is None and int(_os.environ.get("PF_VC_DUAL_BN", "1"))
-                    and _deconv_fusable(blk6, up) and blk6.bn is not None and blk6.relu and blk0.relu
-                    and (blk6.bn.training or not blk6.bn.track_running_stats)):
-                # conv6_0's BatchNorm + ReLU, conv0_1's BatchNorm + ReLU and the add of the two: ONE pass
-                y6, p6 = pointflow.deconv3d_k3s2(up.contiguous(), half.contiguous(), blk6.conv.weight, True)
-                raw0, p0 = full
-                summed = pointflow.batch_norm_act2_(raw0, blk0.bn, p0, y6, blk6.bn, p6, B)
-                return f(self.conv6_2, summed)
-            up = f(self.conv6_0, (up, half))
-        if aux is not None:
-            torch.cuda.current_stream().wait_stream(aux)
+        half = f(self.conv1_1, half)
+        quarter = f(self.conv2_1, quarter)
+        up = f(self.conv5_0, (up, quarter))
+        if (isinstance(full, tuple) and _deconv_fusable(blk6, up) and blk6.bn is not None and blk6.relu
+                and (blk6.bn.training or not blk6.bn.track_running_stats)):
+            # conv6_0's BatchNorm + ReLU, conv0_1's BatchNorm + ReLU and the add of the two: ONE pass
+            y6, p6 = pointflow.deconv3d_k3s2(up.contiguous(), half.contiguous(), blk6.conv.weight, True)
+            raw0, p0 = full
+            return f(self.conv6_2, pointflow.batch_norm_act2_(raw0, blk0.bn, p0, y6, blk6.bn, p6, B))
+        up = f(blk6, (up, half))
         # (conv6_2 does not add on load: its kernel is bound by its tap loads and adding there doubles them --
-        # 63 us against 15 + 5, profiles/r01h_microbench_deconv3d.log; instead the add rides on conv0_1's
-        # BatchNorm+ReLU pass, which has to stream that tensor anyway)
+        # 63 us against 15 + 5, profiles/r01h_microbench_deconv3d.log; the add rides on conv0_1's BatchNorm pass)
         if isinstance(full, tuple):
             raw, partials = full
-            summed = pointflow.batch_norm_act_(raw, self.conv0_1.bn, self.conv0_1.relu, B, partials=partials,
-                                               addend=up.contiguous())
+            summed = pointflow.batch_norm_act_(raw, blk0.bn, blk0.relu, B, partials=partials, addend=up.contiguous())
         else:
             summed = up + full
         return f(self.conv6_2, summed)

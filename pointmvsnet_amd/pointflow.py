@@ -351,16 +351,25 @@ def flush_lazy_stats(device=None):
 
 
 # Concurrency level (PF_CONCURRENCY): 0 = single stream; 1 = flow tower beside the coarse stage;
-# 2 = + lattice kNN beside the first EdgeConv GEMM; 3 = + conv0_1 beside the VolumeConv encoder/decoder.
+# 2 = + lattice kNN beside the first EdgeConv GEMM (default).
 CONCURRENCY = int(_os.environ.get("PF_CONCURRENCY", "2"))
 
 _side_streams = {}
+_lane = 0
+
+
+def set_lane(lane):
+    """Scene lane of the forwards issued from now on (graph.GraphedForward with ``lanes`` > 1 captures several
+    scenes side by side): every lane forks onto its OWN auxiliary streams, so one scene's flow tower never queues
+    behind another scene's."""
+    global _lane
+    _lane = int(lane)
 
 
 def side_stream(device, slot):
-    """A cached auxiliary stream (per device and slot) for independent kernel chains; fork with
+    """A cached auxiliary stream (per device, scene lane and slot) for independent kernel chains; fork with
     ``s.wait_stream(current)``, join with ``current.wait_stream(s)`` -- graph edges under hipGraph capture."""
-    key = (str(device), slot)
+    key = (str(device), _lane, slot)
     st = _side_streams.get(key)
     if st is None:
         st = _side_streams[key] = torch.cuda.Stream(device=device)
@@ -725,10 +734,6 @@ def bn_affine_rows(x, bn, samples_per_stat, partials=None, lazy=False):
         return scale, shift
     sc, sh = eval_affine(bn, G, C)
     return sc.unsqueeze(0).expand(G, C).contiguous(), sh.unsqueeze(0).expand(G, C).contiguous()
-
-
-# PF_UNET_BOTTOM=0: the three smallest VolumeConv layers go back to the library convolution (round-1 path)
-UNET_BOTTOM = int(_os.environ.get("PF_UNET_BOTTOM", "1"))
 
 
 def conv3d_bottom_supported(conv):

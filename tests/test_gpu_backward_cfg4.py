@@ -8,6 +8,15 @@ math; its scatter is a float64 atomic add, i.e. order-independent to ~1e-16).
 
 Tolerances are relative to the largest entry of each gradient: our scatters add float32 values in arrival order
 (the reference's kernel does too, gather_knn_kernel.cu:50-89), which is the error floor measured here.
+
+One effect exists only at this size: an EdgeConv layer has N*k*C = 5e7 .. 2e8 ReLU inputs, so a handful of them lie
+within float32 rounding of zero, and there a float32 and a float64 evaluation legitimately disagree about the ReLU
+mask.  One such flip moves dL/dx at exactly two points (the centre n of the pair and its neighbour idx[n, j]) by
+~go/k * |a| * |W| -- a few 1e-3 of the largest entry -- and every weight gradient by one term of its 1.6e6-term sum.
+The test therefore marks the points that own a pre-activation within AMBIGUOUS of zero in the float64 evaluation
+(a few per cent of the points), requires float32-rounding agreement (2e-5 of the largest entry) at every unmarked point,
+a loose bound at the marked ones, and 2e-3 on the weight gradients (measured: 1.1e-3 worst, conv2 of the 136 -> 32
+layer; the BatchNorm parameters 1e-6 .. 1e-4).
 """
 import pytest
 import torch
@@ -47,7 +56,10 @@ def _edgeconv_f64(x, idx, w1, w2, gamma, beta, concat, eps=1e-5):
     mean = t.mean(dim=(1, 2), keepdim=True)
     var = t.var(dim=(1, 2), unbiased=False, keepdim=True)
     y = (t - mean) / torch.sqrt(var + eps) * gamma.view(-1, 1, 1) + beta.view(-1, 1, 1)
-    return F.relu(y).mean(dim=2).unsqueeze(0)
+    return F.relu(y).mean(dim=2).unsqueeze(0), y.detach()
+
+
+AMBIGUOUS = 2e-5            # |pre-activation| below this: the ReLU mask is undetermined at float32 resolution
 
 
 @pytest.mark.parametrize("cls,cin,cout", [(EdgeConvNoC, 136, 32), (EdgeConv, 32, 32), (EdgeConv, 64, 64)])
@@ -66,16 +78,23 @@ def test_edgeconv_backward_at_cfg4_size_vs_float64(dev, cls, cin, cout):
     # float64 composition, same device
     p64 = {n: p.detach().double().requires_grad_(True) for n, p in mod.named_parameters()}
     x64 = x.detach().double().requires_grad_(True)
-    y64 = _edgeconv_f64(x64, idx, p64["conv1.weight"][:, :, 0], p64["conv2.weight"][:, :, 0], p64["bn.weight"],
-                        p64["bn.bias"], mod.concat)
+    y64, pre = _edgeconv_f64(x64, idx, p64["conv1.weight"][:, :, 0], p64["conv2.weight"][:, :, 0], p64["bn.weight"],
+                             p64["bn.bias"], mod.concat)
     y64.backward(go.double())
+    # points that own an ambiguous ReLU input: the centre n of the pair and the neighbour it gathered
+    amb = (pre.abs() < AMBIGUOUS).any(dim=0)                                       # (N, k)
+    marked = amb.any(dim=1)
+    marked[idx[0][amb]] = True
+    dx_err = (x.grad.double() - x64.grad).abs().max(dim=1)[0][0] / x64.grad.abs().max()          # (N,) per point
     errs = {"y": float((y.detach().double() - y64.detach()).abs().max() / y64.detach().abs().max()),
-            "dx": float((x.grad.double() - x64.grad).abs().max() / x64.grad.abs().max())}
+            "dx_unmarked": float(dx_err[~marked].max()), "dx_marked": float(dx_err[marked].max()),
+            "marked_frac": float(marked.float().mean()), "ambiguous_inputs": float(amb.sum())}
     for n, p in mod.named_parameters():
         errs[n.replace(".", "_")] = float((p.grad.double() - p64[n].grad).abs().max() / p64[n].grad.abs().max())
     report("cfg4size_edgeconv_backward_%s_%d" % (cls.__name__, cout), **errs)
     assert errs["y"] < 1e-5, errs
-    assert max(errs.values()) < 2e-4, errs
+    assert errs["dx_unmarked"] < 2e-5 and errs["dx_marked"] < 5e-2 and errs["marked_frac"] < 0.2, errs
+    assert max(errs[n.replace(".", "_")] for n, _ in mod.named_parameters()) < 2e-3, errs
 
 
 @pytest.mark.parametrize("C,h,w", [(16, 256, 320), (32, 128, 160), (64, 64, 80)])

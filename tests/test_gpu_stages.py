@@ -77,8 +77,7 @@ def _flow_variances_f64(pyr, cur, interval, Kf, ext, R_inv, t):
     return torch.stack(planes, dim=2)                                                                      # (B,112,5,N)
 
 
-# ("cfg3", 2): BASELINE configs[2]'s last iteration at full size -- 16 sub-grids x 96 000 points (about two CPU minutes
-# of oracle on the GPU box; the float64 yardstick is skipped there)
+# ("cfg3", 2): BASELINE configs[2]'s last iteration at full size -- 16 sub-grids x 96 000 points
 @pytest.mark.parametrize("cfg,it", [("tiny", 0), ("tiny", 1), ("small", 2), ("cfg5r", 2), ("cfg2", 0), ("cfg2", 1),
                                     ("cfg3", 2)])
 def test_flow_iteration_stagewise_vs_oracle(dev, cfg, it):
@@ -127,15 +126,15 @@ def test_flow_iteration_stagewise_vs_oracle(dev, cfg, it):
     # below), because the projection of ~600 mm float32 world coordinates moves a tap by ~1e-4 texel and the variance
     # E[x^2] - E[x]^2 cancels.  So: (1) GPU vs oracle within 1e-4 of the feature scale, and (2) the GPU no farther
     # from the float64 value than twice the oracle is (+ 2e-6 of the scale) -- i.e. as accurate as the reference.
-    assert e_f < 1e-4 * max(var_scale, 1e-3)
-    if cfg != "cfg3":
-        with torch.no_grad():
-            f64 = _flow_variances_f64(pyr, cur, interval, Kf, ext, R_inv, t)
-        f64 = f64.view(112, 5, hs, ratio, ws, ratio).permute(3, 5, 0, 1, 2, 4).reshape(ratio * ratio, 112, -1)
-        e_gpu64 = float((f_gpu.cpu()[:, :112].double() - f64).abs().max())
-        e_ref64 = float((f_ref[:, :112].double() - f64).abs().max())
-        report("stage_F64_%s_it%d" % (cfg, it), gpu_vs_f64=e_gpu64, oracle_vs_f64=e_ref64, feat_scale=var_scale)
-        assert e_gpu64 <= 2.0 * e_ref64 + 2e-6 * max(var_scale, 1e-3), (e_gpu64, e_ref64)
+    with torch.no_grad():
+        f64 = _flow_variances_f64(pyr, cur, interval, Kf, ext, R_inv, t)
+    f64 = f64.view(112, 5, hs, ratio, ws, ratio).permute(3, 5, 0, 1, 2, 4).reshape(ratio * ratio, 112, -1)
+    e_gpu64 = float((f_gpu.cpu()[:, :112].double() - f64).abs().max())
+    e_ref64 = float((f_ref[:, :112].double() - f64).abs().max())
+    report("stage_F64_%s_it%d" % (cfg, it), gpu_vs_f64=e_gpu64, oracle_vs_f64=e_ref64, feat_scale=var_scale)
+    assert e_gpu64 <= 2.0 * e_ref64 + 2e-6 * max(var_scale, 1e-3), (e_gpu64, e_ref64)
+    # (measured: the oracle is 1.6e-5 .. 2.5e-4 from the float64 value at scale 2..6, 8.8e-4 on cfg 3's 640x480 grid)
+    assert e_f < max(1e-4 * max(var_scale, 1e-3), 2.5 * e_ref64)
 
     # ---- stages K..H on the ORACLE's features: identical inputs => identical neighbour sets ----------
     f_in, x_in = f_ref.to(dev).contiguous(), x_ref.to(dev).contiguous()
