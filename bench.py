@@ -72,6 +72,9 @@ def parse_args():
                          "step is one pass over a batch of that many synthetic scenes, one scene per forward like "
                          "the reference's test.py (TEST.BATCH_SIZE 1), so that the default 20 steps time seconds, "
                          "not 30 ms")
+    ap.add_argument("--lanes", type=int, default=3,
+                    help="scenes in flight per GPU: that many captured forwards replayed round-robin on as many streams "
+                         "(pointmvsnet_amd.graph.LanedForward); 1 = one scene at a time")
     ap.add_argument("--calibration-steps", type=int, default=10,
                     help="instrumented eager forwards (HIP events around every entry point) before the timed region")
     ap.add_argument("--launch-check", action="store_true",
@@ -335,26 +338,21 @@ def main():
     if not args.eager:
         try:
             from pointmvsnet_amd.graph import GraphedForward
-            # ONE captured graph whose static input the step's images are copied into (12 MB device-to-device, inside
-            # the timed region).  PF_BENCH_GRAPHS=<n_unique> keeps one graph per resident scene buffer instead (no image
-            # copy) -- measured SLOWER, 585 vs 598 depth maps/s (profiles/r02ae_graph_slots_ab.log): alternating graph
-            # executables costs more than the copy.
-            n_graphs = int(os.environ.get("PF_BENCH_GRAPHS", "1"))
+            # one captured graph per scene lane; the step's images are copied into the lane's static input (12 MB
+            # device-to-device, inside the timed region; one graph per resident scene buffer instead measured slower,
+            # profiles/r02ae_graph_slots_ab.log)
+            from pointmvsnet_amd.graph import LanedForward
             with torch.no_grad():
-                if n_graphs == n_unique and n_graphs > 1:
-                    graphs = [GraphedForward(net, scenes[j], img_scales, inter_scales, isFlow=True, isTest=True,
-                                             adopt_input=True) for j in range(n_unique)]
-                else:
-                    graphs = [GraphedForward(net, scenes[0], img_scales, inter_scales, isFlow=True, isTest=True)
-                              for _ in range(n_graphs)]
+                laned = LanedForward(net, scenes[0], img_scales, inter_scales, isFlow=True, isTest=True,
+                                     lanes=max(1, args.lanes))
+            graphs = laned.graphs
 
             def step(i):                                                       # noqa: F811
                 with torch.no_grad():
-                    return graphs[i % n_graphs](scenes[i % n_unique])
+                    return laned.submit(scenes[i % n_unique])[1]
 
-            execution = ("hipGraph replay, one graph per resident input slot (host camera algebra + 1 H2D of the scene "
-                         "constants + 1 graph launch per step)") if (n_graphs == n_unique and n_graphs > 1) \
-                else "hipGraph replay (host camera algebra + image copy into the static input + 1 graph launch per step)"
+            execution = ("hipGraph replay, %d scene lane(s) in flight (per scene: host camera algebra + 1 H2D of the "
+                         "scene constants + image copy into the lane's static input + 1 graph launch)" % laned.lanes)
         except Exception as exc:      # capture support varies with the library stack; say so, do not hide it
             sys.stderr.write("bench.py: hipGraph capture failed (%r); running eager\n" % (exc,))
             step = eager_step
@@ -407,6 +405,7 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     assert torch.isfinite(preds["flow%d" % len(img_scales)]).all()
+    laned_lanes = max(1, args.lanes) if (execution != "eager" and not training) else 1
     from pointmvsnet_amd import pointflow as _pf
     stage_timeline = _pf.timeline_report() if _pf.TIMELINE else None
 
@@ -490,7 +489,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": WORKLOAD_TEXT[args.config], "height": h, "width": w, "views": V, "depth_planes": D,
                    "img_scales": list(img_scales), "inter_scales": list(inter_scales), "batch_per_gpu": 1,
-                   "scenes_per_step": sps,
+                   "scenes_per_step": sps, "scenes_in_flight_per_gpu": (laned_lanes if not training else 1),
                    "parallelism": ("data parallel x%d, one flat 698 936-float gradient bucket, one SUM all-reduce per step"
                                    % world) if training
                    else "scene-sharded replicas x%d (no data-path collective)" % world,

@@ -24,6 +24,8 @@ tensors (``bn.weight.data = ...``, a swapped buffer) re-captures too; in-place u
 them.  The warm-up forwards run on a snapshot of the BatchNorm buffers, which is restored before capture:
 constructing a GraphedForward does not advance running statistics or ``num_batches_tracked``.
 """
+import copy
+
 import torch
 
 from . import pointflow
@@ -98,3 +100,71 @@ class GraphedForward(object):
         else:
             self.graph.replay()
         return self.outputs
+
+
+def replicate_for_lane(model):
+    """A replica of ``model`` that SHARES its parameters (the very same Parameter objects: an optimizer step or a
+    ``load_state_dict`` on either is seen by both) and OWNS its buffers -- ``nn.DataParallel``'s replica semantics
+    (reference test.py:84, train.py:177) on one device.  Every scene lane advances its own BatchNorm running statistics
+    and ``num_batches_tracked`` (in the order of the scenes it sees; batch statistics, hence depth maps, never read
+    them in the reference's train()-mode evaluation, test.py:58); lane 0 is the module itself."""
+    held = {k: model.__dict__[k] for k in ("_plan", "_tplan") if k in model.__dict__}
+    for k in held:                                  # per-call caches (pinned blocks, events) are not part of the module
+        model.__dict__[k] = None
+    try:
+        replica = copy.deepcopy(model)
+    finally:
+        model.__dict__.update(held)
+    for (_, master), (_, rep) in zip(model.named_modules(), replica.named_modules()):
+        for name, p in master._parameters.items():
+            rep._parameters[name] = p
+    return replica
+
+
+class LanedForward(object):
+    """Several scenes in flight on ONE GPU: ``lanes`` captured forwards, each with its own static input, plan block,
+    intermediates, auxiliary streams and BatchNorm buffers (``replicate_for_lane``), replayed round-robin on ``lanes``
+    streams.  A depth map is a chain of ~85 dependent kernels, most of them too small to fill 256 CUs and each paying
+    ~5 us of dependency latency; a second scene fills those holes (measured on MI355X, BASELINE config 2: 669 -> 745
+    depth maps/s with 2 lanes and the host still in the way, profiles/r03_lanes_ab.log).  Depth maps are bit-identical
+    to the single-lane forward's: nothing is shared between lanes but read-only weights.
+
+    ``submit(batch)`` enqueues one scene on the next lane and returns ``(lane, outputs)``; the outputs are that lane's
+    static tensors -- valid once ``streams[lane]`` has been waited for (``wait(lane)``), overwritten by the lane's
+    next ``submit``."""
+
+    def __init__(self, model, example_batch, img_scales, inter_scales, isFlow=True, isTest=True, lanes=2, warmup=3):
+        if lanes < 1:
+            raise ValueError("LanedForward: lanes >= 1")
+        self.lanes = int(lanes)
+        self.models = [model] + [replicate_for_lane(model) for _ in range(self.lanes - 1)]
+        self.streams = [torch.cuda.Stream(device=example_batch["img_list"].device) for _ in range(self.lanes)]
+        self.graphs = []
+        here = torch.cuda.current_stream()
+        try:
+            for lane in range(self.lanes):
+                pointflow.set_lane(lane)
+                self.streams[lane].wait_stream(here)
+                with torch.cuda.stream(self.streams[lane]):
+                    self.graphs.append(GraphedForward(self.models[lane], example_batch, img_scales, inter_scales,
+                                                      isFlow=isFlow, isTest=isTest, warmup=warmup))
+        finally:
+            pointflow.set_lane(0)
+        self._next = 0
+
+    def submit(self, data_batch):
+        lane = self._next
+        self._next = (lane + 1) % self.lanes
+        with torch.cuda.stream(self.streams[lane]):
+            out = self.graphs[lane](data_batch)
+        return lane, out
+
+    def wait(self, lane=None):
+        """Make the CURRENT stream wait for ``lane`` (all lanes when None)."""
+        cur = torch.cuda.current_stream()
+        for i in (range(self.lanes) if lane is None else (lane,)):
+            cur.wait_stream(self.streams[i])
+
+    def synchronize(self):
+        for st in self.streams:
+            st.synchronize()

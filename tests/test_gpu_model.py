@@ -232,6 +232,45 @@ def test_graphed_forward_matches_eager_and_replays_on_new_scenes(dev):
     assert torch.equal(got_c["flow2"], want_c["flow2"]) and not torch.equal(want_c["flow2"], want_a["flow2"])
 
 
+def test_scene_lanes_give_the_single_lane_results_and_keep_their_own_buffers(dev):
+    """LanedForward: three scenes in flight on three streams.  Every scene's maps equal the eager forward's bit for
+    bit (lanes share nothing but read-only weights); the lane replicas hold the SAME Parameter objects and their OWN
+    BatchNorm buffers (nn.DataParallel's replica semantics, reference test.py:84), each advanced by its own scenes."""
+    from pointmvsnet_amd.graph import LanedForward
+    scenes = []
+    for seed in range(5):
+        data, img_scales, inter_scales = synthetic.make_config("tiny", seed=seed)
+        scenes.append(_to(data, dev))
+    eager, net = _model(dev), _model(dev)
+    with torch.no_grad():
+        want = [eager(b, img_scales, inter_scales, isFlow=True, isTest=True) for b in scenes]
+        net(scenes[0], img_scales, inter_scales, isFlow=True, isTest=True)      # a used module (plan cache, pinned block)
+        laned = LanedForward(net, scenes[0], img_scales, inter_scales, lanes=3, warmup=1)
+        for i, b in enumerate(scenes):                         # one at a time: submit, wait for the lane, compare
+            lane, out = laned.submit(b)
+            laned.streams[lane].synchronize()
+            for key in ("coarse_depth_map", "flow1", "flow2", "flow2_prob"):
+                assert torch.equal(out[key], want[i][key]), (i, key)
+    # overlap for real: all five in flight, results copied out on the lane's stream right after the replay
+    copies = []
+    with torch.no_grad():
+        for i, b in enumerate(scenes):
+            lane, out = laned.submit(b)
+            with torch.cuda.stream(laned.streams[lane]):
+                copies.append({k: out[k].clone() for k in ("flow1", "flow2")})
+    laned.synchronize()
+    for i in range(len(scenes)):
+        assert torch.equal(copies[i]["flow2"], want[i]["flow2"]) and torch.equal(copies[i]["flow1"], want[i]["flow1"]), i
+    m0, m1 = laned.models[0], laned.models[1]
+    assert m0 is net and m1.flow_mlp[0][0].conv.weight is net.flow_mlp[0][0].conv.weight
+    b0, b1 = m0.flow_mlp[0][0].bn, m1.flow_mlp[0][0].bn
+    assert b0.running_mean.data_ptr() != b1.running_mean.data_ptr()
+    assert int(b0.num_batches_tracked) > 0 and int(b1.num_batches_tracked) > 0
+    total = sum(int(m.flow_mlp[0][0].bn.num_batches_tracked) for m in laned.models)
+    # 5 module calls per scene (1 + 4 sub-grids): 10 laned scenes + the eager one, whose count the 2 replicas inherited
+    assert total == 5 * (2 * len(scenes) + 1) + 5 * (laned.lanes - 1), total
+
+
 @pytest.mark.parametrize("cfg", ["cfg1", "cfg3"])
 def test_other_baseline_configs_run_and_hold_properties(dev, cfg):
     """BASELINE configs 1 (1 flow iteration) and 3 (1280x960, 5 views, 96 planes, 3 iterations incl. the

@@ -243,3 +243,30 @@ def test_deferred_batchnorm_jobs_are_layered_by_module_call_order(monkeypatch):
     launches.clear()
     pointflow.flush_lazy_stats()                                  # nothing left
     assert launches == []
+
+
+@pytest.mark.parametrize("cfg,batch", [("cfg2", 1), ("cfg3", 1), ("cfg5", 1), ("tiny", 2)])
+@pytest.mark.parametrize("is_test", [True, False])
+def test_scene_plan_block_equals_the_reference_camera_algebra_bit_for_bit(cfg, batch, is_test):
+    """ScenePlan.fill_host_ (a dozen NumPy / LAPACK operations per scene) against the ``_Cameras`` composition, which
+    issues the reference's own ATen-CPU calls (reference model.py:54-61, :159-170): every float of the block equal."""
+    from pointmvsnet_amd.model import ScenePlan, _Cameras, _host_cams
+    for seed in (0, 3):
+        if batch == 1:
+            data, scales, inters = synthetic.make_config(cfg, seed=seed)
+        else:
+            data, scales, inters = synthetic.make_scene(128, 192, 3, 8, seed=11 + seed, batch=batch), (0.125, 0.25), (1.0, 0.75)
+        B, V, _, H, W = data["img_list"].shape
+        D = int(data["cam_params_list"][0, 0, 1, 3, 2])
+        plan = ScenePlan(torch.device("cpu"), B, V, H, W, scales, inters, is_test, D).fill_host_(data)
+        cam = _Cameras(_host_cams(data), is_test)
+        want = {"K_coarse": cam.K_coarse, "ext": cam.ext, "Kinv0": torch.inverse(cam.K_coarse[:, 0]),
+                "Rinv0": cam.R_inv[:, 0], "t0": cam.t[:, 0],
+                "depths": torch.stack([torch.linspace(float(cam.depth_start[b]), float(cam.depth_end[b]), D)
+                                       for b in range(B)]),
+                "sa_params": torch.stack([cam.depth_start, cam.depth_end, cam.depth_interval], dim=1)}
+        for i, (s, inter) in enumerate(zip(scales, inters)):
+            want["pack%d" % i] = cam.packed(cam.flow_intrinsics(s), data["mean"], data["std"], inter * cam.depth_interval)
+        for name, t in want.items():
+            got = plan._h(name)
+            assert torch.equal(got, t.reshape(got.shape).float()), (cfg, seed, is_test, name)

@@ -59,6 +59,19 @@ def main():
         torch.cuda.synchronize()
         return args.steps / (time.perf_counter() - t0)
 
+    # host cost of one step's pieces (nothing waits for the GPU in here except the pinned-block reuse)
+    acc = {"fill": 0.0, "upload+copy": 0.0, "replay": 0.0}
+    torch.cuda.synchronize()
+    for i in range(60):
+        gl = graphs[i % args.lanes]
+        t0 = time.perf_counter(); gl.plan.fill_host_(scenes[i % 4])
+        t1 = time.perf_counter(); gl.plan.upload_(); gl.static_img.copy_(scenes[i % 4]["img_list"], non_blocking=True)
+        t2 = time.perf_counter(); gl.graph.replay()
+        t3 = time.perf_counter()
+        acc["fill"] += t1 - t0; acc["upload+copy"] += t2 - t1; acc["replay"] += t3 - t2
+        if i % 8 == 7:
+            torch.cuda.synchronize()
+    print("host us per step:", {k: round(v / 60 * 1e6, 1) for k, v in acc.items()}, flush=True)
     for mode in (("one", "streams", "one", "streams") if not args.onegraph else ()):
         run(mode)
         print("%-10s %8.1f depth maps/s" % (mode, run(mode)), flush=True)
