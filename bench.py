@@ -72,7 +72,7 @@ def parse_args():
                          "step is one pass over a batch of that many synthetic scenes, one scene per forward like "
                          "the reference's test.py (TEST.BATCH_SIZE 1), so that the default 20 steps time seconds, "
                          "not 30 ms")
-    ap.add_argument("--lanes", type=int, default=3,
+    ap.add_argument("--lanes", type=int, default=4,
                     help="scenes in flight per GPU: that many captured forwards replayed round-robin on as many streams "
                          "(pointmvsnet_amd.graph.LanedForward); 1 = one scene at a time")
     ap.add_argument("--calibration-steps", type=int, default=10,
@@ -406,6 +406,7 @@ def main():
         elapsed = float(t.item())
     assert torch.isfinite(preds["flow%d" % len(img_scales)]).all()
     laned_lanes = max(1, args.lanes) if (execution != "eager" and not training) else 1
+    lane_probe = [round(r, 1) for r in laned.placement] if (laned_lanes > 1 and laned.placement) else None
     from pointmvsnet_amd import pointflow as _pf
     stage_timeline = _pf.timeline_report() if _pf.TIMELINE else None
 
@@ -498,6 +499,7 @@ def main():
                    "PointMVSNet.forward(isFlow=True, isTest=True), BatchNorm in train mode (test.py:58)"},
         "execution": train_execution if training else execution,
         "host_issue_ms_per_depth_map": issued / (args.steps * sps) * 1e3,
+        "lane_placement_probe_maps_per_s": lane_probe,
         "gap_probe": gap_probe,
         "stage_timeline_us": stage_timeline,
         "roofline": roof,

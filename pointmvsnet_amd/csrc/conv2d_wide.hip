@@ -144,6 +144,85 @@ __device__ __forceinline__ void wide_stage_patch(const float* __restrict__ xb, i
   st.template commit<(AFFINE != 0)>(patch, aff);
 }
 
+// Epilogue shared by the two kernels: C/D layout column (channel) = lane & 31, row (pixel) = (r & 3) + 8 (r >> 2) + 4 h;
+// stores straight to NCHW as 16-byte pieces (or channel-last), statistics per lane -> halves -> waves -> one row.
+template <class C, int COUT>
+__device__ __forceinline__ void wide_epilogue(const f32x16& acc, float* __restrict__ y, const WideGeom& g,
+                                              double* __restrict__ partials, double* red, int n, int oh0, int ow0,
+                                              int wm, int wn, int wave, int m, int h, int tid) {
+  // ---- epilogue: C/D layout column (channel) = lane & 31, row (pixel) = (r & 3) + 8 (r >> 2) + 4 h -----------------
+  const int co = wn * 32 + m;
+  float* yb = y + ((int64_t)n * COUT + co) * ((int64_t)g.Ho * g.Wo);
+  const bool vec_ok = (g.Wo & 3) == 0;
+  float s = 0.0f, q = 0.0f;
+  if (g.cl_out) {
+    // channel-last output (the coarse tower's last layer feeds the warp, which samples channel-last maps): for one
+    // accumulator element the 32 lanes of a half-wave hold 32 consecutive channels of one pixel = one 128-byte row
+    float* ycl = y + (int64_t)n * g.Ho * g.Wo * COUT + co;
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      const int oh = oh0 + 2 * wm + (rq >> 1);
+      const int ow = ow0 + (rq & 1) * 8 + 4 * h;
+      if (oh < g.Ho) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (ow + e < g.Wo) {
+            ycl[((int64_t)oh * g.Wo + ow + e) * COUT] = acc[4 * rq + e];
+            s += acc[4 * rq + e];
+            q += acc[4 * rq + e] * acc[4 * rq + e];
+          }
+        }
+      }
+    }
+  } else
+#pragma unroll
+  for (int rq = 0; rq < 4; ++rq) {
+    const int oh = oh0 + 2 * wm + (rq >> 1);
+    const int ow = ow0 + (rq & 1) * 8 + 4 * h;
+    if (oh < g.Ho) {
+      float* dst = yb + (int64_t)oh * g.Wo + ow;
+      if (vec_ok && ow + 3 < g.Wo) {
+        *reinterpret_cast<float4*>(dst) = make_float4(acc[4 * rq], acc[4 * rq + 1], acc[4 * rq + 2], acc[4 * rq + 3]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s += acc[4 * rq + e];
+          q += acc[4 * rq + e] * acc[4 * rq + e];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (ow + e < g.Wo) {
+            dst[e] = acc[4 * rq + e];
+            s += acc[4 * rq + e];
+            q += acc[4 * rq + e] * acc[4 * rq + e];
+          }
+        }
+      }
+    }
+  }
+  if (partials != nullptr) {
+    s += __shfl_xor(s, 32);
+    q += __shfl_xor(q, 32);
+    if (h == 0) {
+      red[(wave * 32 + m) * 2 + 0] = (double)s;
+      red[(wave * 32 + m) * 2 + 1] = (double)q;
+    }
+    __syncthreads();
+    if (tid < COUT) {
+      const int cn = tid >> 5, cm = tid & 31;
+      double ds = 0.0, dq = 0.0;
+#pragma unroll
+      for (int w = 0; w < C::NWM; ++w) {
+        ds += red[((w * C::NWN + cn) * 32 + cm) * 2 + 0];
+        dq += red[((w * C::NWN + cn) * 32 + cm) * 2 + 1];
+      }
+      double* o = partials + (((int64_t)n * gridDim.x + blockIdx.x) * COUT + tid) * 2;
+      o[0] = ds;
+      o[1] = dq;
+    }
+  }
+}
+
 // AFFINE: 0 = x is taken as is; 1 = relu(x * in_scale + in_shift), rows (N/sps, CIN); 2 = the same with the rows
 // computed here from the PRODUCER's statistics (pf_bn_resolve: the pending BatchNorm never gets its own launch)
 template <int KS, int STRIDE, int CIN, int COUT, int AFFINE>
@@ -234,77 +313,79 @@ __global__ __launch_bounds__(256) void conv2d_wide_kernel(const float* __restric
     }
   }
 
-  // ---- epilogue: C/D layout column (channel) = lane & 31, row (pixel) = (r & 3) + 8 (r >> 2) + 4 h -----------------
-  const int co = wn * 32 + m;
-  float* yb = y + ((int64_t)n * COUT + co) * ((int64_t)g.Ho * g.Wo);
-  const bool vec_ok = (g.Wo & 3) == 0;
-  float s = 0.0f, q = 0.0f;
-  if (g.cl_out) {
-    // channel-last output (the coarse tower's last layer feeds the warp, which samples channel-last maps): for one
-    // accumulator element the 32 lanes of a half-wave hold 32 consecutive channels of one pixel = one 128-byte row
-    float* ycl = y + (int64_t)n * g.Ho * g.Wo * COUT + co;
+  wide_epilogue<C, COUT>(acc, y, g, partials, red, n, oh0, ow0, wm, wn, wave, m, h, tid);
+}
+
+// Variant: the B operands (weights) straight from global memory / L2 into a ring of registers -- no weight rows in
+// LDS (27-55 KB of patch instead of 75-130 KB: several blocks per CU, i.e. several waves per SIMD covering each
+// other's prologue, LDS and memory latencies) and no barrier inside the tile.  A lane's B operand for four MFMA steps
+// is one 16-byte load; a wave's load is two contiguous 512-byte runs of the host-packed weights.
+template <int KS, int STRIDE, int CIN, int COUT>
+struct WideGCfg : WideCfg<KS, STRIDE, CIN, COUT> {
+  using B = WideCfg<KS, STRIDE, CIN, COUT>;
+  static constexpr size_t LDS = sizeof(float) * (size_t)(B::PATCH + 2 * CIN) + sizeof(double) * 4 * 32 * 2;
+  static_assert(B::PATCH * sizeof(float) >= 4096, "pf_bn_resolve's scratch lives in the (still empty) patch");
+};
+
+template <int KS, int STRIDE, int CIN, int COUT, int AFFINE>
+__global__ __launch_bounds__(256) void conv2d_wide_g_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                            float* __restrict__ y, WideGeom g,
+                                                            const float* __restrict__ in_scale,
+                                                            const float* __restrict__ in_shift,
+                                                            double* __restrict__ partials, pf_bn_job in_bn) {
+  using C = WideGCfg<KS, STRIDE, CIN, COUT>;
+  constexpr int PW = C::PW, RS = C::RS, NPIX = C::NPIX;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* patch = lds;
+  float* aff = lds + C::PATCH;
+  double* red = reinterpret_cast<double*>(aff + 2 * CIN);
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int m = lane & 31, h = lane >> 5;
+  const int wm = wave / C::NWN, wn = wave % C::NWN;
+  const int n = blockIdx.y;
+  const int tw = blockIdx.x % g.tiles_w, th = blockIdx.x / g.tiles_w;
+  const int oh0 = th * C::TH, ow0 = tw * C::TW;
+  const int ih0 = oh0 * STRIDE - C::PAD, iw0 = ow0 * STRIDE - C::PAD;
+  const int plane_i = g.Hi * g.Wi;
+  const float* xb = x + (int64_t)n * CIN * plane_i;
+
+  constexpr int NP = KS * KS * C::KC;                  // 16-byte operand pairs of the tile
+  constexpr int D = 6;                                 // B pieces in flight per lane
+  const f32x4* bg = reinterpret_cast<const f32x4*>(wp) + (h * COUT + wn * 32 + m);
+  f32x4 bq[D];
 #pragma unroll
-    for (int rq = 0; rq < 4; ++rq) {
-      const int oh = oh0 + 2 * wm + (rq >> 1);
-      const int ow = ow0 + (rq & 1) * 8 + 4 * h;
-      if (oh < g.Ho) {
+  for (int d = 0; d < D; ++d) bq[d] = bg[(d < NP ? d : 0) * 2 * COUT];
+
+  wide_stage_patch<CIN, NPIX, PW, RS, AFFINE>(xb, plane_i, ih0, iw0, g.Hi, g.Wi, patch, aff, in_scale, in_shift,
+                                              n / g.sps, in_bn, reinterpret_cast<double*>(patch));
+  __syncthreads();
+
+  f32x16 acc;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (ow + e < g.Wo) {
-            ycl[((int64_t)oh * g.Wo + ow + e) * COUT] = acc[4 * rq + e];
-            s += acc[4 * rq + e];
-            q += acc[4 * rq + e] * acc[4 * rq + e];
-          }
-        }
-      }
+  for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+  const float* abase = patch + ((2 * wm + (m >> 4)) * STRIDE * PW + (m & 15) * STRIDE) * RS + 4 * h;
+  f32x4 a = *reinterpret_cast<const f32x4*>(abase);
+#pragma unroll
+  for (int t = 0; t < NP; ++t) {
+    f32x4 an = a;
+    if (t + 1 < NP) {
+      const int tap = (t + 1) / C::KC, kc = (t + 1) % C::KC;
+      const int kh = tap / KS, kw = tap % KS;
+      an = *reinterpret_cast<const f32x4*>(abase + (kh * PW + kw) * RS + 8 * kc);
     }
-  } else
-#pragma unroll
-  for (int rq = 0; rq < 4; ++rq) {
-    const int oh = oh0 + 2 * wm + (rq >> 1);
-    const int ow = ow0 + (rq & 1) * 8 + 4 * h;
-    if (oh < g.Ho) {
-      float* dst = yb + (int64_t)oh * g.Wo + ow;
-      if (vec_ok && ow + 3 < g.Wo) {
-        *reinterpret_cast<float4*>(dst) = make_float4(acc[4 * rq], acc[4 * rq + 1], acc[4 * rq + 2], acc[4 * rq + 3]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          s += acc[4 * rq + e];
-          q += acc[4 * rq + e] * acc[4 * rq + e];
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (ow + e < g.Wo) {
-            dst[e] = acc[4 * rq + e];
-            s += acc[4 * rq + e];
-            q += acc[4 * rq + e] * acc[4 * rq + e];
-          }
-        }
-      }
-    }
+    const f32x4 b = bq[t % D];
+    __builtin_amdgcn_sched_barrier(0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + D < NP) bq[t % D] = bg[(t + D) * 2 * COUT];
+    a = an;
   }
-  if (partials != nullptr) {
-    s += __shfl_xor(s, 32);
-    q += __shfl_xor(q, 32);
-    if (h == 0) {
-      red[(wave * 32 + m) * 2 + 0] = (double)s;
-      red[(wave * 32 + m) * 2 + 1] = (double)q;
-    }
-    __syncthreads();
-    if (tid < COUT) {
-      const int cn = tid >> 5, cm = tid & 31;
-      double ds = 0.0, dq = 0.0;
-#pragma unroll
-      for (int w = 0; w < C::NWM; ++w) {
-        ds += red[((w * C::NWN + cn) * 32 + cm) * 2 + 0];
-        dq += red[((w * C::NWN + cn) * 32 + cm) * 2 + 1];
-      }
-      double* o = partials + (((int64_t)n * gridDim.x + blockIdx.x) * COUT + tid) * 2;
-      o[0] = ds;
-      o[1] = dq;
-    }
-  }
+  wide_epilogue<C, COUT>(acc, y, g, partials, red, n, oh0, ow0, wm, wn, wave, m, h, tid);
 }
 
 template <int KS, int STRIDE, int CIN, int COUT, int AFFINE>
@@ -320,6 +401,13 @@ int launch_wide_mode(const float* x, const float* wp, float* y, WideGeom g, int6
   g.tiles_w = (g.Wo + C::TW - 1) / C::TW;
   const int tiles_h = (g.Ho + C::TH - 1) / C::TH;
   dim3 grid((unsigned)(tiles_h * g.tiles_w), (unsigned)N);
+  static const int global_b = []() { const char* e = getenv("PF_WIDE_GLOBALB"); return e ? atoi(e) : 0; }();
+  if (global_b) {
+    using G = WideGCfg<KS, STRIDE, CIN, COUT>;
+    hipLaunchKernelGGL((conv2d_wide_g_kernel<KS, STRIDE, CIN, COUT, AFFINE>), grid, dim3(256), G::LDS, s, x, wp, y, g,
+                       in_scale, in_shift, partials, in_bn);
+    return pf_launch_status();
+  }
   hipLaunchKernelGGL((conv2d_wide_kernel<KS, STRIDE, CIN, COUT, AFFINE>), grid, dim3(256), C::LDS, s, x, wp, y, g,
                      in_scale, in_shift, partials, in_bn);
   return pf_launch_status();

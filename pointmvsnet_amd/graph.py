@@ -43,13 +43,10 @@ class GraphedForward(object):
         self.plan = model.make_plan(example_batch, img_scales, inter_scales, isTest)
         self._packs = []
         self.recaptures = 0
+        self._lane, self._level = pointflow.current_lane(), pointflow.CONCURRENCY      # re-captures keep both
         buffers = [(b, b.clone()) for b in model.buffers()]          # warm-up must not advance BN statistics
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):                      # library warm-up (MIOpen find, lazy allocations)
-            for _ in range(warmup):
-                model.run(self.plan, self.static_img, isFlow)
-        torch.cuda.current_stream().wait_stream(side)
+        for _ in range(warmup):                            # lazy allocations, packed weights, code objects
+            model.run(self.plan, self.static_img, isFlow)
         torch.cuda.synchronize()
         with torch.no_grad():
             for b, saved in buffers:
@@ -62,12 +59,15 @@ class GraphedForward(object):
         # at 402 depth maps/s against 486: replays on different streams did not overlap, profiles/r01h_split_ab.log.)
         pointflow.pack_unpin(self._packs)
         self.graph = torch.cuda.CUDAGraph()
+        lane_now = pointflow.current_lane()
+        pointflow.set_lane(self._lane)
         pointflow.pack_log_begin()
         try:
-            with torch.cuda.graph(self.graph):
+            with pointflow.concurrency(self._level), torch.cuda.graph(self.graph):
                 self.outputs = self.model.run(self.plan, self.static_img, self.isFlow)
         finally:
             self._packs = pointflow.pack_log_end(pin=True)
+            pointflow.set_lane(lane_now)
         self._watched = [t for t in list(self.model.parameters()) + list(self.model.buffers())]
         self._addresses = [t.data_ptr() for t in self._watched]
 
@@ -123,34 +123,78 @@ def replicate_for_lane(model):
 
 class LanedForward(object):
     """Several scenes in flight on ONE GPU: ``lanes`` captured forwards, each with its own static input, plan block,
-    intermediates, auxiliary streams and BatchNorm buffers (``replicate_for_lane``), replayed round-robin on ``lanes``
-    streams.  A depth map is a chain of ~85 dependent kernels, most of them too small to fill 256 CUs and each paying
-    ~5 us of dependency latency; a second scene fills those holes (measured on MI355X, BASELINE config 2: 669 -> 745
-    depth maps/s with 2 lanes and the host still in the way, profiles/r03_lanes_ab.log).  Depth maps are bit-identical
-    to the single-lane forward's: nothing is shared between lanes but read-only weights.
+    intermediates and BatchNorm buffers (``replicate_for_lane``), replayed round-robin on ``lanes`` streams.
 
+    Why: a depth map is a chain of ~85 dependent kernels, most of them too small to fill 256 CUs and each paying ~5 us
+    of dependency latency; other scenes fill those holes.  Measured on MI355X (BASELINE config 2,
+    profiles/r03b_lanes_queues.md): 640 depth maps/s with one lane, 895 with two, 970 with three, 1030 with four
+    (more lanes add nothing: four hardware queues).
+
+    Every lane is captured as a single chain (``pointflow.concurrency(0)``): forks inside the graphs take hardware
+    queues away from the lanes (3 lanes: 771 / 938 / 808 depth maps/s at intra-forward levels 0 / 1 / 2 -- erratic,
+    because which streams share a queue changes with every fork).  WHICH streams the lanes run on matters as much:
+    HIP maps streams to its hardware queues (GPU_MAX_HW_QUEUES, default 4) by rules that depend on the process's
+    history -- four streams created first thing in the process gave 860 depth maps/s, four created after the capture
+    1030, with the same graphs; two queues congruent modulo 4 (GPU_MAX_HW_QUEUES = 8) gave 530, less than one lane.
+    A graph can be replayed on any stream, so the placement is MEASURED: ``calibrate`` candidate stream sets each
+    replay a short burst of the captured graphs (BatchNorm buffers restored afterwards) and the fastest set is kept
+    (``placement`` holds the rates).
+
+    Depth maps are bit-identical to the single-lane forward's: nothing is shared between lanes but read-only weights.
     ``submit(batch)`` enqueues one scene on the next lane and returns ``(lane, outputs)``; the outputs are that lane's
     static tensors -- valid once ``streams[lane]`` has been waited for (``wait(lane)``), overwritten by the lane's
     next ``submit``."""
 
-    def __init__(self, model, example_batch, img_scales, inter_scales, isFlow=True, isTest=True, lanes=2, warmup=3):
+    def __init__(self, model, example_batch, img_scales, inter_scales, isFlow=True, isTest=True, lanes=4, warmup=3,
+                 concurrency=None, streams=None, calibrate=3):
         if lanes < 1:
             raise ValueError("LanedForward: lanes >= 1")
         self.lanes = int(lanes)
+        dev = example_batch["img_list"].device
         self.models = [model] + [replicate_for_lane(model) for _ in range(self.lanes - 1)]
-        self.streams = [torch.cuda.Stream(device=example_batch["img_list"].device) for _ in range(self.lanes)]
+        level = (0 if self.lanes > 1 else pointflow.CONCURRENCY) if concurrency is None else int(concurrency)
         self.graphs = []
-        here = torch.cuda.current_stream()
         try:
-            for lane in range(self.lanes):
-                pointflow.set_lane(lane)
-                self.streams[lane].wait_stream(here)
-                with torch.cuda.stream(self.streams[lane]):
+            with pointflow.concurrency(level):
+                for lane in range(self.lanes):
+                    pointflow.set_lane(lane)
                     self.graphs.append(GraphedForward(self.models[lane], example_batch, img_scales, inter_scales,
                                                       isFlow=isFlow, isTest=isTest, warmup=warmup))
         finally:
             pointflow.set_lane(0)
+        torch.cuda.synchronize(dev)
+        self.placement = None
+        if streams is not None:
+            self.streams = list(streams[:self.lanes])
+        else:
+            candidates = [[torch.cuda.Stream(device=dev) for _ in range(self.lanes)]
+                          for _ in range(max(1, int(calibrate)) if self.lanes > 1 else 1)]
+            self.streams = candidates[0]
+            if len(candidates) > 1:
+                self.placement = [self._burst(c) for c in candidates]
+                self.streams = candidates[max(range(len(candidates)), key=lambda i: self.placement[i])]
         self._next = 0
+
+    def _burst(self, streams, scenes_per_lane=6):
+        """Scenes per second of a short burst of replays on ``streams`` (the static inputs as they are); the modules'
+        buffers come back unchanged."""
+        import time
+        saved = [[(b, b.clone()) for b in m.buffers()] for m in self.models]
+        rate = 0.0
+        for timed in (False, True):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(self.lanes * scenes_per_lane):
+                with torch.cuda.stream(streams[i % self.lanes]):
+                    self.graphs[i % self.lanes].graph.replay()
+            torch.cuda.synchronize()
+            rate = self.lanes * scenes_per_lane / (time.perf_counter() - t0)
+        with torch.no_grad():
+            for per_model in saved:
+                for b, old in per_model:
+                    b.copy_(old)
+        torch.cuda.synchronize()
+        return rate
 
     def submit(self, data_batch):
         lane = self._next

@@ -350,9 +350,29 @@ def flush_lazy_stats(device=None):
             z.done = True
 
 
-# Concurrency level (PF_CONCURRENCY): 0 = single stream; 1 = flow tower beside the coarse stage;
-# 2 = + lattice kNN beside the first EdgeConv GEMM (default).
+# Concurrency level INSIDE one forward (PF_CONCURRENCY): 0 = single stream; 1 = flow tower beside the coarse stage;
+# 2 = + lattice kNN beside the first EdgeConv GEMM (default: best for ONE scene at a time, 422 / 487 depth maps/s for
+# 0 / 2 in round 1).  With several scenes in flight (graph.LanedForward) the lanes ARE the concurrency and every
+# lane is captured as a single chain (level 0): forks inside the graphs cost hardware queues that the lanes need
+# (profiles/r03b_lanes_queues.md: 3 lanes 771 / 938 / 808 depth maps/s at levels 0 / 1 / 2, 4 lanes on 4 queues 1030).
 CONCURRENCY = int(_os.environ.get("PF_CONCURRENCY", "2"))
+
+
+class concurrency(object):
+    """Context: forwards issued (or captured) inside run at this intra-forward concurrency level."""
+
+    def __init__(self, level):
+        self.level = int(level)
+
+    def __enter__(self):
+        global CONCURRENCY
+        self.saved, CONCURRENCY = CONCURRENCY, self.level
+        return self
+
+    def __exit__(self, *exc):
+        global CONCURRENCY
+        CONCURRENCY = self.saved
+        return False
 
 _side_streams = {}
 _lane = 0
@@ -364,6 +384,10 @@ def set_lane(lane):
     behind another scene's."""
     global _lane
     _lane = int(lane)
+
+
+def current_lane():
+    return _lane
 
 
 def side_stream(device, slot):

@@ -29,7 +29,7 @@ def timeit(fn, reps=100):
 
 LAYERS = [("conv0.0", 3, 8, 512, 640, 3, 1), ("conv0.1", 8, 8, 512, 640, 3, 1), ("conv1.0", 8, 16, 512, 640, 5, 2), ("conv1.1", 16, 16, 256, 320, 3, 1), ("conv2.0", 16, 32, 256, 320, 5, 2), ("conv2.1", 32, 32, 128, 160, 3, 1),
           ("conv3.0", 32, 64, 128, 160, 5, 2), ("conv3.1", 64, 64, 64, 80, 3, 1)]
-for views in (3, 5):
+for views in (3, 6):
     for name, cin, cout, h, w, ks, stride in LAYERS:
         conv = torch.nn.Conv2d(cin, cout, ks, stride=stride, padding=ks // 2, bias=False).to(dev)
         x = torch.randn(views, cin, h, w, device=dev)
