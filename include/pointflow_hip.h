@@ -203,20 +203,8 @@ typedef struct pf_bn_job {
 } pf_bn_job;
 int pf_bn_finalize_jobs_f32(const pf_bn_job* jobs, int njobs, void* stream);
 
-/* The finalize FOLDED INTO THE PRODUCER ("last block done", csrc/pf_bn_tail.h).  The kernels that write statistics
- * rows -- pf_pointwise_gemm_f32, pf_edge_stats_f32, pf_conv2d_f32, pf_conv2d_small_f32 -- accept up to two
- * pf_bn_job (host array `bn_jobs_host`, n_bn_jobs; the fields partials / T / pcols / G are filled in by the
- * call from its own launch geometry) and then perform those jobs themselves: blocks publish their rows
- * write-through, the last block of every cluster of rows reduces the cluster, the last cluster-reducer
- * finalizes -- fixed summation order, bit-reproducible, no separate launch.  With n_bn_jobs > 0 the statistics
- * buffer must hold pf_bn_tail_rows(G, T) extra rows after the (G, T, pcols, 2) block rows, and `tickets` must
- * point to pf_bn_tail_tickets(G, T) zero-initialised unsigned counters that no concurrently running launch
- * uses (the kernel leaves them zero again).  pcols must be 8/16/32/64/128 (else PF_ERR_UNSUPPORTED). */
-int pf_bn_tail_rows(int G, int T);
-int pf_bn_tail_tickets(int G, int T);
-
 /* The finalize FOLDED INTO THE CONSUMER (`in_bn`, host pointer, of pf_pointwise_gemm_f32 / pf_conv2d_wide_f32 /
- * pf_flow_head_f32; csrc/pf_bn_tail.h): instead of (in_scale, in_shift) rows the consumer gets the pf_bn_job of
+ * pf_flow_head_f32; csrc/pf_bn_resolve.h): instead of (in_scale, in_shift) rows the consumer gets the pf_bn_job of
  * the pending BatchNorm -- finished statistics rows `partials` (G, T, pcols, 2) of the PRODUCER launch, count,
  * gamma, beta, eps -- and every block computes the (scale, shift) of its statistic group itself while its first
  * loads are in flight (fixed summation order: bit-reproducible).  The job's scale / shift rows and running
@@ -233,7 +221,7 @@ int pf_bn_tail_tickets(int G, int T);
 int pf_pointwise_gemm_f32(const float* X, int x_point_major, int64_t ldx, const float* Wt, float* Y,
                           int64_t ldy, int G, int Ng, int K, int Nc, int Nc_store, const float* in_scale,
                           const float* in_shift, const pf_bn_job* in_bn, int groups_per_stat, double* col_partials,
-                          const pf_bn_job* bn_jobs_host, int n_bn_jobs, unsigned* tickets, void* stream);
+                          void* stream);
 
 /* Pass A of EdgeConv: for rows LE = [l (C) | e (C)] (point-major, ldle floats per point) and local
  * neighbour indices idx (G, Ng, k): partial sums over all (point, neighbour) pairs of
@@ -245,8 +233,7 @@ int pf_pointwise_gemm_f32(const float* X, int x_point_major, int64_t ldx, const 
  * hk = lat_ks/2 -- get_knn_3d's own index arithmetic (utils/torch_utils.py:51-59) done on the fly, so the six
  * gather passes of a PointFlow iteration read 16 instead of 128 index bytes per point.  lat_ks in {3, 5}. */
 int pf_edge_stats_f32(const float* LE, int64_t ldle, int C, const int64_t* idx, int k, int G, int Ng,
-                      double* partials, const pf_bn_job* bn_jobs_host, int n_bn_jobs, unsigned* tickets,
-                      const uint8_t* codes, int lat_ks, int lat_h, int lat_w, void* stream);
+                      double* partials, const uint8_t* codes, int lat_ks, int lat_h, int lat_w, void* stream);
 
 
 /* Pass B of EdgeConv (reference networks.py:37-43 / :74-79):
@@ -357,29 +344,6 @@ int pf_deconv3d_k3s2_f32(const float* xa, const float* xb, const float* w, float
                          int64_t Cout, int64_t D, int64_t H, int64_t W, const float* in_scale, const float* in_shift,
                          const pf_bn_job* in_bn, int samples_per_stat, double* partials, void* stream);
 
-/* ---- ImageConv (SURVEY.md section 8(f) item 1): conv2d on the f32 matrix cores ------------------------
- * Replaces the nn.Conv2d of the Conv2d blocks of reference networks.py:89-110 (nn/conv.py:62-77) for the
- * two shapes the towers use: 3x3 / stride 1 / pad 1 and 5x5 / stride 2 / pad 2, bias-free, Cout <= 64.
- * x (N,Cin,Hi,Wi) NCHW holds the RAW output of the previous conv when in_scale/in_shift (N/sps, Cin) are
- * given: relu(x*scale+shift) -- the previous block's BatchNorm+ReLU -- is applied while staging, so that
- * activation is never written to memory.  wp = weights packed as (ceil(Cin/4), K*K, 4, NCP) zero padded,
- * NCP = 16, 32 or 64 (>= Cout).  partials (N, pf_conv2d_blocks(...), Cout, 2) float64 or NULL receives
- * the BatchNorm statistics of y; samples_per_stat consecutive samples share in_scale rows. */
-int pf_conv2d_blocks(int64_t N, int64_t Cout, int64_t Hi, int64_t Wi, int kernel_size, int stride);
-int pf_conv2d_f32(const float* x, const float* wp, float* y, int64_t N, int64_t Cin, int64_t Cout, int64_t Hi,
-                  int64_t Wi, int kernel_size, int stride, const float* in_scale, const float* in_shift,
-                  int samples_per_stat, double* partials, const pf_bn_job* bn_jobs_host, int n_bn_jobs,
-                  unsigned* tickets, void* stream);
-
-/* Same contract as pf_conv2d_f32 for the few-channel layers (Cin <= 16, Cout = 8 or 16; 3x3/s1 or 5x5/s2),
- * on plain float32 FMAs.  wp = weights packed as (ceil(Cin/4), 4, K, K, Cout), zero padded over channels.
- * partials (N, pf_conv2d_small_blocks(...), Cout, 2). */
-int pf_conv2d_small_blocks(int64_t N, int64_t Hi, int64_t Wi, int kernel_size, int stride);
-int pf_conv2d_small_f32(const float* x, const float* wp, float* y, int64_t N, int64_t Cin, int64_t Cout, int64_t Hi,
-                        int64_t Wi, int kernel_size, int stride, const float* in_scale, const float* in_shift,
-                        int samples_per_stat, double* partials, const pf_bn_job* bn_jobs_host, int n_bn_jobs,
-                        unsigned* tickets, void* stream);
-
 /* The bottom of VolumeConv's U-Net (reference networks.py:136-141) on volumes of a few thousand voxels, one launch
  * per layer (csrc/conv3d_bottom.hip): 3x3x3 / pad 1 convolutions 32 -> 64 stride 2 and 64 -> 64 stride 1, and the
  * ConvTranspose3d 64 -> 32 (3x3x3, stride 2, pad 1, output_padding 1: output = twice the input per dimension).
@@ -401,10 +365,15 @@ int pf_deconv3d_bottom_f32(const float* x, const float* wp, float* y, int64_t N,
                            int64_t Hi, int64_t Wi, const float* in_scale, const float* in_shift, const pf_bn_job* in_bn,
                            int samples_per_stat, double* partials, void* stream);
 
-/* ImageConv's 16-, 32- and 64-channel layers (reference networks.py:95-110: 3x3/1 16->16, 32->32, 64->64 and
- * 5x5/2 8->16, 16->32, 32->64), the small-tile mapping of pf_conv2d_f32's contract (csrc/conv2d_wide.hip): same
- * x / y / in_scale / in_shift / samples_per_stat / partials meaning, partials (N, pf_conv2d_wide_blocks(...),
- * Cout, 2); in_bn: see "the finalize folded into the consumer" above.  wp is the weight packed
+/* ---- ImageConv (SURVEY.md section 8(f) item 1): conv2d on the f32 matrix cores ------------------------
+ * Replaces the nn.Conv2d of the Conv2d blocks of reference networks.py:89-110 (nn/conv.py:62-77) for the tower's
+ * shapes: 3x3 / stride 1 / pad 1 (3->8, 8->8, 16->16, 32->32, 64->64) and 5x5 / stride 2 / pad 2 (8->16, 16->32,
+ * 32->64), bias-free (csrc/conv2d_wide.hip).  x (N,Cin,Hi,Wi) NCHW holds the RAW output of the previous conv when
+ * in_scale / in_shift (N/sps, Cin) or in_bn (see "the finalize folded into the consumer" above) are given:
+ * relu(x*scale+shift) -- the previous block's BatchNorm+ReLU -- is applied while staging, so that activation is
+ * never written to memory; samples_per_stat consecutive samples share one affine row.  partials
+ * (N, pf_conv2d_wide_blocks(...), Cout, 2) float64 or NULL receives the BatchNorm statistics of y (per-block sums
+ * of y and y*y).  wp is the weight packed
  * (K, K, Cin/8, 2, Cout, 4): wp[kh][kw][kc][h][co][j] = w[co][8 kc + 4 h + j][kh][kw] for Cout 32 / 64, and
  * (K, K, 4, 16, Cin'/4), Cin' = Cin rounded up to 4: wp[kh][kw][kq][co][j] = w[co][(Cin'/4) kq + j][kh][kw] for
  * Cout 8 / 16 (zero where co >= Cout or the channel does not exist; shapes 3x3/1 3->8 and 8->8 as well).

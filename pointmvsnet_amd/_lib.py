@@ -47,10 +47,8 @@ PROTOTYPES = {
     "pf_flow_features_f32": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp], _i),
     "pf_stat_blocks": ([_i, _i], _i),
     "pf_gemm_blocks": ([_i, _i], _i),
-    "pf_bn_tail_rows": ([_i, _i], _i),
-    "pf_bn_tail_tickets": ([_i, _i], _i),
     "pf_pointwise_gemm_f32": ([_vp, _i, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, ctypes.POINTER(BnJob), _i,
-                               _vp, ctypes.POINTER(BnJob), _i, _vp, _vp], _i),
+                               _vp, _vp], _i),
     "pf_conv3d_blocks": ([_i64, _i64, _i64, _i64, _i64, _i], _i),
     "pf_conv3d_k3_f32": ([_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i, _vp, _vp, ctypes.POINTER(BnJob), _i,
                           _vp, _vp], _i),
@@ -68,16 +66,10 @@ PROTOTYPES = {
     "pf_deconv3d_bottom_blocks": ([_i64, _i64, _i64], _i),
     "pf_deconv3d_bottom_f32": ([_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, ctypes.POINTER(BnJob), _i,
                                 _vp, _vp], _i),
-    "pf_conv2d_blocks": ([_i64, _i64, _i64, _i64, _i, _i], _i),
-    "pf_conv2d_f32": ([_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i, _i, _vp, _vp, _i, _vp,
-                       ctypes.POINTER(BnJob), _i, _vp, _vp], _i),
     "pf_conv2d_wide_supported": ([_i64, _i64, _i, _i], _i),
     "pf_conv2d_wide_blocks": ([_i64, _i64, _i64, _i], _i),
     "pf_conv2d_wide_f32": ([_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i, _i, _vp, _vp, ctypes.POINTER(BnJob), _i,
                             _vp, _i, _vp], _i),
-    "pf_conv2d_small_blocks": ([_i64, _i64, _i64, _i, _i], _i),
-    "pf_conv2d_small_f32": ([_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i, _i, _vp, _vp, _i, _vp,
-                             ctypes.POINTER(BnJob), _i, _vp, _vp], _i),
     "pf_norm_blocks": ([_i64], _i),
     "pf_channel_stats_f32": ([_vp, _i64, _i64, _i64, _vp, _vp], _i),
     "pf_channel_affine_f32": ([_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _vp], _i),
@@ -85,8 +77,7 @@ PROTOTYPES = {
     "pf_channel_bn_apply2_f32": ([_vp, _vp, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _i, _vp, _vp, _vp, _vp, _f, _f, _vp,
                                   _i64, _i64, _i64, _i, _d, _vp], _i),
     "pf_channel_bn_fused_f32": ([_vp, _vp, _i64, _i64, _i64, _i, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _i, _vp], _i),
-    "pf_edge_stats_f32": ([_vp, _i64, _i, _vp, _i, _i, _i, _vp, ctypes.POINTER(BnJob), _i, _vp,
-                           _vp, _i, _i, _i, _vp], _i),
+    "pf_edge_stats_f32": ([_vp, _i64, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp], _i),
     "pf_edge_backward_reduce_f32": ([_vp, _i64, _i, _vp, _i, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp], _i),
     "pf_edge_backward_apply_f32": ([_vp, _i64, _i, _vp, _i, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i,
                                     _vp, _vp], _i),
@@ -145,38 +136,6 @@ def require_gpu(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:
             raise RuntimeError("pointmvsnet_amd: expected a GPU (HIP) tensor; this operator has no CPU path")
-
-
-# ---------------------------------------------------------------------------------------------
-# ticket counters of the fused BatchNorm finalize (csrc/pf_bn_tail.h)
-# ---------------------------------------------------------------------------------------------
-_TICKET_POOL = 1 << 16
-_ticket_pools = {}
-
-
-def tickets(device, n):
-    """Device pointer to ``n`` zero unsigned counters for ONE launch (pf_bn_tail_tickets).  Slots come round-robin
-    out of a per-device pool of 65 536 that starts zeroed; every launch leaves its counters zero again, and a
-    forward uses a few thousand, so two launches in flight at the same time (different streams of one forward)
-    never share a slot.  Under hipGraph capture the pointer is baked into the graph; the pool lives as long as
-    the process."""
-    key = str(device)
-    pool = _ticket_pools.get(key)
-    if pool is None:
-        pool = _ticket_pools[key] = [torch.zeros(_TICKET_POOL, dtype=torch.int32, device=device), 0]
-    buf, cur = pool
-    if n > _TICKET_POOL:
-        raise RuntimeError("pointmvsnet_amd: a launch needs %d ticket counters (pool %d)" % (n, _TICKET_POOL))
-    if cur + n > _TICKET_POOL:
-        cur = 0
-    pool[1] = cur + n
-    return ctypes.c_void_p(buf.data_ptr() + 4 * cur)
-
-
-def reset_tickets():
-    """Re-zero every pool (after a failed launch left counters behind)."""
-    for buf, _ in _ticket_pools.values():
-        buf.zero_()
 
 
 def status():

@@ -1,37 +1,33 @@
 // ImageConv, all eleven layers of a tower (reference networks.py:84-124).  First the
 // 32- and 64-channel layers (conv2d_wide_kernel); the 8- and 16-channel ones follow further down
-// (conv2d_wide16_kernel, the same idea on the 16x16x4 MFMA).  KxK conv2d
-// (3x3 stride 1 or 5x5 stride 2, pad K/2, no bias) as an implicit GEMM on v_mfma_f32_32x32x2_f32, with the previous
-// layer's BatchNorm+ReLU applied while the input patch is staged and this layer's BatchNorm batch statistics in
-// the epilogue -- the same contract as pf_conv2d_f32 (conv2d.hip), a different machine mapping for the layers
-// whose maps are SMALL (64 x 80 pixels x 3 views at 64 channels: 960 wave tiles of 32 pixels x 32 channels for
-// 1 024 SIMDs -- every SIMD gets ONE wave, so that wave has to keep its matrix pipe busy on its own):
+// (conv2d_wide16_kernel, the same idea on the 16x16x4 MFMA).  KxK conv2d (3x3 stride 1 or 5x5 stride 2, pad K/2, no
+// bias) as an implicit GEMM on v_mfma_f32_32x32x2_f32, with the previous layer's BatchNorm+ReLU applied while the input
+// patch is staged and this layer's BatchNorm batch statistics in the epilogue:
 //
 //   * the staged input patch is channel-last in LDS ([pixel][C_in + 4]) and the reduction index is assigned to
 //     (MFMA step, lane half) as  c = 8 kc + 4 h + j : lane (pixel m, half h) reads the 16 bytes
 //     patch[pixel(m) + tap][8 kc + 4 h ..] with ONE ds_read_b128 and feeds element j to step (kc, j) -- a quarter
 //     of an LDS instruction per MFMA and, the patch geometry being compile-time, no address arithmetic at all
-//     (base register + immediate for every tap and chunk).  conv2d.hip's 16x16x4 loop issues 1.25 ds_read_b32
-//     and ~7 VALU per MFMA of half the size (SQ counters, profiles/r02r_sq_counters.md);
-//   * the weights are packed on the host in the matching order [kh][kw][kc][h][c_out][j], so a lane's B operand
-//     for four steps is one ds_read_b128 of consecutive 16-byte pieces (conflict-free); one kernel ROW of weights
-//     (K x C_in x C_out floats, 40-48 KB at 64 channels) is resident per stage, double buffered: the next row
-//     travels global -> registers while the matrix cores work, one barrier per kernel row (3 or 5 per tile);
+//     (base register + immediate for every tap and chunk).  Round 1's 16x16x4 loop issued 1.25 ds_read_b32 and ~7 VALU
+//     per MFMA of half the size (SQ counters, profiles/r02r_sq_counters.md);
+//   * the weights are packed on the host in the matching order [kh][kw][kc][h][c_out][j], so a lane's B operand for
+//     four steps is one 16-byte piece; a wave reads it from global memory / L2 as two contiguous 512-byte runs, six
+//     pieces ahead (round 3; round 2 staged one kernel row of weights at a time through 80-100 KB of LDS);
 //   * a 256-thread block owns (2 * NWM) x 16 output pixels x C_out channels: wave (wm, wn) the two rows
 //     2 wm, 2 wm + 1 (32 pixels) x channels [32 wn, 32 wn + 32); C_out = 64: 2 x 2 waves (4 x 16 pixels), C_out = 32:
 //     4 x 1 (8 x 16 pixels).  The accumulator layout (lane = channel, 4 consecutive registers = 4 consecutive
 //     pixels of a row) stores straight to NCHW as 16-byte pieces -- no transpose through LDS; with cl_out the same
 //     registers go out channel-last (a half-wave = 32 consecutive channels of one pixel) for the coarse warp;
 //   * statistics: per lane over its 16 outputs (float), the two lane halves by one shuffle, waves through LDS,
-//     one float64 partial row per block -- the layout pf_bn_finalize consumes from pf_conv2d_f32.
+//     one float64 partial row per block -- the layout pf_bn_finalize_jobs_f32 / pf_bn_resolve consume.
 //
-// Exact float32: every output is one fmaf chain over (kh, kw, kc, j, h); the order differs from conv2d.hip's and
-// from the library's Winograd kernels, so results agree with either to rounding (tests compare with float64).
+// Exact float32: every output is one fmaf chain over (kh, kw, kc, j, h); the order differs from the library's, so
+// results agree with it to rounding (tests compare with float64).
 // Bound: the f32 matrix peak (157 TF): 2 K^2 C_in C_out flop per output pixel against 4 (C_in / S^2 + C_out) bytes.
 #include <stdlib.h>
 
 #include "pf_common.h"
-#include "pf_bn_tail.h"
+#include "pf_bn_resolve.h"
 
 namespace {
 
@@ -55,13 +51,11 @@ struct WideCfg {
                                                         // consecutive pixels fall on 16 distinct bank quads)
   static constexpr int PATCH = NPIX * RS;
   static constexpr int KC = CIN / 8;
-  static constexpr int WROW = KS * CIN * COUT;          // floats of one kernel row of packed weights
-  static constexpr int WROW4 = WROW / 4;
-  static constexpr int NWR = (WROW4 + 255) / 256;       // 16-byte pieces per thread per row
-  static constexpr size_t LDS = sizeof(float) * (size_t)(PATCH + 2 * WROW + 2 * CIN) + sizeof(double) * 4 * 32 * 2;
+  static constexpr size_t LDS = sizeof(float) * (size_t)(PATCH + 2 * CIN) + sizeof(double) * 4 * 32 * 2;
   static_assert(COUT == 32 || COUT == 64, "C_out is 32 or 64");
-  static_assert(CIN % 8 == 0 && PATCH % 4 == 0 && WROW % 4 == 0, "16-byte pieces");
-  static_assert(LDS <= 160 * 1024, "tile does not fit the LDS of a CU");
+  static_assert(CIN % 8 == 0 && PATCH % 4 == 0, "16-byte pieces");
+  static_assert(PATCH * sizeof(float) >= 4096, "pf_bn_resolve's scratch lives in the (still empty) patch");
+  static_assert(LDS <= 80 * 1024, "two blocks per CU");
 };
 
 // The input patch of a block: NCHW planes -> [pixel][channel] in LDS, the previous BatchNorm+ReLU on the way.
@@ -224,116 +218,21 @@ __device__ __forceinline__ void wide_epilogue(const f32x16& acc, float* __restri
 }
 
 // AFFINE: 0 = x is taken as is; 1 = relu(x * in_scale + in_shift), rows (N/sps, CIN); 2 = the same with the rows
-// computed here from the PRODUCER's statistics (pf_bn_resolve: the pending BatchNorm never gets its own launch)
+// computed here from the PRODUCER's statistics (pf_bn_resolve: the pending BatchNorm never gets its own launch).
+// The B operands (weights) come straight from global memory / L2 into a ring of registers: no weight rows in LDS
+// (27-55 KB of patch per block instead of the 75-130 KB of round 2's row-staged form, so several blocks -- waves per
+// SIMD -- share a CU and cover each other's prologue, LDS and memory latencies; two towers' worth of the 64-channel
+// layer in one launch: 25.9 us against 31.8, profiles/r03c_microbench_conv2d_wide.log) and no barrier inside the tile.
+// A lane's B operand for four MFMA steps is one 16-byte load; a wave's load is two contiguous 512-byte runs of the
+// host-packed weights.
+
 template <int KS, int STRIDE, int CIN, int COUT, int AFFINE>
 __global__ __launch_bounds__(256) void conv2d_wide_kernel(const float* __restrict__ x, const float* __restrict__ wp,
-                                                          float* __restrict__ y, WideGeom g,
-                                                          const float* __restrict__ in_scale,
-                                                          const float* __restrict__ in_shift,
-                                                          double* __restrict__ partials, pf_bn_job in_bn) {
-  using C = WideCfg<KS, STRIDE, CIN, COUT>;
-  constexpr int PW = C::PW, RS = C::RS, NPIX = C::NPIX, WROW = C::WROW, WROW4 = C::WROW4, NWR = C::NWR;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* patch = lds;
-  float* wbuf = lds + C::PATCH;
-  float* aff = wbuf + 2 * WROW;                       // scale[CIN], shift[CIN] of the pending BatchNorm
-  double* red = reinterpret_cast<double*>(aff + 2 * CIN);
-
-  const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int m = lane & 31, h = lane >> 5;
-  const int wm = wave / C::NWN, wn = wave % C::NWN;
-  const int n = blockIdx.y;
-  const int tw = blockIdx.x % g.tiles_w, th = blockIdx.x / g.tiles_w;
-  const int oh0 = th * C::TH, ow0 = tw * C::TW;
-  const int ih0 = oh0 * STRIDE - C::PAD, iw0 = ow0 * STRIDE - C::PAD;
-  const int plane_i = g.Hi * g.Wi;                    // CIN * plane_i < 2^31 (checked on the host)
-  const float* xb = x + (int64_t)n * CIN * plane_i;
-
-  // ---- kernel row 0 of the weights: global -> registers ------------------------------------------------------
-  f32x4 rw[NWR];
-  auto load_w = [&](int kh) {
-    const f32x4* src = reinterpret_cast<const f32x4*>(wp + (int64_t)kh * WROW);
-#pragma unroll
-    for (int r = 0; r < NWR; ++r) {
-      const int e = tid + 256 * r;
-      rw[r] = src[e < WROW4 ? e : WROW4 - 1];
-    }
-  };
-  auto store_w = [&](int buf) {
-    f32x4* dst = reinterpret_cast<f32x4*>(wbuf + buf * WROW);
-#pragma unroll
-    for (int r = 0; r < NWR; ++r) {
-      const int e = tid + 256 * r;
-      if (256 * (r + 1) <= WROW4 || e < WROW4) dst[e] = rw[r];
-    }
-  };
-  load_w(0);
-
-  wide_stage_patch<CIN, NPIX, PW, RS, AFFINE>(xb, plane_i, ih0, iw0, g.Hi, g.Wi, patch, aff, in_scale, in_shift,
-                                              n / g.sps, in_bn, reinterpret_cast<double*>(wbuf));
-  store_w(0);
-  __syncthreads();
-
-  // ---- the MFMA loop: every LDS address below is (lane base) + (compile-time offset) ------------------------------
-  f32x16 acc;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-  const float* abase = patch + ((2 * wm + (m >> 4)) * STRIDE * PW + (m & 15) * STRIDE) * RS + 4 * h;
-  const float* bbase = wbuf + (h * COUT + wn * 32 + m) * 4;
-  // (operands of step t + 1 are read while the four MFMAs of step t run: a wave is alone on its SIMD here, so
-  // nobody else would cover the LDS latency; the sched_barriers keep the compiler from sinking the reads again)
-  constexpr int T = KS * C::KC;                        // 16-byte operand pairs per kernel row
-#pragma unroll
-  for (int kh = 0; kh < KS; ++kh) {
-    if (kh + 1 < KS) load_w(kh + 1);
-    const float* bb = bbase + (kh & 1) * WROW;
-    f32x4 a = *reinterpret_cast<const f32x4*>(abase + (kh * PW) * RS);
-    f32x4 b = *reinterpret_cast<const f32x4*>(bb);
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-      f32x4 an = a, bn = b;
-      if (t + 1 < T) {
-        const int kw = (t + 1) / C::KC, kc = (t + 1) % C::KC;
-        an = *reinterpret_cast<const f32x4*>(abase + (kh * PW + kw) * RS + 8 * kc);
-        bn = *reinterpret_cast<const f32x4*>(bb + (t + 1) * 2 * COUT * 4);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      a = an;
-      b = bn;
-    }
-    if (kh + 1 < KS) {
-      store_w((kh + 1) & 1);
-      __syncthreads();
-    }
-  }
-
-  wide_epilogue<C, COUT>(acc, y, g, partials, red, n, oh0, ow0, wm, wn, wave, m, h, tid);
-}
-
-// Variant: the B operands (weights) straight from global memory / L2 into a ring of registers -- no weight rows in
-// LDS (27-55 KB of patch instead of 75-130 KB: several blocks per CU, i.e. several waves per SIMD covering each
-// other's prologue, LDS and memory latencies) and no barrier inside the tile.  A lane's B operand for four MFMA steps
-// is one 16-byte load; a wave's load is two contiguous 512-byte runs of the host-packed weights.
-template <int KS, int STRIDE, int CIN, int COUT>
-struct WideGCfg : WideCfg<KS, STRIDE, CIN, COUT> {
-  using B = WideCfg<KS, STRIDE, CIN, COUT>;
-  static constexpr size_t LDS = sizeof(float) * (size_t)(B::PATCH + 2 * CIN) + sizeof(double) * 4 * 32 * 2;
-  static_assert(B::PATCH * sizeof(float) >= 4096, "pf_bn_resolve's scratch lives in the (still empty) patch");
-};
-
-template <int KS, int STRIDE, int CIN, int COUT, int AFFINE>
-__global__ __launch_bounds__(256) void conv2d_wide_g_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                             float* __restrict__ y, WideGeom g,
                                                             const float* __restrict__ in_scale,
                                                             const float* __restrict__ in_shift,
                                                             double* __restrict__ partials, pf_bn_job in_bn) {
-  using C = WideGCfg<KS, STRIDE, CIN, COUT>;
+  using C = WideCfg<KS, STRIDE, CIN, COUT>;
   constexpr int PW = C::PW, RS = C::RS, NPIX = C::NPIX;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* patch = lds;
@@ -401,13 +300,6 @@ int launch_wide_mode(const float* x, const float* wp, float* y, WideGeom g, int6
   g.tiles_w = (g.Wo + C::TW - 1) / C::TW;
   const int tiles_h = (g.Ho + C::TH - 1) / C::TH;
   dim3 grid((unsigned)(tiles_h * g.tiles_w), (unsigned)N);
-  static const int global_b = []() { const char* e = getenv("PF_WIDE_GLOBALB"); return e ? atoi(e) : 0; }();
-  if (global_b) {
-    using G = WideGCfg<KS, STRIDE, CIN, COUT>;
-    hipLaunchKernelGGL((conv2d_wide_g_kernel<KS, STRIDE, CIN, COUT, AFFINE>), grid, dim3(256), G::LDS, s, x, wp, y, g,
-                       in_scale, in_shift, partials, in_bn);
-    return pf_launch_status();
-  }
   hipLaunchKernelGGL((conv2d_wide_kernel<KS, STRIDE, CIN, COUT, AFFINE>), grid, dim3(256), C::LDS, s, x, wp, y, g,
                      in_scale, in_shift, partials, in_bn);
   return pf_launch_status();
@@ -630,17 +522,9 @@ __global__ __launch_bounds__(256) void conv2d_wide16_kernel(const float* __restr
   }
 }
 
-// Blocks per sample of the 16-wide kernel: PF_WIDE16_TPB tiles per block (default 2), walked with a stride of the
-// block count so that neighbouring blocks stay on neighbouring tiles.
-int wide16_tiles_per_block() {
-  const char* e = getenv("PF_WIDE16_TPB");
-  const int v = e ? atoi(e) : 2;
-  return v >= 1 && v <= 8 ? v : 2;
-}
-int wide16_blocks(int tiles) {
-  const int tpb = wide16_tiles_per_block();
-  return (tiles + tpb - 1) / tpb;
-}
+// Blocks per sample of the 16-wide kernel: two tiles per block (1 / 3 / 4 measured slower, profiles/r02aj_small_ab.txt),
+// walked with a stride of the block count so that neighbouring blocks stay on neighbouring tiles.
+int wide16_blocks(int tiles) { return (tiles + 1) / 2; }
 
 template <int KS, int STRIDE, int CIN, int COUT, int AFFINE>
 int launch_wide16_mode(const float* x, const float* wp, float* y, WideGeom g, int64_t N, const float* in_scale,

@@ -31,7 +31,7 @@
 #include <stdlib.h>
 
 #include "pf_common.h"
-#include "pf_bn_tail.h"
+#include "pf_bn_resolve.h"
 
 namespace {
 
@@ -43,7 +43,7 @@ struct ConvGeom {
   int tiles_d, tiles_h, tiles_w;
   // the pending BatchNorm + ReLU of the INPUT, applied while a channel is staged (zero padding after it):
   // aff_mode 0 = none, 1 = (scale, shift) rows (N / sps, Cin), 2 = resolved by every block from the producer's
-  // statistics rows (pf_bn_resolve, pf_bn_tail.h).  aff_off: float offset of the 2 * Cin affine values in LDS.
+  // statistics rows (pf_bn_resolve, pf_bn_resolve.h).  aff_off: float offset of the 2 * Cin affine values in LDS.
   int aff_mode, sps, aff_off;
   const float* in_scale;
   const float* in_shift;
@@ -358,26 +358,16 @@ size_t lds_bytes_for(const ConvGeom& g, int NT) {      // + the input BatchNorm'
   return lds_work_bytes(g, NT) + sizeof(float) * 2 * (size_t)g.Cin;
 }
 
-// Tuning hook (microbenchmarks only): PF_CONV3D_VARIANT = 10*TD + MINW forces the tile depth and the
-// waves-per-SIMD target of the NT == 1 kernels.
-int variant_override() {
-  const char* e = getenv("PF_CONV3D_VARIANT");
-  return e ? atoi(e) : 0;
-}
-
 // Deepest admissible tile (TD in {4,2,1}) whose LDS image fits and that still leaves >= 512 blocks of work
 // (2 per CU); if none has 512 blocks, the shallowest that fits.
 int pick_td(int64_t Cin, int64_t Cout, int64_t Di, int64_t Hi, int64_t Wi, int stride) {
   const int NT = (int)((Cout + 15) / 16);
   int best = 0;
-  const int ov = variant_override() / 10;
   // stride-2 TD=4 would need > 80 KiB of LDS; with <= 16 output channels TD=2 at twice the occupancy beats TD=4
-  for (int td = (stride == 1 && (NT > 1 || ov)) ? 4 : 2; td >= 1; td >>= 1) {
+  for (int td = (stride == 1 && NT > 1) ? 4 : 2; td >= 1; td >>= 1) {
     const ConvGeom g = make_geom(Cin, Cout, Di, Hi, Wi, stride, td);
     if (lds_bytes_for(g, NT) > kMaxLds) continue;
-    if (ov && NT == 1 && td > ov) continue;
     best = td;
-    if (ov && NT == 1) return td;
     if ((int64_t)g.tiles_d * g.tiles_h * g.tiles_w >= 512) return td;
   }
   return best;
@@ -412,12 +402,6 @@ int launch_w(const float* x, const float* wp, float* y, const ConvGeom& g, int64
   // measured (profiles/r01g_microbench_conv3d.log): the 64 -> 8 layer runs 151 us at TD 4 / 2 waves per
   // SIMD and 131 us at TD 2 / 4 waves per SIMD (124 VGPRs, no spills); the stride-2 tile is best left alone
   constexpr int kDefault = (NT == 1 && STRIDE == 1 && TD == 2) ? 4 : 2;
-  if constexpr (NT == 1) {
-    const int minw = variant_override() % 10;
-    if (minw == 2) return launch<NT, STRIDE, TD, 2>(x, wp, y, g, N, partials, s);
-    if (minw == 4) return launch<NT, STRIDE, TD, 4>(x, wp, y, g, N, partials, s);
-    if (minw == 5) return launch<NT, STRIDE, TD, 5>(x, wp, y, g, N, partials, s);
-  }
   return launch<NT, STRIDE, TD, kDefault>(x, wp, y, g, N, partials, s);
 }
 

@@ -10,7 +10,7 @@
 //     output is one exact f32 fmaf chain, and still a wave for half of the chip's SIMDs;
 //   * the input patch (3 depths x 6 x 6 or 9 x 9 voxels, channel-last, <= 36 KB) sits in LDS with the PREVIOUS
 //     layer's BatchNorm + ReLU applied while it is staged -- from (scale, shift) rows or resolved by the block itself
-//     from the producer's statistics rows (pf_bn_resolve, pf_bn_tail.h); the weights never touch LDS: each is used by
+//     from the producer's statistics rows (pf_bn_resolve, pf_bn_resolve.h); the weights never touch LDS: each is used by
 //     one wave of a block only, so every lane streams its own 16-byte pieces from L2 through a ring of 32 registers
 //     (the kernels are bound by that stream's latency, not by the 0.1 GFLOP of matrix work);
 //   * the transposed convolution is the same GEMM with the 2 x 2 x 2 input neighbourhood as reduction index and
@@ -22,7 +22,7 @@
 #include <stdlib.h>
 
 #include "pf_common.h"
-#include "pf_bn_tail.h"
+#include "pf_bn_resolve.h"
 
 namespace {
 

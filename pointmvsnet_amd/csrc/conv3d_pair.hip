@@ -261,17 +261,8 @@ int pf_conv3d_k3_pair_f32(const float* x, const float* wp, float* y, int64_t N, 
   constexpr size_t lds_bytes = pair_lds_bytes<kPairTD>();
   static_assert(lds_bytes <= 64 * 1024, "pair tile must fit the default dynamic LDS limit");
   dim3 grid((unsigned)pair_blocks(g), (unsigned)N);
-  const char* mw = getenv("PF_CONV3D_PAIR_MINW");             // tuning hook: waves per SIMD the registers are capped for
-  const int minw = mw ? atoi(mw) : 3;
-  if (minw == 2)
-    hipLaunchKernelGGL((conv3d_k3_pair_kernel<kPairTD, 2>), grid, dim3(256), lds_bytes, (hipStream_t)stream, x, wp, y, g,
-                       partials);
-  else if (minw == 3)
-    hipLaunchKernelGGL((conv3d_k3_pair_kernel<kPairTD, 3>), grid, dim3(256), lds_bytes, (hipStream_t)stream, x, wp, y, g,
-                       partials);
-  else
-    hipLaunchKernelGGL((conv3d_k3_pair_kernel<kPairTD, 4>), grid, dim3(256), lds_bytes, (hipStream_t)stream, x, wp, y, g,
-                       partials);
+  hipLaunchKernelGGL((conv3d_k3_pair_kernel<kPairTD, 3>), grid, dim3(256), lds_bytes, (hipStream_t)stream, x, wp, y, g,
+                     partials);
   return pf_launch_status();
 }
 

@@ -16,7 +16,7 @@
 // stores two adjacent floats per output row.
 // Bound: latency / issue (tiny); algorithmic bytes 4*(Cin*vol*(1 or 2) + Cout*8*vol).
 #include "pf_common.h"
-#include "pf_bn_tail.h"
+#include "pf_bn_resolve.h"
 
 namespace {
 

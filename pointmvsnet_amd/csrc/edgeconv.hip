@@ -29,7 +29,7 @@
 #include <stdlib.h>
 
 #include "pf_common.h"
-#include "pf_bn_tail.h"
+#include "pf_bn_resolve.h"
 
 namespace {
 
@@ -55,7 +55,7 @@ template <bool POINT_MAJOR, int NT>
 __global__ __launch_bounds__(256, 2) void pointwise_gemm_kernel(
     const float* __restrict__ X, int64_t ldx, const float* __restrict__ Wt, float* __restrict__ Y, int64_t ldy,
     int Ng, int K, int Nc_store, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
-    int groups_per_stat, double* __restrict__ partials, int T, PfTail tail) {
+    int groups_per_stat, double* __restrict__ partials, int T) {
   constexpr int NC = NT * 32;
   constexpr int KC = NT == 4 ? 16 : 32;
   constexpr int NA = KC * GT / 256;   // A floats staged per thread per chunk (16 or 8)
@@ -208,16 +208,9 @@ __global__ __launch_bounds__(256, 2) void pointwise_gemm_kernel(
         q += red[((w * NC) + tid) * 2 + 1];
       }
       double* o = partials + (((int64_t)g * T + tb) * NC + tid) * 2;
-      if (tail.njobs > 0) {                // rows another CU reduces go out write-through (pf_bn_tail.h)
-        pf_row_store(o, s);
-        pf_row_store(o + 1, q);
-      } else {
-        o[0] = s;
-        o[1] = q;
-      }
+      o[0] = s;
+      o[1] = q;
     }
-    // BatchNorm finalize by the last block (pf_bn_tail.h); the staging buffers are free by now
-    if (tail.njobs > 0) pf_bn_tail<256>(tail, g, tb, red);
   }
 }
 
@@ -237,7 +230,7 @@ __global__ __launch_bounds__(256, 2) void pointwise_gemm_kernel(
 // from the chunked kernel's (still one exact f32 fmaf chain per output), so results agree to rounding, not bits.
 // ------------------------------------------------------------------------------------------------
 // AFFINE: 0 = rows as they are; 1 = relu(x * in_scale + in_shift); 2 = the same, the rows computed by every block
-// from the producer's statistics (pf_bn_resolve, pf_bn_tail.h: the pending BatchNorm gets no launch of its own)
+// from the producer's statistics (pf_bn_resolve, pf_bn_resolve.h: the pending BatchNorm gets no launch of its own)
 template <int KJ, int NT, int AFFINE>
 __global__ __launch_bounds__(256) void pointwise_gemm_direct_kernel(
     const float* __restrict__ X, int64_t ldx, const float* __restrict__ Wt, float* __restrict__ Y, int64_t ldy,
@@ -505,7 +498,7 @@ template <int C, int K>   // K == 0: neighbour count known only at run time
 __global__ __launch_bounds__(256) void edge_stats_kernel(const float* __restrict__ LE, int64_t ldle,
                                                          const int64_t* __restrict__ idx, int k, int Ng,
                                                          double* __restrict__ partials, int T,
-                                                         unsigned* __restrict__ status, PfTail tail,
+                                                         unsigned* __restrict__ status,
                                                          const uint8_t* __restrict__ codes, Lattice lat) {
   constexpr int Q = C / 4;         // lanes per point
   constexpr int PPB = 256 / Q;     // points per pass
@@ -571,10 +564,8 @@ __global__ __launch_bounds__(256) void edge_stats_kernel(const float* __restrict
     double acc = 0.0;
     for (int s = 0; s < PPB; ++s) acc += red[(s * Q + qq) * 8 + comp];
     double* o = partials + (((int64_t)g * T + tb) * C + 4 * qq + (comp & 3)) * 2 + (comp >> 2);
-    if (tail.njobs > 0) pf_row_store(o, acc);
-    else *o = acc;
+    *o = acc;
   }
-  if (tail.njobs > 0) pf_bn_tail<256>(tail, g, tb, red);
 }
 
 template <int C, int K>
@@ -884,12 +875,8 @@ constexpr int kBnThreads = 256;
 // Channels per block: the kernel is a chain of dependent L2 round trips (rows -> LDS -> statistics), so the more
 // blocks share the rows of a job the fewer batches each thread walks through -- in principle; measured
 // (profiles/r02aj_small_ab.txt) 4 channels per block beat 2 and 1 (646 / 645 / 642 depth maps/s): the fixed
-// launch + round-trip latency dominates, not the row batches.  PF_BN_CB: tuning hook.
-static int bn_channels_per_block() {
-  const char* e = getenv("PF_BN_CB");
-  const int v = e ? atoi(e) : 4;
-  return (v == 1 || v == 2 || v == 4) ? v : 4;
-}
+// launch + round-trip latency dominates, not the row batches.
+static int bn_channels_per_block() { return 4; }
 struct BnJobs {
   pf_bn_job j[kBnJobs];
 };
@@ -980,7 +967,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_finalize_kernel(BnJobs jobs, in
 // ------------------------------------------------------------------------------------------------
 // flow head
 // ------------------------------------------------------------------------------------------------
-// LAZY: the last BatchNorm of the MLP is resolved here (pf_bn_tail.h, consumer side): a block's pixels belong to
+// LAZY: the last BatchNorm of the MLP is resolved here (pf_bn_resolve.h, consumer side): a block's pixels belong to
 // all ratio^2 sub-grids, so every block reduces the statistics rows of all S = G groups x 16 channels (one
 // (group, channel) pair per thread, S * 16 <= 256) -- the rows of the persistent GEMM blocks, 32-128 per group.
 template <bool LAZY>
@@ -1107,25 +1094,13 @@ int pf_stat_blocks(int G, int Ng) {
   return (tiles + per - 1) / per;
 }
 
-int pf_bn_tail_rows(int G, int T) {
-  if (G <= 0 || T <= 0) return 0;
-  return pf_tail_fan(G, T) > 1 ? G * pf_tail_clusters(G, T) : 0;
-}
-
-int pf_bn_tail_tickets(int G, int T) {
-  if (G <= 0 || T <= 0) return 0;
-  return 1 + (pf_tail_fan(G, T) > 1 ? G * pf_tail_clusters(G, T) : 0);
-}
-
 // Blocks per group of the pointwise GEMM: about two persistent blocks per CU over the whole launch (the direct-A
 // kernel keeps W in LDS for a block's lifetime, so a block should own several tiles), every block the same number
 // of tiles; a launch with fewer tiles than that gives each tile its own block.
 int pf_gemm_blocks(int G, int Ng) {
   if (G <= 0 || Ng <= 0) return 0;
   const int tiles = (Ng + GT - 1) / GT;
-  const char* e = getenv("PF_GEMM_CAP");              // tuning hook: persistent GEMM blocks over all groups
-  const int total = e ? atoi(e) : 512;
-  int cap = (total > 0 ? total : 512) / G;
+  int cap = 512 / G;                                  // persistent GEMM blocks over all groups (measured: fewer is slower)
   cap = cap < 16 ? 16 : cap;
   if (tiles <= cap) return tiles;
   const int per = (tiles + cap - 1) / cap;
@@ -1144,30 +1119,26 @@ static int bn_materialize_rows(const pf_bn_job* in_bn, hipStream_t s) {
 int pf_pointwise_gemm_f32(const float* X, int x_point_major, int64_t ldx, const float* Wt, float* Y, int64_t ldy,
                           int G, int Ng, int K, int Nc, int Nc_store, const float* in_scale,
                           const float* in_shift, const pf_bn_job* in_bn, int groups_per_stat, double* col_partials,
-                          const pf_bn_job* bn_jobs, int n_bn_jobs, unsigned* tickets, void* stream) {
+                          void* stream) {
   PF_REQUIRE(in_bn == nullptr || in_scale == nullptr);
   if (in_bn != nullptr && G > 0 && Ng > 0) {
     PF_REQUIRE(groups_per_stat >= 1 && G % groups_per_stat == 0);
     const int rc = pf_bn_in_check(in_bn, K, G / groups_per_stat);
     if (rc != PF_OK && rc != PF_ERR_UNSUPPORTED) return rc;
-    const char* legacy = getenv("PF_GEMM_LEGACY");
     const int kj = (K + 7) / 8, nt = Nc / 32;
     const bool shape = (kj == 17 && nt == 2) || (kj == 4 && nt == 2) || (kj == 8 && nt == 4) || (kj == 28 && nt == 2) ||
                        (kj == 8 && nt == 2) || (kj == 8 && nt == 1);
     const bool direct = rc == PF_OK && shape && x_point_major && (K % 4) == 0 && (ldx % 4) == 0 &&
-                        kj * 8 * Nc <= 16384 && !(legacy && legacy[0] == '1') &&
-                        (reinterpret_cast<uintptr_t>(X) % 16) == 0 && n_bn_jobs == 0 && K <= 256;
+                        kj * 8 * Nc <= 16384 && (reinterpret_cast<uintptr_t>(X) % 16) == 0 && K <= 256;
     if (!direct) {
       const int rc2 = bn_materialize_rows(in_bn, (hipStream_t)stream);
       if (rc2 != PF_OK) return rc2;
       PF_REQUIRE(in_bn->ld_affine == K);
       return pf_pointwise_gemm_f32(X, x_point_major, ldx, Wt, Y, ldy, G, Ng, K, Nc, Nc_store, in_bn->scale,
-                                   in_bn->shift, nullptr, groups_per_stat, col_partials, bn_jobs, n_bn_jobs, tickets,
-                                   stream);
+                                   in_bn->shift, nullptr, groups_per_stat, col_partials, stream);
     }
   }
   PF_REQUIRE(G >= 0 && Ng >= 0 && K >= 1 && Nc >= 32 && Nc_store >= 1 && Nc_store <= Nc);
-  PF_REQUIRE(n_bn_jobs >= 0 && (n_bn_jobs == 0 || col_partials != nullptr));
   PF_REQUIRE(Nc % 32 == 0 && groups_per_stat >= 1);
   if (Nc != 32 && Nc != 64 && Nc != 128) return PF_ERR_UNSUPPORTED;
   PF_REQUIRE((in_scale == nullptr) == (in_shift == nullptr));
@@ -1176,21 +1147,14 @@ int pf_pointwise_gemm_f32(const float* X, int x_point_major, int64_t ldx, const 
   PF_REQUIRE(X && Wt && Y && ldy >= Nc_store);
   if (x_point_major) PF_REQUIRE(ldx >= K);
   const int T = pf_gemm_blocks(G, Ng);
-  PfTail tail;
-  {
-    const int rc = pf_tail_setup(tail, bn_jobs, n_bn_jobs, col_partials, G, T, Nc, tickets);
-    if (rc != PF_OK) return rc;
-  }
   dim3 grid((unsigned)T, (unsigned)G);
   hipStream_t s = (hipStream_t)stream;
   // the PointFlow chain's shapes (point-major rows, K a multiple of 4 that fits LDS with W): direct-A kernel
   {
     const pf_bn_job no_bn = {};
-    const char* legacy = getenv("PF_GEMM_LEGACY");
     const int kj = (K + 7) / 8, nt = Nc / 32;
     const bool direct = x_point_major && (K % 4) == 0 && (ldx % 4) == 0 && kj * 8 * Nc <= 16384 &&
-                        !(legacy && legacy[0] == '1') && (reinterpret_cast<uintptr_t>(X) % 16) == 0 &&
-                        tail.njobs == 0;      // (a launch that finalizes its own BatchNorm takes the chunked kernel)
+                        (reinterpret_cast<uintptr_t>(X) % 16) == 0;
 #define PF_GEMM_DIRECT(KJV, NTV)                                                                                   \
   if (direct && kj == KJV && nt == NTV) {                                                                          \
     if (in_bn != nullptr)                                                                                          \
@@ -1214,7 +1178,7 @@ int pf_pointwise_gemm_f32(const float* X, int x_point_major, int64_t ldx, const 
   }
 #define PF_GEMM_LAUNCH(PM, NTV)                                                                                  \
   hipLaunchKernelGGL((pointwise_gemm_kernel<PM, NTV>), grid, dim3(256), 0, s, X, ldx, Wt, Y, ldy, Ng, K, Nc_store, \
-                     in_scale, in_shift, groups_per_stat, col_partials, T, tail)
+                     in_scale, in_shift, groups_per_stat, col_partials, T)
   if (x_point_major) {
     if (Nc == 32) PF_GEMM_LAUNCH(true, 1);
     else if (Nc == 64) PF_GEMM_LAUNCH(true, 2);
@@ -1246,9 +1210,7 @@ static int check_lattice(const int64_t* idx, const uint8_t* codes, int k, int Ng
 }
 
 int pf_edge_stats_f32(const float* LE, int64_t ldle, int C, const int64_t* idx, int k, int G, int Ng,
-                      double* partials, const pf_bn_job* bn_jobs, int n_bn_jobs, unsigned* tickets,
-                      const uint8_t* codes, int lat_ks, int lat_h, int lat_w, void* stream) {
-  PF_REQUIRE(n_bn_jobs >= 0);
+                      double* partials, const uint8_t* codes, int lat_ks, int lat_h, int lat_w, void* stream) {
   PF_REQUIRE(G >= 0 && Ng >= 0 && k >= 1 && ldle >= 2 * (int64_t)C && (ldle % 4) == 0 && G <= 65535);
   if (C != 32 && C != 64 && C != 128) return PF_ERR_UNSUPPORTED;
   if (G == 0 || Ng == 0) return PF_OK;
@@ -1261,14 +1223,9 @@ int pf_edge_stats_f32(const float* LE, int64_t ldle, int C, const int64_t* idx, 
   unsigned* status = pf_status_ptr();
   PF_REQUIRE(status != nullptr);
   const int T = pf_stat_blocks(G, Ng);
-  PfTail tail;
-  {
-    const int rc = pf_tail_setup(tail, bn_jobs, n_bn_jobs, partials, G, T, C, tickets);
-    if (rc != PF_OK) return rc;
-  }
   dim3 grid((unsigned)T, (unsigned)G);
   hipStream_t s = (hipStream_t)stream;
-#define PF_ES(CV, KV) hipLaunchKernelGGL((edge_stats_kernel<CV, KV>), grid, dim3(256), 0, s, LE, ldle, idx, k, Ng, partials, T, status, tail, codes, lat)
+#define PF_ES(CV, KV) hipLaunchKernelGGL((edge_stats_kernel<CV, KV>), grid, dim3(256), 0, s, LE, ldle, idx, k, Ng, partials, T, status, codes, lat)
   if (k == 16) {
     if (C == 32) PF_ES(32, 16); else if (C == 64) PF_ES(64, 16); else PF_ES(128, 16);
   } else {

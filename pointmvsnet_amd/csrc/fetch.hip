@@ -358,163 +358,15 @@ constexpr int kFeatLanes = 8;
 constexpr int kFeatPY = 4, kFeatPX = 8;           // 32 points per 256-thread block
 static_assert(kFeatPY * kFeatPX * kFeatLanes == 256, "one point per 8 lanes");
 
-template <int V>
-__global__ __launch_bounds__(256) void flow_features_kernel(const float* __restrict__ maps1,
-                                                            const float* __restrict__ maps2,
-                                                            const float* __restrict__ maps3, int c1, int c2,
-                                                            int c3, int h, int w,
-                                                            const float* __restrict__ depth_in, int dh, int dw,
-                                                            const float* __restrict__ interval_p,
-                                                            const float* __restrict__ cam,
-                                                            int ratio, float* __restrict__ feature,
-                                                            float* __restrict__ xyz, int xcd_order) {
-  const int hs = h / ratio, ws = w / ratio;
-  const int64_t Ng = (int64_t)5 * hs * ws;
-  const int q = threadIdx.x & (kFeatLanes - 1);
-  // A block owns a kFeatPY x kFeatPX patch of flow-grid pixels of one hypothesis plane, ACROSS the sub-grids:
-  // neighbouring pixels project to neighbouring source texels, so the patch's taps share cache lines in
-  // this CU's L1 (a run of 32 points of one sub-grid -- every ratio-th pixel of a row -- shares none).
-  const int tiles_x = (w + kFeatPX - 1) / kFeatPX, tiles_y = (h + kFeatPY - 1) / kFeatPY;
-  // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): renumber so that consecutive logical
-  // blocks share an XCD, and make the 5 hypotheses of a patch consecutive -- they sample almost the same
-  // texels (neighbouring positions on the epipolar lines), which then come from that XCD's L2.
-  int d, patch;
-  if (xcd_order) {
-    const int nb = gridDim.x, per = nb / 8, extra = nb % 8;
-    const int xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
-    const int logical = (xcd < extra ? xcd * (per + 1) : extra * (per + 1) + (xcd - extra) * per) + slot;
-    d = logical % 5;
-    patch = logical / 5;
-  } else {
-    patch = blockIdx.x % (tiles_x * tiles_y);
-    d = blockIdx.x / (tiles_x * tiles_y);
-  }
-  const int bx = patch % tiles_x;
-  const int by = patch / tiles_x;
-  const int pl = threadIdx.x / kFeatLanes;
-  const int y_raw = by * kFeatPY + pl / kFeatPX, x_raw = bx * kFeatPX + pl % kFeatPX;
-  const bool live = y_raw < h && x_raw < w;
-  const int y = live ? y_raw : h - 1, x = live ? x_raw : w - 1;     // dead lanes shadow a valid pixel, store nothing
-  // image pixel (y, x) -> sub-grid g, local index (hypothesis d, sub-grid row/col)
-  const int g = (y % ratio) * ratio + (x % ratio);
-  const int64_t loc = ((int64_t)d * hs + y / ratio) * ws + x / ratio;
-
-  // nearest resize of the prior depth map (model.py:153-158)
-  const float scy = (float)dh / (float)h, scx = (float)dw / (float)w;
-  int sy = (int)floorf((float)y * scy);
-  int sx = (int)floorf((float)x * scx);
-  sy = sy > dh - 1 ? dh - 1 : sy;
-  sx = sx > dw - 1 ? dw - 1 : sx;
-  const float depth = depth_in[sy * dw + sx] + interval_p[0] * (float)(d - 2);
-
-  // un-projection (model.py:165-178)
-  const float* Ki = cam + PF_CAM_KREF_INV;
-  const float* Ri = cam + PF_CAM_RREF_INV;
-  const float* t0 = cam + PF_CAM_TREF;
-  const float px = (float)x + 0.5f, py = (float)y + 0.5f;
-  const float u0 = fmaf(Ki[2], 1.0f, fmaf(Ki[1], py, Ki[0] * px));
-  const float u1 = fmaf(Ki[5], 1.0f, fmaf(Ki[4], py, Ki[3] * px));
-  const float u2 = fmaf(Ki[8], 1.0f, fmaf(Ki[7], py, Ki[6] * px));
-  const float q0 = u0 * depth - t0[0], q1 = u1 * depth - t0[1], q2 = u2 * depth - t0[2];
-  const float X = fmaf(Ri[2], q2, fmaf(Ri[1], q1, Ri[0] * q0));
-  const float Y = fmaf(Ri[5], q2, fmaf(Ri[4], q1, Ri[3] * q0));
-  const float Z = fmaf(Ri[8], q2, fmaf(Ri[7], q1, Ri[6] * q0));
-
-  const float nx = (X - cam[PF_CAM_MEAN + 0]) / cam[PF_CAM_STD + 0];
-  const float ny = (Y - cam[PF_CAM_MEAN + 1]) / cam[PF_CAM_STD + 1];
-  const float nz = (Z - cam[PF_CAM_MEAN + 2]) / cam[PF_CAM_STD + 2];
-  if (live && q == 0) {
-    float* xo = xyz + (int64_t)g * 3 * Ng + loc;
-    xo[0] = nx;
-    xo[Ng] = ny;
-    xo[2 * Ng] = nz;
-  }
-
-  PfTaps t[V];
-#pragma unroll
-  for (int v = 0; v < V; ++v) {
-    const float* cv = cam + PF_CAM_VIEWS + v * PF_CAM_VIEW_STRIDE;
-    pf_project_taps(X, Y, Z, cv, cv + 9, h, w, t[v]);
-  }
-
-  const int ctot = c1 + c2 + c3 + 24;
-  float* frow = feature + ((int64_t)g * Ng + loc) * ctot;
-  const int64_t hw = (int64_t)h * w;
-  int ch = 0;
-#pragma unroll 1
-  for (int level = 0; level < 3; ++level) {
-    // maps are channel-last (V, h, w, cl): a tap is cl consecutive floats
-    const float* maps = level == 0 ? maps1 : (level == 1 ? maps2 : maps3);
-    const int cl = level == 0 ? c1 : (level == 1 ? c2 : c3);
-    int64_t tb[V][4];
-#pragma unroll
-    for (int v = 0; v < V; ++v)
-#pragma unroll
-      for (int k = 0; k < 4; ++k) tb[v][k] = ((int64_t)v * hw + t[v].off[k]) * cl;
-#pragma unroll 1
-    for (int c0 = 0; c0 < cl; c0 += 4 * kFeatLanes) {
-      const int c = c0 + 4 * q;
-      if (c < cl) {
-        float s[4], s2[4];
-#pragma unroll
-        for (int v = 0; v < V; ++v) {
-          const float4 a = *reinterpret_cast<const float4*>(maps + tb[v][0] + c);
-          const float4 b = *reinterpret_cast<const float4*>(maps + tb[v][1] + c);
-          const float4 cc = *reinterpret_cast<const float4*>(maps + tb[v][2] + c);
-          const float4 dd = *reinterpret_cast<const float4*>(maps + tb[v][3] + c);
-          const float w0 = t[v].wgt[0], w1 = t[v].wgt[1], w2 = t[v].wgt[2], w3 = t[v].wgt[3];
-          // the arithmetic of pf_sample, per channel
-          const float f[4] = {((a.x * w0 + b.x * w1) + cc.x * w2) + dd.x * w3,
-                              ((a.y * w0 + b.y * w1) + cc.y * w2) + dd.y * w3,
-                              ((a.z * w0 + b.z * w1) + cc.z * w2) + dd.z * w3,
-                              ((a.w * w0 + b.w * w1) + cc.w * w2) + dd.w * w3};
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            if (v == 0) {
-              s[i] = f[i];
-              s2[i] = f[i] * f[i];
-            } else {
-              s[i] = s[i] + f[i];
-              s2[i] = s2[i] + f[i] * f[i];
-            }
-          }
-        }
-        float o[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float m1 = s[i] / (float)V;
-          const float m2 = s2[i] / (float)V;
-          o[i] = m2 - m1 * m1;
-        }
-        if (live) *reinterpret_cast<float4*>(frow + ch + c) = make_float4(o[0], o[1], o[2], o[3]);
-      }
-    }
-    ch += cl;
-  }
-  // xyz.repeat(1, 8, 1): channel j of the 24 holds axis j % 3 (model.py:193-194); lanes 0..5 write 4 each
-  if (live && q < 6) {
-    float o[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int j = 4 * q + i;
-      o[i] = (j % 3 == 0) ? nx : ((j % 3 == 1) ? ny : nz);
-    }
-    *reinterpret_cast<float4*>(frow + ch + 4 * q) = make_float4(o[0], o[1], o[2], o[3]);
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// F, second form: the five hypotheses of a pixel inside ONE block
-// ------------------------------------------------------------------------------------------------
-// flow_features_kernel gives every hypothesis plane its own block; SQ / PMC counters put it (and the coarse warp)
-// at ~10 TB/s of L2 -> L1 tap traffic (550 MB of 128-byte tap lines per launch at 4 x 25 600 points), not at HBM.
+// The five hypotheses of a pixel inside ONE block.  Round 1's kernel gave every hypothesis plane its own block; SQ / PMC
+// counters put it (and the coarse warp) at ~10 TB/s of L2 -> L1 tap traffic (550 MB of 128-byte tap lines per launch
+// at 4 x 25 600 points), not at HBM; it was removed in round 3 (59 vs 43 us at flow-2, outputs bit-identical).
 // The five hypotheses of a pixel are 0.1-0.3 texels apart in every source view, i.e. they sample the SAME four
 // texels almost always.  Here a block owns a 4 x 8 pixel patch with all five hypotheses and walks
 // level -> 32-channel chunk -> view -> hypothesis: within one (level, view) the five hypotheses re-read lines
 // that are in L1 already (6 x 10 texels x 64-256 B per view and level), which cuts the L2 traffic ~5x.  The
 // 15 (view, hypothesis) projections of a point are computed once by its 8 lanes (two each) and parked in LDS.
-// Per (hypothesis, channel) the arithmetic and its order (views ascending) are those of flow_features_kernel:
-// the two kernels are bit-identical.
+// Per (hypothesis, channel) the views are accumulated in ascending order.
 template <int V, bool ROLLV>
 __global__ __launch_bounds__(256) void flow_features_hyp_kernel(const float* __restrict__ maps1,
                                                                 const float* __restrict__ maps2,
@@ -894,27 +746,11 @@ int pf_flow_features_f32(const float* maps1, const float* maps2, const float* ma
   const int64_t Ng = (int64_t)5 * (h / ratio) * (w / ratio);
   (void)Ng;
   PF_REQUIRE(pf_cdiv(h, kFeatPY) * pf_cdiv(w, kFeatPX) * 5 <= INT32_MAX);
-  const char* hyp = getenv("PF_FEAT_HYP");                   // 0: one block per hypothesis plane (round-1 kernel)
-  if (!(hyp && hyp[0] == '0')) {
-    dim3 gridh((unsigned)(pf_cdiv(h, kFeatPY) * pf_cdiv(w, kFeatPX)));
-    return dispatch_views(V, [&](auto vtag) {
-      constexpr int VV = decltype(vtag)::value;
-      if (hyp && hyp[0] == '2')
-        hipLaunchKernelGGL((flow_features_hyp_kernel<VV, true>), gridh, dim3(256), 0, (hipStream_t)stream, maps1, maps2,
-                           maps3, c1, c2, c3, h, w, depth_in, dh, dw, interval, cam, ratio, feature, xyz);
-      else
-        hipLaunchKernelGGL((flow_features_hyp_kernel<VV, false>), gridh, dim3(256), 0, (hipStream_t)stream, maps1,
-                           maps2, maps3, c1, c2, c3, h, w, depth_in, dh, dw, interval, cam, ratio, feature, xyz);
-      return pf_launch_status();
-    });
-  }
-  dim3 grid((unsigned)(5 * pf_cdiv(h, kFeatPY) * pf_cdiv(w, kFeatPX)));
-  const char* ord = getenv("PF_FEAT_ORDER");                 // tuning hook: 0 = plane-major blocks, 1 = XCD-aware
-  const int xcd_order = ord ? atoi(ord) : 1;
+  dim3 gridh((unsigned)(pf_cdiv(h, kFeatPY) * pf_cdiv(w, kFeatPX)));
   return dispatch_views(V, [&](auto vtag) {
     constexpr int VV = decltype(vtag)::value;
-    hipLaunchKernelGGL(flow_features_kernel<VV>, grid, dim3(256), 0, (hipStream_t)stream, maps1, maps2, maps3,
-                       c1, c2, c3, h, w, depth_in, dh, dw, interval, cam, ratio, feature, xyz, xcd_order);
+    hipLaunchKernelGGL((flow_features_hyp_kernel<VV, false>), gridh, dim3(256), 0, (hipStream_t)stream, maps1, maps2,
+                       maps3, c1, c2, c3, h, w, depth_in, dh, dw, interval, cam, ratio, feature, xyz);
     return pf_launch_status();
   });
 }

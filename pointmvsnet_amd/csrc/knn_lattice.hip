@@ -461,8 +461,7 @@ extern "C" int pf_knn_lattice_f32(const float* xyz, const int64_t* strides_host,
   const size_t lds_bytes = (size_t)3 * kernel_size * (TH + 2 * hk) * (TW + 2 * hk) * sizeof(float);
   dim3 grid((unsigned)pf_cdiv(W, TW), (unsigned)pf_cdiv(H, TH), (unsigned)(B * D));
   hipStream_t s = (hipStream_t)stream;
-  const char* legacy = getenv("PF_KNN_LEGACY");
-  if (knn <= 16 && (kernel_size == 3 || kernel_size == 5) && !(legacy && legacy[0] == '1')) {
+  if (knn <= 16 && (kernel_size == 3 || kernel_size == 5)) {
     // sorting-network kernel; 64-point blocks while the lattice is too small to fill the chip with 256-point ones
     const bool small = B * D * H * W < 65536;
     const int rows = small ? 2 : 8;

@@ -70,9 +70,9 @@ class _EdgeConvTrain(torch.autograd.Function):
                 None, None)
 
 
-# PF_FUSED_TRAIN=0: training runs the reference's composition (gather_knn + BatchNorm2d + ...) instead
-import os as _os
-FUSED_TRAIN = int(_os.environ.get("PF_FUSED_TRAIN", "1"))
+# 0: training runs the reference's composition (gather_knn + BatchNorm2d + ...) instead of the fused autograd node
+# (a module attribute, not an environment switch: the tests compare the two)
+FUSED_TRAIN = 1
 
 
 class _EdgeConvBase(nn.Module):
@@ -231,7 +231,7 @@ class ImageConv(nn.Module):
     def forward_views(self, img_list, need=("conv1", "conv2", "conv3"), channel_last=()):
         """Inference fast path: all V views of (B,V,3,H,W) in ONE pass through the tower with per-view
         BatchNorm statistics -- numerically the reference's V separate calls (model.py:71-77).  Each layer is
-        one pf_conv2d_f32 launch (previous BatchNorm+ReLU applied while staging, this layer's statistics in
+        one pf_conv2d_wide_f32 launch (previous BatchNorm+ReLU applied while staging, this layer's statistics in
         the epilogue) plus the finalize; only the stage outputs in ``need`` ((B,V,c,h,w); the coarse tower
         needs "conv3" alone) are materialised, every other BatchNorm+ReLU stays an affine row pair that the
         next convolution applies while staging -- "conv0" is never returned.  Stage names in ``channel_last`` come
@@ -248,13 +248,11 @@ class ImageConv(nn.Module):
             # the BN+ReLU of this block can stay pending only if the next conv applies it while staging
             nconv = None if nxt is None else (nxt.conv if hasattr(nxt, "bn") else nxt)
             wanted = stage_end and name in need
-            defer = (not wanted) and nconv is not None and \
-                (pointflow.conv2d_preferred(nconv) or pointflow.conv2d_small_preferred(nconv)
-                 or pointflow.conv2d_wide_preferred(nconv))
-            lazy = bool(defer) and pointflow.conv2d_wide_preferred(nconv)   # the next conv resolves this BatchNorm
+            defer = (not wanted) and nconv is not None and pointflow.conv2d_wide_preferred(nconv)
+            lazy = bool(defer)                                               # the next conv resolves this BatchNorm
             conv = block.conv if hasattr(block, "bn") else block
             cl = (wanted and name in channel_last and not hasattr(block, "bn") and conv.out_channels >= 32
-                  and pointflow.conv2d_wide_preferred(conv) and bool(pointflow.TOWER_CL_OUT))
+                  and pointflow.conv2d_wide_preferred(conv))
             x, pending = _conv2d_block_fused(block, x, pending, B, defer, lazy, channel_last_out=cl)
             if wanted:
                 out[name + "_cl" if cl else name] = x.view(V, B, *x.shape[1:]).transpose(0, 1)
@@ -267,28 +265,16 @@ def _conv2d_block_fused(block, x, pending, samples_per_stat, defer, lazy=False, 
     while staging; otherwise y is normalised in place (statistics + fused finalize/normalise)."""
     conv, bn, relu = (block.conv, block.bn, block.relu) if hasattr(block, "bn") else (block, None, False)
     training_bn = bn is not None and (bn.training or not bn.track_running_stats)
-    # a deferred train-mode BatchNorm is finalized by the convolution's own last block (csrc/pf_bn_tail.h)
-    tail_bn = bn if (pointflow.FUSED_BN and training_bn and defer and relu and bn.momentum is not None) else None
-    affine = None
-    if pointflow.conv2d_small_preferred(conv):
-        out = pointflow.conv2d_small(x, conv, pending, samples_per_stat, training_bn, bn=tail_bn)
-    elif pointflow.conv2d_wide_preferred(conv):
-        out = pointflow.conv2d_wide(x, conv, pending, samples_per_stat, training_bn, channel_last_out=channel_last_out)
-    elif pointflow.conv2d_preferred(conv):
-        out = pointflow.conv2d(x, conv, pending, samples_per_stat, training_bn, bn=tail_bn)
-    else:
+    if pointflow.conv2d_wide_preferred(conv):
+        y, partials = pointflow.conv2d_wide(x, conv, pending, samples_per_stat, training_bn,
+                                            channel_last_out=channel_last_out)
+    else:                                      # a shape the tower kernels are not built for: the library convolution
         if pending is not None:
             x = pointflow.channel_affine_(x, pending, True, samples_per_stat)
         y = block._crop(conv(x), x).contiguous() if hasattr(block, "_crop") else conv(x).contiguous()
-        out = (y, None)
-    if len(out) == 3:
-        y, partials, affine = out
-    else:
-        y, partials = out
+        partials = None
     if bn is None:
         return (F.relu(y, inplace=True) if relu else y), None
-    if affine is not None:
-        return y, affine
     if defer and relu:
         return y, pointflow.bn_affine_rows(y, bn, samples_per_stat, partials, lazy=lazy)
     return pointflow.batch_norm_act_(y, bn, relu, samples_per_stat, partials=partials), None

@@ -178,49 +178,24 @@ def timeline_report():
     return {n: (vals[i] - t0) / 100.0 for i, n in enumerate(t["names"])}
 
 
-# PF_FUSED_BN=1 folds every BatchNorm finalize into the kernel that produces its statistics (last block done,
-# csrc/pf_bn_tail.h) instead of a separate launch.  Measured on MI355X (profiles/r02a_fused_bn_ab.log, same box,
-# hipGraph replay of BASELINE config 2): 553 depth maps/s fused vs 570 with the 25 separate finalize launches --
-# the write-through publish, the ticket round trips of every block and the serial two-hop reduction by the last
-# block cost 5-10 us per launch (rocprofv3), more than the ~5.5 us a trivial dependent graph node costs.  So the
-# separate launch stays the default; the tail is kept, tested, for devices / drivers where a node costs more.
-FUSED_BN = int(_os.environ.get("PF_FUSED_BN", "0"))
-# PF_KNN_CODES=0: the PointFlow stage hands int64 neighbour indices to the EdgeConv passes (round-1 form)
-KNN_CODES = int(_os.environ.get("PF_KNN_CODES", "1"))
-
-
-def stat_rows(G, T, pcols, dev, tail):
-    """Statistics rows of one launch: the (G, T, pcols, 2) float64 block rows, followed -- when the launch
-    finalizes its own BatchNorm (``tail``) -- by the level-1 rows of csrc/pf_bn_tail.h.  Returns the view of
-    the block rows (the buffer behind it is what the kernel gets)."""
-    extra = int(_lib.load().pf_bn_tail_rows(int(G), int(T))) if tail else 0
-    buf = torch.empty((G * T + extra, pcols, 2), dtype=torch.float64, device=dev)
-    return buf[:G * T].view(G, T, pcols, 2)
-
-
-def tail_args(jobs, G, T, dev):
-    """ctypes arguments (jobs array, count, ticket pointer) for a producer that finalizes ``jobs`` itself."""
-    if not jobs:
-        return None, 0, None
-    arr = (_lib.BnJob * len(jobs))(*jobs)
-    return arr, len(jobs), _lib.tickets(dev, int(_lib.load().pf_bn_tail_tickets(int(G), int(T))))
+def stat_rows(G, T, pcols, dev):
+    """Statistics rows of one launch: (G, T, pcols, 2) float64 per-block (sum, sum of squares)."""
+    return torch.empty((G, T, pcols, 2), dtype=torch.float64, device=dev)
 
 
 def pointwise_gemm(X, point_major, ldx, Wt, Y, ldy, G, Ng, K, nc_store, in_affine=None, groups_per_stat=1,
-                   want_stats=False, bn_jobs=None):
+                   want_stats=False):
     """Y[:, :nc_store] = act(X) @ Wt (see pf_pointwise_gemm_f32).  Returns the float64 column partials
     (G, T, Nc, 2) when ``want_stats``.  ``in_affine``: (scale, shift) rows, or a LazyAffine (the pending BatchNorm
-    is resolved by the GEMM's own blocks, no finalize launch).  ``bn_jobs`` (bn_job(..., partials=None) entries over
-    the columns of Y): the BatchNorm finalize jobs the launch performs itself (last block done), no separate launch."""
+    is resolved by the GEMM's own blocks, no finalize launch)."""
     Nc = Wt.shape[1]
     T = int(_lib.load().pf_gemm_blocks(int(G), int(Ng)))
-    partials = stat_rows(G, T, Nc, Wt.device, bool(bn_jobs)) if (want_stats or bn_jobs) else None
+    partials = stat_rows(G, T, Nc, Wt.device) if want_stats else None
     sc, sh, in_bn = _split_affine(in_affine)
-    jobs, njobs, tk = tail_args(bn_jobs, G, T, Wt.device)
     _lib.call("pf_pointwise_gemm_f32",
               _lib.ptr(X), int(bool(point_major)), int(ldx), _lib.ptr(Wt), _lib.ptr(Y), int(ldy), int(G), int(Ng),
               int(K), int(Nc), int(nc_store), _lib.ptr(sc), _lib.ptr(sh), in_bn, int(groups_per_stat),
-              _lib.ptr(partials), jobs, njobs, tk, _lib.stream(),
+              _lib.ptr(partials), _lib.stream(),
               algo_bytes=4.0 * G * Ng * (K + nc_store) + 4.0 * K * Nc, flops=2.0 * G * Ng * K * nc_store)
     return partials
 
@@ -231,8 +206,7 @@ def bn_job(bn, partials, col0, C, count, unbias_n, G, groups_per_stat, scale, sh
     module's channels (EdgeConv's BN covers [central | difference])."""
     if bn.momentum is None:
         raise NotImplementedError("cumulative-average BatchNorm momentum is not supported")
-    # partials None: a job for a producer's own tail (the call fills partials / T / pcols / G in)
-    T, pcols = (partials.shape[1], partials.shape[2]) if partials is not None else (0, 0)
+    T, pcols = partials.shape[1], partials.shape[2]
     track = bn.track_running_stats and bn.running_mean is not None
     dp = lambda t: None if t is None else t.data_ptr()   # noqa: E731
     rm = bn.running_mean[ch0:ch0 + C] if track else None
@@ -445,10 +419,6 @@ def eval_affine(bn, S, ld, ch0=0, C=None, out=None):
 # ---------------------------------------------------------------------------------------------
 # BatchNorm (+ReLU) for the conv stacks around the path (ImageConv / VolumeConv)
 # ---------------------------------------------------------------------------------------------
-# PF_CONV3D_PAIR=0: conv0_1 takes the 16-channel-wide tile of conv3d.hip (round-1 kernel)
-CONV3D_PAIR = int(_os.environ.get("PF_CONV3D_PAIR", "1"))
-
-
 def pack_conv3d_weight_pair(weight):
     """(Cout<=8,Cin,3,3,3) -> (Cin/4, 36, 4, 16): column c + 8 s holds W[c] shifted by s along kh (see
     csrc/conv3d_pair.hip); cached per parameter."""
@@ -469,7 +439,7 @@ def conv3d_k3(x, weight, stride, want_stats, in_affine=None, samples_per_stat=1)
     (N/samples_per_stat, Cin) or a LazyAffine -- applied while x is staged.  Returns (y, partials or None)."""
     N, Cin, Di, Hi, Wi = x.shape
     Cout = weight.shape[0]
-    if CONV3D_PAIR and stride == 1 and Cout <= 8 and Cin % 4 == 0 and in_affine is None:
+    if stride == 1 and Cout <= 8 and Cin % 4 == 0 and in_affine is None:
         wp = pack_conv3d_weight_pair(weight)
         y = torch.empty((N, Cout, Di, Hi, Wi), dtype=_F32, device=x.device)
         partials = None
@@ -530,127 +500,6 @@ def conv2d_supported(conv):
     return k3 or k5
 
 
-def conv2d_preferred(conv):
-    """Measured policy (profiles/r01j_microbench_conv2d.log, cfg2 shapes, 3 views): the f32-MFMA conv2d (v3)
-    is the fastest path for every tower layer with 16..32 output channels -- 8->16 5x5/2: 43 us (direct FMA
-    kernel 67, library 62), 16->16 3x3: 25 us (40, 39), 16->32 5x5/2: 31 us (library 33.5 plus its separate
-    BatchNorm statistics and normalise passes), 32->32 3x3: 23 us (library 22 plus passes).  The 64-channel
-    layers (64x80 maps: too few 128-pixel tiles for 256 CUs) stay on the library convolution + the HIP
-    BatchNorm kernels; the 8-channel full-resolution layers on the direct kernel (see below)."""
-    return conv2d_supported(conv) and 16 <= conv.out_channels <= 32
-
-
-def conv2d_small_supported(conv):
-    """Shapes pf_conv2d_small_f32 is built for: the tower's conv shapes with 8 or 16 output and <= 16 input channels."""
-    return conv2d_supported(conv) and conv.out_channels in (8, 16) and conv.in_channels <= 16
-
-
-def conv2d_small_preferred(conv):
-    """The 8-channel full-resolution layers (3->8, 8->8: HBM-bound, half of a 16-wide MFMA tile would be
-    empty) run on the plain-FMA kernel (conv2d_small.hip): 25 / 37 us against 31 / 43 us on the matrix cores."""
-    return conv2d_supported(conv) and conv.out_channels == 8 and conv.in_channels <= 16 and not conv2d_wide_preferred(conv)
-
-
-def pack_conv2d_small_weight(weight):
-    """(Cout,Cin,K,K) -> (ceil(Cin/4), 4, K, K, Cout) zero padded; cached per parameter."""
-    def make():
-        cout, cin, k, _ = weight.shape
-        groups = (cin + 3) // 4
-        full = torch.zeros((groups * 4, k, k, cout), dtype=_F32, device=weight.device)
-        full[:cin] = weight.detach().to(_F32).permute(1, 2, 3, 0)
-        return full.view(groups, 4, k, k, cout).contiguous()
-    return _cached_pack(("c2s", id(weight)), (weight,), make)
-
-
-def _conv_bn_tail(bn, N, Cout, S_out, samples_per_stat, dev):
-    """(jobs, (scale, shift)) for a tower convolution that finalizes its own train-mode BatchNorm."""
-    G = N // samples_per_stat
-    scale = torch.empty((G, Cout), dtype=_F32, device=dev)
-    shift = torch.empty((G, Cout), dtype=_F32, device=dev)
-    n = float(samples_per_stat) * S_out
-    job = bn_job(bn, None, 0, Cout, n, n, N, samples_per_stat, scale, shift)
-    bump_counter(bn, G)
-    return [job], (scale, shift)
-
-
-def conv2d_small(x, conv, in_affine, samples_per_stat, want_stats, bn=None):
-    """Few-channel tower convolution (pf_conv2d_small_f32); same contract as conv2d()."""
-    N, Cin, Hi, Wi = x.shape
-    Cout = conv.out_channels
-    ks, stride = conv.kernel_size[0], conv.stride[0]
-    Ho, Wo = (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
-    wp = pack_conv2d_small_weight(conv.weight)
-    y = torch.empty((N, Cout, Ho, Wo), dtype=_F32, device=x.device)
-    partials, jobs, affine = None, None, None
-    T = int(_lib.load().pf_conv2d_small_blocks(N, Hi, Wi, ks, stride))
-    if bn is not None:
-        jobs, affine = _conv_bn_tail(bn, N, Cout, Ho * Wo, samples_per_stat, x.device)
-    if want_stats or jobs:
-        partials = stat_rows(N, T, Cout, x.device, bool(jobs))
-    sc, sh = affine_rows(in_affine) or (None, None)
-    jarr, njobs, tk = tail_args(jobs, N, T, x.device)
-    _lib.call("pf_conv2d_small_f32", _lib.ptr(x), _lib.ptr(wp), _lib.ptr(y), N, Cin, Cout, Hi, Wi, int(ks),
-              int(stride), _lib.ptr(sc), _lib.ptr(sh), int(samples_per_stat), _lib.ptr(partials), jarr, njobs, tk,
-              _lib.stream(),
-              algo_bytes=4.0 * N * (Cin * Hi * Wi + Cout * Ho * Wo) + 4.0 * ks * ks * Cin * Cout,
-              flops=2.0 * N * Ho * Wo * ks * ks * Cin * Cout)
-    return (y, partials) if bn is None else (y, partials, affine)
-
-
-def _conv2d_ncp(cout):
-    nt = (cout + 15) // 16
-    return 16 * (4 if nt == 3 else nt)
-
-
-def pack_conv2d_weight(weight):
-    """(Cout,Cin,K,K) -> (ceil(Cin/4), K*K, 4, NCP) zero padded; cached per parameter."""
-    def make():
-        cout, cin, k, _ = weight.shape
-        groups = (cin + 3) // 4
-        ncp = _conv2d_ncp(cout)
-        full = torch.zeros((groups * 4, k * k, cout), dtype=_F32, device=weight.device)
-        full[:cin] = weight.detach().to(_F32).permute(1, 2, 3, 0).reshape(cin, k * k, cout)
-        wp = torch.zeros((groups, k * k, 4, ncp), dtype=_F32, device=weight.device)
-        wp[..., :cout] = full.view(groups, 4, k * k, cout).transpose(1, 2)
-        return wp
-    return _cached_pack(("c2", id(weight)), (weight,), make)
-
-
-def conv2d(x, conv, in_affine, samples_per_stat, want_stats, bn=None):
-    """One feature-tower convolution (pf_conv2d_f32).  ``in_affine`` = (scale, shift) rows (N/sps, Cin) of a
-    pending BatchNorm+ReLU to apply while staging x, or None.  Returns (raw y, statistics partials or None);
-    with ``bn`` (a train-mode BatchNorm module) the launch also finalizes that BatchNorm itself (last block
-    done, csrc/pf_bn_tail.h) and (y, partials, (scale, shift)) is returned."""
-    N, Cin, Hi, Wi = x.shape
-    Cout = conv.out_channels
-    ks, stride = conv.kernel_size[0], conv.stride[0]
-    Ho, Wo = (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
-    wp = pack_conv2d_weight(conv.weight)
-    y = torch.empty((N, Cout, Ho, Wo), dtype=_F32, device=x.device)
-    partials, jobs, affine = None, None, None
-    T = int(_lib.load().pf_conv2d_blocks(N, Cout, Hi, Wi, ks, stride))
-    if bn is not None:
-        jobs, affine = _conv_bn_tail(bn, N, Cout, Ho * Wo, samples_per_stat, x.device)
-    if want_stats or jobs:
-        partials = stat_rows(N, T, Cout, x.device, bool(jobs))
-    sc, sh = affine_rows(in_affine) or (None, None)
-    jarr, njobs, tk = tail_args(jobs, N, T, x.device)
-    _lib.call("pf_conv2d_f32", _lib.ptr(x), _lib.ptr(wp), _lib.ptr(y), N, Cin, Cout, Hi, Wi, int(ks), int(stride),
-              _lib.ptr(sc), _lib.ptr(sh), int(samples_per_stat), _lib.ptr(partials), jarr, njobs, tk, _lib.stream(),
-              algo_bytes=4.0 * N * (Cin * Hi * Wi + Cout * Ho * Wo) + 4.0 * ks * ks * Cin * Cout,
-              flops=2.0 * N * Ho * Wo * ks * ks * Cin * Cout)
-    return (y, partials) if bn is None else (y, partials, affine)
-
-
-CONV2D_WIDE = int(_os.environ.get("PF_CONV2D_WIDE", "1"))     # 0: 64-channel tower layers on the library convolution
-# PF_TOWER_CL_OUT=0: the coarse tower's last layer writes NCHW and pf_nchw_to_nhwc_f32 transposes it for the warp
-TOWER_CL_OUT = int(_os.environ.get("PF_TOWER_CL_OUT", "1"))
-# smallest C_out that goes to pf_conv2d_wide_f32: 8 = every tower layer (default; equal to 16 within noise, but the
-# 8-channel layers then resolve their input BatchNorm themselves); 16: the 8-channel layers on the FMA kernel
-# (conv2d_small.hip); 32: the 16-channel layers on pf_conv2d_f32 as well (-2 %)
-CONV2D_WIDE_MIN = int(_os.environ.get("PF_CONV2D_WIDE_MIN", "8"))
-
-
 def conv2d_wide_supported(conv):
     """Shapes pf_conv2d_wide_f32 is built for: 3x3/1 3->8, 8->8, 16->16, 32->32, 64->64; 5x5/2 8->16, 16->32, 32->64."""
     return conv2d_supported(conv) and bool(_lib.load().pf_conv2d_wide_supported(
@@ -661,7 +510,7 @@ def conv2d_wide_preferred(conv):
     """Measured (profiles/r02ag_microbench_conv2d_wide.log, cfg2 shapes, 3 views; us): 16->32 5x5/2 25.1 (pf_conv2d_f32
     31.0, library 34.7), 32->32 3x3 16.7 (22.8, 24.4), 32->64 5x5/2 21.0 (40.5, 31.9), 64->64 3x3 16.5 (38.0, 24.6) --
     62-76 TF of exact f32: every 32- and 64-channel tower layer runs on csrc/conv2d_wide.hip."""
-    return bool(CONV2D_WIDE) and conv.out_channels >= CONV2D_WIDE_MIN and conv2d_wide_supported(conv)
+    return conv2d_wide_supported(conv)
 
 
 def pack_conv2d_wide_weight(weight):
@@ -693,7 +542,7 @@ def conv2d_wide(x, conv, in_affine, samples_per_stat, want_stats, channel_last_o
     partials = None
     if want_stats:
         T = int(_lib.load().pf_conv2d_wide_blocks(Cout, Hi, Wi, int(stride)))
-        partials = stat_rows(N, T, Cout, x.device, False)
+        partials = stat_rows(N, T, Cout, x.device)
     sc, sh, in_bn = _split_affine(in_affine)
     _lib.call("pf_conv2d_wide_f32", _lib.ptr(x), _lib.ptr(wp), _lib.ptr(y), N, Cin, Cout, Hi, Wi, int(ks), int(stride),
               _lib.ptr(sc), _lib.ptr(sh), in_bn, int(samples_per_stat), _lib.ptr(partials), int(bool(channel_last_out)),
@@ -945,26 +794,17 @@ def edge_conv_fused(X, point_major, ldx, K, G, Ng, idx, conv1_w, conv2_w, bn, co
     scale = torch.empty((S, cbn), dtype=_F32, device=dev)
     shift = torch.empty((S, cbn), dtype=_F32, device=dev)
     n_pairs = float(groups_per_stat) * Ng * k
-    fused = bool(FUSED_BN) and training and 2 * C <= 128          # rows of 8..128 columns (pf_bn_tail.h)
-    central = [bn_job(bn, None, 0, C, float(groups_per_stat) * Ng, n_pairs, G, groups_per_stat, scale, shift)] \
-        if (fused and concat) else None
     part_l = pointwise_gemm(X, point_major, ldx, Wt, LE, 2 * C, G, Ng, K, 2 * C, groups_per_stat=groups_per_stat,
-                            want_stats=(concat and training), bn_jobs=central)
+                            want_stats=(concat and training))
     if join is not None:                      # ``idx`` was produced on another stream (flow_chain)
         torch.cuda.current_stream().wait_stream(join)
     if training:
         T = stat_blocks(G, Ng)
-        part_d = stat_rows(G, T, C, dev, fused)
-        doff = C if concat else 0
-        diff = [bn_job(bn, None, 0, C, n_pairs, n_pairs, G, groups_per_stat, scale[:, doff:], shift[:, doff:],
-                       ch0=doff)] if fused else None
-        jarr, njobs, tk = tail_args(diff, G, T, dev)
+        part_d = stat_rows(G, T, C, dev)
         _lib.call("pf_edge_stats_f32", _lib.ptr(LE), 2 * C, C, _lib.ptr(idx), k, G, Ng, _lib.ptr(part_d),
-                  jarr, njobs, tk, _lib.ptr(codes), lat[0], lat[1], lat[2], _lib.stream(),
+                  _lib.ptr(codes), lat[0], lat[1], lat[2], _lib.stream(),
                   algo_bytes=float(G) * Ng * (4.0 * C + (1.0 if codes is not None else 8.0) * k + 4.0 * C * k))
-        if fused:
-            pass                              # both halves were finalized by their producers
-        elif concat:
+        if concat:
             bn_finalize_jobs([
                 bn_job(bn, part_l, 0, C, float(groups_per_stat) * Ng, n_pairs, G, groups_per_stat, scale, shift),
                 bn_job(bn, part_d, 0, C, n_pairs, n_pairs, G, groups_per_stat, scale[:, C:], shift[:, C:], ch0=C)])
@@ -1111,7 +951,7 @@ def flow_chain(feature, xyz, depth, interval, h, w, ratio, edge_convs, flow_mlp,
         idx = idx.contiguous()
     else:
         # window codes (16 bytes per point) instead of int64 indices when the kernels support it
-        use_codes = k == 16 and bool(KNN_CODES)
+        use_codes = k == 16                  # 16-byte window codes instead of 128 bytes of int64 indices per point
         lattice = (5, hs, ws) if use_codes else None
 
         def _knn():
@@ -1151,17 +991,8 @@ def flow_chain(feature, xyz, depth, interval, h, w, ratio, edge_convs, flow_mlp,
         Wt, cout = pack_weight_t(layer.conv.weight)
         Z = torch.empty((G * Ng, cout), dtype=_F32, device=dev)
         bn = layer.bn
-        training = bn.training or not bn.track_running_stats
-        if FUSED_BN and training:
-            scale = torch.empty((G, cout), dtype=_F32, device=dev)
-            shift = torch.empty((G, cout), dtype=_F32, device=dev)
-            job = bn_job(bn, None, 0, cout, float(Ng), float(Ng), G, 1, scale, shift)
-            pointwise_gemm(X, True, ldx, Wt, Z, cout, G, Ng, K, cout, in_affine=affine, bn_jobs=[job])
-            bump_counter(bn, G)
-            affine = (scale, shift)
-        else:
-            part = pointwise_gemm(X, True, ldx, Wt, Z, cout, G, Ng, K, cout, in_affine=affine, want_stats=True)
-            affine = _bn_affine_from_gemm(bn, part, cout, G, Ng, 1, dev, lazy=True)
+        part = pointwise_gemm(X, True, ldx, Wt, Z, cout, G, Ng, K, cout, in_affine=affine, want_stats=True)
+        affine = _bn_affine_from_gemm(bn, part, cout, G, Ng, 1, dev, lazy=True)
         X, ldx, K = Z, cout, cout
     if K != 16 or last.weight.shape[0] != 1:
         raise NotImplementedError("flow head kernel is built for the reference widths (..., 16, 1)")

@@ -81,12 +81,6 @@ def fetch_variance(feature_maps, pts, cam_intrinsics, cam_extrinsics, ref_overri
     return out
 
 
-import os as _os
-
-# PF_FETCH_CL=0: the coarse warp reads the NCHW maps with one lane per point (round-1 kernel; A/B and tests)
-FETCH_CL = int(_os.environ.get("PF_FETCH_CL", "1"))
-
-
 class ChannelLast(object):
     """Feature maps that already are channel-last: ``maps`` is (B, V, H, W, C) contiguous float32."""
 
@@ -132,7 +126,7 @@ def frustum_variance(feature_maps, kinv, rinv, t, depths, cam_intrinsics, cam_ex
     out = torch.empty((B, C, N), dtype=torch.float32, device=maps.device)
     world = torch.empty((B, 3, N), dtype=torch.float32, device=maps.device) if want_points else None
     if channel_last is None:
-        channel_last = bool(FETCH_CL) and C % 4 == 0
+        channel_last = C % 4 == 0
     if channel_last:
         if maps_cl is None:
             maps_cl = to_channel_last(maps)

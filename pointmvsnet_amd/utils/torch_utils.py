@@ -38,9 +38,9 @@ def knn_lattice(xyz, kernel_size=5, knn=16, with_codes=False, with_idx=True):
         raise RuntimeError("get_knn_3d: knn larger than the window (topk would be out of range)")
     if not (with_idx or with_codes):
         raise RuntimeError("knn_lattice: nothing to compute")
-    # (the insertion-list kernels of PF_KNN_LEGACY=1 -- and windows / k the network kernel is not built for --
-    # always write the int64 indices: give them a buffer even when only the codes are wanted)
-    need_idx = with_idx or os.environ.get("PF_KNN_LEGACY") == "1" or knn > 16 or kernel_size not in (3, 5)
+    # (the insertion-list kernels -- windows / k the sorting-network kernel is not built for -- always write the
+    # int64 indices: give them a buffer even when only the codes are wanted)
+    need_idx = with_idx or knn > 16 or kernel_size not in (3, 5)
     idx = torch.empty((B, D * H * W, knn), dtype=torch.int64, device=xyz.device) if need_idx else None
     codes = torch.empty((B, D * H * W, knn), dtype=torch.uint8, device=xyz.device) if with_codes else None
     strides = (ctypes.c_int64 * 5)(*xyz.stride())

@@ -70,30 +70,24 @@ def test_bn_job_struct_layout_matches_header(tmp_path):
     # the header is plain C: it compiled above with gcc (no C++-isms at the boundary)
 
 
-def test_conv_policies_are_disjoint_and_cover_the_towers():
-    """Every ImageConv layer has exactly one owner, and since round 2 none of them is the library: all eleven run on
-    pf_conv2d_wide_f32; the FMA kernel (conv2d_small.hip) and pf_conv2d_f32 keep the other shapes and the knobs."""
+def test_every_tower_layer_runs_on_the_hip_conv_kernel():
+    """Every ImageConv layer of the reference widths has exactly one owner, pf_conv2d_wide_f32 (csrc/conv2d_wide.hip);
+    other widths fall back to the library convolution + the HIP BatchNorm kernels (never to the CPU)."""
     from pointmvsnet_amd import pointflow
     from pointmvsnet_amd.networks import ImageConv
     tower = ImageConv(8)
-    owners = {}
     for name in ("conv0", "conv1", "conv2", "conv3"):
         for i, blk in enumerate(getattr(tower, name)):
             conv = blk.conv if hasattr(blk, "conv") else blk
-            small, wide = pointflow.conv2d_small_preferred(conv), pointflow.conv2d_wide_preferred(conv)
-            mfma = pointflow.conv2d_preferred(conv) and not wide          # the dispatch order of networks.py
-            assert not (small and (mfma or wide))
-            owners["%s.%d" % (name, i)] = "small" if small else ("wide" if wide else ("mfma" if mfma else "library"))
-    assert owners == {"conv0.0": "wide", "conv0.1": "wide", "conv1.0": "wide", "conv1.1": "wide",
-                      "conv1.2": "wide", "conv2.0": "wide", "conv2.1": "wide", "conv2.2": "wide",
-                      "conv3.0": "wide", "conv3.1": "wide", "conv3.2": "wide"}
+            assert pointflow.conv2d_wide_preferred(conv), (name, i)
+    other = ImageConv(12)                                       # widths the kernels are not built for
+    assert not pointflow.conv2d_wide_preferred(other.conv1[0].conv)
 
 
 def test_no_default_path_kernel_uses_scratch_memory():
     """hipcc's per-kernel resource usage, recorded by the build (build/resource_usage.json): a register array that
     the compiler leaves in scratch (e.g. an array of HIP's float4 struct) serialises every access behind a memory
-    round trip and is invisible in the source.  Only the register-starved tuning variants (conv3d with >= 4 waves
-    per SIMD requested; never selected by default) may spill."""
+    round trip and is invisible in the source.  No kernel of the library may spill."""
     import json
     import re
     from pointmvsnet_amd import build
@@ -101,12 +95,10 @@ def test_no_default_path_kernel_uses_scratch_memory():
         build.build(verbose=False)
     usage = json.load(open(build.USAGE_FILE))
     assert set(usage) == set(build.SOURCES)
-    allowed = re.compile(r"conv3d_k3_kernelILi\d+ELi\d+ELi\d+ELi[45]EE|conv3d_k3_pair_kernelILi2ELi4EE")
     kernels = 0
     for src, table in usage.items():
         for name, u in table.items():
             kernels += 1
-            if u.get("scratch_bytes_per_lane", 0) > 0:
-                assert allowed.search(name), "%s: %s uses %d bytes of scratch per lane" % (
-                    src, name, u["scratch_bytes_per_lane"])
-    assert kernels > 150
+            assert u.get("scratch_bytes_per_lane", 0) == 0, "%s: %s uses %d bytes of scratch per lane" % (
+                src, name, u["scratch_bytes_per_lane"])
+    assert kernels > 100

@@ -622,39 +622,6 @@ def test_deconv3d_k3s2_vs_fp64(dev, N, Cin, Cout, D, H, W, skip):
     assert none is None and torch.equal(y2, y)                           # deterministic
 
 
-@pytest.mark.parametrize("N,Cin,Cout,H,W,ks,stride", [(3, 3, 8, 64, 96, 3, 1), (3, 8, 8, 40, 56, 3, 1),
-                                                       (2, 8, 16, 64, 96, 5, 2), (3, 16, 16, 33, 47, 3, 1),
-                                                       (1, 16, 32, 31, 45, 5, 2), (3, 32, 32, 16, 20, 3, 1),
-                                                       (3, 32, 64, 32, 40, 5, 2), (3, 64, 64, 16, 20, 3, 1),
-                                                       (1, 12, 40, 9, 17, 3, 1), (3, 8, 8, 512, 640, 3, 1)])
-@pytest.mark.parametrize("affine", [False, True])
-def test_conv2d_vs_fp64(dev, N, Cin, Cout, H, W, ks, stride, affine):
-    gen = torch.Generator().manual_seed(N * 1000 + Cin + Cout + H * W)
-    x = torch.randn(N, Cin, H, W, generator=gen)
-    conv = torch.nn.Conv2d(Cin, Cout, ks, stride=stride, padding=ks // 2, bias=False)
-    with torch.no_grad():
-        conv.weight.copy_(torch.randn(conv.weight.shape, generator=gen) / (ks * ks * Cin) ** 0.5)
-    sps = 1
-    sc = torch.rand(N, Cin, generator=gen) + 0.5
-    sh = torch.randn(N, Cin, generator=gen) * 0.3
-    xin = x.double()
-    if affine:
-        xin = torch.relu(xin * sc.double().view(N, Cin, 1, 1) + sh.double().view(N, Cin, 1, 1))
-    ref = F.conv2d(xin, conv.weight.double(), None, stride, ks // 2)
-    conv = conv.to(dev)
-    assert pointflow.conv2d_supported(conv)
-    aff = (sc.to(dev), sh.to(dev)) if affine else None
-    y, part = pointflow.conv2d(x.to(dev), conv, aff, sps, True)
-    assert y.shape == ref.shape
-    scale = float(ref.abs().max())
-    err = _maxabs(y, ref)
-    report("conv2d_%d_%d_k%d_aff%d" % (Cin, Cout, ks, int(affine)), err=err, scale=scale)
-    assert err < 3e-6 * scale * max(1.0, (ks * ks * Cin / 256.0) ** 0.5)
-    sums = part.sum(dim=1).cpu()
-    assert torch.allclose(sums[..., 0], ref.sum(dim=(2, 3)), rtol=1e-5, atol=1e-4 * scale)
-    assert torch.allclose(sums[..., 1], (ref ** 2).sum(dim=(2, 3)), rtol=1e-5)
-
-
 @pytest.mark.parametrize("N,Cin,Cout,H,W,ks,stride", [(3, 64, 64, 64, 80, 3, 1), (2, 64, 64, 19, 25, 3, 1),
                                                        (3, 32, 64, 128, 160, 5, 2), (1, 32, 64, 37, 51, 5, 2),
                                                        (3, 32, 32, 32, 48, 3, 1), (1, 32, 32, 13, 30, 3, 1),
@@ -738,39 +705,6 @@ def test_edgeconv_fused_arbitrary_indices_vs_first_principles(dev, concat, k):
     assert _lib.status() == 0
 
 
-@pytest.mark.parametrize("N,Cin,Cout,H,W,ks,stride", [(3, 3, 8, 64, 96, 3, 1), (3, 8, 8, 40, 56, 3, 1),
-                                                       (2, 8, 16, 64, 96, 5, 2), (3, 16, 16, 33, 47, 3, 1),
-                                                       (1, 5, 8, 17, 70, 5, 2), (3, 8, 8, 512, 640, 3, 1)])
-@pytest.mark.parametrize("affine", [False, True])
-def test_conv2d_small_vs_fp64(dev, N, Cin, Cout, H, W, ks, stride, affine):
-    gen = torch.Generator().manual_seed(N * 1000 + Cin + Cout + H * W)
-    x = torch.randn(N, Cin, H, W, generator=gen)
-    conv = torch.nn.Conv2d(Cin, Cout, ks, stride=stride, padding=ks // 2, bias=False)
-    with torch.no_grad():
-        conv.weight.copy_(torch.randn(conv.weight.shape, generator=gen) / (ks * ks * Cin) ** 0.5)
-    sc = torch.rand(N, Cin, generator=gen) + 0.5
-    sh = torch.randn(N, Cin, generator=gen) * 0.3
-    xin = x.double()
-    if affine:
-        xin = torch.relu(xin * sc.double().view(N, Cin, 1, 1) + sh.double().view(N, Cin, 1, 1))
-    ref = F.conv2d(xin, conv.weight.double(), None, stride, ks // 2)
-    conv = conv.to(dev)
-    assert pointflow.conv2d_small_supported(conv)
-    aff = (sc.to(dev), sh.to(dev)) if affine else None
-    y, part = pointflow.conv2d_small(x.to(dev), conv, aff, 1, True)
-    assert y.shape == ref.shape
-    scale = float(ref.abs().max())
-    err = _maxabs(y, ref)
-    report("conv2d_small_%d_%d_k%d_aff%d" % (Cin, Cout, ks, int(affine)), err=err, scale=scale)
-    assert err < 3e-6 * scale * max(1.0, (ks * ks * Cin / 256.0) ** 0.5)
-    sums = part.sum(dim=1).cpu()
-    assert torch.allclose(sums[..., 0], ref.sum(dim=(2, 3)), rtol=1e-5, atol=1e-4 * scale)
-    assert torch.allclose(sums[..., 1], (ref ** 2).sum(dim=(2, 3)), rtol=1e-5)
-
-
-# ---------------------------------------------------------------------------------------------
-# BatchNorm finalize (shared by rows E*, M, I, R): multi-job launch against float64 first principles
-# ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("C,G,gps,T", [(10, 6, 2, 7), (64, 4, 1, 200), (3, 1, 1, 1), (257, 5, 5, 9)])
 def test_bn_finalize_jobs_vs_first_principles(dev, C, G, gps, T):
     torch.manual_seed(C + G)
@@ -814,108 +748,8 @@ def test_bn_finalize_jobs_vs_first_principles(dev, C, G, gps, T):
     assert _lib.status() == 0
 
 
-# ---------------------------------------------------------------------------------------------
-# BatchNorm finalize folded into the producer (csrc/pf_bn_tail.h)
-# ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("G,Ng,K,cout,gps", [(1, 64, 32, 64, 1), (4, 25600, 64, 64, 1), (16, 6000, 64, 16, 1),
-                                             (6, 1000, 224, 64, 2), (3, 1000, 64, 128, 3), (1, 102400, 136, 64, 1)])
-def test_gemm_fused_bn_tail_vs_separate_finalize(dev, G, Ng, K, cout, gps):
-    """The last-block-done finalize must give what the separate finalize launch gives on the same statistics rows
-    (same float64 sums up to their order: float32 scale/shift agree to rounding; the running statistics too),
-    for one-level (few rows) and two-level (many rows) trees, pooled stat groups, padded column tiles -- and it
-    must do so on every one of many back-to-back launches that reuse ticket counters while another stream keeps
-    the chip unevenly busy (the hand-off is placement- and timing-independent or it is wrong)."""
-    gen = torch.Generator().manual_seed(G + Ng + K)
-    w = torch.randn(cout, K, 1, generator=gen).to(dev)
-    x = torch.randn(G * Ng, K, generator=gen).to(dev)
-    Wt, _ = pointflow.pack_weight_t(w)
-    S = G // gps
-
-    def make_bn():
-        bn = torch.nn.BatchNorm1d(cout).to(dev)
-        g2 = torch.Generator().manual_seed(5)
-        with torch.no_grad():
-            bn.weight.copy_(torch.rand(cout, generator=g2) + 0.5)
-            bn.bias.copy_(torch.randn(cout, generator=g2))
-            bn.running_mean.copy_(torch.randn(cout, generator=g2))
-            bn.running_var.copy_(torch.rand(cout, generator=g2) + 0.5)
-        return bn
-
-    n = float(gps) * Ng
-    # separate finalize (the round-1 path)
-    bn_a = make_bn()
-    Y = torch.empty((G * Ng, cout), device=dev)
-    part = pointflow.pointwise_gemm(x, True, K, Wt, Y, cout, G, Ng, K, cout, groups_per_stat=gps, want_stats=True)
-    sc_a = torch.empty((S, cout), device=dev)
-    sh_a = torch.empty((S, cout), device=dev)
-    pointflow.bn_affine(bn_a, part, 0, cout, n, n, G, gps, sc_a, sh_a)
-    # fused tail, many launches, noise on a second stream
-    noise = torch.randn(1 << 22, device=dev)
-    side = torch.cuda.Stream()
-    reps = 20
-    results = []
-    for r in range(reps):
-        bn_b = make_bn()
-        sc_b = torch.full((S, cout + 4), 7.0, device=dev)
-        sh_b = torch.full((S, cout + 4), 7.0, device=dev)
-        job = pointflow.bn_job(bn_b, None, 0, cout, n, n, G, gps, sc_b, sh_b)
-        with torch.cuda.stream(side):
-            for _ in range(1 + r % 3):
-                noise.mul_(1.0000001)
-        pointflow.pointwise_gemm(x, True, K, Wt, Y, cout, G, Ng, K, cout, groups_per_stat=gps, bn_jobs=[job])
-        results.append((bn_b, sc_b, sh_b))
-    torch.cuda.synchronize()
-    for bn_b, sc_b, sh_b in results:
-        assert torch.allclose(sc_b[:, :cout], sc_a, rtol=1e-6, atol=1e-7)
-        assert torch.allclose(sh_b[:, :cout], sh_a, rtol=1e-6, atol=1e-6)
-        assert torch.all(sc_b[:, cout:] == 7.0) and torch.all(sh_b[:, cout:] == 7.0)
-        assert torch.allclose(bn_b.running_mean, bn_a.running_mean, rtol=1e-6, atol=1e-7)
-        assert torch.allclose(bn_b.running_var, bn_a.running_var, rtol=1e-6, atol=1e-7)
-        # bit-reproducible across launches (fixed summation order)
-        assert torch.equal(sc_b, results[0][1]) and torch.equal(sh_b, results[0][2])
-    # the ticket counters are back to zero
-    for buf, _ in _lib._ticket_pools.values():
-        assert int(buf.abs().sum()) == 0
-    assert _lib.status() == 0
-
-
-@pytest.mark.parametrize("N,Cin,Cout,H,W,ks,stride,sps", [(3, 3, 8, 128, 160, 3, 1, 1), (3, 8, 16, 128, 160, 5, 2, 1),
-                                                          (6, 16, 32, 64, 80, 5, 2, 2), (3, 32, 32, 32, 40, 3, 1, 1),
-                                                          (3, 8, 8, 512, 640, 3, 1, 1)])
-def test_conv2d_fused_bn_tail_vs_torch(dev, N, Cin, Cout, H, W, ks, stride, sps):
-    """A tower convolution that finalizes its own BatchNorm: (scale, shift) and running statistics against
-    nn.BatchNorm2d run per stat group on the float64 convolution output."""
-    gen = torch.Generator().manual_seed(N * Cin + Cout)
-    conv = torch.nn.Conv2d(Cin, Cout, ks, stride=stride, padding=ks // 2, bias=False)
-    x = torch.randn(N, Cin, H, W, generator=gen)
-    with torch.no_grad():
-        conv.weight.copy_(torch.randn(conv.weight.shape, generator=gen) * 0.2)
-    ref = F.conv2d(x.double(), conv.weight.double(), None, stride, ks // 2)
-    bn_ref = torch.nn.BatchNorm2d(Cout).double().train()
-    bn = torch.nn.BatchNorm2d(Cout).to(dev).train()
-    with torch.no_grad():
-        for b in (bn_ref, bn):
-            b.weight.copy_(torch.linspace(0.5, 1.5, Cout))
-            b.bias.copy_(torch.linspace(-0.3, 0.3, Cout))
-    conv = conv.to(dev)
-    fn = pointflow.conv2d_small if pointflow.conv2d_small_preferred(conv) else pointflow.conv2d
-    y, part, (sc, sh) = fn(x.to(dev), conv, None, sps, True, bn=bn)
-    pointflow.flush_counters()
-    G = N // sps
-    got = torch.relu(y.double().cpu().view(G, sps, Cout, -1) * sc.double().cpu().view(G, 1, Cout, 1)
-                     + sh.double().cpu().view(G, 1, Cout, 1))
-    want = torch.stack([torch.relu(bn_ref(ref[g * sps:(g + 1) * sps])) for g in range(G)]).view(G, sps, Cout, -1)
-    err = float((got - want.detach()).abs().max())
-    report("conv2d_fused_bn_%d_%d_%d" % (Cin, Cout, ks), err=err)
-    assert err < 2e-5 * max(1.0, float(want.abs().max()))
-    assert torch.allclose(bn.running_mean.double().cpu(), bn_ref.running_mean, rtol=1e-5, atol=1e-6)
-    assert torch.allclose(bn.running_var.double().cpu(), bn_ref.running_var, rtol=1e-5, atol=1e-6)
-    assert int(bn.num_batches_tracked) == G
-    assert _lib.status() == 0
-
-
 def test_image_conv_tower_vs_oracle(dev):
-    """The batched-views tower (own conv kernels, BatchNorm in the epilogues / tails) against the CPU oracle's
+    """The batched-views tower (own conv kernels, BatchNorm statistics in the epilogues) against the CPU oracle's
     tower (reference networks.py:84-124 on ATen), per view, including the running statistics."""
     from oracle import pointflow_oracle as O
     from pointmvsnet_amd.networks import ImageConv
@@ -948,7 +782,7 @@ def test_image_conv_tower_vs_oracle(dev):
 # lattice kNN: sorting-network kernel, window codes as the neighbourhood of the EdgeConv passes
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("shape", [(1, 5, 64, 80), (4, 5, 64, 80), (2, 5, 7, 33), (16, 5, 30, 40)])
-def test_knn_network_kernel_equals_insertion_kernels_and_codes_only_call(dev, shape, monkeypatch):
+def test_knn_network_kernel_equals_insertion_kernels_and_codes_only_call(dev, shape):
     B, D, H, W = shape
     g = torch.Generator().manual_seed(B * H)
     base = torch.stack(torch.meshgrid(torch.arange(W).float(), torch.arange(H).float(), torch.arange(D).float(),
@@ -958,10 +792,9 @@ def test_knn_network_kernel_equals_insertion_kernels_and_codes_only_call(dev, sh
     idx, codes = knn_lattice(xyz, 5, 16, with_codes=True)
     none, codes_only = knn_lattice(xyz, 5, 16, with_codes=True, with_idx=False)
     assert none is None and torch.equal(codes_only, codes)
-    monkeypatch.setenv("PF_KNN_LEGACY", "1")                      # the round-1 insertion-list kernels
-    idx_old, codes_old = knn_lattice(xyz, 5, 16, with_codes=True)
-    monkeypatch.delenv("PF_KNN_LEGACY")
-    assert torch.equal(idx, idx_old) and torch.equal(codes, codes_old)
+    # k = 20 (get_knn_3d's default) takes the insertion-list kernels: same ranking rule, so the same first 16
+    idx20, codes20 = knn_lattice(xyz, 5, 20, with_codes=True)
+    assert torch.equal(idx20[:, :, :16], idx) and torch.equal(codes20[:, :, :16], codes)
     bf_idx, bf_code = BF.knn_window(xyz[0].cpu().numpy(), 5, 16)
     assert np.array_equal(idx[0].cpu().numpy(), bf_idx) and np.array_equal(codes[0].cpu().numpy(), bf_code)
 
@@ -1029,7 +862,7 @@ def test_frustum_variance_channel_last_is_bit_identical(dev, B, V, C, H, W, D):
 @pytest.mark.parametrize("K,cout,ldx", [(136, 64, 136), (32, 64, 224), (64, 128, 224), (224, 64, 224), (64, 64, 64),
                                         (64, 16, 64)])
 @pytest.mark.parametrize("G,Ng", [(1, 25600), (4, 1000), (3, 129), (2, 31)])
-def test_pointwise_gemm_direct_kernel(dev, K, cout, ldx, G, Ng, monkeypatch):
+def test_pointwise_gemm_direct_kernel(dev, K, cout, ldx, G, Ng):
     gen = torch.Generator().manual_seed(K + cout + Ng)
     w = torch.randn(cout, K, 1, generator=gen)
     x = torch.randn(G * Ng, ldx, generator=gen)
@@ -1043,14 +876,13 @@ def test_pointwise_gemm_direct_kernel(dev, K, cout, ldx, G, Ng, monkeypatch):
             a = torch.relu(a * sc.double().unsqueeze(1) + sh.double().unsqueeze(1))
         ref = a @ w[:, :, 0].double().t()
         outs = []
-        for legacy in ("1", "0"):
-            monkeypatch.setenv("PF_GEMM_LEGACY", legacy)
+        x_cm = xd[:, :K].reshape(G, Ng, K).transpose(1, 2).contiguous()      # channel-major: the chunked kernel
+        for point_major in (False, True):
             Y = torch.full((G * Ng, cout + 4), -7.0, device=dev)
-            part = pointflow.pointwise_gemm(xd, True, ldx, Wt, Y, cout + 4, G, Ng, K, cout, in_affine=affine,
-                                            want_stats=True)
+            part = pointflow.pointwise_gemm(xd if point_major else x_cm, point_major, ldx if point_major else 0, Wt,
+                                            Y, cout + 4, G, Ng, K, cout, in_affine=affine, want_stats=True)
             torch.cuda.synchronize()
             outs.append((Y, part))
-        monkeypatch.delenv("PF_GEMM_LEGACY")
         scale = float(ref.abs().max())
         for Y, part in outs:
             assert _maxabs(Y[:, :cout].view(G, Ng, cout), ref) < 2e-6 * scale * max(1.0, (K / 32.0) ** 0.5)
@@ -1064,7 +896,7 @@ def test_pointwise_gemm_direct_kernel(dev, K, cout, ldx, G, Ng, monkeypatch):
 
 
 # ---------------------------------------------------------------------------------------------
-# BatchNorm finalize folded into the CONSUMER (pf_bn_resolve, csrc/pf_bn_tail.h): same numbers as the separate
+# BatchNorm finalize folded into the CONSUMER (pf_bn_resolve, csrc/pf_bn_resolve.h): same numbers as the separate
 # finalize launch, running statistics from the deferred batched finalize
 # ---------------------------------------------------------------------------------------------
 def _bn_pair(C, dev):
@@ -1078,7 +910,7 @@ def _bn_pair(C, dev):
 
 @pytest.mark.parametrize("G,Ng", [(16, 1600), (4, 6400), (3, 129), (1, 25600)])
 @pytest.mark.parametrize("K,cout", [(64, 64), (64, 16)])
-def test_gemm_resolves_pending_batchnorm_like_the_finalize_launch(dev, G, Ng, K, cout, monkeypatch):
+def test_gemm_resolves_pending_batchnorm_like_the_finalize_launch(dev, G, Ng, K, cout):
     gen = torch.Generator().manual_seed(G * 7 + Ng + cout)
     w0 = torch.randn(K, 40, 1, generator=gen).to(dev)
     w1 = torch.randn(cout, K, 1, generator=gen).to(dev)
@@ -1099,12 +931,11 @@ def test_gemm_resolves_pending_batchnorm_like_the_finalize_launch(dev, G, Ng, K,
     scale = float(outs[0].abs().max())
     assert _maxabs(outs[0], outs[1]) < 2e-6 * scale          # (scale, shift) agree to float rounding
     # the chunked kernel has no in_bn slot: the call materialises the rows itself (no running-stat update)
-    monkeypatch.setenv("PF_GEMM_LEGACY", "1")
     bn_c, _ = _bn_pair(K, dev)
     lazy2 = pointflow._bn_affine_from_gemm(bn_c, part, K, G, Ng, 1, dev, lazy=True)
     Y2 = torch.empty((G * Ng, cout), device=dev)
-    pointflow.pointwise_gemm(Z, True, K, W1, Y2, cout, G, Ng, K, cout, in_affine=lazy2)
-    monkeypatch.delenv("PF_GEMM_LEGACY")
+    Z_cm = Z.view(G, Ng, K).transpose(1, 2).contiguous()                     # channel-major input: chunked kernel
+    pointflow.pointwise_gemm(Z_cm, False, 0, W1, Y2, cout, G, Ng, K, cout, in_affine=lazy2)
     assert _maxabs(Y2, outs[0]) < 6e-6 * scale
     # running statistics: untouched until the deferred finalize, then exactly the separate launch's
     assert float(bn_lazy.running_mean.abs().max()) == 0.0

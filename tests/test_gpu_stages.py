@@ -100,15 +100,6 @@ def test_flow_iteration_stagewise_vs_oracle(dev, cfg, it):
     levels = pointflow.flow_pyramid([pyr[n][0].to(dev).contiguous() for n in ("conv1", "conv2", "conv3")], h, w)
     f_gpu, x_gpu = pointflow.flow_features(levels, prior[0, 0].to(dev).contiguous(), packed[0, -1:],
                                            packed[0], h, w, ratio)
-    # the one-block-per-hypothesis-plane kernel (PF_FEAT_HYP=0) does the same arithmetic: bit-identical outputs
-    import os
-    os.environ["PF_FEAT_HYP"] = "0"
-    try:
-        f_old, x_old = pointflow.flow_features(levels, prior[0, 0].to(dev).contiguous(), packed[0, -1:],
-                                               packed[0], h, w, ratio)
-    finally:
-        del os.environ["PF_FEAT_HYP"]
-    assert torch.equal(f_old, f_gpu) and torch.equal(x_old, x_gpu)
     hs, ws = h // ratio, w // ratio
     # oracle tensors re-ordered to the sub-grid-major layout: (C,5,hs,r,ws,r) -> (r,r,C,5,hs,ws)
     f_ref = feature.view(136, 5, hs, ratio, ws, ratio).permute(3, 5, 0, 1, 2, 4).reshape(ratio * ratio, 136, -1)

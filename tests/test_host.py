@@ -196,9 +196,9 @@ def test_pack_cache_follows_data_swaps_and_pins():
     c, _ = pf.pack_weight_t(w)
     assert c is not b and torch.equal(c[:, :16], w.detach()[:, :, 0].t())
     conv = torch.nn.Conv2d(8, 16, 3, bias=False)
-    p1 = pf.pack_conv2d_weight(conv.weight)
+    p1 = pf.pack_conv2d_wide_weight(conv.weight)
     conv.double()                                         # dtype change through .data
-    p2 = pf.pack_conv2d_weight(conv.weight)
+    p2 = pf.pack_conv2d_wide_weight(conv.weight)
     assert p2 is not p1 and p2.dtype == torch.float32
     # pinned entries survive eviction pressure; unpinned least-recently-used ones go first
     pf.pack_log_begin()

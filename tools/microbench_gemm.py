@@ -1,5 +1,5 @@
 """Micro-benchmark of pf_pointwise_gemm_f32 on the six GEMM shapes of one flow iteration (cfg2: flow-1 G=1,
-flow-2 G=4, Ng=25600): the chunked-through-LDS kernel (PF_GEMM_LEGACY=1) against the direct-A kernel."""
+flow-2 G=4, Ng=25600): the chunked-through-LDS kernel (channel-major input) against the direct-A kernel (point-major rows)."""
 import os
 import sys
 
@@ -37,15 +37,13 @@ for G in (1, 4):
         ref = None
         line = "G=%d %s K=%d Nc=%d:" % (G, name, K, Nc)
         flops = 2.0 * G * Ng * K * Nc
-        for legacy in ("1", "0"):                          # chunked-through-LDS kernel, then the direct-A kernel
-            os.environ["PF_GEMM_LEGACY"] = legacy
-            pointflow.pointwise_gemm(X, True, ldx, Wt, Y, Nc, G, Ng, K, Nc, in_affine=aff, want_stats=True)
+        X_cm = X[:, :K].reshape(G, Ng, K).transpose(1, 2).contiguous()
+        for pm in (False, True):                           # chunked-through-LDS kernel (channel-major input), then direct-A
+            args = (X if pm else X_cm, pm, ldx if pm else 0, Wt, Y, Nc, G, Ng, K, Nc)
+            pointflow.pointwise_gemm(*args, in_affine=aff, want_stats=True)
             if ref is None:
                 ref = Y.clone()
             err = float((Y - ref).abs().max()) / float(ref.abs().max())
-            t = timeit(lambda: pointflow.pointwise_gemm(X, True, ldx, Wt, Y, Nc, G, Ng, K, Nc, in_affine=aff,
-                                                        want_stats=True))
-            line += "  [%s] %.1f us %.1f TF (rel diff %.1e)" % ("chunked" if legacy == "1" else "direct", t,
-                                                                 flops / t / 1e6, err)
+            t = timeit(lambda: pointflow.pointwise_gemm(*args, in_affine=aff, want_stats=True))
+            line += "  [%s] %.1f us %.1f TF (rel diff %.1e)" % ("direct" if pm else "chunked", t, flops / t / 1e6, err)
         print(line, flush=True)
-os.environ.pop("PF_GEMM_LEGACY", None)

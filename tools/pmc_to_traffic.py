@@ -17,7 +17,7 @@ import sys
 
 ENTRY_KERNELS = {
     "pf_conv3d_k3_f32": "conv3d_k3_kernel", "pf_conv3d_k3_few_f32": "conv3d_k3_few_kernel",
-    "pf_conv2d_f32": "conv2d_kernel", "pf_conv2d_small_f32": "conv2d_small_kernel", "pf_pointwise_gemm_f32": "pointwise_gemm_",
+    "pf_pointwise_gemm_f32": "pointwise_gemm_",
     "pf_edge_apply_f32": "edge_apply_kernel", "pf_edge_stats_f32": "edge_stats_kernel",
     "pf_flow_features_f32": "flow_features_", "pf_knn_lattice_f32": "knn_",
     "pf_conv2d_wide_f32": "conv2d_wide", "pf_conv3d_k3_pair_f32": "conv3d_k3_pair_kernel",

@@ -10,16 +10,7 @@ from pointmvsnet_amd import pointflow  # noqa: E402
 
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-which = sys.argv[1:] or ["conv2d"]
-if "conv2d" in which:
-    for cin, cout, h, w, ks, stride in ((16, 16, 256, 320, 3, 1), (32, 32, 128, 160, 3, 1), (8, 16, 512, 640, 5, 2),
-                                        (16, 32, 256, 320, 5, 2)):
-        conv = torch.nn.Conv2d(cin, cout, ks, stride=stride, padding=ks // 2, bias=False).to(dev)
-        x = torch.randn(3, cin, h, w, device=dev)
-        sc = torch.rand(3, cin, device=dev) + 0.5
-        sh = torch.randn(3, cin, device=dev) * 0.1
-        for _ in range(4):
-            pointflow.conv2d(x, conv, (sc, sh), 1, True)
+which = sys.argv[1:] or ["wide"]
 if "wide" in which:
     for cin, cout, h, w, ks, stride in ((16, 16, 256, 320, 3, 1), (32, 32, 128, 160, 3, 1), (32, 64, 128, 160, 5, 2),
                                         (64, 64, 64, 80, 3, 1)):
