@@ -77,6 +77,11 @@ def parse_args():
                          "(pointmvsnet_amd.graph.LanedForward); 1 = one scene at a time")
     ap.add_argument("--calibration-steps", type=int, default=10,
                     help="instrumented eager forwards (HIP events around every entry point) before the timed region")
+    ap.add_argument("--route", default="fused", choices=["fused", "reference-model"],
+                    help="reference-model: time the REFERENCE'S OWN model graph (its unmodified pointmvsnet/model.py, "
+                         "--reference-model-py) running eagerly on this package's operator layer "
+                         "(compat.load_reference_model) instead of pointmvsnet_amd.model.PointMVSNet")
+    ap.add_argument("--reference-model-py", default="/root/reference/pointmvsnet/model.py")
     ap.add_argument("--launch-check", action="store_true",
                     help="only initialise the process group, count the ranks with an all-reduce of ones, print and "
                          "exit (gloo when no GPU is visible: the N > 1 launch path is testable on CPU)")
@@ -277,7 +282,16 @@ def main():
             batch = to_device(data, dev)
             batch["gt_depth_img"] = synthetic.make_gt_depth(data, seed=my_scenes[i]).to(dev)
             scenes.append(batch)
-    net = PointMVSNet()
+    if args.route == "reference-model":
+        from pointmvsnet_amd import compat
+        if not os.path.isfile(args.reference_model_py):
+            raise SystemExit("bench.py --route reference-model: %s not found" % args.reference_model_py)
+        net = compat.load_reference_model(args.reference_model_py).PointMVSNet()
+        args.eager, args.lanes = True, 1                     # the reference graph syncs with the host: no capture
+        sps = args.scenes_per_step or 4
+        scenes = [{k: v for k, v in b.items() if not k.endswith("_host")} for b in scenes]
+    else:
+        net = PointMVSNet()
     synthetic.seed_weights(net, seed=0)
     net = net.to(dev).train()                                                   # reference test.py:58
 
@@ -498,6 +512,7 @@ def main():
                    if training else
                    "PointMVSNet.forward(isFlow=True, isTest=True), BatchNorm in train mode (test.py:58)"},
         "execution": train_execution if training else execution,
+        "route": args.route,
         "host_issue_ms_per_depth_map": issued / (args.steps * sps) * 1e3,
         "lane_placement_probe_maps_per_s": lane_probe,
         "gap_probe": gap_probe,

@@ -221,6 +221,13 @@ class ImageConv(nn.Module):
         self.conv3 = stage(4 * b, 8 * b, last_plain=True)
 
     def forward(self, imgs):
+        """The reference's call (model.py:71-77, :140-148: one view at a time, BatchNorm statistics over the batch).
+        Without an autograd graph the HIP tower kernels run (the batched-views path with one view); with one, the
+        stock ATen composition, whose backward the training step uses."""
+        if pointflow.hip_inference(imgs, self):
+            out = self.forward_views(imgs.unsqueeze(1), need=("conv0", "conv1", "conv2", "conv3"))
+            pointflow.flush_counters()
+            return {k: v[:, 0] for k, v in out.items()}
         out = {}
         x = imgs
         for name in ("conv0", "conv1", "conv2", "conv3"):
@@ -359,6 +366,10 @@ class VolumeConv(nn.Module):
         return f(self.conv6_2, summed)
 
     def forward(self, x):
+        if pointflow.hip_inference(x, self):        # reference model.py:113-115 without an autograd graph: own kernels
+            y = self.forward_fused(x.float())
+            pointflow.flush_counters()
+            return y
         full = self.conv0_1(x)
         half = self.conv1_0(x)
         quarter = self.conv2_0(half)

@@ -2,9 +2,10 @@
 
 Same constructor signatures, sub-module names (``conv``, ``bn``) and initialisation as the reference
 blocks (reference nn/conv.py:7-216) so state dicts are interchangeable; implemented once, generically,
-instead of five times.  The convolution arithmetic itself is the stock ROCm library path (MIOpen via
-PyTorch-ROCm): SURVEY.md section 8 lists ImageConv as adjacent / out of scope for hand kernels and
-VolumeConv's hand-written MFMA implicit GEMM as "next".
+instead of five times.  A block's own ``forward`` is the stock ATen composition (it carries the autograd graph of the
+training step); the inference paths of the containers -- ``ImageConv.forward`` / ``forward_views``,
+``VolumeConv.forward`` / ``forward_fused``, ``SharedMLP.forward`` -- run the blocks' convolutions and BatchNorms on
+the HIP kernels of csrc/ (conv2d_wide.hip, conv3d*.hip, deconv3d.hip, edgeconv.hip, norm.hip) instead.
 """
 from torch import nn
 import torch.nn.functional as F

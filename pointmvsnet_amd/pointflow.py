@@ -22,6 +22,46 @@ _F32 = torch.float32
 # ---------------------------------------------------------------------------------------------
 # small helpers
 # ---------------------------------------------------------------------------------------------
+def hip_inference(x, module):
+    """True when ``module(x)`` needs no autograd graph and can take the HIP inference kernels: a float32 GPU tensor,
+    and either grad mode off or nothing involved that requires grad.  (The reference's model.py calls the operator
+    modules' plain ``forward``; this is how those calls reach the kernels.)"""
+    if not (torch.is_tensor(x) and x.is_cuda and x.dtype == _F32):
+        return False
+    if not torch.is_grad_enabled():
+        return True
+    return not (x.requires_grad or any(p.requires_grad for p in module.parameters()))
+
+
+def shared_mlp_forward(blocks, x):
+    """SharedMLP over points (reference nn/mlp.py:45-81 with ndim = 1: [Conv1d 1x1 -> BatchNorm1d -> ReLU] x n on
+    (B, C, N)) on pf_pointwise_gemm_f32: the chain stays point-major, every BatchNorm + ReLU is applied by the next
+    GEMM's A load, statistics pooled over the batch like BatchNorm1d.  Returns (B, C_out, N), or None when a block
+    is not of that form (the caller then runs the stock composition)."""
+    B, C, N = x.shape
+    for blk in blocks:
+        conv, bn = blk.conv, blk.bn
+        if (type(conv) is not torch.nn.Conv1d or conv.kernel_size != (1,) or conv.stride != (1,) or conv.groups != 1
+                or conv.bias is not None or bn is None or not blk.relu or conv.out_channels > 128
+                or bn.momentum is None or not bn.affine):
+            return None
+    dev = x.device
+    X, pm, ldx, K = x.contiguous(), False, 0, C
+    affine = None
+    with torch.cuda.device(dev):
+        for blk in blocks:
+            Wt, cout = pack_weight_t(blk.conv.weight)
+            Z = torch.empty((B * N, cout), dtype=_F32, device=dev)
+            part = pointwise_gemm(X, pm, ldx, Wt, Z, cout, B, N, K, cout, in_affine=affine, groups_per_stat=B,
+                                  want_stats=True)
+            affine = _bn_affine_from_gemm(blk.bn, part, cout, B, N, B, dev, lazy=True)
+            X, pm, ldx, K = Z, True, cout, cout
+        scale, shift = affine_rows(affine)                 # (1, cout): the last BatchNorm + ReLU, then channel-major
+        y = torch.relu_(X * scale + shift).view(B, N, K).transpose(1, 2).contiguous()
+        flush_counters()
+    return y
+
+
 def stat_blocks(G, Ng):
     return int(_lib.load().pf_stat_blocks(int(G), int(Ng)))
 

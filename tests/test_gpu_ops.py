@@ -1182,3 +1182,71 @@ def test_batch_norm_act2_two_batchnorms_and_their_sum_in_one_pass(dev, N, C, D, 
         assert torch.allclose(m.running_var.double().cpu(), r.running_var, rtol=1e-5, atol=1e-6)
         assert int(m.num_batches_tracked) == 1
     assert _lib.status() == 0
+
+
+# ---------------------------------------------------------------------------------------------
+# the operator modules' plain forward (what the reference's model.py calls) reaches the HIP kernels when no autograd
+# graph is needed, and equals the stock ATen composition the same module runs under autograd
+# ---------------------------------------------------------------------------------------------
+def _twin(mod, dev):
+    import copy
+    a = mod.to(dev).train()
+    return a, copy.deepcopy(a)
+
+
+def _buffers_close(a, b, rtol=1e-5, atol=1e-6):
+    for (k, x), (_, y) in zip(a.state_dict().items(), b.state_dict().items()):
+        if "num_batches" in k:
+            assert int(x) == int(y), k
+        elif "running" in k:
+            assert torch.allclose(x, y, rtol=rtol, atol=atol), k
+
+
+def test_image_conv_forward_takes_the_hip_route_without_autograd(dev):
+    from pointmvsnet_amd.networks import ImageConv
+    mod = ImageConv(8)
+    synthetic.seed_weights(mod, seed=4)
+    hip, stock = _twin(mod, dev)
+    x = torch.randn(2, 3, 64, 96, generator=torch.Generator().manual_seed(1)).to(dev)
+    with torch.no_grad():
+        got = hip(x)
+    want = stock(x.clone().requires_grad_(True))                       # autograd on: the ATen composition
+    assert set(got) == {"conv0", "conv1", "conv2", "conv3"}
+    for k in got:
+        scale = float(want[k].abs().max())
+        err = _maxabs(got[k], want[k].detach())
+        report("image_conv_forward_hip_" + k, err=err, scale=scale)
+        assert got[k].shape == want[k].shape and err < 3e-5 * scale
+        assert not got[k].requires_grad
+    _buffers_close(hip, stock, rtol=1e-4, atol=1e-5)
+
+
+def test_volume_conv_forward_takes_the_hip_route_without_autograd(dev):
+    from pointmvsnet_amd.networks import VolumeConv
+    mod = VolumeConv(64, 8)
+    synthetic.seed_weights(mod, seed=2)
+    hip, stock = _twin(mod, dev)
+    x = torch.rand(1, 64, 16, 32, 40, generator=torch.Generator().manual_seed(9)).to(dev)
+    with torch.no_grad():
+        got = hip(x)
+    want = stock(x.clone().requires_grad_(True)).detach()
+    err, scale = _maxabs(got, want), float(want.abs().max())
+    report("volume_conv_forward_hip", err=err, scale=scale)
+    assert got.shape == want.shape and err < 2e-5 * scale
+    _buffers_close(hip, stock, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,C,N,widths", [(1, 224, 25600, (64, 64, 16)), (2, 224, 1000, (64, 64, 16)), (3, 40, 77, (32, 128))])
+def test_shared_mlp_forward_takes_the_hip_route_without_autograd(dev, B, C, N, widths):
+    from pointmvsnet_amd.nn.mlp import SharedMLP
+    mod = SharedMLP(C, widths)
+    synthetic.seed_weights(mod, seed=6)
+    hip, stock = _twin(mod, dev)
+    x = torch.randn(B, C, N, generator=torch.Generator().manual_seed(2)).to(dev)
+    with torch.no_grad():
+        got = hip(x)
+    want = stock(x.clone().requires_grad_(True)).detach()
+    err, scale = _maxabs(got, want), float(want.abs().max())
+    report("shared_mlp_forward_hip_%d_%d" % (B, N), err=err, scale=scale)
+    assert got.shape == want.shape and got.is_contiguous() and err < 2e-5 * scale
+    _buffers_close(hip, stock, rtol=1e-4, atol=1e-5)
