@@ -69,6 +69,20 @@ __global__ __launch_bounds__(256) void fetch_bwd_kernel(const float* __restrict_
 // ------------------------------------------------------------------------------------------------
 // W+V: fetch + variance over views (reference model.py:102-111 coarse, :187-190 flow)
 // ------------------------------------------------------------------------------------------------
+// The three coarse fetch+variance kernels share these two expressions (their outputs are bit-identical to each
+// other, tests/test_gpu_ops.py): the bilinear sample as one fmaf chain over the taps in (nw, ne, sw, se) order and the
+// variance E[x^2] - E[x]^2 with the means taken by a multiplication with 1/V.  Round 3: through round 2 they were
+// separate multiplies / adds and two IEEE divisions per channel -- 22 instead of 3 instructions per variance, a third
+// of the warp kernel's arithmetic; against the reference's own composition the fused result moves by float32
+// rounding either way (tolerance in tests/test_gpu_ops.py::test_fetch_variance_vs_oracle).
+__device__ __forceinline__ float pf_bilerp(float a, float b, float c, float d, float w0, float w1, float w2, float w3) {
+  return fmaf(d, w3, fmaf(c, w2, fmaf(b, w1, a * w0)));
+}
+__device__ __forceinline__ float pf_variance(float s, float s2, float inv_v) {
+  const float m1 = s * inv_v;
+  return fmaf(-m1, m1, s2 * inv_v);
+}
+
 // Frustum of the reference view (reference model.py:79-100): point n = d*H*W + y*W + x is the un-projection
 // of pixel centre (x+0.5, y+0.5) at depth hypothesis d,  world = Rinv (depth * Kinv (x+0.5, y+0.5, 1)^T - t).
 struct Frustum {
@@ -135,18 +149,19 @@ __global__ __launch_bounds__(256) void fetch_variance_kernel(const float* __rest
 #pragma unroll
     for (int v = 0; v < V; ++v) {
       const float* plane = mb + ((int64_t)v * C + c) * HW;
-      const float f = (v == 0 && ref_override) ? plane[ref_off] : pf_sample(plane, t[v]);
+      const float f = (v == 0 && ref_override)
+                          ? plane[ref_off]
+                          : pf_bilerp(plane[t[v].off[0]], plane[t[v].off[1]], plane[t[v].off[2]], plane[t[v].off[3]],
+                                      t[v].wgt[0], t[v].wgt[1], t[v].wgt[2], t[v].wgt[3]);
       if (v == 0) {
         s = f;
         s2 = f * f;
       } else {
         s = s + f;
-        s2 = s2 + f * f;
+        s2 = fmaf(f, f, s2);
       }
     }
-    const float m1 = s / (float)V;
-    const float m2 = s2 / (float)V;
-    o[(int64_t)c * N] = m2 - m1 * m1;
+    o[(int64_t)c * N] = pf_variance(s, s2, 1.0f / (float)V);
   }
 }
 
@@ -218,10 +233,23 @@ __global__ __launch_bounds__(256) void frustum_variance_cl_kernel(const float* _
       const float Y = fmaf(ri[5], q2, fmaf(ri[4], q1, ri[3] * q0));
       const float Z = fmaf(ri[8], q2, fmaf(ri[7], q1, ri[6] * q0));
       if (c0 == 0 && q < 3) tile[64 + q][p] = q == 0 ? X : (q == 1 ? Y : Z);
+      // the V - 1 projections of a point: lane q of its 16 lanes computes ONE of them (view 1 + q mod (V - 1)) and the
+      // 16 lanes exchange taps and weights by shuffles -- round 2 had every lane compute all V - 1 (~150 instructions
+      // each, two IEEE divisions: two thirds of the kernel's arithmetic at V = 3, 85 % at V = 7)
       PfTaps t[V];
+      if (V > 1) {
+        const int vq = 1 + (q % (V > 1 ? V - 1 : 1));
+        PfTaps mine;
+        pf_project_taps(X, Y, Z, Kmat + (b * V + vq) * 9, Emat ? Emat + (b * V + vq) * 12 : nullptr, H, W, mine);
 #pragma unroll
-      for (int v = 1; v < V; ++v)
-        pf_project_taps(X, Y, Z, Kmat + (b * V + v) * 9, Emat ? Emat + (b * V + v) * 12 : nullptr, H, W, t[v]);
+        for (int v = 1; v < V; ++v) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            t[v].off[k] = __shfl(mine.off[k], v - 1, 16);
+            t[v].wgt[k] = __shfl(mine.wgt[k], v - 1, 16);
+          }
+        }
+      }
       const int c = c0 + 4 * q;
       if (c < C) {
         // view 0 contributes its un-warped feature (model.py:103-106)
@@ -236,22 +264,16 @@ __global__ __launch_bounds__(256) void frustum_variance_cl_kernel(const float* _
           const float4 cc = *reinterpret_cast<const float4*>(mv + (int64_t)t[v].off[2] * C);
           const float4 dd = *reinterpret_cast<const float4*>(mv + (int64_t)t[v].off[3] * C);
           const float w0 = t[v].wgt[0], w1 = t[v].wgt[1], w2 = t[v].wgt[2], w3 = t[v].wgt[3];
-          const float f[4] = {((a.x * w0 + bb.x * w1) + cc.x * w2) + dd.x * w3,
-                              ((a.y * w0 + bb.y * w1) + cc.y * w2) + dd.y * w3,
-                              ((a.z * w0 + bb.z * w1) + cc.z * w2) + dd.z * w3,
-                              ((a.w * w0 + bb.w * w1) + cc.w * w2) + dd.w * w3};
+          const float f[4] = {pf_bilerp(a.x, bb.x, cc.x, dd.x, w0, w1, w2, w3), pf_bilerp(a.y, bb.y, cc.y, dd.y, w0, w1, w2, w3),
+                              pf_bilerp(a.z, bb.z, cc.z, dd.z, w0, w1, w2, w3), pf_bilerp(a.w, bb.w, cc.w, dd.w, w0, w1, w2, w3)};
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             s[i] = s[i] + f[i];
-            s2[i] = s2[i] + f[i] * f[i];
+            s2[i] = fmaf(f[i], f[i], s2[i]);
           }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float m1 = s[i] / (float)V;
-          const float m2 = s2[i] / (float)V;
-          tile[4 * q + i][p] = m2 - m1 * m1;
-        }
+        for (int i = 0; i < 4; ++i) tile[4 * q + i][p] = pf_variance(s[i], s2[i], 1.0f / (float)V);
       }
     }
     __syncthreads();

@@ -71,6 +71,8 @@ struct PfTaps {
   int off[4];     // y*W + x of the nw, ne, sw, se taps; 0 (a valid address) when the tap is outside the map
   float wgt[4];   // bilinear weights; exactly 0 for a tap outside the map (zero padding)
   bool ok[4];     // tap inside the map (only the backward scatter needs it)
+  int xi, yi;     // column / row of the nw tap (tap k sits at (xi + (k & 1), yi + (k >> 1)) when ok[k])
+  float fx, fy;   // fractional parts: wgt = {(1-fy)(1-fx), (1-fy) fx, fy (1-fx), fy fx} where ok
 };
 
 __device__ __forceinline__ void pf_project_taps(float X, float Y, float Z, const float* __restrict__ Kv,
@@ -99,6 +101,10 @@ __device__ __forceinline__ void pf_project_taps(float X, float Y, float Z, const
   const bool vy1 = (y0 + 1.0f >= 0.0f) && (y0 + 1.0f <= ymax);
   const int xi = (vx0 || vx1) ? (int)x0 : 0;
   const int yi = (vy0 || vy1) ? (int)y0 : 0;
+  t.xi = xi;
+  t.yi = yi;
+  t.fx = wx1;
+  t.fy = wy1;
   t.ok[0] = vy0 && vx0;
   t.ok[1] = vy0 && vx1;
   t.ok[2] = vy1 && vx0;
