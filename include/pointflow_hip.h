@@ -142,10 +142,13 @@ int pf_resize_bilinear_f32(const float* in, float* out, int64_t P, int64_t IH, i
 
 /* The three pyramid levels of one flow iteration (model.py:180-186) in one launch: in_l (V, c_l, h_l, w_l)
  * -> out_l (V, h, w, c_l) CHANNEL-LAST, bilinear align_corners = False (a level already at (h, w) is
- * transposed only).  c_l % 4 == 0 (else PF_ERR_UNSUPPORTED); c_l == 0 skips a level. */
+ * transposed only).  c_l % 4 == 0 (else PF_ERR_UNSUPPORTED); c_l == 0 skips a level.  in_scale / in_shift (host
+ * arrays of three device pointers, or NULL; an entry may be NULL): rows (V, c_l) of the pending BatchNorm + ReLU of
+ * level l -- the tower's raw convolution output is normalised texel by texel BEFORE it is interpolated, i.e. the
+ * F.interpolate of relu(bn(x)) without the normalised map ever being written (reference nn/conv.py:62-77 + model.py:184). */
 int pf_flow_pyramid_f32(const float* in1, int c1, int h1, int w1, const float* in2, int c2, int h2, int w2,
                         const float* in3, int c3, int h3, int w3, int V, int h, int w, float* out1, float* out2,
-                        float* out3, void* stream);
+                        float* out3, const float* const* in_scale, const float* const* in_shift, void* stream);
 
 /* ---- row F (+U, +T ordering) : flow feature assembly ------------------------------------------
  * One launch builds what reference model.py:153-204 builds with ~100 ATen calls, for batch item 0..0

@@ -43,7 +43,8 @@ PROTOTYPES = {
     "pf_frustum_variance_cl_f32": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp], _i),
     "pf_nchw_to_nhwc_f32": ([_vp, _vp, _i64, _i64, _i64, _vp], _i),
     "pf_resize_bilinear_f32": ([_vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp], _i),
-    "pf_flow_pyramid_f32": ([_vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp], _i),
+    "pf_flow_pyramid_f32": ([_vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp,
+                             ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp], _i),
     "pf_flow_features_f32": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp], _i),
     "pf_stat_blocks": ([_i, _i], _i),
     "pf_gemm_blocks": ([_i, _i], _i),

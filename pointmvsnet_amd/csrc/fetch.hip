@@ -332,6 +332,8 @@ __global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __res
 struct PyramidLevel {
   const float* in;
   float* out;
+  const float* scale;   // (V, C) rows of a pending BatchNorm + ReLU of `in`, or nullptr: in is taken as is
+  const float* shift;
   int C, IH, IW;
 };
 struct Pyramid {
@@ -347,9 +349,21 @@ __global__ __launch_bounds__(256) void pyramid_resize_kernel(Pyramid py, int V, 
   const int plane = L.IH * L.IW;
   const float* src = L.in + ((int64_t)v * L.C + 4 * cq) * plane;
   float r[4];
+  // the tower's last BatchNorm + ReLU of this level, applied to every texel BEFORE it is interpolated (round 3: the
+  // tower used to write the normalised maps with a pass of its own; this kernel reads the raw convolution output)
+  float sc[4] = {1.0f, 1.0f, 1.0f, 1.0f}, sh[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  const bool aff = L.scale != nullptr;
+  if (aff) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      sc[c] = L.scale[(int64_t)v * L.C + 4 * cq + c];
+      sh[c] = L.shift[(int64_t)v * L.C + 4 * cq + c];
+    }
+  }
+  auto act = [&](float x, int c) { return aff ? fmaxf(fmaf(x, sc[c], sh[c]), 0.0f) : x; };
   if (L.IH == OH && L.IW == OW) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) r[c] = src[(int64_t)c * plane + i];
+    for (int c = 0; c < 4; ++c) r[c] = act(src[(int64_t)c * plane + i], c);
   } else {
     int y0, y1, x0, x1;
     float ly0, ly1, lx0, lx1;
@@ -358,8 +372,8 @@ __global__ __launch_bounds__(256) void pyramid_resize_kernel(Pyramid py, int V, 
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const float* pc = src + (int64_t)c * plane;
-      const float a = pc[y0 * L.IW + x0], b = pc[y0 * L.IW + x1];
-      const float cc = pc[y1 * L.IW + x0], d = pc[y1 * L.IW + x1];
+      const float a = act(pc[y0 * L.IW + x0], c), b = act(pc[y0 * L.IW + x1], c);
+      const float cc = act(pc[y1 * L.IW + x0], c), d = act(pc[y1 * L.IW + x1], c);
       r[c] = ly0 * (lx0 * a + lx1 * b) + ly1 * (lx0 * cc + lx1 * d);
     }
   }
@@ -499,14 +513,14 @@ __global__ __launch_bounds__(256) void flow_features_hyp_kernel(const float* __r
             const float4 b = *reinterpret_cast<const float4*>(mv + (int64_t)o.y * cl);
             const float4 cc = *reinterpret_cast<const float4*>(mv + (int64_t)o.z * cl);
             const float4 dd = *reinterpret_cast<const float4*>(mv + (int64_t)o.w * cl);
-            const float f[4] = {((a.x * wg.x + b.x * wg.y) + cc.x * wg.z) + dd.x * wg.w,
-                                ((a.y * wg.x + b.y * wg.y) + cc.y * wg.z) + dd.y * wg.w,
-                                ((a.z * wg.x + b.z * wg.y) + cc.z * wg.z) + dd.z * wg.w,
-                                ((a.w * wg.x + b.w * wg.y) + cc.w * wg.z) + dd.w * wg.w};
+            const float f[4] = {pf_bilerp(a.x, b.x, cc.x, dd.x, wg.x, wg.y, wg.z, wg.w),
+                                pf_bilerp(a.y, b.y, cc.y, dd.y, wg.x, wg.y, wg.z, wg.w),
+                                pf_bilerp(a.z, b.z, cc.z, dd.z, wg.x, wg.y, wg.z, wg.w),
+                                pf_bilerp(a.w, b.w, cc.w, dd.w, wg.x, wg.y, wg.z, wg.w)};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               s[d][i] = s[d][i] + f[i];
-              s2[d][i] = s2[d][i] + f[i] * f[i];
+              s2[d][i] = fmaf(f[i], f[i], s2[d][i]);
             }
           }
         }
@@ -515,11 +529,7 @@ __global__ __launch_bounds__(256) void flow_features_hyp_kernel(const float* __r
           for (int d = 0; d < 5; ++d) {
             float o[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const float m1 = s[d][i] / (float)V;
-              const float m2 = s2[d][i] / (float)V;
-              o[i] = m2 - m1 * m1;
-            }
+            for (int i = 0; i < 4; ++i) o[i] = pf_variance(s[d][i], s2[d][i], 1.0f / (float)V);
             *reinterpret_cast<float4*>(frow0 + d * dstride + ch + c) = make_float4(o[0], o[1], o[2], o[3]);
           }
         }
@@ -736,8 +746,16 @@ int pf_resize_bilinear_f32(const float* in, float* out, int64_t P, int64_t IH, i
 
 int pf_flow_pyramid_f32(const float* in1, int c1, int h1, int w1, const float* in2, int c2, int h2, int w2,
                         const float* in3, int c3, int h3, int w3, int V, int h, int w, float* out1, float* out2,
-                        float* out3, void* stream) {
+                        float* out3, const float* const* in_scale, const float* const* in_shift, void* stream) {
   PF_REQUIRE(V >= 1 && h >= 1 && w >= 1 && c1 >= 0 && c2 >= 0 && c3 >= 0);
+  PF_REQUIRE((in_scale == nullptr) == (in_shift == nullptr));
+  const float* sc[3] = {nullptr, nullptr, nullptr};
+  const float* sh[3] = {nullptr, nullptr, nullptr};
+  for (int l = 0; in_scale != nullptr && l < 3; ++l) {
+    PF_REQUIRE((in_scale[l] == nullptr) == (in_shift[l] == nullptr));
+    sc[l] = in_scale[l];
+    sh[l] = in_shift[l];
+  }
   PF_REQUIRE(h1 >= 1 && w1 >= 1 && h2 >= 1 && w2 >= 1 && h3 >= 1 && w3 >= 1);
   if ((c1 % 4) != 0 || (c2 % 4) != 0 || (c3 % 4) != 0) return PF_ERR_UNSUPPORTED;
   PF_REQUIRE((int64_t)h * w <= INT32_MAX && (int64_t)h1 * w1 <= INT32_MAX && (int64_t)h2 * w2 <= INT32_MAX &&
@@ -748,9 +766,9 @@ int pf_flow_pyramid_f32(const float* in1, int c1, int h1, int w1, const float* i
   PF_REQUIRE((c1 == 0 || (in1 && out1)) && (c2 == 0 || (in2 && out2)) && (c3 == 0 || (in3 && out3)));
   PF_REQUIRE((int64_t)V * (cmax / 4) <= 65535);
   Pyramid py;
-  py.l[0] = PyramidLevel{in1, out1, c1, h1, w1};
-  py.l[1] = PyramidLevel{in2, out2, c2, h2, w2};
-  py.l[2] = PyramidLevel{in3, out3, c3, h3, w3};
+  py.l[0] = PyramidLevel{in1, out1, sc[0], sh[0], c1, h1, w1};
+  py.l[1] = PyramidLevel{in2, out2, sc[1], sh[1], c2, h2, w2};
+  py.l[2] = PyramidLevel{in3, out3, sc[2], sh[2], c3, h3, w3};
   dim3 grid((unsigned)pf_cdiv((int64_t)h * w, 256), (unsigned)(V * (cmax / 4)), 3);
   hipLaunchKernelGGL(pyramid_resize_kernel, grid, dim3(256), 0, (hipStream_t)stream, py, V, h, w, cmax / 4);
   return pf_launch_status();

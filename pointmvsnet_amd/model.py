@@ -386,7 +386,7 @@ class PointMVSNet(nn.Module):
             pointflow.flush_counters()
             return preds
         if pointflow.CONCURRENCY < 1:
-            pyramids = self.run_flow_tower(img_list)
+            pyramids = self.run_flow_tower(img_list, raw=True)
             preds = self.run_coarse_stage(plan, feature_list)
             return self.run_flows(plan, pyramids, preds)
         # (fork structure measured in round 2, profiles/r02p_fork_mode_ab.log: flow tower captured first / coarse stage
@@ -394,10 +394,14 @@ class PointMVSNet(nn.Module):
         side = pointflow.side_stream(dev, 0)
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            pyramids = self.run_flow_tower(img_list)
+            pyramids = self.run_flow_tower(img_list, raw=True)
             pointflow.stamp("flow_tower_end")
             for p in pyramids.values():
-                p.record_stream(main)
+                if isinstance(p, pointflow.RawLevel):
+                    for t in (p.raw,) + (tuple(pointflow.affine_rows(p.affine)) if p.affine is not None else ()):
+                        t.record_stream(main)
+                else:
+                    p.record_stream(main)
         preds = self.run_coarse_stage(plan, feature_list)
         main.wait_stream(side)
         return self.run_flows(plan, pyramids, preds)
@@ -411,7 +415,12 @@ class PointMVSNet(nn.Module):
             return ChannelLast(out["conv3_cl"].contiguous())
         return out["conv3"].contiguous()
 
-    def run_flow_tower(self, img_list):
+    def run_flow_tower(self, img_list, raw=False):
+        """The three pyramid levels {"conv1","conv2","conv3"}: (B,V,c,h,w) maps, or with ``raw`` (one scene) the levels
+        as ``pointflow.RawLevel`` -- BatchNorm + ReLU pending, applied by the resize kernel of every iteration."""
+        if raw and img_list.shape[0] == 1:
+            out = self.flow_img_conv.forward_views(img_list, raw=("conv1", "conv2", "conv3"))
+            return {n: out[n + "_raw"] if n + "_raw" in out else out[n] for n in ("conv1", "conv2", "conv3")}
         return self.flow_img_conv.forward_views(img_list)
 
     def run_coarse_stage(self, plan, feature_list):
@@ -445,7 +454,8 @@ class PointMVSNet(nn.Module):
             packed = plan.d("pack%d" % it)
             outs, probs = [], []
             for b in range(B):
-                pyr_b = [pyramids[n][b].contiguous() for n in names]
+                pyr_b = [pyramids[n] if isinstance(pyramids[n], pointflow.RawLevel) else pyramids[n][b].contiguous()
+                         for n in names]
                 d_b, p_b = pointflow.flow_iteration(pyr_b, pred_depth[b, 0], packed[b, -1:], packed[b], h, w, ratio,
                                                     self.flow_edge_conv, self.flow_mlp, k=self.k)
                 outs.append(d_b)

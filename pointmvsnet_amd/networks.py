@@ -235,7 +235,7 @@ class ImageConv(nn.Module):
             out[name] = x
         return out
 
-    def forward_views(self, img_list, need=("conv1", "conv2", "conv3"), channel_last=()):
+    def forward_views(self, img_list, need=("conv1", "conv2", "conv3"), channel_last=(), raw=()):
         """Inference fast path: all V views of (B,V,3,H,W) in ONE pass through the tower with per-view
         BatchNorm statistics -- numerically the reference's V separate calls (model.py:71-77).  Each layer is
         one pf_conv2d_wide_f32 launch (previous BatchNorm+ReLU applied while staging, this layer's statistics in
@@ -243,7 +243,11 @@ class ImageConv(nn.Module):
         needs "conv3" alone) are materialised, every other BatchNorm+ReLU stays an affine row pair that the
         next convolution applies while staging -- "conv0" is never returned.  Stage names in ``channel_last`` come
         back as (B,V,h,w,c) under the key name + "_cl" when the stage's last layer is a plain convolution on the
-        wide kernel (the coarse tower's "conv3" feeds the channel-last warp: no transposition pass), else as usual."""
+        wide kernel (the coarse tower's "conv3" feeds the channel-last warp: no transposition pass), else as usual.
+        Stage names in ``raw`` (B = 1) come back under name + "_raw" as ``pointflow.RawLevel``: the stage's last
+        convolution output (V,c,h,w) with its BatchNorm + ReLU still pending as (scale, shift) rows -- the flow
+        tower's three levels are normalised by the kernel that resizes them (pf_flow_pyramid_f32), not by a pass of
+        their own."""
         B, V = img_list.shape[:2]
         x = img_list.transpose(0, 1).reshape(V * B, *img_list.shape[2:]).float().contiguous()   # view-major
         pending = None                      # (scale, shift) of a BatchNorm+ReLU not yet applied to x
@@ -255,13 +259,16 @@ class ImageConv(nn.Module):
             # the BN+ReLU of this block can stay pending only if the next conv applies it while staging
             nconv = None if nxt is None else (nxt.conv if hasattr(nxt, "bn") else nxt)
             wanted = stage_end and name in need
-            defer = (not wanted) and nconv is not None and pointflow.conv2d_wide_preferred(nconv)
-            lazy = bool(defer)                                               # the next conv resolves this BatchNorm
+            as_raw = wanted and name in raw and B == 1 and (nconv is None or pointflow.conv2d_wide_preferred(nconv))
+            defer = (as_raw or not wanted) and nconv is not None and pointflow.conv2d_wide_preferred(nconv)
+            lazy = bool(defer) and not as_raw      # the next conv resolves this BatchNorm (a raw level needs the rows)
             conv = block.conv if hasattr(block, "bn") else block
             cl = (wanted and name in channel_last and not hasattr(block, "bn") and conv.out_channels >= 32
                   and pointflow.conv2d_wide_preferred(conv))
             x, pending = _conv2d_block_fused(block, x, pending, B, defer, lazy, channel_last_out=cl)
-            if wanted:
+            if as_raw:
+                out[name + "_raw"] = pointflow.RawLevel(x, pending)
+            elif wanted:
                 out[name + "_cl" if cl else name] = x.view(V, B, *x.shape[1:]).transpose(0, 1)
         return out
 

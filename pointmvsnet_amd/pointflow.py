@@ -939,16 +939,31 @@ def resize_maps(maps, h, w):
     return out
 
 
+class RawLevel(object):
+    """A pyramid level as the tower's last convolution left it: ``raw`` (V, c, h_l, w_l) with its BatchNorm + ReLU still
+    pending -- ``affine`` = (scale, shift) rows (V, c), or a LazyAffine.  flow_pyramid applies it while it resizes."""
+
+    def __init__(self, raw, affine):
+        self.raw, self.affine = raw, affine
+
+
 def flow_pyramid(pyramid, h, w):
-    """The three pyramid levels (V,c_l,h_l,w_l) of a scene resized to the flow grid (model.py:180-186) in one
-    launch, CHANNEL-LAST (V,h,w,c_l) -- the layout flow_features samples with 16-byte loads."""
-    V = pyramid[0].shape[0]
-    outs = [torch.empty((V, h, w, int(m.shape[1])), dtype=_F32, device=m.device) for m in pyramid]
+    """The three pyramid levels of a scene resized to the flow grid (model.py:180-186) in one launch, CHANNEL-LAST
+    (V,h,w,c_l) -- the layout flow_features samples with 16-byte loads.  A level is a (V,c_l,h_l,w_l) tensor, or a
+    ``RawLevel`` whose pending BatchNorm + ReLU the kernel applies to every texel before interpolating."""
+    maps = [(m.raw if isinstance(m, RawLevel) else m) for m in pyramid]
+    rows = [(affine_rows(m.affine) if isinstance(m, RawLevel) else None) for m in pyramid]
+    V = maps[0].shape[0]
+    outs = [torch.empty((V, h, w, int(m.shape[1])), dtype=_F32, device=m.device) for m in maps]
     args = []
-    for m in pyramid:
+    for m in maps:
         args += [_lib.ptr(m), int(m.shape[1]), int(m.shape[2]), int(m.shape[3])]
-    _lib.call("pf_flow_pyramid_f32", *args, V, h, w, _lib.ptr(outs[0]), _lib.ptr(outs[1]), _lib.ptr(outs[2]),
-              _lib.stream(), algo_bytes=sum(4.0 * m.numel() + 4.0 * o.numel() for m, o in zip(pyramid, outs)))
+    sc = sh = None
+    if any(r is not None for r in rows):
+        sc = (ctypes.c_void_p * 3)(*[None if r is None else r[0].data_ptr() for r in rows])
+        sh = (ctypes.c_void_p * 3)(*[None if r is None else r[1].data_ptr() for r in rows])
+    _lib.call("pf_flow_pyramid_f32", *args, V, h, w, _lib.ptr(outs[0]), _lib.ptr(outs[1]), _lib.ptr(outs[2]), sc, sh,
+              _lib.stream(), algo_bytes=sum(4.0 * m.numel() + 4.0 * o.numel() for m, o in zip(maps, outs)))
     return outs
 
 

@@ -311,7 +311,28 @@ def test_flow_pyramid_vs_interpolate(dev):
     lib = _lib.load()
     z = torch.zeros(64, device=dev)
     assert lib.pf_flow_pyramid_f32(_lib.ptr(z), 6, 2, 2, _lib.ptr(z), 4, 2, 2, _lib.ptr(z), 4, 2, 2, 1, 2, 2,
-                                   _lib.ptr(z), _lib.ptr(z), _lib.ptr(z), _lib.stream()) == -2   # c % 4 != 0
+                                   _lib.ptr(z), _lib.ptr(z), _lib.ptr(z), None, None, _lib.stream()) == -2   # c % 4 != 0
+
+
+def test_flow_pyramid_applies_a_pending_batchnorm_before_interpolating(dev):
+    """RawLevel: the tower's raw convolution output + (scale, shift) rows per view == resizing relu(x * scale + shift);
+    a level without rows (the plain last convolution of the tower) passes through."""
+    g = torch.Generator().manual_seed(8)
+    V, (h, w) = 3, (16, 20)
+    raws = [torch.randn(V, c, ih, iw, generator=g) for c, ih, iw in [(16, 32, 40), (32, 16, 20), (64, 8, 10)]]
+    rows = [(torch.rand(V, r.shape[1], generator=g) + 0.5, torch.randn(V, r.shape[1], generator=g) * 0.3) for r in raws]
+    levels = [pointflow.RawLevel(raws[0].to(dev), (rows[0][0].to(dev), rows[0][1].to(dev))),
+              pointflow.RawLevel(raws[1].to(dev), (rows[1][0].to(dev), rows[1][1].to(dev))),
+              pointflow.RawLevel(raws[2].to(dev), None)]
+    outs = pointflow.flow_pyramid(levels, h, w)
+    for i, (r, o) in enumerate(zip(raws, outs)):
+        x = r.double()
+        if i < 2:
+            x = torch.relu(x * rows[i][0].double()[:, :, None, None] + rows[i][1].double()[:, :, None, None])
+        ref = F.interpolate(x, (h, w), mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+        err = _maxabs(o, ref)
+        report("pyramid_raw_level%d" % i, err=err)
+        assert err < 2e-6 * float(x.abs().max())
 
 
 # ---------------------------------------------------------------------------------------------
