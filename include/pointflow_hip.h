@@ -389,6 +389,18 @@ int pf_conv2d_wide_f32(const float* x, const float* wp, float* y, int64_t N, int
                        int64_t Wi, int kernel_size, int stride, const float* in_scale, const float* in_shift,
                        const pf_bn_job* in_bn, int samples_per_stat, double* partials, int out_channel_last,
                        void* stream);
+/* The same launch over `sets` (1 or 2) PARAMETER SETS -- the model's two towers (coarse: model.py:71-77, flow:
+ * model.py:140-148) have identical shapes and run on the same images, so each of their eleven layers is ONE launch:
+ * samples [s*N/sets, (s+1)*N/sets) convolve with the packed weights at wp + s*wp_set_stride (floats, a multiple
+ * of 4) and take their pending BatchNorm from in_bn[s] (an array of `sets` jobs; the (in_scale, in_shift) rows are
+ * indexed by the global statistic group n / samples_per_stat as before).  shared_input != 0: x holds N/sets
+ * samples that every set reads (the towers' first layer reads the same views).  Bit s of out_channel_last selects
+ * the (Ho, Wo, Cout) layout for the samples of set s (each sample's region of y has the same size either way).
+ * Per sample the arithmetic is that of pf_conv2d_wide_f32: results are bit-identical to `sets` separate calls. */
+int pf_conv2d_wide_sets_f32(const float* x, int shared_input, const float* wp, int64_t wp_set_stride, int sets, float* y,
+                            int64_t N, int64_t Cin, int64_t Cout, int64_t Hi, int64_t Wi, int kernel_size, int stride,
+                            const float* in_scale, const float* in_shift, const pf_bn_job* in_bn, int samples_per_stat,
+                            double* partials, int out_channel_last, void* stream);
 
 /* ---- rows M (last layer) + H + T : flow head ---------------------------------------------------
  * Z (G*Ng, ldz) holds the pre-BN output of the 64->16 MLP layer.  Per pixel of the (h,w) grid:

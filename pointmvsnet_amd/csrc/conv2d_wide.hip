@@ -36,8 +36,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));   // (HIP's float4 struct in a register ARRAY ends up in scratch)
 
 struct WideGeom {
-  int Hi, Wi, Ho, Wo, tiles_w, tiles_h, sps, cl_out;   // cl_out: y is (N, Ho, Wo, C_out) instead of (N, C_out, Ho, Wo)
+  int Hi, Wi, Ho, Wo, tiles_w, tiles_h, sps;
+  int cl_out;      // bit s: parameter set s writes y as (Ho, Wo, C_out) per sample instead of (C_out, Ho, Wo)
+  // Parameter sets (pf_conv2d_wide_sets_f32: the two towers of the model in ONE launch): samples
+  // [s * spset, (s + 1) * spset) convolve with the weights at wp + s * w_stride and normalise their input with the
+  // s-th pending BatchNorm; shared_x: every set reads the SAME spset input samples (the towers' first layer)
+  int sets, spset, shared_x;
+  int64_t w_stride;
 };
+
+// which parameter set sample n belongs to (block-uniform)
+__device__ __forceinline__ int wide_set(const WideGeom& g, int n) { return (g.sets > 1 && n >= g.spset) ? 1 : 0; }
 
 template <int KS, int STRIDE, int CIN, int COUT>
 struct WideCfg {
@@ -143,13 +152,13 @@ __device__ __forceinline__ void wide_stage_patch(const float* __restrict__ xb, i
 template <class C, int COUT>
 __device__ __forceinline__ void wide_epilogue(const f32x16& acc, float* __restrict__ y, const WideGeom& g,
                                               double* __restrict__ partials, double* red, int n, int oh0, int ow0,
-                                              int wm, int wn, int wave, int m, int h, int tid) {
+                                              int wm, int wn, int wave, int m, int h, int tid, bool cl_out) {
   // ---- epilogue: C/D layout column (channel) = lane & 31, row (pixel) = (r & 3) + 8 (r >> 2) + 4 h -----------------
   const int co = wn * 32 + m;
   float* yb = y + ((int64_t)n * COUT + co) * ((int64_t)g.Ho * g.Wo);
   const bool vec_ok = (g.Wo & 3) == 0;
   float s = 0.0f, q = 0.0f;
-  if (g.cl_out) {
+  if (cl_out) {
     // channel-last output (the coarse tower's last layer feeds the warp, which samples channel-last maps): for one
     // accumulator element the 32 lanes of a half-wave hold 32 consecutive channels of one pixel = one 128-byte row
     float* ycl = y + (int64_t)n * g.Ho * g.Wo * COUT + co;
@@ -231,7 +240,8 @@ __global__ __launch_bounds__(256) void conv2d_wide_kernel(const float* __restric
                                                             float* __restrict__ y, WideGeom g,
                                                             const float* __restrict__ in_scale,
                                                             const float* __restrict__ in_shift,
-                                                            double* __restrict__ partials, pf_bn_job in_bn) {
+                                                            double* __restrict__ partials, pf_bn_job in_bn,
+                                                            pf_bn_job in_bn1) {
   using C = WideCfg<KS, STRIDE, CIN, COUT>;
   constexpr int PW = C::PW, RS = C::RS, NPIX = C::NPIX;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -248,17 +258,20 @@ __global__ __launch_bounds__(256) void conv2d_wide_kernel(const float* __restric
   const int oh0 = th * C::TH, ow0 = tw * C::TW;
   const int ih0 = oh0 * STRIDE - C::PAD, iw0 = ow0 * STRIDE - C::PAD;
   const int plane_i = g.Hi * g.Wi;
-  const float* xb = x + (int64_t)n * CIN * plane_i;
+  const int set = wide_set(g, n);
+  const float* xb = x + (int64_t)(g.shared_x ? n - set * g.spset : n) * CIN * plane_i;
 
   constexpr int NP = KS * KS * C::KC;                  // 16-byte operand pairs of the tile
   constexpr int D = 6;                                 // B pieces in flight per lane
-  const f32x4* bg = reinterpret_cast<const f32x4*>(wp) + (h * COUT + wn * 32 + m);
+  const f32x4* bg = reinterpret_cast<const f32x4*>(wp + set * g.w_stride) + (h * COUT + wn * 32 + m);
   f32x4 bq[D];
 #pragma unroll
   for (int d = 0; d < D; ++d) bq[d] = bg[(d < NP ? d : 0) * 2 * COUT];
 
+  // (AFFINE 1: affine rows are indexed by the global statistic group; AFFINE 2: by the group inside the set's job)
   wide_stage_patch<CIN, NPIX, PW, RS, AFFINE>(xb, plane_i, ih0, iw0, g.Hi, g.Wi, patch, aff, in_scale, in_shift,
-                                              n / g.sps, in_bn, reinterpret_cast<double*>(patch));
+                                              AFFINE == 2 ? (n - set * g.spset) / g.sps : n / g.sps,
+                                              set ? in_bn1 : in_bn, reinterpret_cast<double*>(patch));
   __syncthreads();
 
   f32x16 acc;
@@ -284,12 +297,13 @@ __global__ __launch_bounds__(256) void conv2d_wide_kernel(const float* __restric
     if (t + D < NP) bq[t % D] = bg[(t + D) * 2 * COUT];
     a = an;
   }
-  wide_epilogue<C, COUT>(acc, y, g, partials, red, n, oh0, ow0, wm, wn, wave, m, h, tid);
+  wide_epilogue<C, COUT>(acc, y, g, partials, red, n, oh0, ow0, wm, wn, wave, m, h, tid, (g.cl_out >> set) & 1);
 }
 
 template <int KS, int STRIDE, int CIN, int COUT, int AFFINE>
 int launch_wide_mode(const float* x, const float* wp, float* y, WideGeom g, int64_t N, const float* in_scale,
-                     const float* in_shift, double* partials, const pf_bn_job& in_bn, hipStream_t s) {
+                     const float* in_shift, double* partials, const pf_bn_job& in_bn, const pf_bn_job& in_bn1,
+                     hipStream_t s) {
   using C = WideCfg<KS, STRIDE, CIN, COUT>;
   if (C::LDS > 64 * 1024) {
     static std::atomic<unsigned long long> done{0};   // per instantiation, one bit per device
@@ -301,7 +315,7 @@ int launch_wide_mode(const float* x, const float* wp, float* y, WideGeom g, int6
   const int tiles_h = (g.Ho + C::TH - 1) / C::TH;
   dim3 grid((unsigned)(tiles_h * g.tiles_w), (unsigned)N);
   hipLaunchKernelGGL((conv2d_wide_kernel<KS, STRIDE, CIN, COUT, AFFINE>), grid, dim3(256), C::LDS, s, x, wp, y, g,
-                     in_scale, in_shift, partials, in_bn);
+                     in_scale, in_shift, partials, in_bn, in_bn1);
   return pf_launch_status();
 }
 
@@ -309,14 +323,17 @@ template <int KS, int STRIDE, int CIN, int COUT>
 int launch_wide(const float* x, const float* wp, float* y, WideGeom g, int64_t N, const float* in_scale,
                 const float* in_shift, double* partials, const pf_bn_job* in_bn, hipStream_t s) {
   if (in_bn != nullptr) {
-    const int rc = pf_bn_in_check(in_bn, CIN, (int)(N / g.sps));
-    if (rc != PF_OK) return rc;
-    return launch_wide_mode<KS, STRIDE, CIN, COUT, 2>(x, wp, y, g, N, nullptr, nullptr, partials, *in_bn, s);
+    for (int k = 0; k < g.sets; ++k) {
+      const int rc = pf_bn_in_check(in_bn + k, CIN, g.spset / g.sps);
+      if (rc != PF_OK) return rc;
+    }
+    return launch_wide_mode<KS, STRIDE, CIN, COUT, 2>(x, wp, y, g, N, nullptr, nullptr, partials, in_bn[0],
+                                                      in_bn[g.sets - 1], s);
   }
   pf_bn_job none = {};
   if (in_scale != nullptr)
-    return launch_wide_mode<KS, STRIDE, CIN, COUT, 1>(x, wp, y, g, N, in_scale, in_shift, partials, none, s);
-  return launch_wide_mode<KS, STRIDE, CIN, COUT, 0>(x, wp, y, g, N, nullptr, nullptr, partials, none, s);
+    return launch_wide_mode<KS, STRIDE, CIN, COUT, 1>(x, wp, y, g, N, in_scale, in_shift, partials, none, none, s);
+  return launch_wide_mode<KS, STRIDE, CIN, COUT, 0>(x, wp, y, g, N, nullptr, nullptr, partials, none, none, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -351,7 +368,8 @@ __global__ __launch_bounds__(256) void conv2d_wide16_kernel(const float* __restr
                                                             float* __restrict__ y, WideGeom g,
                                                             const float* __restrict__ in_scale,
                                                             const float* __restrict__ in_shift,
-                                                            double* __restrict__ partials, pf_bn_job in_bn) {
+                                                            double* __restrict__ partials, pf_bn_job in_bn,
+                                                            pf_bn_job in_bn1) {
   using C = Wide16Cfg<KS, STRIDE, CIN, COUT>;
   constexpr int PW = C::PW, RS = C::RS, NPIX = C::NPIX, CPL = C::CPL, NCOL = 16;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -365,7 +383,9 @@ __global__ __launch_bounds__(256) void conv2d_wide16_kernel(const float* __restr
   const int li = lane & 15, kq = lane >> 4;
   const int n = blockIdx.y;
   const int plane_i = g.Hi * g.Wi;
-  const float* xb = x + (int64_t)n * CIN * plane_i;
+  const int set = wide_set(g, n);
+  const float* xb = x + (int64_t)(g.shared_x ? n - set * g.spset : n) * CIN * plane_i;
+  wp += set * g.w_stride;
   const int tiles = g.tiles_h * g.tiles_w;
   const int nb = gridDim.x;
 
@@ -392,7 +412,8 @@ __global__ __launch_bounds__(256) void conv2d_wide16_kernel(const float* __restr
     tile_origin(tile, oh0, ow0);
     st.load(xb, plane_i, oh0 * STRIDE - C::PAD, ow0 * STRIDE - C::PAD, g.Hi, g.Wi);
   }
-  wide_affine_prologue<CIN, AFFINE>(aff, in_scale, in_shift, n / g.sps, in_bn, reinterpret_cast<double*>(wl));
+  wide_affine_prologue<CIN, AFFINE>(aff, in_scale, in_shift, AFFINE == 2 ? (n - set * g.spset) / g.sps : n / g.sps,
+                                    set ? in_bn1 : in_bn, reinterpret_cast<double*>(wl));
 #pragma unroll
   for (int r = 0; r < NWR; ++r) {
     const int e = tid + 256 * r;
@@ -528,7 +549,8 @@ int wide16_blocks(int tiles) { return (tiles + 1) / 2; }
 
 template <int KS, int STRIDE, int CIN, int COUT, int AFFINE>
 int launch_wide16_mode(const float* x, const float* wp, float* y, WideGeom g, int64_t N, const float* in_scale,
-                       const float* in_shift, double* partials, const pf_bn_job& in_bn, hipStream_t s) {
+                       const float* in_shift, double* partials, const pf_bn_job& in_bn, const pf_bn_job& in_bn1,
+                       hipStream_t s) {
   using C = Wide16Cfg<KS, STRIDE, CIN, COUT>;
   if (C::LDS > 64 * 1024) {
     static std::atomic<unsigned long long> done{0};
@@ -540,7 +562,7 @@ int launch_wide16_mode(const float* x, const float* wp, float* y, WideGeom g, in
   g.tiles_h = (g.Ho + C::TH - 1) / C::TH;
   dim3 grid((unsigned)wide16_blocks(g.tiles_h * g.tiles_w), (unsigned)N);
   hipLaunchKernelGGL((conv2d_wide16_kernel<KS, STRIDE, CIN, COUT, AFFINE>), grid, dim3(256), C::LDS, s, x, wp, y, g,
-                     in_scale, in_shift, partials, in_bn);
+                     in_scale, in_shift, partials, in_bn, in_bn1);
   return pf_launch_status();
 }
 
@@ -550,16 +572,19 @@ int launch_wide16(const float* x, const float* wp, float* y, WideGeom g, int64_t
   pf_bn_job none = {};
   if constexpr (CIN % 4 == 0) {
     if (in_bn != nullptr) {
-      const int rc = pf_bn_in_check(in_bn, CIN, (int)(N / g.sps));
-      if (rc != PF_OK) return rc;
-      return launch_wide16_mode<KS, STRIDE, CIN, COUT, 2>(x, wp, y, g, N, nullptr, nullptr, partials, *in_bn, s);
+      for (int k = 0; k < g.sets; ++k) {
+        const int rc = pf_bn_in_check(in_bn + k, CIN, g.spset / g.sps);
+        if (rc != PF_OK) return rc;
+      }
+      return launch_wide16_mode<KS, STRIDE, CIN, COUT, 2>(x, wp, y, g, N, nullptr, nullptr, partials, in_bn[0],
+                                                          in_bn[g.sets - 1], s);
     }
     if (in_scale != nullptr)
-      return launch_wide16_mode<KS, STRIDE, CIN, COUT, 1>(x, wp, y, g, N, in_scale, in_shift, partials, none, s);
+      return launch_wide16_mode<KS, STRIDE, CIN, COUT, 1>(x, wp, y, g, N, in_scale, in_shift, partials, none, none, s);
   } else {
     if (in_bn != nullptr || in_scale != nullptr) return PF_ERR_UNSUPPORTED;   // (the image layer has no pending BatchNorm)
   }
-  return launch_wide16_mode<KS, STRIDE, CIN, COUT, 0>(x, wp, y, g, N, nullptr, nullptr, partials, none, s);
+  return launch_wide16_mode<KS, STRIDE, CIN, COUT, 0>(x, wp, y, g, N, nullptr, nullptr, partials, none, none, s);
 }
 
 int wide_tile_rows(int64_t Cout) { return Cout == 64 ? 4 : (Cout == 32 ? 8 : 16); }   // 8 and 16 channels: 16 x 16 tiles
@@ -588,10 +613,20 @@ int pf_conv2d_wide_f32(const float* x, const float* wp, float* y, int64_t N, int
                        int64_t Wi, int kernel_size, int stride, const float* in_scale, const float* in_shift,
                        const pf_bn_job* in_bn, int samples_per_stat, double* partials, int out_channel_last,
                        void* stream) {
+  return pf_conv2d_wide_sets_f32(x, 0, wp, 0, 1, y, N, Cin, Cout, Hi, Wi, kernel_size, stride, in_scale, in_shift, in_bn,
+                                 samples_per_stat, partials, out_channel_last ? 1 : 0, stream);
+}
+
+int pf_conv2d_wide_sets_f32(const float* x, int shared_input, const float* wp, int64_t wp_set_stride, int sets, float* y,
+                            int64_t N, int64_t Cin, int64_t Cout, int64_t Hi, int64_t Wi, int kernel_size, int stride,
+                            const float* in_scale, const float* in_shift, const pf_bn_job* in_bn, int samples_per_stat,
+                            double* partials, int out_channel_last, void* stream) {
   PF_REQUIRE(N >= 0 && Cin >= 1 && Cout >= 1 && Hi >= 1 && Wi >= 1 && N <= 65535 && samples_per_stat >= 1);
+  PF_REQUIRE((sets == 1 || sets == 2) && N % sets == 0 && wp_set_stride >= 0 && (wp_set_stride & 3) == 0);
+  PF_REQUIRE(out_channel_last >= 0 && out_channel_last < (1 << sets));
   if (out_channel_last && Cout < 32) return PF_ERR_UNSUPPORTED;     // (built for the 32x32x2 kernels only)
   PF_REQUIRE((in_scale == nullptr) == (in_shift == nullptr) && (in_bn == nullptr || in_scale == nullptr));
-  PF_REQUIRE(N % samples_per_stat == 0 || in_bn == nullptr);
+  PF_REQUIRE((N / sets) % samples_per_stat == 0 || (in_bn == nullptr && sets == 1));
   if (!pf_conv2d_wide_supported(Cin, Cout, kernel_size, stride)) return PF_ERR_UNSUPPORTED;
   PF_REQUIRE(Cin * Hi * Wi <= INT32_MAX);
   if (N == 0) return PF_OK;
@@ -603,7 +638,11 @@ int pf_conv2d_wide_f32(const float* x, const float* wp, float* y, int64_t N, int
   g.Wo = (int)((Wi - 1) / stride + 1);
   g.tiles_w = g.tiles_h = 0;
   g.sps = samples_per_stat;
-  g.cl_out = out_channel_last ? 1 : 0;
+  g.cl_out = out_channel_last;
+  g.sets = sets;
+  g.spset = (int)(N / sets);
+  g.shared_x = (shared_input && sets > 1) ? 1 : 0;
+  g.w_stride = wp_set_stride;
   hipStream_t s = (hipStream_t)stream;
   if (Cout == 8) {
     if (Cin == 3) return launch_wide16<3, 1, 3, 8>(x, wp, y, g, N, in_scale, in_shift, partials, in_bn, s);

@@ -26,7 +26,8 @@ import torch.nn.functional as F
 
 from . import pointflow
 from .functions.functions import get_pixel_grids, get_propability_map
-from .networks import EdgeConv, EdgeConvNoC, ImageConv, VolumeConv, MAELoss, Valid_MAELoss
+from .networks import (EdgeConv, EdgeConvNoC, ImageConv, VolumeConv, MAELoss, Valid_MAELoss, tower_pair_supported,
+                       tower_pair_views)
 from .nn.mlp import SharedMLP
 from .utils.feature_fetcher import ChannelLast, FeatureFetcher, frustum_variance
 from .utils.torch_utils import get_knn_3d
@@ -379,6 +380,13 @@ class PointMVSNet(nn.Module):
         dev = img_list.device
         main = torch.cuda.current_stream()
         pointflow.stamp("start")
+        if isFlow and pointflow.CONCURRENCY < 1 and tower_pair_supported(self.coarse_img_conv, self.flow_img_conv,
+                                                                         img_list):
+            # a single chain (one lane of graph.LanedForward): the two towers share their eleven launches
+            coarse_cl, pyramids = tower_pair_views(self.coarse_img_conv, self.flow_img_conv, img_list)
+            pointflow.stamp("coarse_tower_end")
+            preds = self.run_coarse_stage(plan, ChannelLast(coarse_cl))
+            return self.run_flows(plan, pyramids, preds)
         feature_list = self.run_coarse_tower(img_list)
         pointflow.stamp("coarse_tower_end")
         if not isFlow:

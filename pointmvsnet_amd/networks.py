@@ -273,6 +273,51 @@ class ImageConv(nn.Module):
         return out
 
 
+def tower_pair_supported(coarse, flow, img_list):
+    """Both towers on the shared launches of ``tower_pair_views``: one scene, identical towers whose every layer is
+    a tower-kernel shape, train-mode BatchNorm everywhere (the reference's test mode, test.py:58)."""
+    if img_list.shape[0] != 1 or coarse.base_channels != flow.base_channels or coarse.out_channels < 32:
+        return False
+    for tower in (coarse, flow):
+        for name in ("conv0", "conv1", "conv2", "conv3"):
+            for blk in getattr(tower, name):
+                conv, bn = (blk.conv, blk.bn) if hasattr(blk, "bn") else (blk, None)
+                if not pointflow.conv2d_wide_preferred(conv):
+                    return False
+                if bn is not None and not (blk.relu and (bn.training or not bn.track_running_stats)):
+                    return False
+    return True
+
+
+def tower_pair_views(coarse, flow, img_list):
+    """The coarse and the flow tower of one scene (1,V,3,H,W) side by side: every one of the eleven layers is ONE
+    pf_conv2d_wide_sets_f32 launch over 2 V samples (set 0 = coarse tower, set 1 = flow tower; weights, pending
+    BatchNorm and output layout per set) -- half the launches and twice the blocks per launch on the small maps
+    (240 -> 480 on 64 x 80).  Per sample the arithmetic is ``forward_views``': bit-identical results.  Returns what
+    the fused forward consumes: (coarse "conv3" channel-last (1,V,h,w,C), {"conv1","conv2","conv3"} of the flow
+    tower as pointflow.RawLevel)."""
+    V = img_list.shape[1]
+    x = img_list[0].float().contiguous()                   # (V,3,H,W): the towers' first layer shares its input
+    blocks = [(name, cb, fb) for name in ("conv0", "conv1", "conv2", "conv3")
+              for cb, fb in zip(getattr(coarse, name), getattr(flow, name))]
+    pending = None
+    levels = {}
+    for i, (name, cb, fb) in enumerate(blocks):
+        last = i + 1 == len(blocks)
+        stage_end = last or blocks[i + 1][0] != name
+        has_bn = hasattr(cb, "bn")
+        convs = [cb.conv, fb.conv] if has_bn else [cb, fb]
+        y, partials = pointflow.conv2d_wide_sets(x, convs, pending, 1, has_bn, shared_input=(i == 0),
+                                                 channel_last_sets=(0,) if last else ())
+        raw_level = stage_end and name != "conv0"          # the flow tower's pyramid level: its rows are needed now
+        pending = pointflow.bn_affine_rows_sets(y, [cb.bn, fb.bn], 1, partials, lazy=not raw_level) if has_bn else None
+        if raw_level:
+            levels[name] = pointflow.RawLevel(y[V:], None if pending is None else pending.rows_of(1))
+        x = y
+    C = x.shape[1]
+    return x[:V].view(1, V, x.shape[2], x.shape[3], C), levels
+
+
 def _conv2d_block_fused(block, x, pending, samples_per_stat, defer, lazy=False, channel_last_out=False):
     """One tower block.  ``pending``: BN+ReLU affine rows not yet applied to x.  Returns (y, pending'): with
     ``defer`` the block's own BatchNorm+ReLU is returned as affine rows for the next (custom) conv to apply

@@ -591,6 +591,95 @@ def conv2d_wide(x, conv, in_affine, samples_per_stat, want_stats, channel_last_o
     return y, partials
 
 
+class AffineSets(object):
+    """The pending BatchNorm(+ReLU)s of a launch over parameter sets (the model's two towers side by side): joint
+    (sets * G, C) scale / shift rows -- set s owns rows [s G, (s + 1) G) -- and, while nobody has asked for the rows,
+    one LazyAffine per set whose consumer resolves it (pf_conv2d_wide_sets_f32's ``in_bn`` array)."""
+
+    def __init__(self, scale, shift, lazies=None):
+        self.scale, self.shift, self.lazies = scale, shift, lazies
+
+    def split(self):
+        """(scale, shift, in_bn array) for the consuming launch."""
+        if self.lazies is not None and not any(l.done for l in self.lazies):
+            for l in self.lazies:
+                l.job_ptr()                     # (queues the deferred finalize: running statistics, rows)
+            return None, None, (_lib.BnJob * len(self.lazies))(*[l.job for l in self.lazies])
+        self.rows()
+        return self.scale, self.shift, None
+
+    def rows(self):
+        if self.lazies is not None:
+            todo = [l for l in self.lazies if not l.done]
+            if todo:
+                bn_finalize_jobs([l.job for l in todo])
+                for l in todo:
+                    l.done = True
+        return self.scale, self.shift
+
+    def rows_of(self, s):
+        sc, sh = self.rows()
+        G = sc.shape[0] // (len(self.lazies) if self.lazies is not None else 2)
+        return sc[s * G:(s + 1) * G], sh[s * G:(s + 1) * G]
+
+
+def pack_conv2d_wide_weight_sets(weights):
+    """The packed weights of ``pack_conv2d_wide_weight`` for several same-shaped convolutions, stacked (sets, ...)."""
+    def make():
+        return torch.stack([pack_conv2d_wide_weight(w) for w in weights]).contiguous()
+    return _cached_pack(("c2ws",) + tuple(id(w) for w in weights), tuple(weights), make)
+
+
+def conv2d_wide_sets(x, convs, in_affine, samples_per_stat, want_stats, shared_input=False, channel_last_sets=()):
+    """pf_conv2d_wide_sets_f32: ONE launch for the same layer of several towers.  x: (sets * n, Cin, H, W) -- set s owns
+    samples [s n, (s + 1) n) -- or (n, Cin, H, W) with ``shared_input``; ``in_affine``: None or an AffineSets;
+    ``channel_last_sets``: the sets whose samples are written (Ho, Wo, Cout).  Returns (y (sets * n, ...), partials)."""
+    sets = len(convs)
+    conv = convs[0]
+    Cin, Hi, Wi = x.shape[1:]
+    N = x.shape[0] * (sets if shared_input else 1)
+    Cout = conv.out_channels
+    ks, stride = conv.kernel_size[0], conv.stride[0]
+    Ho, Wo = (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
+    wp = pack_conv2d_wide_weight_sets([c.weight for c in convs])
+    y = torch.empty((N, Cout, Ho, Wo), dtype=_F32, device=x.device)
+    partials = None
+    if want_stats:
+        T = int(_lib.load().pf_conv2d_wide_blocks(Cout, Hi, Wi, int(stride)))
+        partials = stat_rows(N, T, Cout, x.device)
+    sc, sh, in_bn = (None, None, None) if in_affine is None else in_affine.split()
+    mask = sum(1 << s for s in channel_last_sets)
+    _lib.call("pf_conv2d_wide_sets_f32", _lib.ptr(x), int(bool(shared_input)), _lib.ptr(wp), int(wp[0].numel()), sets,
+              _lib.ptr(y), N, Cin, Cout, Hi, Wi, int(ks), int(stride), _lib.ptr(sc), _lib.ptr(sh), in_bn,
+              int(samples_per_stat), _lib.ptr(partials), int(mask), _lib.stream(),
+              algo_bytes=4.0 * (x.numel() + N * Cout * Ho * Wo) + 4.0 * sets * ks * ks * Cin * Cout,
+              flops=2.0 * N * Ho * Wo * ks * ks * Cin * Cout)
+    return y, partials
+
+
+def bn_affine_rows_sets(y, bns, samples_per_stat, partials, lazy):
+    """``bn_affine_rows`` for the raw output y (sets * n, C, h, w) of a conv2d_wide_sets launch in train mode: one job per
+    set over its own slice of the statistics rows, joint (sets * G, C) affine rows.  Returns an AffineSets."""
+    sets = len(bns)
+    N, C = y.shape[:2]
+    S = y[0, 0].numel()
+    n = N // sets
+    G = n // samples_per_stat
+    scale = torch.empty((sets * G, C), dtype=_F32, device=y.device)
+    shift = torch.empty((sets * G, C), dtype=_F32, device=y.device)
+    cnt = float(samples_per_stat) * S
+    jobs = []
+    for s, bn in enumerate(bns):
+        jobs.append(bn_job(bn, partials[s * n:(s + 1) * n], 0, C, cnt, cnt, n, samples_per_stat,
+                           scale[s * G:(s + 1) * G], shift[s * G:(s + 1) * G]))
+        bump_counter(bn, G)
+    if lazy and LAZY_BN and samples_per_stat * partials.shape[1] * C <= LAZY_MAX_ELEMS:
+        lazies = [LazyAffine(j, (partials, scale, shift) + _bn_tensors(bn), scale, shift) for j, bn in zip(jobs, bns)]
+        return AffineSets(scale, shift, lazies)
+    bn_finalize_jobs(jobs)
+    return AffineSets(scale, shift)
+
+
 def channel_affine_(x, affine, relu, samples_per_stat):
     """In place y = act(x*scale + shift) with (N/sps, C) affine rows."""
     affine = affine_rows(affine)

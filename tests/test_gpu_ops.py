@@ -799,6 +799,43 @@ def test_image_conv_tower_vs_oracle(dev):
             assert torch.allclose(state[key[2:]].cpu(), val, rtol=1e-4, atol=1e-5), key
 
 
+@pytest.mark.parametrize("hw", [(128, 160), (72, 104)])
+def test_tower_pair_launches_equal_the_two_towers_bit_for_bit(dev, hw):
+    """pf_conv2d_wide_sets_f32 (both towers in each of the eleven launches: weights, pending BatchNorm and output
+    layout per set) against the same towers run one after the other: every output the fused forward consumes, the
+    pending affine rows of the pyramid levels, and all running statistics -- bit for bit."""
+    import copy
+    from pointmvsnet_amd.networks import ImageConv, tower_pair_supported, tower_pair_views
+    gen = torch.Generator().manual_seed(5)
+    imgs = torch.randn(1, 3, 3, hw[0], hw[1], generator=gen).to(dev)
+    coarse, flow = ImageConv(8), ImageConv(8)
+    synthetic.seed_weights(coarse, 1)
+    synthetic.seed_weights(flow, 2)
+    coarse, flow = coarse.to(dev).train(), flow.to(dev).train()
+    coarse2, flow2 = copy.deepcopy(coarse), copy.deepcopy(flow)
+    assert tower_pair_supported(coarse, flow, imgs)
+    with torch.no_grad():
+        want_c = coarse.forward_views(imgs, need=("conv3",), channel_last=("conv3",))["conv3_cl"]
+        want_f = flow.forward_views(imgs, raw=("conv1", "conv2", "conv3"))
+        pointflow.flush_counters()
+        got_c, got_f = tower_pair_views(coarse2, flow2, imgs)
+        pointflow.flush_counters()
+    torch.cuda.synchronize()
+    assert got_c.shape == want_c.shape and torch.equal(got_c, want_c)
+    for name in ("conv1", "conv2", "conv3"):
+        w, g = want_f[name + "_raw"], got_f[name]
+        assert torch.equal(g.raw, w.raw), name
+        if w.affine is None:
+            assert g.affine is None
+        else:
+            for a, b in zip(pointflow.affine_rows(g.affine), pointflow.affine_rows(w.affine)):
+                assert torch.equal(a, b), name
+    for ref, new in ((coarse, coarse2), (flow, flow2)):
+        for (k, a), (_, b) in zip(ref.state_dict().items(), new.state_dict().items()):
+            assert torch.equal(a, b), k
+    assert int(coarse2.conv1[0].bn.num_batches_tracked) == 3 and _lib.status() == 0
+
+
 # ---------------------------------------------------------------------------------------------
 # lattice kNN: sorting-network kernel, window codes as the neighbourhood of the EdgeConv passes
 # ---------------------------------------------------------------------------------------------
