@@ -370,7 +370,7 @@ int pf_deconv3d_bottom_f32(const float* x, const float* wp, float* y, int64_t N,
 
 /* ---- ImageConv: conv2d on the f32 matrix cores ------------------------
  * Replaces the nn.Conv2d of the Conv2d blocks of reference networks.py:89-110 (nn/conv.py:62-77) for the tower's
- * shapes: 3x3 / stride 1 / pad 1 (3->8, 8->8, 16->16, 32->32, 64->64) and 5x5 / stride 2 / pad 2 (8->16, 16->32,
+ * shapes: 3x3 / stride 1 / pad 1 (3->8, 3->16, 8->8, 16->16, 32->32, 64->64) and 5x5 / stride 2 / pad 2 (8->16, 16->32,
  * 32->64), bias-free (csrc/conv2d_wide.hip).  x (N,Cin,Hi,Wi) NCHW holds the RAW output of the previous conv when
  * in_scale / in_shift (N/sps, Cin) or in_bn (see "the finalize folded into the consumer" above) are given:
  * relu(x*scale+shift) -- the previous block's BatchNorm+ReLU -- is applied while staging, so that activation is
@@ -393,11 +393,14 @@ int pf_conv2d_wide_f32(const float* x, const float* wp, float* y, int64_t N, int
  * model.py:140-148) have identical shapes and run on the same images, so each of their eleven layers is ONE launch:
  * samples [s*N/sets, (s+1)*N/sets) convolve with the packed weights at wp + s*wp_set_stride (floats, a multiple
  * of 4) and take their pending BatchNorm from in_bn[s] (an array of `sets` jobs; the (in_scale, in_shift) rows are
- * indexed by the global statistic group n / samples_per_stat as before).  shared_input != 0: x holds N/sets
- * samples that every set reads (the towers' first layer reads the same views).  Bit s of out_channel_last selects
+ * indexed by the global statistic group n / samples_per_stat as before).  x_layout says where sample
+ * n = s*N/sets + i reads its input: 0 = sample n of x (N samples); 1 = sample i (x holds N/sets samples that
+ * every set reads); 2 = sample i*sets + s (x is (N/sets, sets, Cin, Hi, Wi): what ONE convolution with the sets'
+ * output channels stacked wrote -- the towers' first layer, 3 -> 8 + 8 on the same views, is a single
+ * pf_conv2d_wide_f32 call with Cout = 16 and fills every column of the matrix tile).  Bit s of out_channel_last selects
  * the (Ho, Wo, Cout) layout for the samples of set s (each sample's region of y has the same size either way).
  * Per sample the arithmetic is that of pf_conv2d_wide_f32: results are bit-identical to `sets` separate calls. */
-int pf_conv2d_wide_sets_f32(const float* x, int shared_input, const float* wp, int64_t wp_set_stride, int sets, float* y,
+int pf_conv2d_wide_sets_f32(const float* x, int x_layout, const float* wp, int64_t wp_set_stride, int sets, float* y,
                             int64_t N, int64_t Cin, int64_t Cout, int64_t Hi, int64_t Wi, int kernel_size, int stride,
                             const float* in_scale, const float* in_shift, const pf_bn_job* in_bn, int samples_per_stat,
                             double* partials, int out_channel_last, void* stream);

@@ -40,13 +40,19 @@ struct WideGeom {
   int cl_out;      // bit s: parameter set s writes y as (Ho, Wo, C_out) per sample instead of (C_out, Ho, Wo)
   // Parameter sets (pf_conv2d_wide_sets_f32: the two towers of the model in ONE launch): samples
   // [s * spset, (s + 1) * spset) convolve with the weights at wp + s * w_stride and normalise their input with the
-  // s-th pending BatchNorm; shared_x: every set reads the SAME spset input samples (the towers' first layer)
-  int sets, spset, shared_x;
+  // s-th pending BatchNorm.  x_mode: where sample n = s * spset + i reads its input -- 0: sample n; 1: sample i
+  // (every set reads the SAME spset samples); 2: sample i * sets + s (set-interleaved: x is (spset, sets, C_in, H, W),
+  // what ONE convolution with the sets' stacked output channels wrote)
+  int sets, spset, x_mode;
   int64_t w_stride;
 };
 
-// which parameter set sample n belongs to (block-uniform)
+// which parameter set sample n belongs to (block-uniform), and which input sample it reads
 __device__ __forceinline__ int wide_set(const WideGeom& g, int n) { return (g.sets > 1 && n >= g.spset) ? 1 : 0; }
+__device__ __forceinline__ int wide_input_sample(const WideGeom& g, int n, int set) {
+  const int i = n - set * g.spset;
+  return g.x_mode == 0 ? n : (g.x_mode == 1 ? i : i * g.sets + set);
+}
 
 template <int KS, int STRIDE, int CIN, int COUT>
 struct WideCfg {
@@ -259,7 +265,7 @@ __global__ __launch_bounds__(256) void conv2d_wide_kernel(const float* __restric
   const int ih0 = oh0 * STRIDE - C::PAD, iw0 = ow0 * STRIDE - C::PAD;
   const int plane_i = g.Hi * g.Wi;
   const int set = wide_set(g, n);
-  const float* xb = x + (int64_t)(g.shared_x ? n - set * g.spset : n) * CIN * plane_i;
+  const float* xb = x + (int64_t)wide_input_sample(g, n, set) * CIN * plane_i;
 
   constexpr int NP = KS * KS * C::KC;                  // 16-byte operand pairs of the tile
   constexpr int D = 6;                                 // B pieces in flight per lane
@@ -384,7 +390,7 @@ __global__ __launch_bounds__(256) void conv2d_wide16_kernel(const float* __restr
   const int n = blockIdx.y;
   const int plane_i = g.Hi * g.Wi;
   const int set = wide_set(g, n);
-  const float* xb = x + (int64_t)(g.shared_x ? n - set * g.spset : n) * CIN * plane_i;
+  const float* xb = x + (int64_t)wide_input_sample(g, n, set) * CIN * plane_i;
   wp += set * g.w_stride;
   const int tiles = g.tiles_h * g.tiles_w;
   const int nb = gridDim.x;
@@ -596,7 +602,7 @@ extern "C" {
 int pf_conv2d_wide_supported(int64_t Cin, int64_t Cout, int kernel_size, int stride) {
   if (kernel_size == 3 && stride == 1)
     return (Cin == 64 && Cout == 64) || (Cin == 32 && Cout == 32) || (Cin == 16 && Cout == 16) || (Cin == 8 && Cout == 8) ||
-           (Cin == 3 && Cout == 8);
+           (Cin == 3 && (Cout == 8 || Cout == 16));
   if (kernel_size == 5 && stride == 2) return (Cin == 32 && Cout == 64) || (Cin == 16 && Cout == 32) || (Cin == 8 && Cout == 16);
   return 0;
 }
@@ -617,13 +623,13 @@ int pf_conv2d_wide_f32(const float* x, const float* wp, float* y, int64_t N, int
                                  samples_per_stat, partials, out_channel_last ? 1 : 0, stream);
 }
 
-int pf_conv2d_wide_sets_f32(const float* x, int shared_input, const float* wp, int64_t wp_set_stride, int sets, float* y,
+int pf_conv2d_wide_sets_f32(const float* x, int x_layout, const float* wp, int64_t wp_set_stride, int sets, float* y,
                             int64_t N, int64_t Cin, int64_t Cout, int64_t Hi, int64_t Wi, int kernel_size, int stride,
                             const float* in_scale, const float* in_shift, const pf_bn_job* in_bn, int samples_per_stat,
                             double* partials, int out_channel_last, void* stream) {
   PF_REQUIRE(N >= 0 && Cin >= 1 && Cout >= 1 && Hi >= 1 && Wi >= 1 && N <= 65535 && samples_per_stat >= 1);
   PF_REQUIRE((sets == 1 || sets == 2) && N % sets == 0 && wp_set_stride >= 0 && (wp_set_stride & 3) == 0);
-  PF_REQUIRE(out_channel_last >= 0 && out_channel_last < (1 << sets));
+  PF_REQUIRE(out_channel_last >= 0 && out_channel_last < (1 << sets) && x_layout >= 0 && x_layout <= 2);
   if (out_channel_last && Cout < 32) return PF_ERR_UNSUPPORTED;     // (built for the 32x32x2 kernels only)
   PF_REQUIRE((in_scale == nullptr) == (in_shift == nullptr) && (in_bn == nullptr || in_scale == nullptr));
   PF_REQUIRE((N / sets) % samples_per_stat == 0 || (in_bn == nullptr && sets == 1));
@@ -641,7 +647,7 @@ int pf_conv2d_wide_sets_f32(const float* x, int shared_input, const float* wp, i
   g.cl_out = out_channel_last;
   g.sets = sets;
   g.spset = (int)(N / sets);
-  g.shared_x = (shared_input && sets > 1) ? 1 : 0;
+  g.x_mode = sets > 1 ? x_layout : 0;
   g.w_stride = wp_set_stride;
   hipStream_t s = (hipStream_t)stream;
   if (Cout == 8) {
@@ -649,6 +655,7 @@ int pf_conv2d_wide_sets_f32(const float* x, int shared_input, const float* wp, i
     return launch_wide16<3, 1, 8, 8>(x, wp, y, g, N, in_scale, in_shift, partials, in_bn, s);
   }
   if (Cout == 16) {
+    if (Cin == 3) return launch_wide16<3, 1, 3, 16>(x, wp, y, g, N, in_scale, in_shift, partials, in_bn, s);
     if (kernel_size == 3) return launch_wide16<3, 1, 16, 16>(x, wp, y, g, N, in_scale, in_shift, partials, in_bn, s);
     return launch_wide16<5, 2, 8, 16>(x, wp, y, g, N, in_scale, in_shift, partials, in_bn, s);
   }

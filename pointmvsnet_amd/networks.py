@@ -278,6 +278,8 @@ def tower_pair_supported(coarse, flow, img_list):
     a tower-kernel shape, train-mode BatchNorm everywhere (the reference's test mode, test.py:58)."""
     if img_list.shape[0] != 1 or coarse.base_channels != flow.base_channels or coarse.out_channels < 32:
         return False
+    if not pointflow.conv2d_wide_stacked_supported([coarse.conv0[0].conv, flow.conv0[0].conv]):
+        return False
     for tower in (coarse, flow):
         for name in ("conv0", "conv1", "conv2", "conv3"):
             for blk in getattr(tower, name):
@@ -291,9 +293,9 @@ def tower_pair_supported(coarse, flow, img_list):
 
 def tower_pair_views(coarse, flow, img_list):
     """The coarse and the flow tower of one scene (1,V,3,H,W) side by side: every one of the eleven layers is ONE
-    pf_conv2d_wide_sets_f32 launch over 2 V samples (set 0 = coarse tower, set 1 = flow tower; weights, pending
-    BatchNorm and output layout per set) -- half the launches and twice the blocks per launch on the small maps
-    (240 -> 480 on 64 x 80).  Per sample the arithmetic is ``forward_views``': bit-identical results.  Returns what
+    launch -- the first a single 3 -> 8 + 8 convolution of the shared views, the others pf_conv2d_wide_sets_f32
+    over 2 V samples (set 0 = coarse tower, set 1 = flow tower; weights, pending BatchNorm and output layout per
+    set) -- half the launches and twice the blocks per launch on the small maps (240 -> 480 on 64 x 80).  Per sample the arithmetic is ``forward_views``': bit-identical results.  Returns what
     the fused forward consumes: (coarse "conv3" channel-last (1,V,h,w,C), {"conv1","conv2","conv3"} of the flow
     tower as pointflow.RawLevel)."""
     V = img_list.shape[1]
@@ -307,10 +309,14 @@ def tower_pair_views(coarse, flow, img_list):
         stage_end = last or blocks[i + 1][0] != name
         has_bn = hasattr(cb, "bn")
         convs = [cb.conv, fb.conv] if has_bn else [cb, fb]
-        y, partials = pointflow.conv2d_wide_sets(x, convs, pending, 1, has_bn, shared_input=(i == 0),
-                                                 channel_last_sets=(0,) if last else ())
+        if i == 0:       # same input: ONE 3 -> 8 + 8 convolution; its output is read set-interleaved by the next layer
+            y, partials = pointflow.conv2d_wide_stacked(x, convs, has_bn)
+        else:
+            y, partials = pointflow.conv2d_wide_sets(x, convs, pending, 1, has_bn, interleaved=(i == 1),
+                                                     channel_last_sets=(0,) if last else ())
         raw_level = stage_end and name != "conv0"          # the flow tower's pyramid level: its rows are needed now
-        pending = pointflow.bn_affine_rows_sets(y, [cb.bn, fb.bn], 1, partials, lazy=not raw_level) if has_bn else None
+        pending = pointflow.bn_affine_rows_sets(y, [cb.bn, fb.bn], 1, partials, lazy=not raw_level,
+                                                interleaved=(i == 0)) if has_bn else None
         if raw_level:
             levels[name] = pointflow.RawLevel(y[V:], None if pending is None else pending.rows_of(1))
         x = y

@@ -541,7 +541,8 @@ def conv2d_supported(conv):
 
 
 def conv2d_wide_supported(conv):
-    """Shapes pf_conv2d_wide_f32 is built for: 3x3/1 3->8, 8->8, 16->16, 32->32, 64->64; 5x5/2 8->16, 16->32, 32->64."""
+    """Shapes pf_conv2d_wide_f32 is built for: 3x3/1 3->8, 3->16 (two towers' first layers stacked), 8->8, 16->16,
+    32->32, 64->64; 5x5/2 8->16, 16->32, 32->64."""
     return conv2d_supported(conv) and bool(_lib.load().pf_conv2d_wide_supported(
         conv.in_channels, conv.out_channels, int(conv.kernel_size[0]), int(conv.stride[0])))
 
@@ -630,14 +631,46 @@ def pack_conv2d_wide_weight_sets(weights):
     return _cached_pack(("c2ws",) + tuple(id(w) for w in weights), tuple(weights), make)
 
 
-def conv2d_wide_sets(x, convs, in_affine, samples_per_stat, want_stats, shared_input=False, channel_last_sets=()):
+def conv2d_wide_stacked_supported(convs):
+    c = convs[0]
+    return all(conv2d_supported(k) for k in convs) and bool(_lib.load().pf_conv2d_wide_supported(
+        c.in_channels, sum(k.out_channels for k in convs), int(c.kernel_size[0]), int(c.stride[0])))
+
+
+def conv2d_wide_stacked(x, convs, want_stats):
+    """The towers' FIRST layer: same input, so the sets' output channels are stacked into one convolution (3 -> 8 + 8
+    fills all 16 columns of the matrix tile).  Returns y (n, sets * Cout, Ho, Wo) -- sample-major, set-interleaved:
+    the ``interleaved`` input layout of conv2d_wide_sets -- and the statistics partials (n, T, sets * Cout, 2)."""
+    N, Cin, Hi, Wi = x.shape
+    Cout = sum(c.out_channels for c in convs)
+    ks, stride = convs[0].kernel_size[0], convs[0].stride[0]
+    Ho, Wo = (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
+    weights = tuple(c.weight for c in convs)
+    wp = _cached_pack(("c2wst",) + tuple(id(w) for w in weights), weights,
+                      lambda: pack_conv2d_wide_weight(torch.cat([w.detach() for w in weights], dim=0)))
+    y = torch.empty((N, Cout, Ho, Wo), dtype=_F32, device=x.device)
+    partials = None
+    if want_stats:
+        T = int(_lib.load().pf_conv2d_wide_blocks(Cout, Hi, Wi, int(stride)))
+        partials = stat_rows(N, T, Cout, x.device)
+    _lib.call("pf_conv2d_wide_f32", _lib.ptr(x), _lib.ptr(wp), _lib.ptr(y), N, Cin, Cout, Hi, Wi, int(ks), int(stride),
+              None, None, None, 1, _lib.ptr(partials), 0, _lib.stream(),
+              algo_bytes=4.0 * N * (Cin * Hi * Wi + Cout * Ho * Wo) + 4.0 * ks * ks * Cin * Cout,
+              flops=2.0 * N * Ho * Wo * ks * ks * Cin * Cout)
+    return y, partials
+
+
+def conv2d_wide_sets(x, convs, in_affine, samples_per_stat, want_stats, interleaved=False, channel_last_sets=()):
     """pf_conv2d_wide_sets_f32: ONE launch for the same layer of several towers.  x: (sets * n, Cin, H, W) -- set s owns
-    samples [s n, (s + 1) n) -- or (n, Cin, H, W) with ``shared_input``; ``in_affine``: None or an AffineSets;
-    ``channel_last_sets``: the sets whose samples are written (Ho, Wo, Cout).  Returns (y (sets * n, ...), partials)."""
+    samples [s n, (s + 1) n) -- or, ``interleaved``, (n, sets * Cin, H, W) as conv2d_wide_stacked wrote it;
+    ``in_affine``: None or an AffineSets; ``channel_last_sets``: the sets whose samples are written (Ho, Wo, Cout).
+    Returns (y (sets * n, Cout, Ho, Wo), partials)."""
     sets = len(convs)
     conv = convs[0]
+    if interleaved:
+        x = x.view(x.shape[0] * sets, x.shape[1] // sets, x.shape[2], x.shape[3])
     Cin, Hi, Wi = x.shape[1:]
-    N = x.shape[0] * (sets if shared_input else 1)
+    N = x.shape[0]
     Cout = conv.out_channels
     ks, stride = conv.kernel_size[0], conv.stride[0]
     Ho, Wo = (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
@@ -649,7 +682,7 @@ def conv2d_wide_sets(x, convs, in_affine, samples_per_stat, want_stats, shared_i
         partials = stat_rows(N, T, Cout, x.device)
     sc, sh, in_bn = (None, None, None) if in_affine is None else in_affine.split()
     mask = sum(1 << s for s in channel_last_sets)
-    _lib.call("pf_conv2d_wide_sets_f32", _lib.ptr(x), int(bool(shared_input)), _lib.ptr(wp), int(wp[0].numel()), sets,
+    _lib.call("pf_conv2d_wide_sets_f32", _lib.ptr(x), 2 if interleaved else 0, _lib.ptr(wp), int(wp[0].numel()), sets,
               _lib.ptr(y), N, Cin, Cout, Hi, Wi, int(ks), int(stride), _lib.ptr(sc), _lib.ptr(sh), in_bn,
               int(samples_per_stat), _lib.ptr(partials), int(mask), _lib.stream(),
               algo_bytes=4.0 * (x.numel() + N * Cout * Ho * Wo) + 4.0 * sets * ks * ks * Cin * Cout,
@@ -657,20 +690,21 @@ def conv2d_wide_sets(x, convs, in_affine, samples_per_stat, want_stats, shared_i
     return y, partials
 
 
-def bn_affine_rows_sets(y, bns, samples_per_stat, partials, lazy):
+def bn_affine_rows_sets(y, bns, samples_per_stat, partials, lazy, interleaved=False):
     """``bn_affine_rows`` for the raw output y (sets * n, C, h, w) of a conv2d_wide_sets launch in train mode: one job per
-    set over its own slice of the statistics rows, joint (sets * G, C) affine rows.  Returns an AffineSets."""
+    set over its own slice of the statistics rows, joint (sets * G, C) affine rows.  ``interleaved``: y is
+    (n, sets * C, h, w) from conv2d_wide_stacked -- a set's job reads its C columns of every row.  Returns an AffineSets."""
     sets = len(bns)
-    N, C = y.shape[:2]
     S = y[0, 0].numel()
-    n = N // sets
+    n, C = (y.shape[0], y.shape[1] // sets) if interleaved else (y.shape[0] // sets, y.shape[1])
     G = n // samples_per_stat
     scale = torch.empty((sets * G, C), dtype=_F32, device=y.device)
     shift = torch.empty((sets * G, C), dtype=_F32, device=y.device)
     cnt = float(samples_per_stat) * S
     jobs = []
     for s, bn in enumerate(bns):
-        jobs.append(bn_job(bn, partials[s * n:(s + 1) * n], 0, C, cnt, cnt, n, samples_per_stat,
+        rows, col0 = (partials, s * C) if interleaved else (partials[s * n:(s + 1) * n], 0)
+        jobs.append(bn_job(bn, rows, col0, C, cnt, cnt, n, samples_per_stat,
                            scale[s * G:(s + 1) * G], shift[s * G:(s + 1) * G]))
         bump_counter(bn, G)
     if lazy and LAZY_BN and samples_per_stat * partials.shape[1] * C <= LAZY_MAX_ELEMS:
