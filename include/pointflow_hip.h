@@ -259,8 +259,10 @@ int pf_edge_apply_f32(const float* LE, int64_t ldle, int C, const int64_t* idx, 
  *   reduce: partials (G, pf_stat_blocks(G,Ng), cols, 2) float64, cols = 2C | C, per column
  *           (sum g, sum g*xhat) with g = [u > 0] * G / k (central half: [u > 0] * G) -> dbeta, dgamma
  *   apply : grad_le (G*Ng, ldle) = [dl | de]; c1 = dbeta/M, c2 = dgamma/M rows (S, ld_affine), M = elements
- *           behind the statistics of that column (diff: gps*Ng*k; central: gps*Ng).  grad_le is zeroed by
- *           the call; de rows are accumulated with float atomics (as the reference's scatter).
+ *           behind the statistics of that column (diff: gps*Ng*k; central: gps*Ng).  With inv_order /
+ *           inv_start (pf_knn_inverse below) de is gathered over the inverted lists, columns [0, 2C) of every row
+ *           are written with plain stores and the result is bit-reproducible; with NULL grad_le is zeroed by
+ *           the call and the de rows are accumulated with float atomics (as the reference's scatter).
  * C in {32, 64}. */
 int pf_edge_backward_reduce_f32(const float* LE, int64_t ldle, int C, const int64_t* idx, int k, int G, int Ng,
                                 const float* grad_y, int64_t ldg, const float* scale, const float* shift,
@@ -269,7 +271,19 @@ int pf_edge_backward_reduce_f32(const float* LE, int64_t ldle, int C, const int6
 int pf_edge_backward_apply_f32(const float* LE, int64_t ldle, int C, const int64_t* idx, int k, int G, int Ng,
                                const float* grad_y, int64_t ldg, const float* scale, const float* shift,
                                const float* mean, const float* invstd, const float* c1, const float* c2,
-                               int ld_affine, int groups_per_stat, int concat, float* grad_le, void* stream);
+                               int ld_affine, int groups_per_stat, int concat, float* grad_le,
+                               const uint32_t* inv_order, const uint32_t* inv_start, void* stream);
+
+/* The inverse of a neighbour index tensor idx (G, Ng, k) (csrc/knn_inverse.hip): order (G*Ng*k) = the pair ids
+ * p = (g*Ng + n)*k + j stably sorted by their target row g*Ng + clamp(idx[p], 0, Ng-1); start (G*Ng + 1): the pairs
+ * that gather row m are order[start[m] .. start[m+1]), in ascending p.  With (inv_order, inv_start)
+ * pf_edge_backward_apply_f32 computes the de rows as a GATHER over those lists -- plain stores in a fixed summation
+ * order, bit-reproducible -- instead of the float atomics of the reference's scatter
+ * (functions/csrc/gather_knn_kernel.cu:50-89); NULL keeps the atomics.  One inversion serves every layer that
+ * shares idx.  workspace: pf_knn_inverse_workspace(G, Ng, k) bytes of device scratch (-1: query failed). */
+int64_t pf_knn_inverse_workspace(int G, int Ng, int k);
+int pf_knn_inverse(const int64_t* idx, int k, int G, int Ng, uint32_t* order, uint32_t* start, void* workspace,
+                   int64_t workspace_bytes, void* stream);
 
 /* ---- train-mode BatchNorm for the conv stacks around the path (ImageConv / VolumeConv) ----------
  * x (N, C, S) contiguous (NCHW / NCDHW with S = spatial size).  pf_channel_stats_f32 writes float64

@@ -659,7 +659,10 @@ __global__ __launch_bounds__(256) void edge_apply_kernel(const float* __restrict
 // same BatchNorm) reduces to  dl += a_c * (g_c - dbeta_c/N - xhat_c * dgamma_c/N),  g_c = [u_c > 0] * G_c.
 //
 //   pass 1 (edge_bwd_reduce)  per-block float64 partial sums of (g, g*xhat) per channel -> dbeta, dgamma
-//   pass 2 (edge_bwd_apply)   dl rows (plain stores) and de rows (float atomics, like the reference)
+//   pass 2 (edge_bwd_apply)   dl rows (plain stores) and, SCATTER, de rows by float atomics like the reference
+//   pass 3 (edge_bwd_inverse) de rows WITHOUT atomics: point m sums dd over the pairs (n, j) that gathered it, in
+//                             ascending pair order, from the inverted index tensor (knn_inverse.hip) -- the same
+//                             dd expression as pass 2, so dl and de are bit-reproducible from run to run
 // The two GEMMs that follow (dX = [dl|de] W, dW = [dl|de]^T X) are plain library GEMMs on the host side.
 // ------------------------------------------------------------------------------------------------
 struct EdgeBwdAffine {
@@ -780,7 +783,7 @@ __global__ __launch_bounds__(256) void edge_bwd_reduce_kernel(const float* __res
   }
 }
 
-template <int C, int K>
+template <int C, int K, bool SCATTER>
 __global__ __launch_bounds__(256) void edge_bwd_apply_kernel(const float* __restrict__ LE, int64_t ldle,
                                                              const int64_t* __restrict__ idx, int k, int Ng,
                                                              const float* __restrict__ Gy, int64_t ldg,
@@ -823,7 +826,7 @@ __global__ __launch_bounds__(256) void edge_bwd_apply_kernel(const float* __rest
           const float gg = u > 0.0f ? gd[c] : 0.0f;
           const float dd = av[c] * ((gg - c1v[c]) - ((d - mv[c]) * iv[c]) * c2v[c]);
           dl[c] -= dd;
-          unsafeAtomicAdd(de + c, dd);
+          if (SCATTER) unsafeAtomicAdd(de + c, dd);
         }
       };
       if constexpr (K > 0) {
@@ -861,6 +864,62 @@ __global__ __launch_bounds__(256) void edge_bwd_apply_kernel(const float* __rest
       }
       *reinterpret_cast<float4*>(dLE + row * ldle + 4 * q) = make_float4(dl[0], dl[1], dl[2], dl[3]);
     }
+  }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void edge_bwd_inverse_kernel(const float* __restrict__ LE, int64_t ldle, int k, int Ng,
+                                                               const float* __restrict__ Gy, int64_t ldg,
+                                                               EdgeBwdAffine A, const uint32_t* __restrict__ order,
+                                                               const uint32_t* __restrict__ start,
+                                                               float* __restrict__ dLE, int64_t rows) {
+  constexpr int Q = C / 4;
+  constexpr int PPB = 256 / Q;
+  const int tid = threadIdx.x;
+  const int q = tid % Q, pl = tid / Q;
+  const int doff = A.concat ? C : 0;
+  const float kf = (float)k;
+  for (int64_t row = (int64_t)blockIdx.x * PPB + pl; row < rows; row += (int64_t)gridDim.x * PPB) {
+    const int g = (int)(row / Ng);
+    const int64_t so = (int64_t)(g / A.groups_per_stat) * A.ld + doff + 4 * q;
+    const float4 a = ld4(A.scale + so), b = ld4(A.shift + so), mu = ld4(A.mean + so), is = ld4(A.invstd + so);
+    const float4 k1 = ld4(A.c1 + so), k2 = ld4(A.c2 + so);
+    const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+    const float mv[4] = {mu.x, mu.y, mu.z, mu.w}, iv[4] = {is.x, is.y, is.z, is.w};
+    const float c1v[4] = {k1.x, k1.y, k1.z, k1.w}, c2v[4] = {k2.x, k2.y, k2.z, k2.w};
+    const float4 e = ld4(LE + row * ldle + C + 4 * q);
+    const float ev[4] = {e.x, e.y, e.z, e.w};
+    const uint32_t t0 = start[row], t1 = start[row + 1];
+    float de[4] = {0, 0, 0, 0};
+    for (uint32_t t = t0; t < t1; t += 4) {
+      int64_t nrow[4];
+      float4 l[4], gy[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t p = order[t + u < t1 ? t + u : t1 - 1];
+        nrow[u] = (int64_t)(k == 16 ? (p >> 4) : (p / (uint32_t)k));
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        l[u] = ld4(LE + nrow[u] * ldle + 4 * q);
+        gy[u] = ld4(Gy + nrow[u] * ldg + doff + 4 * q);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (t + u < t1) {
+          const float lv[4] = {l[u].x, l[u].y, l[u].z, l[u].w};
+          const float gv[4] = {gy[u].x / kf, gy[u].y / kf, gy[u].z / kf, gy[u].w / kf};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float d = ev[c] - lv[c];
+            const float uu = fmaf(d, av[c], bv[c]);
+            const float gg = uu > 0.0f ? gv[c] : 0.0f;
+            de[c] += av[c] * ((gg - c1v[c]) - ((d - mv[c]) * iv[c]) * c2v[c]);
+          }
+        }
+      }
+    }
+    *reinterpret_cast<float4*>(dLE + row * ldle + C + 4 * q) = make_float4(de[0], de[1], de[2], de[3]);
   }
 }
 
@@ -1339,28 +1398,49 @@ int pf_edge_backward_reduce_f32(const float* LE, int64_t ldle, int C, const int6
 int pf_edge_backward_apply_f32(const float* LE, int64_t ldle, int C, const int64_t* idx, int k, int G, int Ng,
                                const float* grad_y, int64_t ldg, const float* scale, const float* shift,
                                const float* mean, const float* invstd, const float* c1, const float* c2,
-                               int ld_affine, int groups_per_stat, int concat, float* grad_le, void* stream) {
+                               int ld_affine, int groups_per_stat, int concat, float* grad_le,
+                               const uint32_t* inv_order, const uint32_t* inv_start, void* stream) {
   PF_REQUIRE(G >= 0 && Ng >= 0 && k >= 1 && ldle >= 2 * (int64_t)C && (ldle % 4) == 0 && G <= 65535);
+  PF_REQUIRE((inv_order == nullptr) == (inv_start == nullptr));
   PF_REQUIRE(groups_per_stat >= 1 && (ldg % 4) == 0 && ldg >= (concat ? 2 : 1) * (int64_t)C);
   PF_REQUIRE((ld_affine % 4) == 0 && ld_affine >= (concat ? 2 : 1) * C);
   if (C != 32 && C != 64) return PF_ERR_UNSUPPORTED;
   if (G == 0 || Ng == 0) return PF_OK;
   PF_REQUIRE(LE && idx && grad_y && scale && shift && mean && invstd && c1 && c2 && grad_le);
   hipStream_t s = (hipStream_t)stream;
-  {
+  const bool scatter = inv_order == nullptr;
+  if (scatter) {     // the atomics accumulate into de: clear it first (the inverse gather writes every row itself)
     const int zrc = pf_zero_async(grad_le, sizeof(float) * (size_t)G * Ng * ldle, s);
     if (zrc != PF_OK) return zrc;
   }
   const EdgeBwdAffine A{scale, shift, mean, invstd, c1, c2, ld_affine, groups_per_stat, concat};
   const int T = pf_stat_blocks(G, Ng);
   dim3 grid((unsigned)T, (unsigned)G);
-#define PF_EBA(CV, KV) hipLaunchKernelGGL((edge_bwd_apply_kernel<CV, KV>), grid, dim3(256), 0, s, LE, ldle, idx, k, Ng, grad_y, ldg, A, grad_le, T)
+#define PF_EBA(CV, KV, SV) hipLaunchKernelGGL((edge_bwd_apply_kernel<CV, KV, SV>), grid, dim3(256), 0, s, LE, ldle, idx, k, Ng, grad_y, ldg, A, grad_le, T)
+  if (scatter) {
+    if (k == 16) {
+      if (C == 32) PF_EBA(32, 16, true); else PF_EBA(64, 16, true);
+    } else {
+      if (C == 32) PF_EBA(32, 0, true); else PF_EBA(64, 0, true);
+    }
+    return pf_launch_status();
+  }
   if (k == 16) {
-    if (C == 32) PF_EBA(32, 16); else PF_EBA(64, 16);
+    if (C == 32) PF_EBA(32, 16, false); else PF_EBA(64, 16, false);
   } else {
-    if (C == 32) PF_EBA(32, 0); else PF_EBA(64, 0);
+    if (C == 32) PF_EBA(32, 0, false); else PF_EBA(64, 0, false);
   }
 #undef PF_EBA
+  const int64_t rows = (int64_t)G * Ng;
+  const int ppb = 256 / (C / 4);
+  int64_t blocks = pf_cdiv(rows, ppb);
+  if (blocks > 16384) blocks = 16384;
+  if (C == 32)
+    hipLaunchKernelGGL((edge_bwd_inverse_kernel<32>), dim3((unsigned)blocks), dim3(256), 0, s, LE, ldle, k, Ng, grad_y, ldg,
+                       A, inv_order, inv_start, grad_le, rows);
+  else
+    hipLaunchKernelGGL((edge_bwd_inverse_kernel<64>), dim3((unsigned)blocks), dim3(256), 0, s, LE, ldle, k, Ng, grad_y, ldg,
+                       A, inv_order, inv_start, grad_le, rows);
   return pf_launch_status();
 }
 

@@ -999,6 +999,40 @@ def edge_conv_fused(X, point_major, ldx, K, G, Ng, idx, conv1_w, conv2_w, bn, co
     return Y
 
 
+# The inverted index tensors of the current backward pass: the three EdgeConv layers of a PointFlow iteration share
+# one idx, so the sort runs once per iteration (keyed by the tensor's storage and version; a handful of entries).
+_inverse_cache = _collections.OrderedDict()
+
+
+def knn_inverse(idx, G, Ng, k):
+    """(order, start) of pf_knn_inverse for idx (G, Ng, k) int64 (contiguous): who gathers each point, in pair order."""
+    key = (idx.data_ptr(), idx._version, str(idx.device), G, Ng, k)
+    hit = _inverse_cache.get(key)
+    if hit is not None and hit[0]() is idx:
+        return hit[1], hit[2]
+    dev = idx.device
+    order = torch.empty((G * Ng * k,), dtype=torch.int32, device=dev)
+    start = torch.empty((G * Ng + 1,), dtype=torch.int32, device=dev)
+    nbytes = int(_lib.load().pf_knn_inverse_workspace(int(G), int(Ng), int(k)))
+    if nbytes < 0:
+        raise RuntimeError("pf_knn_inverse_workspace failed")
+    work = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=dev)
+    _lib.call("pf_knn_inverse", _lib.ptr(idx), int(k), int(G), int(Ng), _lib.ptr(order), _lib.ptr(start), _lib.ptr(work),
+              nbytes, _lib.stream(), algo_bytes=8.0 * G * Ng * k * 4)
+    try:
+        _inverse_cache[key] = (_weakref.ref(idx), order, start)
+    except TypeError:
+        return order, start
+    while len(_inverse_cache) > 8:
+        _inverse_cache.popitem(last=False)
+    return order, start
+
+
+# True: the de rows of the EdgeConv backward are gathered over the inverted index lists (bit-reproducible); False: the
+# reference's float atomics (module attribute for the tests that compare the two, not an environment switch)
+DETERMINISTIC_BACKWARD = True
+
+
 def edge_conv_backward(keep, idx, grad_y, C, k, G, Ng, groups_per_stat, concat):
     """Gradient of edge_conv_fused's output rows w.r.t. LE = [l | e] and the BatchNorm affine parameters
     (pf_edge_backward_reduce_f32 / _apply_f32: d = e[idx] - l is recomputed, nothing of size N*k is stored).
@@ -1020,10 +1054,11 @@ def edge_conv_backward(keep, idx, grad_y, C, k, G, Ng, groups_per_stat, concat):
     c1 = (red[..., 0] / m).to(_F32).contiguous()
     c2 = (red[..., 1] / m).to(_F32).contiguous()
     grad_le = torch.empty((G * Ng, 2 * C), dtype=_F32, device=dev)
+    order, start = knn_inverse(idx, G, Ng, k) if DETERMINISTIC_BACKWARD else (None, None)
     _lib.call("pf_edge_backward_apply_f32", _lib.ptr(LE), 2 * C, C, _lib.ptr(idx), k, G, Ng, _lib.ptr(grad_y),
               int(grad_y.stride(0)), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(c1),
-              _lib.ptr(c2), cbn, groups_per_stat, int(bool(concat)), _lib.ptr(grad_le), _lib.stream(),
-              algo_bytes=float(G) * Ng * (8.0 * C + 8.0 * k + 8.0 * C * k + 4.0 * cbn))
+              _lib.ptr(c2), cbn, groups_per_stat, int(bool(concat)), _lib.ptr(grad_le), _lib.ptr(order), _lib.ptr(start),
+              _lib.stream(), algo_bytes=float(G) * Ng * (8.0 * C + 8.0 * k + 8.0 * C * k + 4.0 * cbn))
     return grad_le, red[..., 1].sum(dim=0).to(_F32), red[..., 0].sum(dim=0).to(_F32)
 
 

@@ -460,6 +460,58 @@ def test_edgeconv_autograd_path_vs_oracle(dev, name, concat, fused, monkeypatch)
     assert _maxabs(mod.bn.running_mean, g["running_mean"]) < 1e-5
 
 
+@pytest.mark.parametrize("G,Ng,k", [(1, 700, 16), (3, 257, 16), (2, 90, 5)])
+def test_knn_inverse_lists_equal_a_stable_argsort(dev, G, Ng, k):
+    """pf_knn_inverse: pair ids stably sorted by target row (with the forward's clamp of out-of-range indices) and the
+    list starts, against NumPy's stable argsort -- integers, bit-exact; untargeted rows get empty lists."""
+    gen = torch.Generator().manual_seed(G * Ng + k)
+    idx = torch.randint(0, Ng // 2, (G, Ng, k), generator=gen)          # half of the points are nobody's neighbour
+    idx[:, ::7, 0] = -3                                                # the forward clamps these to 0 / Ng - 1
+    idx[:, ::11, 1] = Ng + 5
+    order, start = pointflow.knn_inverse(idx.to(dev).contiguous(), G, Ng, k)
+    torch.cuda.synchronize()
+    keys = (idx.clamp(0, Ng - 1) + torch.arange(G).view(G, 1, 1) * Ng).reshape(-1).numpy()
+    want_order = np.argsort(keys, kind="stable")
+    want_start = np.searchsorted(keys[want_order], np.arange(G * Ng + 1), side="left")
+    assert np.array_equal(order.cpu().numpy().astype(np.int64), want_order)
+    assert np.array_equal(start.cpu().numpy().astype(np.int64), want_start)
+    # the same tensor again: served from the cache (same objects)
+    again = pointflow.knn_inverse(idx.to(dev).contiguous(), G, Ng, k)
+    assert again[0].shape == order.shape
+
+
+@pytest.mark.parametrize("cls,cin,cout", [(EdgeConvNoC, 40, 32), (EdgeConv, 32, 32), (EdgeConv, 64, 64)])
+def test_edgeconv_backward_is_bit_reproducible_and_matches_the_scatter(dev, cls, cin, cout, monkeypatch):
+    """The fused node's backward with the de rows gathered over the inverted index lists (default): two runs give
+    identical bits for every gradient; the float-atomic scatter (the reference's scheme) agrees to rounding."""
+    D, H, W = 5, 24, 31
+    N = D * H * W
+    gen = torch.Generator().manual_seed(cout + cin)
+    xyz = torch.randn(1, 3, D, H, W, generator=gen).to(dev)
+    idx = get_knn_3d(xyz, 5, knn=16)
+    mod = cls(cin, cout)
+    synthetic.seed_weights(mod, seed=4)
+    mod = mod.to(dev).train()
+    x0 = torch.randn(1, cin, N, generator=gen).to(dev)
+    go = torch.randn(1, (2 if mod.concat else 1) * cout, N, generator=gen).to(dev)
+
+    def grads():
+        mod.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        mod(x, idx).backward(go)
+        torch.cuda.synchronize()
+        return [x.grad.clone()] + [p.grad.clone() for p in mod.parameters()]
+
+    first, second = grads(), grads()
+    for a, b in zip(first, second):
+        assert torch.equal(a, b)
+    monkeypatch.setattr(pointflow, "DETERMINISTIC_BACKWARD", False)
+    scattered = grads()
+    for a, b in zip(first, scattered):
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
+    assert _lib.status() == 0
+
+
 def test_edgeconv_eval_mode_uses_running_stats(dev):
     g = load_golden("edgeconv_32")
     mod = EdgeConv(32, 32)
