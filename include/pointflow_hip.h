@@ -71,16 +71,21 @@ int pf_check_status(unsigned* status_host, void* stream);
  * Replaces dgcnn_ext.gather_knn_forward / gather_knn_backward
  * (reference functions/csrc/gather_knn_kernel.cu:25-47 and :97-148).
  *   forward : out[b,c,n,j] = feature[b,c,index[b,n,j]]      feature (B,C,N), index (B,N,K), out (B,C,N,K)
- *   backward: grad_in[b,c,index[b,n,j]] += grad_out[b,c,n,j]  (grad_in is zeroed by the call)
+ *   backward: grad_in[b,c,index[b,n,j]] += grad_out[b,c,n,j]  (grad_in is zeroed by the call) -- float atomics in
+ *             arrival order like the reference's kernel when inv_order / inv_start are NULL; with the inverted index
+ *             lists of pf_knn_inverse(index, K, B, N, ...) (further down) every grad_in element is one thread's sum
+ *             over the slots that name it, in ascending slot order: no atomics, bit-reproducible.
  * float32 and float64 like the reference's AT_DISPATCH_FLOATING_TYPES (:134). */
 int pf_gather_knn_forward_f32(const float* feature, const int64_t* index, float* out,
                               int64_t B, int64_t C, int64_t N, int64_t K, void* stream);
 int pf_gather_knn_forward_f64(const double* feature, const int64_t* index, double* out,
                               int64_t B, int64_t C, int64_t N, int64_t K, void* stream);
 int pf_gather_knn_backward_f32(const float* grad_out, const int64_t* index, float* grad_in,
-                               int64_t B, int64_t C, int64_t N, int64_t K, void* stream);
+                               int64_t B, int64_t C, int64_t N, int64_t K, const uint32_t* inv_order,
+                               const uint32_t* inv_start, void* stream);
 int pf_gather_knn_backward_f64(const double* grad_out, const int64_t* index, double* grad_in,
-                               int64_t B, int64_t C, int64_t N, int64_t K, void* stream);
+                               int64_t B, int64_t C, int64_t N, int64_t K, const uint32_t* inv_order,
+                               const uint32_t* inv_start, void* stream);
 
 /* ---- row K : lattice kNN -------------------------------------------------------------------
  * Replaces get_knn_3d (reference utils/torch_utils.py:16-61).  xyz is (B,3,D,H,W) addressed through

@@ -33,8 +33,8 @@ PROTOTYPES = {
     "pf_check_status": ([ctypes.POINTER(ctypes.c_uint), _vp], _i),
     "pf_gather_knn_forward_f32": ([_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp], _i),
     "pf_gather_knn_forward_f64": ([_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp], _i),
-    "pf_gather_knn_backward_f32": ([_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp], _i),
-    "pf_gather_knn_backward_f64": ([_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp], _i),
+    "pf_gather_knn_backward_f32": ([_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp], _i),
+    "pf_gather_knn_backward_f64": ([_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp], _i),
     "pf_knn_lattice_f32": ([_vp, ctypes.POINTER(_i64), _i64, _i64, _i64, _i64, _i, _i, _vp, _vp, _vp], _i),
     "pf_fetch_forward_f32": ([_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp], _i),
     "pf_fetch_backward_f32": ([_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp], _i),

@@ -3,8 +3,10 @@
 // Layout is the reference's: feature (B,C,N), index (B,N,K) int64, out (B,C,N,K).  One thread owns one
 // (n,j) slot of the flattened N*K axis and walks the C channels, so the K-expanded tensor is written
 // with fully coalesced stores (the bound: C*N*K*4 bytes of stores) while the neighbour reads hit L2.
-// The backward is the same walk with hardware float atomics (global_atomic_add_f32/f64) into a zeroed
-// (B,C,N) gradient, i.e. the reference's scatter (gather_knn_kernel.cu:50-89) on the current stream.
+// The backward comes in two forms: the same walk with hardware float atomics (global_atomic_add_f32/f64) into a
+// zeroed (B,C,N) gradient, i.e. the reference's scatter (gather_knn_kernel.cu:50-89); or, given the inverted index
+// lists of pf_knn_inverse (knn_inverse.hip), a GATHER: one thread per (b, c, m) sums the slots that name point m in
+// ascending slot order and stores once -- no atomics, no zero-fill, bit-reproducible.
 #include "pf_common.h"
 
 namespace {
@@ -58,6 +60,27 @@ __global__ __launch_bounds__(256) void gather_bwd_kernel(const T* __restrict__ g
 }
 
 template <typename T>
+__global__ __launch_bounds__(256) void gather_bwd_inverse_kernel(const T* __restrict__ gout,
+                                                                 const int64_t* __restrict__ idx,
+                                                                 const uint32_t* __restrict__ order,
+                                                                 const uint32_t* __restrict__ start,
+                                                                 T* __restrict__ gin, int C, int64_t N, int64_t NK,
+                                                                 unsigned* status) {
+  const int64_t b = blockIdx.z, c = blockIdx.y;
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= N) return;
+  const uint32_t t0 = start[b * N + m], t1 = start[b * N + m + 1];
+  const T* gb = gout + (b * C + c) * NK - b * NK;      // order holds pair ids over all batches: b * NK + slot
+  T acc = T(0);
+  for (uint32_t t = t0; t < t1; ++t) {
+    const uint32_t p = order[t];
+    if (idx[p] == m) acc += gb[p];                     // (an out-of-range index was filed under the clamped row:
+    else if (c == 0) atomicOr(status, PF_STATUS_BAD_INDEX);   //  the forward wrote zeros for it, it carries no gradient)
+  }
+  gin[(b * C + c) * N + m] = acc;
+}
+
+template <typename T>
 int gather_forward(const T* feature, const int64_t* index, T* out, int64_t B, int64_t C, int64_t N, int64_t K,
                    void* stream) {
   PF_REQUIRE(B >= 0 && C >= 0 && N >= 0 && K >= 0);
@@ -75,11 +98,20 @@ int gather_forward(const T* feature, const int64_t* index, T* out, int64_t B, in
 
 template <typename T>
 int gather_backward(const T* grad_out, const int64_t* index, T* grad_in, int64_t B, int64_t C, int64_t N,
-                    int64_t K, void* stream) {
+                    int64_t K, const uint32_t* inv_order, const uint32_t* inv_start, void* stream) {
   PF_REQUIRE(B >= 0 && C >= 0 && N >= 0 && K >= 0);
-  PF_REQUIRE(B <= 65535 && C <= INT32_MAX);
+  PF_REQUIRE(B <= 65535 && C <= INT32_MAX && (inv_order == nullptr) == (inv_start == nullptr));
   if (B == 0 || C == 0 || N == 0) return PF_OK;
   PF_REQUIRE(grad_in != nullptr);
+  if (inv_order != nullptr && K > 0) {
+    PF_REQUIRE(grad_out != nullptr && index != nullptr && C <= 65535);
+    unsigned* status = pf_status_ptr();
+    PF_REQUIRE(status != nullptr);
+    dim3 grid((unsigned)pf_cdiv(N, 256), (unsigned)C, (unsigned)B);
+    hipLaunchKernelGGL(gather_bwd_inverse_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, grad_out, index, inv_order,
+                       inv_start, grad_in, (int)C, N, N * K, status);
+    return pf_launch_status();
+  }
   {
     const int zrc = pf_zero_async(grad_in, sizeof(T) * (size_t)(B * C * N), (hipStream_t)stream);
     if (zrc != PF_OK) return zrc;
@@ -108,12 +140,14 @@ int pf_gather_knn_forward_f64(const double* feature, const int64_t* index, doubl
   return gather_forward<double>(feature, index, out, B, C, N, K, stream);
 }
 int pf_gather_knn_backward_f32(const float* grad_out, const int64_t* index, float* grad_in, int64_t B, int64_t C,
-                               int64_t N, int64_t K, void* stream) {
-  return gather_backward<float>(grad_out, index, grad_in, B, C, N, K, stream);
+                               int64_t N, int64_t K, const uint32_t* inv_order, const uint32_t* inv_start,
+                               void* stream) {
+  return gather_backward<float>(grad_out, index, grad_in, B, C, N, K, inv_order, inv_start, stream);
 }
 int pf_gather_knn_backward_f64(const double* grad_out, const int64_t* index, double* grad_in, int64_t B, int64_t C,
-                               int64_t N, int64_t K, void* stream) {
-  return gather_backward<double>(grad_out, index, grad_in, B, C, N, K, stream);
+                               int64_t N, int64_t K, const uint32_t* inv_order, const uint32_t* inv_start,
+                               void* stream) {
+  return gather_backward<double>(grad_out, index, grad_in, B, C, N, K, inv_order, inv_start, stream);
 }
 
 }  // extern "C"

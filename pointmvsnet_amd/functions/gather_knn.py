@@ -5,7 +5,9 @@ Same surface as reference ``pointmvsnet/functions/gather_knn.py:10-24``: ``Gathe
 returns ``(grad_feature, None)``; ``gather_knn = GatherKNN.apply``.  ``dgcnn_ext`` mirrors the two
 functions of the reference's pybind module (``functions/csrc/main.cpp:3-6``) on top of the C ABI
 (``pf_gather_knn_{forward,backward}_{f32,f64}``), float and double like the reference dispatch
-(``gather_knn_kernel.cu:134``).  Kernels run on the *current* stream and device.
+(``gather_knn_kernel.cu:134``).  Kernels run on the *current* stream and device.  The backward sums every
+gradient element in a fixed order over the inverted index lists (``pf_knn_inverse``): unlike the reference's
+``atomicAdd`` scatter (``gather_knn_kernel.cu:50-89``) it is bit-reproducible from run to run.
 """
 import torch
 
@@ -52,8 +54,13 @@ class _Ext(object):
         g, idx = grad_output.contiguous(), index.contiguous()
         grad_in = torch.empty((B, C, N), dtype=g.dtype, device=g.device)
         with torch.cuda.device(g.device):
+            # (default: the scatter as a gather over the inverted index lists -- bit-reproducible; the reference's
+            # float atomics when pointflow.DETERMINISTIC_BACKWARD is off)
+            from .. import pointflow
+            det = pointflow.DETERMINISTIC_BACKWARD and B * N * K > 0 and B * N * K < 2 ** 32 - 1 and C <= 65535
+            order, start = pointflow.knn_inverse(idx, B, N, K) if det else (None, None)
             _lib.call("pf_gather_knn_backward_" + _SUFFIX[g.dtype], _lib.ptr(g), _lib.ptr(idx), _lib.ptr(grad_in),
-                      B, C, N, K, _lib.stream(),
+                      B, C, N, K, _lib.ptr(order), _lib.ptr(start), _lib.stream(),
                       algo_bytes=float(B) * (g.element_size() * C * N * (1 + K) + 8.0 * N * K))
         return grad_in
 

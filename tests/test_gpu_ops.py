@@ -56,6 +56,29 @@ def test_gather_knn_forward_backward(dev, dtype, B, C, N, K):
     assert err < (2e-5 if dtype == torch.float32 else 1e-12)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_gather_knn_backward_is_bit_reproducible_and_drops_bad_indices(dev, dtype, monkeypatch):
+    """The default backward gathers over the inverted index lists: identical bits from run to run (many slots per
+    target here: N = 300 points named by 300 * 16 slots drawn from 40 targets), out-of-range slots carry no gradient
+    like the forward's zeros, and the reference's atomic scatter agrees to rounding."""
+    B, C, N, K = 2, 9, 300, 16
+    g = torch.Generator().manual_seed(3)
+    idx = torch.randint(0, 40, (B, N, K), generator=g)
+    idx[0, 5, 3], idx[1, 7, 0] = -1, N                                       # flagged; no gradient through them
+    go = torch.randn(B, C, N, K, generator=g, dtype=dtype)
+    first = dgcnn_ext.gather_knn_backward(go.to(dev), idx.to(dev))
+    assert _lib.status() & 1
+    second = dgcnn_ext.gather_knn_backward(go.to(dev), idx.to(dev))
+    assert _lib.status() & 1 and torch.equal(first, second)
+    valid = (idx >= 0) & (idx < N)
+    ref = O.gather_knn_backward((go.double() * valid.unsqueeze(1)), idx.clamp(0, N - 1))
+    assert _maxabs(first, ref) < (1e-4 if dtype == torch.float32 else 1e-11)
+    monkeypatch.setattr(pointflow, "DETERMINISTIC_BACKWARD", False)
+    scattered = dgcnn_ext.gather_knn_backward(go.to(dev), idx.to(dev))
+    assert _lib.status() & 1
+    assert _maxabs(first, scattered) < (1e-4 if dtype == torch.float32 else 1e-11)
+
+
 def test_gather_knn_empty_and_noncontiguous(dev):
     x = torch.randn(2, 4, 9, device=dev)
     idx = torch.randint(0, 9, (2, 9, 0), device=dev)
