@@ -75,6 +75,9 @@ def parse_args():
     ap.add_argument("--lanes", type=int, default=4,
                     help="scenes in flight per GPU: that many captured forwards replayed round-robin on as many streams "
                          "(pointmvsnet_amd.graph.LanedForward); 1 = one scene at a time")
+    ap.add_argument("--concurrency", type=int, default=None,
+                    help="intra-forward concurrency level of eager forwards and of a single lane (default: the "
+                         "process default, PF_CONCURRENCY; scene lanes are always single chains, level 0)")
     ap.add_argument("--calibration-steps", type=int, default=10,
                     help="instrumented eager forwards (HIP events around every entry point) before the timed region")
     ap.add_argument("--route", default="fused", choices=["fused", "reference-model"],
@@ -338,6 +341,8 @@ def main():
     # The pass runs the launch sequence of the timed region: scene lanes are captured as single chains (intra-forward
     # concurrency level 0, where the two towers share their launches), a single lane at the process default.
     from pointmvsnet_amd import pointflow
+    if args.concurrency is not None:
+        pointflow.CONCURRENCY = int(args.concurrency)
     cal_level = 0 if (not training and not args.eager and args.lanes > 1) else pointflow.CONCURRENCY
     with pointflow.concurrency(cal_level):
         for i in range(min(max(args.warmup, 1), 3)):

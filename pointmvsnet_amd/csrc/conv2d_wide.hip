@@ -98,7 +98,11 @@ struct PatchStager {
       okmask |= (ok ? 1u : 0u) << r;
       const float* src = xb + (int64_t)(4 * q) * plane_i + (ok ? ih * Wi + iw : 0);
 #pragma unroll
+#ifdef PF_DBG_NOLOAD
+      for (int j = 0; j < 4; ++j) rx[r][j] = (float)(tid + j) + (float)(src - xb) * 1e-9f;
+#else
       for (int j = 0; j < 4; ++j) rx[r][j] = (CIN % 4 == 0 || j < CIN) ? src[j * plane_i] : 0.0f;
+#endif
     }
   }
 
@@ -487,7 +491,11 @@ __global__ __launch_bounds__(256) void conv2d_wide16_kernel(const float* __restr
 #pragma unroll
       for (int j = 0; j < CPL; ++j)
 #pragma unroll
+#ifdef PF_DBG_NOMFMA
+        for (int r = 0; r < 4; ++r) acc[r][(j + t) & 3] += a[r].v[j] * b.v[j];
+#else
         for (int r = 0; r < 4; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r].v[j], b.v[j], acc[r], 0, 0, 0);
+#endif
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int r = 0; r < 4; ++r) a[r] = an[r];
@@ -503,6 +511,9 @@ __global__ __launch_bounds__(256) void conv2d_wide16_kernel(const float* __restr
       if (oh < g.Ho && col_ok) {
         float* dst = yb + (int64_t)oh * g.Wo + ow;
         if (vec_ok && ow + 3 < g.Wo) {
+#ifdef PF_DBG_NOSTORE
+          if (acc[r][0] == 123.456f)
+#endif
           *reinterpret_cast<f32x4*>(dst) = acc[r];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {

@@ -20,7 +20,7 @@ ENTRY_KERNELS = {
     "pf_pointwise_gemm_f32": "pointwise_gemm_",
     "pf_edge_apply_f32": "edge_apply_kernel", "pf_edge_stats_f32": "edge_stats_kernel",
     "pf_flow_features_f32": "flow_features_", "pf_knn_lattice_f32": "knn_",
-    "pf_conv2d_wide_f32": "conv2d_wide", "pf_conv3d_k3_pair_f32": "conv3d_k3_pair_kernel",
+    "pf_conv2d_wide_f32": "conv2d_wide", "pf_conv2d_wide_sets_f32": "conv2d_wide", "pf_conv3d_k3_pair_f32": "conv3d_k3_pair_kernel",
     "pf_conv3d_bottom_f32": "::conv3d_bottom_kernel", "pf_deconv3d_bottom_f32": "::deconv3d_bottom_kernel",
     "pf_fetch_variance_f32": "fetch_variance_kernel", "pf_frustum_variance_f32": "fetch_variance_kernel",
     "pf_frustum_variance_cl_f32": "frustum_variance_cl_kernel", "pf_nchw_to_nhwc_f32": "nchw_to_nhwc_kernel",
