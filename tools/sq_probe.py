@@ -20,6 +20,14 @@ if "wide" in which:
         sh = torch.randn(3, cin, device=dev) * 0.1
         for _ in range(4):
             pointflow.conv2d_wide(x, conv, (sc, sh), 1, True)
+if "lowch" in which:      # the towers' full-resolution / 16-channel layers, both towers' worth of samples
+    for cin, cout, h, w, ks, stride, views in ((3, 16, 512, 640, 3, 1, 3), (8, 8, 512, 640, 3, 1, 6), (8, 16, 512, 640, 5, 2, 6),
+                                               (16, 16, 256, 320, 3, 1, 6)):
+        conv = torch.nn.Conv2d(cin, cout, ks, stride=stride, padding=ks // 2, bias=False).to(dev)
+        x = torch.randn(views, cin, h, w, device=dev)
+        aff = None if cin == 3 else (torch.rand(views, cin, device=dev) + 0.5, torch.randn(views, cin, device=dev) * 0.1)
+        for _ in range(4):
+            pointflow.conv2d_wide(x, conv, aff, 1, True)
 if "gemm" in which:
     for K, Nc, ldx in ((136, 64, 136), (224, 64, 224), (64, 128, 224)):
         X = torch.randn(4 * 25600, ldx, device=dev)
