@@ -280,12 +280,13 @@ int pf_edge_backward_apply_f32(const float* LE, int64_t ldle, int C, const int64
                                const uint32_t* inv_order, const uint32_t* inv_start, void* stream);
 
 /* The inverse of a neighbour index tensor idx (G, Ng, k) (csrc/knn_inverse.hip): order (G*Ng*k) = the pair ids
- * p = (g*Ng + n)*k + j stably sorted by their target row g*Ng + clamp(idx[p], 0, Ng-1); start (G*Ng + 1): the pairs
+ * p = (g*Ng + n)*k + j grouped by their target row g*Ng + clamp(idx[p], 0, Ng-1); start (G*Ng + 1): the pairs
  * that gather row m are order[start[m] .. start[m+1]), in ascending p.  With (inv_order, inv_start)
  * pf_edge_backward_apply_f32 computes the de rows as a GATHER over those lists -- plain stores in a fixed summation
  * order, bit-reproducible -- instead of the float atomics of the reference's scatter
  * (functions/csrc/gather_knn_kernel.cu:50-89); NULL keeps the atomics.  One inversion serves every layer that
- * shares idx.  workspace: pf_knn_inverse_workspace(G, Ng, k) bytes of device scratch (-1: query failed). */
+ * shares idx.  A counting sort in kernel launches only (no memset / memcpy nodes, no library call: capturable in a
+ * hipGraph).  workspace: pf_knn_inverse_workspace(G, Ng, k) bytes of device scratch. */
 int64_t pf_knn_inverse_workspace(int G, int Ng, int k);
 int pf_knn_inverse(const int64_t* idx, int k, int G, int Ng, uint32_t* order, uint32_t* start, void* workspace,
                    int64_t workspace_bytes, void* stream);

@@ -2,51 +2,143 @@
 //
 // The backward of a neighbour gather (reference functions/csrc/gather_knn_kernel.cu:50-89) is a scatter-add:
 // grad[idx[n, j]] += g[n, j], done there -- and in rounds 1-2 here -- with float atomics, i.e. in arrival order:
-// two runs of the same step give different low bits.  With the pairs sorted by target the scatter becomes a GATHER:
-// point m sums the pairs that name it, in ascending pair order (a stable sort keeps them so), with plain stores --
-// bit-reproducible and no zero-fill of the output.  One inversion serves every backward pass that shares the index
-// tensor (the three EdgeConv layers of a PointFlow iteration).
+// two runs of the same step give different low bits.  With the pairs grouped by target the scatter becomes a GATHER:
+// point m sums the pairs that name it, in ascending pair order, with plain stores -- bit-reproducible and no zero-fill
+// of the output.  One inversion serves every backward pass that shares the index tensor (the three EdgeConv layers of
+// a PointFlow iteration).
 //
-//   keys[p]  = g * Ng + clamp(idx[g, n, j], 0, Ng - 1)        p = (g * Ng + n) * k + j      (the forward's clamp)
-//   order    = the pair ids p sorted by key (rocPRIM radix sort: stable)
-//   start[m] = first position in `order` whose key is >= m, m in [0, G * Ng]  ->  pairs of m: order[start[m] .. start[m+1])
-#include <string.h>
-
-#include <rocprim/device/device_radix_sort.hpp>
-
+//   key(p)   = g * Ng + clamp(idx[g, n, j], 0, Ng - 1)        p = (g * Ng + n) * k + j      (the forward's clamp)
+//   start[m] = number of pairs with key < m, m in [0, G * Ng]
+//   order    = the pair ids grouped by key, ascending inside a group: pairs of m = order[start[m] .. start[m+1])
+//
+// A counting sort in five kernel launches and nothing else -- no memset / memcpy nodes, no library call -- so the whole
+// thing can sit inside a captured hipGraph (train_step.GraphedTrainStep; rocPRIM's radix sort clears its look-back
+// state with hipMemsetAsync, and memset nodes recorded from the autograd thread are not replayed reliably, see
+// pf_common.h):  count (integer atomics: the totals do not depend on arrival order) -> exclusive scan (per-block
+// sums, one block over the block sums, per-block scan) -> fill (a slot per pair from an atomic cursor: arrival order)
+// -> every list sorted in place by pair id (lists are short: at most window^3 = 125 entries for a lattice kNN,
+// k on average), which makes the result independent of the arrival order again.
 #include "pf_common.h"
 
 namespace {
 
-__global__ __launch_bounds__(256) void inverse_keys_kernel(const int64_t* __restrict__ idx, int64_t pairs, int k, int Ng,
-                                                           uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
-  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (p >= pairs) return;
+constexpr int kScanBlock = 1024;   // elements per scan block (256 threads x 4)
+
+__device__ __forceinline__ uint32_t pair_key(const int64_t* __restrict__ idx, int64_t p, int k, int Ng) {
   const int64_t row = p / k;
   const int64_t g = row / Ng;
   int64_t i = idx[p];
   i = i < 0 ? 0 : (i > Ng - 1 ? Ng - 1 : i);
-  keys[p] = (uint32_t)(g * Ng + i);
-  vals[p] = (uint32_t)p;
+  return (uint32_t)(g * Ng + i);
 }
 
-// start[m] for every m in (key[t-1], key[t]] is t; one thread per sorted position (runs of equal keys: one writer)
-__global__ __launch_bounds__(256) void inverse_starts_kernel(const uint32_t* __restrict__ sorted, int64_t pairs, int64_t rows,
-                                                             uint32_t* __restrict__ start) {
-  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (t > pairs) return;
-  const int64_t lo = t == 0 ? -1 : (int64_t)sorted[t - 1];
-  const int64_t hi = t == pairs ? rows : (int64_t)sorted[t];          // start[rows] = pairs closes the last list
-  for (int64_t m = lo + 1; m <= hi; ++m) start[m] = (uint32_t)t;
+__global__ __launch_bounds__(256) void inverse_zero_kernel(uint32_t* __restrict__ a, int64_t na, uint32_t* __restrict__ b,
+                                                           int64_t nb) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < na; i += stride) a[i] = 0u;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nb; i += stride) b[i] = 0u;
+}
+
+__global__ __launch_bounds__(256) void inverse_count_kernel(const int64_t* __restrict__ idx, int64_t pairs, int k, int Ng,
+                                                            uint32_t* __restrict__ count) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p < pairs) atomicAdd(count + pair_key(idx, p, k, Ng), 1u);
+}
+
+// exclusive scan of count[0 .. n) in place, three launches: block sums, scan of the block sums, block scans
+__global__ __launch_bounds__(256) void scan_block_sums_kernel(const uint32_t* __restrict__ v, int64_t n,
+                                                              uint32_t* __restrict__ sums) {
+  __shared__ uint32_t red[256];
+  const int64_t base = (int64_t)blockIdx.x * kScanBlock + 4 * threadIdx.x;
+  uint32_t s = 0;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) s += base + u < n ? v[base + u] : 0u;
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) sums[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(1024) void scan_sums_kernel(uint32_t* __restrict__ sums, int nblocks) {
+  // one block: exclusive scan of `nblocks` values, 1024 at a time with a running carry
+  __shared__ uint32_t buf[1024];
+  __shared__ uint32_t carry;
+  if (threadIdx.x == 0) carry = 0u;
+  __syncthreads();
+  for (int base = 0; base < nblocks; base += 1024) {
+    const int i = base + threadIdx.x;
+    const uint32_t x = i < nblocks ? sums[i] : 0u;
+    buf[threadIdx.x] = x;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {           // Hillis-Steele inclusive scan
+      const uint32_t t = (int)threadIdx.x >= off ? buf[threadIdx.x - off] : 0u;
+      __syncthreads();
+      buf[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (i < nblocks) sums[i] = carry + buf[threadIdx.x] - x;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += buf[1023];
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void scan_blocks_kernel(uint32_t* __restrict__ v, int64_t n,
+                                                          const uint32_t* __restrict__ sums) {
+  __shared__ uint32_t part[256];
+  const int64_t base = (int64_t)blockIdx.x * kScanBlock + 4 * threadIdx.x;
+  uint32_t x[4], s = 0;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    x[u] = base + u < n ? v[base + u] : 0u;
+    s += x[u];
+  }
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    const uint32_t t = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+    __syncthreads();
+    part[threadIdx.x] += t;
+    __syncthreads();
+  }
+  uint32_t run = sums[blockIdx.x] + part[threadIdx.x] - s;   // exclusive prefix of this thread's four elements
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    if (base + u < n) v[base + u] = run;
+    run += x[u];
+  }
+}
+
+__global__ __launch_bounds__(256) void inverse_fill_kernel(const int64_t* __restrict__ idx, int64_t pairs, int k, int Ng,
+                                                           const uint32_t* __restrict__ start,
+                                                           uint32_t* __restrict__ cursor, uint32_t* __restrict__ order) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= pairs) return;
+  const uint32_t key = pair_key(idx, p, k, Ng);
+  order[start[key] + atomicAdd(cursor + key, 1u)] = (uint32_t)p;
+}
+
+// every list ascending by pair id (insertion sort in place; one thread per list)
+__global__ __launch_bounds__(256) void inverse_sort_lists_kernel(const uint32_t* __restrict__ start, int64_t rows,
+                                                                 uint32_t* __restrict__ order) {
+  const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (m >= rows) return;
+  const uint32_t t0 = start[m], t1 = start[m + 1];
+  for (uint32_t i = t0 + 1; i < t1; ++i) {
+    const uint32_t v = order[i];
+    uint32_t j = i;
+    while (j > t0 && order[j - 1] > v) {
+      order[j] = order[j - 1];
+      --j;
+    }
+    order[j] = v;
+  }
 }
 
 size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
-
-int sort_bits(int64_t rows) {
-  int bits = 1;
-  while (bits < 32 && ((int64_t)1 << bits) < rows) ++bits;
-  return bits;
-}
 
 }  // namespace
 
@@ -54,13 +146,9 @@ extern "C" {
 
 int64_t pf_knn_inverse_workspace(int G, int Ng, int k) {
   if (G <= 0 || Ng <= 0 || k <= 0) return 0;
-  const int64_t pairs = (int64_t)G * Ng * k;
-  size_t tmp = 0;
-  uint32_t* nul = nullptr;
-  if (rocprim::radix_sort_pairs(nullptr, tmp, nul, nul, nul, nul, (size_t)pairs, 0, sort_bits((int64_t)G * Ng),
-                                (hipStream_t) nullptr) != hipSuccess)
-    return -1;
-  return (int64_t)(3 * align256(sizeof(uint32_t) * (size_t)pairs) + align256(tmp));
+  const int64_t rows = (int64_t)G * Ng;
+  const int64_t nblocks = pf_cdiv(rows + 1, kScanBlock);
+  return (int64_t)(align256(sizeof(uint32_t) * (size_t)rows) + align256(sizeof(uint32_t) * (size_t)nblocks));
 }
 
 int pf_knn_inverse(const int64_t* idx, int k, int G, int Ng, uint32_t* order, uint32_t* start, void* workspace,
@@ -71,18 +159,20 @@ int pf_knn_inverse(const int64_t* idx, int k, int G, int Ng, uint32_t* order, ui
   if (pairs == 0) return PF_OK;
   PF_REQUIRE(idx && order && start && workspace && workspace_bytes >= pf_knn_inverse_workspace(G, Ng, k));
   hipStream_t s = (hipStream_t)stream;
-  const size_t arr = align256(sizeof(uint32_t) * (size_t)pairs);
   char* w = reinterpret_cast<char*>(workspace);
-  uint32_t* keys = reinterpret_cast<uint32_t*>(w);
-  uint32_t* sorted = reinterpret_cast<uint32_t*>(w + arr);
-  uint32_t* vals = reinterpret_cast<uint32_t*>(w + 2 * arr);
-  void* tmp = w + 3 * arr;
-  size_t tmp_bytes = (size_t)workspace_bytes - 3 * arr;
-  hipLaunchKernelGGL(inverse_keys_kernel, dim3((unsigned)pf_cdiv(pairs, 256)), dim3(256), 0, s, idx, pairs, k, Ng, keys,
-                     vals);
-  PF_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, sorted, vals, order, (size_t)pairs, 0, sort_bits(rows), s));
-  hipLaunchKernelGGL(inverse_starts_kernel, dim3((unsigned)pf_cdiv(pairs + 1, 256)), dim3(256), 0, s, sorted, pairs, rows,
-                     start);
+  uint32_t* cursor = reinterpret_cast<uint32_t*>(w);
+  uint32_t* sums = reinterpret_cast<uint32_t*>(w + align256(sizeof(uint32_t) * (size_t)rows));
+  const int64_t n = rows + 1;                                  // start[rows] = pairs closes the last list
+  const int nblocks = (int)pf_cdiv(n, kScanBlock);
+  const unsigned pb = (unsigned)pf_cdiv(pairs, 256);
+  hipLaunchKernelGGL(inverse_zero_kernel, dim3((unsigned)(pf_cdiv(n, 256) > 2048 ? 2048 : pf_cdiv(n, 256))), dim3(256), 0, s,
+                     start, n, cursor, rows);
+  hipLaunchKernelGGL(inverse_count_kernel, dim3(pb), dim3(256), 0, s, idx, pairs, k, Ng, start);
+  hipLaunchKernelGGL(scan_block_sums_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, start, n, sums);
+  hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, s, sums, nblocks);
+  hipLaunchKernelGGL(scan_blocks_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, start, n, sums);
+  hipLaunchKernelGGL(inverse_fill_kernel, dim3(pb), dim3(256), 0, s, idx, pairs, k, Ng, start, cursor, order);
+  hipLaunchKernelGGL(inverse_sort_lists_kernel, dim3((unsigned)pf_cdiv(rows, 256)), dim3(256), 0, s, start, rows, order);
   return pf_launch_status();
 }
 

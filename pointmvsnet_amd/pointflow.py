@@ -1014,8 +1014,6 @@ def knn_inverse(idx, G, Ng, k):
     order = torch.empty((G * Ng * k,), dtype=torch.int32, device=dev)
     start = torch.empty((G * Ng + 1,), dtype=torch.int32, device=dev)
     nbytes = int(_lib.load().pf_knn_inverse_workspace(int(G), int(Ng), int(k)))
-    if nbytes < 0:
-        raise RuntimeError("pf_knn_inverse_workspace failed")
     work = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=dev)
     _lib.call("pf_knn_inverse", _lib.ptr(idx), int(k), int(G), int(Ng), _lib.ptr(order), _lib.ptr(start), _lib.ptr(work),
               nbytes, _lib.stream(), algo_bytes=8.0 * G * Ng * k * 4)
