@@ -396,7 +396,11 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         preds = run_step(args.warmup + k)
-    issued = time.perf_counter() - t0            # host-side time to enqueue every step (diagnostic only)
+    # wall time until the last step is ENQUEUED (diagnostic only).  Not the host's cost: a lane's pinned constant block is
+    # refilled only after its previous upload has run, which queues behind the lane's previous replay, so the enqueue
+    # loop is paced by the GPU (one replay queued per lane); the host's own share is ~0.1 ms of camera algebra + ~0.3 ms
+    # of copies and graph launch per scene (profiles/r03b_lanes_queues.md)
+    issued = time.perf_counter() - t0
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -523,7 +527,7 @@ def main():
                    "PointMVSNet.forward(isFlow=True, isTest=True), BatchNorm in train mode (test.py:58)"},
         "execution": train_execution if training else execution,
         "route": args.route,
-        "host_issue_ms_per_depth_map": issued / (args.steps * sps) * 1e3,
+        "enqueue_wall_ms_per_depth_map": issued / (args.steps * sps) * 1e3,
         "lane_placement_probe_maps_per_s": lane_probe,
         "gap_probe": gap_probe,
         "stage_timeline_us": stage_timeline,
