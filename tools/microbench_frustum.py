@@ -1,4 +1,4 @@
-"""Micro-benchmark of the coarse warp (pf_frustum_variance_cl_f32) on the BASELINE shapes; PF_FV_LDS=0/1 A/B."""
+"""Micro-benchmark of the coarse warp (pf_frustum_variance_cl_f32) on the BASELINE shapes (cfg 2 / 3 / 5)."""
 import os
 import sys
 

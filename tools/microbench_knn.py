@@ -30,16 +30,6 @@ for G in (1, 4):
     zz, yy, xx = torch.meshgrid(torch.arange(5.0), torch.arange(64.0), torch.arange(80.0), indexing="ij")
     base = torch.stack([xx * 1.7, yy * 1.7, 600 + zz * 2.1 + 0.01 * xx], 0)
     xyz = (base.unsqueeze(0) + 0.3 * torch.randn(G, 3, 5, 64, 80)).to(dev).contiguous()
-    ref = None
-    line = "G=%d:" % G
-    for v, name in ((0, "centre-out"), (1, "split"), (2, "raster")):
-        if v:
-            os.environ["PF_KNN_VARIANT"] = str(v)
-        else:
-            os.environ.pop("PF_KNN_VARIANT", None)
-        idx = knn_lattice(xyz, 5, 16)
-        if ref is None:
-            ref = idx
-        line += "  %s %.1f us%s" % (name, timeit(lambda: knn_lattice(xyz, 5, 16)), "" if torch.equal(idx, ref) else " (DIFF)")
-    print(line, flush=True)
-os.environ.pop("PF_KNN_VARIANT", None)
+    print("G=%d: sorting-network kNN (codes + int64 indices) %.1f us, codes only %.1f us"
+          % (G, timeit(lambda: knn_lattice(xyz, 5, 16, with_codes=True)),
+             timeit(lambda: knn_lattice(xyz, 5, 16, with_codes=True, with_idx=False))), flush=True)
