@@ -1,5 +1,4 @@
-"""Micro-benchmark of pf_knn_lattice_f32 on the two flow lattices of cfg2 (G x 5 x 64 x 80 points, window 5, k 16):
-centre-out scan (default), split scan (PF_KNN_VARIANT=1), raster scan (=2); results must be identical."""
+"""Micro-benchmark of pf_knn_lattice_f32 on the two flow lattices of cfg2 (G x 5 x 64 x 80 points, window 5, k 16)."""
 import os
 import sys
 
