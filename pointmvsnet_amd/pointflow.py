@@ -554,21 +554,23 @@ def conv2d_wide_preferred(conv):
     return conv2d_wide_supported(conv)
 
 
+def _pack_conv2d_wide(weight):
+    cout, cin, k, _ = weight.shape
+    if cout <= 16:
+        cinp = (cin + 3) // 4 * 4
+        full = torch.zeros((k, k, cinp, 16), dtype=_F32, device=weight.device)
+        full[:, :, :cin, :cout] = weight.detach().to(_F32).permute(2, 3, 1, 0)
+        return full.view(k, k, 4, cinp // 4, 16).permute(0, 1, 2, 4, 3).contiguous()
+    w = weight.detach().to(_F32).permute(2, 3, 1, 0).reshape(k, k, cin // 8, 2, 4, cout)
+    return w.permute(0, 1, 2, 3, 5, 4).contiguous()
+
+
 def pack_conv2d_wide_weight(weight):
     """(Cout,Cin,K,K) -> (K, K, Cin/8, 2, Cout, 4): [kh][kw][kc][h][co][j] = w[co][8 kc + 4 h + j][kh][kw]
     (Cout 32 / 64: 32x32x2 MFMA), or, for Cout = 8 / 16 (16x16x4 MFMA), (K, K, 4, 16, Cin'/4) with Cin' = Cin
     rounded up to 4: [kh][kw][kq][co][j] = w[co][(Cin'/4) kq + j][kh][kw], zero where co >= Cout or the channel
-    does not exist."""
-    def make():
-        cout, cin, k, _ = weight.shape
-        if cout <= 16:
-            cinp = (cin + 3) // 4 * 4
-            full = torch.zeros((k, k, cinp, 16), dtype=_F32, device=weight.device)
-            full[:, :, :cin, :cout] = weight.detach().to(_F32).permute(2, 3, 1, 0)
-            return full.view(k, k, 4, cinp // 4, 16).permute(0, 1, 2, 4, 3).contiguous()
-        w = weight.detach().to(_F32).permute(2, 3, 1, 0).reshape(k, k, cin // 8, 2, 4, cout)
-        return w.permute(0, 1, 2, 3, 5, 4).contiguous()
-    return _cached_pack(("c2w", id(weight)), (weight,), make)
+    does not exist.  Cached per weight (see the packed-weight cache above)."""
+    return _cached_pack(("c2w", id(weight)), (weight,), lambda: _pack_conv2d_wide(weight))
 
 
 def conv2d_wide(x, conv, in_affine, samples_per_stat, want_stats, channel_last_out=False):
@@ -597,8 +599,8 @@ class AffineSets(object):
     (sets * G, C) scale / shift rows -- set s owns rows [s G, (s + 1) G) -- and, while nobody has asked for the rows,
     one LazyAffine per set whose consumer resolves it (pf_conv2d_wide_sets_f32's ``in_bn`` array)."""
 
-    def __init__(self, scale, shift, lazies=None):
-        self.scale, self.shift, self.lazies = scale, shift, lazies
+    def __init__(self, scale, shift, sets, lazies=None):
+        self.scale, self.shift, self.sets, self.lazies = scale, shift, int(sets), lazies
 
     def split(self):
         """(scale, shift, in_bn array) for the consuming launch."""
@@ -620,14 +622,14 @@ class AffineSets(object):
 
     def rows_of(self, s):
         sc, sh = self.rows()
-        G = sc.shape[0] // (len(self.lazies) if self.lazies is not None else 2)
+        G = sc.shape[0] // self.sets
         return sc[s * G:(s + 1) * G], sh[s * G:(s + 1) * G]
 
 
 def pack_conv2d_wide_weight_sets(weights):
     """The packed weights of ``pack_conv2d_wide_weight`` for several same-shaped convolutions, stacked (sets, ...)."""
     def make():
-        return torch.stack([pack_conv2d_wide_weight(w) for w in weights]).contiguous()
+        return torch.stack([_pack_conv2d_wide(w) for w in weights]).contiguous()
     return _cached_pack(("c2ws",) + tuple(id(w) for w in weights), tuple(weights), make)
 
 
@@ -647,7 +649,7 @@ def conv2d_wide_stacked(x, convs, want_stats):
     Ho, Wo = (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
     weights = tuple(c.weight for c in convs)
     wp = _cached_pack(("c2wst",) + tuple(id(w) for w in weights), weights,
-                      lambda: pack_conv2d_wide_weight(torch.cat([w.detach() for w in weights], dim=0)))
+                      lambda: _pack_conv2d_wide(torch.cat([w.detach() for w in weights], dim=0)))
     y = torch.empty((N, Cout, Ho, Wo), dtype=_F32, device=x.device)
     partials = None
     if want_stats:
@@ -709,9 +711,9 @@ def bn_affine_rows_sets(y, bns, samples_per_stat, partials, lazy, interleaved=Fa
         bump_counter(bn, G)
     if lazy and LAZY_BN and samples_per_stat * partials.shape[1] * C <= LAZY_MAX_ELEMS:
         lazies = [LazyAffine(j, (partials, scale, shift) + _bn_tensors(bn), scale, shift) for j, bn in zip(jobs, bns)]
-        return AffineSets(scale, shift, lazies)
+        return AffineSets(scale, shift, sets, lazies)
     bn_finalize_jobs(jobs)
-    return AffineSets(scale, shift)
+    return AffineSets(scale, shift, sets)
 
 
 def channel_affine_(x, affine, relu, samples_per_stat):
