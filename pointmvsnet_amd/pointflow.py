@@ -270,7 +270,7 @@ def bn_affine(bn, partials, col0, C, count, unbias_n, G, groups_per_stat, scale,
 
 
 # PF_LAZY_BN=1 (default): a train-mode BatchNorm whose statistics rows are few (persistent GEMM blocks, the small
-# maps of conv2d_wide) and whose consumer can resolve it (pf_bn_resolve, csrc/pf_bn_tail.h) gets NO finalize launch
+# maps of conv2d_wide) and whose consumer can resolve it (pf_bn_resolve, csrc/pf_bn_resolve.h) gets NO finalize launch
 # on the critical path: the consumer's blocks compute (scale, shift) themselves, and the running statistics are
 # updated by batched finalize launches on a side stream (flush_lazy_stats / join at flush_counters).
 LAZY_BN = int(_os.environ.get("PF_LAZY_BN", "1"))
