@@ -560,9 +560,16 @@ __global__ __launch_bounds__(256) void conv2d_wide16_kernel(const float* __restr
   }
 }
 
-// Blocks per sample of the 16-wide kernel: two tiles per block (1 / 3 / 4 measured slower, profiles/r02aj_small_ab.txt),
-// walked with a stride of the block count so that neighbouring blocks stay on neighbouring tiles.
-int wide16_blocks(int tiles) { return (tiles + 1) / 2; }
+// Blocks per sample of the 16-wide kernel: a block walks PF_W16_TPB tiles with a stride of the block count (neighbouring
+// blocks stay on neighbouring tiles).  Two tiles per block were best for ONE forward at a time (1 / 3 / 4 slower,
+// profiles/r02aj_small_ab.txt: too few blocks on the small maps); with four scene lanes in flight the chip is full
+// anyway and the ~190-instruction block prologue (vector instructions cost matrix time, profiles/r03j) is worth
+// amortising: 2 / 3 / 4 / 5 / 8 tiles per block = 1 065 / 1 078 / 1 083 depth maps/s on one box, 994 / - / 1 015 / 1 016 /
+// 1 015 on a slower one (profiles/r03l_block_policies_ab.log).
+#ifndef PF_W16_TPB
+#define PF_W16_TPB 4
+#endif
+int wide16_blocks(int tiles) { return (tiles + PF_W16_TPB - 1) / PF_W16_TPB; }
 
 template <int KS, int STRIDE, int CIN, int COUT, int AFFINE>
 int launch_wide16_mode(const float* x, const float* wp, float* y, WideGeom g, int64_t N, const float* in_scale,

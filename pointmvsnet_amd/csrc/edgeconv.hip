@@ -1146,7 +1146,10 @@ extern "C" {
 int pf_stat_blocks(int G, int Ng) {
   if (G <= 0 || Ng <= 0) return 0;
   const int tiles = (Ng + TILE - 1) / TILE;
-  int cap = 4096 / G;
+#ifndef PF_STAT_CAP
+#define PF_STAT_CAP 4096
+#endif
+  int cap = PF_STAT_CAP / G;
   cap = cap < 32 ? 32 : cap;
   if (tiles <= cap) return tiles;
   const int per = (tiles + cap - 1) / cap;
@@ -1159,7 +1162,10 @@ int pf_stat_blocks(int G, int Ng) {
 int pf_gemm_blocks(int G, int Ng) {
   if (G <= 0 || Ng <= 0) return 0;
   const int tiles = (Ng + GT - 1) / GT;
-  int cap = 512 / G;                                  // persistent GEMM blocks over all groups (measured: fewer is slower)
+#ifndef PF_GEMM_CAP
+#define PF_GEMM_CAP 512
+#endif
+  int cap = PF_GEMM_CAP / G;                          // persistent GEMM blocks over all groups (measured: fewer is slower)
   cap = cap < 16 ? 16 : cap;
   if (tiles <= cap) return tiles;
   const int per = (tiles + cap - 1) / cap;
