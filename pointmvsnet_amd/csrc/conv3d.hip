@@ -375,7 +375,12 @@ int pick_td(int64_t Cin, int64_t Cout, int64_t Di, int64_t Hi, int64_t Wi, int s
 
 int blocks_for(const ConvGeom& g) {
   const int64_t total = (int64_t)g.tiles_d * g.tiles_h * g.tiles_w;
-  return (int)(total < 2048 ? total : 2048);
+#ifndef PF_CONV3D_CAP
+#define PF_CONV3D_CAP 2048
+#endif
+  if (total <= PF_CONV3D_CAP) return (int)total;
+  const int64_t per = (total + PF_CONV3D_CAP - 1) / PF_CONV3D_CAP;      // every block the same number of tiles
+  return (int)((total + per - 1) / per);
 }
 
 template <int NT, int STRIDE, int TD, int MINW>

@@ -238,7 +238,12 @@ PairGeom make_pair_geom(int64_t Cin, int64_t Cout, int64_t D, int64_t H, int64_t
 
 int pair_blocks(const PairGeom& g) {
   const int64_t total = (int64_t)g.tiles_d * g.tiles_h * g.tiles_w;
-  return (int)(total < 2048 ? total : 2048);
+#ifndef PF_CONV3D_CAP
+#define PF_CONV3D_CAP 2048
+#endif
+  if (total <= PF_CONV3D_CAP) return (int)total;
+  const int64_t per = (total + PF_CONV3D_CAP - 1) / PF_CONV3D_CAP;      // every block the same number of tiles
+  return (int)((total + per - 1) / per);
 }
 
 }  // namespace
