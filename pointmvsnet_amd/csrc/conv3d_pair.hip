@@ -221,7 +221,13 @@ __global__ __launch_bounds__(256, MINW) void conv3d_k3_pair_kernel(const float* 
   }
 }
 
-constexpr int kPairTD = 2;
+#ifndef PF_PAIR_TD
+#define PF_PAIR_TD 2
+#endif
+#ifndef PF_PAIR_MINW
+#define PF_PAIR_MINW 3
+#endif
+constexpr int kPairTD = PF_PAIR_TD;
 
 PairGeom make_pair_geom(int64_t Cin, int64_t Cout, int64_t D, int64_t H, int64_t W) {
   PairGeom g;
@@ -266,7 +272,7 @@ int pf_conv3d_k3_pair_f32(const float* x, const float* wp, float* y, int64_t N, 
   constexpr size_t lds_bytes = pair_lds_bytes<kPairTD>();
   static_assert(lds_bytes <= 64 * 1024, "pair tile must fit the default dynamic LDS limit");
   dim3 grid((unsigned)pair_blocks(g), (unsigned)N);
-  hipLaunchKernelGGL((conv3d_k3_pair_kernel<kPairTD, 3>), grid, dim3(256), lds_bytes, (hipStream_t)stream, x, wp, y, g,
+  hipLaunchKernelGGL((conv3d_k3_pair_kernel<kPairTD, PF_PAIR_MINW>), grid, dim3(256), lds_bytes, (hipStream_t)stream, x, wp, y, g,
                      partials);
   return pf_launch_status();
 }

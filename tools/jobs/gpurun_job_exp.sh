@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_ops.py -q -x -k "tower or image_conv or conv2d" 2>&1 | tail -2
-timeout 900 python -m pytest tests/test_gpu_model.py -q -x -k "lanes or golden or reference or graphed_forward" 2>&1 | tail -2
-LIB_LIST='base tpb4new' LANES_LIST='1' bash tools/jobs/gpurun_job_libab.sh | tail -8
-cp pointmvsnet_amd/build/variants/lib_tpb4new.so pointmvsnet_amd/libpointflow_hip.so
+V=pointmvsnet_amd/build/variants
+for arm in base td3 td4 td2w2; do cp $V/lib_$arm.so pointmvsnet_amd/libpointflow_hip.so; echo "== $arm: $(timeout 200 python tools/microbench_conv3d_pair.py 2>/dev/null | tr '\n' ' ')"; done
+cp $V/lib_base.so pointmvsnet_amd/libpointflow_hip.so
+LIB_LIST='base td3 td4' LANES_LIST=4 bash tools/jobs/gpurun_job_libab.sh | tail -12
