@@ -11,7 +11,7 @@
 //   start[m] = number of pairs with key < m, m in [0, G * Ng]
 //   order    = the pair ids grouped by key, ascending inside a group: pairs of m = order[start[m] .. start[m+1])
 //
-// A counting sort in five kernel launches and nothing else -- no memset / memcpy nodes, no library call -- so the whole
+// A counting sort in seven kernel launches and nothing else -- no memset / memcpy nodes, no library call -- so the whole
 // thing can sit inside a captured hipGraph (train_step.GraphedTrainStep; rocPRIM's radix sort clears its look-back
 // state with hipMemsetAsync, and memset nodes recorded from the autograd thread are not replayed reliably, see
 // pf_common.h):  count (integer atomics: the totals do not depend on arrival order) -> exclusive scan (per-block
