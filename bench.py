@@ -65,7 +65,9 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1,
                     help="GPUs of this node; N > 1 without a torchrun environment re-launches this command under "
                          "torch.distributed.run with N ranks (one process per GPU, RCCL)")
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed steps (default 40 for the inference configurations: >= 2 s of timed region at cfg 2; "
+                         "20 for the training step)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scenes-per-step", type=int, default=None,
                     help="depth maps per step (default: 64 for cfg1/cfg2, 8 for cfg3/cfg5, 1 for the training step): a "
@@ -267,6 +269,8 @@ def main():
 
     h, w, V, D, _, img_scales, inter_scales = synthetic.CONFIGS[args.config]
     training = args.config == "cfg4"
+    if args.steps is None:
+        args.steps = 20 if training else 40
     sps = args.scenes_per_step or {"cfg1": 64, "cfg2": 64, "cfg3": 8, "cfg5": 8, "cfg4": 1}.get(args.config, 8)
     if training:
         sps = 1                                       # a training step is one scene per GPU (BASELINE configs[3])
