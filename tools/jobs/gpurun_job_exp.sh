@@ -1,9 +1,14 @@
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_model.py -q -x -k "independent_scenes or lanes" 2>&1 | tail -12
-timeout 300 python -m pytest tests/test_gpu_ops.py -q -x -k "tower" 2>&1 | tail -3
-for cfgs in "4 1" "4 2" "2 2" "2 4" "4 3" "3 2"; do set -- $cfgs
-echo "== lanes=$1 scenes-per-call=$2"
-timeout 300 python bench.py --no-cpu-baseline --calibration-steps 2 --steps 10 --scenes-per-step 48 --lanes $1 --scenes-per-call $2 2>gpurun_out/err.log | grep "^{" | tail -1 | python -c "
-import json,sys
-d=json.loads(sys.stdin.readline()); print(round(d['value'],1), round(d['ms_per_depth_map'],4))" || tail -3 gpurun_out/err.log
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; : > gpurun_out/clocks.log
+for lanes in 4 1; do
+  echo "== lanes=$lanes" >> gpurun_out/clocks.log
+  python bench.py --no-cpu-baseline --calibration-steps 1 --steps 150 --lanes $lanes > gpurun_out/clk_bench.log 2>&1 &
+  BP=$!
+  for i in $(seq 1 60); do
+    kill -0 $BP 2>/dev/null || break
+    echo "t=$i $(/opt/rocm/bin/rocm-smi --showclocks --showpower --showuse 2>/dev/null | grep -E 'sclk|Power \(W\)|GPU use' | sed 's/.*: //; s/clock level//' | tr '\n' ' ')" >> gpurun_out/clocks.log
+    sleep 0.7
+  done
+  wait $BP
+  grep "^{" gpurun_out/clk_bench.log | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('rate', round(d['value'],1))" >> gpurun_out/clocks.log
 done
+grep -v "(9[0-9]Mhz)\|(1[0-9][0-9]Mhz)" gpurun_out/clocks.log | cut -c1-160
