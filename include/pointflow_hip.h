@@ -458,6 +458,81 @@ int pf_eval_prob_filter_f32(const float* depth, const float* flow_conf, const fl
                             int iw, float flow_threshold, float init_threshold, float* dst, int flip_rows,
                             void* stream);
 
+
+/* ==== Row Z : the training step (BASELINE config 4; reference train.py:72-82) ======================================
+ * Hand-written backward for the convolution -> BatchNorm(batch statistics) -> ReLU blocks of ImageConv, VolumeConv
+ * and the flow MLP (reference nn/conv.py:24-35,62-77,108-121,197-210; networks.py:84-167; model.py:40-43), replacing
+ * ATen's convolution_backward / batch_norm backward (MIOpen / CK solvers) in the reference's loss.backward().
+ * Everything below sums in a fixed order: gradients are bit-reproducible run to run.
+ *
+ * Forward finalize that keeps what the backward needs: like pf_bn_finalize_f32, but the result is ONE tensor
+ * rows (4, S, C) = [scale | shift | mean | invstd], S = G / groups_per_stat; rows[0], rows[1] are the (S, C)
+ * in_scale / in_shift rows the forward kernels take.  Running statistics updated as by pf_bn_finalize_f32. */
+int pf_bn_train_rows_f32(const double* partials, int T, int pcols, int col0, int C, double count, double unbias_n,
+                         const float* gamma, const float* beta, float* running_mean, float* running_var,
+                         float momentum, float eps, int G, int groups_per_stat, float* rows, void* stream);
+/* BatchNorm(+ReLU) backward on planar tensors (N, C, S): g = dL/dz for z = act(y * scale + shift), y the raw
+ * convolution output, rows as above (statistic group s = n / samples_per_stat).
+ *   reduce : partials (N, pf_norm_blocks(S), C, 2) float64 = per-block (sum g', sum g' * xhat),
+ *            g' = [y * scale + shift > 0] * g when relu != 0, else g;  xhat = (y - mean) * invstd
+ *   coeffs : partials (G, T, pcols, 2) -> coef (2, S, C) = [scale * dbeta_s / count | scale * invstd * dgamma_s / count]
+ *            and dgamma[c] / dbeta[c] = sum over the S statistic groups (accumulate != 0: added to what is there)
+ *   apply  : dy = scale * g' - coef0 - coef1 * (y - mean)           (dy may alias g) */
+int pf_bn_bwd_reduce_f32(const float* g, const float* y, const float* rows, int64_t N, int64_t C, int64_t S,
+                         int samples_per_stat, int relu, double* partials, void* stream);
+int pf_bn_bwd_coeffs_f32(const double* partials, int T, int pcols, int col0, int C, double count, int G,
+                         int groups_per_stat, const float* rows, float* coef, float* dgamma, float* dbeta,
+                         int accumulate, void* stream);
+int pf_bn_bwd_apply_f32(const float* g, const float* y, const float* rows, const float* coef, float* dy, int64_t N,
+                        int64_t C, int64_t S, int samples_per_stat, int relu, void* stream);
+/* The same on point-major rows (G groups of Ng rows, ld floats per row; C in {16, 32, 64, 128} for reduce,
+ * C % 4 == 0 for apply / affine): the flow MLP's BatchNorm1d.  reduce partials: (G, pf_rows_bn_blocks(G, Ng), C, 2).
+ * pf_rows_affine_f32: z = act(y * scale + shift), the normalised activation handed on. */
+int pf_rows_bn_blocks(int G, int Ng);
+int pf_rows_bn_bwd_reduce_f32(const float* g, int64_t ldg, const float* y, int64_t ldy, const float* rows, int C, int G,
+                              int Ng, int groups_per_stat, int relu, double* partials, void* stream);
+int pf_rows_bn_bwd_apply_f32(const float* g, int64_t ldg, const float* y, int64_t ldy, const float* rows,
+                             const float* coef, float* dy, int64_t ldo, int C, int G, int Ng, int groups_per_stat,
+                             int relu, void* stream);
+int pf_rows_affine_f32(const float* y, int64_t ldy, const float* rows, float* z, int64_t ldz, int C, int G, int Ng,
+                       int groups_per_stat, int relu, void* stream);
+
+/* Weight gradient of a convolution on the f32 matrix cores (csrc/conv_wgrad.hip), one formulation for nn.Conv2d /
+ * nn.Conv3d / nn.ConvTranspose3d / the 1x1 convolutions over points:
+ *     dw[cg][cx][kd][kh][kw] = sum_{n, o} gr[n, cg, o] * x[n, cx, o * stride + k - pad]           (zero outside x)
+ * gr (N, Cg, Do, Ho, Wo) lives on the COARSE grid, x (N, Cx, Di, Hi, Wi) on the FINE one (2-D: Do = Di = KD = 1):
+ *   convolution            gr = dL/dy, x = the layer input        -> dw in (Cout, Cin, k...) order;
+ *   transposed convolution gr = the layer input, x = dL/dy (stride 2, pad 1) -> dw in (Cin, Cout, k...) order.
+ * x_scale / x_shift (N / x_samples_per_stat, Cx) or NULL: x holds a RAW convolution output whose BatchNorm + ReLU is
+ * pending; relu(x * scale + shift) is applied while x is staged (zero padding after it).
+ * workspace: pf_conv_wgrad_workspace(...) bytes of device scratch (per-split partial gradients, added in split
+ * order: no atomics).  accumulate != 0: dw += instead of dw =.  Limits: kernel extents <= 7, taps/16-channel block
+ * <= 28 column tiles (27 taps x 16 channels, 25 x 16, ...); PF_ERR_UNSUPPORTED otherwise. */
+int64_t pf_conv_wgrad_workspace(int64_t N, int64_t Cg, int64_t Cx, int64_t Do, int64_t Ho, int64_t Wo, int64_t Di,
+                                int64_t Hi, int64_t Wi, int KD, int KH, int KW, int stride);
+int pf_conv_wgrad_f32(const float* gr, const float* x, float* dw, int64_t N, int64_t Cg, int64_t Cx, int64_t Do,
+                      int64_t Ho, int64_t Wo, int64_t Di, int64_t Hi, int64_t Wi, int KD, int KH, int KW, int stride,
+                      int pd, int ph, int pw, const float* x_scale, const float* x_shift, int x_samples_per_stat,
+                      void* workspace, int64_t workspace_bytes, int accumulate, void* stream);
+/* The same for a 1x1 convolution over point-major rows: dw[cg][cx] = sum_p gr[p, cg] * act(x[p, cx]);
+ * gr (P, ldg), x (P, ldx), Cg % 4 == Cx % 4 == 0; x_scale / x_shift rows (P / x_rows_per_stat, Cx) or NULL. */
+int64_t pf_rows_wgrad_workspace(int64_t P, int Cg, int Cx);
+int pf_rows_wgrad_f32(const float* gr, int64_t ldg, const float* x, int64_t ldx, float* dw, int64_t P, int Cg, int Cx,
+                      const float* x_scale, const float* x_shift, int64_t x_rows_per_stat, void* workspace,
+                      int64_t workspace_bytes, int accumulate, void* stream);
+
+/* Data gradient of ImageConv's 5x5 / stride 2 / pad 2 convolutions (reference networks.py:93,98,103), i.e.
+ * ConvTranspose2d(5, stride 2, pad 2, output_padding 1): dy (N, Cout, Ho, Wo) -> dx (N, Cin, 2 Ho, 2 Wo);
+ * wp = the convolution's weight W (Cout, Cin, 5, 5) packed (Cout/4, 25 taps [kh][kw], 4, 16*ceil(Cin/16)):
+ * wp[g][tap][k][ci] = W[4g + k][ci][kh][kw], zero padded.  Cout % 4 == 0, Cin <= 32.  (csrc/conv_dgrad.hip) */
+int pf_deconv2d_k5s2_supported(int64_t Cout, int64_t Cin);
+int pf_deconv2d_k5s2_f32(const float* dy, const float* wp, float* dx, int64_t N, int64_t Cout, int64_t Cin, int64_t Ho,
+                         int64_t Wo, void* stream);
+/* 3x3x3 / pad 1 / stride 1 conv3d of a ONE-channel volume x (N, 1, D, H, W) with w (Cout <= 8, 27): the data
+ * gradient of VolumeConv's 8 -> 1 output layer (reference networks.py:147) when w holds the flipped kernels. */
+int pf_conv3d_k3_c1_f32(const float* x, const float* w, float* y, int64_t N, int64_t Cout, int64_t D, int64_t H,
+                        int64_t W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -95,6 +95,21 @@ PROTOTYPES = {
     "pf_eval_flow_prob_f32": ([_vp, _vp, _i, _i, _i, _vp], _i),
     "pf_eval_prob_filter_f32": ([_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _i, _vp], _i),
     "pf_softargmin_prob_f32": ([_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp], _i),
+    "pf_bn_train_rows_f32": ([_vp, _i, _i, _i, _i, _d, _d, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _vp, _vp], _i),
+    "pf_bn_bwd_reduce_f32": ([_vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _vp, _vp], _i),
+    "pf_bn_bwd_coeffs_f32": ([_vp, _i, _i, _i, _i, _d, _i, _i, _vp, _vp, _vp, _vp, _i, _vp], _i),
+    "pf_bn_bwd_apply_f32": ([_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _vp], _i),
+    "pf_rows_bn_blocks": ([_i, _i], _i),
+    "pf_rows_bn_bwd_reduce_f32": ([_vp, _i64, _vp, _i64, _vp, _i, _i, _i, _i, _i, _vp, _vp], _i),
+    "pf_rows_bn_bwd_apply_f32": ([_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp], _i),
+    "pf_rows_affine_f32": ([_vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp], _i),
+    "pf_conv_wgrad_workspace": ([_i64] * 9 + [_i] * 4, _i64),
+    "pf_conv_wgrad_f32": ([_vp, _vp, _vp] + [_i64] * 9 + [_i] * 7 + [_vp, _vp, _i, _vp, _i64, _i, _vp], _i),
+    "pf_rows_wgrad_workspace": ([_i64, _i, _i], _i64),
+    "pf_rows_wgrad_f32": ([_vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _vp, _vp, _i64, _vp, _i64, _i, _vp], _i),
+    "pf_deconv2d_k5s2_supported": ([_i64, _i64], _i),
+    "pf_deconv2d_k5s2_f32": ([_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp], _i),
+    "pf_conv3d_k3_c1_f32": ([_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp], _i),
 }
 
 _lib = None

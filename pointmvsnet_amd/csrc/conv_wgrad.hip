@@ -1,0 +1,469 @@
+// Row Z (training step, BASELINE config 4): WEIGHT GRADIENTS of every convolution of the step on the f32 matrix
+// cores -- ImageConv's 2-D convolutions (reference networks.py:84-124), VolumeConv's 3-D convolutions and transposed
+// convolutions (networks.py:127-167), and the 1x1 convolutions of EdgeConv / the flow MLP (networks.py:13-14,
+// model.py:40-43) -- replacing the library kernels ATen's convolution_backward reaches (reference train.py:80; the
+// MIOpen / CK weight-gradient solvers took 84 of the step's 117 ms, profiles/r02al_cfg4_last_steps_eager.md).
+//
+// One formulation for all of them.  With a COARSE-grid tensor Gr (N, Cg, Do, Ho, Wo) and a FINE-grid tensor X
+// (N, Cx, Di, Hi, Wi):
+//       dW[cg][cx][kd][kh][kw] = sum_{n, o} Gr[n, cg, o] * X[n, cx, o * stride + k - pad]        (zero outside X)
+//   * convolution  y = conv(x, W (Cout, Cin, k..)):   Gr = dL/dy, X = x            -> dW in nn.ConvNd's layout;
+//   * transposed convolution (stride 2, pad 1, output_padding 1)  y = convT(x, W (Cin, Cout, k..)):
+//                                                      Gr = x,    X = dL/dy        -> dW in nn.ConvTransposeNd's layout
+//     (y[co][2 i - 1 + k] += x[ci][i] * W[ci][co][k], so dW[ci][co][k] = sum_i x[ci][i] * dy[co][2 i - 1 + k]);
+//   * 1x1 convolution over points: the same with one tap, on point-major rows (P, ld).
+// As a GEMM: M = Cg rows, N = Cx * taps columns, reduction over (sample, position): a reduction 10^4..10^6 long into a
+// tiny output.  Mapping:
+//   * a 256-thread block owns a slice of the positions (`split`), a block of input channels (blockIdx.y) and up to
+//     64 rows (blockIdx.z).  It walks its position tiles (TD x TH x 16) with ALL its accumulators resident in
+//     registers: acc[row tile][column tile] of v_mfma_f32_16x16x4_f32, rows = 16 channels of Gr, columns = 16
+//     (channel, tap) pairs, reduction step = 4 consecutive positions along W;
+//   * per tile the block stages the Gr tile [cg][position] and the X patch [cx][(TD-1)s+KD][(TH-1)s+KH][15s+KW]
+//     (zero outside the tensor, optional pending BatchNorm + ReLU of x applied on the way) into LDS; a lane's B operand
+//     for column (cx, tap) is the patch read at a per-lane constant offset + the position, so no im2col exists anywhere;
+//   * column tiles are dealt round-robin to the four waves; every wave reads the A operands (Gr) of a position row
+//     once and reuses them for all its column tiles;
+//   * at the end each block writes its partial dW to a workspace (split, Cg, Cx, taps); a second kernel adds the
+//     splits in split order: plain stores, fixed order -- the gradient is bit-reproducible run to run (the library's
+//     split-K solvers use float atomics).
+// Bound: fp32 MFMA (2 * taps * Cg * Cx flop per position against 4 * (Cg + Cx) bytes); the 8-channel layers fill half
+// of the 16 MFMA rows.
+#include "pf_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kMaxNTW = 7;            // column tiles per wave (27 taps x 16 channels = 27 tiles over 4 waves)
+
+struct WgGeom {
+  int N, Cg, Cx;
+  int Do, Ho, Wo, Di, Hi, Wi;
+  int KD, KH, KW, T;
+  int pd, ph, pw;
+  int TD, TH, lgTH, lgR;              // tile rows R = TD * TH (a power of two)
+  int ID, IH, IW, IWP, XPLANE, GPLANE;
+  int CBP, lgCBP, TPT, TPC, CBLK, NTILES;
+  int tiles_d, tiles_h, tiles_w;
+  int total_tiles, per_split;
+  int gs_floats, xs_floats, ntasks;
+  // pending BatchNorm + ReLU of X: relu(x * scale[s, c] + shift[s, c]); s = n / x_sps (planar) or p / x_pps (rows)
+  const float* x_scale;
+  const float* x_shift;
+  int x_sps;
+  int64_t x_pps;
+  // point-major rows (taps == 1): Gr (P, ldg), X (P, ldx)
+  int point_major;
+  int64_t P, ldg, ldx;
+};
+
+template <int MT, int STRIDE>
+__global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ Gr, const float* __restrict__ X,
+                                                    float* __restrict__ part, WgGeom g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* gs = lds;                                    // [MT*16][GPLANE]
+  float* xs = lds + g.gs_floats;                      // [CBLK*CBP][XPLANE]
+  int* tab = reinterpret_cast<int*>(xs + g.xs_floats);   // [ntasks][4]: global offset, LDS offset, dz, hy | c << 16
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int li = lane & 15, lk = lane >> 4;
+  const int split = blockIdx.x;
+  const int cbtot = g.CBLK * g.CBP;
+  const int ci0 = blockIdx.y * cbtot;
+  const int cg0 = blockIdx.z * 64;
+  const int R = g.TD * g.TH;
+  const int plane_i = g.Hi * g.Wi, vol_i = plane_i * g.Di;
+  const int plane_o = g.Ho * g.Wo, vol_o = plane_o * g.Do;
+
+  // per-lane B offsets of this wave's column tiles: column li of tile nt = (channel sub-block, tap group)
+  int boff[kMaxNTW];
+#pragma unroll
+  for (int t = 0; t < kMaxNTW; ++t) {
+    const int nt = wave + 4 * t;
+    int off = 0;
+    if (nt < g.NTILES) {
+      const int sub = nt / g.TPC, tg = nt - sub * g.TPC;
+      const int cil = li & (g.CBP - 1), tl = li >> g.lgCBP;
+      int tap = tg * g.TPT + tl;
+      tap = tap < g.T ? tap : g.T - 1;                 // (a padded column: computed, never stored)
+      const int kd = tap / (g.KH * g.KW);
+      const int r2 = tap - kd * (g.KH * g.KW);
+      const int kh = r2 / g.KW, kw = r2 - kh * g.KW;
+      off = (sub * g.CBP + cil) * g.XPLANE + (kd * g.IH + kh) * g.IWP + kw + 4 * lk * STRIDE;
+    }
+    boff[t] = off;
+  }
+  const int aoff = li * g.GPLANE + 4 * lk;
+
+  f32x4 acc[MT][kMaxNTW];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int t = 0; t < kMaxNTW; ++t) acc[m][t] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+
+  if (!g.point_major) {
+    // row tasks of the X patch: (channel, dz, hy) -> one row of IW floats; the same for every tile of the block
+    const int rows_per_c = g.ID * g.IH;
+    for (int task = tid; task < g.ntasks; task += 256) {
+      const int c = task / rows_per_c;
+      const int rr = task - c * rows_per_c;
+      const int dz = rr / g.IH, hy = rr - dz * g.IH;
+      tab[task * 4 + 0] = c * vol_i + dz * plane_i + hy * g.Wi;
+      tab[task * 4 + 1] = c * g.XPLANE + (dz * g.IH + hy) * g.IWP;
+      tab[task * 4 + 2] = dz;
+      tab[task * 4 + 3] = hy | (c << 16);
+    }
+  }
+
+  const int t_lo = split * g.per_split;
+  const int t_hi = min(g.total_tiles, t_lo + g.per_split);
+  for (int tile = t_lo; tile < t_hi; ++tile) {
+    __syncthreads();                    // the previous tile's MFMA reads (and the table) are done
+    if (g.point_major) {
+      // R * 16 consecutive points; thread = (point, 4 channels): coalesced 16-byte row pieces, transposed into LDS
+      const int PT = R * 16;
+      const int64_t p0 = (int64_t)tile * PT;
+      const int qg = MT * 4;
+      for (int e = tid; e < PT * qg; e += 256) {
+        const int pt = e / qg, c4 = (e - pt * qg) * 4;
+        const int64_t p = p0 + pt;
+        f32x4 v = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        if (p < g.P && cg0 + c4 < g.Cg) v = *reinterpret_cast<const f32x4*>(Gr + p * g.ldg + cg0 + c4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gs[(c4 + j) * g.GPLANE + pt] = v[j];
+      }
+      const int qx = cbtot >> 2;
+      for (int e = tid; e < PT * qx; e += 256) {
+        const int pt = e / qx, c4 = (e - pt * qx) * 4;
+        const int64_t p = p0 + pt;
+        f32x4 v = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        if (p < g.P && ci0 + c4 < g.Cx) {
+          v = *reinterpret_cast<const f32x4*>(X + p * g.ldx + ci0 + c4);
+          if (g.x_scale != nullptr) {
+            const int64_t so = (p / g.x_pps) * g.Cx + ci0 + c4;
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(g.x_scale + so);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(g.x_shift + so);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(v[j], sc[j], sh[j]), 0.0f);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xs[(c4 + j) * g.XPLANE + pt] = v[j];
+      }
+    } else {
+      int rest = tile;
+      const int tw = rest % g.tiles_w;
+      rest /= g.tiles_w;
+      const int th = rest % g.tiles_h;
+      rest /= g.tiles_h;
+      const int td = rest % g.tiles_d;
+      const int n = rest / g.tiles_d;
+      const int od0 = td * g.TD, oh0 = th * g.TH, ow0 = tw * 16;
+      const int id0 = od0 * STRIDE - g.pd, ih0 = oh0 * STRIDE - g.ph, iw0 = ow0 * STRIDE - g.pw;
+      // Gr tile: 16-lane groups, one row of 16 positions along W per task
+      {
+        const int grp = tid >> 4, l16 = tid & 15;
+        const float* gb = Gr + (int64_t)n * g.Cg * vol_o;
+        const int ow = ow0 + l16;
+        for (int task = grp; task < MT * 16 * R; task += 16) {
+          const int cgl = task >> g.lgR, r = task & (R - 1);
+          const int d = r >> g.lgTH, h = r & (g.TH - 1);
+          const int cg = cg0 + cgl, od = od0 + d, oh = oh0 + h;
+          const bool ok = cg < g.Cg && od < g.Do && oh < g.Ho && ow < g.Wo;
+          gs[cgl * g.GPLANE + r * 16 + l16] = ok ? gb[(int64_t)cg * vol_o + od * plane_o + oh * g.Wo + ow] : 0.0f;
+        }
+      }
+      // X patch: 32-lane groups, one patch row per task
+      {
+        const int grp = tid >> 5, l32 = tid & 31;
+        const float* xb = X + ((int64_t)n * g.Cx + ci0) * vol_i;
+        const int origin = id0 * plane_i + ih0 * g.Wi + iw0;
+        const int stat = n / g.x_sps;
+        for (int task = grp; task < g.ntasks; task += 8) {
+          const int4 e = *reinterpret_cast<const int4*>(tab + task * 4);
+          const int c = e.w >> 16, hy = e.w & 0xffff;
+          const int id = id0 + e.z, ih = ih0 + hy;
+          const bool rowok = id >= 0 && id < g.Di && ih >= 0 && ih < g.Hi && ci0 + c < g.Cx;
+          float sc = 1.0f, sh = 0.0f;
+          const bool aff = g.x_scale != nullptr && rowok;
+          if (aff) {
+            sc = g.x_scale[(int64_t)stat * g.Cx + ci0 + c];
+            sh = g.x_shift[(int64_t)stat * g.Cx + ci0 + c];
+          }
+          for (int w = l32; w < g.IW; w += 32) {
+            const int iw = iw0 + w;
+            float v = 0.0f;
+            if (rowok && iw >= 0 && iw < g.Wi) {
+              v = xb[e.x + origin + w];
+              if (aff) v = fmaxf(fmaf(v, sc, sh), 0.0f);
+            }
+            xs[e.y + w] = v;
+          }
+        }
+      }
+    }
+    __syncthreads();
+
+    for (int r = 0; r < R; ++r) {
+      const int d = r >> g.lgTH, h = r & (g.TH - 1);
+      float a[MT][4];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const float* ap = gs + m * 16 * g.GPLANE + aoff + r * 16;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[m][u] = ap[u];
+      }
+      const int rowoff = ((d * STRIDE) * g.IH + h * STRIDE) * g.IWP;
+#pragma unroll
+      for (int t = 0; t < kMaxNTW; ++t) {
+        if (wave + 4 * t < g.NTILES) {                // wave-uniform
+          const float* bp = xs + boff[t] + rowoff;
+          float b[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) b[u] = bp[u * STRIDE];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+              acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][u], b[u], acc[m][t], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // partial dW of this block: C/D layout col = lane & 15 (column of the tile), row = (lane >> 4) * 4 + r (channel of Gr)
+  float* pb = part + (int64_t)split * g.Cg * g.Cx * g.T;
+#pragma unroll
+  for (int t = 0; t < kMaxNTW; ++t) {
+    const int nt = wave + 4 * t;
+    if (nt >= g.NTILES) continue;
+    const int sub = nt / g.TPC, tg = nt - sub * g.TPC;
+    const int cil = li & (g.CBP - 1), tl = li >> g.lgCBP;
+    const int tap = tg * g.TPT + tl;
+    const int ci = ci0 + sub * g.CBP + cil;
+    if (tap >= g.T || ci >= g.Cx) continue;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int cg = cg0 + m * 16 + lk * 4 + r;
+        if (cg < g.Cg) pb[((int64_t)cg * g.Cx + ci) * g.T + tap] = acc[m][t][r];
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                           int64_t elems, int splits, int accumulate) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= elems) return;
+  float s = accumulate ? dw[i] : 0.0f;
+  for (int k = 0; k < splits; ++k) s += part[(int64_t)k * elems + i];
+  dw[i] = s;
+}
+
+int ilog2(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+
+constexpr size_t kLdsSoft = 64 * 1024;
+constexpr size_t kLdsHard = 96 * 1024;
+constexpr int64_t kWorkspaceCap = 32ll << 20;     // bytes of split partials a launch may use
+
+struct WgPlan {
+  WgGeom g;
+  int MT, cblocks, mblocks, splits;
+  size_t lds_bytes;
+  bool ok;
+};
+
+WgPlan make_plan(int64_t N, int64_t Cg, int64_t Cx, int64_t Do, int64_t Ho, int64_t Wo, int64_t Di, int64_t Hi,
+                 int64_t Wi, int KD, int KH, int KW, int stride, int pd, int ph, int pw, bool rows, int64_t P) {
+  WgPlan p;
+  WgGeom& g = p.g;
+  p.ok = false;
+  g.N = (int)N;
+  g.Cg = (int)Cg;
+  g.Cx = (int)Cx;
+  g.Do = (int)Do;
+  g.Ho = (int)Ho;
+  g.Wo = (int)Wo;
+  g.Di = (int)Di;
+  g.Hi = (int)Hi;
+  g.Wi = (int)Wi;
+  g.KD = KD;
+  g.KH = KH;
+  g.KW = KW;
+  g.T = KD * KH * KW;
+  g.pd = pd;
+  g.ph = ph;
+  g.pw = pw;
+  g.x_scale = g.x_shift = nullptr;
+  g.x_sps = 1;
+  g.x_pps = 1;
+  g.point_major = rows ? 1 : 0;
+  g.P = P;
+  g.ldg = g.ldx = 0;
+  g.CBP = Cx >= 16 ? 16 : (Cx > 4 ? 8 : 4);
+  g.lgCBP = ilog2(g.CBP);
+  g.TPT = 16 / g.CBP;
+  g.TPC = (g.T + g.TPT - 1) / g.TPT;
+  p.MT = Cg <= 16 ? 1 : (Cg <= 32 ? 2 : 4);
+  p.mblocks = (int)((Cg + 63) / 64);
+  const int cx_pad = (int)((Cx + g.CBP - 1) / g.CBP);          // channel sub-blocks in all
+  // tile candidates: 3-D volumes 2 x 4 x 16, else 1 x 8 x 16, 1 x 4 x 16
+  const int cand[3][2] = {{2, 4}, {1, 8}, {1, 4}};
+  for (int ci = rows ? 2 : (Do > 1 ? 0 : 1); ci < 3; ++ci) {      // (rows: 64 points per tile)
+    g.TD = cand[ci][0];
+    g.TH = cand[ci][1];
+    g.lgTH = ilog2(g.TH);
+    g.lgR = ilog2(g.TD * g.TH);
+    g.ID = (g.TD - 1) * stride + KD;
+    g.IH = (g.TH - 1) * stride + KH;
+    g.IW = 15 * stride + KW;
+    g.IWP = g.IW;
+    int xraw = g.ID * g.IH * g.IWP;
+    g.XPLANE = xraw | 1;                                       // odd: the 16 channels of a column tile on 16 banks
+    g.GPLANE = (g.TD * g.TH * 16) | 1;
+    int cblk = kMaxNTW * 4 / g.TPC;
+    if (cblk < 1) cblk = 1;                                    // (more than 28 tap groups: PF_ERR_UNSUPPORTED below)
+    if (cblk > cx_pad) cblk = cx_pad;
+    for (; cblk >= 1; --cblk) {
+      g.CBLK = cblk;
+      g.NTILES = cblk * g.TPC;
+      g.gs_floats = p.MT * 16 * g.GPLANE;
+      g.gs_floats = (g.gs_floats + 3) & ~3;
+      g.xs_floats = cblk * g.CBP * g.XPLANE;
+      g.xs_floats = (g.xs_floats + 3) & ~3;
+      g.ntasks = rows ? 0 : cblk * g.CBP * g.ID * g.IH;
+      p.lds_bytes = sizeof(float) * (size_t)(g.gs_floats + g.xs_floats) + sizeof(int) * 4 * (size_t)g.ntasks;
+      if (p.lds_bytes <= kLdsSoft) break;
+    }
+    if (g.CBLK >= 1 && p.lds_bytes <= kLdsSoft && g.NTILES <= kMaxNTW * 4) {
+      p.ok = true;
+      break;
+    }
+    if (ci == 2 && g.NTILES <= kMaxNTW * 4 && p.lds_bytes <= kLdsHard) {   // last resort: the big-LDS opt-in
+      p.ok = true;
+      break;
+    }
+  }
+  if (!p.ok) return p;
+  p.cblocks = (cx_pad + g.CBLK - 1) / g.CBLK;
+  if (rows) {
+    g.tiles_d = g.tiles_h = 1;
+    g.tiles_w = (int)((P + g.TD * g.TH * 16 - 1) / (g.TD * g.TH * 16));
+    g.total_tiles = g.tiles_w;
+  } else {
+    g.tiles_d = (g.Do + g.TD - 1) / g.TD;
+    g.tiles_h = (g.Ho + g.TH - 1) / g.TH;
+    g.tiles_w = (g.Wo + 15) / 16;
+    g.total_tiles = g.N * g.tiles_d * g.tiles_h * g.tiles_w;
+  }
+  const int64_t elems = Cg * Cx * g.T;
+  int64_t splits = 1024 / ((int64_t)p.cblocks * p.mblocks);
+  if (splits < 1) splits = 1;
+  const int64_t cap = kWorkspaceCap / (4 * elems);
+  if (splits > cap) splits = cap < 1 ? 1 : cap;
+  if (splits > g.total_tiles) splits = g.total_tiles;
+  if (splits < 1) splits = 1;
+  g.per_split = (int)((g.total_tiles + splits - 1) / splits);
+  if (g.per_split < 1) g.per_split = 1;
+  p.splits = (int)((g.total_tiles + g.per_split - 1) / g.per_split);
+  if (p.splits < 1) p.splits = 1;
+  return p;
+}
+
+template <int MT, int STRIDE>
+int launch_wgrad(const float* Gr, const float* X, float* part, const WgPlan& p, hipStream_t s) {
+  if (p.lds_bytes > kLdsSoft) {
+    static std::atomic<unsigned long long> done{0};
+    const int rc = pf_allow_big_lds(reinterpret_cast<const void*>(&wgrad_kernel<MT, STRIDE>), (int)kLdsHard, done);
+    if (rc != PF_OK) return rc;
+  }
+  dim3 grid((unsigned)p.splits, (unsigned)p.cblocks, (unsigned)p.mblocks);
+  hipLaunchKernelGGL((wgrad_kernel<MT, STRIDE>), grid, dim3(256), p.lds_bytes, s, Gr, X, part, p.g);
+  return pf_launch_status();
+}
+
+int run_plan(const float* Gr, const float* X, float* dw, const WgPlan& p, int stride, void* workspace,
+             int64_t workspace_bytes, int accumulate, hipStream_t s) {
+  const int64_t elems = (int64_t)p.g.Cg * p.g.Cx * p.g.T;
+  PF_REQUIRE(workspace != nullptr && workspace_bytes >= 4 * elems * p.splits);
+  float* part = reinterpret_cast<float*>(workspace);
+  int rc;
+  if (stride == 1) {
+    rc = p.MT == 1 ? launch_wgrad<1, 1>(Gr, X, part, p, s)
+                   : (p.MT == 2 ? launch_wgrad<2, 1>(Gr, X, part, p, s) : launch_wgrad<4, 1>(Gr, X, part, p, s));
+  } else {
+    rc = p.MT == 1 ? launch_wgrad<1, 2>(Gr, X, part, p, s)
+                   : (p.MT == 2 ? launch_wgrad<2, 2>(Gr, X, part, p, s) : launch_wgrad<4, 2>(Gr, X, part, p, s));
+  }
+  if (rc != PF_OK) return rc;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)pf_cdiv(elems, 256)), dim3(256), 0, s, part, dw, elems,
+                     p.splits, accumulate);
+  return pf_launch_status();
+}
+
+bool conv_args_ok(int64_t N, int64_t Cg, int64_t Cx, int64_t Do, int64_t Ho, int64_t Wo, int64_t Di, int64_t Hi,
+                  int64_t Wi, int KD, int KH, int KW, int stride) {
+  return N >= 1 && Cg >= 1 && Cx >= 1 && Do >= 1 && Ho >= 1 && Wo >= 1 && Di >= 1 && Hi >= 1 && Wi >= 1 && KD >= 1 &&
+         KH >= 1 && KW >= 1 && KD <= 7 && KH <= 7 && KW <= 7 && (stride == 1 || stride == 2) &&
+         Cx * Di * Hi * Wi <= INT32_MAX && Cg * Do * Ho * Wo <= INT32_MAX && N <= 65535;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t pf_conv_wgrad_workspace(int64_t N, int64_t Cg, int64_t Cx, int64_t Do, int64_t Ho, int64_t Wo, int64_t Di,
+                                int64_t Hi, int64_t Wi, int KD, int KH, int KW, int stride) {
+  if (!conv_args_ok(N, Cg, Cx, Do, Ho, Wo, Di, Hi, Wi, KD, KH, KW, stride)) return -1;
+  const WgPlan p = make_plan(N, Cg, Cx, Do, Ho, Wo, Di, Hi, Wi, KD, KH, KW, stride, 0, 0, 0, false, 0);
+  if (!p.ok) return -1;
+  return 4 * Cg * Cx * (int64_t)p.g.T * p.splits;
+}
+
+int pf_conv_wgrad_f32(const float* gr, const float* x, float* dw, int64_t N, int64_t Cg, int64_t Cx, int64_t Do,
+                      int64_t Ho, int64_t Wo, int64_t Di, int64_t Hi, int64_t Wi, int KD, int KH, int KW, int stride,
+                      int pd, int ph, int pw, const float* x_scale, const float* x_shift, int x_samples_per_stat,
+                      void* workspace, int64_t workspace_bytes, int accumulate, void* stream) {
+  PF_REQUIRE(conv_args_ok(N, Cg, Cx, Do, Ho, Wo, Di, Hi, Wi, KD, KH, KW, stride));
+  PF_REQUIRE(pd >= 0 && ph >= 0 && pw >= 0 && x_samples_per_stat >= 1 && (x_scale == nullptr) == (x_shift == nullptr));
+  PF_REQUIRE(gr && x && dw);
+  WgPlan p = make_plan(N, Cg, Cx, Do, Ho, Wo, Di, Hi, Wi, KD, KH, KW, stride, pd, ph, pw, false, 0);
+  if (!p.ok) return PF_ERR_UNSUPPORTED;
+  p.g.x_scale = x_scale;
+  p.g.x_shift = x_shift;
+  p.g.x_sps = x_samples_per_stat;
+  return run_plan(gr, x, dw, p, stride, workspace, workspace_bytes, accumulate, (hipStream_t)stream);
+}
+
+int64_t pf_rows_wgrad_workspace(int64_t P, int Cg, int Cx) {
+  if (P < 1 || Cg < 1 || Cx < 1 || (Cg & 3) || (Cx & 3)) return -1;
+  const WgPlan p = make_plan(1, Cg, Cx, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, true, P);
+  if (!p.ok) return -1;
+  return 4 * (int64_t)Cg * Cx * p.splits;
+}
+
+int pf_rows_wgrad_f32(const float* gr, int64_t ldg, const float* x, int64_t ldx, float* dw, int64_t P, int Cg, int Cx,
+                      const float* x_scale, const float* x_shift, int64_t x_rows_per_stat, void* workspace,
+                      int64_t workspace_bytes, int accumulate, void* stream) {
+  PF_REQUIRE(P >= 1 && Cg >= 1 && Cx >= 1 && ldg >= Cg && ldx >= Cx && x_rows_per_stat >= 1);
+  PF_REQUIRE((x_scale == nullptr) == (x_shift == nullptr) && gr && x && dw);
+  if ((Cg & 3) || (Cx & 3) || (ldg & 3) || (ldx & 3)) return PF_ERR_UNSUPPORTED;
+  PF_REQUIRE((((uintptr_t)gr | (uintptr_t)x | (uintptr_t)x_scale | (uintptr_t)x_shift) & 15) == 0);
+  WgPlan p = make_plan(1, Cg, Cx, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, true, P);
+  if (!p.ok) return PF_ERR_UNSUPPORTED;
+  p.g.x_scale = x_scale;
+  p.g.x_shift = x_shift;
+  p.g.x_pps = x_rows_per_stat;
+  p.g.ldg = ldg;
+  p.g.ldx = ldx;
+  return run_plan(gr, x, dw, p, 1, workspace, workspace_bytes, accumulate, (hipStream_t)stream);
+}
+
+}  // extern "C"

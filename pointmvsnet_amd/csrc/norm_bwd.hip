@@ -1,0 +1,457 @@
+// Row Z (training step, BASELINE config 4): train-mode BatchNorm (+ReLU) BACKWARD for the conv stacks and the flow
+// MLP, and the forward finalize that keeps what the backward needs.
+//
+// The reference's step (train.py:72-82) differentiates  conv -> BatchNorm(batch statistics) -> ReLU  blocks
+// (nn/conv.py:24-35, :62-77, :108-121, :197-210) through ATen's batch_norm backward.  Here, per block with raw
+// convolution output y, z = relu(y * scale + shift), upstream gradient g = dL/dz:
+//     g'     = [y * scale + shift > 0] * g                      (g' = g for a block without ReLU)
+//     dbeta  = sum g'            dgamma = sum g' * xhat         xhat = (y - mean) * invstd
+//     dy     = scale * (g' - dbeta / M - xhat * dgamma / M)     M = elements behind the statistic
+// as three launches: `reduce` streams (g, y) once into float64 per-block partials (fixed order: bit-reproducible),
+// `coeffs` folds them into per-(statistic group, channel) constants and dgamma / dbeta, `apply` streams (g, y) -> dy.
+// Planar tensors are (N, C, S) like norm.hip; the MLP's are point-major rows (P, ld).  All HBM-bound streams:
+// reduce 8 bytes per element, apply 12.
+#include "pf_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// forward finalize that also keeps (mean, invstd): rows (4, S, C) = [scale | shift | mean | invstd] (each an (S, C) block, the layout the
+// forward kernels' in_scale / in_shift rows have)
+// ------------------------------------------------------------------------------------------------
+// One block per 4 channels; the S statistic groups in order (the running statistics are sequential state, one update
+// per group like S successive nn.BatchNorm calls).  Thread (channel c = tid & 3, slice tid >> 2) sums every 64th
+// statistics row; the 64 slices are added in slice order.  Same arithmetic as bn_finalize_kernel (edgeconv.hip).
+__global__ __launch_bounds__(256) void bn_train_rows_kernel(const double* __restrict__ partials, int T, int pcols,
+                                                            int col0, int C, double count, double unbias_n,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta,
+                                                            float* __restrict__ running_mean,
+                                                            float* __restrict__ running_var, float momentum, float eps,
+                                                            int S, int gps, float* __restrict__ rows) {
+  __shared__ double2 red[256];
+  const int tid = threadIdx.x;
+  const int cl = tid & 3, sl = tid >> 2;
+  const int c = blockIdx.x * 4 + cl;
+  const bool live = c < C;
+  const int entries = gps * T;
+  const bool track = running_mean != nullptr;
+  float rm = 0.0f, rv = 0.0f;
+  if (track && sl == 0 && live) {
+    rm = running_mean[c];
+    rv = running_var[c];
+  }
+  for (int s = 0; s < S; ++s) {
+    double a = 0.0, b = 0.0;
+    if (live) {
+      const double* base = partials + ((int64_t)s * entries * pcols + col0 + c) * 2;
+      for (int e = sl; e < entries; e += 64) {
+        const double2 v = *reinterpret_cast<const double2*>(base + (int64_t)e * pcols * 2);
+        a += v.x;
+        b += v.y;
+      }
+    }
+    red[tid] = make_double2(a, b);
+    __syncthreads();
+    if (sl == 0 && live) {
+      double sum = 0.0, sq = 0.0;
+      for (int i = 0; i < 64; ++i) {
+        sum += red[i * 4 + cl].x;
+        sq += red[i * 4 + cl].y;
+      }
+      const double mean = sum / count;
+      double var = sq / count - mean * mean;
+      var = var < 0.0 ? 0.0 : var;
+      const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+      const float sc = invstd * gamma[c];
+      const int64_t SC = (int64_t)S * C;
+      float* r = rows + (int64_t)s * C + c;
+      r[0] = sc;
+      r[SC] = beta[c] - (float)mean * sc;
+      r[2 * SC] = (float)mean;
+      r[3 * SC] = invstd;
+      if (track) {
+        const double unbiased = unbias_n > 1.0 ? var * (unbias_n / (unbias_n - 1.0)) : var;
+        rm = (1.0f - momentum) * rm + momentum * (float)mean;
+        rv = (1.0f - momentum) * rv + momentum * (float)unbiased;
+      }
+    }
+    __syncthreads();
+  }
+  if (track && sl == 0 && live) {
+    running_mean[c] = rm;
+    running_var[c] = rv;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// planar (N, C, S): reduce / apply
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float masked(float g, float y, float sc, float sh, int relu) {
+  return (!relu || fmaf(y, sc, sh) > 0.0f) ? g : 0.0f;
+}
+
+// grid = (T, C, N); block t of (n, c) reduces elements [t*chunk, (t+1)*chunk) -> partials (N, T, C, 2).
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ g, const float* __restrict__ y,
+                                                            const float* __restrict__ rows, int C, int64_t S,
+                                                            int64_t chunk, int sps, int relu,
+                                                            double* __restrict__ partials, int T) {
+  __shared__ double red[2 * 4];
+  const int t = blockIdx.x, c = blockIdx.y, n = blockIdx.z;
+  const int64_t SC = (int64_t)(gridDim.z / sps) * C;
+  const float* r = rows + (int64_t)(n / sps) * C + c;
+  const float sc = r[0], sh = r[SC], mean = r[2 * SC], invstd = r[3 * SC];
+  const float* pg = g + ((int64_t)n * C + c) * S;
+  const float* py = y + ((int64_t)n * C + c) * S;
+  const int64_t lo = (int64_t)t * chunk;
+  const int64_t hi = min(S, lo + chunk);
+  float s0 = 0.0f, s1 = 0.0f, q0 = 0.0f, q1 = 0.0f;
+  auto one = [&](float gv, float yv, float& s, float& q) {
+    const float m = masked(gv, yv, sc, sh, relu);
+    s += m;
+    q += m * ((yv - mean) * invstd);
+  };
+  if ((((uintptr_t)(pg + lo) | (uintptr_t)(py + lo)) & 15) == 0) {
+    const int64_t n4 = (hi - lo) >> 2;
+    const float4* g4 = reinterpret_cast<const float4*>(pg + lo);
+    const float4* y4 = reinterpret_cast<const float4*>(py + lo);
+    int64_t i = threadIdx.x;
+    for (; i + 256 < n4; i += 512) {
+      const float4 a = g4[i], b = y4[i], a2 = g4[i + 256], b2 = y4[i + 256];
+      one(a.x, b.x, s0, q0);
+      one(a.y, b.y, s0, q0);
+      one(a.z, b.z, s0, q0);
+      one(a.w, b.w, s0, q0);
+      one(a2.x, b2.x, s1, q1);
+      one(a2.y, b2.y, s1, q1);
+      one(a2.z, b2.z, s1, q1);
+      one(a2.w, b2.w, s1, q1);
+    }
+    for (; i < n4; i += 256) {
+      const float4 a = g4[i], b = y4[i];
+      one(a.x, b.x, s0, q0);
+      one(a.y, b.y, s0, q0);
+      one(a.z, b.z, s0, q0);
+      one(a.w, b.w, s0, q0);
+    }
+    for (int64_t j = lo + (n4 << 2) + threadIdx.x; j < hi; j += 256) one(pg[j], py[j], s0, q0);
+  } else {
+    for (int64_t j = lo + threadIdx.x; j < hi; j += 256) one(pg[j], py[j], s0, q0);
+  }
+  double ds = (double)s0 + (double)s1;
+  double dq = (double)q0 + (double)q1;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    ds += __shfl_xor(ds, off);
+    dq += __shfl_xor(dq, off);
+  }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    red[wave * 2 + 0] = ds;
+    red[wave * 2 + 1] = dq;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double* o = partials + (((int64_t)n * T + t) * C + c) * 2;
+    o[0] = (red[0] + red[2]) + (red[4] + red[6]);
+    o[1] = (red[1] + red[3]) + (red[5] + red[7]);
+  }
+}
+
+// coef rows (2, S, C): k1 = scale * dbeta_s / M, k2 = scale * invstd * dgamma_s / M, so that
+//   dy = scale * g' - k1 - k2 * (y - mean);  dgamma[c] / dbeta[c] = sums over the S statistic groups, in order.
+// One block per 4 channels, as bn_train_rows_kernel.
+__global__ __launch_bounds__(256) void bn_bwd_coeffs_kernel(const double* __restrict__ partials, int T, int pcols,
+                                                            int col0, int C, double count, int S, int gps,
+                                                            const float* __restrict__ rows, float* __restrict__ coef,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            int accumulate) {
+  __shared__ double2 red[256];
+  const int tid = threadIdx.x;
+  const int cl = tid & 3, sl = tid >> 2;
+  const int c = blockIdx.x * 4 + cl;
+  const bool live = c < C;
+  const int entries = gps * T;
+  double tg = 0.0, tb = 0.0;
+  for (int s = 0; s < S; ++s) {
+    double a = 0.0, b = 0.0;
+    if (live) {
+      const double* base = partials + ((int64_t)s * entries * pcols + col0 + c) * 2;
+      for (int e = sl; e < entries; e += 64) {
+        const double2 v = *reinterpret_cast<const double2*>(base + (int64_t)e * pcols * 2);
+        a += v.x;
+        b += v.y;
+      }
+    }
+    red[tid] = make_double2(a, b);
+    __syncthreads();
+    if (sl == 0 && live) {
+      double sb = 0.0, sg = 0.0;
+      for (int i = 0; i < 64; ++i) {
+        sb += red[i * 4 + cl].x;
+        sg += red[i * 4 + cl].y;
+      }
+      const int64_t SC = (int64_t)S * C;
+      const float* r = rows + (int64_t)s * C + c;
+      const double sc = (double)r[0], invstd = (double)r[3 * SC];
+      coef[(int64_t)s * C + c] = (float)(sc * sb / count);
+      coef[SC + (int64_t)s * C + c] = (float)(sc * invstd * sg / count);
+      tb += sb;
+      tg += sg;
+    }
+    __syncthreads();
+  }
+  if (sl == 0 && live) {
+    if (dgamma != nullptr) dgamma[c] = (accumulate ? dgamma[c] : 0.0f) + (float)tg;
+    if (dbeta != nullptr) dbeta[c] = (accumulate ? dbeta[c] : 0.0f) + (float)tb;
+  }
+}
+
+// grid = (blocks, C, N): dy = scale * g' - k1 - k2 * (y - mean)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ y,
+                                                           const float* __restrict__ rows,
+                                                           const float* __restrict__ coef, float* __restrict__ dy,
+                                                           int C, int64_t S, int sps, int relu) {
+  const int c = blockIdx.y, n = blockIdx.z;
+  const int s = n / sps;
+  const int64_t SC = (int64_t)(gridDim.z / sps) * C;
+  const float* r = rows + (int64_t)s * C + c;
+  const float sc = r[0], sh = r[SC], mean = r[2 * SC];
+  const float k1 = coef[(int64_t)s * C + c], k2 = coef[SC + (int64_t)s * C + c];
+  const float* pg = g + ((int64_t)n * C + c) * S;
+  const float* py = y + ((int64_t)n * C + c) * S;
+  float* po = dy + ((int64_t)n * C + c) * S;
+  auto one = [&](float gv, float yv) {
+    const float m = masked(gv, yv, sc, sh, relu);
+    return fmaf(-k2, yv - mean, fmaf(sc, m, -k1));
+  };
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  if ((((uintptr_t)pg | (uintptr_t)py | (uintptr_t)po) & 15) == 0 && (S & 3) == 0) {
+    const int64_t n4 = S >> 2;
+    const float4* g4 = reinterpret_cast<const float4*>(pg);
+    const float4* y4 = reinterpret_cast<const float4*>(py);
+    float4* o4 = reinterpret_cast<float4*>(po);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+      const float4 a = g4[i], b = y4[i];
+      float4 v;
+      v.x = one(a.x, b.x);
+      v.y = one(a.y, b.y);
+      v.z = one(a.z, b.z);
+      v.w = one(a.w, b.w);
+      o4[i] = v;
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < S; i += stride) po[i] = one(pg[i], py[i]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// point-major rows (P, ld): the flow MLP's BatchNorm1d (reference nn/conv.py:24-35 via nn/mlp.py:45-81)
+// ------------------------------------------------------------------------------------------------
+// G groups of Ng rows; block (t, g) reduces rows [t*chunk, (t+1)*chunk) of group g: thread = (column c = tid % C,
+// row phase tid / C), C in {16, 32, 64, 128}.  partials (G, T, C, 2).
+constexpr int kRowT = 64;      // blocks per group (at most)
+
+__global__ __launch_bounds__(256) void rows_bn_bwd_reduce_kernel(const float* __restrict__ g, int64_t ldg,
+                                                                 const float* __restrict__ y, int64_t ldy,
+                                                                 const float* __restrict__ rows, int C, int Ng,
+                                                                 int chunk, int gps, int relu,
+                                                                 double* __restrict__ partials, int T) {
+  __shared__ double2 red[256];
+  const int tid = threadIdx.x;
+  const int t = blockIdx.x, grp = blockIdx.y;
+  const int c = tid % C, ph = tid / C, nph = 256 / C;
+  const int64_t SC = (int64_t)(gridDim.y / gps) * C;
+  const float* r = rows + (int64_t)(grp / gps) * C + c;
+  const float sc = r[0], sh = r[SC], mean = r[2 * SC], invstd = r[3 * SC];
+  const int lo = t * chunk, hi = min(Ng, lo + chunk);
+  double ds = 0.0, dq = 0.0;
+  float s = 0.0f, q = 0.0f;
+  int cnt = 0;
+  for (int m = lo + ph; m < hi; m += nph) {
+    const int64_t row = (int64_t)grp * Ng + m;
+    const float gv = g[row * ldg + c], yv = y[row * ldy + c];
+    const float mk = masked(gv, yv, sc, sh, relu);
+    s += mk;
+    q += mk * ((yv - mean) * invstd);
+    if (++cnt == 64) {            // float32 over short runs, float64 across them
+      ds += (double)s;
+      dq += (double)q;
+      s = q = 0.0f;
+      cnt = 0;
+    }
+  }
+  ds += (double)s;
+  dq += (double)q;
+  red[tid] = make_double2(ds, dq);
+  __syncthreads();
+  if (ph == 0) {
+    double a = 0.0, b = 0.0;
+    for (int i = 0; i < nph; ++i) {
+      a += red[i * C + c].x;
+      b += red[i * C + c].y;
+    }
+    double* o = partials + (((int64_t)grp * T + t) * C + c) * 2;
+    o[0] = a;
+    o[1] = b;
+  }
+}
+
+// thread = (row, 4 columns): dy rows (P, ldo)
+__global__ __launch_bounds__(256) void rows_bn_bwd_apply_kernel(const float* __restrict__ g, int64_t ldg,
+                                                                const float* __restrict__ y, int64_t ldy,
+                                                                const float* __restrict__ rows,
+                                                                const float* __restrict__ coef,
+                                                                float* __restrict__ dy, int64_t ldo, int C, int Ng,
+                                                                int64_t P, int gps, int relu) {
+  const int q4 = C >> 2;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t row = i / q4;
+  const int c0 = (int)(i - row * q4) * 4;
+  if (row >= P) return;
+  const int s = (int)(row / Ng) / gps;
+  const int64_t SC = (P / Ng / gps) * C;
+  const float* r = rows + (int64_t)s * C + c0;
+  const float* k = coef + (int64_t)s * C + c0;
+  const float4 gv = *reinterpret_cast<const float4*>(g + row * ldg + c0);
+  const float4 yv = *reinterpret_cast<const float4*>(y + row * ldy + c0);
+  const float4 sc = *reinterpret_cast<const float4*>(r), sh = *reinterpret_cast<const float4*>(r + SC);
+  const float4 mean = *reinterpret_cast<const float4*>(r + 2 * SC);
+  const float4 k1 = *reinterpret_cast<const float4*>(k), k2 = *reinterpret_cast<const float4*>(k + SC);
+  float4 o;
+  o.x = fmaf(-k2.x, yv.x - mean.x, fmaf(sc.x, masked(gv.x, yv.x, sc.x, sh.x, relu), -k1.x));
+  o.y = fmaf(-k2.y, yv.y - mean.y, fmaf(sc.y, masked(gv.y, yv.y, sc.y, sh.y, relu), -k1.y));
+  o.z = fmaf(-k2.z, yv.z - mean.z, fmaf(sc.z, masked(gv.z, yv.z, sc.z, sh.z, relu), -k1.z));
+  o.w = fmaf(-k2.w, yv.w - mean.w, fmaf(sc.w, masked(gv.w, yv.w, sc.w, sh.w, relu), -k1.w));
+  *reinterpret_cast<float4*>(dy + row * ldo + c0) = o;
+}
+
+// z rows = relu(y * scale + shift) (materialises a normalised activation the training step hands to ATen)
+__global__ __launch_bounds__(256) void rows_affine_kernel(const float* __restrict__ y, int64_t ldy,
+                                                          const float* __restrict__ rows, float* __restrict__ z,
+                                                          int64_t ldz, int C, int Ng, int64_t P, int gps, int relu) {
+  const int q4 = C >> 2;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t row = i / q4;
+  const int c0 = (int)(i - row * q4) * 4;
+  if (row >= P) return;
+  const int s = (int)(row / Ng) / gps;
+  const int64_t SC = (P / Ng / gps) * C;
+  const float* r = rows + (int64_t)s * C + c0;
+  const float4 yv = *reinterpret_cast<const float4*>(y + row * ldy + c0);
+  const float4 sc = *reinterpret_cast<const float4*>(r), sh = *reinterpret_cast<const float4*>(r + SC);
+  float4 o;
+  o.x = fmaf(yv.x, sc.x, sh.x);
+  o.y = fmaf(yv.y, sc.y, sh.y);
+  o.z = fmaf(yv.z, sc.z, sh.z);
+  o.w = fmaf(yv.w, sc.w, sh.w);
+  if (relu) {
+    o.x = fmaxf(o.x, 0.0f);
+    o.y = fmaxf(o.y, 0.0f);
+    o.z = fmaxf(o.z, 0.0f);
+    o.w = fmaxf(o.w, 0.0f);
+  }
+  *reinterpret_cast<float4*>(z + row * ldz + c0) = o;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pf_bn_train_rows_f32(const double* partials, int T, int pcols, int col0, int C, double count, double unbias_n,
+                         const float* gamma, const float* beta, float* running_mean, float* running_var,
+                         float momentum, float eps, int G, int groups_per_stat, float* rows, void* stream) {
+  PF_REQUIRE(T >= 1 && pcols >= 1 && col0 >= 0 && C >= 1 && col0 + C <= pcols && count > 0.0);
+  PF_REQUIRE(G >= 1 && groups_per_stat >= 1 && (G % groups_per_stat) == 0);
+  PF_REQUIRE(partials && gamma && beta && rows && (running_mean == nullptr) == (running_var == nullptr));
+  hipLaunchKernelGGL(bn_train_rows_kernel, dim3((unsigned)pf_cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, partials, T,
+                     pcols, col0, C, count, unbias_n, gamma, beta, running_mean, running_var, momentum, eps,
+                     G / groups_per_stat, groups_per_stat, rows);
+  return pf_launch_status();
+}
+
+int pf_bn_bwd_reduce_f32(const float* g, const float* y, const float* rows, int64_t N, int64_t C, int64_t S,
+                         int samples_per_stat, int relu, double* partials, void* stream) {
+  PF_REQUIRE(N >= 0 && C >= 0 && S >= 0 && N <= 65535 && C <= 65535 && samples_per_stat >= 1);
+  if (N == 0 || C == 0 || S == 0) return PF_OK;
+  PF_REQUIRE(g && y && rows && partials && (N % samples_per_stat) == 0);
+  const int T = pf_norm_blocks(S);
+  int64_t chunk = (S + T - 1) / T;
+  chunk = (chunk + 3) & ~(int64_t)3;
+  dim3 grid((unsigned)T, (unsigned)C, (unsigned)N);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(256), 0, (hipStream_t)stream, g, y, rows, (int)C, S, chunk,
+                     samples_per_stat, relu, partials, T);
+  return pf_launch_status();
+}
+
+int pf_bn_bwd_coeffs_f32(const double* partials, int T, int pcols, int col0, int C, double count, int G,
+                         int groups_per_stat, const float* rows, float* coef, float* dgamma, float* dbeta,
+                         int accumulate, void* stream) {
+  PF_REQUIRE(T >= 1 && pcols >= 1 && col0 >= 0 && C >= 1 && col0 + C <= pcols && count > 0.0);
+  PF_REQUIRE(G >= 1 && groups_per_stat >= 1 && (G % groups_per_stat) == 0 && partials && rows && coef);
+  hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3((unsigned)pf_cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, partials, T,
+                     pcols, col0, C, count, G / groups_per_stat, groups_per_stat, rows, coef, dgamma, dbeta, accumulate);
+  return pf_launch_status();
+}
+
+int pf_bn_bwd_apply_f32(const float* g, const float* y, const float* rows, const float* coef, float* dy, int64_t N,
+                        int64_t C, int64_t S, int samples_per_stat, int relu, void* stream) {
+  PF_REQUIRE(N >= 0 && C >= 0 && S >= 0 && N <= 65535 && C <= 65535 && samples_per_stat >= 1);
+  if (N == 0 || C == 0 || S == 0) return PF_OK;
+  PF_REQUIRE(g && y && rows && coef && dy);
+  int64_t blocks = (S / 4 + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 64 ? 64 : blocks);
+  dim3 grid((unsigned)blocks, (unsigned)C, (unsigned)N);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream, g, y, rows, coef, dy, (int)C, S,
+                     samples_per_stat, relu);
+  return pf_launch_status();
+}
+
+int pf_rows_bn_blocks(int G, int Ng) {
+  if (G <= 0 || Ng <= 0) return 0;
+  const int t = (Ng + 511) / 512;            // >= 512 rows per block
+  return t > kRowT ? kRowT : t;
+}
+
+int pf_rows_bn_bwd_reduce_f32(const float* g, int64_t ldg, const float* y, int64_t ldy, const float* rows, int C, int G,
+                              int Ng, int groups_per_stat, int relu, double* partials, void* stream) {
+  PF_REQUIRE(G >= 0 && Ng >= 0 && groups_per_stat >= 1 && ldg >= C && ldy >= C);
+  if (C != 16 && C != 32 && C != 64 && C != 128) return PF_ERR_UNSUPPORTED;
+  if (G == 0 || Ng == 0) return PF_OK;
+  PF_REQUIRE(g && y && rows && partials && (G % groups_per_stat) == 0);
+  const int T = pf_rows_bn_blocks(G, Ng);
+  const int chunk = (Ng + T - 1) / T;
+  hipLaunchKernelGGL(rows_bn_bwd_reduce_kernel, dim3((unsigned)T, (unsigned)G), dim3(256), 0, (hipStream_t)stream, g, ldg,
+                     y, ldy, rows, C, Ng, chunk, groups_per_stat, relu, partials, T);
+  return pf_launch_status();
+}
+
+int pf_rows_bn_bwd_apply_f32(const float* g, int64_t ldg, const float* y, int64_t ldy, const float* rows,
+                             const float* coef, float* dy, int64_t ldo, int C, int G, int Ng, int groups_per_stat,
+                             int relu, void* stream) {
+  PF_REQUIRE(G >= 0 && Ng >= 0 && groups_per_stat >= 1 && ldg >= C && ldy >= C && ldo >= C);
+  if ((C & 3) != 0 || ((ldg | ldy | ldo) & 3) != 0) return PF_ERR_UNSUPPORTED;
+  if (G == 0 || Ng == 0) return PF_OK;
+  PF_REQUIRE(g && y && rows && coef && dy);
+  PF_REQUIRE((((uintptr_t)g | (uintptr_t)y | (uintptr_t)dy | (uintptr_t)rows | (uintptr_t)coef) & 15) == 0);
+  const int64_t P = (int64_t)G * Ng;
+  const int64_t items = P * (C >> 2);
+  hipLaunchKernelGGL(rows_bn_bwd_apply_kernel, dim3((unsigned)pf_cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream, g,
+                     ldg, y, ldy, rows, coef, dy, ldo, C, Ng, P, groups_per_stat, relu);
+  return pf_launch_status();
+}
+
+int pf_rows_affine_f32(const float* y, int64_t ldy, const float* rows, float* z, int64_t ldz, int C, int G, int Ng,
+                       int groups_per_stat, int relu, void* stream) {
+  PF_REQUIRE(G >= 0 && Ng >= 0 && groups_per_stat >= 1 && ldy >= C && ldz >= C);
+  if ((C & 3) != 0 || ((ldy | ldz) & 3) != 0) return PF_ERR_UNSUPPORTED;
+  if (G == 0 || Ng == 0) return PF_OK;
+  PF_REQUIRE(y && rows && z && (((uintptr_t)y | (uintptr_t)z | (uintptr_t)rows) & 15) == 0);
+  const int64_t P = (int64_t)G * Ng;
+  const int64_t items = P * (C >> 2);
+  hipLaunchKernelGGL(rows_affine_kernel, dim3((unsigned)pf_cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream, y, ldy,
+                     rows, z, ldz, C, Ng, P, groups_per_stat, relu);
+  return pf_launch_status();
+}
+
+}  // extern "C"

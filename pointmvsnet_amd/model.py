@@ -24,7 +24,9 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import networks as _networks
 from . import pointflow
+from . import train_ops
 from .functions.functions import get_pixel_grids, get_propability_map
 from .networks import (EdgeConv, EdgeConvNoC, ImageConv, VolumeConv, MAELoss, Valid_MAELoss, tower_pair_supported,
                        tower_pair_views)
@@ -33,6 +35,10 @@ from .utils.feature_fetcher import ChannelLast, FeatureFetcher, frustum_variance
 from .utils.torch_utils import get_knn_3d
 
 _HYPOTHESES = (-2, -1, 0, 1, 2)
+
+# 0: the training step differentiates the ATen composition of the conv stacks instead of the train_ops nodes (a module
+# attribute the tests flip to compare the two, not a knob)
+FUSED_TRAIN = 1
 
 
 def _host_cams(data_batch):
@@ -507,8 +513,17 @@ class PointMVSNet(nn.Module):
         K_coarse = tplan.d("K_coarse")
         ext = tplan.d("ext")
 
-        coarse_maps = [self.coarse_img_conv(img_list[:, v])["conv3"] for v in range(V)]
-        feature_list = torch.stack(coarse_maps, dim=1)                       # (B,V,C,FH,FW)
+        # Row Z: one scene per process and the reference's widths -> every conv / BatchNorm stack is ONE autograd node
+        # on this package's own forward and backward kernels (train_ops.py); anything else: the ATen composition
+        fused = (FUSED_TRAIN and _networks.FUSED_TRAIN and B == 1 and self.training
+                 and train_ops.tower_supported(self.coarse_img_conv, img_list[0])
+                 and train_ops.tower_supported(self.flow_img_conv, img_list[0]))
+        if fused:
+            feature_list = train_ops.tower_train(self.coarse_img_conv, img_list[0], ("conv3",))["conv3"].unsqueeze(0)
+            coarse_maps = [feature_list[:, 0]]
+        else:
+            coarse_maps = [self.coarse_img_conv(img_list[:, v])["conv3"] for v in range(V)]
+            feature_list = torch.stack(coarse_maps, dim=1)                   # (B,V,C,FH,FW)
         C, FH, FW = feature_list.shape[2:]
         D = tplan.D
         depths = tplan.d("depths")                                           # (B,D)
@@ -525,7 +540,11 @@ class PointMVSNet(nn.Module):
         point_features = torch.cat([ref.unsqueeze(1), point_features[:, 1:]], dim=1)
         avg = point_features.mean(dim=1)
         cost = (point_features ** 2).mean(dim=1) - avg ** 2
-        filtered = self.coarse_vol_conv(cost.view(B, C, D, FH, FW)).squeeze(1)
+        cost = cost.view(B, C, D, FH, FW)
+        if fused and train_ops.volume_supported(self.coarse_vol_conv, cost):
+            filtered = train_ops.volume_train(self.coarse_vol_conv, cost).squeeze(1)
+        else:
+            filtered = self.coarse_vol_conv(cost).squeeze(1)
 
         d_start = tplan.d("d_start")
         d_int = tplan.d("d_int")
@@ -537,8 +556,12 @@ class PointMVSNet(nn.Module):
             return preds
 
         names = ("conv1", "conv2", "conv3")
-        per_view = [self.flow_img_conv(img_list[:, v]) for v in range(V)]
-        pyramids = {n: torch.stack([pv[n] for pv in per_view], dim=1) for n in names}   # (B,V,c,h_l,w_l)
+        if fused:
+            levels = train_ops.tower_train(self.flow_img_conv, img_list[0], names)
+            pyramids = {n: levels[n].unsqueeze(0) for n in names}
+        else:
+            per_view = [self.flow_img_conv(img_list[:, v]) for v in range(V)]
+            pyramids = {n: torch.stack([pv[n] for pv in per_view], dim=1) for n in names}   # (B,V,c,h_l,w_l)
         if isTest:
             pyramids = {n: p.detach() for n, p in pyramids.items()}
         for it, img_scale in enumerate(img_scales):
@@ -561,11 +584,24 @@ class PointMVSNet(nn.Module):
         B, _, D, hs, ws = xyz.shape
         nn_idx = get_knn_3d(xyz, D, knn=self.k)
         x = feature.contiguous().view(B, -1, D * hs * ws)
-        edges = []
-        for conv in self.flow_edge_conv:
-            x = conv(x, nn_idx)
-            edges.append(x)
-        flow = self.flow_mlp(torch.cat(edges, dim=1)).contiguous().view(B, D, hs, ws)
+        rows = x[0].t().contiguous() if (FUSED_TRAIN and _networks.FUSED_TRAIN and B == 1 and self.training) else None     # (N, 136) point-major
+        if (rows is not None and train_ops.edge_chain_supported(self.flow_edge_conv, rows, nn_idx)
+                and len(self.flow_mlp) == 2 and type(self.flow_mlp[1]) is nn.Conv1d
+                and self.flow_mlp[1].bias is None and self.flow_mlp[1].out_channels == 1):
+            # EdgeConv x3 + the shared MLP as two autograd nodes on point-major rows; the 16 -> 1 convolution and
+            # everything after it are a few element-wise ATen operations on (N, 16)
+            edges = train_ops.edge_chain_train(self.flow_edge_conv, rows, nn_idx)          # (N, 224)
+            if train_ops.mlp_supported(self.flow_mlp[0], edges):
+                act = train_ops.mlp_train(self.flow_mlp[0], edges)                             # (N, 16)
+                flow = (act * self.flow_mlp[1].weight.view(1, -1)).sum(dim=1).view(B, D, hs, ws)
+            else:
+                flow = self.flow_mlp(edges.t().unsqueeze(0)).contiguous().view(B, D, hs, ws)
+        else:
+            edges = []
+            for conv in self.flow_edge_conv:
+                x = conv(x, nn_idx)
+                edges.append(x)
+            flow = self.flow_mlp(torch.cat(edges, dim=1)).contiguous().view(B, D, hs, ws)
         prob = F.softmax(-flow, dim=1)
         length = self._hypotheses(xyz.device).view(1, -1, 1, 1) * interval.view(-1, 1, 1, 1)
         return torch.sum(prob * length, dim=1, keepdim=True), prob

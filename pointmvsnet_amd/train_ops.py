@@ -1,0 +1,640 @@
+"""Row Z -- the training step of BASELINE config 4 on this package's own kernels (reference train.py:72-82).
+
+The reference differentiates its conv -> BatchNorm -> ReLU stacks (networks.py:84-167 through nn/conv.py:62-77,
+:108-121, :197-210; the flow MLP, model.py:40-43, through nn/conv.py:24-35) with ATen's convolution_backward and
+batch_norm backward.  Here every such stack is ONE ``torch.autograd.Function`` whose forward runs the fused inference
+kernels (raw convolution output + BatchNorm statistics from the epilogue, the pending BatchNorm + ReLU applied by the
+next convolution while it stages its input) and whose backward is hand-written on the C ABI:
+
+    BatchNorm+ReLU backward   pf_bn_bwd_reduce / _coeffs / _apply (csrc/norm_bwd.hip; rows forms for the MLP)
+    weight gradients          pf_conv_wgrad_f32 / pf_rows_wgrad_f32 (csrc/conv_wgrad.hip; f32 MFMA, fixed-order sums)
+    data gradients            stride-1 layers: the FORWARD kernel on the flipped, transposed weight;
+                              stride-2 convolutions: the transposed-convolution kernels (pf_deconv2d_k5s2_f32,
+                              pf_deconv3d_k3s2_f32, pf_deconv3d_bottom_f32); ConvTranspose3d layers: the stride-2
+                              forward convolution on the weight read as (Cout', Cin') = (Cin, Cout)
+    1x1 convolutions          pf_pointwise_gemm_f32 on W itself (dX = dY W)
+
+No library convolution, BatchNorm or GEMM kernel runs in the step, and nothing uses float atomics: the gradient is
+bit-reproducible.  One scene per process (B = 1, the reference's per-replica batch under DataParallel with 8 scenes on
+8 GPUs, train.py:177): other batch sizes, other widths and eval-mode BatchNorm take the composed ATen path.
+"""
+import torch
+
+from . import _lib
+from . import pointflow
+
+_F32 = torch.float32
+
+
+# ---------------------------------------------------------------------------------------------
+# thin wrappers over the C ABI
+# ---------------------------------------------------------------------------------------------
+def bn_train_rows(bn, partials, col0, C, count, G, groups_per_stat):
+    """(4, S, C) rows [scale | shift | mean | invstd] of a train-mode BatchNorm from the statistics partials
+    (G, T, pcols, 2) of its producer; updates the running statistics like the module would (one update per group)."""
+    if bn.momentum is None:
+        raise NotImplementedError("cumulative-average BatchNorm momentum is not supported")
+    S = G // groups_per_stat
+    rows = torch.empty((4, S, C), dtype=_F32, device=partials.device)
+    track = bn.track_running_stats and bn.running_mean is not None
+    _lib.call("pf_bn_train_rows_f32", _lib.ptr(partials), int(partials.shape[1]), int(partials.shape[2]), int(col0),
+              int(C), float(count), float(count), _lib.ptr(bn.weight.detach()), _lib.ptr(bn.bias.detach()),
+              _lib.ptr(bn.running_mean if track else None), _lib.ptr(bn.running_var if track else None),
+              float(bn.momentum), float(bn.eps), int(G), int(groups_per_stat), _lib.ptr(rows), _lib.stream(),
+              algo_bytes=16.0 * partials.shape[0] * partials.shape[1] * C)
+    pointflow.bump_counter(bn, S)
+    return rows
+
+
+def channel_affine(y, rows, samples_per_stat, relu=True):
+    """z = act(y * scale + shift), out of place (y stays: the backward needs the raw convolution output)."""
+    N, C = y.shape[:2]
+    S = y[0, 0].numel()
+    z = torch.empty_like(y)
+    _lib.call("pf_channel_affine_f32", _lib.ptr(y), _lib.ptr(z), _lib.ptr(rows[0]), _lib.ptr(rows[1]), N, C, S,
+              int(samples_per_stat), int(bool(relu)), _lib.stream(), algo_bytes=8.0 * N * C * S)
+    return z
+
+
+def bn_backward(g, y, rows, samples_per_stat, relu=True):
+    """BatchNorm(+ReLU) backward on planar (N, C, *spatial) tensors: (dy, dgamma, dbeta)."""
+    N, C = y.shape[:2]
+    S = y[0, 0].numel()
+    g = g.contiguous()
+    dev = y.device
+    T = int(_lib.load().pf_norm_blocks(S))
+    partials = torch.empty((N, T, C, 2), dtype=torch.float64, device=dev)
+    _lib.call("pf_bn_bwd_reduce_f32", _lib.ptr(g), _lib.ptr(y), _lib.ptr(rows), N, C, S, int(samples_per_stat),
+              int(bool(relu)), _lib.ptr(partials), _lib.stream(), algo_bytes=8.0 * N * C * S)
+    G = N // samples_per_stat
+    coef = torch.empty((2, G, C), dtype=_F32, device=dev)
+    dgamma = torch.empty((C,), dtype=_F32, device=dev)
+    dbeta = torch.empty((C,), dtype=_F32, device=dev)
+    _lib.call("pf_bn_bwd_coeffs_f32", _lib.ptr(partials), T, C, 0, C, float(samples_per_stat) * S, N,
+              int(samples_per_stat), _lib.ptr(rows), _lib.ptr(coef), _lib.ptr(dgamma), _lib.ptr(dbeta), 0, _lib.stream(),
+              algo_bytes=16.0 * N * T * C)
+    dy = torch.empty_like(y)
+    _lib.call("pf_bn_bwd_apply_f32", _lib.ptr(g), _lib.ptr(y), _lib.ptr(rows), _lib.ptr(coef), _lib.ptr(dy), N, C, S,
+              int(samples_per_stat), int(bool(relu)), _lib.stream(), algo_bytes=12.0 * N * C * S)
+    return dy, dgamma, dbeta
+
+
+def rows_bn_backward(g, y, rows, C, G, Ng, groups_per_stat, relu=True):
+    """The same on point-major rows: g, y (G*Ng, ld) views whose first C columns are used."""
+    dev = y.device
+    T = int(_lib.load().pf_rows_bn_blocks(int(G), int(Ng)))
+    partials = torch.empty((G, T, C, 2), dtype=torch.float64, device=dev)
+    _lib.call("pf_rows_bn_bwd_reduce_f32", _lib.ptr(g), int(g.stride(0)), _lib.ptr(y), int(y.stride(0)), _lib.ptr(rows),
+              int(C), int(G), int(Ng), int(groups_per_stat), int(bool(relu)), _lib.ptr(partials), _lib.stream(),
+              algo_bytes=8.0 * G * Ng * C)
+    S = G // groups_per_stat
+    coef = torch.empty((2, S, C), dtype=_F32, device=dev)
+    dgamma = torch.empty((C,), dtype=_F32, device=dev)
+    dbeta = torch.empty((C,), dtype=_F32, device=dev)
+    _lib.call("pf_bn_bwd_coeffs_f32", _lib.ptr(partials), T, C, 0, C, float(groups_per_stat) * Ng, int(G),
+              int(groups_per_stat), _lib.ptr(rows), _lib.ptr(coef), _lib.ptr(dgamma), _lib.ptr(dbeta), 0, _lib.stream(),
+              algo_bytes=16.0 * G * T * C)
+    dy = torch.empty((G * Ng, C), dtype=_F32, device=dev)
+    _lib.call("pf_rows_bn_bwd_apply_f32", _lib.ptr(g), int(g.stride(0)), _lib.ptr(y), int(y.stride(0)), _lib.ptr(rows),
+              _lib.ptr(coef), _lib.ptr(dy), C, int(C), int(G), int(Ng), int(groups_per_stat), int(bool(relu)),
+              _lib.stream(), algo_bytes=12.0 * G * Ng * C)
+    return dy, dgamma, dbeta
+
+
+def rows_affine(y, rows, C, G, Ng, groups_per_stat, relu=True):
+    z = torch.empty((G * Ng, C), dtype=_F32, device=y.device)
+    _lib.call("pf_rows_affine_f32", _lib.ptr(y), int(y.stride(0)), _lib.ptr(rows), _lib.ptr(z), C, int(C), int(G),
+              int(Ng), int(groups_per_stat), int(bool(relu)), _lib.stream(), algo_bytes=8.0 * G * Ng * C)
+    return z
+
+
+def conv_wgrad(gr, x, kernel, stride, pad, x_affine=None, x_samples_per_stat=1):
+    """dw (Cg, Cx, *kernel) = sum gr[n, cg, o] * act(x)[n, cx, o * stride + k - pad] (pf_conv_wgrad_f32).
+    gr (N, Cg, *coarse grid), x (N, Cx, *fine grid), 2-D or 3-D; x_affine = (scale, shift) rows of x's pending
+    BatchNorm + ReLU or None."""
+    nd = gr.dim() - 2
+    N, Cg = gr.shape[:2]
+    Cx = x.shape[1]
+    go = (1,) * (3 - nd) + tuple(gr.shape[2:])
+    xi = (1,) * (3 - nd) + tuple(x.shape[2:])
+    k3 = (1,) * (3 - nd) + tuple(kernel)
+    p3 = (0,) * (3 - nd) + tuple(pad)
+    lib = _lib.load()
+    nbytes = int(lib.pf_conv_wgrad_workspace(N, Cg, Cx, go[0], go[1], go[2], xi[0], xi[1], xi[2], k3[0], k3[1], k3[2],
+                                             int(stride)))
+    if nbytes < 0:
+        raise RuntimeError("conv_wgrad: unsupported shape")
+    work = torch.empty((max(nbytes, 4) // 4,), dtype=_F32, device=gr.device)
+    dw = torch.empty((Cg, Cx) + tuple(kernel), dtype=_F32, device=gr.device)
+    sc, sh = (None, None) if x_affine is None else x_affine
+    taps = k3[0] * k3[1] * k3[2]
+    _lib.call("pf_conv_wgrad_f32", _lib.ptr(gr), _lib.ptr(x), _lib.ptr(dw), N, Cg, Cx, go[0], go[1], go[2], xi[0], xi[1],
+              xi[2], k3[0], k3[1], k3[2], int(stride), p3[0], p3[1], p3[2], _lib.ptr(sc), _lib.ptr(sh),
+              int(x_samples_per_stat), _lib.ptr(work), nbytes, 0, _lib.stream(),
+              algo_bytes=4.0 * (gr.numel() + x.numel()) + 4.0 * dw.numel(),
+              flops=2.0 * N * go[0] * go[1] * go[2] * taps * Cg * Cx)
+    return dw
+
+
+def rows_wgrad(gr, x, Cg, Cx, x_affine=None, x_rows_per_stat=None):
+    """dw (Cg, Cx) = sum_p gr[p, :Cg]^T act(x[p, :Cx]) on point-major row views (pf_rows_wgrad_f32)."""
+    P = gr.shape[0]
+    lib = _lib.load()
+    nbytes = int(lib.pf_rows_wgrad_workspace(P, int(Cg), int(Cx)))
+    if nbytes < 0:
+        raise RuntimeError("rows_wgrad: unsupported shape")
+    work = torch.empty((max(nbytes, 4) // 4,), dtype=_F32, device=gr.device)
+    dw = torch.empty((Cg, Cx), dtype=_F32, device=gr.device)
+    sc, sh = (None, None) if x_affine is None else x_affine
+    _lib.call("pf_rows_wgrad_f32", _lib.ptr(gr), int(gr.stride(0)), _lib.ptr(x), int(x.stride(0)), _lib.ptr(dw), P,
+              int(Cg), int(Cx), _lib.ptr(sc), _lib.ptr(sh), int(x_rows_per_stat or P), _lib.ptr(work), nbytes, 0,
+              _lib.stream(), algo_bytes=4.0 * P * (Cg + Cx) + 4.0 * Cg * Cx, flops=2.0 * P * Cg * Cx)
+    return dw
+
+
+def gemm_rows(x, w, K, n_out):
+    """(P, n_out) = x[:, :K] @ w (K, n_out) on point-major rows through pf_pointwise_gemm_f32 (column chunks of at most
+    128, zero padded to the kernel's 32 / 64 / 128 widths)."""
+    P = x.shape[0]
+    y = torch.empty((P, n_out), dtype=_F32, device=x.device)
+    col = 0
+    while col < n_out:
+        width = min(128, n_out - col)
+        nc = 32 if width <= 32 else (64 if width <= 64 else 128)
+        wt = torch.zeros((K, nc), dtype=_F32, device=x.device)
+        wt[:, :width] = w[:, col:col + width]
+        pointflow.pointwise_gemm(x, True, int(x.stride(0)), wt, y[:, col:], n_out, 1, P, K, width)
+        col += width
+    return y
+
+
+def _flip_t(w):
+    """(Cout, Cin, k...) -> (Cin, Cout, k...) with every spatial axis reversed: the weight of the data gradient of a
+    stride-1 'same' convolution, itself a convolution."""
+    return w.detach().transpose(0, 1).flip(*range(2, w.dim())).contiguous()
+
+
+def conv2d_dgrad(dy, weight, stride):
+    """dL/dx of y = conv2d(x, weight, stride, pad = k // 2) for ImageConv's shapes (3x3 / 1, 5x5 / 2)."""
+    N, Cout, Ho, Wo = dy.shape
+    Cin, k = weight.shape[1], weight.shape[2]
+    dy = dy.contiguous()
+    if stride == 1:
+        wp = pointflow._pack_conv2d_wide(_flip_t(weight))
+        dx = torch.empty((N, Cin, Ho, Wo), dtype=_F32, device=dy.device)
+        _lib.call("pf_conv2d_wide_f32", _lib.ptr(dy), _lib.ptr(wp), _lib.ptr(dx), N, Cout, Cin, Ho, Wo, int(k), 1,
+                  None, None, None, 1, None, 0, _lib.stream(),
+                  algo_bytes=4.0 * N * (Cin + Cout) * Ho * Wo, flops=2.0 * N * Ho * Wo * k * k * Cin * Cout)
+        return dx
+    ncp = (Cin + 15) // 16 * 16
+    wp = torch.zeros((Cout // 4, k * k, 4, ncp), dtype=_F32, device=dy.device)
+    wp[..., :Cin] = weight.detach().reshape(Cout // 4, 4, Cin, k * k).permute(0, 3, 1, 2)
+    dx = torch.empty((N, Cin, 2 * Ho, 2 * Wo), dtype=_F32, device=dy.device)
+    _lib.call("pf_deconv2d_k5s2_f32", _lib.ptr(dy), _lib.ptr(wp), _lib.ptr(dx), N, Cout, Cin, Ho, Wo, _lib.stream(),
+              algo_bytes=4.0 * N * (Cout + 4 * Cin) * Ho * Wo, flops=2.0 * N * Ho * Wo * k * k * Cin * Cout)
+    return dx
+
+
+def _conv3d_k3_w(x, w, stride):
+    """conv3d 3x3x3 / pad 1 with an explicit weight tensor (Cout, Cin, 3, 3, 3) on the forward kernels: Cout <= 32
+    through pf_conv3d_k3_f32 (<= 8 at stride 1: the paired-rows kernel), Cout = 64 as two halves (one sample)."""
+    Cout = w.shape[0]
+    if Cout <= 32:
+        return pointflow.conv3d_k3(x, w, stride, False)[0]
+    N, Cin, D, H, W = x.shape
+    if N != 1 or stride != 1 or Cout % 32:
+        raise RuntimeError("conv3d dgrad: unsupported shape")
+    y = torch.empty((1, Cout, D, H, W), dtype=_F32, device=x.device)
+    for c0 in range(0, Cout, 32):
+        wp = pointflow.pack_conv3d_weight(w[c0:c0 + 32].contiguous())
+        _lib.call("pf_conv3d_k3_f32", _lib.ptr(x), _lib.ptr(wp), _lib.ptr(y[:, c0:]), 1, Cin, 32, D, H, W, 1, None, None,
+                  None, 1, None, _lib.stream(), algo_bytes=4.0 * (Cin + 32) * D * H * W,
+                  flops=2.0 * D * H * W * 27 * Cin * 32)
+    return y
+
+
+def _conv3d_bottom_w(x, w, stride):
+    """pf_conv3d_bottom_f32 (Cout = 64; 32 -> 64 / 2 or 64 -> 64 / 1) with an explicit weight (64, Cin, 3, 3, 3)."""
+    N, Cin, Di, Hi, Wi = x.shape
+    Do, Ho, Wo = (Di - 1) // stride + 1, (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
+    wp = w.detach().to(_F32).permute(2, 3, 4, 1, 0).reshape(3, 3, 3, Cin // 16, 4, 4, 64).permute(0, 1, 2, 3, 4, 6, 5)
+    wp = wp.contiguous()
+    y = torch.empty((N, 64, Do, Ho, Wo), dtype=_F32, device=x.device)
+    _lib.call("pf_conv3d_bottom_f32", _lib.ptr(x), _lib.ptr(wp), _lib.ptr(y), N, Cin, 64, Di, Hi, Wi, int(stride), None,
+              None, None, 1, None, _lib.stream(), algo_bytes=4.0 * N * (Cin * Di * Hi * Wi + 64 * Do * Ho * Wo),
+              flops=2.0 * N * Do * Ho * Wo * 27 * Cin * 64)
+    return y
+
+
+def _deconv3d_bottom_w(x, w):
+    """pf_deconv3d_bottom_f32 with an explicit ConvTranspose3d-layout weight (64, 32, 3, 3, 3)."""
+    N, Cin, Di, Hi, Wi = x.shape
+    wp = w.detach().to(_F32).permute(2, 3, 4, 0, 1).reshape(27, Cin // 16, 4, 4, 32).permute(0, 1, 2, 4, 3).contiguous()
+    y = torch.empty((N, 32, 2 * Di, 2 * Hi, 2 * Wi), dtype=_F32, device=x.device)
+    _lib.call("pf_deconv3d_bottom_f32", _lib.ptr(x), _lib.ptr(wp), _lib.ptr(y), N, Cin, 32, Di, Hi, Wi, None, None, None,
+              1, None, _lib.stream(), algo_bytes=4.0 * N * Di * Hi * Wi * (Cin + 8 * 32),
+              flops=2.0 * N * Di * Hi * Wi * 27 * Cin * 32)
+    return y
+
+
+# ---------------------------------------------------------------------------------------------
+# ImageConv tower (reference networks.py:84-124), all V views of one scene per launch, per-view BatchNorm statistics
+# ---------------------------------------------------------------------------------------------
+_STAGES = ("conv0", "conv1", "conv2", "conv3")
+
+
+def _tower_blocks(tower):
+    out = []
+    for name in _STAGES:
+        seq = getattr(tower, name)
+        for i, blk in enumerate(seq):
+            conv, bn = (blk.conv, blk.bn) if hasattr(blk, "bn") else (blk, None)
+            out.append((name, i + 1 == len(seq), conv, bn))
+    return out
+
+
+def tower_supported(tower, img):
+    """The fused training path of a tower: every layer a tower-kernel shape with a train-mode BatchNorm + ReLU (the
+    last one plain), stride-2 data gradients within the transposed kernel's widths."""
+    if img.dim() != 4 or img.dtype != _F32 or not img.is_cuda:
+        return False
+    blocks = _tower_blocks(tower)
+    for i, (name, last, conv, bn) in enumerate(blocks):
+        if not pointflow.conv2d_wide_supported(conv):
+            return False
+        blk = getattr(tower, name)
+        if bn is not None and not (bn.training and bn.affine and bn.momentum is not None):
+            return False
+        if conv.stride[0] == 2 and not _lib.load().pf_deconv2d_k5s2_supported(conv.out_channels, conv.in_channels):
+            return False
+        if conv.stride[0] == 1 and i > 0 and not _lib.load().pf_conv2d_wide_supported(
+                conv.out_channels, conv.in_channels, int(conv.kernel_size[0]), 1):
+            return False
+    for name in _STAGES:
+        for blk in getattr(tower, name):
+            if hasattr(blk, "bn") and not blk.relu:
+                return False
+    return blocks[-1][3] is None and all(b[3] is not None for b in blocks[:-1])
+
+
+class _TowerTrain(torch.autograd.Function):
+    """(V, 3, H, W) -> the stage outputs named in ``want`` (normalised; "conv3" is the plain last convolution)."""
+
+    @staticmethod
+    def forward(ctx, img, tower, want, *params):
+        blocks = _tower_blocks(tower)
+        V = img.shape[0]
+        x = img.detach().contiguous()
+        saved, outs = [], []
+        pending = None
+        with torch.cuda.device(x.device):
+            for name, stage_end, conv, bn in blocks:
+                y, partials = pointflow.conv2d_wide(x, conv, pending, 1, bn is not None)
+                rows = None
+                if bn is not None:
+                    S = y[0, 0].numel()
+                    rows = bn_train_rows(bn, partials, 0, conv.out_channels, float(S), V, 1)
+                saved.append((x, pending, y, rows))
+                if stage_end and name in want:
+                    outs.append(y if rows is None else channel_affine(y, rows, 1, True))
+                x, pending = y, (None if rows is None else (rows[0], rows[1]))
+            pointflow.flush_counters()
+        ctx.tower, ctx.want, ctx.saved = tower, tuple(want), saved
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        tower, want, saved = ctx.tower, ctx.want, ctx.saved
+        blocks = _tower_blocks(tower)
+        incoming = dict(zip([n for n in _STAGES if n in want], grads))
+        gparams = [None] * sum(1 if b[3] is None else 3 for b in blocks)
+        slots, k = [], 0
+        for b in blocks:
+            slots.append(k)
+            k += 1 if b[3] is None else 3
+        g = None
+        with torch.cuda.device(saved[0][0].device):
+            for i in range(len(blocks) - 1, -1, -1):
+                name, stage_end, conv, bn = blocks[i]
+                x, pending, y, rows = saved[i]
+                if stage_end and incoming.get(name) is not None:
+                    gi = incoming[name].contiguous()
+                    g = gi if g is None else g + gi
+                if g is None:
+                    continue
+                if bn is not None:
+                    dy, dgamma, dbeta = bn_backward(g, y, rows, 1, True)
+                    gparams[slots[i] + 1], gparams[slots[i] + 2] = dgamma, dbeta
+                else:
+                    dy = g.contiguous()
+                ks, st = int(conv.kernel_size[0]), int(conv.stride[0])
+                gparams[slots[i]] = conv_wgrad(dy, x, (ks, ks), st, (ks // 2, ks // 2), x_affine=pending)
+                g = conv2d_dgrad(dy, conv.weight, st) if i > 0 else None
+        return (None, None, None) + tuple(gparams)
+
+
+def tower_params(tower):
+    ps = []
+    for _, _, conv, bn in _tower_blocks(tower):
+        ps.append(conv.weight)
+        if bn is not None:
+            ps += [bn.weight, bn.bias]
+    return ps
+
+
+def tower_train(tower, img, want):
+    """Stage outputs {name: (V, c, h, w)} of ``tower`` for the views ``img`` (V, 3, H, W) with the hand-written
+    backward attached."""
+    want = tuple(n for n in _STAGES if n in want)
+    outs = _TowerTrain.apply(img, tower, want, *tower_params(tower))
+    return dict(zip(want, outs))
+
+
+# ---------------------------------------------------------------------------------------------
+# VolumeConv (reference networks.py:127-167), one scene
+# ---------------------------------------------------------------------------------------------
+def volume_supported(vc, x):
+    if x.dim() != 5 or x.shape[0] != 1 or x.dtype != _F32 or not x.is_cuda:
+        return False
+    if vc.in_channels != 64 or vc.base_channels != 8 or not vc._bottom_fusable():
+        return False
+    D, H, W = x.shape[2:]
+    if D % 8 or H % 8 or W % 8:
+        return False
+    for name in ("conv0_1", "conv1_0", "conv2_0", "conv3_0", "conv1_1", "conv2_1", "conv3_1", "conv4_0", "conv5_0",
+                 "conv6_0"):
+        blk = getattr(vc, name)
+        if blk.bn is None or not blk.relu or not (blk.bn.training and blk.bn.affine and blk.bn.momentum is not None):
+            return False
+    return type(vc.conv6_2) is torch.nn.Conv3d and vc.conv6_2.bias is None
+
+
+_VC_BLOCKS = ("conv0_1", "conv1_0", "conv2_0", "conv3_0", "conv3_1", "conv1_1", "conv2_1", "conv4_0", "conv5_0",
+              "conv6_0")
+
+
+def volume_params(vc):
+    ps = []
+    for name in _VC_BLOCKS:
+        blk = getattr(vc, name)
+        ps += [blk.conv.weight, blk.bn.weight, blk.bn.bias]
+    ps.append(vc.conv6_2.weight)
+    return ps
+
+
+class _VolumeTrain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cost, vc, *params):
+        x0 = cost.detach().contiguous()
+        rec = {}
+
+        def bn_act(name, y, partials):
+            blk = getattr(vc, name)
+            S = y[0, 0].numel()
+            rows = bn_train_rows(blk.bn, partials, 0, y.shape[1], float(S), 1, 1)
+            z = channel_affine(y, rows, 1, True)
+            return rows, z
+
+        def conv(name, x, stride):
+            blk = getattr(vc, name)
+            y, p = pointflow.conv3d_k3(x, blk.conv.weight, stride, True)
+            rows, z = bn_act(name, y, p)
+            rec[name] = (x, y, rows)
+            return z
+
+        with torch.cuda.device(x0.device):
+            z01 = conv("conv0_1", x0, 1)
+            z10 = conv("conv1_0", x0, 2)
+            z20 = conv("conv2_0", z10, 2)
+            y30, p30 = pointflow.conv3d_bottom(z20, vc.conv3_0.conv, None, 1, True)
+            r30, z30 = bn_act("conv3_0", y30, p30)
+            rec["conv3_0"] = (z20, y30, r30)
+            y31, p31 = pointflow.conv3d_bottom(z30, vc.conv3_1.conv, None, 1, True)
+            r31, z31 = bn_act("conv3_1", y31, p31)
+            rec["conv3_1"] = (z30, y31, r31)
+            z11 = conv("conv1_1", z10, 1)
+            z21 = conv("conv2_1", z20, 1)
+            y40, p40 = pointflow.deconv3d_bottom(z31, vc.conv4_0.conv, None, 1, True)
+            r40, z40 = bn_act("conv4_0", y40, p40)
+            rec["conv4_0"] = (z31, y40, r40)
+            s5 = z40 + z21
+            y50, p50 = pointflow.deconv3d_k3s2(s5, None, vc.conv5_0.conv.weight, True)
+            r50, z50 = bn_act("conv5_0", y50, p50)
+            rec["conv5_0"] = (s5, y50, r50)
+            s6 = z50 + z11
+            y60, p60 = pointflow.deconv3d_k3s2(s6, None, vc.conv6_0.conv.weight, True)
+            r60, z60 = bn_act("conv6_0", y60, p60)
+            rec["conv6_0"] = (s6, y60, r60)
+            s7 = z60 + z01
+            out = pointflow.conv3d_k3_few(s7, vc.conv6_2.weight)
+            rec["conv6_2"] = (s7, None, None)
+            pointflow.flush_counters()
+        ctx.vc, ctx.rec = vc, rec
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        vc, rec = ctx.vc, ctx.rec
+        grads = {}
+        K3, P3 = (3, 3, 3), (1, 1, 1)
+
+        def bnb(name, g):
+            _, y, rows = rec[name]
+            dy, dgamma, dbeta = bn_backward(g, y, rows, 1, True)
+            grads[name + ".bn"] = (dgamma, dbeta)
+            return dy
+
+        def conv_back(name, g, stride):          # Conv3d block: returns dy
+            dy = bnb(name, g)
+            grads[name] = conv_wgrad(dy, rec[name][0], K3, stride, P3)
+            return dy
+
+        def deconv_back(name, g):                # Deconv3d block: weight gradient in (Cin, Cout, 3, 3, 3) order
+            dy = bnb(name, g)
+            grads[name] = conv_wgrad(rec[name][0], dy, K3, 2, P3)
+            return dy
+
+        with torch.cuda.device(gout.device):
+            g = gout.contiguous()
+            w62 = vc.conv6_2.weight
+            grads["conv6_2"] = conv_wgrad(g, rec["conv6_2"][0], K3, 1, P3)
+            wf = w62.detach().flip(2, 3, 4).reshape(w62.shape[1], 27).contiguous()
+            D, H, W = g.shape[2:]
+            g7 = torch.empty((1, w62.shape[1], D, H, W), dtype=_F32, device=g.device)
+            _lib.call("pf_conv3d_k3_c1_f32", _lib.ptr(g), _lib.ptr(wf), _lib.ptr(g7), 1, int(w62.shape[1]), D, H, W,
+                      _lib.stream(), algo_bytes=4.0 * (1 + w62.shape[1]) * D * H * W)
+            # decoder: a ConvTranspose3d's data gradient is the stride-2 convolution with its weight read (Cout', Cin')
+            dy60 = deconv_back("conv6_0", g7)
+            g6 = _conv3d_k3_w(dy60, vc.conv6_0.conv.weight.detach(), 2)               # -> dz50, dz11
+            dy50 = deconv_back("conv5_0", g6)
+            g5 = _conv3d_k3_w(dy50, vc.conv5_0.conv.weight.detach(), 2)               # -> dz40, dz21
+            dy40 = deconv_back("conv4_0", g5)
+            g31 = _conv3d_bottom_w(dy40, vc.conv4_0.conv.weight.detach(), 2)          # -> dz31
+            dy31 = conv_back("conv3_1", g31, 1)
+            g30 = _conv3d_bottom_w(dy31, _flip_t(vc.conv3_1.conv.weight), 1)
+            dy30 = conv_back("conv3_0", g30, 2)
+            g20 = _deconv3d_bottom_w(dy30, vc.conv3_0.conv.weight.detach())           # stride-2 conv: transposed kernel
+            dy21 = conv_back("conv2_1", g5, 1)
+            g20 = g20 + _conv3d_k3_w(dy21, _flip_t(vc.conv2_1.conv.weight), 1)
+            dy20 = conv_back("conv2_0", g20, 2)
+            g10 = pointflow.deconv3d_k3s2(dy20, None, vc.conv2_0.conv.weight.detach(), False)[0]
+            dy11 = conv_back("conv1_1", g6, 1)
+            g10 = g10 + _conv3d_k3_w(dy11, _flip_t(vc.conv1_1.conv.weight), 1)
+            dy10 = conv_back("conv1_0", g10, 2)
+            gx = pointflow.deconv3d_k3s2(dy10, None, vc.conv1_0.conv.weight.detach(), False)[0]
+            dy01 = conv_back("conv0_1", g7, 1)
+            gx = gx + _conv3d_k3_w(dy01, _flip_t(vc.conv0_1.conv.weight), 1)
+        out = [gx, None]
+        for name in _VC_BLOCKS:
+            out += [grads[name], grads[name + ".bn"][0], grads[name + ".bn"][1]]
+        out.append(grads["conv6_2"])
+        return tuple(out)
+
+
+def volume_train(vc, cost):
+    return _VolumeTrain.apply(cost, vc, *volume_params(vc))
+
+
+# ---------------------------------------------------------------------------------------------
+# PointFlow chain: EdgeConv x3 on point-major rows, then the flow MLP (reference model.py:205-216, networks.py:9-81)
+# ---------------------------------------------------------------------------------------------
+def edge_chain_supported(edge_convs, feature, idx):
+    if feature.dim() != 2 or not feature.is_cuda or feature.dtype != _F32 or idx.dim() != 3 or idx.shape[0] != 1:
+        return False
+    cin = feature.shape[1]
+    for m in edge_convs:
+        C = m.conv1.weight.shape[0]
+        if C not in (32, 64) or m.conv1.weight.shape[1] != cin or cin % 4:
+            return False
+        if not (m.bn.training and m.bn.affine and m.bn.momentum is not None):
+            return False
+        cin = (2 if m.concat else 1) * C
+    return True
+
+
+def edge_chain_params(edge_convs):
+    ps = []
+    for m in edge_convs:
+        ps += [m.conv1.weight, m.conv2.weight, m.bn.weight, m.bn.bias]
+    return ps
+
+
+class _EdgeChainTrain(torch.autograd.Function):
+    """feature (N, Cin) point-major rows + idx (1, N, k) -> the (N, sum widths) concat buffer of the EdgeConv outputs
+    (reference model.py:209-216: each layer's output is the next one's input and a slice of the MLP's input)."""
+
+    @staticmethod
+    def forward(ctx, feature, idx, edge_convs, *params):
+        x = feature.detach().contiguous()
+        N, cin = x.shape
+        idx = idx.contiguous()
+        widths = [(2 if m.concat else 1) * m.conv1.weight.shape[0] for m in edge_convs]
+        ctot = sum(widths)
+        edges = torch.empty((N, ctot), dtype=_F32, device=x.device)
+        keeps = []
+        X, ldx, K, col = x, cin, cin, 0
+        with torch.cuda.device(x.device):
+            for m, wdt in zip(edge_convs, widths):
+                keep = {}
+                Y = edges[:, col:]
+                pointflow.edge_conv_fused(X, True, ldx, K, 1, N, idx, m.conv1.weight, m.conv2.weight, m.bn, m.concat, Y,
+                                          ctot, groups_per_stat=1, keep=keep)
+                keeps.append((keep, X, ldx, K, col, wdt))
+                X, ldx, K = Y, ctot, wdt
+                col += wdt
+            pointflow.flush_counters()
+        ctx.edge_convs, ctx.keeps, ctx.idx, ctx.N, ctx.ctot = edge_convs, keeps, idx, N, ctot
+        return edges
+
+    @staticmethod
+    def backward(ctx, gedges):
+        edge_convs, keeps, idx, N = ctx.edge_convs, ctx.keeps, ctx.idx, ctx.N
+        k = idx.shape[2]
+        g = gedges.contiguous().clone()            # a layer's data gradient is added into its input's column slice
+        gparams = []
+        gx = None
+        with torch.cuda.device(g.device):
+            for m, (keep, X, ldx, K, col, wdt) in reversed(list(zip(edge_convs, keeps))):
+                C = m.conv1.weight.shape[0]
+                gy = g[:, col:col + wdt]
+                grad_le, dgamma, dbeta = pointflow.edge_conv_backward(keep, idx, gy, C, k, 1, N, 1, m.concat)
+                wcat = torch.cat([m.conv1.weight.detach().reshape(C, K), m.conv2.weight.detach().reshape(C, K)], dim=0)
+                dw = rows_wgrad(grad_le, X, 2 * C, K)
+                dX = gemm_rows(grad_le, wcat, 2 * C, K)                         # (N, K)
+                if col == 0:
+                    gx = dX
+                else:
+                    g[:, col - K:col] += dX
+                gparams = [dw[:C].reshape(m.conv1.weight.shape), dw[C:].reshape(m.conv2.weight.shape), dgamma,
+                           dbeta] + gparams
+        return (gx, None, None) + tuple(gparams)
+
+
+def edge_chain_train(edge_convs, feature, idx):
+    return _EdgeChainTrain.apply(feature, idx, edge_convs, *edge_chain_params(edge_convs))
+
+
+def mlp_supported(shared, x):
+    if x.dim() != 2 or not x.is_cuda or x.dtype != _F32 or x.shape[1] % 4:
+        return False
+    cin = x.shape[1]
+    for blk in shared:
+        conv, bn = blk.conv, blk.bn
+        if (type(conv) is not torch.nn.Conv1d or conv.kernel_size != (1,) or conv.bias is not None or bn is None
+                or not blk.relu or conv.in_channels != cin or conv.out_channels not in (16, 32, 64, 128)):
+            return False
+        if not (bn.training and bn.affine and bn.momentum is not None):
+            return False
+        cin = conv.out_channels
+    return len(shared) >= 1
+
+
+def mlp_params(shared):
+    ps = []
+    for blk in shared:
+        ps += [blk.conv.weight, blk.bn.weight, blk.bn.bias]
+    return ps
+
+
+class _MLPTrain(torch.autograd.Function):
+    """SharedMLP over point-major rows (reference nn/mlp.py:45-81): (N, Cin) -> the last block's normalised (N, Cout)."""
+
+    @staticmethod
+    def forward(ctx, x, shared, *params):
+        X = x.detach()
+        if X.stride(1) != 1:
+            X = X.contiguous()
+        N = X.shape[0]
+        saved = []
+        affine = None
+        ldx, K = int(X.stride(0)), X.shape[1]
+        with torch.cuda.device(X.device):
+            for blk in shared:
+                Wt, cout = pointflow.pack_weight_t(blk.conv.weight)
+                Z = torch.empty((N, cout), dtype=_F32, device=X.device)
+                part = pointflow.pointwise_gemm(X, True, ldx, Wt, Z, cout, 1, N, K, cout, in_affine=affine,
+                                                want_stats=True)
+                rows = bn_train_rows(blk.bn, part, 0, cout, float(N), 1, 1)
+                saved.append((X, affine, Z, rows, K, cout))
+                X, ldx, K, affine = Z, cout, cout, (rows[0], rows[1])
+            out = rows_affine(X, saved[-1][3], K, 1, N, 1, True)
+            pointflow.flush_counters()
+        ctx.shared, ctx.saved, ctx.N = shared, saved, N
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        shared, saved, N = ctx.shared, ctx.saved, ctx.N
+        g = gout.contiguous()
+        gparams = []
+        with torch.cuda.device(g.device):
+            for blk, (X, affine, Z, rows, K, cout) in reversed(list(zip(shared, saved))):
+                dZ, dgamma, dbeta = rows_bn_backward(g, Z, rows, cout, 1, N, 1, True)
+                dw = rows_wgrad(dZ, X, cout, K, x_affine=affine, x_rows_per_stat=N)
+                g = gemm_rows(dZ, blk.conv.weight.detach().reshape(cout, K), cout, K)   # gradient w.r.t. act(X)
+                gparams = [dw.reshape(blk.conv.weight.shape), dgamma, dbeta] + gparams
+        return (g, None) + tuple(gparams)
+
+
+def mlp_train(shared, x):
+    return _MLPTrain.apply(x, shared, *mlp_params(shared))

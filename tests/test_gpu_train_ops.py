@@ -1,0 +1,281 @@
+"""GPU parity tests of the training step's own backward kernels (Row Z; pointmvsnet_amd/train_ops.py, csrc/norm_bwd.hip,
+csrc/conv_wgrad.hip, csrc/conv_dgrad.hip) against float64 autograd of the SAME ATen operators the reference
+differentiates (reference nn/conv.py:24-35,62-77,108-121,197-210; networks.py:84-167; train.py:80), evaluated on the
+same device.  Tolerances are float32-rounding class: a weight gradient is a sum over 10^4..10^6 positions of float32
+products accumulated in float32 MFMA chains per block and added in a fixed order, so it is compared at 2e-5 of the
+tensor's largest entry; data gradients and BatchNorm gradients at 1e-5 / 2e-5.  Every result is produced twice and
+must be bit-identical (no atomics anywhere in the step).
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import report
+from pointmvsnet_amd import networks, synthetic, train_ops
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
+
+
+def _seeded(shape, dev, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dev)
+
+
+@pytest.mark.parametrize("N,C,S,sps,relu", [(3, 8, (40, 56), 1, True), (2, 16, (6, 10, 12), 2, True),
+                                            (1, 64, (3, 4, 5), 1, False)])
+def test_bn_relu_backward_vs_float64_autograd(dev, N, C, S, sps, relu):
+    """pf_bn_train_rows + pf_bn_bwd_reduce / _coeffs / _apply against autograd of F.batch_norm(training) (+ relu)."""
+    y = _seeded((N, C) + S, dev, 1, 2.0) + 0.3
+    g = _seeded((N, C) + S, dev, 2)
+    bn = (torch.nn.BatchNorm2d if len(S) == 2 else torch.nn.BatchNorm3d)(C).to(dev).train()
+    with torch.no_grad():
+        bn.weight.copy_(1.0 + 0.2 * _seeded((C,), dev, 3))
+        bn.bias.copy_(0.1 * _seeded((C,), dev, 4))
+    spatial = y[0, 0].numel()
+    T = 7
+    # statistics partials as a producer's epilogue would leave them: T unequal slices of every (sample, channel)
+    flat = y.reshape(N, C, spatial).double()
+    cuts = [0] + sorted(set(int(spatial * (i + 1) / T) for i in range(T)))
+    parts = torch.zeros((N, T, C, 2), dtype=torch.float64, device=dev)
+    for t in range(len(cuts) - 1):
+        seg = flat[:, :, cuts[t]:cuts[t + 1]]
+        parts[:, t, :, 0] = seg.sum(-1)
+        parts[:, t, :, 1] = (seg * seg).sum(-1)
+    rows = train_ops.bn_train_rows(bn, parts, 0, C, float(sps * spatial), N, sps)
+    z = train_ops.channel_affine(y, rows, sps, relu)
+    dy, dgamma, dbeta = train_ops.bn_backward(g, y, rows, sps, relu)
+    dy2, dgamma2, dbeta2 = train_ops.bn_backward(g, y, rows, sps, relu)
+    assert torch.equal(dy, dy2) and torch.equal(dgamma, dgamma2) and torch.equal(dbeta, dbeta2)
+    # reference: one F.batch_norm call per statistic group, float64
+    yd = y.double().requires_grad_(True)
+    w, b = bn.weight.double().detach().requires_grad_(True), bn.bias.double().detach().requires_grad_(True)
+    outs = []
+    for s in range(N // sps):
+        o = F.batch_norm(yd[s * sps:(s + 1) * sps], None, None, w, b, True, 0.0, bn.eps)
+        outs.append(torch.relu(o) if relu else o)
+    zr = torch.cat(outs)
+    zr.backward(g.double())
+    e = dict(z=_rel(z, zr), dy=_rel(dy, yd.grad), dgamma=_rel(dgamma, w.grad), dbeta=_rel(dbeta, b.grad))
+    report("bn_bwd_%dx%dx%d_sps%d" % (N, C, spatial, sps), **e)
+    assert e["z"] < 2e-6 and e["dy"] < 1e-5 and e["dgamma"] < 2e-5 and e["dbeta"] < 2e-5, e
+
+
+_WG_CASES = [
+    # (N, Cout, Cin, in spatial, k, stride, affine)   -- ImageConv's eleven layer shapes (networks.py:89-110)
+    (3, 8, 3, (40, 56), 3, 1, False), (3, 8, 8, (40, 56), 3, 1, True), (3, 16, 8, (40, 56), 5, 2, True),
+    (2, 16, 16, (24, 40), 3, 1, True), (2, 32, 16, (24, 40), 5, 2, True), (2, 32, 32, (16, 24), 3, 1, True),
+    (2, 64, 32, (16, 24), 5, 2, True), (3, 64, 64, (8, 12), 3, 1, False),
+    # VolumeConv's (networks.py:133-147)
+    (1, 8, 64, (8, 16, 24), 3, 1, False), (1, 16, 64, (8, 16, 24), 3, 2, False), (1, 32, 16, (8, 8, 12), 3, 2, True),
+    (1, 64, 32, (4, 8, 12), 3, 2, False), (1, 64, 64, (2, 4, 6), 3, 1, False), (1, 16, 16, (4, 8, 12), 3, 1, False),
+    (1, 32, 32, (4, 4, 6), 3, 1, False), (1, 1, 8, (8, 16, 24), 3, 1, False),
+]
+
+
+@pytest.mark.parametrize("N,Cout,Cin,sp,k,stride,affine", _WG_CASES)
+def test_conv_weight_gradient_vs_float64_autograd(dev, N, Cout, Cin, sp, k, stride, affine):
+    nd = len(sp)
+    conv = F.conv2d if nd == 2 else F.conv3d
+    x = _seeded((N, Cin) + sp, dev, 5)
+    osp = tuple((s - 1) // stride + 1 for s in sp)
+    dy = _seeded((N, Cout) + osp, dev, 6)
+    sc = sh = None
+    xin = x.double()
+    if affine:
+        sc = (1.0 + 0.3 * _seeded((N, Cin), dev, 7)).contiguous()
+        sh = (0.2 * _seeded((N, Cin), dev, 8)).contiguous()
+        view = (N, Cin) + (1,) * nd
+        xin = torch.relu(xin * sc.double().view(view) + sh.double().view(view))
+    w = torch.zeros((Cout, Cin) + (k,) * nd, dtype=torch.float64, device=dev, requires_grad=True)
+    conv(xin, w, None, stride, k // 2).backward(dy.double())
+    dw = train_ops.conv_wgrad(dy, x, (k,) * nd, stride, (k // 2,) * nd, None if sc is None else (sc, sh), 1)
+    dw2 = train_ops.conv_wgrad(dy, x, (k,) * nd, stride, (k // 2,) * nd, None if sc is None else (sc, sh), 1)
+    assert torch.equal(dw, dw2)
+    err = _rel(dw, w.grad)
+    report("conv_wgrad_%dd_%dto%d_k%ds%d" % (nd, Cin, Cout, k, stride), rel=err)
+    assert dw.shape == w.shape and err < 2e-5, err
+
+
+@pytest.mark.parametrize("Cin,Cout,sp", [(64, 32, (2, 4, 6)), (32, 16, (4, 8, 12)), (16, 8, (8, 8, 12))])
+def test_transposed_conv_weight_gradient_vs_float64_autograd(dev, Cin, Cout, sp):
+    """ConvTranspose3d(3, stride 2, pad 1, output_padding 1), VolumeConv's decoder (networks.py:141-143): the layer
+    input sits on the coarse grid, dL/dy on the fine one; the result is in nn.ConvTranspose3d's (Cin, Cout, ...) order."""
+    x = _seeded((1, Cin) + sp, dev, 9)
+    dy = _seeded((1, Cout) + tuple(2 * s for s in sp), dev, 10)
+    w = torch.zeros((Cin, Cout, 3, 3, 3), dtype=torch.float64, device=dev, requires_grad=True)
+    F.conv_transpose3d(x.double(), w, None, 2, 1, 1).backward(dy.double())
+    dw = train_ops.conv_wgrad(x, dy, (3, 3, 3), 2, (1, 1, 1))
+    err = _rel(dw, w.grad)
+    report("deconv_wgrad_%dto%d" % (Cin, Cout), rel=err)
+    assert dw.shape == w.shape and err < 2e-5, err
+
+
+@pytest.mark.parametrize("P,Cg,Cx,affine", [(5000, 64, 136, False), (4097, 64, 32, False), (3000, 128, 64, False),
+                                            (6000, 64, 224, False), (2500, 64, 64, True), (2500, 16, 64, True)])
+def test_rows_weight_gradient_vs_float64(dev, P, Cg, Cx, affine):
+    """1x1 convolutions over point-major rows (EdgeConv's conv1 / conv2, the flow MLP) incl. strided row views."""
+    gbuf = _seeded((P, Cg + 8), dev, 11)
+    xbuf = _seeded((P, Cx + 12), dev, 12)
+    g, x = gbuf[:, 4:4 + Cg], xbuf[:, 8:8 + Cx]
+    xa = x.double()
+    aff = None
+    if affine:
+        sc = (1.0 + 0.3 * _seeded((1, Cx), dev, 13)).contiguous()
+        sh = (0.2 * _seeded((1, Cx), dev, 14)).contiguous()
+        aff = (sc, sh)
+        xa = torch.relu(xa * sc.double() + sh.double())
+    ref = g.double().t() @ xa
+    dw = train_ops.rows_wgrad(g, x, Cg, Cx, aff, P)
+    assert torch.equal(dw, train_ops.rows_wgrad(g, x, Cg, Cx, aff, P))
+    err = _rel(dw, ref)
+    report("rows_wgrad_%dx%d" % (Cg, Cx), rel=err)
+    assert err < 2e-5, err
+
+
+@pytest.mark.parametrize("N,Cout,Cin,sp,k,stride", [(3, 8, 8, (40, 56), 3, 1), (2, 16, 8, (40, 56), 5, 2),
+                                                    (2, 32, 16, (24, 40), 5, 2), (2, 64, 32, (16, 24), 5, 2),
+                                                    (2, 64, 32, (10, 14), 5, 2), (2, 64, 64, (8, 12), 3, 1)])
+def test_conv2d_data_gradient_vs_float64_autograd(dev, N, Cout, Cin, sp, k, stride):
+    x = torch.zeros((N, Cin) + sp, dtype=torch.float64, device=dev, requires_grad=True)
+    w = _seeded((Cout, Cin, k, k), dev, 15, 0.2)
+    osp = tuple((s - 1) // stride + 1 for s in sp)
+    dy = _seeded((N, Cout) + osp, dev, 16)
+    F.conv2d(x, w.double(), None, stride, k // 2).backward(dy.double())
+    dx = train_ops.conv2d_dgrad(dy, w, stride)
+    err = _rel(dx, x.grad)
+    report("conv2d_dgrad_%dto%d_k%ds%d" % (Cin, Cout, k, stride), rel=err)
+    assert dx.shape == x.shape and err < 1e-5, err
+
+
+def _grads(params):
+    return [p.grad.detach().clone() for p in params]
+
+
+def test_image_tower_node_vs_float64_autograd(dev):
+    """The whole ImageConv tower (eleven layers, per-view BatchNorm statistics) as ONE autograd node against the ATen
+    composition in float64: the three stage outputs, every parameter gradient, the running statistics."""
+    tower = networks.ImageConv(8)
+    synthetic.seed_weights(tower, seed=3)
+    tower = tower.to(dev).train()
+    ref = networks.ImageConv(8)
+    ref.load_state_dict({k: v.cpu() for k, v in tower.state_dict().items()})
+    ref = ref.to(dev).double().train()
+    img = _seeded((3, 3, 64, 96), dev, 17)
+    assert train_ops.tower_supported(tower, img)
+    names = ("conv1", "conv2", "conv3")
+    out = train_ops.tower_train(tower, img, names)
+    gs = {n: _seeded(tuple(out[n].shape), dev, 18 + i) for i, n in enumerate(names)}
+    sum((out[n] * gs[n]).sum() for n in names).backward()
+    mine = _grads(tower.parameters())
+    tower.zero_grad()
+    out_b = train_ops.tower_train(tower, img, names)
+    sum((out_b[n] * gs[n]).sum() for n in names).backward()
+    for a, b in zip(mine, _grads(tower.parameters())):
+        assert torch.equal(a, b)                                        # bit-reproducible
+    views = [ref(img[v:v + 1].double()) for v in range(3)]              # one call per view: per-view statistics
+    sum((torch.cat([views[v][n] for v in range(3)]) * gs[n].double()).sum() for n in names).backward()
+    worst = 0.0
+    for n in names:
+        e = _rel(out[n], torch.cat([views[v][n] for v in range(3)]))
+        worst = max(worst, e)
+        assert e < 2e-5, (n, e)
+    errs = sorted(((_rel(a, p.grad), k) for a, (k, p) in zip(mine, ref.named_parameters())), reverse=True)
+    report("tower_node", out_rel=worst, worst_grad_rel=errs[0][0], median_grad_rel=errs[len(errs) // 2][0])
+    assert errs[0][0] < 2e-4, errs[:5]
+    for (k, a), (_, b) in zip(tower.named_buffers(), ref.named_buffers()):
+        if "num_batches" in k:
+            assert int(a) == 2 * int(b) == 6, k                          # two forwards of three views here
+    # only "conv3" wanted (the coarse tower): same gradients for the layers that feed it alone
+    tower.zero_grad()
+    o3 = train_ops.tower_train(tower, img, ("conv3",))["conv3"]
+    (o3 * gs["conv3"]).sum().backward()
+    assert all(p.grad is not None for p in tower.parameters())
+
+
+def test_volume_conv_node_vs_float64_autograd(dev):
+    vc = networks.VolumeConv(64, 8)
+    synthetic.seed_weights(vc, seed=4)
+    vc = vc.to(dev).train()
+    ref = networks.VolumeConv(64, 8)
+    ref.load_state_dict({k: v.cpu() for k, v in vc.state_dict().items()})
+    ref = ref.to(dev).double().train()
+    cost = (_seeded((1, 64, 16, 32, 40), dev, 21).abs()).requires_grad_(True)
+    assert train_ops.volume_supported(vc, cost)
+    out = train_ops.volume_train(vc, cost)
+    g = _seeded(tuple(out.shape), dev, 22)
+    (out * g).sum().backward()
+    mine, gx = _grads(vc.parameters()), cost.grad.detach().clone()
+    vc.zero_grad()
+    cost.grad = None
+    (train_ops.volume_train(vc, cost) * g).sum().backward()
+    assert torch.equal(gx, cost.grad)
+    for a, b in zip(mine, _grads(vc.parameters())):
+        assert torch.equal(a, b)
+    cd = cost.detach().double().requires_grad_(True)
+    rout = ref(cd)
+    (rout * g.double()).sum().backward()
+    errs = sorted(((_rel(a, p.grad), k) for a, (k, p) in zip(mine, ref.named_parameters())), reverse=True)
+    e_out, e_x = _rel(out, rout), _rel(gx, cd.grad)
+    report("volume_node", out_rel=e_out, dcost_rel=e_x, worst_grad_rel=errs[0][0], median_grad_rel=errs[len(errs) // 2][0])
+    assert e_out < 2e-5 and e_x < 1e-4, (e_out, e_x)
+    assert errs[0][0] < 2e-4, errs[:5]
+
+
+def test_edge_chain_and_mlp_nodes_vs_composed_operators(dev):
+    """EdgeConv x3 + SharedMLP on point-major rows (two nodes) against the module compositions (the reference's graph
+    on the HIP gather_knn + ATen, float32 on the same device): outputs, input gradient, parameter gradients."""
+    from pointmvsnet_amd.model import PointMVSNet
+    from pointmvsnet_amd.utils.torch_utils import get_knn_3d
+    net = PointMVSNet()
+    synthetic.seed_weights(net, seed=0)
+    net = net.to(dev).train()
+    D, h, w = 5, 16, 24
+    N = D * h * w
+    xyz = _seeded((1, 3, D, h, w), dev, 23)
+    idx = get_knn_3d(xyz, 5, knn=16)
+    feat = _seeded((N, 136), dev, 24).requires_grad_(True)
+    assert train_ops.edge_chain_supported(net.flow_edge_conv, feat, idx)
+    edges = train_ops.edge_chain_train(net.flow_edge_conv, feat, idx)
+    assert train_ops.mlp_supported(net.flow_mlp[0], edges)
+    act = train_ops.mlp_train(net.flow_mlp[0], edges)
+    g = _seeded(tuple(act.shape), dev, 25)
+    (act * g).sum().backward()
+    params = list(net.flow_edge_conv.parameters()) + list(net.flow_mlp[0].parameters())
+    mine, gfeat = _grads(params), feat.grad.detach().clone()
+    for p in params:
+        p.grad = None
+    feat.grad = None
+    act_b = train_ops.mlp_train(net.flow_mlp[0], train_ops.edge_chain_train(net.flow_edge_conv, feat, idx))
+    (act_b * g).sum().backward()
+    assert torch.equal(act, act_b) and torch.equal(gfeat, feat.grad)
+    for a, b in zip(mine, _grads(params)):
+        assert torch.equal(a, b)
+    # composed: float64 modules, explicit gather
+    ref = PointMVSNet()
+    ref.load_state_dict({k: v.cpu() for k, v in net.state_dict().items()})
+    ref = ref.to(dev).double().train()
+    fd = feat.detach().double().requires_grad_(True)
+    x = fd.t().unsqueeze(0)
+    outs = []
+    for m in ref.flow_edge_conv:
+        k = idx.shape[2]
+        l, e = m.conv1(x), m.conv2(x)
+        nb = torch.gather(e.unsqueeze(3).expand(-1, -1, -1, k), 2, idx.unsqueeze(1).expand(-1, e.shape[1], -1, -1))
+        central = l.unsqueeze(-1).expand(-1, -1, -1, k)
+        edge = torch.cat([central, nb - central], dim=1) if m.concat else nb - central
+        x = torch.relu(m.bn(edge)).mean(dim=3)
+        outs.append(x)
+    y = torch.cat(outs, dim=1)
+    for blk in ref.flow_mlp[0]:
+        y = torch.relu(blk.bn(blk.conv(y)))
+    ract = y[0].t()
+    (ract * g.double()).sum().backward()
+    rparams = list(ref.flow_edge_conv.parameters()) + list(ref.flow_mlp[0].parameters())
+    errs = sorted(((_rel(a, p.grad), i) for i, (a, p) in enumerate(zip(mine, rparams))), reverse=True)
+    e_act, e_x = _rel(act, ract), _rel(gfeat, fd.grad)
+    report("edge_chain_mlp_nodes", act_rel=e_act, dfeature_rel=e_x, worst_grad_rel=errs[0][0])
+    assert e_act < 2e-5 and e_x < 2e-4 and errs[0][0] < 5e-4, (e_act, e_x, errs[:5])
