@@ -533,6 +533,47 @@ int pf_deconv2d_k5s2_f32(const float* dy, const float* wp, float* dx, int64_t N,
 int pf_conv3d_k3_c1_f32(const float* x, const float* w, float* y, int64_t N, int64_t Cout, int64_t D, int64_t H,
                         int64_t W, void* stream);
 
+
+/* ---- Row Z : backward of the fused warp + variance stages without atomics (csrc/warp_bwd.hip) -------------------
+ * Replaces, in the reference's loss.backward(), grid_sample's backward (a float-atomic scatter-add,
+ * utils/feature_fetcher.py:55) and the element-wise chain of the variance (model.py:103-111, :187-190) for the coarse
+ * cost volume and for the flow feature assembly.  One scene; maps channel-last (V, H, W, C) as the forward kernels
+ * read them; points n = d * H * W + y * W + x.  Gradients never flow into the sampling positions
+ * (utils/feature_fetcher.py:29).
+ *
+ * pf_sort_pairs_by_key: counting sort of `pairs` pair ids by keys[p] < nkeys (larger keys are dropped): start
+ * (nkeys + 1), order = the ids grouped by key, ascending inside a group.  Kernel launches only (capturable). */
+int64_t pf_sort_pairs_workspace(int64_t pairs, int64_t nkeys);
+int pf_sort_pairs_by_key(const uint32_t* keys, int64_t pairs, int64_t nkeys, uint32_t* order, uint32_t* start,
+                         void* workspace, int64_t workspace_bytes, void* stream);
+/* taps: for every (view v, point n), pair id p = v * N + n: keys[p] = v * (H+1) * (W+1) + (yi+1) * (W+1) + (xi+1) for
+ * the north-west tap (yi, xi) of its bilinear footprint (0xffffffff when no tap is inside the map) and
+ * fxy[p] = (fx, fy), the fractional offsets.  flow: the points of pf_flow_features_f32 (depth (H, W) at the flow
+ * resolution, ratio 1); frustum: the points of pf_frustum_variance_f32 (skip_view0 != 0: view 0 gets no keys, it
+ * contributes its un-warped map, model.py:103-106). */
+int pf_warp_taps_flow_f32(const float* depth, const float* interval, const float* cam, int V, int H, int W,
+                          uint32_t* keys, float* fxy, void* stream);
+int pf_warp_taps_frustum_f32(const float* kinv, const float* rinv, const float* t, const float* depths, const float* K,
+                             const float* E, int V, int H, int W, int D, int skip_view0, uint32_t* keys, float* fxy,
+                             void* stream);
+/* gval (V, N, ctot) = (2 / V) * dvar[n, c] * (f_v[n, c] - mean_v f), ctot = c1 + c2 + c3 (levels concatenated, c_l % 4
+ * == 0, c2 / c3 may be 0); dvar rows (N, ldv) point-major. */
+int pf_variance_grad_f32(const float* maps1, int c1, const float* maps2, int c2, const float* maps3, int c3, int V, int H,
+                         int W, int64_t N, const uint32_t* keys, const float* fxy, const float* dvar, int64_t ldv,
+                         int ref_override, float* gval, void* stream);
+/* dmaps[v] (H, W, ctot) for v in [v0, V): every texel adds weight * gval over the sorted lists of the four cells whose
+ * pairs have it as a tap -- plain stores, fixed order. */
+int pf_warp_gather_f32(const float* gval, const float* fxy, const uint32_t* order, const uint32_t* start, int V, int v0,
+                       int H, int W, int ctot, float* dmaps, void* stream);
+/* ddepth (H, W): gradient w.r.t. the prior depth through the xyz features (24 columns from c0 of the point's
+ * feature row; reference model.py:178-194). */
+int pf_flow_depth_grad_f32(const float* dfeat, int64_t ld, int c0, const float* cam, int H, int W, float* ddepth,
+                           void* stream);
+/* Adjoint of the bilinear resize (align_corners = False) of pf_flow_pyramid_f32 for one level: dres (V, OH, OW, ld)
+ * channel-last, columns [c0, c0 + C) -> dlevel (V, C, IH, IW). */
+int pf_resize_bilinear_backward_f32(const float* dres, int ld, int c0, int C, int V, int OH, int OW, int IH, int IW,
+                                    float* dlevel, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

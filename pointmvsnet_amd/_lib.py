@@ -110,6 +110,14 @@ PROTOTYPES = {
     "pf_deconv2d_k5s2_supported": ([_i64, _i64], _i),
     "pf_deconv2d_k5s2_f32": ([_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp], _i),
     "pf_conv3d_k3_c1_f32": ([_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp], _i),
+    "pf_sort_pairs_workspace": ([_i64, _i64], _i64),
+    "pf_sort_pairs_by_key": ([_vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp], _i),
+    "pf_warp_taps_flow_f32": ([_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp], _i),
+    "pf_warp_taps_frustum_f32": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp], _i),
+    "pf_variance_grad_f32": ([_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i64, _vp, _vp, _vp, _i64, _i, _vp, _vp], _i),
+    "pf_warp_gather_f32": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp], _i),
+    "pf_flow_depth_grad_f32": ([_vp, _i64, _i, _vp, _i, _i, _vp, _vp], _i),
+    "pf_resize_bilinear_backward_f32": ([_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp], _i),
 }
 
 _lib = None

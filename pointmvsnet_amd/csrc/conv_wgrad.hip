@@ -254,13 +254,34 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ Gr
   }
 }
 
+// dw[e] = sum over the splits, in a fixed order: 16 elements x 16 slices per block; slice sl adds splits sl, sl + 16, ...
+// and the 16 slice sums are added in slice order.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
                                                            int64_t elems, int splits, int accumulate) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= elems) return;
-  float s = accumulate ? dw[i] : 0.0f;
-  for (int k = 0; k < splits; ++k) s += part[(int64_t)k * elems + i];
-  dw[i] = s;
+  __shared__ float red[16][17];
+  const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int64_t e = (int64_t)blockIdx.x * 16 + el;
+  float s = 0.0f;
+  if (e < elems) {
+    int k = sl;
+    for (; k + 48 < splits; k += 64) {           // four independent loads in flight
+      const float a = part[(int64_t)k * elems + e], b = part[(int64_t)(k + 16) * elems + e];
+      const float c = part[(int64_t)(k + 32) * elems + e], d = part[(int64_t)(k + 48) * elems + e];
+      s += a;
+      s += b;
+      s += c;
+      s += d;
+    }
+    for (; k < splits; k += 16) s += part[(int64_t)k * elems + e];
+  }
+  red[sl][el] = s;
+  __syncthreads();
+  if (sl == 0 && e < elems) {
+    float t = accumulate ? dw[e] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += red[i][el];
+    dw[e] = t;
+  }
 }
 
 int ilog2(int v) {
@@ -403,7 +424,7 @@ int run_plan(const float* Gr, const float* X, float* dw, const WgPlan& p, int st
                    : (p.MT == 2 ? launch_wgrad<2, 2>(Gr, X, part, p, s) : launch_wgrad<4, 2>(Gr, X, part, p, s));
   }
   if (rc != PF_OK) return rc;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)pf_cdiv(elems, 256)), dim3(256), 0, s, part, dw, elems,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)pf_cdiv(elems, 16)), dim3(256), 0, s, part, dw, elems,
                      p.splits, accumulate);
   return pf_launch_status();
 }

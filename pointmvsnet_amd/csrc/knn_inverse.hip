@@ -138,6 +138,61 @@ __global__ __launch_bounds__(256) void inverse_sort_lists_kernel(const uint32_t*
   }
 }
 
+
+// The same counting sort for pairs whose keys are given as an array (csrc/warp_bwd.hip: (view, point) pairs keyed by
+// the texel cell their bilinear footprint starts in); keys >= nkeys are dropped (no list holds them).
+__global__ __launch_bounds__(256) void keys_count_kernel(const uint32_t* __restrict__ keys, int64_t pairs, uint32_t nkeys,
+                                                         uint32_t* __restrict__ count) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p < pairs && keys[p] < nkeys) atomicAdd(count + keys[p], 1u);
+}
+
+__global__ __launch_bounds__(256) void keys_fill_kernel(const uint32_t* __restrict__ keys, int64_t pairs, uint32_t nkeys,
+                                                        const uint32_t* __restrict__ start,
+                                                        uint32_t* __restrict__ cursor, uint32_t* __restrict__ order) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= pairs) return;
+  const uint32_t key = keys[p];
+  if (key < nkeys) order[start[key] + atomicAdd(cursor + key, 1u)] = (uint32_t)p;
+}
+
+// Lists sorted ascending by pair id, one 64-lane wave per list when lists are long (the coarse cost volume puts ~D
+// points on every texel cell): rank of an element = number of smaller ids in its list (ids are distinct), computed
+// by all lanes against a copy of the list in LDS; lists longer than kSortCap fall back to chunks of rank counting
+// against global memory.  Result independent of the arrival order of keys_fill_kernel.
+constexpr int kSortCap = 1024;
+__global__ __launch_bounds__(256) void sort_lists_wave_kernel(const uint32_t* __restrict__ start, int64_t rows,
+                                                              uint32_t* __restrict__ order,
+                                                              uint32_t* __restrict__ scratch) {
+  __shared__ uint32_t buf[4][kSortCap];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t m = (int64_t)blockIdx.x * 4 + wave;
+  if (m >= rows) return;
+  const uint32_t t0 = start[m], t1 = start[m + 1];
+  const uint32_t len = t1 - t0;
+  if (len < 2) return;
+  if (len <= (uint32_t)kSortCap) {
+    for (uint32_t i = lane; i < len; i += 64) buf[wave][i] = order[t0 + i];
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t i = lane; i < len; i += 64) {
+      const uint32_t v = buf[wave][i];
+      uint32_t r = 0;
+      for (uint32_t j = 0; j < len; ++j) r += buf[wave][j] < v ? 1u : 0u;
+      order[t0 + r] = v;
+    }
+  } else {                                   // (degenerate geometry: thousands of points on one cell)
+    for (uint32_t i = lane; i < len; i += 64) scratch[t0 + i] = order[t0 + i];
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    for (uint32_t i = lane; i < len; i += 64) {
+      const uint32_t v = scratch[t0 + i];
+      uint32_t r = 0;
+      for (uint32_t j = 0; j < len; ++j) r += scratch[t0 + j] < v ? 1u : 0u;
+      order[t0 + r] = v;
+    }
+  }
+}
+
 size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 }  // namespace
@@ -173,6 +228,45 @@ int pf_knn_inverse(const int64_t* idx, int k, int G, int Ng, uint32_t* order, ui
   hipLaunchKernelGGL(scan_blocks_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, start, n, sums);
   hipLaunchKernelGGL(inverse_fill_kernel, dim3(pb), dim3(256), 0, s, idx, pairs, k, Ng, start, cursor, order);
   hipLaunchKernelGGL(inverse_sort_lists_kernel, dim3((unsigned)pf_cdiv(rows, 256)), dim3(256), 0, s, start, rows, order);
+  return pf_launch_status();
+}
+
+
+int64_t pf_sort_pairs_workspace(int64_t pairs, int64_t nkeys) {
+  if (pairs <= 0 || nkeys <= 0) return 0;
+  const int64_t nblocks = pf_cdiv(nkeys + 1, kScanBlock);
+  return (int64_t)(align256(sizeof(uint32_t) * (size_t)nkeys) + align256(sizeof(uint32_t) * (size_t)nblocks) +
+                   align256(sizeof(uint32_t) * (size_t)pairs));
+}
+
+int pf_sort_pairs_by_key(const uint32_t* keys, int64_t pairs, int64_t nkeys, uint32_t* order, uint32_t* start,
+                         void* workspace, int64_t workspace_bytes, void* stream) {
+  PF_REQUIRE(pairs >= 0 && nkeys >= 1 && pairs < ((int64_t)1 << 32) - 1 && nkeys < ((int64_t)1 << 32) - 1);
+  PF_REQUIRE(start && workspace && workspace_bytes >= pf_sort_pairs_workspace(pairs > 0 ? pairs : 1, nkeys));
+  hipStream_t s = (hipStream_t)stream;
+  char* w = reinterpret_cast<char*>(workspace);
+  uint32_t* cursor = reinterpret_cast<uint32_t*>(w);
+  uint32_t* sums = reinterpret_cast<uint32_t*>(w + align256(sizeof(uint32_t) * (size_t)nkeys));
+  const int64_t n = nkeys + 1;
+  const int nblocks = (int)pf_cdiv(n, kScanBlock);
+  uint32_t* scratch = reinterpret_cast<uint32_t*>(w + align256(sizeof(uint32_t) * (size_t)nkeys) +
+                                                  align256(sizeof(uint32_t) * (size_t)nblocks));
+  hipLaunchKernelGGL(inverse_zero_kernel, dim3((unsigned)(pf_cdiv(n, 256) > 2048 ? 2048 : pf_cdiv(n, 256))), dim3(256), 0, s,
+                     start, n, cursor, nkeys);
+  if (pairs > 0) {
+    PF_REQUIRE(keys && order);
+    hipLaunchKernelGGL(keys_count_kernel, dim3((unsigned)pf_cdiv(pairs, 256)), dim3(256), 0, s, keys, pairs,
+                       (uint32_t)nkeys, start);
+  }
+  hipLaunchKernelGGL(scan_block_sums_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, start, n, sums);
+  hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, s, sums, nblocks);
+  hipLaunchKernelGGL(scan_blocks_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, start, n, sums);
+  if (pairs > 0) {
+    hipLaunchKernelGGL(keys_fill_kernel, dim3((unsigned)pf_cdiv(pairs, 256)), dim3(256), 0, s, keys, pairs,
+                       (uint32_t)nkeys, start, cursor, order);
+    hipLaunchKernelGGL(sort_lists_wave_kernel, dim3((unsigned)pf_cdiv(nkeys, 4)), dim3(256), 0, s, start, nkeys, order,
+                       scratch);
+  }
   return pf_launch_status();
 }
 

@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 // ------------------------------------------------------------------------------------------------
 // G groups of Ng rows; block (t, g) reduces rows [t*chunk, (t+1)*chunk) of group g: thread = (column c = tid % C,
 // row phase tid / C), C in {16, 32, 64, 128}.  partials (G, T, C, 2).
-constexpr int kRowT = 64;      // blocks per group (at most)
+constexpr int kRowT = 512;     // blocks per group (at most)
 
 __global__ __launch_bounds__(256) void rows_bn_bwd_reduce_kernel(const float* __restrict__ g, int64_t ldg,
                                                                  const float* __restrict__ y, int64_t ldy,
@@ -409,7 +409,7 @@ int pf_bn_bwd_apply_f32(const float* g, const float* y, const float* rows, const
 
 int pf_rows_bn_blocks(int G, int Ng) {
   if (G <= 0 || Ng <= 0) return 0;
-  const int t = (Ng + 511) / 512;            // >= 512 rows per block
+  const int t = (Ng + 255) / 256;            // >= 256 rows per block
   return t > kRowT ? kRowT : t;
 }
 

@@ -250,7 +250,8 @@ class TrainPlan(object):
                    ("t0", (B, 1, 3, 1)), ("depths", (B, self.D)), ("d_start", (B,)), ("d_int", (B,)),
                    ("mean", (B, 3, 1)), ("std", (B, 3, 1))]
         for i in range(len(self.img_scales)):
-            entries += [("interval%d" % i, (B,)), ("K_flow%d" % i, (B, V, 3, 3)), ("Kinv_flow%d" % i, (B, 1, 3, 3))]
+            entries += [("interval%d" % i, (B,)), ("K_flow%d" % i, (B, V, 3, 3)), ("Kinv_flow%d" % i, (B, 1, 3, 3)),
+                        ("pack%d" % i, (B, 27 + 21 * V + 1))]      # the PF_CAM_* block + interval of the fused kernels
         self._layout, off = {}, 0
         for name, shape in entries:
             n = 1
@@ -301,6 +302,8 @@ class TrainPlan(object):
             self._h("interval%d" % i).copy_(inter * cam.depth_interval)
             self._h("K_flow%d" % i).copy_(K_flow)
             self._h("Kinv_flow%d" % i).copy_(torch.inverse(K_flow[:, 0]).unsqueeze(1))
+            self._h("pack%d" % i).copy_(cam.packed(K_flow, mean_h.float().reshape(self.B, 3),
+                                                   std_h.float().reshape(self.B, 3), inter * cam.depth_interval))
         return self
 
     def upload_(self):
@@ -504,6 +507,15 @@ class PointMVSNet(nn.Module):
             tplan.update_(data_batch)
         return self.run_autograd(tplan, img_list, isFlow)
 
+    def _coarse_cost_autograd(self, feature_list, world_points, K_coarse, ext, D):
+        """The reference's coarse cost volume (model.py:102-111) composed from differentiable operators: (B, C, N)."""
+        B, V, C = feature_list.shape[:3]
+        point_features = self.feature_fetcher(feature_list, world_points, K_coarse, ext)
+        ref = feature_list[:, 0].unsqueeze(2).expand(-1, -1, D, -1, -1).contiguous().view(B, C, -1)
+        point_features = torch.cat([ref.unsqueeze(1), point_features[:, 1:]], dim=1)
+        avg = point_features.mean(dim=1)
+        return (point_features ** 2).mean(dim=1) - avg ** 2
+
     def run_autograd(self, tplan, img_list, isFlow=True):
         """Device-only autograd forward on the constants of ``tplan`` (capturable together with its backward)."""
         dev = img_list.device
@@ -527,19 +539,22 @@ class PointMVSNet(nn.Module):
         C, FH, FW = feature_list.shape[2:]
         D = tplan.D
         depths = tplan.d("depths")                                           # (B,D)
-        grid = self._pixel_grid(FH, FW, dev).view(1, 1, 3, -1).expand(B, 1, 3, -1)
-        uv = torch.matmul(tplan.d("Kinv0"), grid)
-        cam_points = (uv.unsqueeze(3) * depths.view(B, 1, 1, D, 1)).view(B, 1, 3, -1)
         R_inv0 = tplan.d("Rinv0")
         t0 = tplan.d("t0")
-        world_points = torch.matmul(R_inv0, cam_points - t0).transpose(1, 2).contiguous().view(B, 3, -1)
-        preds["world_points"] = world_points
+        if not (fused and C % 4 == 0 and V <= 8):
+            grid = self._pixel_grid(FH, FW, dev).view(1, 1, 3, -1).expand(B, 1, 3, -1)
+            uv = torch.matmul(tplan.d("Kinv0"), grid)
+            cam_points = (uv.unsqueeze(3) * depths.view(B, 1, 1, D, 1)).view(B, 1, 3, -1)
+            world_points = torch.matmul(R_inv0, cam_points - t0).transpose(1, 2).contiguous().view(B, 3, -1)
+            preds["world_points"] = world_points
 
-        point_features = self.feature_fetcher(feature_list, world_points, K_coarse, ext)
-        ref = coarse_maps[0].unsqueeze(2).expand(-1, -1, D, -1, -1).contiguous().view(B, C, -1)
-        point_features = torch.cat([ref.unsqueeze(1), point_features[:, 1:]], dim=1)
-        avg = point_features.mean(dim=1)
-        cost = (point_features ** 2).mean(dim=1) - avg ** 2
+        if fused and C % 4 == 0 and V <= 8:
+            # warp + variance as ONE node (forward: the inference kernel; backward: csrc/warp_bwd.hip, no atomics)
+            cost, world_points = train_ops.coarse_volume_train(feature_list[0], tplan.d("Kinv0"), R_inv0, t0, depths,
+                                                               K_coarse, ext)
+            preds["world_points"] = world_points
+        else:
+            cost = self._coarse_cost_autograd(feature_list, world_points, K_coarse, ext, D)
         cost = cost.view(B, C, D, FH, FW)
         if fused and train_ops.volume_supported(self.coarse_vol_conv, cost):
             filtered = train_ops.volume_train(self.coarse_vol_conv, cost).squeeze(1)
@@ -571,7 +586,8 @@ class PointMVSNet(nn.Module):
                     raise NotImplementedError
             h, w = int(H * img_scale), int(W * img_scale)
             ratio = int(img_scale * 8) if (isTest and img_scale != 0.125) else 1
-            pred_depth, flow_prob = self._point_flow_autograd(pyramids, pred_depth, tplan, it, h, w, ratio)
+            pred_depth, flow_prob = self._point_flow_autograd(pyramids, pred_depth, tplan, it, h, w, ratio,
+                                                              fused=fused and ratio == 1)
             preds["flow{}_prob".format(it + 1)] = flow_prob
             preds["flow{}".format(it + 1)] = pred_depth
         pointflow.flush_counters()
@@ -580,11 +596,16 @@ class PointMVSNet(nn.Module):
     # ------------------------------------------------------------------------------------------
     # differentiable composition (training): reference model.py:150-295 on the HIP operators
     # ------------------------------------------------------------------------------------------
-    def _sub_flow_autograd(self, xyz, feature, interval):
+    def _sub_flow_autograd(self, xyz, feature, interval, rows=None):
+        """xyz (B,3,D,hs,ws); feature (B,C,D,hs,ws), or ``rows`` (N, C) point-major (one scene, the fused nodes)."""
         B, _, D, hs, ws = xyz.shape
         nn_idx = get_knn_3d(xyz, D, knn=self.k)
-        x = feature.contiguous().view(B, -1, D * hs * ws)
-        rows = x[0].t().contiguous() if (FUSED_TRAIN and _networks.FUSED_TRAIN and B == 1 and self.training) else None     # (N, 136) point-major
+        if rows is None:
+            x = feature.contiguous().view(B, -1, D * hs * ws)
+            if FUSED_TRAIN and _networks.FUSED_TRAIN and B == 1 and self.training:
+                rows = x[0].t().contiguous()                                                   # (N, 136) point-major
+        else:
+            x = None
         if (rows is not None and train_ops.edge_chain_supported(self.flow_edge_conv, rows, nn_idx)
                 and len(self.flow_mlp) == 2 and type(self.flow_mlp[1]) is nn.Conv1d
                 and self.flow_mlp[1].bias is None and self.flow_mlp[1].out_channels == 1):
@@ -597,6 +618,8 @@ class PointMVSNet(nn.Module):
             else:
                 flow = self.flow_mlp(edges.t().unsqueeze(0)).contiguous().view(B, D, hs, ws)
         else:
+            if x is None:
+                x = rows.t().unsqueeze(0)
             edges = []
             for conv in self.flow_edge_conv:
                 x = conv(x, nn_idx)
@@ -606,12 +629,46 @@ class PointMVSNet(nn.Module):
         length = self._hypotheses(xyz.device).view(1, -1, 1, 1) * interval.view(-1, 1, 1, 1)
         return torch.sum(prob * length, dim=1, keepdim=True), prob
 
-    def _point_flow_autograd(self, pyramids, depth_map, tplan, it, h, w, ratio):
+    def _point_flow_autograd(self, pyramids, depth_map, tplan, it, h, w, ratio, fused=False):
         dev = depth_map.device
         B = depth_map.shape[0]
         interval, K_flow, ext = tplan.d("interval%d" % it), tplan.d("K_flow%d" % it), tplan.d("ext")
         if depth_map.shape[2] != h:
             depth_map = F.interpolate(depth_map, (h, w), mode="nearest")
+        levels = [pyramids[n][0] for n in ("conv1", "conv2", "conv3")] if (fused and B == 1) else None
+        if levels is not None and train_ops.flow_features_supported(levels, depth_map[0, 0], h, w):
+            # feature assembly (5 hypotheses x 3 levels: resize, warp, variance, xyz) as ONE node on the inference kernels,
+            # backward without atomics (csrc/warp_bwd.hip); gradients reach the pyramid levels and the prior depth
+            pack = tplan.d("pack%d" % it)[0]
+            rows, xyz = train_ops.flow_features_train(levels, depth_map[0, 0], pack[-1:], pack, h, w)
+            flow, prob = self._sub_flow_autograd(xyz.view(1, 3, 5, h, w), None, interval, rows=rows)
+            return depth_map + flow, prob
+        feature, xyz = self._assemble_autograd(pyramids, depth_map, tplan, it, h, w)
+        if ratio == 1:
+            flow, prob = self._sub_flow_autograd(xyz, feature.view(B, -1, 5, h, w), interval)
+        else:
+            hs, ws = h // ratio, w // ratio
+            f7 = feature.view(B, -1, 5, hs, ratio, ws, ratio)
+            x7 = xyz.view(B, 3, 5, hs, ratio, ws, ratio)
+            rows_f, rows_p = [], []
+            for i in range(ratio):
+                cols_f, cols_p = [], []
+                for j in range(ratio):
+                    fij, pij = self._sub_flow_autograd(x7[:, :, :, :, i, :, j], f7[:, :, :, :, i, :, j], interval)
+                    cols_f.append(fij)
+                    cols_p.append(pij)
+                rows_f.append(torch.stack(cols_f, dim=4))
+                rows_p.append(torch.stack(cols_p, dim=4))
+            flow = torch.stack(rows_f, dim=3).contiguous().view(B, 1, h, w)
+            prob = torch.stack(rows_p, dim=3).contiguous().view(B, 5, h, w)
+        return depth_map + flow, prob
+
+    def _assemble_autograd(self, pyramids, depth_map, tplan, it, h, w):
+        """The reference's feature assembly (model.py:153-204) composed from differentiable operators: feature
+        (B, 136, 5, h*w) and xyz (B, 3, 5, h, w).  depth_map (B, 1, h, w) at the flow resolution."""
+        dev = depth_map.device
+        B = depth_map.shape[0]
+        interval, K_flow, ext = tplan.d("interval%d" % it), tplan.d("K_flow%d" % it), tplan.d("ext")
         mean = tplan.d("mean")
         std = tplan.d("std")
         grid = self._pixel_grid(h, w, dev).view(1, 1, 3, -1).expand(B, 1, 3, -1)
@@ -639,24 +696,7 @@ class PointMVSNet(nn.Module):
             xyzs.append(xyz)
         feature = torch.stack(feats, dim=2)                                  # (B,136,5,h*w)
         xyz = torch.stack(xyzs, dim=2).contiguous().view(B, 3, 5, h, w)
-        if ratio == 1:
-            flow, prob = self._sub_flow_autograd(xyz, feature.view(B, -1, 5, h, w), interval)
-        else:
-            hs, ws = h // ratio, w // ratio
-            f7 = feature.view(B, -1, 5, hs, ratio, ws, ratio)
-            x7 = xyz.view(B, 3, 5, hs, ratio, ws, ratio)
-            rows_f, rows_p = [], []
-            for i in range(ratio):
-                cols_f, cols_p = [], []
-                for j in range(ratio):
-                    fij, pij = self._sub_flow_autograd(x7[:, :, :, :, i, :, j], f7[:, :, :, :, i, :, j], interval)
-                    cols_f.append(fij)
-                    cols_p.append(pij)
-                rows_f.append(torch.stack(cols_f, dim=4))
-                rows_p.append(torch.stack(cols_p, dim=4))
-            flow = torch.stack(rows_f, dim=3).contiguous().view(B, 1, h, w)
-            prob = torch.stack(rows_p, dim=3).contiguous().view(B, 5, h, w)
-        return depth_map + flow, prob
+        return feature, xyz
 
 
 class PointMVSNetLoss(nn.Module):

@@ -638,3 +638,131 @@ class _MLPTrain(torch.autograd.Function):
 
 def mlp_train(shared, x):
     return _MLPTrain.apply(x, shared, *mlp_params(shared))
+
+
+# ---------------------------------------------------------------------------------------------
+# warp + variance stages: coarse cost volume (reference model.py:79-111), flow feature assembly (model.py:153-204)
+# ---------------------------------------------------------------------------------------------
+def sort_pairs(keys, nkeys):
+    """(order, start) of pf_sort_pairs_by_key: the pair ids grouped by key, ascending inside a group."""
+    pairs = keys.numel()
+    dev = keys.device
+    order = torch.empty((max(pairs, 1),), dtype=torch.int32, device=dev)
+    start = torch.empty((nkeys + 1,), dtype=torch.int32, device=dev)
+    nbytes = int(_lib.load().pf_sort_pairs_workspace(max(pairs, 1), int(nkeys)))
+    work = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=dev)
+    _lib.call("pf_sort_pairs_by_key", _lib.ptr(keys), pairs, int(nkeys), _lib.ptr(order), _lib.ptr(start), _lib.ptr(work),
+              nbytes, _lib.stream(), algo_bytes=16.0 * pairs + 8.0 * nkeys)
+    return order, start
+
+
+def _warp_backward(levels_cl, V, H, W, N, keys, fxy, dvar, ref_override, v0):
+    """gval + sorted gather: dmaps (V, H, W, ctot) channel-last (views < v0 left to the caller), and gval (V, N, ctot)."""
+    dev = dvar.device
+    cs = [int(l.shape[3]) for l in levels_cl] + [0, 0]
+    ctot = sum(cs)
+    lv = list(levels_cl) + [None, None]
+    order, start = sort_pairs(keys, V * (H + 1) * (W + 1))
+    gval = torch.empty((V, N, ctot), dtype=_F32, device=dev)
+    _lib.call("pf_variance_grad_f32", _lib.ptr(lv[0]), cs[0], _lib.ptr(lv[1]), cs[1], _lib.ptr(lv[2]), cs[2], V, H, W, N,
+              _lib.ptr(keys), _lib.ptr(fxy), _lib.ptr(dvar), int(dvar.stride(0)), int(bool(ref_override)),
+              _lib.ptr(gval), _lib.stream(), algo_bytes=4.0 * (V * H * W * ctot + N * ctot * (1 + V)) + 12.0 * V * N)
+    dmaps = torch.empty((V, H, W, ctot), dtype=_F32, device=dev)
+    _lib.call("pf_warp_gather_f32", _lib.ptr(gval), _lib.ptr(fxy), _lib.ptr(order), _lib.ptr(start), V, int(v0), H, W, ctot,
+              _lib.ptr(dmaps), _lib.stream(), algo_bytes=4.0 * ctot * (V * N + V * H * W) + 12.0 * V * N)
+    return dmaps, gval
+
+
+class _FlowFeaturesTrain(torch.autograd.Function):
+    """Pyramid levels (V, c_l, h_l, w_l) + prior depth (h, w) -> the point-major feature rows (N, c1 + c2 + c3 + 24) and
+    xyz (1, 3, N) of one PointFlow iteration (pf_flow_pyramid_f32 + pf_flow_features_f32, ratio 1); backward on
+    csrc/warp_bwd.hip.  interval: one-element device tensor; cam: the packed camera block of this scale."""
+
+    @staticmethod
+    def forward(ctx, l1, l2, l3, depth, interval, cam, h, w):
+        lv = [t.detach().contiguous() for t in (l1, l2, l3)]
+        depth = depth.detach().contiguous()
+        with torch.cuda.device(depth.device):
+            levels = pointflow.flow_pyramid(lv, h, w)
+            feature, xyz = pointflow.flow_features(levels, depth, interval, cam, h, w, 1)
+        ctx.levels, ctx.depth, ctx.interval, ctx.cam, ctx.hw = levels, depth, interval, cam, (h, w)
+        ctx.shapes = [tuple(t.shape) for t in lv]
+        ctx.mark_non_differentiable(xyz)
+        return feature.view(feature.shape[1], feature.shape[2]), xyz
+
+    @staticmethod
+    def backward(ctx, dfeature, _dxyz):
+        levels, depth, interval, cam = ctx.levels, ctx.depth, ctx.interval, ctx.cam
+        h, w = ctx.hw
+        V = levels[0].shape[0]
+        N = 5 * h * w
+        dev = depth.device
+        g = dfeature.contiguous()
+        cs = [int(l.shape[3]) for l in levels]
+        ctot = sum(cs)
+        with torch.cuda.device(dev):
+            keys = torch.empty((V * N,), dtype=torch.int32, device=dev)
+            fxy = torch.empty((V * N, 2), dtype=_F32, device=dev)
+            _lib.call("pf_warp_taps_flow_f32", _lib.ptr(depth), _lib.ptr(interval), _lib.ptr(cam), V, h, w, _lib.ptr(keys),
+                      _lib.ptr(fxy), _lib.stream(), algo_bytes=12.0 * V * N)
+            dres, _ = _warp_backward(levels, V, h, w, N, keys, fxy, g, False, 0)
+            outs, c0 = [], 0
+            for c, shp in zip(cs, ctx.shapes):
+                dl = torch.empty(shp, dtype=_F32, device=dev)
+                _lib.call("pf_resize_bilinear_backward_f32", _lib.ptr(dres), ctot, c0, c, V, h, w, int(shp[2]), int(shp[3]),
+                          _lib.ptr(dl), _lib.stream(), algo_bytes=4.0 * V * c * (h * w + shp[2] * shp[3]))
+                outs.append(dl)
+                c0 += c
+            ddepth = torch.empty((h, w), dtype=_F32, device=dev)
+            _lib.call("pf_flow_depth_grad_f32", _lib.ptr(g), int(g.stride(0)), ctot, _lib.ptr(cam), h, w, _lib.ptr(ddepth),
+                      _lib.stream(), algo_bytes=4.0 * N * 24 + 4.0 * h * w)
+        return outs[0], outs[1], outs[2], ddepth, None, None, None, None
+
+
+def flow_features_supported(levels, depth, h, w):
+    return (len(levels) == 3 and all(t.dim() == 4 and t.is_cuda and t.dtype == _F32 and t.shape[1] % 4 == 0 for t in levels)
+            and depth.dim() == 2 and tuple(depth.shape) == (h, w) and levels[0].shape[0] <= 8)
+
+
+def flow_features_train(levels, depth, interval, cam, h, w):
+    return _FlowFeaturesTrain.apply(levels[0], levels[1], levels[2], depth, interval, cam, h, w)
+
+
+class _CoarseVolumeTrain(torch.autograd.Function):
+    """Coarse tower maps (V, C, FH, FW) of one scene -> cost volume (1, C, D*FH*FW) and the frustum points
+    (pf_frustum_variance_cl_f32; view 0 contributes its un-warped map, reference model.py:103-106)."""
+
+    @staticmethod
+    def forward(ctx, maps, kinv, rinv, t, depths, K, E):
+        from .utils.feature_fetcher import ChannelLast, frustum_variance, to_channel_last
+        m = maps.detach().contiguous()
+        with torch.cuda.device(m.device):
+            cl = to_channel_last(m)                                         # (V, FH, FW, C)
+            cost, world = frustum_variance(ChannelLast(cl.unsqueeze(0)), kinv, rinv, t, depths, K, E)
+        ctx.cl = cl
+        ctx.cams = tuple(x.detach().float().contiguous() for x in (kinv, rinv, t, depths, K, E))
+        ctx.mark_non_differentiable(world)
+        return cost, world
+
+    @staticmethod
+    def backward(ctx, dcost, _dworld):
+        cl = ctx.cl
+        kinv, rinv, t, depths, K, E = ctx.cams
+        V, FH, FW, C = cl.shape
+        D = depths.shape[-1]
+        N = D * FH * FW
+        dev = cl.device
+        with torch.cuda.device(dev):
+            keys = torch.empty((V * N,), dtype=torch.int32, device=dev)
+            fxy = torch.empty((V * N, 2), dtype=_F32, device=dev)
+            _lib.call("pf_warp_taps_frustum_f32", _lib.ptr(kinv), _lib.ptr(rinv), _lib.ptr(t), _lib.ptr(depths), _lib.ptr(K),
+                      _lib.ptr(E), V, FH, FW, D, 1, _lib.ptr(keys), _lib.ptr(fxy), _lib.stream(), algo_bytes=12.0 * V * N)
+            dvar = dcost.reshape(C, N).t().contiguous()                      # point-major rows (N, C)
+            dmaps, gval = _warp_backward([cl], V, FH, FW, N, keys, fxy, dvar, True, 1)
+            dmaps[0] = gval[0].view(D, FH * FW, C).sum(dim=0).view(FH, FW, C)   # the reference view: a sum over depth
+            out = dmaps.permute(0, 3, 1, 2).contiguous()
+        return out, None, None, None, None, None, None
+
+
+def coarse_volume_train(maps, kinv, rinv, t, depths, K, E):
+    return _CoarseVolumeTrain.apply(maps, kinv, rinv, t, depths, K, E)

