@@ -466,11 +466,15 @@ int pf_eval_prob_filter_f32(const float* depth, const float* flow_conf, const fl
  * Everything below sums in a fixed order: gradients are bit-reproducible run to run.
  *
  * Forward finalize that keeps what the backward needs: like pf_bn_finalize_f32, but the result is ONE tensor
- * rows (4, S, C) = [scale | shift | mean | invstd], S = G / groups_per_stat; rows[0], rows[1] are the (S, C)
- * in_scale / in_shift rows the forward kernels take.  Running statistics updated as by pf_bn_finalize_f32. */
+ * rows (4, S, ld_rows) = [scale | shift | mean | invstd], S = G / groups_per_stat; rows[0], rows[1] are the (S, ld)
+ * in_scale / in_shift rows the forward kernels take.  The C channels of this call are channels [ch0, ch0 + C) of
+ * gamma / beta / the running statistics and land in columns [col_out, col_out + C) of every row (EdgeConv's
+ * BatchNorm covers [central | difference] halves with separate statistics, reference networks.py:33-36).  Running
+ * statistics updated as by pf_bn_finalize_f32. */
 int pf_bn_train_rows_f32(const double* partials, int T, int pcols, int col0, int C, double count, double unbias_n,
                          const float* gamma, const float* beta, float* running_mean, float* running_var,
-                         float momentum, float eps, int G, int groups_per_stat, float* rows, void* stream);
+                         float momentum, float eps, int G, int groups_per_stat, float* rows, int ld_rows, int col_out,
+                         int ch0, void* stream);
 /* BatchNorm(+ReLU) backward on planar tensors (N, C, S): g = dL/dz for z = act(y * scale + shift), y the raw
  * convolution output, rows as above (statistic group s = n / samples_per_stat).
  *   reduce : partials (N, pf_norm_blocks(S), C, 2) float64 = per-block (sum g', sum g' * xhat),

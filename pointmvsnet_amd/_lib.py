@@ -95,7 +95,7 @@ PROTOTYPES = {
     "pf_eval_flow_prob_f32": ([_vp, _vp, _i, _i, _i, _vp], _i),
     "pf_eval_prob_filter_f32": ([_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _i, _vp], _i),
     "pf_softargmin_prob_f32": ([_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp], _i),
-    "pf_bn_train_rows_f32": ([_vp, _i, _i, _i, _i, _d, _d, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _vp, _vp], _i),
+    "pf_bn_train_rows_f32": ([_vp, _i, _i, _i, _i, _d, _d, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _vp, _i, _i, _i, _vp], _i),
     "pf_bn_bwd_reduce_f32": ([_vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _vp, _vp], _i),
     "pf_bn_bwd_coeffs_f32": ([_vp, _i, _i, _i, _i, _d, _i, _i, _vp, _vp, _vp, _vp, _i, _vp], _i),
     "pf_bn_bwd_apply_f32": ([_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _vp], _i),

@@ -120,36 +120,65 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ Gr
   const int t_hi = min(g.total_tiles, t_lo + g.per_split);
   for (int tile = t_lo; tile < t_hi; ++tile) {
     __syncthreads();                    // the previous tile's MFMA reads (and the table) are done
+    // Staging issues its global loads in batches (kU independent loads per lane in flight) and stores to LDS afterwards:
+    // one load -> one store per iteration made the kernel latency-bound (conv0_1's gradient: 525 us for 22 us of MFMA).
+    constexpr int kU = 8, kUR = 4;
+    const int grows = min(MT * 16, g.Cg - cg0);          // rows / channels that exist: the rest of the LDS tiles is
+    const int creal = min(cbtot, g.Cx - ci0);            // never stored from (their products are not written)
     if (g.point_major) {
       // R * 16 consecutive points; thread = (point, 4 channels): coalesced 16-byte row pieces, transposed into LDS
       const int PT = R * 16;
       const int64_t p0 = (int64_t)tile * PT;
-      const int qg = MT * 4;
-      for (int e = tid; e < PT * qg; e += 256) {
-        const int pt = e / qg, c4 = (e - pt * qg) * 4;
-        const int64_t p = p0 + pt;
-        f32x4 v = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-        if (p < g.P && cg0 + c4 < g.Cg) v = *reinterpret_cast<const f32x4*>(Gr + p * g.ldg + cg0 + c4);
+      const int qg = (grows + 3) >> 2;
+      for (int e0 = tid; e0 < PT * qg; e0 += 256 * kUR) {
+        f32x4 v[kUR];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) gs[(c4 + j) * g.GPLANE + pt] = v[j];
+        for (int u = 0; u < kUR; ++u) {
+          const int e = e0 + 256 * u;
+          const int pt = e / qg, c4 = (e - pt * qg) * 4;
+          const int64_t p = p0 + pt;
+          v[u] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+          if (e < PT * qg && p < g.P) v[u] = *reinterpret_cast<const f32x4*>(Gr + p * g.ldg + cg0 + c4);
+        }
+#pragma unroll
+        for (int u = 0; u < kUR; ++u) {
+          const int e = e0 + 256 * u;
+          const int pt = e / qg, c4 = (e - pt * qg) * 4;
+          if (e < PT * qg) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) gs[(c4 + j) * g.GPLANE + pt] = v[u][j];
+          }
+        }
       }
-      const int qx = cbtot >> 2;
-      for (int e = tid; e < PT * qx; e += 256) {
-        const int pt = e / qx, c4 = (e - pt * qx) * 4;
-        const int64_t p = p0 + pt;
-        f32x4 v = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-        if (p < g.P && ci0 + c4 < g.Cx) {
-          v = *reinterpret_cast<const f32x4*>(X + p * g.ldx + ci0 + c4);
-          if (g.x_scale != nullptr) {
-            const int64_t so = (p / g.x_pps) * g.Cx + ci0 + c4;
-            const f32x4 sc = *reinterpret_cast<const f32x4*>(g.x_scale + so);
-            const f32x4 sh = *reinterpret_cast<const f32x4*>(g.x_shift + so);
+      const int qx = (creal + 3) >> 2;
+      for (int e0 = tid; e0 < PT * qx; e0 += 256 * kUR) {
+        f32x4 v[kUR];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(v[j], sc[j], sh[j]), 0.0f);
+        for (int u = 0; u < kUR; ++u) {
+          const int e = e0 + 256 * u;
+          const int pt = e / qx, c4 = (e - pt * qx) * 4;
+          const int64_t p = p0 + pt;
+          v[u] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+          if (e < PT * qx && p < g.P) {
+            v[u] = *reinterpret_cast<const f32x4*>(X + p * g.ldx + ci0 + c4);
+            if (g.x_scale != nullptr) {
+              const int64_t so = (p / g.x_pps) * g.Cx + ci0 + c4;
+              const f32x4 sc = *reinterpret_cast<const f32x4*>(g.x_scale + so);
+              const f32x4 sh = *reinterpret_cast<const f32x4*>(g.x_shift + so);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[u][j] = fmaxf(fmaf(v[u][j], sc[j], sh[j]), 0.0f);
+            }
           }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) xs[(c4 + j) * g.XPLANE + pt] = v[j];
+        for (int u = 0; u < kUR; ++u) {
+          const int e = e0 + 256 * u;
+          const int pt = e / qx, c4 = (e - pt * qx) * 4;
+          if (e < PT * qx) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xs[(c4 + j) * g.XPLANE + pt] = v[u][j];
+          }
+        }
       }
     } else {
       int rest = tile;
@@ -164,41 +193,71 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ Gr
       // Gr tile: 16-lane groups, one row of 16 positions along W per task
       {
         const int grp = tid >> 4, l16 = tid & 15;
-        const float* gb = Gr + (int64_t)n * g.Cg * vol_o;
+        const float* gb = Gr + ((int64_t)n * g.Cg + cg0) * vol_o;
         const int ow = ow0 + l16;
-        for (int task = grp; task < MT * 16 * R; task += 16) {
-          const int cgl = task >> g.lgR, r = task & (R - 1);
-          const int d = r >> g.lgTH, h = r & (g.TH - 1);
-          const int cg = cg0 + cgl, od = od0 + d, oh = oh0 + h;
-          const bool ok = cg < g.Cg && od < g.Do && oh < g.Ho && ow < g.Wo;
-          gs[cgl * g.GPLANE + r * 16 + l16] = ok ? gb[(int64_t)cg * vol_o + od * plane_o + oh * g.Wo + ow] : 0.0f;
+        const int gtasks = grows * R;
+        for (int t0 = grp; t0 < gtasks; t0 += 16 * kU) {
+          float v[kU];
+#pragma unroll
+          for (int u = 0; u < kU; ++u) {
+            const int task = t0 + 16 * u;
+            const int cgl = task >> g.lgR, r = task & (R - 1);
+            const int d = r >> g.lgTH, h = r & (g.TH - 1);
+            const int od = od0 + d, oh = oh0 + h;
+            const bool ok = task < gtasks && od < g.Do && oh < g.Ho && ow < g.Wo;
+            v[u] = ok ? gb[(int64_t)cgl * vol_o + od * plane_o + oh * g.Wo + ow] : 0.0f;
+          }
+#pragma unroll
+          for (int u = 0; u < kU; ++u) {
+            const int task = t0 + 16 * u;
+            if (task < gtasks) gs[(task >> g.lgR) * g.GPLANE + (task & (R - 1)) * 16 + l16] = v[u];
+          }
         }
       }
-      // X patch: 32-lane groups, one patch row per task
+      // X patch: 32-lane groups, one patch row (<= 64 floats) per task
       {
         const int grp = tid >> 5, l32 = tid & 31;
         const float* xb = X + ((int64_t)n * g.Cx + ci0) * vol_i;
         const int origin = id0 * plane_i + ih0 * g.Wi + iw0;
         const int stat = n / g.x_sps;
-        for (int task = grp; task < g.ntasks; task += 8) {
-          const int4 e = *reinterpret_cast<const int4*>(tab + task * 4);
-          const int c = e.w >> 16, hy = e.w & 0xffff;
-          const int id = id0 + e.z, ih = ih0 + hy;
-          const bool rowok = id >= 0 && id < g.Di && ih >= 0 && ih < g.Hi && ci0 + c < g.Cx;
-          float sc = 1.0f, sh = 0.0f;
-          const bool aff = g.x_scale != nullptr && rowok;
-          if (aff) {
-            sc = g.x_scale[(int64_t)stat * g.Cx + ci0 + c];
-            sh = g.x_shift[(int64_t)stat * g.Cx + ci0 + c];
-          }
-          for (int w = l32; w < g.IW; w += 32) {
-            const int iw = iw0 + w;
-            float v = 0.0f;
-            if (rowok && iw >= 0 && iw < g.Wi) {
-              v = xb[e.x + origin + w];
-              if (aff) v = fmaxf(fmaf(v, sc, sh), 0.0f);
+        const int xtasks = creal * g.ID * g.IH;
+        const bool wide = g.IW > 32;
+        const int iwa = iw0 + l32, iwb = iw0 + l32 + 32;
+        const bool cola = l32 < g.IW && iwa >= 0 && iwa < g.Wi;
+        const bool colb = l32 + 32 < g.IW && iwb >= 0 && iwb < g.Wi;
+        for (int t0 = grp; t0 < xtasks; t0 += 8 * kU) {
+          float va[kU], vb[kU];
+          int dst[kU];
+#pragma unroll
+          for (int u = 0; u < kU; ++u) {
+            const int task = t0 + 8 * u;
+            va[u] = vb[u] = 0.0f;
+            dst[u] = -1;
+            if (task < xtasks) {
+              const int4 e = *reinterpret_cast<const int4*>(tab + task * 4);
+              const int c = e.w >> 16, hy = e.w & 0xffff;
+              const int id = id0 + e.z, ih = ih0 + hy;
+              const bool rowok = id >= 0 && id < g.Di && ih >= 0 && ih < g.Hi;
+              dst[u] = e.y;
+              if (rowok) {
+                const float* src = xb + e.x + origin + l32;
+                if (cola) va[u] = src[0];
+                if (wide && colb) vb[u] = src[32];
+                if (g.x_scale != nullptr) {
+                  const float sc = g.x_scale[(int64_t)stat * g.Cx + ci0 + c];
+                  const float sh = g.x_shift[(int64_t)stat * g.Cx + ci0 + c];
+                  if (cola) va[u] = fmaxf(fmaf(va[u], sc, sh), 0.0f);
+                  if (wide && colb) vb[u] = fmaxf(fmaf(vb[u], sc, sh), 0.0f);
+                }
+              }
             }
-            xs[e.y + w] = v;
+          }
+#pragma unroll
+          for (int u = 0; u < kU; ++u) {
+            if (dst[u] >= 0) {
+              if (l32 < g.IW) xs[dst[u] + l32] = va[u];
+              if (wide && l32 + 32 < g.IW) xs[dst[u] + l32 + 32] = vb[u];
+            }
           }
         }
       }

@@ -16,8 +16,8 @@
 // state with hipMemsetAsync, and memset nodes recorded from the autograd thread are not replayed reliably, see
 // pf_common.h):  count (integer atomics: the totals do not depend on arrival order) -> exclusive scan (per-block
 // sums, one block over the block sums, per-block scan) -> fill (a slot per pair from an atomic cursor: arrival order)
-// -> every list sorted in place by pair id (lists are short: at most window^3 = 125 entries for a lattice kNN,
-// k on average), which makes the result independent of the arrival order again.
+// -> every list sorted by pair id (one wave per list, rank counting in LDS), which makes the result independent of the
+// arrival order again.
 #include "pf_common.h"
 
 namespace {
@@ -121,24 +121,6 @@ __global__ __launch_bounds__(256) void inverse_fill_kernel(const int64_t* __rest
   order[start[key] + atomicAdd(cursor + key, 1u)] = (uint32_t)p;
 }
 
-// every list ascending by pair id (insertion sort in place; one thread per list)
-__global__ __launch_bounds__(256) void inverse_sort_lists_kernel(const uint32_t* __restrict__ start, int64_t rows,
-                                                                 uint32_t* __restrict__ order) {
-  const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (m >= rows) return;
-  const uint32_t t0 = start[m], t1 = start[m + 1];
-  for (uint32_t i = t0 + 1; i < t1; ++i) {
-    const uint32_t v = order[i];
-    uint32_t j = i;
-    while (j > t0 && order[j - 1] > v) {
-      order[j] = order[j - 1];
-      --j;
-    }
-    order[j] = v;
-  }
-}
-
-
 // The same counting sort for pairs whose keys are given as an array (csrc/warp_bwd.hip: (view, point) pairs keyed by
 // the texel cell their bilinear footprint starts in); keys >= nkeys are dropped (no list holds them).
 __global__ __launch_bounds__(256) void keys_count_kernel(const uint32_t* __restrict__ keys, int64_t pairs, uint32_t nkeys,
@@ -203,7 +185,8 @@ int64_t pf_knn_inverse_workspace(int G, int Ng, int k) {
   if (G <= 0 || Ng <= 0 || k <= 0) return 0;
   const int64_t rows = (int64_t)G * Ng;
   const int64_t nblocks = pf_cdiv(rows + 1, kScanBlock);
-  return (int64_t)(align256(sizeof(uint32_t) * (size_t)rows) + align256(sizeof(uint32_t) * (size_t)nblocks));
+  return (int64_t)(align256(sizeof(uint32_t) * (size_t)rows) + align256(sizeof(uint32_t) * (size_t)nblocks) +
+                   align256(sizeof(uint32_t) * (size_t)rows * (size_t)k));
 }
 
 int pf_knn_inverse(const int64_t* idx, int k, int G, int Ng, uint32_t* order, uint32_t* start, void* workspace,
@@ -219,6 +202,8 @@ int pf_knn_inverse(const int64_t* idx, int k, int G, int Ng, uint32_t* order, ui
   uint32_t* sums = reinterpret_cast<uint32_t*>(w + align256(sizeof(uint32_t) * (size_t)rows));
   const int64_t n = rows + 1;                                  // start[rows] = pairs closes the last list
   const int nblocks = (int)pf_cdiv(n, kScanBlock);
+  uint32_t* scratch = reinterpret_cast<uint32_t*>(w + align256(sizeof(uint32_t) * (size_t)rows) +
+                                                  align256(sizeof(uint32_t) * (size_t)nblocks));
   const unsigned pb = (unsigned)pf_cdiv(pairs, 256);
   hipLaunchKernelGGL(inverse_zero_kernel, dim3((unsigned)(pf_cdiv(n, 256) > 2048 ? 2048 : pf_cdiv(n, 256))), dim3(256), 0, s,
                      start, n, cursor, rows);
@@ -227,7 +212,9 @@ int pf_knn_inverse(const int64_t* idx, int k, int G, int Ng, uint32_t* order, ui
   hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, s, sums, nblocks);
   hipLaunchKernelGGL(scan_blocks_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, start, n, sums);
   hipLaunchKernelGGL(inverse_fill_kernel, dim3(pb), dim3(256), 0, s, idx, pairs, k, Ng, start, cursor, order);
-  hipLaunchKernelGGL(inverse_sort_lists_kernel, dim3((unsigned)pf_cdiv(rows, 256)), dim3(256), 0, s, start, rows, order);
+  // lists ascending by pair id: one wave per list, rank counting in LDS (round 4; the one-thread-per-list insertion sort
+  // took 300-430 us at 1.6 M pairs and was quadratic in the list length)
+  hipLaunchKernelGGL(sort_lists_wave_kernel, dim3((unsigned)pf_cdiv(rows, 4)), dim3(256), 0, s, start, rows, order, scratch);
   return pf_launch_status();
 }
 

@@ -28,7 +28,8 @@ __global__ __launch_bounds__(256) void bn_train_rows_kernel(const double* __rest
                                                             const float* __restrict__ beta,
                                                             float* __restrict__ running_mean,
                                                             float* __restrict__ running_var, float momentum, float eps,
-                                                            int S, int gps, float* __restrict__ rows) {
+                                                            int S, int gps, float* __restrict__ rows, int ld,
+                                                            int col_out, int ch0) {
   __shared__ double2 red[256];
   const int tid = threadIdx.x;
   const int cl = tid & 3, sl = tid >> 2;
@@ -38,8 +39,8 @@ __global__ __launch_bounds__(256) void bn_train_rows_kernel(const double* __rest
   const bool track = running_mean != nullptr;
   float rm = 0.0f, rv = 0.0f;
   if (track && sl == 0 && live) {
-    rm = running_mean[c];
-    rv = running_var[c];
+    rm = running_mean[ch0 + c];
+    rv = running_var[ch0 + c];
   }
   for (int s = 0; s < S; ++s) {
     double a = 0.0, b = 0.0;
@@ -63,11 +64,11 @@ __global__ __launch_bounds__(256) void bn_train_rows_kernel(const double* __rest
       double var = sq / count - mean * mean;
       var = var < 0.0 ? 0.0 : var;
       const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-      const float sc = invstd * gamma[c];
-      const int64_t SC = (int64_t)S * C;
-      float* r = rows + (int64_t)s * C + c;
+      const float sc = invstd * gamma[ch0 + c];
+      const int64_t SC = (int64_t)S * ld;
+      float* r = rows + (int64_t)s * ld + col_out + c;
       r[0] = sc;
-      r[SC] = beta[c] - (float)mean * sc;
+      r[SC] = beta[ch0 + c] - (float)mean * sc;
       r[2 * SC] = (float)mean;
       r[3 * SC] = invstd;
       if (track) {
@@ -79,8 +80,8 @@ __global__ __launch_bounds__(256) void bn_train_rows_kernel(const double* __rest
     __syncthreads();
   }
   if (track && sl == 0 && live) {
-    running_mean[c] = rm;
-    running_var[c] = rv;
+    running_mean[ch0 + c] = rm;
+    running_var[ch0 + c] = rv;
   }
 }
 
@@ -360,13 +361,15 @@ extern "C" {
 
 int pf_bn_train_rows_f32(const double* partials, int T, int pcols, int col0, int C, double count, double unbias_n,
                          const float* gamma, const float* beta, float* running_mean, float* running_var,
-                         float momentum, float eps, int G, int groups_per_stat, float* rows, void* stream) {
+                         float momentum, float eps, int G, int groups_per_stat, float* rows, int ld_rows, int col_out,
+                         int ch0, void* stream) {
   PF_REQUIRE(T >= 1 && pcols >= 1 && col0 >= 0 && C >= 1 && col0 + C <= pcols && count > 0.0);
+  PF_REQUIRE(col_out >= 0 && ld_rows >= col_out + C && ch0 >= 0);
   PF_REQUIRE(G >= 1 && groups_per_stat >= 1 && (G % groups_per_stat) == 0);
   PF_REQUIRE(partials && gamma && beta && rows && (running_mean == nullptr) == (running_var == nullptr));
   hipLaunchKernelGGL(bn_train_rows_kernel, dim3((unsigned)pf_cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, partials, T,
                      pcols, col0, C, count, unbias_n, gamma, beta, running_mean, running_var, momentum, eps,
-                     G / groups_per_stat, groups_per_stat, rows);
+                     G / groups_per_stat, groups_per_stat, rows, ld_rows, col_out, ch0);
   return pf_launch_status();
 }
 

@@ -963,13 +963,26 @@ def edge_conv_fused(X, point_major, ldx, K, G, Ng, idx, conv1_w, conv2_w, bn, co
                             want_stats=(concat and training))
     if join is not None:                      # ``idx`` was produced on another stream (flow_chain)
         torch.cuda.current_stream().wait_stream(join)
+    rows4 = None
     if training:
         T = stat_blocks(G, Ng)
         part_d = stat_rows(G, T, C, dev)
         _lib.call("pf_edge_stats_f32", _lib.ptr(LE), 2 * C, C, _lib.ptr(idx), k, G, Ng, _lib.ptr(part_d),
                   _lib.ptr(codes), lat[0], lat[1], lat[2], _lib.stream(),
                   algo_bytes=float(G) * Ng * (4.0 * C + (1.0 if codes is not None else 8.0) * k + 4.0 * C * k))
-        if concat:
+        if keep is not None:
+            # training: one finalize per half that also keeps (mean, invstd) for the backward (pf_bn_train_rows_f32)
+            from . import train_ops
+            rows4 = torch.empty((4, S, cbn), dtype=_F32, device=dev)
+            if concat:
+                train_ops.bn_train_rows(bn, part_l, 0, C, float(groups_per_stat) * Ng, G, groups_per_stat,
+                                        unbias_n=n_pairs, rows=rows4, col_out=0, ch0=0, bump=False)
+                train_ops.bn_train_rows(bn, part_d, 0, C, n_pairs, G, groups_per_stat, rows=rows4, col_out=C, ch0=C,
+                                        bump=False)
+            else:
+                train_ops.bn_train_rows(bn, part_d, 0, C, n_pairs, G, groups_per_stat, rows=rows4, bump=False)
+            scale, shift = rows4[0], rows4[1]
+        elif concat:
             bn_finalize_jobs([
                 bn_job(bn, part_l, 0, C, float(groups_per_stat) * Ng, n_pairs, G, groups_per_stat, scale, shift),
                 bn_job(bn, part_d, 0, C, n_pairs, n_pairs, G, groups_per_stat, scale[:, C:], shift[:, C:], ch0=C)])
@@ -983,17 +996,7 @@ def edge_conv_fused(X, point_major, ldx, K, G, Ng, idx, conv1_w, conv2_w, bn, co
     if keep is not None:
         if not training:
             raise RuntimeError("edge_conv_fused(keep=...) needs a train-mode BatchNorm")
-        sums_d = part_d.view(S, -1, C, 2).sum(dim=1)                       # float64 (S, C, 2)
-        mean = sums_d[..., 0] / n_pairs
-        var = (sums_d[..., 1] / n_pairs - mean * mean).clamp_min(0.0)
-        if concat:
-            n_pts = float(groups_per_stat) * Ng
-            sums_l = part_l.view(S, -1, part_l.shape[2], 2)[:, :, :C].sum(dim=1)
-            mean_l = sums_l[..., 0] / n_pts
-            var_l = (sums_l[..., 1] / n_pts - mean_l * mean_l).clamp_min(0.0)
-            mean, var = torch.cat([mean_l, mean], dim=1), torch.cat([var_l, var], dim=1)
-        keep.update(LE=LE, scale=scale, shift=shift, mean=mean.to(_F32).contiguous(),
-                    invstd=torch.rsqrt(var + bn.eps).to(_F32).contiguous())
+        keep.update(LE=LE, scale=rows4[0], shift=rows4[1], mean=rows4[2], invstd=rows4[3])
     _lib.call("pf_edge_apply_f32", _lib.ptr(LE), 2 * C, C, _lib.ptr(idx), k, G, Ng, _lib.ptr(scale),
               _lib.ptr(shift), cbn, groups_per_stat, int(bool(concat)), _lib.ptr(Y), int(ldy), _lib.ptr(codes),
               lat[0], lat[1], lat[2], _lib.stream(),

@@ -29,20 +29,26 @@ _F32 = torch.float32
 # ---------------------------------------------------------------------------------------------
 # thin wrappers over the C ABI
 # ---------------------------------------------------------------------------------------------
-def bn_train_rows(bn, partials, col0, C, count, G, groups_per_stat):
-    """(4, S, C) rows [scale | shift | mean | invstd] of a train-mode BatchNorm from the statistics partials
-    (G, T, pcols, 2) of its producer; updates the running statistics like the module would (one update per group)."""
+def bn_train_rows(bn, partials, col0, C, count, G, groups_per_stat, unbias_n=None, rows=None, col_out=0, ch0=0,
+                  bump=True):
+    """(4, S, ld) rows [scale | shift | mean | invstd] of a train-mode BatchNorm from the statistics partials
+    (G, T, pcols, 2) of its producer; updates the running statistics like the module would (one update per group).
+    ``rows`` / ``col_out`` / ``ch0``: write channels [ch0, ch0 + C) of the module into columns [col_out, col_out + C)
+    of an existing rows tensor (EdgeConv's BatchNorm: central and difference halves have separate statistics)."""
     if bn.momentum is None:
         raise NotImplementedError("cumulative-average BatchNorm momentum is not supported")
     S = G // groups_per_stat
-    rows = torch.empty((4, S, C), dtype=_F32, device=partials.device)
+    if rows is None:
+        rows = torch.empty((4, S, C), dtype=_F32, device=partials.device)
     track = bn.track_running_stats and bn.running_mean is not None
     _lib.call("pf_bn_train_rows_f32", _lib.ptr(partials), int(partials.shape[1]), int(partials.shape[2]), int(col0),
-              int(C), float(count), float(count), _lib.ptr(bn.weight.detach()), _lib.ptr(bn.bias.detach()),
-              _lib.ptr(bn.running_mean if track else None), _lib.ptr(bn.running_var if track else None),
-              float(bn.momentum), float(bn.eps), int(G), int(groups_per_stat), _lib.ptr(rows), _lib.stream(),
+              int(C), float(count), float(count if unbias_n is None else unbias_n), _lib.ptr(bn.weight.detach()),
+              _lib.ptr(bn.bias.detach()), _lib.ptr(bn.running_mean if track else None),
+              _lib.ptr(bn.running_var if track else None), float(bn.momentum), float(bn.eps), int(G),
+              int(groups_per_stat), _lib.ptr(rows), int(rows.shape[2]), int(col_out), int(ch0), _lib.stream(),
               algo_bytes=16.0 * partials.shape[0] * partials.shape[1] * C)
-    pointflow.bump_counter(bn, S)
+    if bump:
+        pointflow.bump_counter(bn, S)
     return rows
 
 
