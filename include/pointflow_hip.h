@@ -578,6 +578,15 @@ int pf_flow_depth_grad_f32(const float* dfeat, int64_t ld, int c0, const float* 
 int pf_resize_bilinear_backward_f32(const float* dres, int ld, int c0, int C, int V, int OH, int OW, int IH, int IW,
                                     float* dlevel, void* stream);
 
+
+/* Weight packing for a whole training step in ONE launch (csrc/norm_bwd.hip): `table` is a device array of `npacks`
+ * descriptors (pf_pack_desc_bytes() bytes each; layout in pointmvsnet_amd/train_packs.py), each an affine gather
+ *     dst[d_0 .. d_{n-1}] = src[sum_k a_k * sstride_k],  a_k = off_k + sum_i M[k][i] * d_i,  0 unless 0 <= a_k < lim_k
+ * -- the MFMA operand layouts, zero paddings, flips and transpositions the forward and backward kernels of the step
+ * read their weights in.  max_total: the largest destination element count in the table. */
+int pf_pack_desc_bytes(void);
+int pf_pack_gather_f32(const void* table, int npacks, long long max_total, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -118,6 +118,8 @@ PROTOTYPES = {
     "pf_warp_gather_f32": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp], _i),
     "pf_flow_depth_grad_f32": ([_vp, _i64, _i, _vp, _i, _i, _vp, _vp], _i),
     "pf_resize_bilinear_backward_f32": ([_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp], _i),
+    "pf_pack_desc_bytes": ([], _i),
+    "pf_pack_gather_f32": ([_vp, _i, ctypes.c_longlong, _vp], _i),
 }
 
 _lib = None

@@ -458,3 +458,78 @@ int pf_rows_affine_f32(const float* y, int64_t ldy, const float* rows, float* z,
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// weight packing for a whole training step in ONE launch
+// ------------------------------------------------------------------------------------------------
+// Every kernel of the step reads its weights in a layout of its own (MFMA operand order, zero padded; the data
+// gradients read them flipped and transposed).  Eagerly that is 3-5 tiny ATen launches per layer and direction
+// (flip, permute, zeros, copy): ~350 launches of ~5 us per step.  Each layout is an AFFINE GATHER of the parameter:
+//     dst[d_0 .. d_{n-1}] = src[sum_k a_k * sstride_k],  a_k = off_k + sum_i M[k][i] * d_i,  zero unless 0 <= a_k < lim_k
+// so a table of descriptors in device memory, built once per model (parameter and buffer addresses are stable across
+// optimizer steps), re-packs everything with one kernel at the start of each step -- inside the captured graph.
+namespace {
+constexpr int kPackDims = 7, kPackSrc = 5;
+struct PackDesc {                 // 8-byte aligned, mirrored by pointmvsnet_amd/train_packs.py (numpy structured dtype)
+  const float* src;
+  float* dst;
+  long long total;                // product of dshape
+  int ndim, nsrc;
+  int dshape[kPackDims];
+  int dstride[kPackDims];         // element strides of dst (a pack may fill a column slice of a padded matrix)
+  int off[kPackSrc];
+  int lim[kPackSrc];
+  int sstride[kPackSrc];
+  int M[kPackSrc][kPackDims];
+  int pad_;
+};
+
+__global__ __launch_bounds__(256) void pack_gather_kernel(const PackDesc* __restrict__ table) {
+  const PackDesc& P = table[blockIdx.y];
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < P.total; i += stride) {
+    long long rest = i;
+    int d[kPackDims];
+#pragma unroll
+    for (int k = kPackDims - 1; k >= 0; --k) {
+      d[k] = 0;
+      if (k < P.ndim) {
+        d[k] = (int)(rest % P.dshape[k]);
+        rest /= P.dshape[k];
+      }
+    }
+    long long so = 0, doff = 0;
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < kPackDims; ++k) doff += (long long)d[k] * P.dstride[k];
+#pragma unroll
+    for (int s = 0; s < kPackSrc; ++s) {
+      if (s < P.nsrc) {
+        int a = P.off[s];
+#pragma unroll
+        for (int k = 0; k < kPackDims; ++k) a += P.M[s][k] * d[k];
+        ok = ok && a >= 0 && a < P.lim[s];
+        so += (long long)a * P.sstride[s];
+      }
+    }
+    P.dst[doff] = ok ? P.src[so] : 0.0f;
+  }
+}
+}  // namespace
+
+extern "C" {
+
+int pf_pack_desc_bytes(void) { return (int)sizeof(PackDesc); }
+
+int pf_pack_gather_f32(const void* table, int npacks, long long max_total, void* stream) {
+  PF_REQUIRE(npacks >= 0 && max_total >= 0);
+  if (npacks == 0 || max_total == 0) return PF_OK;
+  PF_REQUIRE(table != nullptr && npacks <= 65535);
+  long long blocks = (max_total + 255) / 256;
+  blocks = blocks > 64 ? 64 : blocks;
+  hipLaunchKernelGGL(pack_gather_kernel, dim3((unsigned)blocks, (unsigned)npacks), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const PackDesc*>(table));
+  return pf_launch_status();
+}
+
+}  // extern "C"

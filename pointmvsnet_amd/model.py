@@ -516,8 +516,30 @@ class PointMVSNet(nn.Module):
         avg = point_features.mean(dim=1)
         return (point_features ** 2).mean(dim=1) - avg ** 2
 
+    def _fused_train(self, img_list):
+        """Row Z: one scene per process and the reference's widths -> every conv / BatchNorm stack, the warps and the
+        PointFlow chain are autograd nodes on this package's own forward and backward kernels (train_ops.py)."""
+        return bool(FUSED_TRAIN and _networks.FUSED_TRAIN and img_list.shape[0] == 1 and self.training
+                    and torch.is_grad_enabled()
+                    and train_ops.tower_supported(self.coarse_img_conv, img_list[0])
+                    and train_ops.tower_supported(self.flow_img_conv, img_list[0]))
+
     def run_autograd(self, tplan, img_list, isFlow=True):
         """Device-only autograd forward on the constants of ``tplan`` (capturable together with its backward)."""
+        if not self._fused_train(img_list):
+            return self._run_autograd(tplan, img_list, isFlow, False)
+        # every packed weight of the step (forward layouts, flipped / transposed backward layouts): one launch
+        from .train_packs import TrainPacks
+        packs = getattr(self, "_train_packs", None)
+        if packs is None or packs.stale():
+            packs = TrainPacks(self)
+            object.__setattr__(self, "_train_packs", packs)
+        with torch.cuda.device(img_list.device):
+            packs.run()
+        with train_ops.use_packs(packs):
+            return self._run_autograd(tplan, img_list, isFlow, True)
+
+    def _run_autograd(self, tplan, img_list, isFlow, fused):
         dev = img_list.device
         B, V, _, H, W = img_list.shape
         isTest, img_scales = tplan.is_test, tplan.img_scales
@@ -525,11 +547,6 @@ class PointMVSNet(nn.Module):
         K_coarse = tplan.d("K_coarse")
         ext = tplan.d("ext")
 
-        # Row Z: one scene per process and the reference's widths -> every conv / BatchNorm stack is ONE autograd node
-        # on this package's own forward and backward kernels (train_ops.py); anything else: the ATen composition
-        fused = (FUSED_TRAIN and _networks.FUSED_TRAIN and B == 1 and self.training
-                 and train_ops.tower_supported(self.coarse_img_conv, img_list[0])
-                 and train_ops.tower_supported(self.flow_img_conv, img_list[0]))
         if fused:
             feature_list = train_ops.tower_train(self.coarse_img_conv, img_list[0], ("conv3",))["conv3"].unsqueeze(0)
             coarse_maps = [feature_list[:, 0]]

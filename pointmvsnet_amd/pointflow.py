@@ -106,7 +106,16 @@ class no_pack_cache(object):
         return False
 
 
+# The packed weights of the training step in flight (train_packs.TrainPacks.active()): refreshed by one launch at the
+# start of the step, found here under the same keys the wrappers below use.
+_prepacked = None
+
+
 def _cached_pack(key, sources, make):
+    if _prepacked is not None:
+        hit = _prepacked.get(key)
+        if hit is not None:
+            return hit
     if _pack_bypass:
         return make()
     hit = _pack_cache.get(key)

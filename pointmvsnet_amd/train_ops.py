@@ -23,7 +23,39 @@ import torch
 from . import _lib
 from . import pointflow
 
+import contextlib
+
 _F32 = torch.float32
+
+# The step's packed weights (train_packs.TrainPacks) while a fused training forward / backward runs; None: every
+# function below packs on the fly with torch operators (the operator tests, eager use of single nodes).
+_PACKS = None
+
+
+@contextlib.contextmanager
+def use_packs(packs):
+    global _PACKS
+    saved, _PACKS = _PACKS, packs
+    try:
+        if packs is None:
+            yield None
+        else:
+            with packs.active():
+                yield packs
+    finally:
+        _PACKS = saved
+
+
+def _packed(kind, tensor):
+    return None if _PACKS is None else _PACKS.get(kind, tensor)
+
+
+def _with_packs(backward):
+    """A node's backward runs under the packs its forward ran under (loss.backward() is called outside the context)."""
+    def wrapped(ctx, *grads):
+        with use_packs(getattr(ctx, "packs", None)):
+            return backward(ctx, *grads)
+    return wrapped
 
 
 # ---------------------------------------------------------------------------------------------
@@ -158,19 +190,22 @@ def rows_wgrad(gr, x, Cg, Cx, x_affine=None, x_rows_per_stat=None):
     return dw
 
 
-def gemm_rows(x, w, K, n_out):
+def gemm_rows(x, w, K, n_out, chunks=None):
     """(P, n_out) = x[:, :K] @ w (K, n_out) on point-major rows through pf_pointwise_gemm_f32 (column chunks of at most
-    128, zero padded to the kernel's 32 / 64 / 128 widths)."""
+    128, zero padded to the kernel's 32 / 64 / 128 widths; ``chunks``: the step's prepacked [(col0, width, wt)])."""
     P = x.shape[0]
     y = torch.empty((P, n_out), dtype=_F32, device=x.device)
-    col = 0
-    while col < n_out:
-        width = min(128, n_out - col)
-        nc = 32 if width <= 32 else (64 if width <= 64 else 128)
-        wt = torch.zeros((K, nc), dtype=_F32, device=x.device)
-        wt[:, :width] = w[:, col:col + width]
+    if chunks is None:
+        chunks, col = [], 0
+        while col < n_out:
+            width = min(128, n_out - col)
+            nc = 32 if width <= 32 else (64 if width <= 64 else 128)
+            wt = torch.zeros((K, nc), dtype=_F32, device=x.device)
+            wt[:, :width] = w[:, col:col + width]
+            chunks.append((col, width, wt))
+            col += width
+    for col, width, wt in chunks:
         pointflow.pointwise_gemm(x, True, int(x.stride(0)), wt, y[:, col:], n_out, 1, P, K, width)
-        col += width
     return y
 
 
@@ -186,45 +221,76 @@ def conv2d_dgrad(dy, weight, stride):
     Cin, k = weight.shape[1], weight.shape[2]
     dy = dy.contiguous()
     if stride == 1:
-        wp = pointflow._pack_conv2d_wide(_flip_t(weight))
+        wp = _packed("c2w_dg", weight)
+        if wp is None:
+            wp = pointflow._pack_conv2d_wide(_flip_t(weight))
         dx = torch.empty((N, Cin, Ho, Wo), dtype=_F32, device=dy.device)
         _lib.call("pf_conv2d_wide_f32", _lib.ptr(dy), _lib.ptr(wp), _lib.ptr(dx), N, Cout, Cin, Ho, Wo, int(k), 1,
                   None, None, None, 1, None, 0, _lib.stream(),
                   algo_bytes=4.0 * N * (Cin + Cout) * Ho * Wo, flops=2.0 * N * Ho * Wo * k * k * Cin * Cout)
         return dx
-    ncp = (Cin + 15) // 16 * 16
-    wp = torch.zeros((Cout // 4, k * k, 4, ncp), dtype=_F32, device=dy.device)
-    wp[..., :Cin] = weight.detach().reshape(Cout // 4, 4, Cin, k * k).permute(0, 3, 1, 2)
+    wp = _packed("d2_dg", weight)
+    if wp is None:
+        ncp = (Cin + 15) // 16 * 16
+        wp = torch.zeros((Cout // 4, k * k, 4, ncp), dtype=_F32, device=dy.device)
+        wp[..., :Cin] = weight.detach().reshape(Cout // 4, 4, Cin, k * k).permute(0, 3, 1, 2)
     dx = torch.empty((N, Cin, 2 * Ho, 2 * Wo), dtype=_F32, device=dy.device)
     _lib.call("pf_deconv2d_k5s2_f32", _lib.ptr(dy), _lib.ptr(wp), _lib.ptr(dx), N, Cout, Cin, Ho, Wo, _lib.stream(),
               algo_bytes=4.0 * N * (Cout + 4 * Cin) * Ho * Wo, flops=2.0 * N * Ho * Wo * k * k * Cin * Cout)
     return dx
 
 
-def _conv3d_k3_w(x, w, stride):
-    """conv3d 3x3x3 / pad 1 with an explicit weight tensor (Cout, Cin, 3, 3, 3) on the forward kernels: Cout <= 32
-    through pf_conv3d_k3_f32 (<= 8 at stride 1: the paired-rows kernel), Cout = 64 as two halves (one sample)."""
-    Cout = w.shape[0]
-    if Cout <= 32:
-        return pointflow.conv3d_k3(x, w, stride, False)[0]
-    N, Cin, D, H, W = x.shape
-    if N != 1 or stride != 1 or Cout % 32:
-        raise RuntimeError("conv3d dgrad: unsupported shape")
-    y = torch.empty((1, Cout, D, H, W), dtype=_F32, device=x.device)
-    for c0 in range(0, Cout, 32):
-        wp = pointflow.pack_conv3d_weight(w[c0:c0 + 32].contiguous())
-        _lib.call("pf_conv3d_k3_f32", _lib.ptr(x), _lib.ptr(wp), _lib.ptr(y[:, c0:]), 1, Cin, 32, D, H, W, 1, None, None,
-                  None, 1, None, _lib.stream(), algo_bytes=4.0 * (Cin + 32) * D * H * W,
-                  flops=2.0 * D * H * W * 27 * Cin * 32)
+def _conv3d_k3_packed(x, wp, Cout, stride, y=None):
+    """pf_conv3d_k3_f32 on an already packed weight (Cin/4, 27, 4, 16 ceil(Cout/16)); ``y``: where to write (one sample:
+    a channel slice of a wider tensor)."""
+    N, Cin, Di, Hi, Wi = x.shape
+    Do, Ho, Wo = (Di - 1) // stride + 1, (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
+    if y is None:
+        y = torch.empty((N, Cout, Do, Ho, Wo), dtype=_F32, device=x.device)
+    _lib.call("pf_conv3d_k3_f32", _lib.ptr(x), _lib.ptr(wp), _lib.ptr(y), N, Cin, Cout, Di, Hi, Wi, int(stride), None,
+              None, None, 1, None, _lib.stream(), algo_bytes=4.0 * N * (Cin * Di * Hi * Wi + Cout * Do * Ho * Wo),
+              flops=2.0 * N * Do * Ho * Wo * 27 * Cin * Cout)
     return y
 
 
-def _conv3d_bottom_w(x, w, stride):
-    """pf_conv3d_bottom_f32 (Cout = 64; 32 -> 64 / 2 or 64 -> 64 / 1) with an explicit weight (64, Cin, 3, 3, 3)."""
+def conv3d_dgrad_flip(dy, weight):
+    """dL/dx of a stride-1 3x3x3 'same' convolution y = conv3d(x, weight): the forward kernel on the flipped, transposed
+    weight; Cin <= 32 in one launch, Cin = 64 as two halves of the output channels (one sample)."""
+    Cout, Cin = weight.shape[:2]
+    if Cin <= 32:
+        wp = _packed("c3_dg", weight)
+        if wp is None:
+            return pointflow.conv3d_k3(dy, _flip_t(weight), 1, False)[0]
+        return _conv3d_k3_packed(dy, wp, Cin, 1)
+    N, _, D, H, W = dy.shape
+    if N != 1 or Cin % 32:
+        raise RuntimeError("conv3d dgrad: unsupported shape")
+    dx = torch.empty((1, Cin, D, H, W), dtype=_F32, device=dy.device)
+    wf = None
+    for h, c0 in enumerate(range(0, Cin, 32)):
+        wp = _packed("c3_dg%d" % h, weight)
+        if wp is None:
+            wf = _flip_t(weight) if wf is None else wf
+            wp = pointflow.pack_conv3d_weight(wf[c0:c0 + 32].contiguous())
+        _conv3d_k3_packed(dy, wp, 32, 1, y=dx[:, c0:])
+    return dx
+
+
+def _conv3d_k3_w(x, w, stride):
+    """conv3d 3x3x3 / pad 1 with the weight tensor (Cout <= 32, Cin, 3, 3, 3) read as it is (pf_conv3d_k3_f32; a
+    ConvTranspose3d weight read this way gives the transposed layer's data gradient at stride 2)."""
+    return pointflow.conv3d_k3(x, w, stride, False)[0]
+
+
+def _conv3d_bottom_w(x, w, stride, flip_t=False):
+    """pf_conv3d_bottom_f32 (Cout = 64; 32 -> 64 / 2 or 64 -> 64 / 1) with the weight (64, Cin, 3, 3, 3) as it is, or
+    flipped and transposed (``flip_t``: the stride-1 layer's data gradient)."""
     N, Cin, Di, Hi, Wi = x.shape
     Do, Ho, Wo = (Di - 1) // stride + 1, (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
-    wp = w.detach().to(_F32).permute(2, 3, 4, 1, 0).reshape(3, 3, 3, Cin // 16, 4, 4, 64).permute(0, 1, 2, 3, 4, 6, 5)
-    wp = wp.contiguous()
+    wp = _packed("c3b_dg" if flip_t else "c3b", w)
+    if wp is None:
+        wt = _flip_t(w) if flip_t else w.detach().to(_F32)
+        wp = wt.permute(2, 3, 4, 1, 0).reshape(3, 3, 3, Cin // 16, 4, 4, 64).permute(0, 1, 2, 3, 4, 6, 5).contiguous()
     y = torch.empty((N, 64, Do, Ho, Wo), dtype=_F32, device=x.device)
     _lib.call("pf_conv3d_bottom_f32", _lib.ptr(x), _lib.ptr(wp), _lib.ptr(y), N, Cin, 64, Di, Hi, Wi, int(stride), None,
               None, None, 1, None, _lib.stream(), algo_bytes=4.0 * N * (Cin * Di * Hi * Wi + 64 * Do * Ho * Wo),
@@ -233,9 +299,11 @@ def _conv3d_bottom_w(x, w, stride):
 
 
 def _deconv3d_bottom_w(x, w):
-    """pf_deconv3d_bottom_f32 with an explicit ConvTranspose3d-layout weight (64, 32, 3, 3, 3)."""
+    """pf_deconv3d_bottom_f32 with the weight (64, 32, 3, 3, 3) read in ConvTranspose3d's layout."""
     N, Cin, Di, Hi, Wi = x.shape
-    wp = w.detach().to(_F32).permute(2, 3, 4, 0, 1).reshape(27, Cin // 16, 4, 4, 32).permute(0, 1, 2, 4, 3).contiguous()
+    wp = _packed("d3b", w)
+    if wp is None:
+        wp = w.detach().to(_F32).permute(2, 3, 4, 0, 1).reshape(27, Cin // 16, 4, 4, 32).permute(0, 1, 2, 4, 3).contiguous()
     y = torch.empty((N, 32, 2 * Di, 2 * Hi, 2 * Wi), dtype=_F32, device=x.device)
     _lib.call("pf_deconv3d_bottom_f32", _lib.ptr(x), _lib.ptr(wp), _lib.ptr(y), N, Cin, 32, Di, Hi, Wi, None, None, None,
               1, None, _lib.stream(), algo_bytes=4.0 * N * Di * Hi * Wi * (Cin + 8 * 32),
@@ -288,6 +356,7 @@ class _TowerTrain(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, img, tower, want, *params):
+        ctx.packs = _PACKS
         blocks = _tower_blocks(tower)
         V = img.shape[0]
         x = img.detach().contiguous()
@@ -309,6 +378,7 @@ class _TowerTrain(torch.autograd.Function):
         return tuple(outs)
 
     @staticmethod
+    @_with_packs
     def backward(ctx, *grads):
         tower, want, saved = ctx.tower, ctx.want, ctx.saved
         blocks = _tower_blocks(tower)
@@ -391,6 +461,7 @@ def volume_params(vc):
 class _VolumeTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cost, vc, *params):
+        ctx.packs = _PACKS
         x0 = cost.detach().contiguous()
         rec = {}
 
@@ -439,6 +510,7 @@ class _VolumeTrain(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_with_packs
     def backward(ctx, gout):
         vc, rec = ctx.vc, ctx.rec
         grads = {}
@@ -464,32 +536,34 @@ class _VolumeTrain(torch.autograd.Function):
             g = gout.contiguous()
             w62 = vc.conv6_2.weight
             grads["conv6_2"] = conv_wgrad(g, rec["conv6_2"][0], K3, 1, P3)
-            wf = w62.detach().flip(2, 3, 4).reshape(w62.shape[1], 27).contiguous()
+            wf = _packed("c1_dg", w62)
+            if wf is None:
+                wf = w62.detach().flip(2, 3, 4).reshape(w62.shape[1], 27).contiguous()
             D, H, W = g.shape[2:]
             g7 = torch.empty((1, w62.shape[1], D, H, W), dtype=_F32, device=g.device)
             _lib.call("pf_conv3d_k3_c1_f32", _lib.ptr(g), _lib.ptr(wf), _lib.ptr(g7), 1, int(w62.shape[1]), D, H, W,
                       _lib.stream(), algo_bytes=4.0 * (1 + w62.shape[1]) * D * H * W)
             # decoder: a ConvTranspose3d's data gradient is the stride-2 convolution with its weight read (Cout', Cin')
             dy60 = deconv_back("conv6_0", g7)
-            g6 = _conv3d_k3_w(dy60, vc.conv6_0.conv.weight.detach(), 2)               # -> dz50, dz11
+            g6 = _conv3d_k3_w(dy60, vc.conv6_0.conv.weight, 2)                        # -> dz50, dz11
             dy50 = deconv_back("conv5_0", g6)
-            g5 = _conv3d_k3_w(dy50, vc.conv5_0.conv.weight.detach(), 2)               # -> dz40, dz21
+            g5 = _conv3d_k3_w(dy50, vc.conv5_0.conv.weight, 2)                        # -> dz40, dz21
             dy40 = deconv_back("conv4_0", g5)
-            g31 = _conv3d_bottom_w(dy40, vc.conv4_0.conv.weight.detach(), 2)          # -> dz31
+            g31 = _conv3d_bottom_w(dy40, vc.conv4_0.conv.weight, 2)                   # -> dz31
             dy31 = conv_back("conv3_1", g31, 1)
-            g30 = _conv3d_bottom_w(dy31, _flip_t(vc.conv3_1.conv.weight), 1)
+            g30 = _conv3d_bottom_w(dy31, vc.conv3_1.conv.weight, 1, flip_t=True)
             dy30 = conv_back("conv3_0", g30, 2)
-            g20 = _deconv3d_bottom_w(dy30, vc.conv3_0.conv.weight.detach())           # stride-2 conv: transposed kernel
+            g20 = _deconv3d_bottom_w(dy30, vc.conv3_0.conv.weight)                    # stride-2 conv: transposed kernel
             dy21 = conv_back("conv2_1", g5, 1)
-            g20 = g20 + _conv3d_k3_w(dy21, _flip_t(vc.conv2_1.conv.weight), 1)
+            g20 = g20 + conv3d_dgrad_flip(dy21, vc.conv2_1.conv.weight)
             dy20 = conv_back("conv2_0", g20, 2)
             g10 = pointflow.deconv3d_k3s2(dy20, None, vc.conv2_0.conv.weight.detach(), False)[0]
             dy11 = conv_back("conv1_1", g6, 1)
-            g10 = g10 + _conv3d_k3_w(dy11, _flip_t(vc.conv1_1.conv.weight), 1)
+            g10 = g10 + conv3d_dgrad_flip(dy11, vc.conv1_1.conv.weight)
             dy10 = conv_back("conv1_0", g10, 2)
             gx = pointflow.deconv3d_k3s2(dy10, None, vc.conv1_0.conv.weight.detach(), False)[0]
             dy01 = conv_back("conv0_1", g7, 1)
-            gx = gx + _conv3d_k3_w(dy01, _flip_t(vc.conv0_1.conv.weight), 1)
+            gx = gx + conv3d_dgrad_flip(dy01, vc.conv0_1.conv.weight)
         out = [gx, None]
         for name in _VC_BLOCKS:
             out += [grads[name], grads[name + ".bn"][0], grads[name + ".bn"][1]]
@@ -531,6 +605,7 @@ class _EdgeChainTrain(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, feature, idx, edge_convs, *params):
+        ctx.packs = _PACKS
         x = feature.detach().contiguous()
         N, cin = x.shape
         idx = idx.contiguous()
@@ -553,6 +628,7 @@ class _EdgeChainTrain(torch.autograd.Function):
         return edges
 
     @staticmethod
+    @_with_packs
     def backward(ctx, gedges):
         edge_convs, keeps, idx, N = ctx.edge_convs, ctx.keeps, ctx.idx, ctx.N
         k = idx.shape[2]
@@ -564,9 +640,10 @@ class _EdgeChainTrain(torch.autograd.Function):
                 C = m.conv1.weight.shape[0]
                 gy = g[:, col:col + wdt]
                 grad_le, dgamma, dbeta = pointflow.edge_conv_backward(keep, idx, gy, C, k, 1, N, 1, m.concat)
-                wcat = torch.cat([m.conv1.weight.detach().reshape(C, K), m.conv2.weight.detach().reshape(C, K)], dim=0)
+                wcat = None if _PACKS is not None else torch.cat(
+                    [m.conv1.weight.detach().reshape(C, K), m.conv2.weight.detach().reshape(C, K)], dim=0)
                 dw = rows_wgrad(grad_le, X, 2 * C, K)
-                dX = gemm_rows(grad_le, wcat, 2 * C, K)                         # (N, K)
+                dX = gemm_rows(grad_le, wcat, 2 * C, K, _packed("rows", m.conv1.weight))   # (N, K)
                 if col == 0:
                     gx = dX
                 else:
@@ -607,6 +684,7 @@ class _MLPTrain(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, shared, *params):
+        ctx.packs = _PACKS
         X = x.detach()
         if X.stride(1) != 1:
             X = X.contiguous()
@@ -629,6 +707,7 @@ class _MLPTrain(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_with_packs
     def backward(ctx, gout):
         shared, saved, N = ctx.shared, ctx.saved, ctx.N
         g = gout.contiguous()
@@ -637,7 +716,8 @@ class _MLPTrain(torch.autograd.Function):
             for blk, (X, affine, Z, rows, K, cout) in reversed(list(zip(shared, saved))):
                 dZ, dgamma, dbeta = rows_bn_backward(g, Z, rows, cout, 1, N, 1, True)
                 dw = rows_wgrad(dZ, X, cout, K, x_affine=affine, x_rows_per_stat=N)
-                g = gemm_rows(dZ, blk.conv.weight.detach().reshape(cout, K), cout, K)   # gradient w.r.t. act(X)
+                g = gemm_rows(dZ, blk.conv.weight.detach().reshape(cout, K), cout, K,
+                              _packed("rows", blk.conv.weight))                           # gradient w.r.t. act(X)
                 gparams = [dw.reshape(blk.conv.weight.shape), dgamma, dbeta] + gparams
         return (g, None) + tuple(gparams)
 
@@ -686,6 +766,7 @@ class _FlowFeaturesTrain(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, l1, l2, l3, depth, interval, cam, h, w):
+        ctx.packs = _PACKS
         lv = [t.detach().contiguous() for t in (l1, l2, l3)]
         depth = depth.detach().contiguous()
         with torch.cuda.device(depth.device):
@@ -697,6 +778,7 @@ class _FlowFeaturesTrain(torch.autograd.Function):
         return feature.view(feature.shape[1], feature.shape[2]), xyz
 
     @staticmethod
+    @_with_packs
     def backward(ctx, dfeature, _dxyz):
         levels, depth, interval, cam = ctx.levels, ctx.depth, ctx.interval, ctx.cam
         h, w = ctx.hw
@@ -740,6 +822,7 @@ class _CoarseVolumeTrain(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, maps, kinv, rinv, t, depths, K, E):
+        ctx.packs = _PACKS
         from .utils.feature_fetcher import ChannelLast, frustum_variance, to_channel_last
         m = maps.detach().contiguous()
         with torch.cuda.device(m.device):
@@ -751,6 +834,7 @@ class _CoarseVolumeTrain(torch.autograd.Function):
         return cost, world
 
     @staticmethod
+    @_with_packs
     def backward(ctx, dcost, _dworld):
         cl = ctx.cl
         kinv, rinv, t, depths, K, E = ctx.cams

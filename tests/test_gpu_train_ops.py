@@ -361,3 +361,95 @@ def test_coarse_volume_node_vs_composed_operators(dev):
              world=_rel(runs[0][1], world_ref), dmaps=_rel(runs[0][2], maps.grad))
     report("coarse_volume_node", **e)
     assert e["cost"] < 2e-5 and e["world"] < 1e-6 and e["dmaps"] < 1e-4, e
+
+
+def test_step_weight_packs_equal_the_torch_built_layouts(dev):
+    """train_packs.TrainPacks: every layout the step's kernels read their weights in, produced by ONE affine-gather launch,
+    is bit-equal to the same layout built with torch operators (the packers of pointflow.py / train_ops.py)."""
+    from pointmvsnet_amd import pointflow
+    from pointmvsnet_amd.model import PointMVSNet
+    from pointmvsnet_amd.train_packs import TrainPacks
+    net = PointMVSNet()
+    synthetic.seed_weights(net, seed=5)
+    net = net.to(dev).train()
+    packs = TrainPacks(net)
+    packs.run()
+    torch.cuda.synchronize()
+    assert not packs.stale()
+    flip_t = train_ops._flip_t
+    checked = 0
+
+    def c3(w):
+        cout, cin = w.shape[:2]
+        ncp = (cout + 15) // 16 * 16
+        wp = torch.zeros((cin // 4, 27, 4, ncp), device=dev)
+        wp[..., :cout] = w.detach().permute(1, 2, 3, 4, 0).reshape(cin // 4, 4, 27, cout).transpose(1, 2)
+        return wp
+
+    def c3b(w):
+        cin = w.shape[1]
+        return w.detach().permute(2, 3, 4, 1, 0).reshape(3, 3, 3, cin // 16, 4, 4, 64).permute(0, 1, 2, 3, 4, 6, 5).contiguous()
+
+    def d3b(w):
+        cin, cout = w.shape[:2]
+        return w.detach().permute(2, 3, 4, 0, 1).reshape(27, cin // 16, 4, 4, cout).permute(0, 1, 2, 4, 3).contiguous()
+
+    for tower in (net.coarse_img_conv, net.flow_img_conv):
+        for i, (_, _, conv, _) in enumerate(train_ops._tower_blocks(tower)):
+            W = conv.weight
+            assert torch.equal(packs.get("c2w", W), pointflow._pack_conv2d_wide(W).view_as(packs.get("c2w", W)))
+            checked += 1
+            if i > 0 and conv.stride[0] == 1:
+                ref = pointflow._pack_conv2d_wide(flip_t(W))
+                assert torch.equal(packs.get("c2w_dg", W), ref.view_as(packs.get("c2w_dg", W)))
+                checked += 1
+            elif i > 0:
+                co, ci, k, _ = W.shape
+                ref = torch.zeros((co // 4, k * k, 4, (ci + 15) // 16 * 16), device=dev)
+                ref[..., :ci] = W.detach().reshape(co // 4, 4, ci, k * k).permute(0, 3, 1, 2)
+                assert torch.equal(packs.get("d2_dg", W), ref)
+                checked += 1
+    vc = net.coarse_vol_conv
+    with pointflow.no_pack_cache():
+        assert torch.equal(packs.get("c3p", vc.conv0_1.conv.weight), pointflow.pack_conv3d_weight_pair(vc.conv0_1.conv.weight))
+    for name in ("conv1_0", "conv2_0", "conv1_1", "conv2_1", "conv6_0", "conv5_0"):
+        W = getattr(vc, name).conv.weight
+        assert torch.equal(packs.get("c3", W), c3(W)), name
+    for name in ("conv1_1", "conv2_1"):
+        W = getattr(vc, name).conv.weight
+        assert torch.equal(packs.get("c3_dg", W), c3(flip_t(W))), name
+    W01 = vc.conv0_1.conv.weight
+    for h in (0, 1):
+        assert torch.equal(packs.get("c3_dg%d" % h, W01), c3(flip_t(W01)[32 * h:32 * h + 32].contiguous()))
+    for name in ("conv3_0", "conv3_1", "conv4_0"):
+        W = getattr(vc, name).conv.weight
+        assert torch.equal(packs.get("c3b", W), c3b(W)), name
+    assert torch.equal(packs.get("c3b_dg", vc.conv3_1.conv.weight), c3b(flip_t(vc.conv3_1.conv.weight)))
+    for name in ("conv4_0", "conv3_0"):
+        W = getattr(vc, name).conv.weight
+        assert torch.equal(packs.get("d3b", W), d3b(W)), name
+    W62 = vc.conv6_2.weight
+    assert torch.equal(packs.get("c1_dg", W62), W62.detach().flip(2, 3, 4).reshape(W62.shape[1], 27))
+    for e in net.flow_edge_conv:
+        wt, cout = packs._dst[("wt", id(e.conv1.weight), id(e.conv2.weight))]
+        ref, rc = pointflow._pack_weight_t(e.conv1.weight, e.conv2.weight)
+        assert cout == rc and torch.equal(wt, ref)
+        C, K = e.conv1.weight.shape[:2]
+        wcat = torch.cat([e.conv1.weight.detach().reshape(C, K), e.conv2.weight.detach().reshape(C, K)], dim=0)
+        for col, width, chunk in packs.get("rows", e.conv1.weight):
+            assert torch.equal(chunk[:, :width], wcat[:, col:col + width]) and float(chunk[:, width:].abs().sum()) == 0.0
+    for blk in net.flow_mlp[0]:
+        W = blk.conv.weight
+        wt, cout = packs._dst[("wt", id(W))]
+        ref, rc = pointflow._pack_weight_t(W)
+        assert cout == rc and torch.equal(wt, ref)
+        for col, width, chunk in packs.get("rows", W):
+            assert torch.equal(chunk[:, :width], W.detach().reshape(W.shape[0], -1)[:, col:col + width])
+    # an optimizer-style in-place update is picked up by the next run(); moved storage is reported
+    with torch.no_grad():
+        W01.mul_(2.0)
+    packs.run()
+    assert torch.equal(packs.get("c3_dg0", W01), c3(flip_t(W01)[:32].contiguous()))
+    W01.data = W01.data.clone()
+    assert packs.stale()
+    assert checked >= 40
