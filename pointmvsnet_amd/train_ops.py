@@ -50,6 +50,33 @@ def _packed(kind, tensor):
     return None if _PACKS is None else _PACKS.get(kind, tensor)
 
 
+# True (train_step.TrainStep sets it around forward + backward): a node adds its parameter gradients straight into the
+# parameters' ``.grad`` tensors -- the views of the flat all-reduce bucket (distributed.GradBucket), zeroed at the start
+# of the step -- from inside its own kernels (their accumulate flags) and hands autograd None for them, instead of
+# returning 115 tensors that autograd then adds with one element-wise launch each (160 launches, 0.56 ms per step).
+DIRECT_GRADS = False
+
+
+@contextlib.contextmanager
+def direct_grads(on=True):
+    global DIRECT_GRADS
+    saved, DIRECT_GRADS = DIRECT_GRADS, bool(on)
+    try:
+        yield
+    finally:
+        DIRECT_GRADS = saved
+
+
+def _grad_target(p):
+    """``p.grad`` when a node may accumulate into it directly, else None."""
+    if not DIRECT_GRADS:
+        return None
+    g = p.grad
+    if g is None or g.dtype != _F32 or g.shape != p.shape or not g.is_contiguous() or g.requires_grad:
+        return None
+    return g
+
+
 def _with_packs(backward):
     """A node's backward runs under the packs its forward ran under (loss.backward() is called outside the context)."""
     def wrapped(ctx, *grads):
@@ -94,8 +121,9 @@ def channel_affine(y, rows, samples_per_stat, relu=True):
     return z
 
 
-def bn_backward(g, y, rows, samples_per_stat, relu=True):
-    """BatchNorm(+ReLU) backward on planar (N, C, *spatial) tensors: (dy, dgamma, dbeta)."""
+def bn_backward(g, y, rows, samples_per_stat, relu=True, into=None):
+    """BatchNorm(+ReLU) backward on planar (N, C, *spatial) tensors: (dy, dgamma, dbeta).  ``into`` = (dgamma, dbeta)
+    tensors to ADD the parameter gradients to (then the returned ones are None)."""
     N, C = y.shape[:2]
     S = y[0, 0].numel()
     g = g.contiguous()
@@ -106,18 +134,21 @@ def bn_backward(g, y, rows, samples_per_stat, relu=True):
               int(bool(relu)), _lib.ptr(partials), _lib.stream(), algo_bytes=8.0 * N * C * S)
     G = N // samples_per_stat
     coef = torch.empty((2, G, C), dtype=_F32, device=dev)
-    dgamma = torch.empty((C,), dtype=_F32, device=dev)
-    dbeta = torch.empty((C,), dtype=_F32, device=dev)
+    if into is None:
+        dgamma = torch.empty((C,), dtype=_F32, device=dev)
+        dbeta = torch.empty((C,), dtype=_F32, device=dev)
+    else:
+        dgamma, dbeta = into
     _lib.call("pf_bn_bwd_coeffs_f32", _lib.ptr(partials), T, C, 0, C, float(samples_per_stat) * S, N,
-              int(samples_per_stat), _lib.ptr(rows), _lib.ptr(coef), _lib.ptr(dgamma), _lib.ptr(dbeta), 0, _lib.stream(),
-              algo_bytes=16.0 * N * T * C)
+              int(samples_per_stat), _lib.ptr(rows), _lib.ptr(coef), _lib.ptr(dgamma), _lib.ptr(dbeta),
+              0 if into is None else 1, _lib.stream(), algo_bytes=16.0 * N * T * C)
     dy = torch.empty_like(y)
     _lib.call("pf_bn_bwd_apply_f32", _lib.ptr(g), _lib.ptr(y), _lib.ptr(rows), _lib.ptr(coef), _lib.ptr(dy), N, C, S,
               int(samples_per_stat), int(bool(relu)), _lib.stream(), algo_bytes=12.0 * N * C * S)
-    return dy, dgamma, dbeta
+    return (dy, dgamma, dbeta) if into is None else (dy, None, None)
 
 
-def rows_bn_backward(g, y, rows, C, G, Ng, groups_per_stat, relu=True):
+def rows_bn_backward(g, y, rows, C, G, Ng, groups_per_stat, relu=True, into=None):
     """The same on point-major rows: g, y (G*Ng, ld) views whose first C columns are used."""
     dev = y.device
     T = int(_lib.load().pf_rows_bn_blocks(int(G), int(Ng)))
@@ -127,16 +158,19 @@ def rows_bn_backward(g, y, rows, C, G, Ng, groups_per_stat, relu=True):
               algo_bytes=8.0 * G * Ng * C)
     S = G // groups_per_stat
     coef = torch.empty((2, S, C), dtype=_F32, device=dev)
-    dgamma = torch.empty((C,), dtype=_F32, device=dev)
-    dbeta = torch.empty((C,), dtype=_F32, device=dev)
+    if into is None:
+        dgamma = torch.empty((C,), dtype=_F32, device=dev)
+        dbeta = torch.empty((C,), dtype=_F32, device=dev)
+    else:
+        dgamma, dbeta = into
     _lib.call("pf_bn_bwd_coeffs_f32", _lib.ptr(partials), T, C, 0, C, float(groups_per_stat) * Ng, int(G),
-              int(groups_per_stat), _lib.ptr(rows), _lib.ptr(coef), _lib.ptr(dgamma), _lib.ptr(dbeta), 0, _lib.stream(),
-              algo_bytes=16.0 * G * T * C)
+              int(groups_per_stat), _lib.ptr(rows), _lib.ptr(coef), _lib.ptr(dgamma), _lib.ptr(dbeta),
+              0 if into is None else 1, _lib.stream(), algo_bytes=16.0 * G * T * C)
     dy = torch.empty((G * Ng, C), dtype=_F32, device=dev)
     _lib.call("pf_rows_bn_bwd_apply_f32", _lib.ptr(g), int(g.stride(0)), _lib.ptr(y), int(y.stride(0)), _lib.ptr(rows),
               _lib.ptr(coef), _lib.ptr(dy), C, int(C), int(G), int(Ng), int(groups_per_stat), int(bool(relu)),
               _lib.stream(), algo_bytes=12.0 * G * Ng * C)
-    return dy, dgamma, dbeta
+    return (dy, dgamma, dbeta) if into is None else (dy, None, None)
 
 
 def rows_affine(y, rows, C, G, Ng, groups_per_stat, relu=True):
@@ -146,7 +180,7 @@ def rows_affine(y, rows, C, G, Ng, groups_per_stat, relu=True):
     return z
 
 
-def conv_wgrad(gr, x, kernel, stride, pad, x_affine=None, x_samples_per_stat=1):
+def conv_wgrad(gr, x, kernel, stride, pad, x_affine=None, x_samples_per_stat=1, into=None):
     """dw (Cg, Cx, *kernel) = sum gr[n, cg, o] * act(x)[n, cx, o * stride + k - pad] (pf_conv_wgrad_f32).
     gr (N, Cg, *coarse grid), x (N, Cx, *fine grid), 2-D or 3-D; x_affine = (scale, shift) rows of x's pending
     BatchNorm + ReLU or None."""
@@ -163,18 +197,18 @@ def conv_wgrad(gr, x, kernel, stride, pad, x_affine=None, x_samples_per_stat=1):
     if nbytes < 0:
         raise RuntimeError("conv_wgrad: unsupported shape")
     work = torch.empty((max(nbytes, 4) // 4,), dtype=_F32, device=gr.device)
-    dw = torch.empty((Cg, Cx) + tuple(kernel), dtype=_F32, device=gr.device)
+    dw = torch.empty((Cg, Cx) + tuple(kernel), dtype=_F32, device=gr.device) if into is None else into   # into: dw +=
     sc, sh = (None, None) if x_affine is None else x_affine
     taps = k3[0] * k3[1] * k3[2]
     _lib.call("pf_conv_wgrad_f32", _lib.ptr(gr), _lib.ptr(x), _lib.ptr(dw), N, Cg, Cx, go[0], go[1], go[2], xi[0], xi[1],
               xi[2], k3[0], k3[1], k3[2], int(stride), p3[0], p3[1], p3[2], _lib.ptr(sc), _lib.ptr(sh),
-              int(x_samples_per_stat), _lib.ptr(work), nbytes, 0, _lib.stream(),
+              int(x_samples_per_stat), _lib.ptr(work), nbytes, 0 if into is None else 1, _lib.stream(),
               algo_bytes=4.0 * (gr.numel() + x.numel()) + 4.0 * dw.numel(),
               flops=2.0 * N * go[0] * go[1] * go[2] * taps * Cg * Cx)
-    return dw
+    return dw if into is None else None
 
 
-def rows_wgrad(gr, x, Cg, Cx, x_affine=None, x_rows_per_stat=None):
+def rows_wgrad(gr, x, Cg, Cx, x_affine=None, x_rows_per_stat=None, into=None):
     """dw (Cg, Cx) = sum_p gr[p, :Cg]^T act(x[p, :Cx]) on point-major row views (pf_rows_wgrad_f32)."""
     P = gr.shape[0]
     lib = _lib.load()
@@ -182,12 +216,13 @@ def rows_wgrad(gr, x, Cg, Cx, x_affine=None, x_rows_per_stat=None):
     if nbytes < 0:
         raise RuntimeError("rows_wgrad: unsupported shape")
     work = torch.empty((max(nbytes, 4) // 4,), dtype=_F32, device=gr.device)
-    dw = torch.empty((Cg, Cx), dtype=_F32, device=gr.device)
+    dw = torch.empty((Cg, Cx), dtype=_F32, device=gr.device) if into is None else into
     sc, sh = (None, None) if x_affine is None else x_affine
     _lib.call("pf_rows_wgrad_f32", _lib.ptr(gr), int(gr.stride(0)), _lib.ptr(x), int(x.stride(0)), _lib.ptr(dw), P,
-              int(Cg), int(Cx), _lib.ptr(sc), _lib.ptr(sh), int(x_rows_per_stat or P), _lib.ptr(work), nbytes, 0,
-              _lib.stream(), algo_bytes=4.0 * P * (Cg + Cx) + 4.0 * Cg * Cx, flops=2.0 * P * Cg * Cx)
-    return dw
+              int(Cg), int(Cx), _lib.ptr(sc), _lib.ptr(sh), int(x_rows_per_stat or P), _lib.ptr(work), nbytes,
+              0 if into is None else 1, _lib.stream(), algo_bytes=4.0 * P * (Cg + Cx) + 4.0 * Cg * Cx,
+              flops=2.0 * P * Cg * Cx)
+    return dw if into is None else None
 
 
 def gemm_rows(x, w, K, n_out, chunks=None):
@@ -399,12 +434,15 @@ class _TowerTrain(torch.autograd.Function):
                 if g is None:
                     continue
                 if bn is not None:
-                    dy, dgamma, dbeta = bn_backward(g, y, rows, 1, True)
+                    tg, tb = _grad_target(bn.weight), _grad_target(bn.bias)
+                    into = (tg, tb) if (tg is not None and tb is not None) else None
+                    dy, dgamma, dbeta = bn_backward(g, y, rows, 1, True, into=into)
                     gparams[slots[i] + 1], gparams[slots[i] + 2] = dgamma, dbeta
                 else:
                     dy = g.contiguous()
                 ks, st = int(conv.kernel_size[0]), int(conv.stride[0])
-                gparams[slots[i]] = conv_wgrad(dy, x, (ks, ks), st, (ks // 2, ks // 2), x_affine=pending)
+                gparams[slots[i]] = conv_wgrad(dy, x, (ks, ks), st, (ks // 2, ks // 2), x_affine=pending,
+                                               into=_grad_target(conv.weight))
                 g = conv2d_dgrad(dy, conv.weight, st) if i > 0 else None
         return (None, None, None) + tuple(gparams)
 
@@ -518,24 +556,27 @@ class _VolumeTrain(torch.autograd.Function):
 
         def bnb(name, g):
             _, y, rows = rec[name]
-            dy, dgamma, dbeta = bn_backward(g, y, rows, 1, True)
+            bn = getattr(vc, name).bn
+            tg, tb = _grad_target(bn.weight), _grad_target(bn.bias)
+            into = (tg, tb) if (tg is not None and tb is not None) else None
+            dy, dgamma, dbeta = bn_backward(g, y, rows, 1, True, into=into)
             grads[name + ".bn"] = (dgamma, dbeta)
             return dy
 
         def conv_back(name, g, stride):          # Conv3d block: returns dy
             dy = bnb(name, g)
-            grads[name] = conv_wgrad(dy, rec[name][0], K3, stride, P3)
+            grads[name] = conv_wgrad(dy, rec[name][0], K3, stride, P3, into=_grad_target(getattr(vc, name).conv.weight))
             return dy
 
         def deconv_back(name, g):                # Deconv3d block: weight gradient in (Cin, Cout, 3, 3, 3) order
             dy = bnb(name, g)
-            grads[name] = conv_wgrad(rec[name][0], dy, K3, 2, P3)
+            grads[name] = conv_wgrad(rec[name][0], dy, K3, 2, P3, into=_grad_target(getattr(vc, name).conv.weight))
             return dy
 
         with torch.cuda.device(gout.device):
             g = gout.contiguous()
             w62 = vc.conv6_2.weight
-            grads["conv6_2"] = conv_wgrad(g, rec["conv6_2"][0], K3, 1, P3)
+            grads["conv6_2"] = conv_wgrad(g, rec["conv6_2"][0], K3, 1, P3, into=_grad_target(w62))
             wf = _packed("c1_dg", w62)
             if wf is None:
                 wf = w62.detach().flip(2, 3, 4).reshape(w62.shape[1], 27).contiguous()
@@ -642,14 +683,24 @@ class _EdgeChainTrain(torch.autograd.Function):
                 grad_le, dgamma, dbeta = pointflow.edge_conv_backward(keep, idx, gy, C, k, 1, N, 1, m.concat)
                 wcat = None if _PACKS is not None else torch.cat(
                     [m.conv1.weight.detach().reshape(C, K), m.conv2.weight.detach().reshape(C, K)], dim=0)
-                dw = rows_wgrad(grad_le, X, 2 * C, K)
+                # conv1 / conv2 are adjacent parameters: in the flat gradient bucket their .grad views form one (2C, K) block
+                t1, t2 = _grad_target(m.conv1.weight), _grad_target(m.conv2.weight)
+                into = None
+                if t1 is not None and t2 is not None and t2.data_ptr() == t1.data_ptr() + 4 * C * K:
+                    into = torch.as_strided(t1, (2 * C, K), (K, 1))
+                dw = rows_wgrad(grad_le, X, 2 * C, K, into=into)
                 dX = gemm_rows(grad_le, wcat, 2 * C, K, _packed("rows", m.conv1.weight))   # (N, K)
                 if col == 0:
                     gx = dX
                 else:
                     g[:, col - K:col] += dX
-                gparams = [dw[:C].reshape(m.conv1.weight.shape), dw[C:].reshape(m.conv2.weight.shape), dgamma,
-                           dbeta] + gparams
+                tg, tb = _grad_target(m.bn.weight), _grad_target(m.bn.bias)
+                if tg is not None and tb is not None:
+                    tg.add_(dgamma)
+                    tb.add_(dbeta)
+                    dgamma = dbeta = None
+                gparams = [None if dw is None else dw[:C].reshape(m.conv1.weight.shape),
+                           None if dw is None else dw[C:].reshape(m.conv2.weight.shape), dgamma, dbeta] + gparams
         return (gx, None, None) + tuple(gparams)
 
 
@@ -714,11 +765,15 @@ class _MLPTrain(torch.autograd.Function):
         gparams = []
         with torch.cuda.device(g.device):
             for blk, (X, affine, Z, rows, K, cout) in reversed(list(zip(shared, saved))):
-                dZ, dgamma, dbeta = rows_bn_backward(g, Z, rows, cout, 1, N, 1, True)
-                dw = rows_wgrad(dZ, X, cout, K, x_affine=affine, x_rows_per_stat=N)
+                tg, tb = _grad_target(blk.bn.weight), _grad_target(blk.bn.bias)
+                into = (tg, tb) if (tg is not None and tb is not None) else None
+                dZ, dgamma, dbeta = rows_bn_backward(g, Z, rows, cout, 1, N, 1, True, into=into)
+                tw = _grad_target(blk.conv.weight)
+                dw = rows_wgrad(dZ, X, cout, K, x_affine=affine, x_rows_per_stat=N,
+                                into=None if tw is None else tw.view(cout, K))
                 g = gemm_rows(dZ, blk.conv.weight.detach().reshape(cout, K), cout, K,
                               _packed("rows", blk.conv.weight))                           # gradient w.r.t. act(X)
-                gparams = [dw.reshape(blk.conv.weight.shape), dgamma, dbeta] + gparams
+                gparams = [None if dw is None else dw.reshape(blk.conv.weight.shape), dgamma, dbeta] + gparams
         return (g, None) + tuple(gparams)
 
 

@@ -9,7 +9,7 @@ no (B,2C,N,k) tensor), the HIP FeatureFetcher forward/backward and stock ATen fo
 """
 import torch
 
-from . import distributed, pointflow
+from . import distributed, pointflow, train_ops
 from .model import PointMVSNetLoss
 
 
@@ -34,10 +34,11 @@ class TrainStep(object):
         Returns (total loss (detached), loss dict, preds)."""
         self.model.train()
         self.bucket.zero_()                                        # optimizer.zero_grad(), keeping the views
-        preds = self.model(batch, img_scales, inter_scales, isFlow=is_flow, isTest=False)
-        losses = self.loss_fn(preds, batch, is_flow)
-        total = sum(losses.values())
-        total.backward()
+        with train_ops.direct_grads():                             # the fused nodes add into the bucket themselves
+            preds = self.model(batch, img_scales, inter_scales, isFlow=is_flow, isTest=False)
+            losses = self.loss_fn(preds, batch, is_flow)
+            total = sum(losses.values())
+            total.backward()
         self.bucket.allreduce_sum(self.group)                      # SUM: the loss sums over the batch (networks.py:176-179)
         self.optimizer.step()
         return total.detach(), losses, preds
@@ -86,11 +87,12 @@ class GraphedTrainStep(object):
 
     def _forward_backward(self):
         self.t.bucket.zero_()
-        preds = self.t.model.run_autograd(self.plan, self.img, self.is_flow)
-        labels = {"gt_depth_img": self.gt, "cam_params_list": self.cams}
-        losses = self.t.loss_fn(preds, labels, self.is_flow)
-        total = sum(losses.values())
-        total.backward()
+        with train_ops.direct_grads():
+            preds = self.t.model.run_autograd(self.plan, self.img, self.is_flow)
+            labels = {"gt_depth_img": self.gt, "cam_params_list": self.cams}
+            losses = self.t.loss_fn(preds, labels, self.is_flow)
+            total = sum(losses.values())
+            total.backward()
         return total.detach(), {k: v.detach() for k, v in losses.items()}, {k: v.detach() for k, v in preds.items()}
 
     def __call__(self, batch):
