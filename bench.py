@@ -11,13 +11,21 @@ the inputs resident in HBM when it starts.  Multi-GPU = one process per GPU, sce
 (pointmvsnet_amd.distributed.shard_scenes), no data-path collective; timing is bracketed by a barrier and
 torch.cuda.synchronize() on both sides and the MAX over ranks is used; `value` is the whole-job rate.
 
+``--config cfg4`` times BASELINE configs[3] instead: one training step (forward in train mode, PointMVSNetLoss,
+backward, one SUM all-reduce of the flat gradient bucket, RMSprop) per GPU and step, every convolution / BatchNorm /
+warp of it on this package's own kernels (pointmvsnet_amd/train_ops.py).
+
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline     - the dominant hand-written kernel of the path: achieved = algorithmic bytes per launch /
-                 average launch duration measured with HIP events inside the timed region (two event
-                 records per launch of that one entry point; which entry point is dominant is decided in
-                 an instrumented calibration pass before the timed region);
-  cpu_baseline - the CPU oracle (oracle/pointflow_oracle.py, a port of the reference's op sequence) timed
-                 on this host's cores on a bounded sample of the same workload (rank 0, N=1 only);
+  roofline     - the dominant hand-written entry point of the path: achieved = algorithmic bytes (or flops) per
+                 launch / average launch duration, measured with HIP events (torch.cuda.Event on the stream the
+                 kernels are launched on) around every C-ABI call of an instrumented EAGER calibration pass BEFORE the
+                 timed region -- events cannot be recorded inside a replayed hipGraph, so the timed region itself
+                 (graph replays, several scene lanes in flight) carries no per-kernel clock; the rocprofv3 kernel
+                 trace of the timed execution mode is committed under profiles/ (tools/per_kernel_roofline.py turns it
+                 into per-template-instantiation FLOP/s and bytes/s);
+  cpu_baseline - the reference's own CPU path when its staged package is present (oracle/_ref, kind "reference"),
+                 else the CPU oracle (oracle/pointflow_oracle.py, kind "port"), timed on this host's cores on a
+                 bounded sample of the same workload (rank 0, N=1 only);
   kernels      - per-entry-point time split of the calibration pass (informational).
 """
 import argparse
@@ -115,6 +123,12 @@ def launch_command(n, argv):
             "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
 
 
+def host_threads_per_rank(n_ranks):
+    """Host threads a rank may use when ``n_ranks`` processes share this node: its share of the logical CPUs, at most 16
+    (the step's host code is a few small NumPy / LAPACK calls; more threads only contend)."""
+    return max(1, min(16, int(os.cpu_count() or 1) // max(1, int(n_ranks))))
+
+
 def maybe_relaunch(args):
     """``python bench.py --gpus N`` with N > 1 and no torchrun environment: become the launcher.  Under torchrun the
     flag must agree with WORLD_SIZE -- a silent mismatch would print a line for the wrong N."""
@@ -133,6 +147,9 @@ def maybe_relaunch(args):
     import subprocess
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")            # dmabuf IPC: RCCL needs it on this driver
+    # N ranks share the host: without a cap every rank starts one OpenMP / ATen thread per logical CPU (N x 128+ threads
+    # on the GPU node), which slows the ranks' host code (camera algebra, graph launches) by contention
+    env.setdefault("OMP_NUM_THREADS", str(host_threads_per_rank(args.gpus)))
     raise SystemExit(subprocess.call(launch_command(args.gpus, sys.argv[1:]), env=env))
 
 
@@ -153,10 +170,12 @@ def to_device(data, dev):
 
 
 def _reference_forward():
-    """The reference's own PointMVSNet.forward on CPU when its tree is present (build container), with the two
-    documented shims of tests/golden/make_golden.py; None on the GPU box (then the oracle -- an op-for-op port,
-    bit-identical to it on every golden -- is what is timed, and ``kind`` says "port")."""
-    if not os.path.isdir("/root/reference/pointmvsnet"):
+    """The reference's own PointMVSNet.forward on CPU (reference test.py:58-69,83-84) with the two documented shims of
+    tests/golden/make_golden.py: from its tree in the build container, from the byte-for-byte staged copy of its
+    hot-path modules on the GPU box (oracle/make_ref.py).  None when neither exists (then the oracle -- an op-for-op
+    port, bit-identical to it on every golden -- is what is timed, and ``kind`` says "port")."""
+    from oracle import make_ref
+    if make_ref.reference_root() is None:     # (/root/reference here; the staged oracle/_ref/pointmvsnet on the GPU box)
         return None
     try:
         sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
@@ -242,6 +261,8 @@ GATHER_PATH_MB = {"cfg1": 404.1, "cfg2": 1658.8, "cfg3": 25194.4, "cfg5": 38116.
 def main():
     args = parse_args()
     maybe_relaunch(args)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:               # one of N ranks (torchrun, or the driver's launch line)
+        torch.set_num_threads(int(os.environ.get("OMP_NUM_THREADS") or host_threads_per_rank(os.environ["WORLD_SIZE"])))
     if args.launch_check:
         rank, world, local = distributed.init_from_env()
         dev = torch.device("cuda", local) if torch.cuda.is_available() else torch.device("cpu")
@@ -250,7 +271,8 @@ def main():
         ranks = count_ranks(dev)
         if rank == 0:
             print(json.dumps({"launch_check": True, "n_gpus": world, "rccl_ranks": ranks,
-                              "backend": torch.distributed.get_backend() if world > 1 else None}))
+                              "backend": torch.distributed.get_backend() if world > 1 else None,
+                              "host_threads_per_rank": torch.get_num_threads()}))
         if world > 1:
             torch.distributed.barrier()
             torch.distributed.destroy_process_group()
@@ -306,7 +328,8 @@ def main():
         from pointmvsnet_amd.train_step import TrainStep
         # PF_MIOPEN_FIND=1: let the library time its convolution solvers (torch.backends.cudnn.benchmark) instead of
         # taking its immediate-mode pick, which for the 3-D weight gradients of VolumeConv is a naive reference kernel
-        if os.environ.get("PF_MIOPEN_FIND", "1") == "1":
+        # (round 4: no library convolution is left in the step -- the knob only matters with train_ops disabled)
+        if os.environ.get("PF_MIOPEN_FIND", "0") == "1":
             torch.backends.cudnn.benchmark = True
         trainer = TrainStep(net)
         graphed_train = None
@@ -348,15 +371,20 @@ def main():
     if args.concurrency is not None:
         pointflow.CONCURRENCY = int(args.concurrency)
     cal_level = 0 if (not training and not args.eager and args.lanes > 1) else pointflow.CONCURRENCY
+    def cal_step(i):
+        if training:                    # the C-ABI calls of a step happen in the EAGER step only (a replay makes none)
+            return trainer(scenes[i % n_unique], img_scales, inter_scales)[2]
+        return eager_step(i)
+
     with pointflow.concurrency(cal_level):
         for i in range(min(max(args.warmup, 1), 3)):
-            eager_step(i)
+            cal_step(i)
         torch.cuda.synchronize()
-        ncal = max(1, int(args.calibration_steps)) if not training else 2
+        ncal = max(1, int(args.calibration_steps)) if not training else 3
         cal = _lib.KernelTimer()
         _lib.set_timer(cal)
         for i in range(ncal):
-            eager_step(i)
+            cal_step(i)
         _lib.set_timer(None)
     split = cal.summary()
     dominant = max(split.items(), key=lambda kv: kv[1]["ms"])[0] if split else None
@@ -479,6 +507,30 @@ def main():
                 if bn:      # every stand-alone BatchNorm pass of the forward (the towers' materialised stage outputs too)
                     roof[tag]["batchnorm_pass_us_per_depth_map_all"] = sum(
                         split[k]["ms"] for k in bn if k in split) * 1e3 / ncal
+    if roof is not None and training:
+        # Row Z: the weight gradients (pf_conv_wgrad_f32 / pf_rows_wgrad_f32: f32 MFMA, fixed-order split sums) as a
+        # group, the BatchNorm backward passes, and the step's arithmetic as a whole against the f32 matrix peak
+        for tag, entries in (("weight_gradients", ("pf_conv_wgrad_f32", "pf_rows_wgrad_f32")),
+                             ("batchnorm_backward", ("pf_bn_bwd_reduce_f32", "pf_bn_bwd_coeffs_f32", "pf_bn_bwd_apply_f32",
+                                                     "pf_rows_bn_bwd_reduce_f32", "pf_rows_bn_bwd_apply_f32")),
+                             ("warp_backward", ("pf_warp_taps_flow_f32", "pf_warp_taps_frustum_f32", "pf_sort_pairs_by_key",
+                                                "pf_variance_grad_f32", "pf_warp_gather_f32",
+                                                "pf_resize_bilinear_backward_f32", "pf_flow_depth_grad_f32"))):
+            grp = [split[k] for k in entries if k in split]
+            if grp:
+                us = sum(v["ms"] for v in grp) * 1e3 / ncal
+                fl = sum(v["flops"] for v in grp) / ncal
+                by = sum(v["bytes"] for v in grp) / ncal
+                roof[tag] = {"kernel_us_per_step": us, "launches_per_step": sum(v["launches"] for v in grp) / float(ncal),
+                             "flops_per_step": fl, "algorithmic_bytes_per_step": by,
+                             "TFLOPs": fl / us / 1e6 if (us > 0 and fl > 0) else None,
+                             "frac_of_f32_mfma_peak": fl / us / 1e6 / MFMA_F32_PEAK_TF if (us > 0 and fl > 0) else None,
+                             "GBps": by / us / 1e3 if us > 0 else None}
+        step_flops = sum(v["flops"] for v in split.values()) / ncal
+        roof["whole_step"] = {"flops_per_step": step_flops, "ms_per_step": elapsed / args.steps * 1e3,
+                              "TFLOPs": step_flops / (elapsed / args.steps) / 1e12,
+                              "frac_of_f32_mfma_peak": step_flops / (elapsed / args.steps) / 1e12 / MFMA_F32_PEAK_TF,
+                              "entry_point_us_per_step_by_events": sum(v["ms"] for v in split.values()) * 1e3 / ncal}
     kernels = {}
     for k, v in sorted(split.items(), key=lambda kv: -kv[1]["ms"]):
         gbps = (v["bytes"] / (v["ms"] / 1e3) / 1e9) if v["ms"] > 0 else None

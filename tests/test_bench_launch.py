@@ -34,6 +34,17 @@ def test_gpus_flag_spawns_that_many_ranks_world2_gloo():
     assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["backend"] == "gloo"
 
 
+def test_eight_ranks_the_drivers_scaling_run_shape_gloo():
+    """`bench.py --gpus 8` as the driver's scaling run launches it: eight ranks rendezvous on 127.0.0.1, the all-reduce of
+    ones counts eight, and every rank's host thread pool is capped (8 x one-thread-per-CPU would oversubscribe the node)."""
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--launch-check"], env=_env(CUDA_VISIBLE_DEVICES="",
+                       HIP_VISIBLE_DEVICES=""), capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = _last_json(p.stdout)
+    assert out["n_gpus"] == 8 and out["rccl_ranks"] == 8 and out["backend"] == "gloo"
+    assert 1 <= out["host_threads_per_rank"] <= 16
+
+
 def test_gpus_flag_must_agree_with_the_torchrun_environment():
     p = subprocess.run([sys.executable, BENCH, "--gpus", "4", "--launch-check"], env=_env(WORLD_SIZE="2", RANK="0"),
                        capture_output=True, text=True, timeout=300)
