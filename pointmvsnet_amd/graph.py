@@ -70,11 +70,21 @@ class GraphedForward(object):
             pointflow.set_lane(lane_now)
         self._watched = [t for t in list(self.model.parameters()) + list(self.model.buffers())]
         self._addresses = [t.data_ptr() for t in self._watched]
+        self._modes = [m.training for m in self.model.modules()]      # train()/eval() picks other kernels: re-capture
+        self._replays = 0
 
     def _rebound(self):
-        """A parameter / buffer was re-bound to other storage since capture (the graph holds its old address)."""
-        now = list(self.model.parameters()) + list(self.model.buffers())
-        return len(now) != len(self._watched) or [t.data_ptr() for t in now] != self._addresses
+        """A parameter / buffer was re-bound to other storage since capture (the graph holds its old address).
+        ``param.data = ...`` / a swapped buffer keep the tensor OBJECT and move its storage, so the addresses of the
+        objects seen at capture are what is compared on every replay (one data_ptr() per tensor: ~0.03 ms for the
+        ~340 tensors; the module tree is walked again only every 64th replay -- a registered / removed module, or a
+        parameter replaced by ``setattr``, changes the objects)."""
+        self._replays += 1
+        if self._replays % 64 == 0:
+            now = list(self.model.parameters()) + list(self.model.buffers())
+            if len(now) != len(self._watched) or any(a is not b for a, b in zip(now, self._watched)):
+                return True
+        return any(t.data_ptr() != a for t, a in zip(self._watched, self._addresses))
 
     def __del__(self):
         try:
@@ -83,7 +93,8 @@ class GraphedForward(object):
             pass
 
     def __call__(self, data_batch):
-        if pointflow.pack_entries_stale(self._packs) or self._rebound():   # the graph holds old packs / addresses
+        if (pointflow.pack_entries_stale(self._packs) or self._rebound()   # the graph holds old packs / addresses
+                or self._modes != [m.training for m in self.model.modules()]):
             torch.cuda.synchronize()
             self._capture()
             self.recaptures += 1
@@ -196,10 +207,46 @@ class LanedForward(object):
         torch.cuda.synchronize()
         return rate
 
+    def _sync_replica(self, lane):
+        """Lane replicas own their BatchNorm buffers and ``training`` flags (replicate_for_lane): ``net.eval()`` /
+        ``net.train()`` on the master, or ``load_state_dict`` (which copies into the MASTER'S buffers only), would
+        otherwise never reach lanes >= 1.  The modes are compared on every submit (cheap); when they differ the replica
+        takes the master's modes AND buffers (its GraphedForward then re-captures itself: it watches the modes).
+        ``sync_buffers()`` copies the buffers on request after a ``load_state_dict``."""
+        master, rep = self.models[0], self.models[lane]
+        if lane == 0 or all(a.training == b.training for a, b in zip(master.modules(), rep.modules())):
+            return False
+        for a, b in zip(master.modules(), rep.modules()):
+            b.training = a.training
+        torch.cuda.synchronize()
+        self._copy_buffers(lane)
+        return True
+
+    def _copy_buffers(self, lane):
+        with torch.no_grad():
+            for a, b in zip(self.models[0].buffers(), self.models[lane].buffers()):
+                b.copy_(a)
+
+    def sync_buffers(self):
+        """Copy the master's buffers (BatchNorm running statistics) into every lane replica -- call after
+        ``load_state_dict`` on the model when eval-mode BatchNorm will read them."""
+        torch.cuda.synchronize()
+        for lane in range(1, self.lanes):
+            self._copy_buffers(lane)
+
     def submit(self, data_batch):
         lane = self._next
         self._next = (lane + 1) % self.lanes
-        with torch.cuda.stream(self.streams[lane]):
+        st = self.streams[lane]
+        # the batch was produced on the caller's stream (e.g. ``v.cuda(non_blocking=True)`` in a loader loop): the lane
+        # must not read it before that work is done, and the caching allocator must not recycle its memory while the
+        # lane still copies from it
+        st.wait_stream(torch.cuda.current_stream())
+        for v in data_batch.values():
+            if torch.is_tensor(v) and v.is_cuda:
+                v.record_stream(st)
+        self._sync_replica(lane)
+        with torch.cuda.stream(st):
             out = self.graphs[lane](data_batch)
         return lane, out
 

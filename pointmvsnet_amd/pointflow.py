@@ -42,7 +42,8 @@ def shared_mlp_forward(blocks, x):
     for blk in blocks:
         conv, bn = blk.conv, blk.bn
         if (type(conv) is not torch.nn.Conv1d or conv.kernel_size != (1,) or conv.stride != (1,) or conv.groups != 1
-                or conv.bias is not None or bn is None or not blk.relu or conv.out_channels > 128
+                or conv.bias is not None or bn is None or not blk.relu
+                or (conv.out_channels + 31) // 32 * 32 not in (32, 64, 128)       # pf_pointwise_gemm_f32's widths
                 or bn.momentum is None or not bn.affine):
             return None
     dev = x.device

@@ -271,6 +271,51 @@ def test_scene_lanes_give_the_single_lane_results_and_keep_their_own_buffers(dev
     assert total == 5 * (2 * len(scenes) + 1) + 5 * (laned.lanes - 1), total
 
 
+def test_scene_lanes_wait_for_the_callers_stream_and_follow_the_masters_mode(dev):
+    """(a) a batch produced on the caller's stream right before ``submit`` (a loader's
+    ``.cuda(non_blocking=True)``) is complete before the lane reads it -- the lane stream waits for the current stream
+    and the batch is recorded on it; (b) ``net.eval()`` on the master reaches the lane replicas (they own their
+    ``training`` flags and buffers): the replica is re-synchronised and its graph re-captured, so every lane gives the
+    eval-mode result of the master's running statistics."""
+    from pointmvsnet_amd.graph import LanedForward
+    data, img_scales, inter_scales = synthetic.make_config("tiny", seed=3)
+    net, eager = _model(dev), _model(dev)
+    pinned = {k: v.pin_memory() for k, v in data.items()}
+    with torch.no_grad():
+        want = eager(_to(data, dev), img_scales, inter_scales, isFlow=True, isTest=True)
+        laned = LanedForward(net, _to(synthetic.make_config("tiny", seed=0)[0], dev), img_scales, inter_scales, lanes=2,
+                             warmup=1)
+        side = torch.cuda.Stream(device=dev)
+        for _ in range(4):                                     # both lanes, twice
+            with torch.cuda.stream(side):
+                junk = torch.randn(1 << 22, device=dev)
+                for _ in range(20):                            # keep the producing stream busy before the copies
+                    junk = junk * 1.0001
+                batch = {k: v.to(dev, non_blocking=True) for k, v in pinned.items()}
+                batch["cam_params_list_host"] = data["cam_params_list"]
+                batch["mean_host"], batch["std_host"] = data["mean"], data["std"]
+                lane, out = laned.submit(batch)
+                del batch                                      # the allocator may recycle it only after the lane's copy
+            laned.streams[lane].synchronize()
+            assert torch.equal(out["flow2"], want["flow2"])
+        # (b) eval mode: running statistics are read now; all lanes must agree with the master's
+        eager.eval()
+        net.eval()
+        want_eval = eager(_to(data, dev), img_scales, inter_scales, isFlow=True, isTest=True)
+        eager_sd = {k: v.clone() for k, v in eager.state_dict().items()}
+        net.load_state_dict(eager_sd)
+        laned.sync_buffers()
+        outs = []
+        for _ in range(2):
+            lane, out = laned.submit(_to(data, dev))
+            laned.streams[lane].synchronize()
+            outs.append({k: out[k].clone() for k in ("coarse_depth_map", "flow2")})
+        assert all(not m.training for m in laned.models[1].modules())
+        for o in outs:
+            assert torch.allclose(o["coarse_depth_map"], want_eval["coarse_depth_map"], rtol=1e-5, atol=1e-3)
+        assert torch.equal(outs[0]["flow2"], outs[1]["flow2"])
+
+
 @pytest.mark.parametrize("cfg", ["cfg1", "cfg3"])
 def test_other_baseline_configs_run_and_hold_properties(dev, cfg):
     """BASELINE configs 1 (1 flow iteration) and 3 (1280x960, 5 views, 96 planes, 3 iterations incl. the
@@ -400,6 +445,26 @@ def test_train_step_runs_and_updates_through_the_bucket(dev):
     assert not torch.equal(net.flow_edge_conv[2].conv2.weight.detach(), before)
     l2, _, _ = step(batch, img_scales, inter_scales)
     assert torch.isfinite(l2) and float(l2) != float(l1)
+
+
+def test_train_step_gradient_is_bit_reproducible(dev):
+    """Round 4: no float atomics and no library split-K solver is left in the step -- every convolution / BatchNorm /
+    warp gradient is a fixed-order sum (train_ops.py) -- so two steps from the same state give the same 698 936
+    gradient bits (the reference's step is not reproducible: atomicAdd scatters in gather_knn_kernel.cu:50-89 and in
+    grid_sample's backward, cuDNN's atomics-based weight-gradient algorithms)."""
+    from pointmvsnet_amd.train_step import TrainStep
+    data, img_scales, inter_scales = synthetic.make_config("tiny", train_intrinsics=True)
+    batch = _to(data, dev)
+    batch["gt_depth_img"] = synthetic.make_gt_depth(data).to(dev)
+    grads, losses = [], []
+    for _ in range(2):
+        net = _model(dev)
+        step = TrainStep(net)
+        loss, _, _ = step(batch, img_scales, inter_scales)
+        grads.append(step.bucket.flat.detach().clone())
+        losses.append(float(loss))
+    assert losses[0] == losses[1]
+    assert torch.equal(grads[0], grads[1]) and float(grads[0].abs().sum()) > 0
 
 
 def test_graphed_train_step_matches_the_eager_step(dev):
