@@ -3,8 +3,9 @@ on the GPU's own inputs (north_star: "depth maps within 1e-4 relative").
 
 tests/test_gpu_model.py compares whole forwards with the reference's golden maps and has to bound the result by the
 reference's measured self-sensitivity, because an iteration is discontinuous in its prior depth (a nearly tied 16th
-neighbour flips under a 1-ulp change).  This file removes the envelope from the argument.  For BASELINE configs 2
-and 3 at full size, after ONE GPU forward, for every iteration i:
+neighbour flips under a 1-ulp change).  This file removes the envelope from the argument.  For BASELINE configs 2,
+3 and 5 at full size (test mode) and for config 4's per-GPU scene in TRAIN mode, after ONE GPU forward, for every
+iteration i:
 
   prior   = the GPU's own coarse_depth_map / flow_i        (copied to the host)
   pyramid = the GPU flow tower's own three levels           (copied to the host)
@@ -80,40 +81,44 @@ def _oracle_iteration(feature, xyz, cur, interval, sd, r, feed=None):
     return cur + flow.view(1, 1, h, w)
 
 
-@pytest.mark.parametrize("cfg,with_own_knn", [("cfg2", True), ("cfg3", False)])
-def test_teacher_forced_iterations_vs_oracle(dev, cfg, with_own_knn):
+@pytest.mark.parametrize("cfg,with_own_knn,is_test", [("cfg2", True, True), ("cfg3", False, True), ("cfg5", False, True),
+                                                       ("cfg4", False, False)])
+def test_teacher_forced_iterations_vs_oracle(dev, cfg, with_own_knn, is_test):
+    """cfg5: BASELINE configs[4]'s size (1600x1152, 7 views, 3 iterations, 16 sub-grids of 144 000 points at the last
+    one); cfg4: BASELINE configs[3]'s per-GPU scene in TRAIN mode (training intrinsics, every iteration ONE lattice:
+    102 400 points at flow-2) -- round 4 additions."""
     threads = torch.get_num_threads()
     torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))      # the oracle's small operators oversubscribe
     try:
-        _run(dev, cfg, with_own_knn)
+        _run(dev, cfg, with_own_knn, is_test)
     finally:
         torch.set_num_threads(threads)
 
 
-def _run(dev, cfg, with_own_knn):
-    data, img_scales, inter_scales = synthetic.make_config(cfg)
+def _run(dev, cfg, with_own_knn, is_test=True):
+    data, img_scales, inter_scales = synthetic.make_config(cfg, train_intrinsics=not is_test)
     net = PointMVSNet()
     synthetic.seed_weights(net, seed=0)
     sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
     net = net.to(dev).train()
     batch = _to(data, dev)
     with torch.no_grad():
-        preds = net(batch, img_scales, inter_scales, isFlow=True, isTest=True)
+        preds = net(batch, img_scales, inter_scales, isFlow=True, isTest=is_test)
         pyr_dev = net.run_flow_tower(batch["img_list"])                # the same bits the forward used
         pointflow.flush_counters()
     pyr = {n: pyr_dev[n].cpu() for n in ("conv1", "conv2", "conv3")}
     cams = data["cam_params_list"]
     ext, R, t, R_inv = O.split_cameras(cams)
-    cam = _Cameras(cams, True)
+    cam = _Cameras(cams, is_test)
     H, W = data["img_list"].shape[3:]
     prior_dev = preds["coarse_depth_map"]
     for it, (s, inter) in enumerate(zip(img_scales, inter_scales)):
         h, w = int(H * s), int(W * s)
-        r = 1 if s == 0.125 else int(s * 8)
+        r = 1 if (s == 0.125 or not is_test) else int(s * 8)
         hs, ws = h // r, w // r
         interval = inter * cams[:, 0, 1, 3, 1]
         Kf = cams[:, :, 1, :3, :3].clone()
-        Kf[:, :, :2, :3] *= s
+        Kf[:, :, :2, :3] *= s if is_test else 4 * s                   # reference model.py:159-163
         prior = prior_dev.cpu()
         got = preds["flow%d" % (it + 1)].cpu()
         with torch.no_grad():
@@ -141,7 +146,7 @@ def _run(dev, cfg, with_own_knn):
                 slack = sum(4.0 * np.sqrt(3.0 * d) * eps + 12.0 * eps * eps + 4.0 * 6e-8 * d for d in (d16, d17))
                 worst_gap = max(worst_gap, (d17 - d16) / max(slack, 1e-30))
                 assert d17 - d16 <= slack, ("neighbour sets differ without a near-tie", cfg, it, g, n, d16, d17, slack)
-        report("teacher_%s_it%d" % (cfg, it), rel_max_same_knn=float(rel_a.max()), rel_median=float(rel_a.median()),
+        report("teacher_%s%s_it%d" % (cfg, "" if is_test else "_train", it), rel_max_same_knn=float(rel_a.max()), rel_median=float(rel_a.median()),
                xyz_eps=eps, rows_differing=float(differ.sum()), rows=float(differ.numel()),
                worst_gap_over_slack=worst_gap)
         assert eps < XYZ_EPS_MAX
