@@ -396,7 +396,7 @@ def main():
             from pointmvsnet_amd.graph import GraphedForward
             # one captured graph per scene lane; the step's images are copied into the lane's static input (12 MB
             # device-to-device, inside the timed region; one graph per resident scene buffer instead measured slower,
-            # profiles/r02ae_graph_slots_ab.log)
+            # profiles/archive/r02/r02ae_graph_slots_ab.log)
             from pointmvsnet_amd.graph import LanedForward
             with torch.no_grad():
                 laned = LanedForward(net, scenes[0], img_scales, inter_scales, isFlow=True, isTest=True,

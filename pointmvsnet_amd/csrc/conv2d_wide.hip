@@ -9,7 +9,7 @@
 //     patch[pixel(m) + tap][8 kc + 4 h ..] with ONE ds_read_b128 and feeds element j to step (kc, j) -- a quarter
 //     of an LDS instruction per MFMA and, the patch geometry being compile-time, no address arithmetic at all
 //     (base register + immediate for every tap and chunk).  Round 1's 16x16x4 loop issued 1.25 ds_read_b32 and ~7 VALU
-//     per MFMA of half the size (SQ counters, profiles/r02r_sq_counters.md);
+//     per MFMA of half the size (SQ counters, profiles/archive/r02/r02r_sq_counters.md);
 //   * the weights are packed on the host in the matching order [kh][kw][kc][h][c_out][j], so a lane's B operand for
 //     four steps is one 16-byte piece; a wave reads it from global memory / L2 as two contiguous 512-byte runs, six
 //     pieces ahead (round 3; round 2 staged one kernel row of weights at a time through 80-100 KB of LDS);
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(256) void conv2d_wide16_kernel(const float* __restr
 
 // Blocks per sample of the 16-wide kernel: a block walks PF_W16_TPB tiles with a stride of the block count (neighbouring
 // blocks stay on neighbouring tiles).  Two tiles per block were best for ONE forward at a time (1 / 3 / 4 slower,
-// profiles/r02aj_small_ab.txt: too few blocks on the small maps); with four scene lanes in flight the chip is full
+// profiles/archive/r02/r02aj_small_ab.txt: too few blocks on the small maps); with four scene lanes in flight the chip is full
 // anyway and the ~190-instruction block prologue (vector instructions cost matrix time, profiles/r03j) is worth
 // amortising: 2 / 3 / 4 / 5 / 8 tiles per block = 1 065 / 1 078 / 1 083 depth maps/s on one box, 994 / - / 1 015 / 1 016 /
 // 1 015 on a slower one (profiles/r03l_block_policies_ab.log).

@@ -20,7 +20,7 @@
 //     idles on row padding; one 32-bit offset per element, computed once per tile, wave-uniform base);
 //     the sub-volume geometry is a compile-time function of (stride, TD), so every LDS address in the
 //     MFMA loop is one base register + an immediate (v3: 132 -> 42 us on the 64 -> 16 stride-2 layer,
-//     168 -> 131 us on 64 -> 8, profiles/r01g_microbench_conv3d.log);
+//     168 -> 131 us on 64 -> 8, profiles/archive/r01/r01g_microbench_conv3d.log);
 //   * v_mfma_f32_16x16x4_f32: lane l (row i = l&15, k = l>>4) reads A = xs[k][d*s+kd][h*s+kh][i*s+kw] and
 //     B = ws[tap][k][16t + i] from LDS (plane stride padded to 16 mod 32 banks: conflict-free); a B value
 //     is reused for the TD depth slices.  Exact float32: an fmaf chain over (channel group, tap, channel).
@@ -404,7 +404,7 @@ int launch(const float* x, const float* wp, float* y, const ConvGeom& g, int64_t
 template <int NT, int STRIDE, int TD>
 int launch_w(const float* x, const float* wp, float* y, const ConvGeom& g, int64_t N, double* partials,
              hipStream_t s) {
-  // measured (profiles/r01g_microbench_conv3d.log): the 64 -> 8 layer runs 151 us at TD 4 / 2 waves per
+  // measured (profiles/archive/r01/r01g_microbench_conv3d.log): the 64 -> 8 layer runs 151 us at TD 4 / 2 waves per
   // SIMD and 131 us at TD 2 / 4 waves per SIMD (124 VGPRs, no spills); the stride-2 tile is best left alone
   constexpr int kDefault = (NT == 1 && STRIDE == 1 && TD == 2) ? 4 : 2;
   return launch<NT, STRIDE, TD, kDefault>(x, wp, y, g, N, partials, s);

@@ -105,7 +105,7 @@ struct BottomCfg {
 // load of step s + PF issued when step s is consumed -- no barrier after the patch is staged.  (A first version
 // staged one (kd, kh) row of weights per barrier through LDS, double buffered: 18 us for conv3_1 on 6 x 8 x 10,
 // each of the 9 rows waiting ~1.8 us for 49 KB per block against 0.6 us of MFMA work,
-// profiles/r02ai_unet_bottom.txt.)
+// profiles/archive/r02/r02ai_unet_bottom.txt.)
 template <int STRIDE, int CIN, int AFFINE>
 __global__ __launch_bounds__(256) void conv3d_bottom_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                             float* __restrict__ y, BottomGeom g,

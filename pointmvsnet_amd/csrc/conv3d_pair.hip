@@ -4,7 +4,7 @@
 //
 // conv3d.hip maps N of v_mfma_f32_16x16x4_f32 to 16 output channels; with 8 of them half of every MFMA
 // multiplies zeros, and SQ counters show that kernel's matrix pipe 62 % busy -- it is MFMA-bound on wasted work
-// (profiles/r02r_sq_counters.md).  Here N = 8 channels x 2 ADJACENT OUTPUT ROWS (h = 2p + s, s in {0,1}):
+// (profiles/archive/r02/r02r_sq_counters.md).  Here N = 8 channels x 2 ADJACENT OUTPUT ROWS (h = 2p + s, s in {0,1}):
 //     out[c][2p+s][x] = sum_{kd, kh, kw, ci} in[ci][..][2p + s + kh - 1][x + kw - 1] W[c][ci][kd][kh][kw]
 // with kh' = s + kh in [0,3] both rows read the SAME four input rows 2p - 1 + kh', so one A operand
 // (16 x-positions x 4 channels at (kd, kh', kw)) feeds both; the weights are packed as

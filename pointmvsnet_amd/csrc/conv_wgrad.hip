@@ -2,7 +2,7 @@
 // cores -- ImageConv's 2-D convolutions (reference networks.py:84-124), VolumeConv's 3-D convolutions and transposed
 // convolutions (networks.py:127-167), and the 1x1 convolutions of EdgeConv / the flow MLP (networks.py:13-14,
 // model.py:40-43) -- replacing the library kernels ATen's convolution_backward reaches (reference train.py:80; the
-// MIOpen / CK weight-gradient solvers took 84 of the step's 117 ms, profiles/r02al_cfg4_last_steps_eager.md).
+// MIOpen / CK weight-gradient solvers took 84 of the step's 117 ms, profiles/archive/r02/r02al_cfg4_last_steps_eager.md).
 //
 // One formulation for all of them.  With a COARSE-grid tensor Gr (N, Cg, Do, Ho, Wo) and a FINE-grid tensor X
 // (N, Cx, Di, Hi, Wi):

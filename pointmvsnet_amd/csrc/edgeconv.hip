@@ -933,7 +933,7 @@ constexpr int kBnJobs = 32;   // (3.3 KB of kernel arguments)
 constexpr int kBnThreads = 256;
 // Channels per block: the kernel is a chain of dependent L2 round trips (rows -> LDS -> statistics), so the more
 // blocks share the rows of a job the fewer batches each thread walks through -- in principle; measured
-// (profiles/r02aj_small_ab.txt) 4 channels per block beat 2 and 1 (646 / 645 / 642 depth maps/s): the fixed
+// (profiles/archive/r02/r02aj_small_ab.txt) 4 channels per block beat 2 and 1 (646 / 645 / 642 depth maps/s): the fixed
 // launch + round-trip latency dominates, not the row batches.
 static int bn_channels_per_block() { return 4; }
 struct BnJobs {
@@ -1141,7 +1141,7 @@ extern "C" {
 
 // Blocks per group of the EdgeConv gather passes: one 64-point tile per block while that stays below ~4096
 // blocks in total (measured: 1 600 single-tile blocks on the 4 x 25 600-point lattice run the passes 10 % faster
-// than 1 024 blocks with 1-2 tiles each -- 552 -> 565 depth maps/s, profiles/r01p_stat_blocks_ab.log), beyond
+// than 1 024 blocks with 1-2 tiles each -- 552 -> 565 depth maps/s, profiles/archive/r01/r01p_stat_blocks_ab.log), beyond
 // that every block the same number of tiles.
 int pf_stat_blocks(int G, int Ng) {
   if (G <= 0 || Ng <= 0) return 0;

@@ -479,7 +479,7 @@ extern "C" int pf_knn_lattice_f32(const float* xyz, const int64_t* strides_host,
     return pf_launch_status();
   }
   PF_REQUIRE(idx_out != nullptr);          // the insertion-list kernels below always write the indices
-  // Measured (profiles/r01n_microbench_knn.log, window 5, k 16): the split scan wins while the lattice is too
+  // Measured (profiles/archive/r01/r01n_microbench_knn.log, window 5, k 16): the split scan wins while the lattice is too
   // small to fill the chip with one lane per point (25 600 points: 27 vs 35 us); on 102 400 points the plain
   // scan does the same work in a quarter of the waves without the merge (49 vs 82 us).
   if (knn <= 16 && k3 >= 64 && B * D * H * W < 65536) {

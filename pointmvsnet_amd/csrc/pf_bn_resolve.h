@@ -6,7 +6,7 @@
 // (pf_bn_finalize_jobs_f32) that is a 5-7 us latency-bound node per layer.  Folding it into the PRODUCER ("last
 // block done": ticket counters, write-through rows, a two-level reduction by whichever block finishes last) was built
 // and measured in round 2 -- correct, bit-reproducible and 3 % SLOWER than the separate launch (the chain of dependent
-// L2 round trips stays on the critical path, profiles/r02a_fused_bn_ab.log); it was removed in round 3.  On the
+// L2 round trips stays on the critical path, profiles/archive/r02/r02a_fused_bn_ab.log); it was removed in round 3.  On the
 // CONSUMER's side the same chain hides behind latency the consumer waits for anyway:
 #pragma once
 

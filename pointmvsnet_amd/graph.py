@@ -5,7 +5,7 @@ The eager forward of BASELINE config 2 is ~330 kernel launches; at ~5 ms of GPU 
 by construction, see ``ScenePlan`` -- once, then serves every scene of the same shape by
 (1) redoing the host camera algebra into the plan's pinned block + one async H2D copy (kept OUTSIDE the graph:
     as the graph's first node, with the host waiting for the previous replay before refilling the pinned block, it
-    measured 587 against 600 depth maps/s, profiles/r02ad_graph_input_ab.log),
+    measured 587 against 600 depth maps/s, profiles/archive/r02/r02ad_graph_input_ab.log),
 (2) copying the images into the static input buffer -- skipped when the caller's images already live there:
     ``adopt_input=True`` makes the example batch's own image tensor the static input (a data loader that fills a
     ring of input buffers keeps one GraphedForward per slot and never copies),
@@ -56,7 +56,7 @@ class GraphedForward(object):
     def _capture(self):
         # One graph for the whole forward; the stream forks inside run() become graph edges.  (Three graphs
         # -- coarse, flow tower on a side stream, flow iterations -- ordered by stream events were measured
-        # at 402 depth maps/s against 486: replays on different streams did not overlap, profiles/r01h_split_ab.log.)
+        # at 402 depth maps/s against 486: replays on different streams did not overlap, profiles/archive/r01/r01h_split_ab.log.)
         pointflow.pack_unpin(self._packs)
         self.graph = torch.cuda.CUDAGraph()
         lane_now = pointflow.current_lane()

@@ -385,7 +385,7 @@ class PointMVSNet(nn.Module):
         (warp, VolumeConv, soft-argmin -- mostly kernels far too small to fill 256 CUs), and is joined
         before the first PointFlow iteration; under hipGraph capture the fork/join becomes graph edges.
         The fork sits AFTER the coarse tower: two towers side by side only slow each other down (same
-        kernels, each fills the chip) -- 474 -> 486 depth maps/s, profiles/r01h_fork_ab.log."""
+        kernels, each fills the chip) -- 474 -> 486 depth maps/s, profiles/archive/r01/r01h_fork_ab.log."""
         dev = img_list.device
         main = torch.cuda.current_stream()
         pointflow.stamp("start")
@@ -406,7 +406,7 @@ class PointMVSNet(nn.Module):
             pyramids = self.run_flow_tower(img_list, raw=True)
             preds = self.run_coarse_stage(plan, feature_list)
             return self.run_flows(plan, pyramids, preds)
-        # (fork structure measured in round 2, profiles/r02p_fork_mode_ab.log: flow tower captured first / coarse stage
+        # (fork structure measured in round 2, profiles/archive/r02/r02p_fork_mode_ab.log: flow tower captured first / coarse stage
         # first / fork after the warp / both towers side by side from the first kernel: 598 / 594 / 596 / within 0.3 %)
         side = pointflow.side_stream(dev, 0)
         side.wait_stream(main)

@@ -155,7 +155,7 @@ def _deconv_fusable(block, x):
 
 
 def _conv3d_fusable(conv, x):
-    """Layers pf_conv3d_k3_f32 takes (measured policy, profiles/r01l_microbench_conv3d.log: 16->32 /2 on
+    """Layers pf_conv3d_k3_f32 takes (measured policy, profiles/archive/r01/r01l_microbench_conv3d.log: 16->32 /2 on
     24x32x40: 14.5 us vs 23.4 us for the library's im2col + GEMM, 32->32 on 12x16x20: 19.6 vs 36.5 us; the
     6x8x10 layers stay on the library)."""
     return (type(conv) is nn.Conv3d and conv.kernel_size == (3, 3, 3) and conv.padding == (1, 1, 1)
@@ -415,7 +415,7 @@ class VolumeConv(nn.Module):
             return f(self.conv6_2, pointflow.batch_norm_act2_(raw0, blk0.bn, p0, y6, blk6.bn, p6, B))
         up = f(blk6, (up, half))
         # (conv6_2 does not add on load: its kernel is bound by its tap loads and adding there doubles them --
-        # 63 us against 15 + 5, profiles/r01h_microbench_deconv3d.log; the add rides on conv0_1's BatchNorm pass)
+        # 63 us against 15 + 5, profiles/archive/r01/r01h_microbench_deconv3d.log; the add rides on conv0_1's BatchNorm pass)
         if isinstance(full, tuple):
             raw, partials = full
             summed = pointflow.batch_norm_act_(raw, blk0.bn, blk0.relu, B, partials=partials, addend=up.contiguous())

@@ -285,7 +285,7 @@ def bn_affine(bn, partials, col0, C, count, unbias_n, G, groups_per_stat, scale,
 # updated by batched finalize launches on a side stream (flush_lazy_stats / join at flush_counters).
 LAZY_BN = int(_os.environ.get("PF_LAZY_BN", "1"))
 # What a consumer block is asked to re-reduce: rows behind one statistic x channels (16 bytes each).  Measured
-# (profiles/r02aj_small_ab.txt): 4000 / 5120 / 16384 / 65536 -> 641 / 646 / 654 / 653 depth maps/s on config 2; the
+# (profiles/archive/r02/r02aj_small_ab.txt): 4000 / 5120 / 16384 / 65536 -> 641 / 646 / 654 / 653 depth maps/s on config 2; the
 # largest job there is the flow MLP at 25 600 points per group (200 rows x 64 channels = 205 KB per GEMM block).
 LAZY_MAX_ELEMS = int(_os.environ.get("PF_LAZY_MAX", "16384"))
 
@@ -349,7 +349,7 @@ def flush_lazy_stats(device=None):
     the last call: ONE batched finalize launch (<= 32 jobs each) on the current stream.  ``flush_counters`` calls
     it at the end of a forward -- the only place where it is off every consumer's critical path without a
     stream of its own (a further side stream made hipGraph serialise the coarse stage behind the flow tower:
-    profiles/r02ah_lazy_bn_side_stream_timeline.txt)."""
+    profiles/archive/r02/r02ah_lazy_bn_side_stream_timeline.txt)."""
     table = getattr(_pending, "lazy", {})
     for dev in list(table.keys()):
         if device is not None and str(device) != dev:
@@ -558,7 +558,7 @@ def conv2d_wide_supported(conv):
 
 
 def conv2d_wide_preferred(conv):
-    """Measured (profiles/r02ag_microbench_conv2d_wide.log, cfg2 shapes, 3 views; us): 16->32 5x5/2 25.1 (pf_conv2d_f32
+    """Measured (profiles/archive/r02/r02ag_microbench_conv2d_wide.log, cfg2 shapes, 3 views; us): 16->32 5x5/2 25.1 (pf_conv2d_f32
     31.0, library 34.7), 32->32 3x3 16.7 (22.8, 24.4), 32->64 5x5/2 21.0 (40.5, 31.9), 64->64 3x3 16.5 (38.0, 24.6) --
     62-76 TF of exact f32: every 32- and 64-channel tower layer runs on csrc/conv2d_wide.hip."""
     return conv2d_wide_supported(conv)
