@@ -32,6 +32,8 @@ WIDE_READERS = ("channel_stats_kernel", "channel_bn_apply_kernel", "channel_affi
 def summarize(db, out, depth_maps):
     con = sqlite3.connect(db)
     rows = con.execute("select name, count(*), sum(duration) / 1000.0 from kernels group by name").fetchall()
+    if not depth_maps:                                # one soft-argmin launch per forward
+        depth_maps = float(sum(c for n, c, _ in rows if "softargmin_prob_kernel" in n))
     json.dump({"depth_maps": depth_maps, "kernels": {n: {"calls": c, "total_us": t} for n, c, t in rows}},
               open(out, "w"), indent=0)
     print("wrote", out, len(rows), "kernels")
@@ -195,7 +197,8 @@ def main():
     a = sub.add_parser("summarize")
     a.add_argument("db")
     a.add_argument("out")
-    a.add_argument("--depth-maps", type=float, required=True)
+    a.add_argument("--depth-maps", type=float, default=0.0,
+                   help="forwards in the trace (default: the number of soft-argmin launches, one per forward)")
     b = sub.add_parser("report")
     b.add_argument("trace")
     b.add_argument("out")

@@ -20,7 +20,11 @@ ENTRY_KERNELS = {
     "pf_pointwise_gemm_f32": "pointwise_gemm_",
     "pf_edge_apply_f32": "edge_apply_kernel", "pf_edge_stats_f32": "edge_stats_kernel",
     "pf_flow_features_f32": "flow_features_", "pf_knn_lattice_f32": "knn_",
-    "pf_conv2d_wide_f32": "conv2d_wide", "pf_conv2d_wide_sets_f32": "conv2d_wide", "pf_conv3d_k3_pair_f32": "conv3d_k3_pair_kernel",
+    # single-chain forward (what a scene lane captures): the towers' first layer is ONE stacked 3 -> 8 + 8 convolution
+    # through pf_conv2d_wide_f32, the other ten layers go through pf_conv2d_wide_sets_f32 (round 4: the two entries no
+    # longer share one averaged figure; per template instantiation: the "instantiations" table below)
+    "pf_conv2d_wide_f32": "conv2d_wide16_kernel<3, 1, 3, 16", "pf_conv2d_wide_sets_f32": "conv2d_wide",
+    "pf_conv3d_k3_pair_f32": "conv3d_k3_pair_kernel",
     "pf_conv3d_bottom_f32": "::conv3d_bottom_kernel", "pf_deconv3d_bottom_f32": "::deconv3d_bottom_kernel",
     "pf_fetch_variance_f32": "fetch_variance_kernel", "pf_frustum_variance_f32": "fetch_variance_kernel",
     "pf_frustum_variance_cl_f32": "frustum_variance_cl_kernel", "pf_nchw_to_nhwc_f32": "nchw_to_nhwc_kernel",
@@ -30,6 +34,7 @@ ENTRY_KERNELS = {
     "pf_resize_bilinear_f32": "resize_bilinear_kernel", "pf_softargmin_prob_f32": "softargmin_prob_kernel",
     "pf_flow_head_f32": "flow_head_kernel", "pf_channel_affine_f32": "channel_affine_kernel",
 }
+ENTRY_EXCLUDE = {"pf_conv2d_wide_sets_f32": "conv2d_wide16_kernel<3, 1, 3, 16"}
 WIDE_READERS = ("channel_stats_kernel", "channel_bn_apply_kernel", "channel_affine_kernel", "pointwise_gemm_",
                 "frustum_variance_cl_kernel")      # 16-byte-per-lane streaming reads (the guide's x2)
 
@@ -41,11 +46,16 @@ def main():
            "entries": {}}
     for entry, sub in ENTRY_KERNELS.items():
         f_sum = f_n = w_sum = w_n = 0.0
+        skip = ENTRY_EXCLUDE.get(entry)
         for name, ctrs in fetch.items():
+            if skip and skip in name:
+                continue
             if sub in name and "FETCH_SIZE" in ctrs:
                 f_sum += ctrs["FETCH_SIZE"]["sum"]
                 f_n += ctrs["FETCH_SIZE"]["dispatches"]
         for name, ctrs in write.items():
+            if skip and skip in name:
+                continue
             if sub in name and "WRITE_SIZE" in ctrs:
                 w_sum += ctrs["WRITE_SIZE"]["sum"]
                 w_n += ctrs["WRITE_SIZE"]["dispatches"]
@@ -57,6 +67,19 @@ def main():
         out["entries"][entry] = {"fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb,
                                  "bytes_per_launch": fb + wb, "fetch_correction": corr,
                                  "dispatches": int(max(f_n, w_n))}
+    # per template instantiation (the kernel name as rocprofv3 prints it, arguments stripped)
+    inst = {}
+    for name in sorted(set(fetch) & set(write)):
+        f, w = fetch[name].get("FETCH_SIZE"), write[name].get("WRITE_SIZE")
+        if not f or not w or "(anonymous namespace)" not in name:
+            continue
+        corr = 2.0 if any(s in name for s in WIDE_READERS) else 1.0
+        short = name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
+        fb = corr * f["sum"] * 1024.0 / max(f["dispatches"], 1)
+        wb = w["sum"] * 1024.0 / max(w["dispatches"], 1)
+        inst[short] = {"fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb, "bytes_per_launch": fb + wb,
+                       "fetch_correction": corr, "dispatches": int(max(f["dispatches"], w["dispatches"]))}
+    out["instantiations"] = inst
     json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
     print("wrote", sys.argv[3], len(out["entries"]), "entries")
 
