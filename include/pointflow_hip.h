@@ -399,7 +399,9 @@ int pf_deconv3d_bottom_f32(const float* x, const float* wp, float* y, int64_t N,
  * of y and y*y).  wp is the weight packed
  * (K, K, Cin/8, 2, Cout, 4): wp[kh][kw][kc][h][co][j] = w[co][8 kc + 4 h + j][kh][kw] for Cout 32 / 64, and
  * (K, K, 4, 16, Cin'/4), Cin' = Cin rounded up to 4: wp[kh][kw][kq][co][j] = w[co][(Cin'/4) kq + j][kh][kw] for
- * Cout 8 / 16 (zero where co >= Cout or the channel does not exist; shapes 3x3/1 3->8 and 8->8 as well).
+ * Cout 16 and the 3 -> 8 image layer (zero where co >= Cout or the channel does not exist), and for 8 -> 8 the PAIRED-ROWS
+ * form (K + 1, K, 4, 16, Cin'/4): wp[kh'][kw][kq][co + 8 s][j] = w[co][(Cin'/4) kq + j][kh' - s][kw], zero where kh' - s
+ * is outside [0, K): the 16 matrix columns are 8 channels x two adjacent output rows.
  * out_channel_last != 0 (Cout 32 / 64 only): y is written (N, Ho, Wo, Cout) -- the coarse tower's last layer
  * feeds pf_frustum_variance_cl_f32 directly, without the pf_nchw_to_nhwc_f32 pass.
  * PF_ERR_UNSUPPORTED for any other shape (pf_conv2d_wide_supported tells). */

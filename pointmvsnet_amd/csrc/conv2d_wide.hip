@@ -80,26 +80,62 @@ template <int CIN, int NPIX, int PW, int RS>   // (CIN % 4 != 0: the last quad i
 struct PatchStager {
   static constexpr int ITEMS = NPIX * ((CIN + 3) / 4);   // (pixel, channel quad) pairs of the patch
   static constexpr int NIT = (ITEMS + 255) / 256;
+  static constexpr int PH = NPIX / PW;
   static_assert(CIN % 4 == 0 || CIN < 4, "a padded quad: one quad only");
+  static_assert(PH < 256 && PW < 256, "patch coordinates are packed in bytes");
   float rx[NIT][4];
+  // Round 4 (profiles/r03i: ~9 vector instructions per load and ~25 per committed item of index arithmetic, bounds and
+  // padding selects cost the 8- and 16-channel layers as much time as their matrix instructions): everything about an
+  // item that does not depend on the tile -- its offset inside a tile's input window, its patch coordinates, its
+  // channel quad -- is computed ONCE per block (init); a tile then costs one add per load, and a tile whose window
+  // lies inside the map (all but the border tiles) takes no bounds test and no padding select at all.
+  int goff[NIT];          // 4 q * plane + pr * Wi + pc
+  int meta[NIT];          // pr | pc << 8 | q << 16
   unsigned okmask;
+  bool interior;
 
-  __device__ __forceinline__ void load(const float* __restrict__ xb, int plane_i, int ih0, int iw0, int Hi, int Wi) {
+  __device__ __forceinline__ void init(int plane_i, int Wi) {
     const int tid = threadIdx.x;
-    okmask = 0;
 #pragma unroll
     for (int r = 0; r < NIT; ++r) {
       const int it = tid + 256 * r;
       const int itc = it < ITEMS ? it : ITEMS - 1;
       const int q = itc / NPIX, p = itc - q * NPIX;     // lanes walk the patch's pixels: coalesced along a patch row
       const int pr = p / PW, pc = p - pr * PW;
+      goff[r] = 4 * q * plane_i + pr * Wi + pc;
+      meta[r] = pr | (pc << 8) | (q << 16);
+    }
+  }
+
+  // (the same call with init() folded in, for the kernels that stage one tile per block)
+  __device__ __forceinline__ void load(const float* __restrict__ xb, int plane_i, int ih0, int iw0, int Hi, int Wi) {
+    interior = ih0 >= 0 && iw0 >= 0 && ih0 + PH <= Hi && iw0 + PW <= Wi;        // block-uniform
+    const int origin = ih0 * Wi + iw0;
+    if (interior) {
+      okmask = ~0u;
+#pragma unroll
+      for (int r = 0; r < NIT; ++r) {
+        const float* src = xb + (goff[r] + origin);
+#pragma unroll
+#ifdef PF_DBG_NOLOAD
+        for (int j = 0; j < 4; ++j) rx[r][j] = (float)(threadIdx.x + j) + (float)(src - xb) * 1e-9f;
+#else
+        for (int j = 0; j < 4; ++j) rx[r][j] = (CIN % 4 == 0 || j < CIN) ? src[j * plane_i] : 0.0f;
+#endif
+      }
+      return;
+    }
+    okmask = 0;
+#pragma unroll
+    for (int r = 0; r < NIT; ++r) {
+      const int pr = meta[r] & 255, pc = (meta[r] >> 8) & 255, q = meta[r] >> 16;
       const int ih = ih0 + pr, iw = iw0 + pc;
       const bool ok = ih >= 0 && ih < Hi && iw >= 0 && iw < Wi;
       okmask |= (ok ? 1u : 0u) << r;
-      const float* src = xb + (int64_t)(4 * q) * plane_i + (ok ? ih * Wi + iw : 0);
+      const float* src = xb + (ok ? goff[r] + origin : 4 * q * plane_i);
 #pragma unroll
 #ifdef PF_DBG_NOLOAD
-      for (int j = 0; j < 4; ++j) rx[r][j] = (float)(tid + j) + (float)(src - xb) * 1e-9f;
+      for (int j = 0; j < 4; ++j) rx[r][j] = (float)(threadIdx.x + j) + (float)(src - xb) * 1e-9f;
 #else
       for (int j = 0; j < 4; ++j) rx[r][j] = (CIN % 4 == 0 || j < CIN) ? src[j * plane_i] : 0.0f;
 #endif
@@ -112,8 +148,7 @@ struct PatchStager {
 #pragma unroll
     for (int r = 0; r < NIT; ++r) {
       const int it = tid + 256 * r;
-      const int itc = it < ITEMS ? it : ITEMS - 1;
-      const int q = itc / NPIX, p = itc - q * NPIX;
+      const int pr = meta[r] & 255, pc = (meta[r] >> 8) & 255, q = meta[r] >> 16;
       f32x4 v = {rx[r][0], rx[r][1], rx[r][2], rx[r][3]};
       if (AFF) {
         const f32x4 a = *reinterpret_cast<const f32x4*>(aff + 4 * q);
@@ -121,8 +156,8 @@ struct PatchStager {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(v[j], a[j], b[j]), 0.0f);
       }
-      if (!((okmask >> r) & 1u)) v = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};       // zero padding applies AFTER it
-      if (256 * (r + 1) <= ITEMS || it < ITEMS) *reinterpret_cast<f32x4*>(patch + p * RS + 4 * q) = v;
+      if (!interior && !((okmask >> r) & 1u)) v = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};   // zero padding applies AFTER it
+      if (256 * (r + 1) <= ITEMS || it < ITEMS) *reinterpret_cast<f32x4*>(patch + (pr * PW + pc) * RS + 4 * q) = v;
     }
   }
 };
@@ -152,6 +187,7 @@ __device__ __forceinline__ void wide_stage_patch(const float* __restrict__ xb, i
                                                  const float* __restrict__ in_shift, int stat, const pf_bn_job& in_bn,
                                                  double* scratch) {
   PatchStager<CIN, NPIX, PW, RS> st;
+  st.init(plane_i, Wi);
   st.load(xb, plane_i, ih0, iw0, Hi, Wi);
   wide_affine_prologue<CIN, AFFINE>(aff, in_scale, in_shift, stat, in_bn, scratch);
   st.template commit<(AFFINE != 0)>(patch, aff);
@@ -364,11 +400,19 @@ struct Wide16Cfg {
   static constexpr int RS = CINP + 4;
   static constexpr int PATCH = NPIX * RS;
   static constexpr int CPL = CINP / 4;                 // channels per lane and tap (4: b128 read, 2: b64, 1: b32)
-  static constexpr int WALL = KS * KS * CINP * NCOL;   // packed weights [tap][kq][column][CPL]
+  // C_out = 8 (round 4; the trick of conv3d_pair.hip): the 16 MFMA columns are 8 channels x TWO adjacent output rows
+  // -- column co + 8 s is output row 2 rp + s -- which read the same KS + 1 patch rows: KS + 1 row taps instead of KS
+  // for two rows at once, 1.5x fewer matrix instructions than half-empty tiles (3x3: 24 instead of 36 per row pair)
+  // (the 3 -> 8 image layer keeps the plain tile: its statistics then sum exactly like the stacked 3 -> 8 + 8 launch of
+  // the towers' shared first layer, which the bit-equality test of the shared launches relies on)
+  static constexpr bool PAIR = COUT == 8 && CIN >= 8;
+  static constexpr int KH = PAIR ? KS + 1 : KS;        // row taps of the MFMA loop
+  static constexpr int WALL = KH * KS * CINP * NCOL;   // packed weights [row tap][kw][kq][column][CPL]
   static constexpr int WSPACE = WALL > 1024 ? WALL : 1024;   // (>= 4 KB: pf_bn_resolve's scratch before W lands)
   static constexpr size_t LDS = sizeof(float) * (size_t)(PATCH + WSPACE + 2 * CINP) + sizeof(double) * 4 * 16 * 2;
   static_assert(CIN == 3 || CIN == 8 || CIN == 16, "C_in is 3, 8 or 16");
   static_assert(COUT == 8 || COUT == 16, "C_out is 8 or 16");
+  static_assert(!PAIR || STRIDE == 1, "paired rows: stride 1");
   static_assert(PATCH % 4 == 0 && WALL % 4 == 0, "16-byte pieces");
   static_assert(LDS <= 80 * 1024, "two blocks per CU");
 };
@@ -411,6 +455,7 @@ __global__ __launch_bounds__(256) void conv2d_wide16_kernel(const float* __restr
   // matrix cores work on the current one: with one tile per block every block of the launch is resident at once and
   // they all load, then all multiply, then all store -- each phase leaving the other units idle.
   PatchStager<CIN, NPIX, PW, RS> st;
+  st.init(plane_i, g.Wi);
   int tile = blockIdx.x;
   auto tile_origin = [&](int t, int& oh0, int& ow0) {
     const int th = t / g.tiles_w;
@@ -430,9 +475,11 @@ __global__ __launch_bounds__(256) void conv2d_wide16_kernel(const float* __restr
     if (256 * (r + 1) <= W4 || e < W4) reinterpret_cast<f32x4*>(wl)[e] = rw[r];
   }
 
+  constexpr bool PAIR = C::PAIR;
+  constexpr int NR = PAIR ? 2 : 4;                     // M tiles of a wave: row pairs, or rows
   const float* abase = patch + ((4 * wave) * STRIDE * PW + li * STRIDE) * RS + CPL * kq;
   const float* bbase = wl + (kq * NCOL + li) * CPL;
-  constexpr int TAPS = KS * KS;
+  constexpr int TAPS = C::KH * KS;
   struct Op {
     float v[CPL];
   };
@@ -456,10 +503,15 @@ __global__ __launch_bounds__(256) void conv2d_wide16_kernel(const float* __restr
   auto read_a = [&](int t, Op* a) {
     const int kh = t / KS, kw = t - kh * KS;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) a[r] = read_op(abase + ((r * STRIDE + kh) * PW + kw) * RS);
+    for (int r = 0; r < NR; ++r) a[r] = read_op(abase + (((PAIR ? 2 * r : r) * STRIDE + kh) * PW + kw) * RS);
   };
   const bool vec_ok = (g.Wo & 3) == 0;
-  const bool col_ok = li < COUT;
+  // the output channel and row of this lane's accumulator column: li, row r -- or, paired, li & 7 and row 2 r + (li >> 3)
+  const int my_co = PAIR ? (li & 7) : li;
+  const int my_row = PAIR ? (li >> 3) : 0;
+  const bool col_ok = my_co < COUT;
+  const int plane_o = g.Ho * g.Wo;                     // (C_out * plane_o < 2^31: C_out <= C_in * stride^2, checked on the host)
+  float* const yn = y + (int64_t)n * COUT * plane_o;
   double ds = 0.0, dq = 0.0;
 #pragma unroll 1
   for (; tile < tiles; tile += nb) {
@@ -472,17 +524,17 @@ __global__ __launch_bounds__(256) void conv2d_wide16_kernel(const float* __restr
       tile_origin(tile + nb, noh0, now0);
       st.load(xb, plane_i, noh0 * STRIDE - C::PAD, now0 * STRIDE - C::PAD, g.Hi, g.Wi);
     }
-    f32x4 acc[4];
+    f32x4 acc[NR];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-    Op a[4], b;
+    for (int r = 0; r < NR; ++r) acc[r] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    Op a[NR], b;
     read_a(0, a);
     b = read_op(bbase);
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) {
-      Op an[4], bn = b;
+      Op an[NR], bn = b;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) an[r] = a[r];
+      for (int r = 0; r < NR; ++r) an[r] = a[r];
       if (t + 1 < TAPS) {
         read_a(t + 1, an);
         bn = read_op(bbase + (t + 1) * 4 * NCOL * CPL);
@@ -492,35 +544,42 @@ __global__ __launch_bounds__(256) void conv2d_wide16_kernel(const float* __restr
       for (int j = 0; j < CPL; ++j)
 #pragma unroll
 #ifdef PF_DBG_NOMFMA
-        for (int r = 0; r < 4; ++r) acc[r][(j + t) & 3] += a[r].v[j] * b.v[j];
+        for (int r = 0; r < NR; ++r) acc[r][(j + t) & 3] += a[r].v[j] * b.v[j];
 #else
-        for (int r = 0; r < 4; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r].v[j], b.v[j], acc[r], 0, 0, 0);
+        for (int r = 0; r < NR; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r].v[j], b.v[j], acc[r], 0, 0, 0);
 #endif
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) a[r] = an[r];
+      for (int r = 0; r < NR; ++r) a[r] = an[r];
       b = bn;
     }
-    // epilogue: C/D layout column (channel) = lane & 15, rows (pixels of the output row) 4 kq + {0..3}
-    float* yb = y + ((int64_t)n * COUT + li) * ((int64_t)g.Ho * g.Wo);
+    // epilogue: C/D layout column = lane & 15, rows (pixels of the output row) 4 kq + {0..3}
     float s = 0.0f, q = 0.0f;
     const int ow = ow0 + 4 * kq;
+    if (vec_ok && oh0 + C::TH <= g.Ho && ow0 + C::TW <= g.Wo) {
+      // a whole tile (block-uniform; every tile of the model's shapes): one base offset, no bounds, 16-byte stores
+      float* dst = yn + (my_co * plane_o + (oh0 + 4 * wave + my_row) * g.Wo + ow);
+      if (col_ok) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int oh = oh0 + 4 * wave + r;
-      if (oh < g.Ho && col_ok) {
-        float* dst = yb + (int64_t)oh * g.Wo + ow;
-        if (vec_ok && ow + 3 < g.Wo) {
+        for (int r = 0; r < NR; ++r) {
 #ifdef PF_DBG_NOSTORE
           if (acc[r][0] == 123.456f)
 #endif
-          *reinterpret_cast<f32x4*>(dst) = acc[r];
+          *reinterpret_cast<f32x4*>(dst + (PAIR ? 2 * r : r) * g.Wo) = acc[r];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             s += acc[r][e];
             q += acc[r][e] * acc[r][e];
           }
-        } else {
+        }
+      }
+    } else {
+      float* yb = yn + (int64_t)my_co * plane_o;
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const int oh = oh0 + 4 * wave + (PAIR ? 2 * r : r) + my_row;
+        if (oh < g.Ho && col_ok) {
+          float* dst = yb + (int64_t)oh * g.Wo + ow;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             if (ow + e < g.Wo) {
@@ -535,6 +594,10 @@ __global__ __launch_bounds__(256) void conv2d_wide16_kernel(const float* __restr
     ds += (double)s;
     dq += (double)q;
     __syncthreads();                                   // every wave is done with the patch: the next commit may land
+  }
+  if (PAIR && partials != nullptr) {                   // the two rows of a pair hold the same channel
+    ds += __shfl_xor(ds, 8);
+    dq += __shfl_xor(dq, 8);
   }
   if (partials != nullptr) {
     ds += __shfl_xor(ds, 16);

@@ -94,7 +94,9 @@ class GraphedForward(object):
 
     def __call__(self, data_batch):
         if (pointflow.pack_entries_stale(self._packs) or self._rebound()   # the graph holds old packs / addresses
-                or self._modes != [m.training for m in self.model.modules()]):
+                or self.model.training != self._modes[0]                   # net.train() / net.eval(): every replay
+                or (self._replays % 64 == 0                                # a sub-module's own flag: every 64th
+                    and self._modes != [m.training for m in self.model.modules()])):
             torch.cuda.synchronize()
             self._capture()
             self.recaptures += 1
@@ -211,10 +213,12 @@ class LanedForward(object):
         """Lane replicas own their BatchNorm buffers and ``training`` flags (replicate_for_lane): ``net.eval()`` /
         ``net.train()`` on the master, or ``load_state_dict`` (which copies into the MASTER'S buffers only), would
         otherwise never reach lanes >= 1.  The modes are compared on every submit (cheap); when they differ the replica
-        takes the master's modes AND buffers (its GraphedForward then re-captures itself: it watches the modes).
+        takes the master's modes AND buffers (its GraphedForward then re-captures itself: it watches the modes).  The
+        root module's flag is what is compared -- the host paces four lanes at ~1 000 scenes/s, a walk over the ~200
+        sub-modules per submit would cost a few per cent of that.
         ``sync_buffers()`` copies the buffers on request after a ``load_state_dict``."""
         master, rep = self.models[0], self.models[lane]
-        if lane == 0 or all(a.training == b.training for a, b in zip(master.modules(), rep.modules())):
+        if lane == 0 or master.training == rep.training:       # (net.train() / net.eval() set every sub-module)
             return False
         for a, b in zip(master.modules(), rep.modules()):
             b.training = a.training

@@ -566,6 +566,15 @@ def conv2d_wide_preferred(conv):
 
 def _pack_conv2d_wide(weight):
     cout, cin, k, _ = weight.shape
+    if cout == 8 and cin >= 8 and _os.environ.get("PF_WIDE_PAIR", "1") != "0":      # (0: tools' A/B against a round-3 library)
+        # paired rows (csrc/conv2d_wide.hip, Wide16Cfg::PAIR): column co + 8 s of the MFMA tile is channel co of output
+        # row 2 rp + s, which takes row tap kh' = kh + s of the K + 1 patch rows the pair reads
+        cinp = (cin + 3) // 4 * 4
+        full = torch.zeros((k + 1, k, cinp, 2, 8), dtype=_F32, device=weight.device)      # [kh'][kw][ci][s][co]
+        src = weight.detach().to(_F32).permute(2, 3, 1, 0)                                    # [kh][kw][ci][co]
+        for s_ in (0, 1):
+            full[s_:s_ + k, :, :cin, s_, :cout] = src
+        return full.view(k + 1, k, 4, cinp // 4, 16).permute(0, 1, 2, 4, 3).contiguous()
     if cout <= 16:
         cinp = (cin + 3) // 4 * 4
         full = torch.zeros((k, k, cinp, 16), dtype=_F32, device=weight.device)

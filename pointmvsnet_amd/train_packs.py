@@ -86,7 +86,16 @@ class TrainPacks(object):
         a_out, a_in = (1, 0) if dgrad else (0, 1)                      # which W axis holds its output / input channel
         kh = (K - 1, {0: -1}) if dgrad else (0, {0: 1})
         kw = (K - 1, {1: -1}) if dgrad else (0, {1: 1})
-        if cout <= 16:
+        if cout == 8 and cin >= 8:                     # paired rows: [kh'][kw][kq][s][co][j] = w[co][cq kq + j][kh' - s][kw]
+            cq = (cin + 3) // 4
+            dst = self._zeros(K + 1, K, 4, 16, cq)
+            coords = [None] * 4
+            coords[a_out] = (0, {4: 1})
+            coords[a_in] = (0, {2: cq, 5: 1})
+            coords[2] = (K - 1, {0: -1, 3: 1}) if dgrad else (0, {0: 1, 3: -1})
+            coords[3] = kw
+            self._add(key, W, dst, (K + 1, K, 4, 2, 8, cq), coords, view=dst.view(K + 1, K, 4, 2, 8, cq))
+        elif cout <= 16:
             cq = (cin + 3) // 4
             dst = self._zeros(K, K, 4, 16, cq)
             coords = [None] * 4
