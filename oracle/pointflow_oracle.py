@@ -66,7 +66,7 @@ def fetch_features(feature_maps, pts, cam_intrinsics, cam_extrinsics):
         if cam_extrinsics is not None:
             E = cam_extrinsics.reshape(B * V, 3, 4)
             p = torch.bmm(E[:, :, :3], p) + E[:, :, 3:4].expand(B * V, 3, N)
-        p = p.float().transpose(1, 2)
+        p = p.to(torch.get_default_dtype()).transpose(1, 2)      # the reference: .float(); float64 only when a test sets it
         x, y, z = p[..., 0], p[..., 1], p[..., 2]
         nuv = torch.stack([x / z, y / z, torch.ones_like(x)], dim=-1)
         uv = torch.bmm(nuv, K.transpose(1, 2))[:, :, :2]

@@ -20,7 +20,13 @@
 //     (channel, tap) pairs, reduction step = 4 consecutive positions along W;
 //   * per tile the block stages the Gr tile [cg][position] and the X patch [cx][(TD-1)s+KD][(TH-1)s+KH][15s+KW]
 //     (zero outside the tensor, optional pending BatchNorm + ReLU of x applied on the way) into LDS; a lane's B operand
-//     for column (cx, tap) is the patch read at a per-lane constant offset + the position, so no im2col exists anywhere;
+//     for column (cx, tap) is the patch read at a per-lane constant offset + the position, so no im2col exists anywhere.
+//     Staging moves 16-byte pieces (dword-aligned global_load_dwordx4 -> two ds_write_b64) through a per-block table of
+//     patch rows, and a tile whose patch lies inside the tensor takes a path without a single bounds test: the first
+//     version tested and addressed every float on its own and spent 10 VALU + 6 SALU instructions per MFMA on it
+//     (SQ counters, profiles/r04b_wgrad_sq_counters.md) -- the f32 matrix pipe shares its issue port with the VALU;
+//   * reduction step u of a position row covers positions lk + 4u (lk = lane >> 4): with planes = 2 (mod 32) floats
+//     the 32 lanes of a half-wave read 32 different LDS banks for A and for B (stride 1);
 //   * column tiles are dealt round-robin to the four waves; every wave reads the A operands (Gr) of a position row
 //     once and reuses them for all its column tiles;
 //   * at the end each block writes its partial dW to a workspace (split, Cg, Cx, taps); a second kernel adds the
@@ -33,6 +39,9 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+struct __attribute__((packed, aligned(4))) U4 {      // 16 bytes at dword alignment: one global_load_dwordx4
+  float v[4];
+};
 
 constexpr int kMaxNTW = 7;            // column tiles per wave (27 taps x 16 channels = 27 tiles over 4 waves)
 
@@ -43,6 +52,7 @@ struct WgGeom {
   int pd, ph, pw;
   int TD, TH, lgTH, lgR;              // tile rows R = TD * TH (a power of two)
   int ID, IH, IW, IWP, XPLANE, GPLANE;
+  int QX, lgGS;                       // 16-byte pieces per patch row; log2 of the lanes that share a row (8 or 16)
   int CBP, lgCBP, TPT, TPC, CBLK, NTILES;
   int tiles_d, tiles_h, tiles_w;
   int total_tiles, per_split;
@@ -57,7 +67,12 @@ struct WgGeom {
   int64_t P, ldg, ldx;
 };
 
-template <int MT, int STRIDE>
+// NTW: column tiles per wave = ceil(NTILES / 4).  Every wave runs NTW tiles -- one that does not exist reads column 0's
+// operands and is never stored -- so the MFMA loop has no branch and the accumulators stay in the matrix pipe's
+// registers: with a per-tile `if (tile exists)` the compiler moved 24 accumulator registers between the two register
+// files on every position row (~16 VALU instructions per MFMA, profiles/r04b_wgrad_sq_counters.md).  The block waits
+// for its fullest wave either way.
+template <int MT, int STRIDE, int NTW>
 __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ Gr, const float* __restrict__ X,
                                                     float* __restrict__ part, WgGeom g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -77,9 +92,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ Gr
   const int plane_o = g.Ho * g.Wo, vol_o = plane_o * g.Do;
 
   // per-lane B offsets of this wave's column tiles: column li of tile nt = (channel sub-block, tap group)
-  int boff[kMaxNTW];
+  int boff[NTW];
 #pragma unroll
-  for (int t = 0; t < kMaxNTW; ++t) {
+  for (int t = 0; t < NTW; ++t) {
     const int nt = wave + 4 * t;
     int off = 0;
     if (nt < g.NTILES) {
@@ -90,17 +105,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ Gr
       const int kd = tap / (g.KH * g.KW);
       const int r2 = tap - kd * (g.KH * g.KW);
       const int kh = r2 / g.KW, kw = r2 - kh * g.KW;
-      off = (sub * g.CBP + cil) * g.XPLANE + (kd * g.IH + kh) * g.IWP + kw + 4 * lk * STRIDE;
+      off = (sub * g.CBP + cil) * g.XPLANE + (kd * g.IH + kh) * g.IWP + kw + lk * STRIDE;
     }
     boff[t] = off;
   }
-  const int aoff = li * g.GPLANE + 4 * lk;
+  const int aoff = li * g.GPLANE + lk;
 
-  f32x4 acc[MT][kMaxNTW];
+  f32x4 acc[MT][NTW];
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int t = 0; t < kMaxNTW; ++t) acc[m][t] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    for (int t = 0; t < NTW; ++t) acc[m][t] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
 
   if (!g.point_major) {
     // row tasks of the X patch: (channel, dz, hy) -> one row of IW floats; the same for every tile of the block
@@ -122,7 +137,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ Gr
     __syncthreads();                    // the previous tile's MFMA reads (and the table) are done
     // Staging issues its global loads in batches (kU independent loads per lane in flight) and stores to LDS afterwards:
     // one load -> one store per iteration made the kernel latency-bound (conv0_1's gradient: 525 us for 22 us of MFMA).
-    constexpr int kU = 8, kUR = 4;
+    constexpr int kU = MT == 4 ? 4 : 8, kG = 4, kUR = 4;
     const int grows = min(MT * 16, g.Cg - cg0);          // rows / channels that exist: the rest of the LDS tiles is
     const int creal = min(cbtot, g.Cx - ci0);            // never stored from (their products are not written)
     if (g.point_major) {
@@ -190,73 +205,117 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ Gr
       const int n = rest / g.tiles_d;
       const int od0 = td * g.TD, oh0 = th * g.TH, ow0 = tw * 16;
       const int id0 = od0 * STRIDE - g.pd, ih0 = oh0 * STRIDE - g.ph, iw0 = ow0 * STRIDE - g.pw;
-      // Gr tile: 16-lane groups, one row of 16 positions along W per task
+      // Gr tile: 4 lanes per row of 16 positions along W, 16 bytes each
       {
-        const int grp = tid >> 4, l16 = tid & 15;
-        const float* gb = Gr + ((int64_t)n * g.Cg + cg0) * vol_o;
-        const int ow = ow0 + l16;
+        const int q4 = (tid & 3) * 4, rg = tid >> 2;
+        const float* gb = Gr + ((int64_t)n * g.Cg + cg0) * vol_o + (int64_t)od0 * plane_o + oh0 * g.Wo + ow0 + q4;
         const int gtasks = grows * R;
-        for (int t0 = grp; t0 < gtasks; t0 += 16 * kU) {
-          float v[kU];
+        const bool inside = od0 + g.TD <= g.Do && oh0 + g.TH <= g.Ho && ow0 + 16 <= g.Wo;
+        for (int t0 = rg; t0 < gtasks; t0 += 64 * kG) {
+          U4 v[kG];
 #pragma unroll
-          for (int u = 0; u < kU; ++u) {
-            const int task = t0 + 16 * u;
+          for (int u = 0; u < kG; ++u) {
+            const int task = t0 + 64 * u;
             const int cgl = task >> g.lgR, r = task & (R - 1);
             const int d = r >> g.lgTH, h = r & (g.TH - 1);
-            const int od = od0 + d, oh = oh0 + h;
-            const bool ok = task < gtasks && od < g.Do && oh < g.Ho && ow < g.Wo;
-            v[u] = ok ? gb[(int64_t)cgl * vol_o + od * plane_o + oh * g.Wo + ow] : 0.0f;
-          }
+            const float* src = gb + (int64_t)cgl * vol_o + d * plane_o + h * g.Wo;
+            v[u] = U4{{0.0f, 0.0f, 0.0f, 0.0f}};
+            if (task < gtasks) {
+              if (inside) {
+                v[u] = *reinterpret_cast<const U4*>(src);
+              } else if (od0 + d < g.Do && oh0 + h < g.Ho) {
 #pragma unroll
-          for (int u = 0; u < kU; ++u) {
-            const int task = t0 + 16 * u;
-            if (task < gtasks) gs[(task >> g.lgR) * g.GPLANE + (task & (R - 1)) * 16 + l16] = v[u];
-          }
-        }
-      }
-      // X patch: 32-lane groups, one patch row (<= 64 floats) per task
-      {
-        const int grp = tid >> 5, l32 = tid & 31;
-        const float* xb = X + ((int64_t)n * g.Cx + ci0) * vol_i;
-        const int origin = id0 * plane_i + ih0 * g.Wi + iw0;
-        const int stat = n / g.x_sps;
-        const int xtasks = creal * g.ID * g.IH;
-        const bool wide = g.IW > 32;
-        const int iwa = iw0 + l32, iwb = iw0 + l32 + 32;
-        const bool cola = l32 < g.IW && iwa >= 0 && iwa < g.Wi;
-        const bool colb = l32 + 32 < g.IW && iwb >= 0 && iwb < g.Wi;
-        for (int t0 = grp; t0 < xtasks; t0 += 8 * kU) {
-          float va[kU], vb[kU];
-          int dst[kU];
-#pragma unroll
-          for (int u = 0; u < kU; ++u) {
-            const int task = t0 + 8 * u;
-            va[u] = vb[u] = 0.0f;
-            dst[u] = -1;
-            if (task < xtasks) {
-              const int4 e = *reinterpret_cast<const int4*>(tab + task * 4);
-              const int c = e.w >> 16, hy = e.w & 0xffff;
-              const int id = id0 + e.z, ih = ih0 + hy;
-              const bool rowok = id >= 0 && id < g.Di && ih >= 0 && ih < g.Hi;
-              dst[u] = e.y;
-              if (rowok) {
-                const float* src = xb + e.x + origin + l32;
-                if (cola) va[u] = src[0];
-                if (wide && colb) vb[u] = src[32];
-                if (g.x_scale != nullptr) {
-                  const float sc = g.x_scale[(int64_t)stat * g.Cx + ci0 + c];
-                  const float sh = g.x_shift[(int64_t)stat * g.Cx + ci0 + c];
-                  if (cola) va[u] = fmaxf(fmaf(va[u], sc, sh), 0.0f);
-                  if (wide && colb) vb[u] = fmaxf(fmaf(vb[u], sc, sh), 0.0f);
-                }
+                for (int j = 0; j < 4; ++j)
+                  if (ow0 + q4 + j < g.Wo) v[u].v[j] = src[j];
               }
             }
           }
 #pragma unroll
-          for (int u = 0; u < kU; ++u) {
-            if (dst[u] >= 0) {
-              if (l32 < g.IW) xs[dst[u] + l32] = va[u];
-              if (wide && l32 + 32 < g.IW) xs[dst[u] + l32 + 32] = vb[u];
+          for (int u = 0; u < kG; ++u) {
+            const int task = t0 + 64 * u;
+            if (task < gtasks) {
+              float* dst = gs + (task >> g.lgR) * g.GPLANE + (task & (R - 1)) * 16 + q4;
+              *reinterpret_cast<float2*>(dst) = make_float2(v[u].v[0], v[u].v[1]);
+              *reinterpret_cast<float2*>(dst + 2) = make_float2(v[u].v[2], v[u].v[3]);
+            }
+          }
+        }
+      }
+      // X patch: 8 (16) lanes per patch row, 16 bytes each; rows come from the block's table
+      {
+        const int gsz = 1 << g.lgGS;
+        const int q = tid & (gsz - 1), rg = tid >> g.lgGS, rp = 256 >> g.lgGS;
+        const int q4 = q * 4;
+        const float* xb = X + ((int64_t)n * g.Cx + ci0) * vol_i + ((int64_t)id0 * plane_i + ih0 * g.Wi + iw0 + q4);
+        const int stat = n / g.x_sps;
+        const int xrows = creal * g.ID * g.IH;
+        const bool lane_on = q < g.QX;
+        const bool inside = id0 >= 0 && id0 + g.ID <= g.Di && ih0 >= 0 && ih0 + g.IH <= g.Hi && iw0 >= 0 &&
+                            iw0 + g.IWP <= g.Wi;
+        const bool affine = g.x_scale != nullptr;
+        const float* scp = affine ? g.x_scale + (int64_t)stat * g.Cx + ci0 : nullptr;
+        const float* shp = affine ? g.x_shift + (int64_t)stat * g.Cx + ci0 : nullptr;
+        if (inside && !affine) {
+          for (int t0 = rg; t0 < xrows; t0 += rp * kU) {
+            U4 v[kU];
+            int dst[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+              const int row = t0 + rp * u;
+              dst[u] = -1;
+              if (row < xrows && lane_on) {
+                const int2 e = *reinterpret_cast<const int2*>(tab + row * 4);
+                v[u] = *reinterpret_cast<const U4*>(xb + e.x);
+                dst[u] = e.y + q4;
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+              if (dst[u] >= 0) {
+                *reinterpret_cast<float2*>(xs + dst[u]) = make_float2(v[u].v[0], v[u].v[1]);
+                *reinterpret_cast<float2*>(xs + dst[u] + 2) = make_float2(v[u].v[2], v[u].v[3]);
+              }
+            }
+          }
+        } else {
+          for (int t0 = rg; t0 < xrows; t0 += rp * kU) {
+            U4 v[kU];
+            int dst[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+              const int row = t0 + rp * u;
+              dst[u] = -1;
+              v[u] = U4{{0.0f, 0.0f, 0.0f, 0.0f}};
+              if (row < xrows && lane_on) {
+                const int4 e = *reinterpret_cast<const int4*>(tab + row * 4);
+                const int c = e.w >> 16, hy = e.w & 0xffff;
+                const int id = id0 + e.z, ih = ih0 + hy, iw = iw0 + q4;
+                dst[u] = e.y + q4;
+                if (id >= 0 && id < g.Di && ih >= 0 && ih < g.Hi) {
+                  const float* src = xb + e.x;
+                  const bool whole = iw >= 0 && iw + 4 <= g.Wi;
+                  if (whole) {
+                    v[u] = *reinterpret_cast<const U4*>(src);
+                  } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                      if (iw + j >= 0 && iw + j < g.Wi) v[u].v[j] = src[j];
+                  }
+                  if (affine) {
+                    const float sc = scp[c], sh = shp[c];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                      if (whole || (iw + j >= 0 && iw + j < g.Wi)) v[u].v[j] = fmaxf(fmaf(v[u].v[j], sc, sh), 0.0f);
+                  }
+                }
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+              if (dst[u] >= 0) {
+                *reinterpret_cast<float2*>(xs + dst[u]) = make_float2(v[u].v[0], v[u].v[1]);
+                *reinterpret_cast<float2*>(xs + dst[u] + 2) = make_float2(v[u].v[2], v[u].v[3]);
+              }
             }
           }
         }
@@ -271,22 +330,20 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ Gr
       for (int m = 0; m < MT; ++m) {
         const float* ap = gs + m * 16 * g.GPLANE + aoff + r * 16;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) a[m][u] = ap[u];
+        for (int u = 0; u < 4; ++u) a[m][u] = ap[4 * u];
       }
       const int rowoff = ((d * STRIDE) * g.IH + h * STRIDE) * g.IWP;
 #pragma unroll
-      for (int t = 0; t < kMaxNTW; ++t) {
-        if (wave + 4 * t < g.NTILES) {                // wave-uniform
-          const float* bp = xs + boff[t] + rowoff;
-          float b[4];
+      for (int t = 0; t < NTW; ++t) {
+        const float* bp = xs + boff[t] + rowoff;
+        float b[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) b[u] = bp[u * STRIDE];
+        for (int u = 0; u < 4; ++u) b[u] = bp[4 * u * STRIDE];
 #pragma unroll
-          for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
-              acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][u], b[u], acc[m][t], 0, 0, 0);
-        }
+          for (int m = 0; m < MT; ++m)
+            acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][u], b[u], acc[m][t], 0, 0, 0);
       }
     }
   }
@@ -294,7 +351,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ Gr
   // partial dW of this block: C/D layout col = lane & 15 (column of the tile), row = (lane >> 4) * 4 + r (channel of Gr)
   float* pb = part + (int64_t)split * g.Cg * g.Cx * g.T;
 #pragma unroll
-  for (int t = 0; t < kMaxNTW; ++t) {
+  for (int t = 0; t < NTW; ++t) {
     const int nt = wave + 4 * t;
     if (nt >= g.NTILES) continue;
     const int sub = nt / g.TPC, tg = nt - sub * g.TPC;
@@ -349,6 +406,8 @@ int ilog2(int v) {
   return l;
 }
 
+constexpr int kCUs = 256;                          // MI355X (gfx950): 8 XCDs x 32 CUs
+constexpr size_t kLdsPerCU = 160 * 1024;
 constexpr size_t kLdsSoft = 64 * 1024;
 constexpr size_t kLdsHard = 96 * 1024;
 constexpr int64_t kWorkspaceCap = 32ll << 20;     // bytes of split partials a launch may use
@@ -359,6 +418,46 @@ struct WgPlan {
   size_t lds_bytes;
   bool ok;
 };
+
+template <int MT, int STRIDE>
+const void* kernel_ptr(int ntw) {
+  switch (ntw) {
+    case 1: return reinterpret_cast<const void*>(&wgrad_kernel<MT, STRIDE, 1>);
+    case 2: return reinterpret_cast<const void*>(&wgrad_kernel<MT, STRIDE, 2>);
+    case 3: return reinterpret_cast<const void*>(&wgrad_kernel<MT, STRIDE, 3>);
+    case 4: return reinterpret_cast<const void*>(&wgrad_kernel<MT, STRIDE, 4>);
+    case 5: return reinterpret_cast<const void*>(&wgrad_kernel<MT, STRIDE, 5>);
+    case 6: return reinterpret_cast<const void*>(&wgrad_kernel<MT, STRIDE, 6>);
+    case 7: return reinterpret_cast<const void*>(&wgrad_kernel<MT, STRIDE, 7>);
+    default: return nullptr;
+  }
+}
+
+// Blocks of this instantiation one CU holds at `lds_bytes` of dynamic LDS: asked from the runtime once per
+// (instantiation, LDS KB), with the register / LDS arithmetic of gfx950 as the fallback (no device, e.g. a build host).
+int resident_blocks(int MT, int stride, int ntw, size_t lds_bytes) {
+  const int kb = (int)((lds_bytes + 1023) / 1024);
+  const int mi = MT == 1 ? 0 : (MT == 2 ? 1 : 2);
+  static std::atomic<int> cache[3][2][8][161];                   // 0 = not asked yet
+  if (ntw < 1 || ntw > 7 || kb > 160) return 1;
+  std::atomic<int>& slot = cache[mi][stride - 1][ntw][kb];
+  int occ = slot.load(std::memory_order_relaxed);
+  if (occ > 0) return occ;
+  const void* fn = stride == 1 ? (MT == 1 ? kernel_ptr<1, 1>(ntw) : (MT == 2 ? kernel_ptr<2, 1>(ntw) : kernel_ptr<4, 1>(ntw)))
+                               : (MT == 1 ? kernel_ptr<1, 2>(ntw) : (MT == 2 ? kernel_ptr<2, 2>(ntw) : kernel_ptr<4, 2>(ntw)));
+  int n = 0;
+  if (fn == nullptr || hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 256, lds_bytes) != hipSuccess || n < 1) {
+    (void)hipGetLastError();
+    const int regs = 116 + (9 * MT * ntw) / 2;                   // VGPRs of the instantiations, within 10 %
+    n = 512 / ((regs + 7) & ~7);
+    const int by_lds = (int)(kLdsPerCU / ((size_t)kb * 1024));
+    if (n > by_lds) n = by_lds;
+    if (n < 1) n = 1;
+  }
+  if (n > 8) n = 8;
+  slot.store(n, std::memory_order_relaxed);
+  return n;
+}
 
 WgPlan make_plan(int64_t N, int64_t Cg, int64_t Cx, int64_t Do, int64_t Ho, int64_t Wo, int64_t Di, int64_t Hi,
                  int64_t Wi, int KD, int KH, int KW, int stride, int pd, int ph, int pw, bool rows, int64_t P) {
@@ -404,10 +503,12 @@ WgPlan make_plan(int64_t N, int64_t Cg, int64_t Cx, int64_t Do, int64_t Ho, int6
     g.ID = (g.TD - 1) * stride + KD;
     g.IH = (g.TH - 1) * stride + KH;
     g.IW = 15 * stride + KW;
-    g.IWP = g.IW;
+    g.IWP = rows ? g.IW : (g.IW + 3) & ~3;                     // planar: rows staged in 16-byte pieces
+    g.QX = g.IWP / 4;
+    g.lgGS = g.QX <= 8 ? 3 : 4;
     int xraw = g.ID * g.IH * g.IWP;
-    g.XPLANE = xraw | 1;                                       // odd: the 16 channels of a column tile on 16 banks
-    g.GPLANE = (g.TD * g.TH * 16) | 1;
+    g.XPLANE = ((xraw + 29) / 32) * 32 + 2;                    // = 2 (mod 32): lanes (channel li, step lk) of a half-wave
+    g.GPLANE = g.TD * g.TH * 16 + 2;                           // read 2 li + lk = 32 different banks
     int cblk = kMaxNTW * 4 / g.TPC;
     if (cblk < 1) cblk = 1;                                    // (more than 28 tap groups: PF_ERR_UNSUPPORTED below)
     if (cblk > cx_pad) cblk = cx_pad;
@@ -444,7 +545,10 @@ WgPlan make_plan(int64_t N, int64_t Cg, int64_t Cx, int64_t Do, int64_t Ho, int6
     g.total_tiles = g.N * g.tiles_d * g.tiles_h * g.tiles_w;
   }
   const int64_t elems = Cg * Cx * g.T;
-  int64_t splits = 1024 / ((int64_t)p.cblocks * p.mblocks);
+  // ONE round of resident blocks: every block walks the same number of tiles, so a second, partly filled round costs a
+  // whole block time (the first version asked for ~1024 blocks: 960 blocks on 768 slots ran 2 rounds for 1.25 of work)
+  const int occ = resident_blocks(p.MT, stride, (g.NTILES + 3) / 4, p.lds_bytes);
+  int64_t splits = (int64_t)kCUs * occ / ((int64_t)p.cblocks * p.mblocks);
   if (splits < 1) splits = 1;
   const int64_t cap = kWorkspaceCap / (4 * elems);
   if (splits > cap) splits = cap < 1 ? 1 : cap;
@@ -457,16 +561,30 @@ WgPlan make_plan(int64_t N, int64_t Cg, int64_t Cx, int64_t Do, int64_t Ho, int6
   return p;
 }
 
-template <int MT, int STRIDE>
+template <int MT, int STRIDE, int NTW>
 int launch_wgrad(const float* Gr, const float* X, float* part, const WgPlan& p, hipStream_t s) {
   if (p.lds_bytes > kLdsSoft) {
     static std::atomic<unsigned long long> done{0};
-    const int rc = pf_allow_big_lds(reinterpret_cast<const void*>(&wgrad_kernel<MT, STRIDE>), (int)kLdsHard, done);
+    const int rc = pf_allow_big_lds(reinterpret_cast<const void*>(&wgrad_kernel<MT, STRIDE, NTW>), (int)kLdsHard, done);
     if (rc != PF_OK) return rc;
   }
   dim3 grid((unsigned)p.splits, (unsigned)p.cblocks, (unsigned)p.mblocks);
-  hipLaunchKernelGGL((wgrad_kernel<MT, STRIDE>), grid, dim3(256), p.lds_bytes, s, Gr, X, part, p.g);
+  hipLaunchKernelGGL((wgrad_kernel<MT, STRIDE, NTW>), grid, dim3(256), p.lds_bytes, s, Gr, X, part, p.g);
   return pf_launch_status();
+}
+
+template <int MT, int STRIDE>
+int launch_wgrad_ntw(const float* Gr, const float* X, float* part, const WgPlan& p, hipStream_t s) {
+  switch ((p.g.NTILES + 3) / 4) {
+    case 1: return launch_wgrad<MT, STRIDE, 1>(Gr, X, part, p, s);
+    case 2: return launch_wgrad<MT, STRIDE, 2>(Gr, X, part, p, s);
+    case 3: return launch_wgrad<MT, STRIDE, 3>(Gr, X, part, p, s);
+    case 4: return launch_wgrad<MT, STRIDE, 4>(Gr, X, part, p, s);
+    case 5: return launch_wgrad<MT, STRIDE, 5>(Gr, X, part, p, s);
+    case 6: return launch_wgrad<MT, STRIDE, 6>(Gr, X, part, p, s);
+    case 7: return launch_wgrad<MT, STRIDE, 7>(Gr, X, part, p, s);
+    default: return PF_ERR_UNSUPPORTED;
+  }
 }
 
 int run_plan(const float* Gr, const float* X, float* dw, const WgPlan& p, int stride, void* workspace,
@@ -476,11 +594,11 @@ int run_plan(const float* Gr, const float* X, float* dw, const WgPlan& p, int st
   float* part = reinterpret_cast<float*>(workspace);
   int rc;
   if (stride == 1) {
-    rc = p.MT == 1 ? launch_wgrad<1, 1>(Gr, X, part, p, s)
-                   : (p.MT == 2 ? launch_wgrad<2, 1>(Gr, X, part, p, s) : launch_wgrad<4, 1>(Gr, X, part, p, s));
+    rc = p.MT == 1 ? launch_wgrad_ntw<1, 1>(Gr, X, part, p, s)
+                   : (p.MT == 2 ? launch_wgrad_ntw<2, 1>(Gr, X, part, p, s) : launch_wgrad_ntw<4, 1>(Gr, X, part, p, s));
   } else {
-    rc = p.MT == 1 ? launch_wgrad<1, 2>(Gr, X, part, p, s)
-                   : (p.MT == 2 ? launch_wgrad<2, 2>(Gr, X, part, p, s) : launch_wgrad<4, 2>(Gr, X, part, p, s));
+    rc = p.MT == 1 ? launch_wgrad_ntw<1, 2>(Gr, X, part, p, s)
+                   : (p.MT == 2 ? launch_wgrad_ntw<2, 2>(Gr, X, part, p, s) : launch_wgrad_ntw<4, 2>(Gr, X, part, p, s));
   }
   if (rc != PF_OK) return rc;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)pf_cdiv(elems, 16)), dim3(256), 0, s, part, dw, elems,

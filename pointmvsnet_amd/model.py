@@ -40,6 +40,23 @@ _HYPOTHESES = (-2, -1, 0, 1, 2)
 # attribute the tests flip to compare the two, not a knob)
 FUSED_TRAIN = 1
 
+# 1: the training step runs the flow tower (forward AND, through autograd's stream bookkeeping, backward) on a second
+# stream beside the coarse stage -- the two are independent until the first PointFlow iteration (reference
+# model.py:71-150), and most of a training step's ~700 launches are too small to fill 256 CUs alone.  Inside a captured
+# step the fork / join become graph dependencies.  PF_TRAIN_FORK=0: one stream (the A/B arm).
+TRAIN_FORK = int(os.environ.get("PF_TRAIN_FORK", "1"))
+_FORK_STREAMS = {}
+
+
+def join_fork_streams():
+    """The current stream waits for everything the fork streams have been given.  Callers of ``backward()`` on a fused
+    training forward run it before they read gradients: autograd joins a side stream at the end of backward only
+    where an AccumulateGrad node ran on it, and with ``train_ops.direct_grads()`` the nodes add into the bucket
+    themselves, the weight gradients on streams of their own (train_ops._wgrad_side)."""
+    for stream in _FORK_STREAMS.values():
+        torch.cuda.current_stream(stream.device).wait_stream(stream)
+    train_ops.join_wgrad_streams()
+
 
 def _host_cams(data_batch):
     """Host copy of the camera block.  ``cam_params_list_host`` (optional) spares the D2H copy + sync; it must be
@@ -539,6 +556,16 @@ class PointMVSNet(nn.Module):
         with train_ops.use_packs(packs):
             return self._run_autograd(tplan, img_list, isFlow, True)
 
+    def _fork_stream(self, dev):
+        streams = _FORK_STREAMS
+        key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+        if key not in streams:
+            streams[key] = torch.cuda.Stream(device=dev)
+            quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+            if quiet is not None:
+                quiet(False)       # intended: a parameter's AccumulateGrad may run beside the stream it was created on
+        return streams[key]
+
     def _run_autograd(self, tplan, img_list, isFlow, fused):
         dev = img_list.device
         B, V, _, H, W = img_list.shape
@@ -547,6 +574,14 @@ class PointMVSNet(nn.Module):
         K_coarse = tplan.d("K_coarse")
         ext = tplan.d("ext")
 
+        names = ("conv1", "conv2", "conv3")
+        levels = side = None
+        if fused and isFlow and TRAIN_FORK and img_list.is_cuda:
+            main = torch.cuda.current_stream(dev)
+            side = self._fork_stream(dev)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                levels = train_ops.tower_train(self.flow_img_conv, img_list[0], names)
         if fused:
             feature_list = train_ops.tower_train(self.coarse_img_conv, img_list[0], ("conv3",))["conv3"].unsqueeze(0)
             coarse_maps = [feature_list[:, 0]]
@@ -587,9 +622,13 @@ class PointMVSNet(nn.Module):
         if not isFlow:
             return preds
 
-        names = ("conv1", "conv2", "conv3")
         if fused:
-            levels = train_ops.tower_train(self.flow_img_conv, img_list[0], names)
+            if levels is None:
+                levels = train_ops.tower_train(self.flow_img_conv, img_list[0], names)
+            else:
+                main.wait_stream(side)                                       # the join; backward mirrors it
+                for n in names:
+                    levels[n].record_stream(main)
             pyramids = {n: levels[n].unsqueeze(0) for n in names}
         else:
             per_view = [self.flow_img_conv(img_list[:, v]) for v in range(V)]

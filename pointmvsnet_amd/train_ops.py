@@ -24,6 +24,7 @@ from . import _lib
 from . import pointflow
 
 import contextlib
+import os
 
 _F32 = torch.float32
 
@@ -77,11 +78,77 @@ def _grad_target(p):
     return g
 
 
+# Weight gradients have no consumer inside the step once they are added straight into the bucket, so they CAN leave the
+# dependency chain  dy -> data gradient -> BatchNorm backward -> dy'  for a second stream per compute stream
+# (PF_WGRAD_FORK=1: one fork per layer, =2: one fork per node, joined by join_wgrad_streams() after backward).
+# Measured same-box at BASELINE config 4 (profiles/r04c_train_streams.md): alone +5.5 % / +6.7 %, but beside the
+# flow-tower fork of model.TRAIN_FORK (+8.5 .. +11.8 %) they take throughput away again (-2 %): the weight-gradient
+# kernels fill the chip by themselves, and every fork adds cross-queue dependencies to the graph.  Default 0: in line.
+WGRAD_FORK = int(os.environ.get("PF_WGRAD_FORK", "0"))
+_WGRAD_STREAMS = {}
+
+
+_WGRAD_PENDING = []
+
+
+def _wgrad_stream(dev, cur):
+    key = (dev.index, cur.stream_id)
+    side = _WGRAD_STREAMS.get(key)
+    if side is None:
+        side = _WGRAD_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return side
+
+
+def _wgrad_issue(launch, into, *tensors):
+    """Run ``launch()`` (a weight-gradient launch that ADDS into ``into``) in line, on the wgrad stream now
+    (PF_WGRAD_FORK=1: one fork per layer), or at the end of the node's backward (=2: one fork per node)."""
+    if not (WGRAD_FORK and DIRECT_GRADS and into is not None and tensors[0].is_cuda):
+        return launch()
+    if WGRAD_FORK == 2:
+        _WGRAD_PENDING.append((launch, tensors))
+        return None
+    dev = tensors[0].device
+    cur = torch.cuda.current_stream(dev)
+    side = _wgrad_stream(dev, cur)
+    side.wait_stream(cur)
+    for t in tensors:
+        if t is not None:
+            t.record_stream(side)
+    with torch.cuda.stream(side):
+        return launch()
+
+
+def _wgrad_flush():
+    if not _WGRAD_PENDING:
+        return
+    pending = list(_WGRAD_PENDING)
+    del _WGRAD_PENDING[:]
+    dev = pending[0][1][0].device
+    cur = torch.cuda.current_stream(dev)
+    side = _wgrad_stream(dev, cur)
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        for launch, tensors in pending:
+            for t in tensors:
+                if t is not None:
+                    t.record_stream(side)
+            launch()
+
+
+def join_wgrad_streams():
+    """The current stream waits for every weight gradient launched beside it."""
+    for (index, _), side in _WGRAD_STREAMS.items():
+        torch.cuda.current_stream(index).wait_stream(side)
+
+
 def _with_packs(backward):
     """A node's backward runs under the packs its forward ran under (loss.backward() is called outside the context)."""
     def wrapped(ctx, *grads):
         with use_packs(getattr(ctx, "packs", None)):
-            return backward(ctx, *grads)
+            try:
+                return backward(ctx, *grads)
+            finally:
+                _wgrad_flush()
     return wrapped
 
 
@@ -196,16 +263,20 @@ def conv_wgrad(gr, x, kernel, stride, pad, x_affine=None, x_samples_per_stat=1, 
                                              int(stride)))
     if nbytes < 0:
         raise RuntimeError("conv_wgrad: unsupported shape")
-    work = torch.empty((max(nbytes, 4) // 4,), dtype=_F32, device=gr.device)
-    dw = torch.empty((Cg, Cx) + tuple(kernel), dtype=_F32, device=gr.device) if into is None else into   # into: dw +=
     sc, sh = (None, None) if x_affine is None else x_affine
     taps = k3[0] * k3[1] * k3[2]
-    _lib.call("pf_conv_wgrad_f32", _lib.ptr(gr), _lib.ptr(x), _lib.ptr(dw), N, Cg, Cx, go[0], go[1], go[2], xi[0], xi[1],
-              xi[2], k3[0], k3[1], k3[2], int(stride), p3[0], p3[1], p3[2], _lib.ptr(sc), _lib.ptr(sh),
-              int(x_samples_per_stat), _lib.ptr(work), nbytes, 0 if into is None else 1, _lib.stream(),
-              algo_bytes=4.0 * (gr.numel() + x.numel()) + 4.0 * dw.numel(),
-              flops=2.0 * N * go[0] * go[1] * go[2] * taps * Cg * Cx)
-    return dw if into is None else None
+
+    def launch():
+        work = torch.empty((max(nbytes, 4) // 4,), dtype=_F32, device=gr.device)
+        dw = torch.empty((Cg, Cx) + tuple(kernel), dtype=_F32, device=gr.device) if into is None else into   # into: dw +=
+        _lib.call("pf_conv_wgrad_f32", _lib.ptr(gr), _lib.ptr(x), _lib.ptr(dw), N, Cg, Cx, go[0], go[1], go[2], xi[0],
+                  xi[1], xi[2], k3[0], k3[1], k3[2], int(stride), p3[0], p3[1], p3[2], _lib.ptr(sc), _lib.ptr(sh),
+                  int(x_samples_per_stat), _lib.ptr(work), nbytes, 0 if into is None else 1, _lib.stream(),
+                  algo_bytes=4.0 * (gr.numel() + x.numel()) + 4.0 * dw.numel(),
+                  flops=2.0 * N * go[0] * go[1] * go[2] * taps * Cg * Cx)
+        return dw if into is None else None
+
+    return _wgrad_issue(launch, into, gr, x, sc, sh)
 
 
 def rows_wgrad(gr, x, Cg, Cx, x_affine=None, x_rows_per_stat=None, into=None):
@@ -215,14 +286,18 @@ def rows_wgrad(gr, x, Cg, Cx, x_affine=None, x_rows_per_stat=None, into=None):
     nbytes = int(lib.pf_rows_wgrad_workspace(P, int(Cg), int(Cx)))
     if nbytes < 0:
         raise RuntimeError("rows_wgrad: unsupported shape")
-    work = torch.empty((max(nbytes, 4) // 4,), dtype=_F32, device=gr.device)
-    dw = torch.empty((Cg, Cx), dtype=_F32, device=gr.device) if into is None else into
     sc, sh = (None, None) if x_affine is None else x_affine
-    _lib.call("pf_rows_wgrad_f32", _lib.ptr(gr), int(gr.stride(0)), _lib.ptr(x), int(x.stride(0)), _lib.ptr(dw), P,
-              int(Cg), int(Cx), _lib.ptr(sc), _lib.ptr(sh), int(x_rows_per_stat or P), _lib.ptr(work), nbytes,
-              0 if into is None else 1, _lib.stream(), algo_bytes=4.0 * P * (Cg + Cx) + 4.0 * Cg * Cx,
-              flops=2.0 * P * Cg * Cx)
-    return dw if into is None else None
+
+    def launch():
+        work = torch.empty((max(nbytes, 4) // 4,), dtype=_F32, device=gr.device)
+        dw = torch.empty((Cg, Cx), dtype=_F32, device=gr.device) if into is None else into
+        _lib.call("pf_rows_wgrad_f32", _lib.ptr(gr), int(gr.stride(0)), _lib.ptr(x), int(x.stride(0)), _lib.ptr(dw), P,
+                  int(Cg), int(Cx), _lib.ptr(sc), _lib.ptr(sh), int(x_rows_per_stat or P), _lib.ptr(work), nbytes,
+                  0 if into is None else 1, _lib.stream(), algo_bytes=4.0 * P * (Cg + Cx) + 4.0 * Cg * Cx,
+                  flops=2.0 * P * Cg * Cx)
+        return dw if into is None else None
+
+    return _wgrad_issue(launch, into, gr, x, sc, sh)
 
 
 def gemm_rows(x, w, K, n_out, chunks=None):

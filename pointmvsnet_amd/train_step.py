@@ -10,7 +10,7 @@ no (B,2C,N,k) tensor), the HIP FeatureFetcher forward/backward and stock ATen fo
 import torch
 
 from . import distributed, pointflow, train_ops
-from .model import PointMVSNetLoss
+from .model import PointMVSNetLoss, join_fork_streams
 
 
 def param_groups(module, weight_decay):
@@ -39,6 +39,7 @@ class TrainStep(object):
             losses = self.loss_fn(preds, batch, is_flow)
             total = sum(losses.values())
             total.backward()
+        join_fork_streams()                                        # the flow tower's backward ran beside the coarse stage's
         self.bucket.allreduce_sum(self.group)                      # SUM: the loss sums over the batch (networks.py:176-179)
         self.optimizer.step()
         return total.detach(), losses, preds
@@ -93,6 +94,7 @@ class GraphedTrainStep(object):
             losses = self.t.loss_fn(preds, labels, self.is_flow)
             total = sum(losses.values())
             total.backward()
+        join_fork_streams()
         return total.detach(), {k: v.detach() for k, v in losses.items()}, {k: v.detach() for k, v in preds.items()}
 
     def __call__(self, batch):

@@ -374,16 +374,25 @@ def test_batch_of_two_scenes_vs_oracle(dev):
 
 @pytest.mark.parametrize("fused", [1, 0])
 def test_train_step_parameter_gradients_vs_oracle_autograd(dev, monkeypatch, fused):
-    """BASELINE config 4's step on "tiny": forward (train mode) + PointMVSNetLoss + backward through the fused
-    EdgeConv node (fused=1; fused=0: the reference's composition on the HIP gather_knn), the HIP fetch backward
-    and ATen, against autograd of the CPU oracle (the reference's composition).  Neighbour choices are
-    discontinuous in the coarse depth (tests/test_sensitivity.py), so the oracle's own kNN indices are injected.
-    Tolerances: the loss to 1e-5; the whole 698 936-element gradient to 2e-3 in relative L2 and every tensor to
-    5e-3 of its largest entry.  Measured on MI355X (profiles/r02*_parity_report.jsonl): worst tensor 1.5e-3 / L2 2.9e-4 with
-    the fused node, 2.2e-3 / 5.6e-4 with the composed path -- that is ATen-on-GPU (MIOpen convolution backward, float
-    atomics in the scatters) against ATen-on-CPU through ~40 BatchNorm layers; the fused node is the CLOSER of the
-    two, two GPU runs differ from each other by 2e-4..6e-4, and per operator our backward kernels match the oracle
-    to 6e-7 (tests/test_gpu_ops.py::test_edgeconv_autograd_path_vs_oracle)."""
+    """BASELINE config 4's step on "tiny": forward (train mode) + PointMVSNetLoss + backward on our own kernels
+    (fused=1: the seven hand-written autograd nodes of train_ops.py; fused=0: the reference's composition on the HIP
+    gather_knn / fetch backward and ATen) against autograd of the CPU oracle (the reference's composition).
+    Neighbour choices are discontinuous in the coarse depth (tests/test_sensitivity.py), so the oracle's own kNN
+    indices are injected on both sides.
+
+    What "equal" can mean here is measured, not assumed: the oracle is run a second time in FLOAT64 on the same
+    weights, inputs and neighbours.  Its own float32 gradient differs from that float64 gradient by 2.7e-4 in
+    relative L2 (~40 BatchNorm layers amplify float32 rounding; worst tensor 1e-3) -- so two CORRECT float32
+    implementations differ from each other by ~sqrt(2)*2.7e-4 = 3.9e-4, which is what GPU-vs-oracle32 measures.
+    The gates (round 4):
+      * the loss to 1e-5 against both oracles;
+      * GPU vs the float64 gradient: relative L2 no worse than 1.5x the float32 ORACLE's own deviation from it
+        (i.e. our float32 step is as accurate as the reference's float32 step; measured 3.1e-4 against the
+        oracle's 3.9e-4 on the same box), every tensor within 3x the oracle's worst tensor (fused arm; the composed
+        arm: 2.5x, measured 5.3e-4);
+      * GPU vs the float32 oracle: relative L2 < 6e-4 (fused) / 1e-3 (composed), every tensor < 3e-3 of its largest
+        entry (round 3: 2e-3 / 5e-3).
+    Per operator our backward kernels match float64 autograd to 1e-7..9e-7 (tests/test_gpu_train_ops.py)."""
     import pointmvsnet_amd.model as M
     from pointmvsnet_amd import networks
     monkeypatch.setattr(networks, "FUSED_TRAIN", fused)
@@ -410,6 +419,22 @@ def test_train_step_parameter_gradients_vs_oracle_autograd(dev, monkeypatch, fus
     monkeypatch.setattr(O, "knn_lattice", orig_knn)
     assert len(recorded) == len(img_scales)
 
+    # the same function in float64 on the same neighbours: the yardstick for what float32 can deliver at all
+    feed64 = iter(recorded)
+    monkeypatch.setattr(O, "knn_lattice", lambda xyz, kernel_size=5, knn=16, return_code=False: next(feed64))
+    torch.set_default_dtype(torch.float64)
+    try:
+        sd64 = {k: (v.detach().double().requires_grad_(True) if k in names else
+                    (v.double() if v.is_floating_point() else v.clone())) for k, v in net.state_dict().items()}
+        data64 = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in data.items()}
+        ref64 = O.forward(sd64, data64, img_scales, inter_scales, True, False)
+        loss64 = sum(loss_fn(ref64, {"gt_depth_img": gt.double(), "cam_params_list": data64["cam_params_list"]},
+                             True).values())
+        loss64.backward()
+    finally:
+        torch.set_default_dtype(torch.float32)
+        monkeypatch.setattr(O, "knn_lattice", orig_knn)
+
     feed = iter(recorded)
     monkeypatch.setattr(M, "get_knn_3d", lambda xyz, kernel_size=5, knn=16: next(feed).to(xyz.device))
     net = net.to(dev).train()
@@ -419,25 +444,41 @@ def test_train_step_parameter_gradients_vs_oracle_autograd(dev, monkeypatch, fus
     loss = sum(loss_fn(preds, batch, True).values())
     loss.backward()
     rel_loss = abs(float(loss) - float(loss_ref)) / abs(float(loss_ref))
-    errs = []
-    num = den = 0.0
-    for name, p in net.named_parameters():
-        g_ref = sd[name].grad
-        assert p.grad is not None and g_ref is not None, name
-        diff = (p.grad.cpu() - g_ref)
-        errs.append((float(diff.abs().max()) / max(float(g_ref.abs().max()), 1e-12), name))
-        num += float((diff.double() ** 2).sum())
-        den += float((g_ref.double() ** 2).sum())
-    errs.sort(reverse=True)
-    l2 = (num / den) ** 0.5
+    rel_loss64 = abs(float(loss) - float(loss64)) / abs(float(loss64))
+
+    def deviation(get_a, get_b):
+        errs, num, den = [], 0.0, 0.0
+        for name in names:
+            a, b = get_a(name).double(), get_b(name).double()
+            diff = a - b
+            errs.append((float(diff.abs().max()) / max(float(b.abs().max()), 1e-12), name))
+            num += float((diff ** 2).sum())
+            den += float((b ** 2).sum())
+        errs.sort(reverse=True)
+        return (num / den) ** 0.5, errs
+
+    gpu = {name: p.grad.cpu() for name, p in net.named_parameters()}
+    assert all(g is not None for g in gpu.values()) and all(sd[n].grad is not None for n in names)
+    l2, errs = deviation(gpu.__getitem__, lambda n: sd[n].grad)                   # GPU      vs oracle float32
+    l2_gpu64, errs_gpu64 = deviation(gpu.__getitem__, lambda n: sd64[n].grad)     # GPU      vs oracle float64
+    l2_ref64, errs_ref64 = deviation(lambda n: sd[n].grad, lambda n: sd64[n].grad)  # oracle32 vs oracle float64
     print("worst per-tensor gradient deviations (max |diff| / max |ref|):")
     for e, name in errs[:12]:
         print("   %-50s %.3e" % (name, e))
     report("train_step_gradients_tiny_fused%d" % fused, loss_rel=rel_loss, worst_grad_rel=errs[0][0], grad_l2_rel=l2,
-           median_grad_rel=errs[len(errs) // 2][0], params=float(len(names)))
-    assert rel_loss < 1e-5
-    assert l2 < 2e-3, l2                                   # the whole 698 936-element gradient, relative L2
-    assert errs[0][0] < 5e-3, errs[:5]
+           median_grad_rel=errs[len(errs) // 2][0], params=float(len(names)),
+           grad_l2_rel_vs_f64=l2_gpu64, oracle32_l2_rel_vs_f64=l2_ref64,
+           worst_grad_rel_vs_f64=errs_gpu64[0][0], oracle32_worst_grad_rel_vs_f64=errs_ref64[0][0],
+           loss_rel_vs_f64=rel_loss64)
+    assert rel_loss < 1e-5 and rel_loss64 < 1e-5
+    # (the oracle's float32 deviation depends on the host's reduction order: 2.7e-4 .. 3.9e-4 on the boxes seen)
+    if fused:
+        assert l2_gpu64 < max(1.5 * l2_ref64, 4.5e-4), (l2_gpu64, l2_ref64)
+        assert errs_gpu64[0][0] < 3.0 * errs_ref64[0][0], (errs_gpu64[:3], errs_ref64[:3])
+    else:
+        assert l2_gpu64 < max(2.5 * l2_ref64, 8e-4), (l2_gpu64, l2_ref64)
+    assert l2 < (6e-4 if fused else 1e-3), l2                # the whole 698 936-element gradient, relative L2
+    assert errs[0][0] < 3e-3, errs[:5]
 
 
 def test_train_step_runs_and_updates_through_the_bucket(dev):

@@ -2,7 +2,7 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp PF_MIOPEN_FIND=0
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_train_ops.py -q -m gpu 2>&1 | tail -5
+timeout 900 python -m pytest tests/test_gpu_train_ops.py tests/test_gpu_model.py -q -m gpu -k "train" 2>&1 | tail -3
 timeout 600 python bench.py --config cfg4 --no-cpu-baseline --steps 10 --warmup 3 2> gpurun_out/bench_cfg4.err | grep "^{" | tail -1 > gpurun_out/bench_cfg4.json
 python -c "
 import json; d=json.loads(open('gpurun_out/bench_cfg4.json').readline()); print('cfg4', round(d['value'],2), d['unit'], round(d['ms_per_step'],3), d.get('execution'))"

@@ -81,9 +81,10 @@ def main():
         us = timed(lambda: train_ops.conv2d_dgrad(dy, wt, s), a.reps)
         fl = 2.0 * N * Co * Ci * k * k * osp[0] * osp[1]
         print("dgrad %-26s %9.1f us  %6.1f TF/s (incl. weight flip / pack)" % (name, us, fl / us / 1e6))
-    dy, wt = r(1, 8, D, 64, 80), w(64, 8, 3, 3, 3)
-    us = timed(lambda: train_ops._conv3d_k3_w(dy, wt, 1), a.reps)
-    print("dgrad %-26s %9.1f us  %6.1f TF/s" % ("vol conv0_1 (8->64 conv)", us, 2.0 * 27 * 64 * 8 * D * 64 * 80 / us / 1e6))
+    dy, wt = r(1, 8, D, 64, 80), w(8, 64, 3, 3, 3)
+    us = timed(lambda: train_ops.conv3d_dgrad_flip(dy, wt), a.reps)
+    print("dgrad %-26s %9.1f us  %6.1f TF/s" % ("vol conv0_1 (8->64, 2 x 8->32)", us,
+                                                 2.0 * 27 * 64 * 8 * D * 64 * 80 / us / 1e6))
     from pointmvsnet_amd import pointflow
     dy, wt = r(1, 16, 24, 32, 40), w(16, 64, 3, 3, 3)
     us = timed(lambda: pointflow.deconv3d_k3s2(dy, None, wt, False), a.reps)

@@ -40,4 +40,16 @@ if "conv3d" in which:
     x = torch.randn(1, 64, 48, 64, 80, device=dev)
     for _ in range(4):
         pointflow.conv3d_k3(x, w, 1, True)
+if "wgrad" in which:      # the training step's weight gradients at BASELINE config 4's shapes
+    from pointmvsnet_amd import train_ops
+    for N, co, ci, sp, k, st in ((1, 8, 64, (48, 64, 80), 3, 1), (3, 8, 8, (512, 640), 3, 1), (3, 16, 16, (256, 320), 3, 1),
+                                 (3, 64, 64, (64, 80), 3, 1), (1, 16, 64, (48, 64, 80), 3, 2)):
+        nd = len(sp)
+        x = torch.randn(N, ci, *sp, device=dev)
+        dy = torch.randn(N, co, *[(v - 1) // st + 1 for v in sp], device=dev)
+        for _ in range(3):
+            train_ops.conv_wgrad(dy, x, (k,) * nd, st, (k // 2,) * nd)
+    g, X = torch.randn(102400, 128, device=dev), torch.randn(102400, 136, device=dev)
+    for _ in range(3):
+        train_ops.rows_wgrad(g, X, 128, 136)
 torch.cuda.synchronize()
