@@ -279,6 +279,15 @@ int pf_edge_backward_apply_f32(const float* LE, int64_t ldle, int C, const int64
                                int ld_affine, int groups_per_stat, int concat, float* grad_le,
                                const uint32_t* inv_order, const uint32_t* inv_start, void* stream);
 
+/* Between the two passes above: partials (G, pf_stat_blocks(G, Ng), cbn, 2) -> c1, c2 (G / groups_per_stat, cbn) =
+ * the statistic set's (sum g', sum g' * xhat) / m in a fixed order (m = groups_per_stat * Ng points for the central
+ * half [0, C) of a concat layer, * k pairs else), and dbeta / dgamma (cbn,) = the sums over the sets (NULL: not
+ * wanted; accumulate != 0: added to what is there).  Replaces a dozen element-wise ATen launches per layer in the
+ * training step (reference: autograd through networks.py:36-45). */
+int pf_edge_backward_coeffs_f32(const double* partials, int G, int T, int cbn, int C, int concat, int groups_per_stat,
+                                int Ng, int k, float* c1, float* c2, float* dgamma, float* dbeta, int accumulate,
+                                void* stream);
+
 /* The inverse of a neighbour index tensor idx (G, Ng, k) (csrc/knn_inverse.hip): order (G*Ng*k) = the pair ids
  * p = (g*Ng + n)*k + j grouped by their target row g*Ng + clamp(idx[p], 0, Ng-1); start (G*Ng + 1): the pairs
  * that gather row m are order[start[m] .. start[m+1]), in ascending p.  With (inv_order, inv_start)
@@ -588,6 +597,32 @@ int pf_resize_bilinear_backward_f32(const float* dres, int ld, int c0, int C, in
  * read their weights in.  max_total: the largest destination element count in the table. */
 int pf_pack_desc_bytes(void);
 int pf_pack_gather_f32(const void* table, int npacks, long long max_total, void* stream);
+
+/* ---- Row Z: the small differentiable heads of the training step (csrc/train_heads.hip) --------------------------
+ * One or two launches each where autograd makes 15-25 element-wise ATen launches; float64 fixed-order reductions.
+ *
+ * pf_softargmin_backward_f32: backward of row S's depth (reference model.py:117-124): gcost[b,k,i] =
+ *   -gdepth[b,i] * p_k * (z_k - depth[b,i]) with p = softmax(-cost) recomputed as pf_softargmin_prob_f32 rounds it.
+ * pf_flow_head_train_f32: act (5*hw, ld >= 16) rows (row = d*hw + pixel) -> logit = act . w16 (channel order),
+ *   prob (5, hw) = softmax(-logit) over d, offset (hw) = sum_d prob_d * (d - 2) * interval[0] (model.py:40-43,218-227).
+ * pf_flow_head_backward_f32: gact (5*hw, 16) = d offset / d act * goffset, gw16 (16) (+)= its weight gradient;
+ *   workspace: pf_flow_head_backward_workspace(hw) bytes.
+ * pf_masked_mae_f32: loss[0] = weight * sum_b [ sum_{gt != 0} |pred - gt| / interval[b] / (count_b + 1e-7) ] with gt
+ *   (B, H, W) read at the nearest-resized positions of pred (B, h, w) (networks.py:170-181, model.py:308-339);
+ *   coef (B) = weight / (interval_b * (count_b + 1e-7)) for the backward: gpred = gloss[0] * coef_b * sign(pred - gt)
+ *   on valid pixels, 0 elsewhere. */
+int pf_softargmin_backward_f32(const float* cost, const float* params, const float* depth, const float* gdepth,
+                               float* gcost, int64_t B, int64_t D, int64_t HW, void* stream);
+int pf_flow_head_train_f32(const float* act, int64_t ld, const float* w16, const float* interval, int64_t hw,
+                           float* offset, float* prob, void* stream);
+int64_t pf_flow_head_backward_workspace(int64_t hw);
+int pf_flow_head_backward_f32(const float* act, int64_t ld, const float* w16, const float* interval, const float* prob,
+                              const float* goffset, int64_t hw, float* gact, float* gw16, int accumulate,
+                              void* workspace, int64_t workspace_bytes, void* stream);
+int pf_masked_mae_f32(const float* pred, const float* gt, const float* interval, int B, int h, int w, int H, int W,
+                      float weight, float* loss, float* coef, void* stream);
+int pf_masked_mae_backward_f32(const float* pred, const float* gt, const float* coef, const float* gloss, int B, int h,
+                               int w, int H, int W, float* gpred, void* stream);
 
 #ifdef __cplusplus
 }

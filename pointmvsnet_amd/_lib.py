@@ -97,6 +97,13 @@ PROTOTYPES = {
     "pf_softargmin_prob_f32": ([_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp], _i),
     "pf_bn_train_rows_f32": ([_vp, _i, _i, _i, _i, _d, _d, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _vp, _i, _i, _i, _vp], _i),
     "pf_bn_bwd_reduce_f32": ([_vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _vp, _vp], _i),
+    "pf_softargmin_backward_f32": ([_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp], _i),
+    "pf_flow_head_train_f32": ([_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp], _i),
+    "pf_flow_head_backward_workspace": ([_i64], _i64),
+    "pf_flow_head_backward_f32": ([_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i, _vp, _i64, _vp], _i),
+    "pf_masked_mae_f32": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp], _i),
+    "pf_masked_mae_backward_f32": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp], _i),
+    "pf_edge_backward_coeffs_f32": ([_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp], _i),
     "pf_bn_bwd_coeffs_f32": ([_vp, _i, _i, _i, _i, _d, _i, _i, _vp, _vp, _vp, _vp, _i, _vp], _i),
     "pf_bn_bwd_apply_f32": ([_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _vp], _i),
     "pf_rows_bn_blocks": ([_i, _i], _i),

@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libpointflow_hip.so")
-SOURCES = ["pf_core.hip", "gather_knn.hip", "knn_lattice.hip", "fetch.hip", "edgeconv.hip", "norm.hip", "conv3d.hip", "conv3d_pair.hip", "deconv3d.hip", "conv3d_bottom.hip", "conv2d_wide.hip", "eval_out.hip", "knn_inverse.hip", "norm_bwd.hip", "conv_wgrad.hip", "conv_dgrad.hip", "warp_bwd.hip"]
+SOURCES = ["pf_core.hip", "gather_knn.hip", "knn_lattice.hip", "fetch.hip", "edgeconv.hip", "norm.hip", "conv3d.hip", "conv3d_pair.hip", "deconv3d.hip", "conv3d_bottom.hip", "conv2d_wide.hip", "eval_out.hip", "knn_inverse.hip", "norm_bwd.hip", "conv_wgrad.hip", "conv_dgrad.hip", "warp_bwd.hip", "train_heads.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics",
          "-fPIC", "-Wno-pass-failed", "-I" + INCLUDE, "-I" + CSRC]
 # every compile also reports the per-kernel resource usage; it is kept next to the object as JSON and merged into

@@ -265,7 +265,7 @@ class TrainPlan(object):
         self.is_test = bool(is_test)
         entries = [("K_coarse", (B, V, 3, 3)), ("ext", (B, V, 3, 4)), ("Kinv0", (B, 1, 3, 3)), ("Rinv0", (B, 1, 3, 3)),
                    ("t0", (B, 1, 3, 1)), ("depths", (B, self.D)), ("d_start", (B,)), ("d_int", (B,)),
-                   ("mean", (B, 3, 1)), ("std", (B, 3, 1))]
+                   ("mean", (B, 3, 1)), ("std", (B, 3, 1)), ("sa_params", (B, 3))]
         for i in range(len(self.img_scales)):
             entries += [("interval%d" % i, (B,)), ("K_flow%d" % i, (B, V, 3, 3)), ("Kinv_flow%d" % i, (B, 1, 3, 3)),
                         ("pack%d" % i, (B, 27 + 21 * V + 1))]      # the PF_CAM_* block + interval of the fused kernels
@@ -312,6 +312,7 @@ class TrainPlan(object):
             self._h("depths")[b].copy_(torch.linspace(float(cam.depth_start[b]), float(cam.depth_end[b]), self.D))
         self._h("d_start").copy_(cam.depth_start)
         self._h("d_int").copy_(cam.depth_interval)
+        self._h("sa_params").copy_(torch.stack([cam.depth_start, cam.depth_end, cam.depth_interval], dim=1))
         self._h("mean").copy_(mean_h.float().reshape(self.B, 3, 1))
         self._h("std").copy_(std_h.float().reshape(self.B, 3, 1))
         for i, (s, inter) in enumerate(zip(self.img_scales, self.inter_scales)):
@@ -613,12 +614,17 @@ class PointMVSNet(nn.Module):
         else:
             filtered = self.coarse_vol_conv(cost).squeeze(1)
 
-        d_start = tplan.d("d_start")
-        d_int = tplan.d("d_int")
-        prob_volume = F.softmax(-filtered, dim=1)
-        pred_depth = torch.sum(depths.view(B, D, 1, 1) * prob_volume, dim=1).unsqueeze(1)
-        preds["coarse_depth_map"] = pred_depth
-        preds["coarse_prob_map"] = get_propability_map(prob_volume, pred_depth, d_start, d_int)
+        if fused and train_ops.FUSED_HEADS:
+            pred_depth, prob_map = train_ops.soft_argmin_train(filtered, tplan.d("sa_params"))
+            preds["coarse_depth_map"] = pred_depth
+            preds["coarse_prob_map"] = prob_map
+        else:
+            d_start = tplan.d("d_start")
+            d_int = tplan.d("d_int")
+            prob_volume = F.softmax(-filtered, dim=1)
+            pred_depth = torch.sum(depths.view(B, D, 1, 1) * prob_volume, dim=1).unsqueeze(1)
+            preds["coarse_depth_map"] = pred_depth
+            preds["coarse_prob_map"] = get_propability_map(prob_volume, pred_depth, d_start, d_int)
         if not isFlow:
             return preds
 
@@ -670,6 +676,10 @@ class PointMVSNet(nn.Module):
             edges = train_ops.edge_chain_train(self.flow_edge_conv, rows, nn_idx)          # (N, 224)
             if train_ops.mlp_supported(self.flow_mlp[0], edges):
                 act = train_ops.mlp_train(self.flow_mlp[0], edges)                             # (N, 16)
+                if train_ops.flow_head_supported(act, self.flow_mlp[1], D) and interval.numel() == 1:
+                    # 16 -> 1, softmax over the hypotheses, expected offset: one node (csrc/train_heads.hip)
+                    offset, prob = train_ops.flow_head_train(act, self.flow_mlp[1], interval, hs * ws)
+                    return offset.view(1, 1, hs, ws), prob.view(1, D, hs, ws)
                 flow = (act * self.flow_mlp[1].weight.view(1, -1)).sum(dim=1).view(B, D, hs, ws)
             else:
                 flow = self.flow_mlp(edges.t().unsqueeze(0)).contiguous().view(B, D, hs, ws)
@@ -770,12 +780,16 @@ class PointMVSNetLoss(nn.Module):
         if isFlow:
             stages += [("flow1_loss", "flow1", 0.75), ("flow2_loss", "flow2", 0.375)]
         losses = {}
+        n = float(len(stages))
         for name, key, scale in stages:
             pred = preds[key]
+            if train_ops.masked_mae_supported(pred, gt, interval):
+                # resize + mask + |.| + the sums + the divisions: one launch forward, one backward (csrc/train_heads.hip)
+                losses[name] = train_ops.masked_mae(pred, gt, interval, 1.0 / (n * scale))
+                continue
             target = F.interpolate(gt, (pred.shape[2], pred.shape[3]))
-            losses[name] = self.maeloss(pred, target, scale * interval if scale != 1.0 else interval)
-        n = float(len(losses))
-        return {k: v / n for k, v in losses.items()}
+            losses[name] = self.maeloss(pred, target, scale * interval if scale != 1.0 else interval) / n
+        return losses
 
 
 def _less_pct(pred, gt, interval, threshold, mask):

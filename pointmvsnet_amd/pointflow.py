@@ -1055,10 +1055,11 @@ def knn_inverse(idx, G, Ng, k):
 DETERMINISTIC_BACKWARD = True
 
 
-def edge_conv_backward(keep, idx, grad_y, C, k, G, Ng, groups_per_stat, concat):
+def edge_conv_backward(keep, idx, grad_y, C, k, G, Ng, groups_per_stat, concat, into=None):
     """Gradient of edge_conv_fused's output rows w.r.t. LE = [l | e] and the BatchNorm affine parameters
-    (pf_edge_backward_reduce_f32 / _apply_f32: d = e[idx] - l is recomputed, nothing of size N*k is stored).
-    grad_y: (G*Ng, cbn) point-major.  Returns (grad_LE (G*Ng, 2C), grad_gamma (cbn,), grad_beta (cbn,))."""
+    (pf_edge_backward_reduce_f32 / _coeffs_f32 / _apply_f32: d = e[idx] - l is recomputed, nothing of size N*k is
+    stored).  grad_y: (G*Ng, cbn) point-major.  Returns (grad_LE (G*Ng, 2C), grad_gamma (cbn,), grad_beta (cbn,));
+    ``into`` = (dgamma, dbeta) tensors to ADD the parameter gradients to (then the returned ones are None)."""
     LE, scale, shift, mean, invstd = keep["LE"], keep["scale"], keep["shift"], keep["mean"], keep["invstd"]
     dev = LE.device
     cbn = 2 * C if concat else C
@@ -1069,19 +1070,23 @@ def edge_conv_backward(keep, idx, grad_y, C, k, G, Ng, groups_per_stat, concat):
               int(grad_y.stride(0)), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(mean), _lib.ptr(invstd), cbn,
               groups_per_stat, int(bool(concat)), _lib.ptr(partials), _lib.stream(),
               algo_bytes=float(G) * Ng * (4.0 * C + 8.0 * k + 4.0 * C * k + 4.0 * cbn))
-    red = partials.view(S, -1, cbn, 2).sum(dim=1)                          # (S, cbn, 2): (dbeta, dgamma)
-    m = torch.full((cbn,), float(groups_per_stat) * Ng * k, dtype=torch.float64, device=dev)
-    if concat:
-        m[:C] = float(groups_per_stat) * Ng
-    c1 = (red[..., 0] / m).to(_F32).contiguous()
-    c2 = (red[..., 1] / m).to(_F32).contiguous()
+    c1 = torch.empty((S, cbn), dtype=_F32, device=dev)
+    c2 = torch.empty((S, cbn), dtype=_F32, device=dev)
+    if into is None:
+        dgamma = torch.empty((cbn,), dtype=_F32, device=dev)
+        dbeta = torch.empty((cbn,), dtype=_F32, device=dev)
+    else:
+        dgamma, dbeta = into
+    _lib.call("pf_edge_backward_coeffs_f32", _lib.ptr(partials), G, T, cbn, C, int(bool(concat)), groups_per_stat, Ng, k,
+              _lib.ptr(c1), _lib.ptr(c2), _lib.ptr(dgamma), _lib.ptr(dbeta), 0 if into is None else 1, _lib.stream(),
+              algo_bytes=16.0 * G * T * cbn)
     grad_le = torch.empty((G * Ng, 2 * C), dtype=_F32, device=dev)
     order, start = knn_inverse(idx, G, Ng, k) if DETERMINISTIC_BACKWARD else (None, None)
     _lib.call("pf_edge_backward_apply_f32", _lib.ptr(LE), 2 * C, C, _lib.ptr(idx), k, G, Ng, _lib.ptr(grad_y),
               int(grad_y.stride(0)), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(c1),
               _lib.ptr(c2), cbn, groups_per_stat, int(bool(concat)), _lib.ptr(grad_le), _lib.ptr(order), _lib.ptr(start),
               _lib.stream(), algo_bytes=float(G) * Ng * (8.0 * C + 8.0 * k + 8.0 * C * k + 4.0 * cbn))
-    return grad_le, red[..., 1].sum(dim=0).to(_F32), red[..., 0].sum(dim=0).to(_F32)
+    return (grad_le, dgamma, dbeta) if into is None else (grad_le, None, None)
 
 
 def _bn_affine_from_gemm(bn, partials, C, G, Ng, groups_per_stat, dev, lazy=False):

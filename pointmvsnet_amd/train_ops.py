@@ -755,7 +755,9 @@ class _EdgeChainTrain(torch.autograd.Function):
             for m, (keep, X, ldx, K, col, wdt) in reversed(list(zip(edge_convs, keeps))):
                 C = m.conv1.weight.shape[0]
                 gy = g[:, col:col + wdt]
-                grad_le, dgamma, dbeta = pointflow.edge_conv_backward(keep, idx, gy, C, k, 1, N, 1, m.concat)
+                tg, tb = _grad_target(m.bn.weight), _grad_target(m.bn.bias)
+                grad_le, dgamma, dbeta = pointflow.edge_conv_backward(
+                    keep, idx, gy, C, k, 1, N, 1, m.concat, into=(tg, tb) if (tg is not None and tb is not None) else None)
                 wcat = None if _PACKS is not None else torch.cat(
                     [m.conv1.weight.detach().reshape(C, K), m.conv2.weight.detach().reshape(C, K)], dim=0)
                 # conv1 / conv2 are adjacent parameters: in the flat gradient bucket their .grad views form one (2C, K) block
@@ -769,11 +771,6 @@ class _EdgeChainTrain(torch.autograd.Function):
                     gx = dX
                 else:
                     g[:, col - K:col] += dX
-                tg, tb = _grad_target(m.bn.weight), _grad_target(m.bn.bias)
-                if tg is not None and tb is not None:
-                    tg.add_(dgamma)
-                    tb.add_(dbeta)
-                    dgamma = dbeta = None
                 gparams = [None if dw is None else dw[:C].reshape(m.conv1.weight.shape),
                            None if dw is None else dw[C:].reshape(m.conv2.weight.shape), dgamma, dbeta] + gparams
         return (gx, None, None) + tuple(gparams)
@@ -854,6 +851,125 @@ class _MLPTrain(torch.autograd.Function):
 
 def mlp_train(shared, x):
     return _MLPTrain.apply(x, shared, *mlp_params(shared))
+
+
+# ---------------------------------------------------------------------------------------------
+# the small heads (csrc/train_heads.hip): soft argmin, flow head, masked MAE -- one or two launches per direction where
+# autograd makes 15-25 element-wise launches of each (a third of the step's dispatches were these)
+# ---------------------------------------------------------------------------------------------
+# 0: the ATen compositions (the A/B arm and what the tests compare the nodes with)
+FUSED_HEADS = int(os.environ.get("PF_FUSED_HEADS", "1"))
+
+
+class _SoftArgminTrain(torch.autograd.Function):
+    """depth (B,1,H,W), prob map (B,1,H,W) of a filtered cost volume (B,D,H,W) (reference model.py:117-130): forward =
+    row S's inference kernel, backward = pf_softargmin_backward_f32.  The probability map carries no gradient (the
+    reference's loss never reads it, model.py:308-339)."""
+
+    @staticmethod
+    def forward(ctx, filtered, params):
+        cost = filtered.detach().contiguous()
+        depth, prob = pointflow.soft_argmin_params(cost, params)
+        ctx.saved = (cost, params, depth)
+        ctx.mark_non_differentiable(prob)
+        return depth, prob
+
+    @staticmethod
+    def backward(ctx, gdepth, _gprob):
+        cost, params, depth = ctx.saved
+        B, D, H, W = cost.shape
+        g = torch.empty_like(cost)
+        with torch.cuda.device(cost.device):
+            _lib.call("pf_softargmin_backward_f32", _lib.ptr(cost), _lib.ptr(params), _lib.ptr(depth),
+                      _lib.ptr(gdepth.contiguous()), _lib.ptr(g), B, D, H * W, _lib.stream(),
+                      algo_bytes=4.0 * B * H * W * (2 * D + 2))
+        return g, None
+
+
+def soft_argmin_train(filtered, params):
+    return _SoftArgminTrain.apply(filtered, params)
+
+
+class _FlowHeadTrain(torch.autograd.Function):
+    """The 16 -> 1 convolution, the softmax over the five hypotheses and the expected offset (reference
+    model.py:40-43, 218-227) on the MLP's (5*hw, 16) point-major output: (offset (hw,), prob (5, hw))."""
+
+    @staticmethod
+    def forward(ctx, act, weight, interval, hw):
+        a = act.detach().contiguous()
+        w = weight.detach().reshape(-1).contiguous()
+        offset = torch.empty((hw,), dtype=_F32, device=a.device)
+        prob = torch.empty((5, hw), dtype=_F32, device=a.device)
+        with torch.cuda.device(a.device):
+            _lib.call("pf_flow_head_train_f32", _lib.ptr(a), int(a.stride(0)), _lib.ptr(w), _lib.ptr(interval), hw,
+                      _lib.ptr(offset), _lib.ptr(prob), _lib.stream(), algo_bytes=4.0 * hw * (5 * 16 + 6))
+        ctx.saved = (a, w, interval, prob, weight)
+        ctx.mark_non_differentiable(prob)
+        return offset, prob
+
+    @staticmethod
+    def backward(ctx, goffset, _gprob):
+        a, w, interval, prob, weight = ctx.saved
+        hw = prob.shape[1]
+        gact = torch.empty((5 * hw, 16), dtype=_F32, device=a.device)
+        target = _grad_target(weight)
+        gw = torch.empty((16,), dtype=_F32, device=a.device) if target is None else target.view(-1)
+        nbytes = int(_lib.load().pf_flow_head_backward_workspace(hw))
+        work = torch.empty((nbytes // 8,), dtype=torch.float64, device=a.device)
+        with torch.cuda.device(a.device):
+            _lib.call("pf_flow_head_backward_f32", _lib.ptr(a), int(a.stride(0)), _lib.ptr(w), _lib.ptr(interval),
+                      _lib.ptr(prob), _lib.ptr(goffset.contiguous()), hw, _lib.ptr(gact), _lib.ptr(gw),
+                      0 if target is None else 1, _lib.ptr(work), nbytes, _lib.stream(),
+                      algo_bytes=4.0 * hw * (2 * 5 * 16 + 6))
+        return gact, (gw.view(weight.shape) if target is None else None), None, None
+
+
+def flow_head_supported(act, conv, D):
+    return (FUSED_HEADS and act.is_cuda and act.dtype == _F32 and act.dim() == 2 and act.shape[1] == 16 and D == 5
+            and act.shape[0] % 5 == 0 and conv.weight.numel() == 16)
+
+
+def flow_head_train(act, conv, interval, hw):
+    return _FlowHeadTrain.apply(act, conv.weight, interval, hw)
+
+
+class _MaskedMAE(torch.autograd.Function):
+    """weight * sum_b [ sum_{gt != 0} |pred - gt| / interval_b / (count_b + 1e-7) ] with the ground truth read at the
+    nearest-resized positions (reference networks.py:170-181 under model.py:308-339's F.interpolate)."""
+
+    @staticmethod
+    def forward(ctx, pred, gt, interval, weight):
+        p, t = pred.detach().contiguous(), gt.contiguous()
+        B, _, h, w = p.shape
+        H, W = t.shape[2:]
+        loss = torch.empty((), dtype=_F32, device=p.device)
+        coef = torch.empty((B,), dtype=_F32, device=p.device)
+        with torch.cuda.device(p.device):
+            _lib.call("pf_masked_mae_f32", _lib.ptr(p), _lib.ptr(t), _lib.ptr(interval), B, h, w, H, W, float(weight),
+                      _lib.ptr(loss), _lib.ptr(coef), _lib.stream(), algo_bytes=8.0 * B * h * w)
+        ctx.saved = (p, t, coef)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        p, t, coef = ctx.saved
+        B, _, h, w = p.shape
+        H, W = t.shape[2:]
+        g = torch.empty_like(p)
+        with torch.cuda.device(p.device):
+            _lib.call("pf_masked_mae_backward_f32", _lib.ptr(p), _lib.ptr(t), _lib.ptr(coef), _lib.ptr(gloss.contiguous()),
+                      B, h, w, H, W, _lib.ptr(g), _lib.stream(), algo_bytes=12.0 * B * h * w)
+        return g, None, None, None
+
+
+def masked_mae_supported(pred, gt, interval):
+    return (FUSED_HEADS and pred.is_cuda and pred.dtype == _F32 and gt.dtype == _F32 and interval.dtype == _F32
+            and pred.dim() == 4 and pred.shape[1] == 1 and gt.dim() == 4 and gt.shape[1] == 1
+            and interval.numel() == pred.shape[0] and interval.is_contiguous())
+
+
+def masked_mae(pred, gt, interval, weight):
+    return _MaskedMAE.apply(pred, gt, interval, weight)
 
 
 # ---------------------------------------------------------------------------------------------

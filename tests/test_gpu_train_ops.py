@@ -453,3 +453,88 @@ def test_step_weight_packs_equal_the_torch_built_layouts(dev):
     W01.data = W01.data.clone()
     assert packs.stale()
     assert checked >= 40
+
+
+def test_soft_argmin_node_vs_float64_autograd(dev):
+    """train_ops.soft_argmin_train (row S's kernel + pf_softargmin_backward_f32) against the reference's composition
+    softmax(-cost) -> sum_k linspace_k p_k (model.py:117-124) in float64; the probability map against
+    functions.get_propability_map through the inference kernel's own tests (tests/test_gpu_ops.py)."""
+    B, D, H, W = 2, 48, 16, 20
+    cost = _seeded((B, D, H, W), dev, 31, 2.0)
+    start = torch.tensor([425.0, 500.0], device=dev)
+    interval = torch.tensor([2.5, 3.0], device=dev)
+    end = start + (D - 1) * interval
+    params = torch.stack([start, end, interval], dim=1).contiguous()
+    g = _seeded((B, 1, H, W), dev, 32)
+    x = cost.clone().requires_grad_(True)
+    depth, prob = train_ops.soft_argmin_train(x, params)
+    (depth * g).sum().backward()
+    x2 = cost.clone().requires_grad_(True)
+    depth2, _ = train_ops.soft_argmin_train(x2, params)
+    (depth2 * g).sum().backward()
+    assert torch.equal(depth, depth2) and torch.equal(x.grad, x2.grad)
+    xr = cost.double().requires_grad_(True)
+    z = torch.stack([torch.linspace(float(start[b]), float(end[b]), D, dtype=torch.float64, device=dev) for b in range(B)])
+    p = F.softmax(-xr, dim=1)
+    dr = (z.view(B, D, 1, 1) * p).sum(dim=1, keepdim=True)
+    (dr * g.double()).sum().backward()
+    e_d, e_g = _rel(depth, dr), _rel(x.grad, xr.grad)
+    report("train_soft_argmin_node", depth=e_d, grad=e_g)
+    assert not prob.requires_grad and prob.shape == depth.shape
+    assert e_d < 2e-6 and e_g < 1e-5, (e_d, e_g)
+
+
+def test_flow_head_node_vs_float64_autograd(dev):
+    """train_ops.flow_head_train against (act * w).sum -> softmax(-flow) over the five hypotheses -> sum prob * length
+    (reference model.py:40-43, 218-227) in float64: offset, probabilities, gradient rows and the 16 weight gradients."""
+    hw = 37 * 41
+    conv = torch.nn.Conv1d(16, 1, 1, bias=False).to(dev)
+    act = torch.relu(_seeded((5 * hw, 16), dev, 41)) + 0.01
+    interval = torch.tensor([1.9], device=dev)
+    g = _seeded((hw,), dev, 42)
+    a = act.clone().requires_grad_(True)
+    offset, prob = train_ops.flow_head_train(a, conv, interval, hw)
+    conv.weight.grad = None
+    (offset * g).sum().backward()
+    gw1, ga1 = conv.weight.grad.clone(), a.grad.clone()
+    a2 = act.clone().requires_grad_(True)
+    conv.weight.grad = None
+    offset2, _ = train_ops.flow_head_train(a2, conv, interval, hw)
+    (offset2 * g).sum().backward()
+    assert torch.equal(offset, offset2) and torch.equal(ga1, a2.grad) and torch.equal(gw1, conv.weight.grad)
+    ar = act.double().requires_grad_(True)
+    wr = conv.weight.detach().double().requires_grad_(True)
+    flow = (ar * wr.view(1, -1)).sum(dim=1).view(5, hw)
+    pr = F.softmax(-flow, dim=0)
+    length = torch.tensor([-2.0, -1.0, 0.0, 1.0, 2.0], dtype=torch.float64, device=dev).view(5, 1) * interval.double()
+    offr = (pr * length).sum(dim=0)
+    (offr * g.double()).sum().backward()
+    errs = dict(offset=_rel(offset, offr), prob=_rel(prob, pr), gact=_rel(ga1, ar.grad), gw=_rel(gw1, wr.grad))
+    report("train_flow_head_node", **errs)
+    assert errs["offset"] < 5e-6 and errs["prob"] < 2e-6 and errs["gact"] < 1e-5 and errs["gw"] < 1e-5, errs
+
+
+@pytest.mark.parametrize("B,h,w,H,W", [(1, 128, 160, 512, 640), (2, 7, 9, 30, 37), (1, 64, 80, 512, 640)])
+def test_masked_mae_node_vs_float64_composition(dev, B, h, w, H, W):
+    """train_ops.masked_mae against F.interpolate(gt) (nearest) + MAELoss (reference networks.py:170-181,
+    model.py:308-339) in float64, ground truth with holes (zeros), a non-integer resize ratio among the cases."""
+    gt = (_seeded((B, 1, H, W), dev, 51).abs() * 100 + 400)
+    gt = gt * (_seeded((B, 1, H, W), dev, 52) > -0.5).float()                   # ~30 % invalid
+    pred = F.interpolate(gt, (h, w)) + _seeded((B, 1, h, w), dev, 53, 3.0)
+    pred[0, 0, 0, 0] = F.interpolate(gt, (h, w))[0, 0, 0, 0]                     # an exact hit: sign(0) = 0
+    interval = (torch.rand(B, device=dev) + 2.0).contiguous()
+    weight = 1.0 / (3 * 0.75)
+    p = pred.clone().requires_grad_(True)
+    loss = train_ops.masked_mae(p, gt, interval, weight)
+    (loss * 1.7).backward()
+    p2 = pred.clone().requires_grad_(True)
+    loss2 = train_ops.masked_mae(p2, gt, interval, weight)
+    (loss2 * 1.7).backward()
+    assert torch.equal(loss, loss2) and torch.equal(p.grad, p2.grad)
+    pr = pred.double().requires_grad_(True)
+    target = F.interpolate(gt, (h, w)).double()
+    ref = networks.MAELoss()(pr, target, interval.double()) * weight
+    (ref * 1.7).backward()
+    e_l, e_g = abs(float(loss) - float(ref)) / abs(float(ref)), _rel(p.grad, pr.grad)
+    report("train_masked_mae_node_%dx%d" % (h, w), loss=e_l, grad=e_g)
+    assert loss.shape == () and e_l < 2e-7 and e_g < 2e-7, (e_l, e_g)

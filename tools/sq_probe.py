@@ -40,6 +40,16 @@ if "conv3d" in which:
     x = torch.randn(1, 64, 48, 64, 80, device=dev)
     for _ in range(4):
         pointflow.conv3d_k3(x, w, 1, True)
+if "volume" in which:     # VolumeConv's forward (the eleven launches of forward_fused) at config 2's cost volume
+    from pointmvsnet_amd import synthetic
+    from pointmvsnet_amd.model import PointMVSNet
+    net = PointMVSNet()
+    synthetic.seed_weights(net, seed=0)
+    vc = net.coarse_vol_conv.to(dev).train()
+    cost = torch.randn(1, 64, 48, 64, 80, device=dev)
+    with torch.no_grad():
+        for _ in range(3):
+            vc.forward_fused(cost)
 if "wgrad" in which:      # the training step's weight gradients at BASELINE config 4's shapes
     from pointmvsnet_amd import train_ops
     for N, co, ci, sp, k, st in ((1, 8, 64, (48, 64, 80), 3, 1), (3, 8, 8, (512, 640), 3, 1), (3, 16, 16, (256, 320), 3, 1),
