@@ -511,7 +511,7 @@ def main():
         # Row Z: the weight gradients (pf_conv_wgrad_f32 / pf_rows_wgrad_f32: f32 MFMA, fixed-order split sums) as a
         # group, the BatchNorm backward passes, and the step's arithmetic as a whole against the f32 matrix peak
         for tag, entries in (("weight_gradients", ("pf_conv_wgrad_f32", "pf_rows_wgrad_f32")),
-                             ("batchnorm_backward", ("pf_bn_bwd_reduce_f32", "pf_bn_bwd_coeffs_f32", "pf_bn_bwd_apply_f32",
+                             ("batchnorm_backward", ("pf_bn_bwd_reduce_f32", "pf_bn_bwd_coeffs_f32", "pf_bn_bwd_apply_f32", "pf_bn_bwd_apply_fused_f32",
                                                      "pf_rows_bn_bwd_reduce_f32", "pf_rows_bn_bwd_apply_f32")),
                              ("warp_backward", ("pf_warp_taps_flow_f32", "pf_warp_taps_frustum_f32", "pf_sort_pairs_by_key",
                                                 "pf_variance_grad_f32", "pf_warp_gather_f32",

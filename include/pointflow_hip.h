@@ -500,6 +500,12 @@ int pf_bn_bwd_coeffs_f32(const double* partials, int T, int pcols, int col0, int
                          int accumulate, void* stream);
 int pf_bn_bwd_apply_f32(const float* g, const float* y, const float* rows, const float* coef, float* dy, int64_t N,
                         int64_t C, int64_t S, int samples_per_stat, int relu, void* stream);
+/* coeffs + apply in one launch (the planar path of the training step): every block re-adds its statistic group's
+ * partial rows (pf_norm_blocks(S) * samples_per_stat of them, the same order and bits as pf_bn_bwd_coeffs_f32), block
+ * (0, c, 0) writes dgamma[c] / dbeta[c] (NULL: not wanted).  count = samples_per_stat * S. */
+int pf_bn_bwd_apply_fused_f32(const float* g, const float* y, const float* rows, const double* partials, int T,
+                              double count, float* dy, int64_t N, int64_t C, int64_t S, int samples_per_stat, int relu,
+                              float* dgamma, float* dbeta, int accumulate, void* stream);
 /* The same on point-major rows (G groups of Ng rows, ld floats per row; C in {16, 32, 64, 128} for reduce,
  * C % 4 == 0 for apply / affine): the flow MLP's BatchNorm1d.  reduce partials: (G, pf_rows_bn_blocks(G, Ng), C, 2).
  * pf_rows_affine_f32: z = act(y * scale + shift), the normalised activation handed on. */

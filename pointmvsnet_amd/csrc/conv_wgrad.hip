@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ Gr
   const int split = blockIdx.x;
   const int cbtot = g.CBLK * g.CBP;
   const int ci0 = blockIdx.y * cbtot;
-  const int cg0 = blockIdx.z * 64;
+  const int cg0 = blockIdx.z * (MT * 16);
   const int R = g.TD * g.TH;
   const int plane_i = g.Hi * g.Wi, vol_i = plane_i * g.Di;
   const int plane_o = g.Ho * g.Wo, vol_o = plane_o * g.Do;
@@ -459,8 +459,10 @@ int resident_blocks(int MT, int stride, int ntw, size_t lds_bytes) {
   return n;
 }
 
-WgPlan make_plan(int64_t N, int64_t Cg, int64_t Cx, int64_t Do, int64_t Ho, int64_t Wo, int64_t Di, int64_t Hi,
-                 int64_t Wi, int KD, int KH, int KW, int stride, int pd, int ph, int pw, bool rows, int64_t P) {
+// The plan at MT row tiles per block (16 MT rows of Gr) and tile candidates from `first_tile` on.
+WgPlan make_plan_mt(int64_t N, int64_t Cg, int64_t Cx, int64_t Do, int64_t Ho, int64_t Wo, int64_t Di, int64_t Hi,
+                    int64_t Wi, int KD, int KH, int KW, int stride, int pd, int ph, int pw, bool rows, int64_t P, int MT,
+                    int first_tile) {
   WgPlan p;
   WgGeom& g = p.g;
   p.ok = false;
@@ -490,12 +492,12 @@ WgPlan make_plan(int64_t N, int64_t Cg, int64_t Cx, int64_t Do, int64_t Ho, int6
   g.lgCBP = ilog2(g.CBP);
   g.TPT = 16 / g.CBP;
   g.TPC = (g.T + g.TPT - 1) / g.TPT;
-  p.MT = Cg <= 16 ? 1 : (Cg <= 32 ? 2 : 4);
-  p.mblocks = (int)((Cg + 63) / 64);
+  p.MT = MT;
+  p.mblocks = (int)((Cg + 16 * MT - 1) / (16 * MT));
   const int cx_pad = (int)((Cx + g.CBP - 1) / g.CBP);          // channel sub-blocks in all
   // tile candidates: 3-D volumes 2 x 4 x 16, else 1 x 8 x 16, 1 x 4 x 16
   const int cand[3][2] = {{2, 4}, {1, 8}, {1, 4}};
-  for (int ci = rows ? 2 : (Do > 1 ? 0 : 1); ci < 3; ++ci) {      // (rows: 64 points per tile)
+  for (int ci = rows ? 2 : (first_tile >= 0 ? first_tile : (Do > 1 ? 0 : 1)); ci < 3; ++ci) {   // (rows: 64 points per tile)
     g.TD = cand[ci][0];
     g.TH = cand[ci][1];
     g.lgTH = ilog2(g.TH);
@@ -558,6 +560,29 @@ WgPlan make_plan(int64_t N, int64_t Cg, int64_t Cx, int64_t Do, int64_t Ho, int6
   if (g.per_split < 1) g.per_split = 1;
   p.splits = (int)((g.total_tiles + g.per_split - 1) / g.per_split);
   if (p.splits < 1) p.splits = 1;
+  return p;
+}
+
+// Row tiles per block: as many as the rows need (1, 2 or 4) -- unless that leaves the chip mostly empty (VolumeConv's
+// 480- and 3 840-voxel layers: 6 tiles x 4 channel blocks = 24 blocks of 27 x 4 accumulator tiles each took 40-75 us):
+// then fewer rows per block and the smallest tile, i.e. more blocks with less work each.
+WgPlan make_plan(int64_t N, int64_t Cg, int64_t Cx, int64_t Do, int64_t Ho, int64_t Wo, int64_t Di, int64_t Hi,
+                 int64_t Wi, int KD, int KH, int KW, int stride, int pd, int ph, int pw, bool rows, int64_t P) {
+  int MT = Cg <= 16 ? 1 : (Cg <= 32 ? 2 : 4);
+  WgPlan p = make_plan_mt(N, Cg, Cx, Do, Ho, Wo, Di, Hi, Wi, KD, KH, KW, stride, pd, ph, pw, rows, P, MT, -1);
+  if (!p.ok || rows) return p;
+  const auto blocks = [](const WgPlan& q) { return (int64_t)q.splits * q.cblocks * q.mblocks; };
+  if (blocks(p) < kCUs / 2) {
+    const WgPlan q = make_plan_mt(N, Cg, Cx, Do, Ho, Wo, Di, Hi, Wi, KD, KH, KW, stride, pd, ph, pw, rows, P, MT, 2);
+    if (q.ok && blocks(q) > blocks(p)) p = q;
+  }
+  while (MT > 1 && blocks(p) < kCUs) {
+    MT /= 2;
+    const WgPlan q = make_plan_mt(N, Cg, Cx, Do, Ho, Wo, Di, Hi, Wi, KD, KH, KW, stride, pd, ph, pw, rows, P, MT,
+                                  p.g.TD == 1 && p.g.TH == 4 ? 2 : -1);
+    if (!q.ok) break;
+    p = q;
+  }
   return p;
 }
 

@@ -246,6 +246,91 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   }
 }
 
+// The coefficients and the apply pass in ONE launch: every block of (n, c) first adds its statistic group's partial
+// rows exactly as bn_bwd_coeffs_kernel does (64 slices, slice order: the same bits), then streams its elements.  Block
+// (0, c, 0) also writes dgamma[c] / dbeta[c] (the sums over all S groups).  entries = sps * T partial rows per group is
+// a few dozen doubles: cheaper than a launch in a chain of ~700.
+__global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const float* __restrict__ g, const float* __restrict__ y,
+                                                                 const float* __restrict__ rows,
+                                                                 const double* __restrict__ partials, int T,
+                                                                 double count, float* __restrict__ dy, int C, int64_t S,
+                                                                 int sps, int relu, float* __restrict__ dgamma,
+                                                                 float* __restrict__ dbeta, int accumulate) {
+  __shared__ double2 red[64];
+  __shared__ double2 tot;
+  const int c = blockIdx.y, n = blockIdx.z;
+  const int s = n / sps;
+  const int groups = gridDim.z / sps;
+  const int64_t SC = (int64_t)groups * C;
+  const int entries = sps * T;
+  const bool writer = blockIdx.x == 0 && n == 0 && (dgamma != nullptr || dbeta != nullptr);
+  double tb = 0.0, tg = 0.0, sb_own = 0.0, sg_own = 0.0;
+  for (int q = writer ? 0 : s; q < (writer ? groups : s + 1); ++q) {
+    if (threadIdx.x < 64) {
+      double a = 0.0, b = 0.0;
+      const double* base = partials + ((int64_t)q * entries * C + c) * 2;
+      for (int e = threadIdx.x; e < entries; e += 64) {
+        const double2 v = *reinterpret_cast<const double2*>(base + (int64_t)e * C * 2);
+        a += v.x;
+        b += v.y;
+      }
+      red[threadIdx.x] = make_double2(a, b);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double sb = 0.0, sg = 0.0;
+      for (int i = 0; i < 64; ++i) {
+        sb += red[i].x;
+        sg += red[i].y;
+      }
+      tb += sb;
+      tg += sg;
+      if (q == s) {
+        sb_own = sb;
+        sg_own = sg;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    tot = make_double2(sb_own, sg_own);
+    if (writer) {
+      if (dgamma != nullptr) dgamma[c] = (accumulate ? dgamma[c] : 0.0f) + (float)tg;
+      if (dbeta != nullptr) dbeta[c] = (accumulate ? dbeta[c] : 0.0f) + (float)tb;
+    }
+  }
+  __syncthreads();
+  const float* r = rows + (int64_t)s * C + c;
+  const float sc = r[0], sh = r[SC], mean = r[2 * SC];
+  const double scd = (double)sc, invstd = (double)r[3 * SC];
+  const float k1 = (float)(scd * tot.x / count), k2 = (float)(scd * invstd * tot.y / count);
+  const float* pg = g + ((int64_t)n * C + c) * S;
+  const float* py = y + ((int64_t)n * C + c) * S;
+  float* po = dy + ((int64_t)n * C + c) * S;
+  auto one = [&](float gv, float yv) {
+    const float m = masked(gv, yv, sc, sh, relu);
+    return fmaf(-k2, yv - mean, fmaf(sc, m, -k1));
+  };
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  if ((((uintptr_t)pg | (uintptr_t)py | (uintptr_t)po) & 15) == 0 && (S & 3) == 0) {
+    const int64_t n4 = S >> 2;
+    const float4* g4 = reinterpret_cast<const float4*>(pg);
+    const float4* y4 = reinterpret_cast<const float4*>(py);
+    float4* o4 = reinterpret_cast<float4*>(po);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+      const float4 a = g4[i], b = y4[i];
+      float4 v;
+      v.x = one(a.x, b.x);
+      v.y = one(a.y, b.y);
+      v.z = one(a.z, b.z);
+      v.w = one(a.w, b.w);
+      o4[i] = v;
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < S; i += stride) po[i] = one(pg[i], py[i]);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // point-major rows (P, ld): the flow MLP's BatchNorm1d (reference nn/conv.py:24-35 via nn/mlp.py:45-81)
 // ------------------------------------------------------------------------------------------------
@@ -438,6 +523,20 @@ int pf_bn_bwd_coeffs_f32(const double* partials, int T, int pcols, int col0, int
   PF_REQUIRE(G >= 1 && groups_per_stat >= 1 && (G % groups_per_stat) == 0 && partials && rows && coef);
   hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3((unsigned)pf_cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, partials, T,
                      pcols, col0, C, count, G / groups_per_stat, groups_per_stat, rows, coef, dgamma, dbeta, accumulate);
+  return pf_launch_status();
+}
+
+int pf_bn_bwd_apply_fused_f32(const float* g, const float* y, const float* rows, const double* partials, int T,
+                              double count, float* dy, int64_t N, int64_t C, int64_t S, int samples_per_stat, int relu,
+                              float* dgamma, float* dbeta, int accumulate, void* stream) {
+  PF_REQUIRE(N >= 0 && C >= 0 && S >= 0 && N <= 65535 && C <= 65535 && samples_per_stat >= 1 && T >= 1 && count > 0.0);
+  if (N == 0 || C == 0 || S == 0) return PF_OK;
+  PF_REQUIRE(g && y && rows && partials && dy && (N % samples_per_stat) == 0);
+  int64_t blocks = (S / 4 + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 64 ? 64 : blocks);
+  dim3 grid((unsigned)blocks, (unsigned)C, (unsigned)N);
+  hipLaunchKernelGGL(bn_bwd_apply_fused_kernel, grid, dim3(256), 0, (hipStream_t)stream, g, y, rows, partials, T, count,
+                     dy, (int)C, S, samples_per_stat, relu, dgamma, dbeta, accumulate);
   return pf_launch_status();
 }
 

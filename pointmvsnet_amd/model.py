@@ -584,8 +584,8 @@ class PointMVSNet(nn.Module):
             with torch.cuda.stream(side):
                 levels = train_ops.tower_train(self.flow_img_conv, img_list[0], names)
         if fused:
-            feature_list = train_ops.tower_train(self.coarse_img_conv, img_list[0], ("conv3",))["conv3"].unsqueeze(0)
-            coarse_maps = [feature_list[:, 0]]
+            maps3 = train_ops.tower_train(self.coarse_img_conv, img_list[0], ("conv3",))["conv3"]     # (V, C, FH, FW)
+            feature_list = maps3.unsqueeze(0)        # (views are used below: an index's backward is a fill + a copy)
         else:
             coarse_maps = [self.coarse_img_conv(img_list[:, v])["conv3"] for v in range(V)]
             feature_list = torch.stack(coarse_maps, dim=1)                   # (B,V,C,FH,FW)
@@ -603,7 +603,7 @@ class PointMVSNet(nn.Module):
 
         if fused and C % 4 == 0 and V <= 8:
             # warp + variance as ONE node (forward: the inference kernel; backward: csrc/warp_bwd.hip, no atomics)
-            cost, world_points = train_ops.coarse_volume_train(feature_list[0], tplan.d("Kinv0"), R_inv0, t0, depths,
+            cost, world_points = train_ops.coarse_volume_train(maps3, tplan.d("Kinv0"), R_inv0, t0, depths,
                                                                K_coarse, ext)
             preds["world_points"] = world_points
         else:
@@ -701,12 +701,12 @@ class PointMVSNet(nn.Module):
         interval, K_flow, ext = tplan.d("interval%d" % it), tplan.d("K_flow%d" % it), tplan.d("ext")
         if depth_map.shape[2] != h:
             depth_map = F.interpolate(depth_map, (h, w), mode="nearest")
-        levels = [pyramids[n][0] for n in ("conv1", "conv2", "conv3")] if (fused and B == 1) else None
-        if levels is not None and train_ops.flow_features_supported(levels, depth_map[0, 0], h, w):
+        levels = [pyramids[n].squeeze(0) for n in ("conv1", "conv2", "conv3")] if (fused and B == 1) else None
+        if levels is not None and train_ops.flow_features_supported(levels, depth_map.view(h, w), h, w):
             # feature assembly (5 hypotheses x 3 levels: resize, warp, variance, xyz) as ONE node on the inference kernels,
             # backward without atomics (csrc/warp_bwd.hip); gradients reach the pyramid levels and the prior depth
             pack = tplan.d("pack%d" % it)[0]
-            rows, xyz = train_ops.flow_features_train(levels, depth_map[0, 0], pack[-1:], pack, h, w)
+            rows, xyz = train_ops.flow_features_train(levels, depth_map.view(h, w), pack[-1:], pack, h, w)
             flow, prob = self._sub_flow_autograd(xyz.view(1, 3, 5, h, w), None, interval, rows=rows)
             return depth_map + flow, prob
         feature, xyz = self._assemble_autograd(pyramids, depth_map, tplan, it, h, w)

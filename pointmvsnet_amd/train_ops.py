@@ -199,19 +199,17 @@ def bn_backward(g, y, rows, samples_per_stat, relu=True, into=None):
     partials = torch.empty((N, T, C, 2), dtype=torch.float64, device=dev)
     _lib.call("pf_bn_bwd_reduce_f32", _lib.ptr(g), _lib.ptr(y), _lib.ptr(rows), N, C, S, int(samples_per_stat),
               int(bool(relu)), _lib.ptr(partials), _lib.stream(), algo_bytes=8.0 * N * C * S)
-    G = N // samples_per_stat
-    coef = torch.empty((2, G, C), dtype=_F32, device=dev)
     if into is None:
         dgamma = torch.empty((C,), dtype=_F32, device=dev)
         dbeta = torch.empty((C,), dtype=_F32, device=dev)
     else:
         dgamma, dbeta = into
-    _lib.call("pf_bn_bwd_coeffs_f32", _lib.ptr(partials), T, C, 0, C, float(samples_per_stat) * S, N,
-              int(samples_per_stat), _lib.ptr(rows), _lib.ptr(coef), _lib.ptr(dgamma), _lib.ptr(dbeta),
-              0 if into is None else 1, _lib.stream(), algo_bytes=16.0 * N * T * C)
     dy = torch.empty_like(y)
-    _lib.call("pf_bn_bwd_apply_f32", _lib.ptr(g), _lib.ptr(y), _lib.ptr(rows), _lib.ptr(coef), _lib.ptr(dy), N, C, S,
-              int(samples_per_stat), int(bool(relu)), _lib.stream(), algo_bytes=12.0 * N * C * S)
+    # the coefficients ride in the apply pass: every block re-adds its group's few dozen partial rows (one launch less
+    # per BatchNorm in a chain of ~600)
+    _lib.call("pf_bn_bwd_apply_fused_f32", _lib.ptr(g), _lib.ptr(y), _lib.ptr(rows), _lib.ptr(partials), T,
+              float(samples_per_stat) * S, _lib.ptr(dy), N, C, S, int(samples_per_stat), int(bool(relu)), _lib.ptr(dgamma),
+              _lib.ptr(dbeta), 0 if into is None else 1, _lib.stream(), algo_bytes=12.0 * N * C * S)
     return (dy, dgamma, dbeta) if into is None else (dy, None, None)
 
 
@@ -748,13 +746,16 @@ class _EdgeChainTrain(torch.autograd.Function):
     def backward(ctx, gedges):
         edge_convs, keeps, idx, N = ctx.edge_convs, ctx.keeps, ctx.idx, ctx.N
         k = idx.shape[2]
-        g = gedges.contiguous().clone()            # a layer's data gradient is added into its input's column slice
+        g = gedges.contiguous()
+        carry = None                               # the next layer's data gradient: added to this layer's column slice
         gparams = []
         gx = None
         with torch.cuda.device(g.device):
             for m, (keep, X, ldx, K, col, wdt) in reversed(list(zip(edge_convs, keeps))):
                 C = m.conv1.weight.shape[0]
                 gy = g[:, col:col + wdt]
+                if carry is not None:
+                    gy = gy + carry
                 tg, tb = _grad_target(m.bn.weight), _grad_target(m.bn.bias)
                 grad_le, dgamma, dbeta = pointflow.edge_conv_backward(
                     keep, idx, gy, C, k, 1, N, 1, m.concat, into=(tg, tb) if (tg is not None and tb is not None) else None)
@@ -770,7 +771,7 @@ class _EdgeChainTrain(torch.autograd.Function):
                 if col == 0:
                     gx = dX
                 else:
-                    g[:, col - K:col] += dX
+                    carry = dX
                 gparams = [None if dw is None else dw[:C].reshape(m.conv1.weight.shape),
                            None if dw is None else dw[C:].reshape(m.conv2.weight.shape), dgamma, dbeta] + gparams
         return (gx, None, None) + tuple(gparams)
