@@ -541,6 +541,12 @@ int64_t pf_rows_wgrad_workspace(int64_t P, int Cg, int Cx);
 int pf_rows_wgrad_f32(const float* gr, int64_t ldg, const float* x, int64_t ldx, float* dw, int64_t P, int Cg, int Cx,
                       const float* x_scale, const float* x_shift, int64_t x_rows_per_stat, void* workspace,
                       int64_t workspace_bytes, int accumulate, void* stream);
+/* dw == NULL in the two calls above: the split partials only (workspace holds (splits, Cg, Cx, taps), splits =
+ * workspace bytes / (4 * Cg * Cx * taps)); pf_wgrad_reduce_batch_f32 then adds the partials of n layers in ONE launch,
+ * each in the same fixed order as the single call (bit-identical results): dws[i][e] (+)= sum_k parts[i][k][e]. */
+int pf_wgrad_reduce_batch_f32(const float* const* parts, float* const* dws, const int64_t* elems, const int* splits,
+                              int n, int accumulate, void* stream);
+
 
 /* Data gradient of ImageConv's 5x5 / stride 2 / pad 2 convolutions (reference networks.py:93,98,103), i.e.
  * ConvTranspose2d(5, stride 2, pad 2, output_padding 1): dy (N, Cout, Ho, Wo) -> dx (N, Cin, 2 Ho, 2 Wo);
@@ -578,7 +584,8 @@ int pf_warp_taps_frustum_f32(const float* kinv, const float* rinv, const float* 
                              const float* E, int V, int H, int W, int D, int skip_view0, uint32_t* keys, float* fxy,
                              void* stream);
 /* gval (V, N, ctot) = (2 / V) * dvar[n, c] * (f_v[n, c] - mean_v f), ctot = c1 + c2 + c3 (levels concatenated, c_l % 4
- * == 0, c2 / c3 may be 0); dvar rows (N, ldv) point-major. */
+ * == 0, c2 / c3 may be 0); dvar rows (N, ldv) point-major, or (ctot, N) channel-major with ldv = -1 (a cost volume's
+ * gradient as it is). */
 int pf_variance_grad_f32(const float* maps1, int c1, const float* maps2, int c2, const float* maps3, int c3, int V, int H,
                          int W, int64_t N, const uint32_t* keys, const float* fxy, const float* dvar, int64_t ldv,
                          int ref_override, float* gval, void* stream);

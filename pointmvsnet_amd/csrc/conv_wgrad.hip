@@ -372,11 +372,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ Gr
 
 // dw[e] = sum over the splits, in a fixed order: 16 elements x 16 slices per block; slice sl adds splits sl, sl + 16, ...
 // and the 16 slice sums are added in slice order.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
-                                                           int64_t elems, int splits, int accumulate) {
-  __shared__ float red[16][17];
+__device__ __forceinline__ void reduce_block(const float* __restrict__ part, float* __restrict__ dw, int64_t elems,
+                                             int splits, int accumulate, int64_t block, float (*red)[17]) {
   const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  const int64_t e = (int64_t)blockIdx.x * 16 + el;
+  const int64_t e = block * 16 + el;
   float s = 0.0f;
   if (e < elems) {
     int k = sl;
@@ -398,6 +397,31 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     for (int i = 0; i < 16; ++i) t += red[i][el];
     dw[e] = t;
   }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                           int64_t elems, int splits, int accumulate) {
+  __shared__ float red[16][17];
+  reduce_block(part, dw, elems, splits, accumulate, blockIdx.x, red);
+}
+
+// Up to kRedBatch layers' reductions in one launch (the training step queues a node's weight gradients and reduces
+// them together: 45 launches of ~5 us each in a dependency chain become 7).
+constexpr int kRedBatch = 16;
+struct RedBatch {
+  const float* part[kRedBatch];
+  float* dw[kRedBatch];
+  int64_t elems[kRedBatch];
+  int splits[kRedBatch];
+  int first_block[kRedBatch + 1];
+  int n, accumulate;
+};
+
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(RedBatch b) {
+  __shared__ float red[16][17];
+  int d = 0;
+  while (d + 1 < b.n && (int)blockIdx.x >= b.first_block[d + 1]) ++d;      // block-uniform
+  reduce_block(b.part[d], b.dw[d], b.elems[d], b.splits[d], b.accumulate, (int64_t)blockIdx.x - b.first_block[d], red);
 }
 
 int ilog2(int v) {
@@ -625,7 +649,7 @@ int run_plan(const float* Gr, const float* X, float* dw, const WgPlan& p, int st
     rc = p.MT == 1 ? launch_wgrad_ntw<1, 2>(Gr, X, part, p, s)
                    : (p.MT == 2 ? launch_wgrad_ntw<2, 2>(Gr, X, part, p, s) : launch_wgrad_ntw<4, 2>(Gr, X, part, p, s));
   }
-  if (rc != PF_OK) return rc;
+  if (rc != PF_OK || dw == nullptr) return rc;          // dw == NULL: the partials only (pf_wgrad_reduce_batch_f32 later)
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)pf_cdiv(elems, 16)), dim3(256), 0, s, part, dw, elems,
                      p.splits, accumulate);
   return pf_launch_status();
@@ -656,7 +680,7 @@ int pf_conv_wgrad_f32(const float* gr, const float* x, float* dw, int64_t N, int
                       void* workspace, int64_t workspace_bytes, int accumulate, void* stream) {
   PF_REQUIRE(conv_args_ok(N, Cg, Cx, Do, Ho, Wo, Di, Hi, Wi, KD, KH, KW, stride));
   PF_REQUIRE(pd >= 0 && ph >= 0 && pw >= 0 && x_samples_per_stat >= 1 && (x_scale == nullptr) == (x_shift == nullptr));
-  PF_REQUIRE(gr && x && dw);
+  PF_REQUIRE(gr && x);
   WgPlan p = make_plan(N, Cg, Cx, Do, Ho, Wo, Di, Hi, Wi, KD, KH, KW, stride, pd, ph, pw, false, 0);
   if (!p.ok) return PF_ERR_UNSUPPORTED;
   p.g.x_scale = x_scale;
@@ -676,7 +700,7 @@ int pf_rows_wgrad_f32(const float* gr, int64_t ldg, const float* x, int64_t ldx,
                       const float* x_scale, const float* x_shift, int64_t x_rows_per_stat, void* workspace,
                       int64_t workspace_bytes, int accumulate, void* stream) {
   PF_REQUIRE(P >= 1 && Cg >= 1 && Cx >= 1 && ldg >= Cg && ldx >= Cx && x_rows_per_stat >= 1);
-  PF_REQUIRE((x_scale == nullptr) == (x_shift == nullptr) && gr && x && dw);
+  PF_REQUIRE((x_scale == nullptr) == (x_shift == nullptr) && gr && x);
   if ((Cg & 3) || (Cx & 3) || (ldg & 3) || (ldx & 3)) return PF_ERR_UNSUPPORTED;
   PF_REQUIRE((((uintptr_t)gr | (uintptr_t)x | (uintptr_t)x_scale | (uintptr_t)x_shift) & 15) == 0);
   WgPlan p = make_plan(1, Cg, Cx, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, true, P);
@@ -687,6 +711,32 @@ int pf_rows_wgrad_f32(const float* gr, int64_t ldg, const float* x, int64_t ldx,
   p.g.ldg = ldg;
   p.g.ldx = ldx;
   return run_plan(gr, x, dw, p, 1, workspace, workspace_bytes, accumulate, (hipStream_t)stream);
+}
+
+int pf_wgrad_reduce_batch_f32(const float* const* parts, float* const* dws, const int64_t* elems, const int* splits,
+                              int n, int accumulate, void* stream) {
+  PF_REQUIRE(n >= 0 && (n == 0 || (parts && dws && elems && splits)));
+  for (int base = 0; base < n; base += kRedBatch) {
+    RedBatch b;
+    b.n = n - base < kRedBatch ? n - base : kRedBatch;
+    b.accumulate = accumulate;
+    int64_t blocks = 0;
+    for (int i = 0; i < b.n; ++i) {
+      PF_REQUIRE(parts[base + i] && dws[base + i] && elems[base + i] >= 1 && splits[base + i] >= 1);
+      b.part[i] = parts[base + i];
+      b.dw[i] = dws[base + i];
+      b.elems[i] = elems[base + i];
+      b.splits[i] = splits[base + i];
+      b.first_block[i] = (int)blocks;
+      blocks += pf_cdiv(elems[base + i], 16);
+      PF_REQUIRE(blocks <= INT32_MAX);
+    }
+    b.first_block[b.n] = (int)blocks;
+    hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, b);
+    const int rc = pf_launch_status();
+    if (rc != PF_OK) return rc;
+  }
+  return PF_OK;
 }
 
 }  // extern "C"

@@ -441,47 +441,51 @@ __global__ __launch_bounds__(256) void rows_affine_kernel(const float* __restric
 }
 
 // Finalize of pf_edge_backward_reduce_f32's partials (G, T, cbn, 2) = per block (sum g', sum g' * xhat): per statistic
-// set s and channel c the sums over the set's groups and blocks in a fixed order, c1 = sum0 / m, c2 = sum1 / m (m = the
-// values per statistic: points for the central half of a concat layer, pairs else), dbeta / dgamma = the sums over
-// the sets.  One thread per channel: consecutive channels are consecutive 16-byte pairs.
+// set s and channel c the sums over the set's groups and blocks in a fixed order (64 slices of the rows, then the slices
+// in order), c1 = sum0 / m, c2 = sum1 / m (m = the values per statistic: points for the central half of a concat layer,
+// pairs else), dbeta / dgamma = the sums over the sets.  Block = 4 channels x 64 slices.
 __global__ __launch_bounds__(256) void edge_bwd_coeffs_kernel(const double* __restrict__ partials, int S, int gps, int T,
                                                               int cbn, int ncentral, double m_points, double m_pairs,
                                                               float* __restrict__ c1, float* __restrict__ c2,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                               int accumulate) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= cbn) return;
+  __shared__ double2 red[256];
+  const int tid = threadIdx.x;
+  const int cl = tid & 3, sl = tid >> 2;
+  const int c = blockIdx.x * 4 + cl;
+  const bool live = c < cbn;
+  const int rows = gps * T;
   const double m = c < ncentral ? m_points : m_pairs;
   double tb = 0.0, tg = 0.0;
   for (int s = 0; s < S; ++s) {
-    const double2* p = reinterpret_cast<const double2*>(partials) + (int64_t)s * gps * T * cbn + c;
-    double r0 = 0.0, r1 = 0.0;
-    const int rows = gps * T;
-    int i = 0;
-    for (; i + 3 < rows; i += 4) {
-      const double2 a = p[(int64_t)i * cbn], b = p[(int64_t)(i + 1) * cbn];
-      const double2 d = p[(int64_t)(i + 2) * cbn], e = p[(int64_t)(i + 3) * cbn];
-      r0 += a.x;
-      r1 += a.y;
-      r0 += b.x;
-      r1 += b.y;
-      r0 += d.x;
-      r1 += d.y;
-      r0 += e.x;
-      r1 += e.y;
+    double a = 0.0, b = 0.0;
+    if (live) {
+      const double2* p = reinterpret_cast<const double2*>(partials) + (int64_t)s * rows * cbn + c;
+      for (int e = sl; e < rows; e += 64) {
+        const double2 v = p[(int64_t)e * cbn];
+        a += v.x;
+        b += v.y;
+      }
     }
-    for (; i < rows; ++i) {
-      const double2 a = p[(int64_t)i * cbn];
-      r0 += a.x;
-      r1 += a.y;
+    red[tid] = make_double2(a, b);
+    __syncthreads();
+    if (sl == 0 && live) {
+      double r0 = 0.0, r1 = 0.0;
+      for (int i = 0; i < 64; ++i) {
+        r0 += red[i * 4 + cl].x;
+        r1 += red[i * 4 + cl].y;
+      }
+      c1[(int64_t)s * cbn + c] = (float)(r0 / m);
+      c2[(int64_t)s * cbn + c] = (float)(r1 / m);
+      tb += r0;
+      tg += r1;
     }
-    c1[(int64_t)s * cbn + c] = (float)(r0 / m);
-    c2[(int64_t)s * cbn + c] = (float)(r1 / m);
-    tb += r0;
-    tg += r1;
+    __syncthreads();
   }
-  if (dgamma != nullptr) dgamma[c] = (accumulate ? dgamma[c] : 0.0f) + (float)tg;
-  if (dbeta != nullptr) dbeta[c] = (accumulate ? dbeta[c] : 0.0f) + (float)tb;
+  if (sl == 0 && live) {
+    if (dgamma != nullptr) dgamma[c] = (accumulate ? dgamma[c] : 0.0f) + (float)tg;
+    if (dbeta != nullptr) dbeta[c] = (accumulate ? dbeta[c] : 0.0f) + (float)tb;
+  }
 }
 
 }  // namespace
@@ -546,7 +550,7 @@ int pf_edge_backward_coeffs_f32(const double* partials, int G, int T, int cbn, i
   PF_REQUIRE(G >= 1 && T >= 1 && cbn >= 1 && C >= 1 && groups_per_stat >= 1 && (G % groups_per_stat) == 0);
   PF_REQUIRE(Ng >= 1 && k >= 1 && partials && c1 && c2 && (concat ? cbn == 2 * C : cbn == C));
   const double points = (double)groups_per_stat * Ng;
-  hipLaunchKernelGGL(edge_bwd_coeffs_kernel, dim3((unsigned)pf_cdiv(cbn, 256)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(edge_bwd_coeffs_kernel, dim3((unsigned)pf_cdiv(cbn, 4)), dim3(256), 0, (hipStream_t)stream,
                      partials, G / groups_per_stat, groups_per_stat, T, cbn, concat ? C : 0, points, points * k, c1, c2,
                      dgamma, dbeta, accumulate);
   return pf_launch_status();

@@ -164,7 +164,13 @@ __global__ __launch_bounds__(256) void variance_grad_kernel(WbLevels L, int H, i
     }
     s += f[v];
   }
-  const f32x4 g = *reinterpret_cast<const f32x4*>(dvar + n * ldv + 4 * q);
+  f32x4 g;
+  if (ldv > 0) {
+    g = *reinterpret_cast<const f32x4*>(dvar + n * ldv + 4 * q);
+  } else {                          // channel-major (ctot, N): the cost volume's own layout, no transposed copy
+#pragma unroll
+    for (int j = 0; j < 4; ++j) g[j] = dvar[(int64_t)(4 * q + j) * N + n];
+  }
   const float inv_v = 1.0f / (float)V;
 #pragma unroll
   for (int v = 0; v < V; ++v) {
@@ -342,8 +348,9 @@ int pf_variance_grad_f32(const float* maps1, int c1, const float* maps2, int c2,
                          int W, int64_t N, const uint32_t* keys, const float* fxy, const float* dvar, int64_t ldv,
                          int ref_override, float* gval, void* stream) {
   PF_REQUIRE(V >= 1 && V <= PF_MAX_VIEWS && H >= 1 && W >= 1 && N >= 1 && c1 >= 4 && c2 >= 0 && c3 >= 0);
-  if ((c1 & 3) || (c2 & 3) || (c3 & 3) || (ldv & 3)) return PF_ERR_UNSUPPORTED;
-  PF_REQUIRE(maps1 && (c2 == 0 || maps2) && (c3 == 0 || maps3) && keys && fxy && dvar && gval && ldv >= c1 + c2 + c3);
+  if ((c1 & 3) || (c2 & 3) || (c3 & 3) || (ldv > 0 && (ldv & 3))) return PF_ERR_UNSUPPORTED;
+  PF_REQUIRE(maps1 && (c2 == 0 || maps2) && (c3 == 0 || maps3) && keys && fxy && dvar && gval);
+  PF_REQUIRE(ldv == -1 || ldv >= c1 + c2 + c3);                    // -1: dvar is channel-major (ctot, N)
   PF_REQUIRE(!ref_override || (N % ((int64_t)H * W)) == 0);
   WbLevels L;
   L.maps[0] = maps1;

@@ -24,6 +24,7 @@ from . import _lib
 from . import pointflow
 
 import contextlib
+import ctypes
 import os
 
 _F32 = torch.float32
@@ -90,6 +91,32 @@ _WGRAD_STREAMS = {}
 
 _WGRAD_PENDING = []
 
+# Weight gradients that are ADDED into the bucket (direct_grads) leave their split partials in the workspace and queue the
+# reduction; a node's backward reduces all of its layers' partials in one launch when it returns
+# (pf_wgrad_reduce_batch_f32: the same fixed order per layer, 45 launches of ~5 us in the chain become 7).
+# PF_WGRAD_BATCH=0: one reduce launch per layer.
+WGRAD_BATCH = int(os.environ.get("PF_WGRAD_BATCH", "1"))
+_REDUCE_PENDING = []
+
+
+def _queue_reduce(work, into, elems, nbytes):
+    _REDUCE_PENDING.append((work, into, int(elems), int(nbytes // (4 * elems))))
+
+
+def _reduce_flush():
+    if not _REDUCE_PENDING:
+        return
+    pending = list(_REDUCE_PENDING)
+    del _REDUCE_PENDING[:]
+    n = len(pending)
+    parts = (ctypes.c_void_p * n)(*[p[0].data_ptr() for p in pending])
+    dws = (ctypes.c_void_p * n)(*[p[1].data_ptr() for p in pending])
+    elems = (ctypes.c_int64 * n)(*[p[2] for p in pending])
+    splits = (ctypes.c_int * n)(*[p[3] for p in pending])
+    with torch.cuda.device(pending[0][0].device):
+        _lib.call("pf_wgrad_reduce_batch_f32", parts, dws, elems, splits, n, 1, _lib.stream(),
+                  algo_bytes=4.0 * sum(p[2] * p[3] for p in pending))
+
 
 def _wgrad_stream(dev, cur):
     key = (dev.index, cur.stream_id)
@@ -149,6 +176,7 @@ def _with_packs(backward):
                 return backward(ctx, *grads)
             finally:
                 _wgrad_flush()
+                _reduce_flush()
     return wrapped
 
 
@@ -267,11 +295,14 @@ def conv_wgrad(gr, x, kernel, stride, pad, x_affine=None, x_samples_per_stat=1, 
     def launch():
         work = torch.empty((max(nbytes, 4) // 4,), dtype=_F32, device=gr.device)
         dw = torch.empty((Cg, Cx) + tuple(kernel), dtype=_F32, device=gr.device) if into is None else into   # into: dw +=
-        _lib.call("pf_conv_wgrad_f32", _lib.ptr(gr), _lib.ptr(x), _lib.ptr(dw), N, Cg, Cx, go[0], go[1], go[2], xi[0],
-                  xi[1], xi[2], k3[0], k3[1], k3[2], int(stride), p3[0], p3[1], p3[2], _lib.ptr(sc), _lib.ptr(sh),
-                  int(x_samples_per_stat), _lib.ptr(work), nbytes, 0 if into is None else 1, _lib.stream(),
+        batched = into is not None and WGRAD_BATCH and DIRECT_GRADS and not WGRAD_FORK and into.is_contiguous()
+        _lib.call("pf_conv_wgrad_f32", _lib.ptr(gr), _lib.ptr(x), None if batched else _lib.ptr(dw), N, Cg, Cx, go[0],
+                  go[1], go[2], xi[0], xi[1], xi[2], k3[0], k3[1], k3[2], int(stride), p3[0], p3[1], p3[2], _lib.ptr(sc),
+                  _lib.ptr(sh), int(x_samples_per_stat), _lib.ptr(work), nbytes, 0 if into is None else 1, _lib.stream(),
                   algo_bytes=4.0 * (gr.numel() + x.numel()) + 4.0 * dw.numel(),
                   flops=2.0 * N * go[0] * go[1] * go[2] * taps * Cg * Cx)
+        if batched:
+            _queue_reduce(work, into, Cg * Cx * taps, nbytes)
         return dw if into is None else None
 
     return _wgrad_issue(launch, into, gr, x, sc, sh)
@@ -289,10 +320,13 @@ def rows_wgrad(gr, x, Cg, Cx, x_affine=None, x_rows_per_stat=None, into=None):
     def launch():
         work = torch.empty((max(nbytes, 4) // 4,), dtype=_F32, device=gr.device)
         dw = torch.empty((Cg, Cx), dtype=_F32, device=gr.device) if into is None else into
-        _lib.call("pf_rows_wgrad_f32", _lib.ptr(gr), int(gr.stride(0)), _lib.ptr(x), int(x.stride(0)), _lib.ptr(dw), P,
-                  int(Cg), int(Cx), _lib.ptr(sc), _lib.ptr(sh), int(x_rows_per_stat or P), _lib.ptr(work), nbytes,
-                  0 if into is None else 1, _lib.stream(), algo_bytes=4.0 * P * (Cg + Cx) + 4.0 * Cg * Cx,
-                  flops=2.0 * P * Cg * Cx)
+        batched = into is not None and WGRAD_BATCH and DIRECT_GRADS and not WGRAD_FORK and into.is_contiguous()
+        _lib.call("pf_rows_wgrad_f32", _lib.ptr(gr), int(gr.stride(0)), _lib.ptr(x), int(x.stride(0)),
+                  None if batched else _lib.ptr(dw), P, int(Cg), int(Cx), _lib.ptr(sc), _lib.ptr(sh),
+                  int(x_rows_per_stat or P), _lib.ptr(work), nbytes, 0 if into is None else 1, _lib.stream(),
+                  algo_bytes=4.0 * P * (Cg + Cx) + 4.0 * Cg * Cx, flops=2.0 * P * Cg * Cx)
+        if batched:
+            _queue_reduce(work, into, int(Cg) * int(Cx), nbytes)
         return dw if into is None else None
 
     return _wgrad_issue(launch, into, gr, x, sc, sh)
@@ -989,8 +1023,9 @@ def sort_pairs(keys, nkeys):
     return order, start
 
 
-def _warp_backward(levels_cl, V, H, W, N, keys, fxy, dvar, ref_override, v0):
-    """gval + sorted gather: dmaps (V, H, W, ctot) channel-last (views < v0 left to the caller), and gval (V, N, ctot)."""
+def _warp_backward(levels_cl, V, H, W, N, keys, fxy, dvar, ref_override, v0, planar=False):
+    """gval + sorted gather: dmaps (V, H, W, ctot) channel-last (views < v0 left to the caller), and gval (V, N, ctot).
+    dvar: (N, ctot) point-major rows, or (ctot, N) with ``planar``."""
     dev = dvar.device
     cs = [int(l.shape[3]) for l in levels_cl] + [0, 0]
     ctot = sum(cs)
@@ -998,7 +1033,7 @@ def _warp_backward(levels_cl, V, H, W, N, keys, fxy, dvar, ref_override, v0):
     order, start = sort_pairs(keys, V * (H + 1) * (W + 1))
     gval = torch.empty((V, N, ctot), dtype=_F32, device=dev)
     _lib.call("pf_variance_grad_f32", _lib.ptr(lv[0]), cs[0], _lib.ptr(lv[1]), cs[1], _lib.ptr(lv[2]), cs[2], V, H, W, N,
-              _lib.ptr(keys), _lib.ptr(fxy), _lib.ptr(dvar), int(dvar.stride(0)), int(bool(ref_override)),
+              _lib.ptr(keys), _lib.ptr(fxy), _lib.ptr(dvar), -1 if planar else int(dvar.stride(0)), int(bool(ref_override)),
               _lib.ptr(gval), _lib.stream(), algo_bytes=4.0 * (V * H * W * ctot + N * ctot * (1 + V)) + 12.0 * V * N)
     dmaps = torch.empty((V, H, W, ctot), dtype=_F32, device=dev)
     _lib.call("pf_warp_gather_f32", _lib.ptr(gval), _lib.ptr(fxy), _lib.ptr(order), _lib.ptr(start), V, int(v0), H, W, ctot,
@@ -1094,8 +1129,8 @@ class _CoarseVolumeTrain(torch.autograd.Function):
             fxy = torch.empty((V * N, 2), dtype=_F32, device=dev)
             _lib.call("pf_warp_taps_frustum_f32", _lib.ptr(kinv), _lib.ptr(rinv), _lib.ptr(t), _lib.ptr(depths), _lib.ptr(K),
                       _lib.ptr(E), V, FH, FW, D, 1, _lib.ptr(keys), _lib.ptr(fxy), _lib.stream(), algo_bytes=12.0 * V * N)
-            dvar = dcost.reshape(C, N).t().contiguous()                      # point-major rows (N, C)
-            dmaps, gval = _warp_backward([cl], V, FH, FW, N, keys, fxy, dvar, True, 1)
+            dvar = dcost.reshape(C, N).contiguous()                           # channel-major as it is: no transposed copy
+            dmaps, gval = _warp_backward([cl], V, FH, FW, N, keys, fxy, dvar, True, 1, planar=True)
             dmaps[0] = gval[0].view(D, FH * FW, C).sum(dim=0).view(FH, FW, C)   # the reference view: a sum over depth
             out = dmaps.permute(0, 3, 1, 2).contiguous()
         return out, None, None, None, None, None, None
