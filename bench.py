@@ -339,8 +339,10 @@ def main():
                 graphed_train = GraphedTrainStep(trainer, scenes[0], img_scales, inter_scales)
             except Exception as exc:          # say so, do not hide it
                 sys.stderr.write("bench.py: hipGraph capture of the training step failed (%r); running eager\n" % (exc,))
+        from pointmvsnet_amd import model as _model
         train_execution = "eager autograd" if graphed_train is None else \
-            "hipGraph replay of zero_grad + forward + loss + backward; all-reduce + RMSprop step eager"
+            ("hipGraph replay of zero_grad + forward + loss + backward%s; all-reduce + RMSprop step eager"
+             % (" (flow tower forward / backward on a second stream)" if _model.TRAIN_FORK else ""))
         args.eager = True                                                       # (no GraphedForward below)
 
         def eager_step(i):
