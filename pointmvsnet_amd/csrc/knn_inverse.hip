@@ -140,8 +140,8 @@ __global__ __launch_bounds__(256) void keys_fill_kernel(const uint32_t* __restri
 
 // Lists sorted ascending by pair id, one 64-lane wave per list when lists are long (the coarse cost volume puts ~D
 // points on every texel cell): rank of an element = number of smaller ids in its list (ids are distinct), computed
-// by all lanes against a copy of the list in LDS; lists longer than kSortCap fall back to chunks of rank counting
-// against global memory.  Result independent of the arrival order of keys_fill_kernel.
+// by all lanes against a copy of the list in LDS; lists longer than kSortCap are sorted in chunks and merged (bounded
+// work for hub rows).  Result independent of the arrival order of keys_fill_kernel.
 constexpr int kSortCap = 1024;
 __global__ __launch_bounds__(256) void sort_lists_wave_kernel(const uint32_t* __restrict__ start, int64_t rows,
                                                               uint32_t* __restrict__ order,
@@ -162,16 +162,59 @@ __global__ __launch_bounds__(256) void sort_lists_wave_kernel(const uint32_t* __
       for (uint32_t j = 0; j < len; ++j) r += buf[wave][j] < v ? 1u : 0u;
       order[t0 + r] = v;
     }
-  } else {                                   // (degenerate geometry: thousands of points on one cell)
-    for (uint32_t i = lane; i < len; i += 64) scratch[t0 + i] = order[t0 + i];
-    __builtin_amdgcn_wave_barrier();
-    __threadfence_block();
-    for (uint32_t i = lane; i < len; i += 64) {
-      const uint32_t v = scratch[t0 + i];
-      uint32_t r = 0;
-      for (uint32_t j = 0; j < len; ++j) r += scratch[t0 + j] < v ? 1u : 0u;
-      order[t0 + r] = v;
+  } else {
+    // Degenerate geometry (thousands of pairs on one row: hub points, clamped out-of-range indices).  Bounded work:
+    // chunks of kSortCap sorted by rank counting in LDS, then log2(len / kSortCap) merge passes between `scratch` and
+    // `order` in which every element finds its place by a binary search in the partner run: O(len log^2 len / 64) for
+    // the wave, where a rank count over the whole list is O(len^2 / 64) -- 1.6 M pairs on one row: ~1e7 instead of
+    // ~4e10 steps.  (volatile: a pass reads what other lanes of this wave wrote in the pass before.)
+    volatile uint32_t* ord = order + t0;
+    volatile uint32_t* scr = scratch + t0;
+    for (uint32_t c0 = 0; c0 < len; c0 += (uint32_t)kSortCap) {
+      const uint32_t cl = min((uint32_t)kSortCap, len - c0);
+      for (uint32_t i = lane; i < cl; i += 64) buf[wave][i] = ord[c0 + i];
+      __builtin_amdgcn_wave_barrier();
+      for (uint32_t i = lane; i < cl; i += 64) {
+        const uint32_t v = buf[wave][i];
+        uint32_t r = 0;
+        for (uint32_t j = 0; j < cl; ++j) r += buf[wave][j] < v ? 1u : 0u;
+        scr[c0 + r] = v;
+      }
+      __builtin_amdgcn_wave_barrier();
     }
+    volatile uint32_t* src = scr;
+    volatile uint32_t* dst = ord;
+    for (uint32_t width = (uint32_t)kSortCap; width < len; width <<= 1) {
+      __threadfence();
+      __builtin_amdgcn_wave_barrier();
+      for (uint32_t i = lane; i < len; i += 64) {
+        const uint32_t run = i / width;
+        const uint32_t own0 = run * width, oth0 = (run ^ 1u) * width;
+        const uint32_t v = src[i];
+        uint32_t pos = i;
+        if (oth0 < len) {
+          const uint32_t on = min(width, len - oth0);
+          uint32_t lo = 0, hi = on;                       // number of partner elements smaller than v (ids are distinct)
+          while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (src[oth0 + mid] < v) {
+              lo = mid + 1;
+            } else {
+              hi = mid;
+            }
+          }
+          pos = min(own0, oth0) + (i - own0) + lo;
+        }
+        dst[pos] = v;
+      }
+      volatile uint32_t* t = src;
+      src = dst;
+      dst = t;
+    }
+    __threadfence();
+    __builtin_amdgcn_wave_barrier();
+    if (src != ord)
+      for (uint32_t i = lane; i < len; i += 64) ord[i] = src[i];
   }
 }
 

@@ -503,6 +503,25 @@ def test_knn_inverse_lists_equal_a_stable_argsort(dev, G, Ng, k):
     assert again[0].shape == order.shape
 
 
+@pytest.mark.parametrize("Ng,k,hub", [(3000, 16, "all"), (5000, 16, "most"), (700, 3, "all")])
+def test_knn_inverse_hub_rows_are_sorted_in_bounded_work(dev, Ng, k, hub):
+    """Every pair (or 90 % of them, the rest random) names ONE row -- all-equal indices, or out-of-range indices
+    clamped to a border row: a list of 2 100 .. 48 000 ids, far beyond the LDS rank sort's 1 024.  The chunk + merge
+    path must give the stable argsort exactly (round 3's one-thread insertion sort was quadratic here: ADVICE r3)."""
+    gen = torch.Generator().manual_seed(Ng + k)
+    idx = torch.full((1, Ng, k), Ng + 9, dtype=torch.int64)             # clamped to Ng - 1 by the forward
+    if hub == "most":
+        mask = torch.rand(1, Ng, k, generator=gen) < 0.1
+        idx[mask] = torch.randint(0, Ng, (int(mask.sum()),), generator=gen)
+    order, start = pointflow.knn_inverse(idx.to(dev).contiguous(), 1, Ng, k)
+    torch.cuda.synchronize()
+    keys = idx.clamp(0, Ng - 1).reshape(-1).numpy()
+    want_order = np.argsort(keys, kind="stable")
+    want_start = np.searchsorted(keys[want_order], np.arange(Ng + 1), side="left")
+    assert np.array_equal(start.cpu().numpy().astype(np.int64), want_start)
+    assert np.array_equal(order.cpu().numpy().astype(np.int64), want_order)
+
+
 @pytest.mark.parametrize("cls,cin,cout", [(EdgeConvNoC, 40, 32), (EdgeConv, 32, 32), (EdgeConv, 64, 64)])
 def test_edgeconv_backward_is_bit_reproducible_and_matches_the_scatter(dev, cls, cin, cout, monkeypatch):
     """The fused node's backward with the de rows gathered over the inverted index lists (default): two runs give
