@@ -636,6 +636,11 @@ int pf_masked_mae_f32(const float* pred, const float* gt, const float* interval,
                       float weight, float* loss, float* coef, void* stream);
 int pf_masked_mae_backward_f32(const float* pred, const float* gt, const float* coef, const float* gloss, int B, int h,
                                int w, int H, int W, float* gpred, void* stream);
+/* torch.optim.RMSprop's update (reference solver.py:17-52; no momentum, not centered) on flat float32 buffers of n
+ * elements: g' = g + wd[i] * p (wd NULL: no weight decay); sq = alpha * sq + (1 - alpha) * g'^2;
+ * p -= lr * g' / (sqrt(sq) + eps).  alpha is taken as the float nearest to the caller's double: pass (float)alpha. */
+int pf_rmsprop_f32(float* p, const float* g, float* sq, const float* wd, int64_t n, float lr, float alpha, float eps,
+                   void* stream);
 
 #ifdef __cplusplus
 }

@@ -101,6 +101,7 @@ PROTOTYPES = {
     "pf_flow_head_train_f32": ([_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp], _i),
     "pf_flow_head_backward_workspace": ([_i64], _i64),
     "pf_flow_head_backward_f32": ([_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i, _vp, _i64, _vp], _i),
+    "pf_rmsprop_f32": ([_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _vp], _i),
     "pf_masked_mae_f32": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp], _i),
     "pf_masked_mae_backward_f32": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp], _i),
     "pf_wgrad_reduce_batch_f32": ([_vp, _vp, _vp, _vp, _i, _i, _vp], _i),

@@ -8,6 +8,9 @@
 //   masked MAE loss        reference networks.py:170-181 (MAELoss) over the nearest-resized ground truth
 //                          (model.py:308-339): sum_b [ sum valid |pred - gt| / interval_b / (count_b + 1e-7) ] * weight.
 //
+//   RMSprop                reference solver.py:17-52 on ONE flat parameter buffer: one launch for PyTorch's five
+//                          multi-tensor launches over 115 tensors (the step's only work outside its hipGraph).
+//
 // All reductions are float64 in a fixed order (no atomics): the step stays bit-reproducible.  Every kernel here moves a
 // few hundred KB: they are launch-latency items, written to be ONE dependency-chain link each.
 #include "pf_common.h"
@@ -226,9 +229,50 @@ __global__ __launch_bounds__(256) void masked_mae_bwd_kernel(const float* __rest
   gpred[(int64_t)b * h * w + i] = g != 0.0f ? gloss[0] * coef[b] * sgn : 0.0f;
 }
 
+// ---- RMSprop on the flat parameter / gradient / square-average buffers ------------------------------------------------
+// torch.optim.RMSprop (reference solver.py:17-52; the foreach form PyTorch runs on a GPU: five multi-tensor launches):
+//   g' = g + wd * p;  sq = sq * alpha + (1 - alpha) * (g' * g');  p = p + (-lr) * (g' / (sqrt(sq) + eps)).
+__global__ __launch_bounds__(256) void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                      float* __restrict__ sq, const float* __restrict__ wd, int64_t n,
+                                                      float neg_lr, float alpha, float one_minus_alpha, float eps) {
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  if (i + 4 <= n) {
+    float4 pv = *reinterpret_cast<float4*>(p + i), sv = *reinterpret_cast<float4*>(sq + i);
+    const float4 gv = *reinterpret_cast<const float4*>(g + i);
+    float pa[4] = {pv.x, pv.y, pv.z, pv.w}, sa[4] = {sv.x, sv.y, sv.z, sv.w}, ga[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gg = wd != nullptr ? ga[j] + wd[i + j] * pa[j] : ga[j];
+      sa[j] = sa[j] * alpha + one_minus_alpha * (gg * gg);
+      pa[j] = pa[j] + neg_lr * (gg / (sqrtf(sa[j]) + eps));
+    }
+    *reinterpret_cast<float4*>(p + i) = make_float4(pa[0], pa[1], pa[2], pa[3]);
+    *reinterpret_cast<float4*>(sq + i) = make_float4(sa[0], sa[1], sa[2], sa[3]);
+  } else {
+    for (int64_t e = i; e < n; ++e) {
+      const float gg = wd != nullptr ? g[e] + wd[e] * p[e] : g[e];
+      const float s = sq[e] * alpha + one_minus_alpha * (gg * gg);
+      sq[e] = s;
+      p[e] = p[e] + neg_lr * (gg / (sqrtf(s) + eps));
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int pf_rmsprop_f32(float* p, const float* g, float* sq, const float* wd, int64_t n, float lr, float alpha, float eps,
+                   void* stream) {
+  PF_REQUIRE(n >= 0 && lr >= 0.0f && alpha >= 0.0f && eps >= 0.0f);
+  if (n == 0) return PF_OK;
+  PF_REQUIRE(p && g && sq && ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)sq)) & 15) == 0);
+  const float one_minus_alpha = (float)(1.0 - (double)alpha);
+  hipLaunchKernelGGL(rmsprop_kernel, dim3((unsigned)pf_cdiv(pf_cdiv(n, 4), 256)), dim3(256), 0, (hipStream_t)stream, p, g,
+                     sq, wd, n, -lr, alpha, one_minus_alpha, eps);
+  return pf_launch_status();
+}
 
 int pf_softargmin_backward_f32(const float* cost, const float* params, const float* depth, const float* gdepth,
                                float* gcost, int64_t B, int64_t D, int64_t HW, void* stream) {

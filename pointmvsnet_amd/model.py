@@ -554,7 +554,7 @@ class PointMVSNet(nn.Module):
             object.__setattr__(self, "_train_packs", packs)
         with torch.cuda.device(img_list.device):
             packs.run()
-        with train_ops.use_packs(packs):
+        with train_ops.use_packs(packs), pointflow.deferred_counters():
             return self._run_autograd(tplan, img_list, isFlow, True)
 
     def _fork_stream(self, dev):

@@ -9,6 +9,7 @@ its own kNN and its own BatchNorm batch statistics (reference model.py:231-267);
 groups of one batched launch (G = r*r, one stat group per group).  The nn.Module API of EdgeConv uses
 G = batch size with all groups pooled into one stat group (BatchNorm2d pools over the batch).
 """
+import contextlib
 import ctypes
 
 import torch
@@ -446,7 +447,25 @@ def bump_counter(bn, n):
         _pending_list(bn.num_batches_tracked.device).append((bn.num_batches_tracked, int(n)))
 
 
+_defer_flush = [0]
+
+
+@contextlib.contextmanager
+def deferred_counters():
+    """Inside: ``flush_counters()`` calls do nothing; ONE flush when the outermost context exits (the training forward:
+    eight nodes each flushed their own BatchNorm counters, eight tiny launches in the step's chain)."""
+    _defer_flush[0] += 1
+    try:
+        yield
+    finally:
+        _defer_flush[0] -= 1
+        if _defer_flush[0] == 0:
+            flush_counters()
+
+
 def flush_counters():
+    if _defer_flush[0] > 0:
+        return
     flush_lazy_stats()
     for pending in list(getattr(_pending, "table", {}).values()):
         if pending:

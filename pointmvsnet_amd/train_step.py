@@ -21,12 +21,80 @@ def param_groups(module, weight_decay):
     return [dict(params=decay, weight_decay=weight_decay), dict(params=no_decay, weight_decay=0.0)]
 
 
+class FlatRMSprop(object):
+    """torch.optim.RMSprop(param_groups(model, weight_decay), lr, alpha) (reference solver.py:17-52) as ONE launch per
+    step (pf_rmsprop_f32): the parameters move into one flat float32 buffer -- every ``p.data`` becomes a view of it, in
+    the bucket's order, so parameter i's gradient sits at the same offset of ``bucket.flat`` -- beside a flat
+    square-average buffer.  PyTorch's foreach form is five multi-tensor launches over 115 tensors plus their host-side
+    grouping, the only per-step work outside the captured graph.  ``step()`` updates in place; ``state_dict()`` /
+    ``load_state_dict()`` carry the square averages per parameter index like torch's optimizer state."""
+
+    def __init__(self, bucket, named_parameters, lr=1e-3, alpha=0.9, eps=1e-8, weight_decay=0.0):
+        self.bucket, self.lr, self.alpha, self.eps = bucket, float(lr), float(alpha), float(eps)
+        params = bucket.params
+        dev = bucket.flat.device
+        self.flat = torch.empty_like(bucket.flat)
+        self.square_avg = torch.zeros_like(bucket.flat)
+        names = {id(p): n for n, p in named_parameters}
+        self.wd = None
+        if weight_decay != 0.0:
+            self.wd = torch.zeros_like(bucket.flat)
+        offset = 0
+        with torch.no_grad():
+            for p in params:
+                n = p.numel()
+                self.flat[offset:offset + n].copy_(p.detach().reshape(-1))
+                p.data = self.flat[offset:offset + n].view(p.shape)          # (packed-weight caches re-pack: new storage)
+                if self.wd is not None and ".bn." not in names.get(id(p), ""):
+                    self.wd[offset:offset + n] = weight_decay
+                offset += n
+        self.device = dev
+
+    def attached(self):
+        base = self.flat.untyped_storage().data_ptr()
+        return all(p.data.untyped_storage().data_ptr() == base for p in self.bucket.params)
+
+    def step(self):
+        if not self.attached():
+            raise RuntimeError("FlatRMSprop: a parameter's storage was replaced (module.to() / load on a new tensor?); "
+                               "build a new TrainStep")
+        from . import _lib
+        with torch.cuda.device(self.device):
+            _lib.call("pf_rmsprop_f32", _lib.ptr(self.flat), _lib.ptr(self.bucket.flat), _lib.ptr(self.square_avg),
+                      _lib.ptr(self.wd), self.flat.numel(), self.lr, self.alpha, self.eps, _lib.stream(),
+                      algo_bytes=20.0 * self.flat.numel())
+        # torch's optimizers update parameters through in-place ops, which the packed-weight caches watch through the
+        # version counter; the flat kernel writes behind autograd's back, so tick the counters
+        for p in self.bucket.params:
+            torch.autograd.graph.increment_version(p)
+
+    def state_dict(self):
+        out, offset = {}, 0
+        for i, p in enumerate(self.bucket.params):
+            n = p.numel()
+            out[i] = {"square_avg": self.square_avg[offset:offset + n].view(p.shape).clone()}
+            offset += n
+        return {"state": out, "lr": self.lr, "alpha": self.alpha, "eps": self.eps}
+
+    def load_state_dict(self, sd):
+        offset = 0
+        for i, p in enumerate(self.bucket.params):
+            n = p.numel()
+            if i in sd["state"]:
+                self.square_avg[offset:offset + n].copy_(sd["state"][i]["square_avg"].reshape(-1))
+            offset += n
+
+
 class TrainStep(object):
     def __init__(self, model, valid_threshold=8.0, lr=1e-3, alpha=0.9, weight_decay=0.0, group=None):
         self.model = model
         self.loss_fn = PointMVSNetLoss(valid_threshold)            # reference config.py MODEL.VALID_THRESHOLD
         self.bucket = distributed.GradBucket(model)
-        self.optimizer = torch.optim.RMSprop(param_groups(model, weight_decay), lr=lr, alpha=alpha)
+        if self.bucket.flat.is_cuda:
+            self.optimizer = FlatRMSprop(self.bucket, list(model.named_parameters()), lr=lr, alpha=alpha,
+                                         weight_decay=weight_decay)
+        else:                                                      # (CPU: the gloo tests of the bucket / step logic)
+            self.optimizer = torch.optim.RMSprop(param_groups(model, weight_decay), lr=lr, alpha=alpha)
         self.group = group
 
     def __call__(self, batch, img_scales, inter_scales, is_flow=True):

@@ -500,6 +500,52 @@ def test_train_step_runs_and_updates_through_the_bucket(dev):
     assert torch.isfinite(l2) and float(l2) != float(l1)
 
 
+@pytest.mark.parametrize("weight_decay", [0.0, 1e-4])
+def test_flat_rmsprop_equals_torch_rmsprop(dev, weight_decay):
+    """train_step.FlatRMSprop (one pf_rmsprop_f32 launch over the flat parameter / gradient / square-average buffers)
+    against torch.optim.RMSprop on the reference's parameter groups (solver.py:17-52: no decay on '.bn.' names) over
+    three steps of seeded gradients: every parameter within float32 rounding (the two evaluate the same formula; ATen's
+    kernels may contract a multiply-add where ours, built with -ffp-contract=off, does not), parameters stay views
+    of the flat buffer, and the state round-trips."""
+    from pointmvsnet_amd import distributed
+    from pointmvsnet_amd.train_step import FlatRMSprop, param_groups
+    net_a, net_b = PointMVSNet(), PointMVSNet()
+    synthetic.seed_weights(net_a, seed=3)
+    net_b.load_state_dict(net_a.state_dict())
+    net_a, net_b = net_a.to(dev), net_b.to(dev)
+    bucket = distributed.GradBucket(net_a)
+    flat = FlatRMSprop(bucket, list(net_a.named_parameters()), lr=1e-3, alpha=0.9, weight_decay=weight_decay)
+    ref = torch.optim.RMSprop(param_groups(net_b, weight_decay), lr=1e-3, alpha=0.9)
+    assert flat.attached() and bucket.attached()
+    for p, q in zip(net_a.parameters(), net_b.parameters()):
+        assert torch.equal(p.detach(), q.detach())
+    gen = torch.Generator().manual_seed(11)
+    worst = 0.0
+    for it in range(3):
+        for p, q in zip(net_a.parameters(), net_b.parameters()):
+            g = (torch.randn(p.shape, generator=gen) * (10.0 ** float(torch.randint(-4, 1, (1,), generator=gen)))).to(dev)
+            p.grad.copy_(g)
+            q.grad = g.clone()
+        versions = [p._version for p in net_a.parameters()]
+        flat.step()
+        ref.step()
+        assert all(p._version > v for p, v in zip(net_a.parameters(), versions))
+        for (name, p), q in zip(net_a.named_parameters(), net_b.parameters()):
+            err = float((p.detach() - q.detach()).abs().max() / q.detach().abs().max().clamp_min(1e-12))
+            worst = max(worst, err)
+            assert err < 2e-6, (it, name, err)
+    report("flat_rmsprop_wd%g" % weight_decay, worst_param_rel=worst)
+    assert flat.attached()
+    sd = flat.state_dict()
+    sq_ref = [ref.state[q]["square_avg"] for q in net_b.parameters()]
+    for i, sq in enumerate(sq_ref):
+        assert float((sd["state"][i]["square_avg"] - sq).abs().max() / sq.abs().max().clamp_min(1e-20)) < 2e-6
+    saved = flat.square_avg.clone()
+    flat.square_avg.zero_()
+    flat.load_state_dict(sd)
+    assert torch.equal(flat.square_avg, saved)
+
+
 def test_train_step_gradient_is_bit_reproducible(dev):
     """Round 4: no float atomics and no library split-K solver is left in the step -- every convolution / BatchNorm /
     warp gradient is a fixed-order sum (train_ops.py) -- so two steps from the same state give the same 698 936
