@@ -43,8 +43,11 @@ FUSED_TRAIN = 1
 # 1: the training step runs the flow tower (forward AND, through autograd's stream bookkeeping, backward) on a second
 # stream beside the coarse stage -- the two are independent until the first PointFlow iteration (reference
 # model.py:71-150), and most of a training step's ~700 launches are too small to fill 256 CUs alone.  Inside a captured
-# step the fork / join become graph dependencies.  PF_TRAIN_FORK=0: one stream (the A/B arm).
-TRAIN_FORK = int(os.environ.get("PF_TRAIN_FORK", "1"))
+# step the fork / join become graph dependencies.  Levels: 0 = one stream (the A/B arm); 1 = the flow tower; 2 = + the
+# pyramid-level gradients of the flow-feature nodes (only the flow tower's backward consumes them: off the chain that
+# the previous iteration and the coarse stage wait on: +5 % same-box, the default); 3 = + VolumeConv's conv0_1 branch in
+# the backward (-0.4 %: `profiles/r04c_train_streams.md`).
+TRAIN_FORK = int(os.environ.get("PF_TRAIN_FORK", "2"))
 _FORK_STREAMS = {}
 
 
@@ -554,7 +557,8 @@ class PointMVSNet(nn.Module):
             object.__setattr__(self, "_train_packs", packs)
         with torch.cuda.device(img_list.device):
             packs.run()
-        with train_ops.use_packs(packs), pointflow.deferred_counters():
+        side = self._fork_stream(img_list.device) if (TRAIN_FORK and isFlow and img_list.is_cuda) else None
+        with train_ops.use_packs(packs), pointflow.deferred_counters(), train_ops.side_stream(side, TRAIN_FORK):
             return self._run_autograd(tplan, img_list, isFlow, True)
 
     def _fork_stream(self, dev):
@@ -635,12 +639,15 @@ class PointMVSNet(nn.Module):
                 main.wait_stream(side)                                       # the join; backward mirrors it
                 for n in names:
                     levels[n].record_stream(main)
+            # (the fused flow-feature nodes take the level tensors themselves: with a view in between, autograd would add
+            # the two iterations' level gradients on the view node's stream, not on the tower's)
             pyramids = {n: levels[n].unsqueeze(0) for n in names}
+            pyramids["levels"] = [levels[n] for n in names]
         else:
             per_view = [self.flow_img_conv(img_list[:, v]) for v in range(V)]
             pyramids = {n: torch.stack([pv[n] for pv in per_view], dim=1) for n in names}   # (B,V,c,h_l,w_l)
         if isTest:
-            pyramids = {n: p.detach() for n, p in pyramids.items()}
+            pyramids = {n: ([t.detach() for t in p] if isinstance(p, list) else p.detach()) for n, p in pyramids.items()}
         for it, img_scale in enumerate(img_scales):
             if isTest:
                 pred_depth = pred_depth.detach()
@@ -701,7 +708,7 @@ class PointMVSNet(nn.Module):
         interval, K_flow, ext = tplan.d("interval%d" % it), tplan.d("K_flow%d" % it), tplan.d("ext")
         if depth_map.shape[2] != h:
             depth_map = F.interpolate(depth_map, (h, w), mode="nearest")
-        levels = [pyramids[n].squeeze(0) for n in ("conv1", "conv2", "conv3")] if (fused and B == 1) else None
+        levels = pyramids.get("levels") if (fused and B == 1) else None
         if levels is not None and train_ops.flow_features_supported(levels, depth_map.view(h, w), h, w):
             # feature assembly (5 hypotheses x 3 levels: resize, warp, variance, xyz) as ONE node on the inference kernels,
             # backward without atomics (csrc/warp_bwd.hip); gradients reach the pyramid levels and the prior depth

@@ -79,12 +79,34 @@ def _grad_target(p):
     return g
 
 
+# The training forward's second stream (model.TRAIN_FORK): set by the model while a fused training forward that forked
+# the flow tower is being built, read by the nodes whose backward has work that only the flow tower's backward consumes
+# (level 2: the pyramid-level gradients of _FlowFeaturesTrain) or that the rest of the node does not wait for (level 3:
+# VolumeConv's conv0_1 branch).  None: everything on the node's own stream.
+_SIDE = {"stream": None, "level": 0}
+
+
+@contextlib.contextmanager
+def side_stream(stream, level):
+    saved = dict(_SIDE)
+    _SIDE["stream"], _SIDE["level"] = stream, int(level)
+    try:
+        yield
+    finally:
+        _SIDE.update(saved)
+
+
+def _on_side(min_level):
+    return _SIDE["stream"] if _SIDE["level"] >= min_level else None
+
+
 # Weight gradients have no consumer inside the step once they are added straight into the bucket, so they CAN leave the
 # dependency chain  dy -> data gradient -> BatchNorm backward -> dy'  for a second stream per compute stream
 # (PF_WGRAD_FORK=1: one fork per layer, =2: one fork per node, joined by join_wgrad_streams() after backward).
 # Measured same-box at BASELINE config 4 (profiles/r04c_train_streams.md): alone +5.5 % / +6.7 %, but beside the
-# flow-tower fork of model.TRAIN_FORK (+8.5 .. +11.8 %) they take throughput away again (-2 %): the weight-gradient
-# kernels fill the chip by themselves, and every fork adds cross-queue dependencies to the graph.  Default 0: in line.
+# flow-tower fork of model.TRAIN_FORK (+8.5 .. +11.8 %) they take throughput away again (-2 %; queued on the flow tower's
+# own stream instead: -5 %): the weight-gradient kernels fill the chip by themselves, and every fork adds cross-queue
+# dependencies to the graph.  Default 0: in line.
 WGRAD_FORK = int(os.environ.get("PF_WGRAD_FORK", "0"))
 _WGRAD_STREAMS = {}
 
@@ -114,6 +136,9 @@ def _reduce_flush():
     elems = (ctypes.c_int64 * n)(*[p[2] for p in pending])
     splits = (ctypes.c_int * n)(*[p[3] for p in pending])
     with torch.cuda.device(pending[0][0].device):
+        cur = torch.cuda.current_stream()
+        for p in pending:                      # (a partial may have been written on the side stream)
+            p[0].record_stream(cur)
         _lib.call("pf_wgrad_reduce_batch_f32", parts, dws, elems, splits, n, 1, _lib.stream(),
                   algo_bytes=4.0 * sum(p[2] * p[3] for p in pending))
 
@@ -652,6 +677,7 @@ class _VolumeTrain(torch.autograd.Function):
             rec["conv6_2"] = (s7, None, None)
             pointflow.flush_counters()
         ctx.vc, ctx.rec = vc, rec
+        ctx.side = _on_side(3)
         return out
 
     @staticmethod
@@ -691,6 +717,16 @@ class _VolumeTrain(torch.autograd.Function):
             g7 = torch.empty((1, w62.shape[1], D, H, W), dtype=_F32, device=g.device)
             _lib.call("pf_conv3d_k3_c1_f32", _lib.ptr(g), _lib.ptr(wf), _lib.ptr(g7), 1, int(w62.shape[1]), D, H, W,
                       _lib.stream(), algo_bytes=4.0 * (1 + w62.shape[1]) * D * H * W)
+            # conv0_1's branch (full resolution: the node's largest weight gradient and two 8 -> 32 data-gradient launches)
+            # needs only g7 and is needed only at the very end: beside the U-Net chain on the second stream when there is one
+            side = ctx.side
+            cur = torch.cuda.current_stream(gout.device)
+            if side is not None:
+                side.wait_stream(cur)
+                g7.record_stream(side)
+                with torch.cuda.stream(side):
+                    dy01 = conv_back("conv0_1", g7, 1)
+                    gx01 = conv3d_dgrad_flip(dy01, vc.conv0_1.conv.weight)
             # decoder: a ConvTranspose3d's data gradient is the stride-2 convolution with its weight read (Cout', Cin')
             dy60 = deconv_back("conv6_0", g7)
             g6 = _conv3d_k3_w(dy60, vc.conv6_0.conv.weight, 2)                        # -> dz50, dz11
@@ -710,8 +746,13 @@ class _VolumeTrain(torch.autograd.Function):
             g10 = g10 + conv3d_dgrad_flip(dy11, vc.conv1_1.conv.weight)
             dy10 = conv_back("conv1_0", g10, 2)
             gx = pointflow.deconv3d_k3s2(dy10, None, vc.conv1_0.conv.weight.detach(), False)[0]
-            dy01 = conv_back("conv0_1", g7, 1)
-            gx = gx + conv3d_dgrad_flip(dy01, vc.conv0_1.conv.weight)
+            if side is not None:
+                cur.wait_stream(side)
+                gx01.record_stream(cur)
+            else:
+                dy01 = conv_back("conv0_1", g7, 1)
+                gx01 = conv3d_dgrad_flip(dy01, vc.conv0_1.conv.weight)
+            gx = gx + gx01
         out = [gx, None]
         for name in _VC_BLOCKS:
             out += [grads[name], grads[name + ".bn"][0], grads[name + ".bn"][1]]
@@ -1056,6 +1097,7 @@ class _FlowFeaturesTrain(torch.autograd.Function):
             feature, xyz = pointflow.flow_features(levels, depth, interval, cam, h, w, 1)
         ctx.levels, ctx.depth, ctx.interval, ctx.cam, ctx.hw = levels, depth, interval, cam, (h, w)
         ctx.shapes = [tuple(t.shape) for t in lv]
+        ctx.side = _on_side(2)
         ctx.mark_non_differentiable(xyz)
         return feature.view(feature.shape[1], feature.shape[2]), xyz
 
@@ -1071,21 +1113,30 @@ class _FlowFeaturesTrain(torch.autograd.Function):
         cs = [int(l.shape[3]) for l in levels]
         ctot = sum(cs)
         with torch.cuda.device(dev):
-            keys = torch.empty((V * N,), dtype=torch.int32, device=dev)
-            fxy = torch.empty((V * N, 2), dtype=_F32, device=dev)
-            _lib.call("pf_warp_taps_flow_f32", _lib.ptr(depth), _lib.ptr(interval), _lib.ptr(cam), V, h, w, _lib.ptr(keys),
-                      _lib.ptr(fxy), _lib.stream(), algo_bytes=12.0 * V * N)
-            dres, _ = _warp_backward(levels, V, h, w, N, keys, fxy, g, False, 0)
-            outs, c0 = [], 0
-            for c, shp in zip(cs, ctx.shapes):
-                dl = torch.empty(shp, dtype=_F32, device=dev)
-                _lib.call("pf_resize_bilinear_backward_f32", _lib.ptr(dres), ctot, c0, c, V, h, w, int(shp[2]), int(shp[3]),
-                          _lib.ptr(dl), _lib.stream(), algo_bytes=4.0 * V * c * (h * w + shp[2] * shp[3]))
-                outs.append(dl)
-                c0 += c
+            # the prior depth's gradient is what the chain (previous iteration, coarse stage) waits for ...
             ddepth = torch.empty((h, w), dtype=_F32, device=dev)
             _lib.call("pf_flow_depth_grad_f32", _lib.ptr(g), int(g.stride(0)), ctot, _lib.ptr(cam), h, w, _lib.ptr(ddepth),
                       _lib.stream(), algo_bytes=4.0 * N * 24 + 4.0 * h * w)
+            # ... the pyramid levels' gradients only reach the flow tower's backward: with the tower on its own stream they
+            # are produced there (autograd accumulates and consumes them on that stream: stream order makes it correct)
+            side = ctx.side
+            if side is not None:
+                side.wait_stream(torch.cuda.current_stream(dev))
+                for t in [g, depth] + list(levels):      # read there after this node (and its saved tensors) are gone
+                    t.record_stream(side)
+            with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                keys = torch.empty((V * N,), dtype=torch.int32, device=dev)
+                fxy = torch.empty((V * N, 2), dtype=_F32, device=dev)
+                _lib.call("pf_warp_taps_flow_f32", _lib.ptr(depth), _lib.ptr(interval), _lib.ptr(cam), V, h, w,
+                          _lib.ptr(keys), _lib.ptr(fxy), _lib.stream(), algo_bytes=12.0 * V * N)
+                dres, _ = _warp_backward(levels, V, h, w, N, keys, fxy, g, False, 0)
+                outs, c0 = [], 0
+                for c, shp in zip(cs, ctx.shapes):
+                    dl = torch.empty(shp, dtype=_F32, device=dev)
+                    _lib.call("pf_resize_bilinear_backward_f32", _lib.ptr(dres), ctot, c0, c, V, h, w, int(shp[2]),
+                              int(shp[3]), _lib.ptr(dl), _lib.stream(), algo_bytes=4.0 * V * c * (h * w + shp[2] * shp[3]))
+                    outs.append(dl)
+                    c0 += c
         return outs[0], outs[1], outs[2], ddepth, None, None, None, None
 
 
