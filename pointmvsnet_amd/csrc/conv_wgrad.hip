@@ -131,6 +131,20 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ Gr
     }
   }
 
+  // Gr rows (planar mode): row (cg, position row) of the tile's window sits at a per-block constant offset, so the
+  // offsets are tabulated once (after the X table) and a tile inside the tensor costs one table read + one add per load
+  int* gtab = tab + 4 * g.ntasks;                            // [MT*16*R][2]: element offset in the window, LDS offset
+  constexpr int kGT = 2 * MT;                                // <= 16 MT rows x 8 position rows x 4 pieces / 256 threads
+  const int grows_blk = min(MT * 16, g.Cg - cg0);
+  if (!g.point_major) {
+    for (int row = tid; row < grows_blk * R; row += 256) {
+      const int cgl = row >> g.lgR, r = row & (R - 1);
+      const int d = r >> g.lgTH, h = r & (g.TH - 1);
+      gtab[2 * row] = cgl * vol_o + d * plane_o + h * g.Wo;
+      gtab[2 * row + 1] = cgl * g.GPLANE + r * 16;
+    }
+  }
+
   const int t_lo = split * g.per_split;
   const int t_hi = min(g.total_tiles, t_lo + g.per_split);
   for (int tile = t_lo; tile < t_hi; ++tile) {
@@ -206,11 +220,39 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ Gr
       const int od0 = td * g.TD, oh0 = th * g.TH, ow0 = tw * 16;
       const int id0 = od0 * STRIDE - g.pd, ih0 = oh0 * STRIDE - g.ph, iw0 = ow0 * STRIDE - g.pw;
       // Gr tile: 4 lanes per row of 16 positions along W, 16 bytes each
-      {
+      const bool g_inside = od0 + g.TD <= g.Do && oh0 + g.TH <= g.Ho && ow0 + 16 <= g.Wo;
+      if (g_inside) {
+        const float* gbu = Gr + ((int64_t)n * g.Cg + cg0) * vol_o + ((int64_t)od0 * plane_o + oh0 * g.Wo + ow0);   // uniform
+        const int q4 = (tid & 3) * 4, rg = tid >> 2;
+        const int gtasks = grows_blk * R;
+        constexpr int kGB = kGT < 4 ? kGT : 4;                 // loads in flight per lane
+#pragma unroll
+        for (int j0 = 0; j0 < kGT; j0 += kGB) {
+          U4 v[kGB];
+          int dst[kGB];
+#pragma unroll
+          for (int j = 0; j < kGB; ++j) {
+            const int row = rg + 64 * (j0 + j);
+            dst[j] = -1;
+            if (row < gtasks) {
+              const int2 e = *reinterpret_cast<const int2*>(gtab + 2 * row);
+              v[j] = *reinterpret_cast<const U4*>(gbu + (e.x + q4));
+              dst[j] = e.y + q4;
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < kGB; ++j) {
+            if (dst[j] >= 0) {
+              *reinterpret_cast<float2*>(gs + dst[j]) = make_float2(v[j].v[0], v[j].v[1]);
+              *reinterpret_cast<float2*>(gs + dst[j] + 2) = make_float2(v[j].v[2], v[j].v[3]);
+            }
+          }
+        }
+      } else {
         const int q4 = (tid & 3) * 4, rg = tid >> 2;
         const float* gb = Gr + ((int64_t)n * g.Cg + cg0) * vol_o + (int64_t)od0 * plane_o + oh0 * g.Wo + ow0 + q4;
         const int gtasks = grows * R;
-        const bool inside = od0 + g.TD <= g.Do && oh0 + g.TH <= g.Ho && ow0 + 16 <= g.Wo;
+        const bool inside = false;
         for (int t0 = rg; t0 < gtasks; t0 += 64 * kG) {
           U4 v[kG];
 #pragma unroll
@@ -246,7 +288,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ Gr
         const int gsz = 1 << g.lgGS;
         const int q = tid & (gsz - 1), rg = tid >> g.lgGS, rp = 256 >> g.lgGS;
         const int q4 = q * 4;
-        const float* xb = X + ((int64_t)n * g.Cx + ci0) * vol_i + ((int64_t)id0 * plane_i + ih0 * g.Wi + iw0 + q4);
+        const float* xbu = X + ((int64_t)n * g.Cx + ci0) * vol_i + ((int64_t)id0 * plane_i + ih0 * g.Wi + iw0);   // uniform
+        const float* xb = xbu + q4;
         const int stat = n / g.x_sps;
         const int xrows = creal * g.ID * g.IH;
         const bool lane_on = q < g.QX;
@@ -265,7 +308,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ Gr
               dst[u] = -1;
               if (row < xrows && lane_on) {
                 const int2 e = *reinterpret_cast<const int2*>(tab + row * 4);
-                v[u] = *reinterpret_cast<const U4*>(xb + e.x);
+                v[u] = *reinterpret_cast<const U4*>(xbu + (e.x + q4));
                 dst[u] = e.y + q4;
               }
             }
@@ -546,7 +589,8 @@ WgPlan make_plan_mt(int64_t N, int64_t Cg, int64_t Cx, int64_t Do, int64_t Ho, i
       g.xs_floats = cblk * g.CBP * g.XPLANE;
       g.xs_floats = (g.xs_floats + 3) & ~3;
       g.ntasks = rows ? 0 : cblk * g.CBP * g.ID * g.IH;
-      p.lds_bytes = sizeof(float) * (size_t)(g.gs_floats + g.xs_floats) + sizeof(int) * 4 * (size_t)g.ntasks;
+      p.lds_bytes = sizeof(float) * (size_t)(g.gs_floats + g.xs_floats) + sizeof(int) * 4 * (size_t)g.ntasks +
+                    (rows ? 0 : sizeof(int) * 2 * (size_t)(p.MT * 16 * g.TD * g.TH));
       if (p.lds_bytes <= kLdsSoft) break;
     }
     if (g.CBLK >= 1 && p.lds_bytes <= kLdsSoft && g.NTILES <= kMaxNTW * 4) {
