@@ -45,8 +45,8 @@ FUSED_TRAIN = 1
 # model.py:71-150), and most of a training step's ~700 launches are too small to fill 256 CUs alone.  Inside a captured
 # step the fork / join become graph dependencies.  Levels: 0 = one stream (the A/B arm); 1 = the flow tower; 2 = + the
 # pyramid-level gradients of the flow-feature nodes (only the flow tower's backward consumes them: off the chain that
-# the previous iteration and the coarse stage wait on: +5 % same-box, the default); 3 = + VolumeConv's conv0_1 branch in
-# the backward (-0.4 %: `profiles/r04c_train_streams.md`).
+# the previous iteration and the coarse stage wait on: +5 % same-box, the default).  (VolumeConv's conv0_1 branch there
+# too: -0.4 %, `profiles/r04c_train_streams.md`; not kept.)
 TRAIN_FORK = int(os.environ.get("PF_TRAIN_FORK", "2"))
 _FORK_STREAMS = {}
 
@@ -55,10 +55,9 @@ def join_fork_streams():
     """The current stream waits for everything the fork streams have been given.  Callers of ``backward()`` on a fused
     training forward run it before they read gradients: autograd joins a side stream at the end of backward only
     where an AccumulateGrad node ran on it, and with ``train_ops.direct_grads()`` the nodes add into the bucket
-    themselves, the weight gradients on streams of their own (train_ops._wgrad_side)."""
+    themselves."""
     for stream in _FORK_STREAMS.values():
         torch.cuda.current_stream(stream.device).wait_stream(stream)
-    train_ops.join_wgrad_streams()
 
 
 def _host_cams(data_batch):

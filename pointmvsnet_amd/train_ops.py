@@ -81,8 +81,7 @@ def _grad_target(p):
 
 # The training forward's second stream (model.TRAIN_FORK): set by the model while a fused training forward that forked
 # the flow tower is being built, read by the nodes whose backward has work that only the flow tower's backward consumes
-# (level 2: the pyramid-level gradients of _FlowFeaturesTrain) or that the rest of the node does not wait for (level 3:
-# VolumeConv's conv0_1 branch).  None: everything on the node's own stream.
+# (level 2: the pyramid-level gradients of _FlowFeaturesTrain).  None: everything on the node's own stream.
 _SIDE = {"stream": None, "level": 0}
 
 
@@ -100,18 +99,9 @@ def _on_side(min_level):
     return _SIDE["stream"] if _SIDE["level"] >= min_level else None
 
 
-# Weight gradients have no consumer inside the step once they are added straight into the bucket, so they CAN leave the
-# dependency chain  dy -> data gradient -> BatchNorm backward -> dy'  for a second stream per compute stream
-# (PF_WGRAD_FORK=1: one fork per layer, =2: one fork per node, joined by join_wgrad_streams() after backward).
-# Measured same-box at BASELINE config 4 (profiles/r04c_train_streams.md): alone +5.5 % / +6.7 %, but beside the
-# flow-tower fork of model.TRAIN_FORK (+8.5 .. +11.8 %) they take throughput away again (-2 %; queued on the flow tower's
-# own stream instead: -5 %): the weight-gradient kernels fill the chip by themselves, and every fork adds cross-queue
-# dependencies to the graph.  Default 0: in line.
-WGRAD_FORK = int(os.environ.get("PF_WGRAD_FORK", "0"))
-_WGRAD_STREAMS = {}
-
-
-_WGRAD_PENDING = []
+# (Weight gradients have no consumer inside the step either, but streams of their own for them -- per layer, per node,
+# or the flow tower's stream -- were measured to LOSE 2-5 % beside the flow-tower fork: profiles/r04c_train_streams.md;
+# the variants are in git history, not here.)
 
 # Weight gradients that are ADDED into the bucket (direct_grads) leave their split partials in the workspace and queue the
 # reduction; a node's backward reduces all of its layers' partials in one launch when it returns
@@ -143,56 +133,6 @@ def _reduce_flush():
                   algo_bytes=4.0 * sum(p[2] * p[3] for p in pending))
 
 
-def _wgrad_stream(dev, cur):
-    key = (dev.index, cur.stream_id)
-    side = _WGRAD_STREAMS.get(key)
-    if side is None:
-        side = _WGRAD_STREAMS[key] = torch.cuda.Stream(device=dev)
-    return side
-
-
-def _wgrad_issue(launch, into, *tensors):
-    """Run ``launch()`` (a weight-gradient launch that ADDS into ``into``) in line, on the wgrad stream now
-    (PF_WGRAD_FORK=1: one fork per layer), or at the end of the node's backward (=2: one fork per node)."""
-    if not (WGRAD_FORK and DIRECT_GRADS and into is not None and tensors[0].is_cuda):
-        return launch()
-    if WGRAD_FORK == 2:
-        _WGRAD_PENDING.append((launch, tensors))
-        return None
-    dev = tensors[0].device
-    cur = torch.cuda.current_stream(dev)
-    side = _wgrad_stream(dev, cur)
-    side.wait_stream(cur)
-    for t in tensors:
-        if t is not None:
-            t.record_stream(side)
-    with torch.cuda.stream(side):
-        return launch()
-
-
-def _wgrad_flush():
-    if not _WGRAD_PENDING:
-        return
-    pending = list(_WGRAD_PENDING)
-    del _WGRAD_PENDING[:]
-    dev = pending[0][1][0].device
-    cur = torch.cuda.current_stream(dev)
-    side = _wgrad_stream(dev, cur)
-    side.wait_stream(cur)
-    with torch.cuda.stream(side):
-        for launch, tensors in pending:
-            for t in tensors:
-                if t is not None:
-                    t.record_stream(side)
-            launch()
-
-
-def join_wgrad_streams():
-    """The current stream waits for every weight gradient launched beside it."""
-    for (index, _), side in _WGRAD_STREAMS.items():
-        torch.cuda.current_stream(index).wait_stream(side)
-
-
 def _with_packs(backward):
     """A node's backward runs under the packs its forward ran under (loss.backward() is called outside the context)."""
     def wrapped(ctx, *grads):
@@ -200,7 +140,6 @@ def _with_packs(backward):
             try:
                 return backward(ctx, *grads)
             finally:
-                _wgrad_flush()
                 _reduce_flush()
     return wrapped
 
@@ -320,7 +259,7 @@ def conv_wgrad(gr, x, kernel, stride, pad, x_affine=None, x_samples_per_stat=1, 
     def launch():
         work = torch.empty((max(nbytes, 4) // 4,), dtype=_F32, device=gr.device)
         dw = torch.empty((Cg, Cx) + tuple(kernel), dtype=_F32, device=gr.device) if into is None else into   # into: dw +=
-        batched = into is not None and WGRAD_BATCH and DIRECT_GRADS and not WGRAD_FORK and into.is_contiguous()
+        batched = into is not None and WGRAD_BATCH and DIRECT_GRADS and into.is_contiguous()
         _lib.call("pf_conv_wgrad_f32", _lib.ptr(gr), _lib.ptr(x), None if batched else _lib.ptr(dw), N, Cg, Cx, go[0],
                   go[1], go[2], xi[0], xi[1], xi[2], k3[0], k3[1], k3[2], int(stride), p3[0], p3[1], p3[2], _lib.ptr(sc),
                   _lib.ptr(sh), int(x_samples_per_stat), _lib.ptr(work), nbytes, 0 if into is None else 1, _lib.stream(),
@@ -330,7 +269,7 @@ def conv_wgrad(gr, x, kernel, stride, pad, x_affine=None, x_samples_per_stat=1, 
             _queue_reduce(work, into, Cg * Cx * taps, nbytes)
         return dw if into is None else None
 
-    return _wgrad_issue(launch, into, gr, x, sc, sh)
+    return launch()
 
 
 def rows_wgrad(gr, x, Cg, Cx, x_affine=None, x_rows_per_stat=None, into=None):
@@ -345,7 +284,7 @@ def rows_wgrad(gr, x, Cg, Cx, x_affine=None, x_rows_per_stat=None, into=None):
     def launch():
         work = torch.empty((max(nbytes, 4) // 4,), dtype=_F32, device=gr.device)
         dw = torch.empty((Cg, Cx), dtype=_F32, device=gr.device) if into is None else into
-        batched = into is not None and WGRAD_BATCH and DIRECT_GRADS and not WGRAD_FORK and into.is_contiguous()
+        batched = into is not None and WGRAD_BATCH and DIRECT_GRADS and into.is_contiguous()
         _lib.call("pf_rows_wgrad_f32", _lib.ptr(gr), int(gr.stride(0)), _lib.ptr(x), int(x.stride(0)),
                   None if batched else _lib.ptr(dw), P, int(Cg), int(Cx), _lib.ptr(sc), _lib.ptr(sh),
                   int(x_rows_per_stat or P), _lib.ptr(work), nbytes, 0 if into is None else 1, _lib.stream(),
@@ -354,7 +293,7 @@ def rows_wgrad(gr, x, Cg, Cx, x_affine=None, x_rows_per_stat=None, into=None):
             _queue_reduce(work, into, int(Cg) * int(Cx), nbytes)
         return dw if into is None else None
 
-    return _wgrad_issue(launch, into, gr, x, sc, sh)
+    return launch()
 
 
 def gemm_rows(x, w, K, n_out, chunks=None):
@@ -677,7 +616,6 @@ class _VolumeTrain(torch.autograd.Function):
             rec["conv6_2"] = (s7, None, None)
             pointflow.flush_counters()
         ctx.vc, ctx.rec = vc, rec
-        ctx.side = _on_side(3)
         return out
 
     @staticmethod
@@ -717,16 +655,6 @@ class _VolumeTrain(torch.autograd.Function):
             g7 = torch.empty((1, w62.shape[1], D, H, W), dtype=_F32, device=g.device)
             _lib.call("pf_conv3d_k3_c1_f32", _lib.ptr(g), _lib.ptr(wf), _lib.ptr(g7), 1, int(w62.shape[1]), D, H, W,
                       _lib.stream(), algo_bytes=4.0 * (1 + w62.shape[1]) * D * H * W)
-            # conv0_1's branch (full resolution: the node's largest weight gradient and two 8 -> 32 data-gradient launches)
-            # needs only g7 and is needed only at the very end: beside the U-Net chain on the second stream when there is one
-            side = ctx.side
-            cur = torch.cuda.current_stream(gout.device)
-            if side is not None:
-                side.wait_stream(cur)
-                g7.record_stream(side)
-                with torch.cuda.stream(side):
-                    dy01 = conv_back("conv0_1", g7, 1)
-                    gx01 = conv3d_dgrad_flip(dy01, vc.conv0_1.conv.weight)
             # decoder: a ConvTranspose3d's data gradient is the stride-2 convolution with its weight read (Cout', Cin')
             dy60 = deconv_back("conv6_0", g7)
             g6 = _conv3d_k3_w(dy60, vc.conv6_0.conv.weight, 2)                        # -> dz50, dz11
@@ -746,13 +674,8 @@ class _VolumeTrain(torch.autograd.Function):
             g10 = g10 + conv3d_dgrad_flip(dy11, vc.conv1_1.conv.weight)
             dy10 = conv_back("conv1_0", g10, 2)
             gx = pointflow.deconv3d_k3s2(dy10, None, vc.conv1_0.conv.weight.detach(), False)[0]
-            if side is not None:
-                cur.wait_stream(side)
-                gx01.record_stream(cur)
-            else:
-                dy01 = conv_back("conv0_1", g7, 1)
-                gx01 = conv3d_dgrad_flip(dy01, vc.conv0_1.conv.weight)
-            gx = gx + gx01
+            dy01 = conv_back("conv0_1", g7, 1)
+            gx = gx + conv3d_dgrad_flip(dy01, vc.conv0_1.conv.weight)
         out = [gx, None]
         for name in _VC_BLOCKS:
             out += [grads[name], grads[name + ".bn"][0], grads[name + ".bn"][1]]
