@@ -346,7 +346,10 @@ __global__ __launch_bounds__(32 * ROWS) void knn_net_kernel(const float* __restr
   constexpr int PLANE = LH * LW, TOTAL = KS * PLANE;
   constexpr int K3 = KS * KS * KS;
   constexpr int GROUPS = (K3 + 15) / 16;
-  __shared__ float lx[TOTAL], ly[TOTAL], lz[TOTAL];
+  __shared__ __attribute__((aligned(16))) float lds3[3 * TOTAL];      // one array: the index staging below reuses all of it
+  float* lx = lds3;
+  float* ly = lds3 + TOTAL;
+  float* lz = lds3 + 2 * TOTAL;
 
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int w0 = blockIdx.x * 32, h0 = blockIdx.y * ROWS;
@@ -374,7 +377,7 @@ __global__ __launch_bounds__(32 * ROWS) void knn_net_kernel(const float* __restr
   __syncthreads();
 
   const int h = h0 + ty, w = w0 + tx;
-  if (h >= H || w >= W) return;
+  const bool live = h < H && w < W;                       // (dead lanes compute on their window too: the block syncs below)
   const int base = ty * LW + tx;                          // window origin of this lane
   const int ce = base + (HK * LH + HK) * LW + HK;
   const float cx = lx[ce], cy = ly[ce], cz = lz[ce];
@@ -410,7 +413,7 @@ __global__ __launch_bounds__(32 * ROWS) void knn_net_kernel(const float* __restr
   const int64_t HW = (int64_t)H * W;
   const int64_t DHW = HW * D;
   const int64_t n = (int64_t)d * HW + (int64_t)h * W + w;
-  if (code_out != nullptr) {
+  if (code_out != nullptr && live) {
     uint8_t* cp = code_out + ((int64_t)b * DHW + n) * knn;
     if (knn == 16) {
       unsigned pk[4];
@@ -425,7 +428,43 @@ __global__ __launch_bounds__(32 * ROWS) void knn_net_kernel(const float* __restr
         if (j < knn) cp[j] = (uint8_t)key_code(best[j]);
     }
   }
-  if (idx_out != nullptr) {
+  if (idx_out == nullptr) return;                         // (block-uniform)
+  if (knn == 16) {
+    // A lane's 16 indices are 128 contiguous bytes and its neighbour lane's start 128 bytes on: stored per lane, every
+    // store instruction touched 32-64 cache lines (65 us for 25 600 points where the code path takes 15).  Staged through
+    // LDS in chunks of J neighbours, a row of 32 points leaves as contiguous 16-byte pieces.
+    constexpr int JMAX = (3 * TOTAL * 4) / (ROWS * 32 * 8);
+    constexpr int J = JMAX >= 16 ? 16 : (JMAX >= 8 ? 8 : (JMAX >= 4 ? 4 : 2));
+    static_assert(JMAX >= 2, "index staging does not fit the window's LDS");
+    int64_t* ob = reinterpret_cast<int64_t*>(lds3);
+    const int64_t row0 = (int64_t)b * DHW + (int64_t)d * HW + (int64_t)h * W + w0;      // first point of this lane's row
+#pragma unroll
+    for (int j0 = 0; j0 < 16; j0 += J) {
+      __syncthreads();                                    // the window (or the previous chunk) has been read
+#pragma unroll
+      for (int jj = 0; jj < J; ++jj) {
+        const int code = (int)key_code(best[j0 + jj]);
+        const int pd = code / (KS * KS), ph = (code / KS) % KS, pw = code % KS;
+        int64_t v = n + (int64_t)(pd - HK) * HW + (int64_t)(ph - HK) * W + (pw - HK);
+        v = v < 0 ? 0 : (v > DHW - 1 ? DHW - 1 : v);
+        ob[(ty * 32 + tx) * J + jj] = v;
+      }
+      __syncthreads();
+      if (h < H) {
+#pragma unroll
+        for (int i = 0; i < J / 2; ++i) {
+          const int piece = tx + 32 * i;                  // 16-byte pieces of this row's 32 x J block
+          const int pt = piece / (J / 2), q = piece - pt * (J / 2);
+          if (w0 + pt < W) {
+            const longlong2 v2 = *reinterpret_cast<const longlong2*>(ob + (ty * 32 + pt) * J + 2 * q);
+            *reinterpret_cast<longlong2*>(idx_out + (row0 + pt) * 16 + j0 + 2 * q) = v2;
+          }
+        }
+      }
+    }
+    return;
+  }
+  if (live) {
     int64_t* op = idx_out + ((int64_t)b * DHW + n) * knn;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
