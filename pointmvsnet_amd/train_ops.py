@@ -6,13 +6,17 @@ batch_norm backward.  Here every such stack is ONE ``torch.autograd.Function`` w
 kernels (raw convolution output + BatchNorm statistics from the epilogue, the pending BatchNorm + ReLU applied by the
 next convolution while it stages its input) and whose backward is hand-written on the C ABI:
 
-    BatchNorm+ReLU backward   pf_bn_bwd_reduce / _coeffs / _apply (csrc/norm_bwd.hip; rows forms for the MLP)
-    weight gradients          pf_conv_wgrad_f32 / pf_rows_wgrad_f32 (csrc/conv_wgrad.hip; f32 MFMA, fixed-order sums)
+    BatchNorm+ReLU backward   pf_bn_bwd_reduce + pf_bn_bwd_apply_fused (csrc/norm_bwd.hip; rows forms for the MLP)
+    weight gradients          pf_conv_wgrad_f32 / pf_rows_wgrad_f32 (csrc/conv_wgrad.hip; f32 MFMA, fixed-order sums;
+                              a node's layers reduced by ONE pf_wgrad_reduce_batch_f32)
     data gradients            stride-1 layers: the FORWARD kernel on the flipped, transposed weight;
                               stride-2 convolutions: the transposed-convolution kernels (pf_deconv2d_k5s2_f32,
                               pf_deconv3d_k3s2_f32, pf_deconv3d_bottom_f32); ConvTranspose3d layers: the stride-2
                               forward convolution on the weight read as (Cout', Cin') = (Cin, Cout)
     1x1 convolutions          pf_pointwise_gemm_f32 on W itself (dX = dY W)
+    warps, resizes            csrc/warp_bwd.hip: the bilinear scatters as gathers over sorted lists
+    soft argmin, flow head,   csrc/train_heads.hip: one launch per direction each (autograd's compositions were 15-25
+    masked MAE loss           element-wise launches)
 
 No library convolution, BatchNorm or GEMM kernel runs in the step, and nothing uses float atomics: the gradient is
 bit-reproducible.  One scene per process (B = 1, the reference's per-replica batch under DataParallel with 8 scenes on
