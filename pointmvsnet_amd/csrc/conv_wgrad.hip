@@ -34,6 +34,8 @@
 //     split-K solvers use float atomics).
 // Bound: fp32 MFMA (2 * taps * Cg * Cx flop per position against 4 * (Cg + Cx) bytes); the 8-channel layers fill half
 // of the 16 MFMA rows.
+#include <stdlib.h>
+
 #include "pf_common.h"
 
 namespace {
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ Gr
   // Gr rows (planar mode): row (cg, position row) of the tile's window sits at a per-block constant offset, so the
   // offsets are tabulated once (after the X table) and a tile inside the tensor costs one table read + one add per load
   int* gtab = tab + 4 * g.ntasks;                            // [MT*16*R][2]: element offset in the window, LDS offset
-  constexpr int kGT = 2 * MT;                                // <= 16 MT rows x 8 position rows x 4 pieces / 256 threads
+  constexpr int kGT = 4 * MT;                                // <= 16 MT rows x 16 position rows x 4 pieces / 256 threads
   const int grows_blk = min(MT * 16, g.Cg - cg0);
   if (!g.point_major) {
     for (int row = tid; row < grows_blk * R; row += 256) {
@@ -562,9 +564,27 @@ WgPlan make_plan_mt(int64_t N, int64_t Cg, int64_t Cx, int64_t Do, int64_t Ho, i
   p.MT = MT;
   p.mblocks = (int)((Cg + 16 * MT - 1) / (16 * MT));
   const int cx_pad = (int)((Cx + g.CBP - 1) / g.CBP);          // channel sub-blocks in all
-  // tile candidates: 3-D volumes 2 x 4 x 16, else 1 x 8 x 16, 1 x 4 x 16
-  const int cand[3][2] = {{2, 4}, {1, 8}, {1, 4}};
-  for (int ci = rows ? 2 : (first_tile >= 0 ? first_tile : (Do > 1 ? 0 : 1)); ci < 3; ++ci) {   // (rows: 64 points per tile)
+  // tile candidates: 3-D volumes 2 x 4 x 16, else 1 x 8 x 16, 1 x 4 x 16; 2-D layers try 1 x 16 x 16 first when it
+  // fits the soft LDS budget: twice the matrix work between two barriers of a latency-bound loop
+  const int cand[4][2] = {{1, 16}, {2, 4}, {1, 8}, {1, 4}};
+  static const bool big_tile = []() {
+    const char* e = getenv("PF_WGRAD_BIG_TILE");
+    return e == nullptr || e[0] != '0';
+  }();
+  int seq[4], nseq = 0;
+  if (rows || first_tile == 2) {
+    seq[nseq++] = 3;
+  } else if (Do > 1) {
+    seq[nseq++] = 1;
+    seq[nseq++] = 2;
+    seq[nseq++] = 3;
+  } else {
+    if (big_tile && Ho >= 16) seq[nseq++] = 0;
+    seq[nseq++] = 2;
+    seq[nseq++] = 3;
+  }
+  for (int si = 0; si < nseq; ++si) {
+    const int ci = seq[si];
     g.TD = cand[ci][0];
     g.TH = cand[ci][1];
     g.lgTH = ilog2(g.TH);
@@ -581,6 +601,7 @@ WgPlan make_plan_mt(int64_t N, int64_t Cg, int64_t Cx, int64_t Do, int64_t Ho, i
     int cblk = kMaxNTW * 4 / g.TPC;
     if (cblk < 1) cblk = 1;                                    // (more than 28 tap groups: PF_ERR_UNSUPPORTED below)
     if (cblk > cx_pad) cblk = cx_pad;
+    const int cblk_max = cblk;
     for (; cblk >= 1; --cblk) {
       g.CBLK = cblk;
       g.NTILES = cblk * g.TPC;
@@ -593,11 +614,12 @@ WgPlan make_plan_mt(int64_t N, int64_t Cg, int64_t Cx, int64_t Do, int64_t Ho, i
                     (rows ? 0 : sizeof(int) * 2 * (size_t)(p.MT * 16 * g.TD * g.TH));
       if (p.lds_bytes <= kLdsSoft) break;
     }
+    if (ci == 0 && g.CBLK != cblk_max) continue;                 // the big tile only where it costs no channel block
     if (g.CBLK >= 1 && p.lds_bytes <= kLdsSoft && g.NTILES <= kMaxNTW * 4) {
       p.ok = true;
       break;
     }
-    if (ci == 2 && g.NTILES <= kMaxNTW * 4 && p.lds_bytes <= kLdsHard) {   // last resort: the big-LDS opt-in
+    if (ci == 3 && g.NTILES <= kMaxNTW * 4 && p.lds_bytes <= kLdsHard) {   // last resort: the big-LDS opt-in
       p.ok = true;
       break;
     }
