@@ -477,7 +477,8 @@ def test_train_step_parameter_gradients_vs_oracle_autograd(dev, monkeypatch, fus
         assert errs_gpu64[0][0] < 3.0 * errs_ref64[0][0], (errs_gpu64[:3], errs_ref64[:3])
     else:
         assert l2_gpu64 < max(2.5 * l2_ref64, 8e-4), (l2_gpu64, l2_ref64)
-    assert l2 < (6e-4 if fused else 1e-3), l2                # the whole 698 936-element gradient, relative L2
+    # the whole 698 936-element gradient, relative L2 (the oracle's own float32 error enters: host dependent)
+    assert l2 < max(6e-4 if fused else 1e-3, 1.6 * l2_ref64), (l2, l2_ref64)
     assert errs[0][0] < 3e-3, errs[:5]
 
 
