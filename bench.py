@@ -47,15 +47,42 @@ HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 T
 MFMA_F32_PEAK_TF = 157.3         # same guide: dense f32-input MFMA peak (v_mfma_f32_32x32x2 / 16x16x4)
 
 
+TRAFFIC_TABLE = os.path.join("profiles", "pmc_traffic.json")
+UNDER_LOAD_TABLE = os.path.join("profiles", "r05_per_kernel_roofline.json")
+
+
 def measured_traffic(entry):
-    """HBM bytes per launch of C-ABI entry point `entry` from the committed PMC passes
-    (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs; tools/pmc_to_traffic.py), or None."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    """HBM bytes per launch of C-ABI entry point `entry` READ FROM THE COMMITTED PMC passes (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE, separate runs of an earlier job; tools/pmc_to_traffic.py), or None.  Not measured by this run: the line
+    says so in ``roofline.traffic_source``."""
     try:
-        table = json.load(open(path))
+        table = json.load(open(os.path.join(ROOT, TRAFFIC_TABLE)))
         return float(table["entries"][entry]["bytes_per_launch"])
     except (OSError, KeyError, ValueError):
         return None
+
+
+def under_load_instantiations(prefixes):
+    """Best / worst template instantiation of the dominant kernel family UNDER LOAD (four lanes, graph replay), from the
+    committed rocprofv3 kernel trace folded by tools/per_kernel_roofline.py -- the calibration clock of this run times
+    eager single-chain launches and cannot see them.  None when the table is not there."""
+    for name in (UNDER_LOAD_TABLE, os.path.join("profiles", "r04_per_kernel_roofline.json")):
+        try:
+            table = json.load(open(os.path.join(ROOT, name)))
+        except (OSError, ValueError):
+            continue
+        rows = [k for k in table.get("kernels", []) if k.get("frac_mfma_peak") and k["kernel"].startswith(prefixes)]
+        if not rows:
+            continue
+        rows.sort(key=lambda k: k["frac_mfma_peak"])
+        us = sum(k["us_per_depth_map"] for k in rows)
+        fl = sum(k["flops_per_depth_map"] for k in rows)
+        pick = lambda k: {"kernel": k["kernel"], "what": k.get("what"), "frac_mfma_peak": k["frac_mfma_peak"],
+                          "us_per_depth_map": k["us_per_depth_map"]}
+        return {"source": name + " (rocprofv3 --kernel-trace of the timed execution mode, committed; not this run)",
+                "family_us_per_depth_map": us, "family_frac_mfma_peak": fl / us / 1e6 / MFMA_F32_PEAK_TF,
+                "best": pick(rows[-1]), "worst": pick(rows[0]), "instantiations": len(rows)}
+    return None
 WORKLOAD_TEXT = {
     "cfg1": "cfg1: DTU 640x512 (160x128 depth grid), 3 views, 48 hypotheses, 1 flow iter",
     "cfg2": "cfg2: DTU 640x512, 3 source views, 48 depth hypotheses, 2 flow iters",
@@ -101,6 +128,9 @@ def parse_args():
     ap.add_argument("--config", default="cfg2", choices=sorted(synthetic.CONFIGS))
     ap.add_argument("--eager", action="store_true", help="do not capture the forward in a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-block", action="store_true",
+                    help="cfg2 only: do not time BASELINE configs[3]'s training step after the headline's timed region")
+    ap.add_argument("--train-steps", type=int, default=20, help="timed replays of the training step in the train block")
     ap.add_argument("--cpu-repeats", type=int, default=3)
     ap.add_argument("--train-cpu-baseline", action="store_true",
                     help="cfg4 only: also time ONE oracle training step on the host (tens of seconds, ~15 GB of RAM)")
@@ -256,6 +286,140 @@ VOLUME_CONV = ("pf_conv3d_k3_f32", "pf_conv3d_k3_pair_f32", "pf_deconv3d_k3s2_f3
 VOLUME_CONV_BN = ("pf_channel_bn_apply_f32", "pf_channel_bn_apply2_f32", "pf_channel_stats_f32", "pf_channel_bn_fused_f32")
 TOWERS = ("pf_conv2d_wide_sets_f32", "pf_conv2d_wide_f32")
 GATHER_PATH_MB = {"cfg1": 404.1, "cfg2": 1658.8, "cfg3": 25194.4, "cfg5": 38116.0}
+
+
+
+TRAIN_GROUPS = (
+    ("weight_gradients", ("pf_conv_wgrad_f32", "pf_rows_wgrad_f32")),
+    ("batchnorm_backward", ("pf_bn_bwd_reduce_f32", "pf_bn_bwd_coeffs_f32", "pf_bn_bwd_apply_f32",
+                            "pf_bn_bwd_apply_fused_f32", "pf_rows_bn_bwd_reduce_f32", "pf_rows_bn_bwd_apply_f32")),
+    ("warp_backward", ("pf_warp_taps_flow_f32", "pf_warp_taps_frustum_f32", "pf_sort_pairs_by_key",
+                       "pf_variance_grad_f32", "pf_warp_gather_f32", "pf_resize_bilinear_backward_f32",
+                       "pf_flow_depth_grad_f32")),
+)
+
+
+def train_groups(split, ncal):
+    """The weight gradients (f32 MFMA, fixed-order split sums), the BatchNorm backward passes and the warps' backward as
+    groups of C-ABI entry points, from the HIP-event calibration of ``ncal`` eager steps."""
+    out = {}
+    for tag, entries in TRAIN_GROUPS:
+        grp = [split[k] for k in entries if k in split]
+        if not grp:
+            continue
+        us = sum(v["ms"] for v in grp) * 1e3 / ncal
+        fl = sum(v["flops"] for v in grp) / ncal
+        by = sum(v["bytes"] for v in grp) / ncal
+        out[tag] = {"kernel_us_per_step": us, "launches_per_step": sum(v["launches"] for v in grp) / float(ncal),
+                    "flops_per_step": fl, "algorithmic_bytes_per_step": by,
+                    "TFLOPs": fl / us / 1e6 if (us > 0 and fl > 0) else None,
+                    "frac_of_f32_mfma_peak": fl / us / 1e6 / MFMA_F32_PEAK_TF if (us > 0 and fl > 0) else None,
+                    "GBps": by / us / 1e3 if us > 0 else None}
+    return out
+
+
+def graph_kernel_nodes(make_graphed):
+    """Kernel nodes of the captured training step = its dispatches per replay: a second capture with
+    ``keep_graph=True`` whose hipGraph is walked with hipGraphGetNodes / hipGraphNodeGetType (the timed capture is the
+    ordinary one).  Returns (kernel nodes, all nodes) or (None, reason)."""
+    import ctypes
+    try:
+        graphed = make_graphed(True)
+        raw = graphed.graph.raw_cuda_graph()
+        hip = ctypes.CDLL("libamdhip64.so")
+        n = ctypes.c_size_t(0)
+        if hip.hipGraphGetNodes(ctypes.c_void_p(raw), None, ctypes.byref(n)) != 0:
+            return None, "hipGraphGetNodes failed"
+        nodes = (ctypes.c_void_p * n.value)()
+        if hip.hipGraphGetNodes(ctypes.c_void_p(raw), nodes, ctypes.byref(n)) != 0:
+            return None, "hipGraphGetNodes failed"
+        kernels = 0
+        for node in nodes:
+            kind = ctypes.c_int(-1)
+            if hip.hipGraphNodeGetType(ctypes.c_void_p(node), ctypes.byref(kind)) == 0 and kind.value == 0:
+                kernels += 1                                        # hipGraphNodeTypeKernel
+        return kernels, int(n.value)
+    except Exception as exc:                                        # measurement aid only: never fail the line for it
+        return None, repr(exc)
+
+
+def train_block(dev, rank, world, steps=20, warmup=3):
+    """BASELINE configs[3] beside the headline (after its timed region, headline fields untouched): the captured
+    training step -- zero the bucket, forward in train mode, PointMVSNetLoss, backward on this package's own kernels;
+    then one SUM all-reduce of the flat bucket and RMSprop -- on one 640x512 scene per GPU (reference train.py:62-67,
+    72-86).  ``steps`` replays timed between synchronisations (and barriers when N > 1), MAX over ranks."""
+    from pointmvsnet_amd import model as _model
+    from pointmvsnet_amd.train_step import GraphedTrainStep, TrainStep
+    _, _, _, _, _, img_scales, inter_scales = synthetic.CONFIGS["cfg4"]
+    scenes = []
+    for i in range(2):
+        data, _, _ = synthetic.make_config("cfg4", seed=rank + world * i, train_intrinsics=True)
+        batch = to_device(data, dev)
+        batch["gt_depth_img"] = synthetic.make_gt_depth(data, seed=rank + world * i).to(dev)
+        scenes.append(batch)
+    net = PointMVSNet()
+    synthetic.seed_weights(net, seed=0)
+    net = net.to(dev).train()
+    trainer = TrainStep(net)
+    # per-entry-point clock: HIP events around every C-ABI call of three EAGER steps (a replay makes no calls)
+    for i in range(2):
+        trainer(scenes[i % 2], img_scales, inter_scales)
+    torch.cuda.synchronize()
+    cal = _lib.KernelTimer()
+    _lib.set_timer(cal)
+    ncal = 3
+    for i in range(ncal):
+        trainer(scenes[i % 2], img_scales, inter_scales)
+    _lib.set_timer(None)
+    split = cal.summary()
+    own_calls = sum(v["launches"] for v in split.values()) / float(ncal)
+    step_flops = sum(v["flops"] for v in split.values()) / ncal
+    graphed = GraphedTrainStep(trainer, scenes[0], img_scales, inter_scales)
+    for i in range(warmup):
+        graphed(scenes[i % 2])
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss, _, _ = graphed(scenes[i % 2])
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    elapsed = time.perf_counter() - t0
+    allreduce_us = None
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(22)]
+        ev[0].record()
+        for j in range(21):
+            trainer.bucket.allreduce_sum()
+            ev[j + 1].record()
+        torch.cuda.synchronize()
+        allreduce_us = statistics.median(ev[j].elapsed_time(ev[j + 1]) for j in range(1, 21)) * 1e3
+    assert torch.isfinite(loss)
+    kernels, all_nodes = graph_kernel_nodes(
+        lambda keep: GraphedTrainStep(trainer, scenes[0], img_scales, inter_scales, warmup=1, keep_graph=keep))
+    ms = elapsed / steps * 1e3
+    out = {"metric": "train-scenes/sec (DTU 640x512, 3 views, 1 scene per GPU, forward+loss+backward+all-reduce+RMSprop)",
+           "value": world * steps / elapsed, "unit": "train-scenes/s", "ms_per_step": ms, "steps": steps,
+           "warmup": warmup, "n_gpus": world, "allreduce_us": allreduce_us,
+           "execution": "hipGraph replay of zero_grad + forward + loss + backward%s; all-reduce + RMSprop step eager"
+                        % (" (flow tower forward / backward on a second stream)" if _model.TRAIN_FORK else ""),
+           "dispatches_per_step": None if kernels is None else kernels + 1 + (1 if world > 1 else 0),
+           "dispatches_source": ("kernel nodes of the captured hipGraph (hipGraphGetNodes: %s nodes in all) + RMSprop%s"
+                                 % (all_nodes, " + the all-reduce" if world > 1 else "")) if kernels is not None
+                                else "unavailable: %s" % (all_nodes,),
+           "own_entry_point_calls_per_step": own_calls,
+           "whole_step": {"flops_per_step": step_flops, "TFLOPs": step_flops / (ms / 1e3) / 1e12,
+                          "frac_of_f32_mfma_peak": step_flops / (ms / 1e3) / 1e12 / MFMA_F32_PEAK_TF,
+                          "entry_point_us_per_step_by_events": sum(v["ms"] for v in split.values()) * 1e3 / ncal},
+           "clock": "groups: HIP events around every C-ABI call of %d eager steps (raw pair times); ms_per_step: wall "
+                    "clock over %d graph replays between synchronisations" % (ncal, steps)}
+    out.update(train_groups(split, ncal))
+    return out
 
 
 def main():
@@ -472,6 +636,17 @@ def main():
     from pointmvsnet_amd import pointflow as _pf
     stage_timeline = _pf.timeline_report() if _pf.TIMELINE else None
 
+    train = None
+    if args.config == "cfg2" and args.route == "fused" and not args.no_train_block:
+        try:                                     # (after the headline's timed region; its fields are not touched)
+            train = train_block(dev, rank, world, steps=max(1, args.train_steps))
+        except Exception as exc:                 # say so in the line, do not lose the headline
+            train = {"error": repr(exc)}
+    placement_by_rank = None
+    if world > 1:
+        gathered = [None] * world
+        torch.distributed.all_gather_object(gathered, lane_probe)
+        placement_by_rank = gathered
     if rank != 0:
         return
     roof = None
@@ -490,7 +665,13 @@ def main():
             achieved = avg_bytes / avg_s / 1e9
             roof = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS}
-        roof.update({"traffic": measured_traffic(dominant), "avg_launch_us": avg_s * 1e6,
+        traffic = measured_traffic(dominant)
+        roof.update({"traffic": traffic,
+                     "traffic_source": None if traffic is None else
+                     TRAFFIC_TABLE + " (two rocprofv3 --pmc passes of a committed earlier job, FETCH_SIZE / WRITE_SIZE; "
+                     "a constant of that job, not measured in this run)",
+                     "under_load": under_load_instantiations(("conv2d_wide",)) if dominant in TOWERS else None,
+                     "avg_launch_us": avg_s * 1e6,
                      "launches": s["launches"], "algorithmic_bytes_per_launch": avg_bytes,
                      "event_pair_floor_us": s["event_floor_ms"] * 1e3,
                      "clock": "HIP events around every launch of the entry point in %d instrumented eager forwards "
@@ -512,22 +693,7 @@ def main():
     if roof is not None and training:
         # Row Z: the weight gradients (pf_conv_wgrad_f32 / pf_rows_wgrad_f32: f32 MFMA, fixed-order split sums) as a
         # group, the BatchNorm backward passes, and the step's arithmetic as a whole against the f32 matrix peak
-        for tag, entries in (("weight_gradients", ("pf_conv_wgrad_f32", "pf_rows_wgrad_f32")),
-                             ("batchnorm_backward", ("pf_bn_bwd_reduce_f32", "pf_bn_bwd_coeffs_f32", "pf_bn_bwd_apply_f32", "pf_bn_bwd_apply_fused_f32",
-                                                     "pf_rows_bn_bwd_reduce_f32", "pf_rows_bn_bwd_apply_f32")),
-                             ("warp_backward", ("pf_warp_taps_flow_f32", "pf_warp_taps_frustum_f32", "pf_sort_pairs_by_key",
-                                                "pf_variance_grad_f32", "pf_warp_gather_f32",
-                                                "pf_resize_bilinear_backward_f32", "pf_flow_depth_grad_f32"))):
-            grp = [split[k] for k in entries if k in split]
-            if grp:
-                us = sum(v["ms"] for v in grp) * 1e3 / ncal
-                fl = sum(v["flops"] for v in grp) / ncal
-                by = sum(v["bytes"] for v in grp) / ncal
-                roof[tag] = {"kernel_us_per_step": us, "launches_per_step": sum(v["launches"] for v in grp) / float(ncal),
-                             "flops_per_step": fl, "algorithmic_bytes_per_step": by,
-                             "TFLOPs": fl / us / 1e6 if (us > 0 and fl > 0) else None,
-                             "frac_of_f32_mfma_peak": fl / us / 1e6 / MFMA_F32_PEAK_TF if (us > 0 and fl > 0) else None,
-                             "GBps": by / us / 1e3 if us > 0 else None}
+        roof.update(train_groups(split, ncal))
         step_flops = sum(v["flops"] for v in split.values()) / ncal
         roof["whole_step"] = {"flops_per_step": step_flops, "ms_per_step": elapsed / args.steps * 1e3,
                               "TFLOPs": step_flops / (elapsed / args.steps) / 1e12,
@@ -587,10 +753,13 @@ def main():
         "route": args.route,
         "enqueue_wall_ms_per_depth_map": issued / (args.steps * sps) * 1e3,
         "lane_placement_probe_maps_per_s": lane_probe,
+        "lane_placement_probe_by_rank": placement_by_rank,
+        "host_threads_per_rank": torch.get_num_threads(),
         "gap_probe": gap_probe,
         "stage_timeline_us": stage_timeline,
         "roofline": roof,
         "kernels": kernels,
+        "train": train,
     }
     if world == 1 and not args.no_cpu_baseline and (not training or args.train_cpu_baseline):
         data_cpu, _, _ = synthetic.make_config(args.config, seed=my_scenes[0], train_intrinsics=training)

@@ -535,6 +535,13 @@ int pf_conv_wgrad_f32(const float* gr, const float* x, float* dw, int64_t N, int
                       int64_t Ho, int64_t Wo, int64_t Di, int64_t Hi, int64_t Wi, int KD, int KH, int KW, int stride,
                       int pd, int ph, int pw, const float* x_scale, const float* x_shift, int x_samples_per_stat,
                       void* workspace, int64_t workspace_bytes, int accumulate, void* stream);
+/* The launch plan the two weight-gradient entry points use for a shape, for tests that pin it (the plan is a pure
+ * function of the shape and of the device's occupancy for the chosen instantiation): plan12 = {row tiles per block MT,
+ * tile TD, tile TH, channel sub-blocks per block, channels per sub-block, accumulator tiles per wave, position splits,
+ * channel blocks, row blocks, LDS bytes, position tiles per block, stride}. */
+int pf_conv_wgrad_plan(int64_t N, int64_t Cg, int64_t Cx, int64_t Do, int64_t Ho, int64_t Wo, int64_t Di, int64_t Hi,
+                       int64_t Wi, int KD, int KH, int KW, int stride, int* plan12);
+int pf_rows_wgrad_plan(int64_t P, int Cg, int Cx, int* plan12);
 /* The same for a 1x1 convolution over point-major rows: dw[cg][cx] = sum_p gr[p, cg] * act(x[p, cx]);
  * gr (P, ldg), x (P, ldx), Cg % 4 == Cx % 4 == 0; x_scale / x_shift rows (P / x_rows_per_stat, Cx) or NULL. */
 int64_t pf_rows_wgrad_workspace(int64_t P, int Cg, int Cx);

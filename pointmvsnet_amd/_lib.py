@@ -115,6 +115,8 @@ PROTOTYPES = {
     "pf_rows_affine_f32": ([_vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp], _i),
     "pf_conv_wgrad_workspace": ([_i64] * 9 + [_i] * 4, _i64),
     "pf_conv_wgrad_f32": ([_vp, _vp, _vp] + [_i64] * 9 + [_i] * 7 + [_vp, _vp, _i, _vp, _i64, _i, _vp], _i),
+    "pf_conv_wgrad_plan": ([_i64] * 9 + [_i] * 4 + [ctypes.POINTER(_i)], _i),
+    "pf_rows_wgrad_plan": ([_i64, _i, _i, ctypes.POINTER(_i)], _i),
     "pf_rows_wgrad_workspace": ([_i64, _i, _i], _i64),
     "pf_rows_wgrad_f32": ([_vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _vp, _vp, _i64, _vp, _i64, _i, _vp], _i),
     "pf_deconv2d_k5s2_supported": ([_i64, _i64], _i),

@@ -747,6 +747,44 @@ int64_t pf_conv_wgrad_workspace(int64_t N, int64_t Cg, int64_t Cx, int64_t Do, i
   return 4 * Cg * Cx * (int64_t)p.g.T * p.splits;
 }
 
+namespace {
+// The fields of a launch plan a test can pin (pf_conv_wgrad_plan / pf_rows_wgrad_plan): the plan is a pure function of
+// the shape, so "the plan tested is the plan the step uses" is "the same shape gives the same twelve numbers".
+void export_plan(const WgPlan& p, int stride, int* out) {
+  out[0] = p.MT;                       // 16-row tiles of Gr per block
+  out[1] = p.g.TD;                     // position tile: TD x TH x 16 (rows mode: TD * TH * 16 points)
+  out[2] = p.g.TH;
+  out[3] = p.g.CBLK;                   // input-channel sub-blocks per block
+  out[4] = p.g.CBP;                    // channels per sub-block
+  out[5] = (p.g.NTILES + 3) / 4;       // NTW: accumulator tiles per wave (template parameter)
+  out[6] = p.splits;                   // position slices (partials added in this order)
+  out[7] = p.cblocks;
+  out[8] = p.mblocks;
+  out[9] = (int)p.lds_bytes;
+  out[10] = p.g.per_split;             // position tiles per block
+  out[11] = stride;
+}
+}  // namespace
+
+int pf_conv_wgrad_plan(int64_t N, int64_t Cg, int64_t Cx, int64_t Do, int64_t Ho, int64_t Wo, int64_t Di, int64_t Hi,
+                       int64_t Wi, int KD, int KH, int KW, int stride, int* plan12) {
+  PF_REQUIRE(plan12 != nullptr);
+  if (!conv_args_ok(N, Cg, Cx, Do, Ho, Wo, Di, Hi, Wi, KD, KH, KW, stride)) return PF_ERR_UNSUPPORTED;
+  const WgPlan p = make_plan(N, Cg, Cx, Do, Ho, Wo, Di, Hi, Wi, KD, KH, KW, stride, 0, 0, 0, false, 0);
+  if (!p.ok) return PF_ERR_UNSUPPORTED;
+  export_plan(p, stride, plan12);
+  return PF_OK;
+}
+
+int pf_rows_wgrad_plan(int64_t P, int Cg, int Cx, int* plan12) {
+  PF_REQUIRE(plan12 != nullptr);
+  if (P < 1 || Cg < 1 || Cx < 1 || (Cg & 3) || (Cx & 3)) return PF_ERR_UNSUPPORTED;
+  const WgPlan p = make_plan(1, Cg, Cx, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, true, P);
+  if (!p.ok) return PF_ERR_UNSUPPORTED;
+  export_plan(p, 1, plan12);
+  return PF_OK;
+}
+
 int pf_conv_wgrad_f32(const float* gr, const float* x, float* dw, int64_t N, int64_t Cg, int64_t Cx, int64_t Do,
                       int64_t Ho, int64_t Wo, int64_t Di, int64_t Hi, int64_t Wi, int KD, int KH, int KW, int stride,
                       int pd, int ph, int pw, const float* x_scale, const float* x_shift, int x_samples_per_stat,

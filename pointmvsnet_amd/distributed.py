@@ -30,6 +30,13 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+def world_size(group=None):
+    """Ranks in ``group`` (1 without an initialised process group)."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(group)
+    return 1
+
+
 def shard_scenes(num_scenes, rank, world_size):
     """Round-robin scene ownership; the union over ranks is exactly range(num_scenes)."""
     return list(range(rank, num_scenes, world_size))
@@ -102,3 +109,22 @@ def broadcast_parameters(module, src=0, group=None):
         return
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src=src, group=group)
+
+
+def assert_replicas_equal(flat, group=None):
+    """Raise unless every rank of ``group`` holds the same ``flat`` tensor: a float64 (sum, sum of squares) checksum is
+    all-reduced with MIN and with MAX and the two must agree exactly (replicas that applied the same updates in the
+    same order hold the same bits, hence the same sums).  Two small collectives, meant for every N-th step.  Returns the
+    checksum as a tuple of floats; a no-op returning the local checksum for one process."""
+    v = flat.detach().double()
+    local = torch.stack([v.sum(), (v * v).sum()])
+    if world_size(group) <= 1:
+        return tuple(float(x) for x in local)
+    lo, hi = local.clone(), local.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    if not torch.equal(lo, hi):
+        raise RuntimeError("replica parameters diverged: checksum range [%r, %r] over %d ranks (rank %d holds %r); every "
+                           "rank must start from the same model (TrainStep broadcasts rank 0's) and apply every step"
+                           % (lo.tolist(), hi.tolist(), world_size(group), dist.get_rank(group), local.tolist()))
+    return tuple(float(x) for x in local)

@@ -86,6 +86,13 @@ class GraphedForward(object):
                 return True
         return any(t.data_ptr() != a for t, a in zip(self._watched, self._addresses))
 
+    def invalidate(self):
+        """Re-capture on the next call.  The storage address of every parameter / buffer seen at capture is checked on
+        EVERY replay, the module tree and the sub-modules' training flags only every 64th (a walk of ~340 objects costs
+        more than the replay's own enqueue): after ``setattr(module, name, new_parameter)``, registering / removing a
+        sub-module, or ``child.eval()`` on a sub-module, call this instead of waiting out that window."""
+        self._modes = None
+
     def __del__(self):
         try:
             pointflow.pack_unpin(self._packs)
@@ -93,7 +100,8 @@ class GraphedForward(object):
             pass
 
     def __call__(self, data_batch):
-        if (pointflow.pack_entries_stale(self._packs) or self._rebound()   # the graph holds old packs / addresses
+        if (self._modes is None                                            # invalidate()
+                or pointflow.pack_entries_stale(self._packs) or self._rebound()   # the graph holds old packs / addresses
                 or self.model.training != self._modes[0]                   # net.train() / net.eval(): every replay
                 or (self._replays % 64 == 0                                # a sub-module's own flag: every 64th
                     and self._modes != [m.training for m in self.model.modules()])):
@@ -230,6 +238,23 @@ class LanedForward(object):
         with torch.no_grad():
             for a, b in zip(self.models[0].buffers(), self.models[lane].buffers()):
                 b.copy_(a)
+
+    def invalidate(self):
+        """Every lane re-captures on its next submit, after taking the master's sub-module modes and buffers: call after
+        structural changes of the master (a Parameter replaced by ``setattr``, a sub-module's own ``eval()``), which
+        the per-submit checks (storage addresses, the ROOT module's training flag) do not see -- see
+        GraphedForward.invalidate."""
+        torch.cuda.synchronize()
+        master = self.models[0]
+        for lane in range(self.lanes):
+            if lane:
+                rep = self.models[lane]
+                for (_, a), (_, b) in zip(master.named_modules(), rep.named_modules()):
+                    b.training = a.training
+                    for name, p in a._parameters.items():
+                        b._parameters[name] = p
+                self._copy_buffers(lane)
+            self.graphs[lane].invalidate()
 
     def sync_buffers(self):
         """Copy the master's buffers (BatchNorm running statistics) into every lane replica -- call after

@@ -442,6 +442,10 @@ def tower_supported(tower, img):
     last one plain), stride-2 data gradients within the transposed kernel's widths."""
     if img.dim() != 4 or img.dtype != _F32 or not img.is_cuda:
         return False
+    # three stride-2 stages: the data gradient of a 5x5 / 2 layer (pf_deconv2d_k5s2_f32) writes (2 Ho, 2 Wo), which is
+    # the layer's input size only when that is even at every stage; other sizes take the composed ATen path
+    if img.shape[-2] % 8 or img.shape[-1] % 8:
+        return False
     blocks = _tower_blocks(tower)
     for i, (name, last, conv, bn) in enumerate(blocks):
         if not pointflow.conv2d_wide_supported(conv):
@@ -508,6 +512,8 @@ class _TowerTrain(torch.autograd.Function):
                     g = gi if g is None else g + gi
                 if g is None:
                     continue
+                if g.shape != y.shape:
+                    raise RuntimeError("tower backward: gradient %s for an activation %s" % (tuple(g.shape), tuple(y.shape)))
                 if bn is not None:
                     tg, tb = _grad_target(bn.weight), _grad_target(bn.bias)
                     into = (tg, tb) if (tg is not None and tb is not None) else None
@@ -761,7 +767,8 @@ class _EdgeChainTrain(torch.autograd.Function):
                 tg, tb = _grad_target(m.bn.weight), _grad_target(m.bn.bias)
                 grad_le, dgamma, dbeta = pointflow.edge_conv_backward(
                     keep, idx, gy, C, k, 1, N, 1, m.concat, into=(tg, tb) if (tg is not None and tb is not None) else None)
-                wcat = None if _PACKS is not None else torch.cat(
+                chunks = _packed("rows", m.conv1.weight)
+                wcat = None if chunks is not None else torch.cat(
                     [m.conv1.weight.detach().reshape(C, K), m.conv2.weight.detach().reshape(C, K)], dim=0)
                 # conv1 / conv2 are adjacent parameters: in the flat gradient bucket their .grad views form one (2C, K) block
                 t1, t2 = _grad_target(m.conv1.weight), _grad_target(m.conv2.weight)
@@ -769,7 +776,7 @@ class _EdgeChainTrain(torch.autograd.Function):
                 if t1 is not None and t2 is not None and t2.data_ptr() == t1.data_ptr() + 4 * C * K:
                     into = torch.as_strided(t1, (2 * C, K), (K, 1))
                 dw = rows_wgrad(grad_le, X, 2 * C, K, into=into)
-                dX = gemm_rows(grad_le, wcat, 2 * C, K, _packed("rows", m.conv1.weight))   # (N, K)
+                dX = gemm_rows(grad_le, wcat, 2 * C, K, chunks)                            # (N, K)
                 if col == 0:
                     gx = dX
                 else:

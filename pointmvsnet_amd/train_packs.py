@@ -233,8 +233,13 @@ class TrainPacks(object):
 
     # ------------------------------------------------------------------------------------------
     def stale(self):
-        """True when a source parameter moved (``.to()``, ``param.data = ...``): rebuild."""
-        return any(t.data_ptr() != p for t, p in self._params)
+        """True when a source parameter moved (``.to()``, ``param.data = ...``) or the module holds other Parameter
+        OBJECTS than at build time (a parameter replaced by setattr keeps the old object's address unchanged, and the
+        packs are keyed by object identity): rebuild."""
+        current = list(self.model.parameters())
+        if len(current) != len(self._params):
+            return True
+        return any(t is not q or t.data_ptr() != p for q, (t, p) in zip(current, self._params))
 
     def run(self):
         _lib.call("pf_pack_gather_f32", _lib.ptr(self.table), self.n, self.max_total, _lib.stream(),

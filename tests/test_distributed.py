@@ -104,3 +104,62 @@ def test_single_process_is_a_noop():
     assert D.allreduce_gradients_sum(net) == 8
     assert torch.equal(net.weight.grad, before)
     assert D.shard_scenes(5, 0, 1) == [0, 1, 2, 3, 4]
+
+
+def _trainstep_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    D.init_from_env(backend="gloo")
+    from pointmvsnet_amd import synthetic
+    from pointmvsnet_amd.model import PointMVSNet
+    from pointmvsnet_amd.train_step import TrainStep
+    net = PointMVSNet()
+    synthetic.seed_weights(net, seed=rank)                # replicas start different on purpose
+    mine_before = float(sum(p.detach().double().sum() for p in net.parameters()))
+    step = TrainStep(net, check_every=1)                  # broadcasts rank 0's parameters and buffers
+    start = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).clone()
+    buffers = torch.cat([b.detach().reshape(-1).double() for b in net.buffers()])
+    sums = []
+    g = torch.Generator().manual_seed(70 + rank)
+    for _ in range(2):                                    # what a step does after its backward pass, twice
+        step.bucket.zero_()
+        for p in net.parameters():
+            p.grad.add_(torch.randn(p.shape, generator=g) * 1e-2)      # per-rank gradients, summed by finish()
+        step.finish()                                     # all-reduce(SUM) + RMSprop + the replica checksum
+        sums.append(step.check_replicas())
+    moved = not torch.equal(torch.cat([p.detach().reshape(-1) for p in net.parameters()]), start)
+    raised = False
+    if rank == 1:                                         # a replica that drifted: every rank must notice
+        with torch.no_grad():
+            next(net.parameters()).add_(1e-3)
+    try:
+        step.check_replicas()
+    except RuntimeError as exc:
+        raised = "diverged" in str(exc)
+    out[rank] = (mine_before, float(start.double().sum()), float(buffers.sum()), sums, moved, raised, step.steps_done)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_train_step_broadcasts_rank0_and_checks_replicas_world2():
+    """TrainStep in a world of two (gloo): the replicas are seeded differently, TrainStep's constructor makes them rank
+    0's model (parameters and buffers; reference train.py:177: nn.DataParallel broadcasts replica 0 every iteration),
+    two finish() calls (SUM all-reduce of per-rank gradients + RMSprop) keep them equal -- the checksum all-reduce
+    agrees -- and a deliberately perturbed replica makes check_replicas() raise on EVERY rank."""
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_trainstep_worker, args=(world, port, out), nprocs=world, join=True)
+    assert out[0][0] != out[1][0]                          # they really started different
+    assert abs(out[0][1] - out[0][0]) < 1e-9 * max(1.0, abs(out[0][0]))     # ... and both became rank 0's model
+    assert out[0][1] == out[1][1] and out[0][2] == out[1][2]
+    assert out[0][3] == out[1][3] and len(out[0][3]) == 2 and out[0][3][0] != out[0][3][1]
+    assert out[0][4] and out[1][4]
+    assert out[0][5] and out[1][5]
+    assert out[0][6] == out[1][6] == 2
+
+
+def test_replica_check_is_a_noop_for_one_process():
+    t = torch.arange(5, dtype=torch.float32)
+    assert D.assert_replicas_equal(t) == (10.0, 30.0) and D.world_size() == 1

@@ -372,9 +372,12 @@ def test_batch_of_two_scenes_vs_oracle(dev):
         assert float(rel.median()) < 1e-4 and float(rel.max()) < 2e-2
 
 
-@pytest.mark.parametrize("fused", [1, 0])
-def test_train_step_parameter_gradients_vs_oracle_autograd(dev, monkeypatch, fused):
-    """BASELINE config 4's step on "tiny": forward (train mode) + PointMVSNetLoss + backward on our own kernels
+@pytest.mark.parametrize("cfg,fused", [("tiny", 1), ("tiny", 0), ("cfg4", 1)])
+def test_train_step_parameter_gradients_vs_oracle_autograd(dev, monkeypatch, cfg, fused):
+    """BASELINE config 4's step -- on "tiny", and (round 5) at ITS OWN size "cfg4": one 640x512 scene, 3 views, 48 planes,
+    flow-2 on one 102 400-point lattice, i.e. with exactly the launch plans bench.py's train block times (the oracle's
+    float32 and float64 steps take about a minute and ~30 GB on the host) -- forward (train mode) + PointMVSNetLoss +
+    backward on our own kernels
     (fused=1: the seven hand-written autograd nodes of train_ops.py; fused=0: the reference's composition on the HIP
     gather_knn / fetch backward and ATen) against autograd of the CPU oracle (the reference's composition).
     Neighbour choices are discontinuous in the coarse depth (tests/test_sensitivity.py), so the oracle's own kNN
@@ -397,7 +400,7 @@ def test_train_step_parameter_gradients_vs_oracle_autograd(dev, monkeypatch, fus
     from pointmvsnet_amd import networks
     monkeypatch.setattr(networks, "FUSED_TRAIN", fused)
     from pointmvsnet_amd.model import PointMVSNetLoss
-    data, img_scales, inter_scales = synthetic.make_config("tiny", train_intrinsics=True)
+    data, img_scales, inter_scales = synthetic.make_config(cfg, train_intrinsics=True)
     gt = synthetic.make_gt_depth(data)
     net = PointMVSNet()
     synthetic.seed_weights(net, seed=0)
@@ -465,7 +468,7 @@ def test_train_step_parameter_gradients_vs_oracle_autograd(dev, monkeypatch, fus
     print("worst per-tensor gradient deviations (max |diff| / max |ref|):")
     for e, name in errs[:12]:
         print("   %-50s %.3e" % (name, e))
-    report("train_step_gradients_tiny_fused%d" % fused, loss_rel=rel_loss, worst_grad_rel=errs[0][0], grad_l2_rel=l2,
+    report("train_step_gradients_%s_fused%d" % (cfg, fused), loss_rel=rel_loss, worst_grad_rel=errs[0][0], grad_l2_rel=l2,
            median_grad_rel=errs[len(errs) // 2][0], params=float(len(names)),
            grad_l2_rel_vs_f64=l2_gpu64, oracle32_l2_rel_vs_f64=l2_ref64,
            worst_grad_rel_vs_f64=errs_gpu64[0][0], oracle32_worst_grad_rel_vs_f64=errs_ref64[0][0],
@@ -537,23 +540,38 @@ def test_flat_rmsprop_equals_torch_rmsprop(dev, weight_decay):
             assert err < 2e-6, (it, name, err)
     report("flat_rmsprop_wd%g" % weight_decay, worst_param_rel=worst)
     assert flat.attached()
-    sd = flat.state_dict()
-    sq_ref = [ref.state[q]["square_avg"] for q in net_b.parameters()]
-    for i, sq in enumerate(sq_ref):
+    # the state speaks torch.optim.RMSprop's layout on the reference's groups: same indices, same keys, both directions
+    sd, sd_ref = flat.state_dict(), ref.state_dict()
+    assert sorted(sd["state"]) == sorted(sd_ref["state"]) and len(sd["param_groups"]) == len(sd_ref["param_groups"])
+    for g, g_ref in zip(sd["param_groups"], sd_ref["param_groups"]):
+        assert g["params"] == g_ref["params"] and g["weight_decay"] == g_ref["weight_decay"] and g["lr"] == g_ref["lr"]
+    for i, st in sd_ref["state"].items():
+        sq = st["square_avg"]
         assert float((sd["state"][i]["square_avg"] - sq).abs().max() / sq.abs().max().clamp_min(1e-20)) < 2e-6
+        assert float(sd["state"][i]["step"]) == float(st["step"]) == 3.0
     saved = flat.square_avg.clone()
     flat.square_avg.zero_()
     flat.load_state_dict(sd)
     assert torch.equal(flat.square_avg, saved)
+    ref.load_state_dict(sd)                                  # torch's optimizer takes ours ...
+    flat.load_state_dict(ref.state_dict())                   # ... and ours takes torch's
+    assert torch.equal(flat.square_avg, saved) and flat.steps == 3
+    # the reference's scheduler attaches (solver.py:65-80) and the next step runs at the scheduled rate
+    sched = torch.optim.lr_scheduler.StepLR(flat, step_size=1, gamma=0.5)
+    flat.step()
+    sched.step()
+    assert abs(flat.lr - 0.5e-3) < 1e-12
 
 
-def test_train_step_gradient_is_bit_reproducible(dev):
-    """Round 4: no float atomics and no library split-K solver is left in the step -- every convolution / BatchNorm /
+@pytest.mark.parametrize("cfg", ["tiny", "cfg4"])
+def test_train_step_gradient_is_bit_reproducible(dev, cfg):
+    """("cfg4": at the size of BASELINE configs[3], i.e. with the position splits, tiles and row modes of the real step.)
+    Round 4: no float atomics and no library split-K solver is left in the step -- every convolution / BatchNorm /
     warp gradient is a fixed-order sum (train_ops.py) -- so two steps from the same state give the same 698 936
     gradient bits (the reference's step is not reproducible: atomicAdd scatters in gather_knn_kernel.cu:50-89 and in
     grid_sample's backward, cuDNN's atomics-based weight-gradient algorithms)."""
     from pointmvsnet_amd.train_step import TrainStep
-    data, img_scales, inter_scales = synthetic.make_config("tiny", train_intrinsics=True)
+    data, img_scales, inter_scales = synthetic.make_config(cfg, train_intrinsics=True)
     batch = _to(data, dev)
     batch["gt_depth_img"] = synthetic.make_gt_depth(data).to(dev)
     grads, losses = [], []
@@ -567,15 +585,16 @@ def test_train_step_gradient_is_bit_reproducible(dev):
     assert torch.equal(grads[0], grads[1]) and float(grads[0].abs().sum()) > 0
 
 
-def test_graphed_train_step_matches_the_eager_step(dev):
-    """GraphedTrainStep (zero_grad + forward + loss + backward replayed from ONE hipGraph, packs re-packed inside
+@pytest.mark.parametrize("cfg", ["tiny", "cfg4"])
+def test_graphed_train_step_matches_the_eager_step(dev, cfg):
+    """("cfg4": the captured step bench.py times, at its own size.)  GraphedTrainStep (zero_grad + forward + loss + backward replayed from ONE hipGraph, packs re-packed inside
     it) against the eager TrainStep: same losses and the same 698 936 gradients on four consecutive steps over two
     alternating scenes, the parameters changing between the replays -- the later steps only agree if a replay really
     runs on the UPDATED parameters and on the new scene's constants."""
     from pointmvsnet_amd.train_step import GraphedTrainStep, TrainStep
     batches = []
     for seed in (0, 1):
-        data, img_scales, inter_scales = synthetic.make_config("tiny", seed=seed, train_intrinsics=True)
+        data, img_scales, inter_scales = synthetic.make_config(cfg, seed=seed, train_intrinsics=True)
         b = _to(data, dev)
         b["gt_depth_img"] = synthetic.make_gt_depth(data, seed=seed).to(dev)
         batches.append(b)
@@ -596,18 +615,21 @@ def test_graphed_train_step_matches_the_eager_step(dev):
         gg = graphed.t.bucket.flat.detach().clone()
         rel = abs(float(le) - float(lg)) / max(abs(float(le)), 1e-6)
         l2 = float((ge - gg).norm() / ge.norm())
-        report("graphed_train_step_%d" % i, loss_eager=float(le), loss_graphed=float(lg), grad_rel_l2=l2)
-        assert rel < 1e-4, (i, float(le), float(lg))
-        assert torch.isfinite(gg).all() and l2 < 1e-3, (i, l2)           # 698 936 gradients, relative L2
+        report("graphed_train_step_%s_%d" % (cfg, i), loss_eager=float(le), loss_graphed=float(lg), grad_rel_l2=l2,
+               bit_equal=float(torch.equal(ge, gg)))
+        assert rel < 1e-6, (i, float(le), float(lg))
+        # 698 936 gradients, relative L2: the replay runs the same kernels on the same plans in the same order (measured
+        # bit-equal; the gate leaves room for nothing but a last-place difference)
+        assert torch.isfinite(gg).all() and l2 < 1e-6, (i, l2)
         for k in parts_e:
             assert abs(float(parts_e[k]) - float(parts_g[k])) < 1e-4 * max(1.0, abs(float(parts_e[k])))
     assert int(net_g.flow_mlp[0][0].bn.num_batches_tracked) == int(net_e.flow_mlp[0][0].bn.num_batches_tracked)
 
 
 def test_train_step_fused_edgeconv_node_vs_composed_path_on_gpu(dev, monkeypatch):
-    """Same model, same inputs, same GPU libraries for everything around it: the fused EdgeConv autograd node
-    (recompute backward kernels) against the reference's composition on the HIP gather_knn operator.  This isolates
-    OUR backward kernels from the ATen-GPU vs ATen-CPU differences the oracle comparison above also contains."""
+    """A CONSISTENCY check between this package's two training routes, not a parity statement (parity of either route is
+    the oracle comparison above, float32 and float64): same model, same inputs, the fused autograd nodes against the
+    reference's composition on the HIP gather_knn / FeatureFetcher operators + ATen."""
     from pointmvsnet_amd import networks
     from pointmvsnet_amd.model import PointMVSNetLoss
     import pointmvsnet_amd.model as M

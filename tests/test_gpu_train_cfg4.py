@@ -1,0 +1,359 @@
+"""Row Z at ITS OWN size: every backward launch of BASELINE configs[3]'s training step (640x512, 3 views, 48 planes;
+flow-1 on 25 600 points, flow-2 on 102 400) at the EXACT shape the step launches it with, against float64 autograd of
+the ATen operator the reference differentiates (reference train.py:72-82, networks.py:84-167,
+nn/conv.py:24-35,62-77,108-121,197-210), on the same device.
+
+Why this file exists: the weight-gradient kernel's launch plan is a function of the shape (tile candidates, row tiles
+per block, channel blocks, position splits, the big-tile / 128-point modes that only switch on above a size;
+csrc/conv_wgrad.hip make_plan), and tests/test_gpu_train_ops.py runs at (40, 56) images and (8, 16, 24) volumes.
+Here
+
+  * ``test_step_launches_exactly_the_tabulated_shapes`` runs one real cfg-4 step with the C ABI and the data-gradient /
+    BatchNorm-backward helpers recorded and asserts that the SET of launched shapes equals the tables below -- so the
+    per-shape tests cover the step, all of it and nothing else;
+  * every table row is then checked alone against float64 (same gates as the small-shape tests), twice, bit for bit,
+    and its launch plan (pf_conv_wgrad_plan / pf_rows_wgrad_plan: a pure function of the shape) goes to the parity
+    report: the plan tested is the plan the step uses because it is the same shape on the same device;
+  * the tower and VolumeConv NODES run at (3, 3, 512, 640) / (1, 64, 48, 64, 80) against the float64 ATen modules.
+
+The whole step against the oracle (float32 and float64 on the host), its bit-reproducibility and graphed == eager at
+this size are the "cfg4" arms of tests/test_gpu_model.py.
+"""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import report
+from pointmvsnet_amd import _lib, networks, pointflow, synthetic, train_ops
+
+pytestmark = pytest.mark.gpu
+
+V, H, W, D = 3, 512, 640, 48
+P1, P2 = 5 * 64 * 80, 5 * 128 * 160          # points of PointFlow iteration 1 / 2
+
+# ImageConv (networks.py:89-110): (Cout, Cin, input (H, W), k, stride, the input carries a pending BatchNorm + ReLU)
+TOWER = [
+    (8, 3, (512, 640), 3, 1, False), (8, 8, (512, 640), 3, 1, True),
+    (16, 8, (512, 640), 5, 2, True), (16, 16, (256, 320), 3, 1, True),
+    (32, 16, (256, 320), 5, 2, True), (32, 32, (128, 160), 3, 1, True),
+    (64, 32, (128, 160), 5, 2, True), (64, 64, (64, 80), 3, 1, True),
+]
+# VolumeConv (networks.py:133-147): (name, kind, Cout, Cin, input (D, H, W), stride)
+VOLUME = [
+    ("conv0_1", "conv", 8, 64, (48, 64, 80), 1), ("conv1_0", "conv", 16, 64, (48, 64, 80), 2),
+    ("conv2_0", "conv", 32, 16, (24, 32, 40), 2), ("conv3_0", "conv", 64, 32, (12, 16, 20), 2),
+    ("conv3_1", "conv", 64, 64, (6, 8, 10), 1), ("conv1_1", "conv", 16, 16, (24, 32, 40), 1),
+    ("conv2_1", "conv", 32, 32, (12, 16, 20), 1), ("conv4_0", "deconv", 32, 64, (6, 8, 10), 2),
+    ("conv5_0", "deconv", 16, 32, (12, 16, 20), 2), ("conv6_0", "deconv", 8, 16, (24, 32, 40), 2),
+    ("conv6_2", "conv", 1, 8, (48, 64, 80), 1),
+]
+# 1x1 convolutions over point-major rows: EdgeConv [conv1 | conv2] x 3, the flow MLP x 3 (model.py:27-43)
+ROWS = [(64, 136, False), (64, 32, False), (128, 64, False), (64, 224, False), (64, 64, True), (16, 64, True)]
+
+
+def _out(sp, stride):
+    return tuple((s - 1) // stride + 1 for s in sp)
+
+
+def _wgrad_key_conv2d(cout, cin, sp, k, stride, affine):
+    o = _out(sp, stride)
+    return ("conv", V, cout, cin, 1, o[0], o[1], 1, sp[0], sp[1], 1, k, k, stride, bool(affine))
+
+
+def _wgrad_key_volume(kind, cout, cin, sp, stride):
+    if kind == "conv":
+        o = _out(sp, stride)
+        return ("conv", 1, cout, cin) + o + tuple(sp) + (3, 3, 3, stride, False)
+    fine = tuple(2 * s for s in sp)                     # transposed: gr = the layer input (coarse), x = dL/dy (fine)
+    return ("conv", 1, cin, cout) + tuple(sp) + fine + (3, 3, 3, 2, False)
+
+
+EXPECTED_WGRAD = set(_wgrad_key_conv2d(*r) for r in TOWER) | set(_wgrad_key_volume(*r[1:]) for r in VOLUME) | \
+    set(("rows", P, cg, cx, aff) for P in (P1, P2) for cg, cx, aff in ROWS)
+
+# data gradients (train_ops helpers): (helper, dy shape, weight shape, extra)
+EXPECTED_DGRAD = set()
+for cout, cin, sp, k, stride, _aff in TOWER[1:]:
+    EXPECTED_DGRAD.add(("conv2d_dgrad", (V, cout) + _out(sp, stride), (cout, cin, k, k), stride))
+EXPECTED_DGRAD |= {
+    ("conv3d_c1", (1, 1, 48, 64, 80), (1, 8, 3, 3, 3), 1),                            # conv6_2
+    ("conv3d_k3_w", (1, 8, 48, 64, 80), (16, 8, 3, 3, 3), 2),                          # conv6_0 (transposed layer)
+    ("conv3d_k3_w", (1, 16, 24, 32, 40), (32, 16, 3, 3, 3), 2),                        # conv5_0
+    ("conv3d_bottom_w", (1, 32, 12, 16, 20), (64, 32, 3, 3, 3), 2, False),             # conv4_0
+    ("conv3d_bottom_w", (1, 64, 6, 8, 10), (64, 64, 3, 3, 3), 1, True),                # conv3_1
+    ("deconv3d_bottom_w", (1, 64, 6, 8, 10), (64, 32, 3, 3, 3)),                       # conv3_0
+    ("conv3d_dgrad_flip", (1, 32, 12, 16, 20), (32, 32, 3, 3, 3)),                     # conv2_1
+    ("conv3d_dgrad_flip", (1, 16, 24, 32, 40), (16, 16, 3, 3, 3)),                     # conv1_1
+    ("conv3d_dgrad_flip", (1, 8, 48, 64, 80), (8, 64, 3, 3, 3)),                       # conv0_1
+    ("deconv3d_k3s2", (1, 32, 12, 16, 20), (32, 16, 3, 3, 3)),                         # conv2_0
+    ("deconv3d_k3s2", (1, 16, 24, 32, 40), (16, 64, 3, 3, 3)),                         # conv1_0
+}
+# BatchNorm(+ReLU) backward: planar (y shape), rows (C, points)
+EXPECTED_BN = set(("planar", (V, c) + _out(sp, s)) for c, _ci, sp, _k, s, _a in TOWER[:-1]) | \
+    set(("planar", (V, 64, 64, 80)) for _ in (0,)) | \
+    set(("planar", (1, c) + (tuple(2 * x for x in sp) if kind == "deconv" else _out(sp, s)))
+        for _n, kind, c, _ci, sp, s in VOLUME[:-1]) | \
+    set(("rows", c, P) for P in (P1, P2) for c in (64, 16))
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
+
+
+def _seeded(shape, dev, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dev)
+
+
+def _batch(dev, seed=0):
+    data, img_scales, inter_scales = synthetic.make_config("cfg4", seed=seed, train_intrinsics=True)
+    batch = {k: v.to(dev) for k, v in data.items()}
+    batch["cam_params_list_host"] = data["cam_params_list"]
+    batch["mean_host"], batch["std_host"] = data["mean"], data["std"]
+    batch["gt_depth_img"] = synthetic.make_gt_depth(data, seed=seed).to(dev)
+    return batch, img_scales, inter_scales
+
+
+def test_step_launches_exactly_the_tabulated_shapes(dev, monkeypatch):
+    """One real cfg-4 step, recorded: the weight-gradient launches (C ABI arguments), the data-gradient helpers and the
+    BatchNorm-backward helpers see exactly the shapes of the tables above -- what the per-shape tests below cover."""
+    from pointmvsnet_amd.model import PointMVSNet
+    from pointmvsnet_amd.train_step import TrainStep
+    seen_w, seen_d, seen_bn = set(), set(), set()
+    real_call = _lib.call
+
+    def call(name, *args, **kw):
+        if name == "pf_conv_wgrad_f32":
+            seen_w.add(("conv",) + tuple(int(a) for a in args[3:16]) + (args[19] is not None,))
+        elif name == "pf_rows_wgrad_f32":
+            seen_w.add(("rows", int(args[5]), int(args[6]), int(args[7]), args[8] is not None))
+        elif name == "pf_conv3d_k3_c1_f32":
+            seen_d.add(("conv3d_c1", (1, 1) + tuple(int(a) for a in args[5:8]), (1, int(args[4]), 3, 3, 3), 1))
+        return real_call(name, *args, **kw)
+
+    monkeypatch.setattr(_lib, "call", call)
+
+    def wrap(mod, fname, key):
+        real = getattr(mod, fname)
+
+        def inner(*a, **kw):
+            k = key(*a, **kw)
+            if k is not None:
+                (seen_bn if k[0] in ("planar", "rows") else seen_d).add(k)
+            return real(*a, **kw)
+        monkeypatch.setattr(mod, fname, inner)
+
+    wrap(train_ops, "conv2d_dgrad", lambda dy, w, s: ("conv2d_dgrad", tuple(dy.shape), tuple(w.shape), int(s)))
+    wrap(train_ops, "conv3d_dgrad_flip", lambda dy, w: ("conv3d_dgrad_flip", tuple(dy.shape), tuple(w.shape)))
+    wrap(train_ops, "_conv3d_k3_w", lambda x, w, s: ("conv3d_k3_w", tuple(x.shape), tuple(w.shape), int(s)))
+    wrap(train_ops, "_conv3d_bottom_w",
+         lambda x, w, s, flip_t=False: ("conv3d_bottom_w", tuple(x.shape), tuple(w.shape), int(s), bool(flip_t)))
+    wrap(train_ops, "_deconv3d_bottom_w", lambda x, w: ("deconv3d_bottom_w", tuple(x.shape), tuple(w.shape)))
+    wrap(pointflow, "deconv3d_k3s2",
+         lambda x, skip, w, stats, *a, **kw: None if stats else ("deconv3d_k3s2", tuple(x.shape), tuple(w.shape)))
+    wrap(train_ops, "bn_backward", lambda g, y, rows, sps, relu=True, into=None: ("planar", tuple(y.shape)))
+    wrap(train_ops, "rows_bn_backward",
+         lambda g, y, rows, C, G, Ng, gps, relu=True, into=None: ("rows", int(C), int(G) * int(Ng)))
+
+    net = PointMVSNet()
+    synthetic.seed_weights(net, seed=0)
+    net = net.to(dev).train()
+    batch, img_scales, inter_scales = _batch(dev)
+    loss, _, _ = TrainStep(net)(batch, img_scales, inter_scales)
+    assert torch.isfinite(loss)
+    assert seen_w == EXPECTED_WGRAD, (sorted(seen_w - EXPECTED_WGRAD), sorted(EXPECTED_WGRAD - seen_w))
+    assert seen_d == EXPECTED_DGRAD, (sorted(seen_d - EXPECTED_DGRAD, key=str), sorted(EXPECTED_DGRAD - seen_d, key=str))
+    assert seen_bn == EXPECTED_BN, (sorted(seen_bn - EXPECTED_BN, key=str), sorted(EXPECTED_BN - seen_bn, key=str))
+
+
+def _plan_conv(N, Cg, Cx, go, xi, k3, stride):
+    plan = (ctypes.c_int * 12)()
+    _lib.check(_lib.load().pf_conv_wgrad_plan(N, Cg, Cx, go[0], go[1], go[2], xi[0], xi[1], xi[2], k3[0], k3[1], k3[2],
+                                              stride, plan), "pf_conv_wgrad_plan")
+    return list(plan)
+
+
+_PLAN_FIELDS = ("MT", "TD", "TH", "CBLK", "CBP", "NTW", "splits", "cblocks", "mblocks", "lds_bytes", "per_split", "stride")
+
+
+def _report_plan(tag, plan, **errs):
+    report(tag, **dict(zip(("plan_" + f for f in _PLAN_FIELDS), plan), **errs))
+
+
+@pytest.mark.parametrize("Cout,Cin,sp,k,stride,affine", TOWER)
+def test_tower_weight_gradient_at_cfg4_shape(dev, Cout, Cin, sp, k, stride, affine):
+    """pf_conv_wgrad_f32 on the three views of a 640x512 scene, the layer input RAW with its pending per-view
+    BatchNorm + ReLU where the step has one, against autograd of F.conv2d in float64."""
+    x = _seeded((V, Cin) + sp, dev, 5)
+    osp = _out(sp, stride)
+    dy = _seeded((V, Cout) + osp, dev, 6)
+    sc = sh = None
+    xin = x.double()
+    if affine:
+        sc = (1.0 + 0.3 * _seeded((V, Cin), dev, 7)).contiguous()
+        sh = (0.2 * _seeded((V, Cin), dev, 8)).contiguous()
+        xin = torch.relu(xin * sc.double().view(V, Cin, 1, 1) + sh.double().view(V, Cin, 1, 1))
+    w = torch.zeros((Cout, Cin, k, k), dtype=torch.float64, device=dev, requires_grad=True)
+    F.conv2d(xin, w, None, stride, k // 2).backward(dy.double())
+    aff = None if sc is None else (sc, sh)
+    dw = train_ops.conv_wgrad(dy, x, (k, k), stride, (k // 2, k // 2), aff, 1)
+    assert torch.equal(dw, train_ops.conv_wgrad(dy, x, (k, k), stride, (k // 2, k // 2), aff, 1))
+    err = _rel(dw, w.grad)
+    plan = _plan_conv(V, Cout, Cin, (1,) + osp, (1,) + sp, (1, k, k), stride)
+    _report_plan("cfg4shape_tower_wgrad_%dto%d_k%ds%d" % (Cin, Cout, k, stride), plan, rel=err)
+    assert err < 2e-5, (err, plan)
+    # the same shape, the same plan: what the step's launch of this layer runs with
+    assert plan == _plan_conv(V, Cout, Cin, (1,) + osp, (1,) + sp, (1, k, k), stride)
+
+
+@pytest.mark.parametrize("name,kind,Cout,Cin,sp,stride", VOLUME)
+def test_volume_weight_gradient_at_cfg4_shape(dev, name, kind, Cout, Cin, sp, stride):
+    """All eleven VolumeConv layers at 48x64x80 .. 6x8x10: Conv3d layers against autograd of F.conv3d, the three
+    ConvTranspose3d layers (stride 2, padding 1, output_padding 1) against autograd of F.conv_transpose3d (result in
+    nn.ConvTranspose3d's (Cin, Cout, 3, 3, 3) order), float64."""
+    x = _seeded((1, Cin) + sp, dev, 9)
+    if kind == "conv":
+        osp = _out(sp, stride)
+        dy = _seeded((1, Cout) + osp, dev, 10)
+        w = torch.zeros((Cout, Cin, 3, 3, 3), dtype=torch.float64, device=dev, requires_grad=True)
+        F.conv3d(x.double(), w, None, stride, 1).backward(dy.double())
+        run = lambda: train_ops.conv_wgrad(dy, x, (3, 3, 3), stride, (1, 1, 1))
+        plan = _plan_conv(1, Cout, Cin, osp, sp, (3, 3, 3), stride)
+    else:
+        osp = tuple(2 * s for s in sp)
+        dy = _seeded((1, Cout) + osp, dev, 10)
+        w = torch.zeros((Cin, Cout, 3, 3, 3), dtype=torch.float64, device=dev, requires_grad=True)
+        F.conv_transpose3d(x.double(), w, None, 2, 1, 1).backward(dy.double())
+        run = lambda: train_ops.conv_wgrad(x, dy, (3, 3, 3), 2, (1, 1, 1))
+        plan = _plan_conv(1, Cin, Cout, sp, osp, (3, 3, 3), 2)
+    dw = run()
+    assert torch.equal(dw, run())
+    err = _rel(dw, w.grad)
+    _report_plan("cfg4shape_volume_wgrad_%s" % name, plan, rel=err)
+    assert dw.shape == w.shape and err < 2e-5, (err, plan)
+
+
+@pytest.mark.parametrize("P", [P1, P2])
+@pytest.mark.parametrize("Cg,Cx,affine", ROWS)
+def test_rows_weight_gradient_at_cfg4_points(dev, P, Cg, Cx, affine):
+    """pf_rows_wgrad_f32 at 25 600 / 102 400 points on strided row views (the EdgeConv layers read column slices of the
+    (N, 224) concat buffer), against a float64 matrix product."""
+    gbuf = _seeded((P, Cg + 8), dev, 11)
+    xbuf = _seeded((P, Cx + 12), dev, 12)
+    g, x = gbuf[:, 4:4 + Cg], xbuf[:, 8:8 + Cx]
+    xa = x.double()
+    aff = None
+    if affine:
+        sc = (1.0 + 0.3 * _seeded((1, Cx), dev, 13)).contiguous()
+        sh = (0.2 * _seeded((1, Cx), dev, 14)).contiguous()
+        aff = (sc, sh)
+        xa = torch.relu(xa * sc.double() + sh.double())
+    ref = g.double().t() @ xa
+    dw = train_ops.rows_wgrad(g, x, Cg, Cx, aff, P)
+    assert torch.equal(dw, train_ops.rows_wgrad(g, x, Cg, Cx, aff, P))
+    plan = (ctypes.c_int * 12)()
+    _lib.check(_lib.load().pf_rows_wgrad_plan(P, Cg, Cx, plan), "pf_rows_wgrad_plan")
+    err = _rel(dw, ref)
+    _report_plan("cfg4shape_rows_wgrad_%dx%d_P%d" % (Cg, Cx, P), list(plan), rel=err)
+    assert err < 2e-5, (err, list(plan))
+
+
+@pytest.mark.parametrize("Cout,Cin,sp,k,stride,_affine", TOWER[1:])
+def test_tower_data_gradient_at_cfg4_shape(dev, Cout, Cin, sp, k, stride, _affine):
+    x = torch.zeros((V, Cin) + sp, dtype=torch.float64, device=dev, requires_grad=True)
+    w = _seeded((Cout, Cin, k, k), dev, 15, 0.2)
+    dy = _seeded((V, Cout) + _out(sp, stride), dev, 16)
+    F.conv2d(x, w.double(), None, stride, k // 2).backward(dy.double())
+    dx = train_ops.conv2d_dgrad(dy, w, stride)
+    assert torch.equal(dx, train_ops.conv2d_dgrad(dy, w, stride))
+    err = _rel(dx, x.grad)
+    report("cfg4shape_tower_dgrad_%dto%d_k%ds%d" % (Cin, Cout, k, stride), rel=err)
+    assert dx.shape == x.shape and err < 1e-5, err
+
+
+@pytest.mark.parametrize("name,kind,Cout,Cin,sp,stride", VOLUME)
+def test_volume_data_gradient_at_cfg4_shape(dev, name, kind, Cout, Cin, sp, stride):
+    """The data gradient of every VolumeConv layer through the helper _VolumeTrain.backward uses for it, against
+    autograd of F.conv3d / F.conv_transpose3d in float64."""
+    x = torch.zeros((1, Cin) + sp, dtype=torch.float64, device=dev, requires_grad=True)
+    if kind == "conv":
+        w = _seeded((Cout, Cin, 3, 3, 3), dev, 17, 0.1)
+        dy = _seeded((1, Cout) + _out(sp, stride), dev, 18)
+        F.conv3d(x, w.double(), None, stride, 1).backward(dy.double())
+    else:
+        w = _seeded((Cin, Cout, 3, 3, 3), dev, 17, 0.1)
+        dy = _seeded((1, Cout) + tuple(2 * s for s in sp), dev, 18)
+        F.conv_transpose3d(x, w.double(), None, 2, 1, 1).backward(dy.double())
+    if name == "conv6_2":
+        def run():
+            wf = w.flip(2, 3, 4).reshape(Cin, 27).contiguous()
+            g7 = torch.empty((1, Cin) + sp, dtype=torch.float32, device=dev)
+            _lib.call("pf_conv3d_k3_c1_f32", _lib.ptr(dy), _lib.ptr(wf), _lib.ptr(g7), 1, Cin, sp[0], sp[1], sp[2],
+                      _lib.stream())
+            return g7
+    elif name in ("conv6_0", "conv5_0"):
+        run = lambda: train_ops._conv3d_k3_w(dy, w, 2)
+    elif name == "conv4_0":
+        run = lambda: train_ops._conv3d_bottom_w(dy, w, 2)
+    elif name == "conv3_1":
+        run = lambda: train_ops._conv3d_bottom_w(dy, w, 1, flip_t=True)
+    elif name == "conv3_0":
+        run = lambda: train_ops._deconv3d_bottom_w(dy, w)
+    elif name in ("conv2_0", "conv1_0"):
+        run = lambda: pointflow.deconv3d_k3s2(dy, None, w, False)[0]
+    else:
+        run = lambda: train_ops.conv3d_dgrad_flip(dy, w)
+    with pointflow.no_pack_cache():
+        dx = run()
+        assert torch.equal(dx, run())
+    err = _rel(dx, x.grad)
+    report("cfg4shape_volume_dgrad_%s" % name, rel=err)
+    assert dx.shape == x.shape and err < 1e-5, err
+
+
+_BN_PLANAR = sorted(set(k[1] for k in EXPECTED_BN if k[0] == "planar"))
+
+
+@pytest.mark.parametrize("shape", _BN_PLANAR, ids=lambda s: "x".join(str(v) for v in s))
+def test_bn_relu_backward_at_cfg4_shape(dev, shape):
+    """pf_bn_bwd_reduce + pf_bn_bwd_apply_fused on every (samples, channels, spatial) the step has: the towers'
+    per-view statistics (3 statistic groups), VolumeConv's single sample."""
+    import test_gpu_train_ops as T
+    T.test_bn_relu_backward_vs_float64_autograd(dev, shape[0], shape[1], tuple(shape[2:]), 1, True)
+
+
+@pytest.mark.parametrize("P", [P1, P2])
+@pytest.mark.parametrize("C", [64, 16])
+def test_rows_bn_relu_backward_at_cfg4_points(dev, P, C):
+    """The flow MLP's BatchNorm1d + ReLU backward on point-major rows (pf_rows_bn_bwd_reduce / pf_bn_bwd_coeffs /
+    pf_rows_bn_bwd_apply) against autograd of F.batch_norm(training) + relu in float64."""
+    y = _seeded((P, C), dev, 21, 2.0) + 0.3
+    g = _seeded((P, C), dev, 22)
+    bn = torch.nn.BatchNorm1d(C).to(dev).train()
+    with torch.no_grad():
+        bn.weight.copy_(1.0 + 0.2 * _seeded((C,), dev, 23))
+        bn.bias.copy_(0.1 * _seeded((C,), dev, 24))
+    yd = y.double()
+    parts = torch.stack([yd.sum(0), (yd * yd).sum(0)], dim=1).view(1, 1, C, 2).contiguous()
+    rows = train_ops.bn_train_rows(bn, parts, 0, C, float(P), 1, 1)
+    dy, dgamma, dbeta = train_ops.rows_bn_backward(g, y, rows, C, 1, P, 1, True)
+    dy2, dgamma2, dbeta2 = train_ops.rows_bn_backward(g, y, rows, C, 1, P, 1, True)
+    assert torch.equal(dy, dy2) and torch.equal(dgamma, dgamma2) and torch.equal(dbeta, dbeta2)
+    yr = yd.clone().requires_grad_(True)
+    wr, br = bn.weight.detach().double().requires_grad_(True), bn.bias.detach().double().requires_grad_(True)
+    torch.relu(F.batch_norm(yr, None, None, wr, br, True, 0.0, bn.eps)).backward(g.double())
+    e = dict(dy=_rel(dy, yr.grad), dgamma=_rel(dgamma, wr.grad), dbeta=_rel(dbeta, br.grad))
+    report("cfg4shape_rows_bn_bwd_C%d_P%d" % (C, P), **e)
+    assert e["dy"] < 1e-5 and e["dgamma"] < 2e-5 and e["dbeta"] < 2e-5, e
+
+
+def test_image_tower_node_at_cfg4_size_vs_float64(dev):
+    import test_gpu_train_ops as T
+    T.test_image_tower_node_vs_float64_autograd(dev, (H, W))
+
+
+def test_volume_conv_node_at_cfg4_size_vs_float64(dev):
+    import test_gpu_train_ops as T
+    T.test_volume_conv_node_vs_float64_autograd(dev, (D, H // 8, W // 8))

@@ -270,3 +270,42 @@ def test_scene_plan_block_equals_the_reference_camera_algebra_bit_for_bit(cfg, b
         for name, t in want.items():
             got = plan._h(name)
             assert torch.equal(got, t.reshape(got.shape).float()), (cfg, seed, is_test, name)
+
+
+def test_flat_rmsprop_state_is_interchangeable_with_torch_rmsprop():
+    """train_step.FlatRMSprop is a torch.optim.Optimizer on the reference's two parameter groups (solver.py:33-52:
+    everything but '.bn.' with weight decay, then the '.bn.' parameters) and its state_dict is torch.optim.RMSprop's
+    layout, both directions -- host logic only (step() is a HIP launch, tests/test_gpu_model.py)."""
+    from pointmvsnet_amd import distributed
+    from pointmvsnet_amd.model import PointMVSNet
+    from pointmvsnet_amd.train_step import FlatRMSprop, param_groups
+    net = PointMVSNet()
+    bucket = distributed.GradBucket(net)
+    flat = FlatRMSprop(bucket, list(net.named_parameters()), lr=1e-3, alpha=0.9, weight_decay=1e-4)
+    ref = torch.optim.RMSprop(param_groups(net, 1e-4), lr=1e-3, alpha=0.9)
+    assert isinstance(flat, torch.optim.Optimizer) and flat.attached() and bucket.attached()
+    assert [len(g["params"]) for g in flat.param_groups] == [len(g["params"]) for g in ref.param_groups]
+    for g, h in zip(flat.param_groups, ref.param_groups):
+        assert all(a is b for a, b in zip(g["params"], h["params"])) and g["weight_decay"] == h["weight_decay"]
+    for p in net.parameters():
+        p.grad.add_(0.01)
+    ref.step()                                              # torch builds its state; ours must accept it
+    flat.load_state_dict(ref.state_dict())
+    sd, sd_ref = flat.state_dict(), ref.state_dict()
+    assert flat.steps == 1 and sorted(sd["state"]) == sorted(sd_ref["state"])
+    assert all(torch.equal(sd["state"][i]["square_avg"], sd_ref["state"][i]["square_avg"]) for i in sd_ref["state"])
+    assert [g["params"] for g in sd["param_groups"]] == [g["params"] for g in sd_ref["param_groups"]]
+    ref.load_state_dict(sd)                                 # ... and torch accepts ours
+    assert flat.wd is not None and float(flat.wd.sum()) > 0
+    # the '.bn.' parameters carry no decay: their span of the per-element vector is zero
+    for name, p in net.named_parameters():
+        o, n = flat._span[id(p)]
+        assert float(flat.wd[o:o + n].abs().sum()) == (0.0 if ".bn." in name else float(flat.wd[o:o + n].abs().sum()))
+        if ".bn." in name:
+            assert float(flat.wd[o:o + n].abs().sum()) == 0.0
+    sched = torch.optim.lr_scheduler.StepLR(flat, step_size=1, gamma=0.1)     # the reference's scheduler attaches
+    assert flat.lr == 1e-3
+    flat.set_lr(5e-4)
+    assert flat.lr == 5e-4 and sched is not None
+    flat.zero_grad(set_to_none=True)                        # must keep the bucket views
+    assert bucket.attached() and float(bucket.flat.abs().sum()) == 0.0
