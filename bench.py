@@ -131,6 +131,10 @@ def parse_args():
     ap.add_argument("--no-train-block", action="store_true",
                     help="cfg2 only: do not time BASELINE configs[3]'s training step after the headline's timed region")
     ap.add_argument("--train-steps", type=int, default=20, help="timed replays of the training step in the train block")
+    ap.add_argument("--train-timeout", type=float, default=240.0,
+                    help="seconds the train block's child process may take before it is killed (the headline is kept)")
+    ap.add_argument("--train-block-only", action="store_true",
+                    help="(internal) be the train block's child process: time BASELINE configs[3]'s step, print its JSON")
     ap.add_argument("--cpu-repeats", type=int, default=3)
     ap.add_argument("--train-cpu-baseline", action="store_true",
                     help="cfg4 only: also time ONE oracle training step on the host (tens of seconds, ~15 GB of RAM)")
@@ -326,7 +330,19 @@ def graph_kernel_nodes(make_graphed):
     try:
         graphed = make_graphed(True)
         raw = graphed.graph.raw_cuda_graph()
-        hip = ctypes.CDLL("libamdhip64.so")
+        # the HIP runtime this process already runs on (torch's bundled one), not whatever "libamdhip64.so" resolves to
+        path = None
+        for line in open("/proc/self/maps"):
+            if "libamdhip64" in line:
+                path = line.split()[-1]
+                break
+        if path is None:
+            return None, "no libamdhip64 mapped"
+        hip = ctypes.CDLL(path)
+        hip.hipGraphGetNodes.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t)]
+        hip.hipGraphGetNodes.restype = ctypes.c_int
+        hip.hipGraphNodeGetType.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+        hip.hipGraphNodeGetType.restype = ctypes.c_int
         n = ctypes.c_size_t(0)
         if hip.hipGraphGetNodes(ctypes.c_void_p(raw), None, ctypes.byref(n)) != 0:
             return None, "hipGraphGetNodes failed"
@@ -400,18 +416,13 @@ def train_block(dev, rank, world, steps=20, warmup=3):
         torch.cuda.synchronize()
         allreduce_us = statistics.median(ev[j].elapsed_time(ev[j + 1]) for j in range(1, 21)) * 1e3
     assert torch.isfinite(loss)
-    kernels, all_nodes = graph_kernel_nodes(
-        lambda keep: GraphedTrainStep(trainer, scenes[0], img_scales, inter_scales, warmup=1, keep_graph=keep))
     ms = elapsed / steps * 1e3
     out = {"metric": "train-scenes/sec (DTU 640x512, 3 views, 1 scene per GPU, forward+loss+backward+all-reduce+RMSprop)",
            "value": world * steps / elapsed, "unit": "train-scenes/s", "ms_per_step": ms, "steps": steps,
            "warmup": warmup, "n_gpus": world, "allreduce_us": allreduce_us,
            "execution": "hipGraph replay of zero_grad + forward + loss + backward%s; all-reduce + RMSprop step eager"
                         % (" (flow tower forward / backward on a second stream)" if _model.TRAIN_FORK else ""),
-           "dispatches_per_step": None if kernels is None else kernels + 1 + (1 if world > 1 else 0),
-           "dispatches_source": ("kernel nodes of the captured hipGraph (hipGraphGetNodes: %s nodes in all) + RMSprop%s"
-                                 % (all_nodes, " + the all-reduce" if world > 1 else "")) if kernels is not None
-                                else "unavailable: %s" % (all_nodes,),
+           "dispatches_per_step": None, "dispatches_source": "not counted",
            "own_entry_point_calls_per_step": own_calls,
            "whole_step": {"flops_per_step": step_flops, "TFLOPs": step_flops / (ms / 1e3) / 1e12,
                           "frac_of_f32_mfma_peak": step_flops / (ms / 1e3) / 1e12 / MFMA_F32_PEAK_TF,
@@ -419,11 +430,94 @@ def train_block(dev, rank, world, steps=20, warmup=3):
            "clock": "groups: HIP events around every C-ABI call of %d eager steps (raw pair times); ms_per_step: wall "
                     "clock over %d graph replays between synchronisations" % (ncal, steps)}
     out.update(train_groups(split, ncal))
-    return out
+
+    def count_dispatches():
+        """A second capture with the hipGraph kept, walked for its kernel nodes (after the timing: the caller has already
+        published ``out`` when this runs, so whatever happens in here costs only these two fields)."""
+        kernels, all_nodes = graph_kernel_nodes(
+            lambda keep: GraphedTrainStep(trainer, scenes[0], img_scales, inter_scales, warmup=1, keep_graph=keep))
+        if kernels is None:
+            out["dispatches_source"] = "unavailable: %s" % (all_nodes,)
+            return out
+        out["dispatches_per_step"] = kernels + 1 + (1 if world > 1 else 0)
+        out["dispatches_source"] = ("kernel nodes of the captured hipGraph (hipGraphGetNodes: %s nodes in all) + RMSprop%s"
+                                    % (all_nodes, " + the all-reduce" if world > 1 else ""))
+        return out
+
+    return out, count_dispatches
+
+def train_block_in_child(args, rank, world):
+    """Run train_block in a CHILD process per rank (``--train-block-only``) and return rank 0's JSON (None on the other
+    ranks): a crash, an exception on one rank or a hang in there -- the step's RCCL path has never run on more than one
+    GPU -- costs the ``train`` entry (it then says what happened), never the headline line.  The children form their own
+    process group on a fresh port; a child that outlives ``--train-timeout`` is killed."""
+    import subprocess
+    env = dict(os.environ)
+    if world > 1:
+        box = [free_port() if rank == 0 else None]
+        torch.distributed.broadcast_object_list(box, src=0)
+        env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(int(box[0])))
+        env.pop("TORCHELASTIC_USE_AGENT_STORE", None)      # rank 0's child hosts the store of the children's group
+    cmd = [sys.executable, os.path.abspath(__file__), "--train-block-only", "--gpus", str(world),
+           "--train-steps", str(max(1, args.train_steps)), "--no-cpu-baseline"]
+    t0 = time.perf_counter()
+    try:
+        proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True,
+                              timeout=float(args.train_timeout))
+    except subprocess.TimeoutExpired:
+        return {"error": "the train block's child process did not finish within %.0f s and was killed"
+                         % float(args.train_timeout)} if rank == 0 else None
+    except OSError as exc:
+        return {"error": repr(exc)} if rank == 0 else None
+    if rank != 0:
+        return None
+    for line in reversed(proc.stdout.splitlines()):
+        if line.startswith("{"):
+            try:
+                out = json.loads(line)
+                out["child_wall_s"] = time.perf_counter() - t0
+                return out
+            except ValueError:
+                break
+    return {"error": "the train block's child process exited with code %s without a result" % (proc.returncode,),
+            "stderr_tail": proc.stderr[-600:]}
+
+
+def train_block_child(args):
+    """``--train-block-only``: this process IS the child of train_block_in_child."""
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        torch.set_num_threads(int(os.environ.get("OMP_NUM_THREADS") or host_threads_per_rank(os.environ["WORLD_SIZE"])))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    rank, world, local = distributed.init_from_env()
+    dev = torch.device("cuda", local)
+    _lib.load()
+    recount = None
+    try:
+        out, recount = train_block(dev, rank, world, steps=max(1, args.train_steps))
+    except Exception as exc:                      # (the parent reports it; a rank that fails here may leave the others
+        out = {"error": repr(exc)}                # waiting in a collective: the parent's timeout ends that)
+    if rank == 0:
+        print(json.dumps(out), flush=True)        # the timing first; the parent takes the LAST line it can parse
+    if recount is not None and world == 1:        # (one more capture: one rank only, nothing collective in it)
+        try:
+            out = recount()
+            print(json.dumps(out), flush=True)
+        except Exception:
+            pass
+    if world > 1:
+        try:
+            torch.distributed.destroy_process_group()
+        except Exception:
+            pass
 
 
 def main():
     args = parse_args()
+    if args.train_block_only:
+        if not torch.cuda.is_available():
+            raise RuntimeError("bench.py needs a GPU: the hot path has no CPU fallback")
+        return train_block_child(args)
     maybe_relaunch(args)
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:               # one of N ranks (torchrun, or the driver's launch line)
         torch.set_num_threads(int(os.environ.get("OMP_NUM_THREADS") or host_threads_per_rank(os.environ["WORLD_SIZE"])))
@@ -638,10 +732,7 @@ def main():
 
     train = None
     if args.config == "cfg2" and args.route == "fused" and not args.no_train_block:
-        try:                                     # (after the headline's timed region; its fields are not touched)
-            train = train_block(dev, rank, world, steps=max(1, args.train_steps))
-        except Exception as exc:                 # say so in the line, do not lose the headline
-            train = {"error": repr(exc)}
+        train = train_block_in_child(args, rank, world)    # (after the headline's timed region; its fields are not touched)
     placement_by_rank = None
     if world > 1:
         gathered = [None] * world

@@ -21,7 +21,7 @@ class BnJob(ctypes.Structure):
                 ("C", ctypes.c_int32), ("count", _d), ("unbias_n", _d), ("gamma", _vp), ("beta", _vp),
                 ("running_mean", _vp), ("running_var", _vp), ("momentum", _f), ("eps", _f),
                 ("G", ctypes.c_int32), ("groups_per_stat", ctypes.c_int32), ("scale", _vp), ("shift", _vp),
-                ("ld_affine", ctypes.c_int32)]
+                ("ld_affine", ctypes.c_int32), ("mean", _vp), ("invstd", _vp)]
 
 
 # name -> argtypes; every entry must exist in include/pointflow_hip.h (tests/test_abi.py checks both ways)
@@ -73,6 +73,9 @@ PROTOTYPES = {
                             _vp, _i, _vp], _i),
     "pf_conv2d_wide_sets_f32": ([_vp, _i, _vp, _i64, _i, _vp, _i64, _i64, _i64, _i64, _i64, _i, _i, _vp, _vp,
                                  ctypes.POINTER(BnJob), _i, _vp, _i, _vp], _i),
+    "pf_conv2d_wide_split_supported": ([_i64, _i64, _i, _i], _i),
+    "pf_conv2d_wide_split_sets_f32": ([_vp, _i, _vp, _i64, _i, _vp, _i64, _i64, _i64, _i64, _i64, _i, _i, _vp, _vp,
+                                       ctypes.POINTER(BnJob), _i, _vp, _i, _vp], _i),
     "pf_norm_blocks": ([_i64], _i),
     "pf_channel_stats_f32": ([_vp, _i64, _i64, _i64, _vp, _vp], _i),
     "pf_channel_affine_f32": ([_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _vp], _i),

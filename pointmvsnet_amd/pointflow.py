@@ -268,8 +268,11 @@ def bn_job(bn, partials, col0, C, count, unbias_n, G, groups_per_stat, scale, sh
                       int(scale.stride(0)))
 
 
+MAX_BN_JOBS = 28          # jobs per pf_bn_finalize_jobs_f32 launch (kBnJobs of csrc/edgeconv.hip: 4 KB of kernel arguments)
+
+
 def bn_finalize_jobs(jobs):
-    """Up to 32 finalize jobs in one launch (pf_bn_finalize_jobs_f32)."""
+    """Up to MAX_BN_JOBS finalize jobs in one launch (pf_bn_finalize_jobs_f32)."""
     arr = (_lib.BnJob * len(jobs))(*jobs)
     _lib.call("pf_bn_finalize_jobs_f32", arr, len(jobs), _lib.stream(),
               algo_bytes=sum(16.0 * j.G * j.T * j.C for j in jobs))
@@ -301,10 +304,14 @@ class LazyAffine(object):
         self.done = False                 # finalize launched (rows valid, running statistics updated)
         self.queued = False
 
-    def job_ptr(self):
+    def defer(self):
+        """Queue the finalize for the next flush_lazy_stats (the rows and running statistics are wanted, just not now)."""
         if not (self.done or self.queued):
             self.queued = True
             _lazy_list(self.scale.device).append(self)
+
+    def job_ptr(self):
+        self.defer()
         return ctypes.pointer(self.job)
 
     def rows(self):
@@ -347,7 +354,7 @@ def _lazy_list(device):
 
 def flush_lazy_stats(device=None):
     """Running statistics (and the scale/shift rows) of every BatchNorm that was resolved by its consumer since
-    the last call: ONE batched finalize launch (<= 32 jobs each) on the current stream.  ``flush_counters`` calls
+    the last call: ONE batched finalize launch (<= MAX_BN_JOBS jobs each) on the current stream.  ``flush_counters`` calls
     it at the end of a forward -- the only place where it is off every consumer's critical path without a
     stream of its own (a further side stream made hipGraph serialise the coarse stage behind the flow tower:
     profiles/archive/r02/r02ah_lazy_bn_side_stream_timeline.txt)."""
@@ -368,9 +375,19 @@ def flush_lazy_stats(device=None):
                 layers.append([])
             layers[k].append(z)
         with torch.cuda.device(torch.device(dev)):
+            cur = None
+            for z in lazy:                     # a job made on another stream (the training step's flow tower): its
+                origin = getattr(z, "origin", None)        # tensors are read here, tell the caching allocator
+                if origin is None:
+                    continue
+                cur = torch.cuda.current_stream() if cur is None else cur
+                if origin != cur:
+                    for t in z.keep:
+                        if t.is_cuda:
+                            t.record_stream(cur)
             for layer in layers:
-                for i in range(0, len(layer), 32):
-                    bn_finalize_jobs([z.job for z in layer[i:i + 32]])
+                for i in range(0, len(layer), MAX_BN_JOBS):
+                    bn_finalize_jobs([z.job for z in layer[i:i + MAX_BN_JOBS]])
         for z in lazy:
             z.done = True
 
@@ -603,6 +620,40 @@ def _pack_conv2d_wide(weight):
     return w.permute(0, 1, 2, 3, 5, 4).contiguous()
 
 
+# PF_MATRIX_SPLIT=1: the 32- / 64-channel tower layers run with their products on the bf16 matrix cores at float32
+# accuracy (csrc/conv2d_wide.hip, conv2d_wide_split_kernel: three bf16 terms per operand, six products, float32
+# accumulate).  An EXPERIMENT: built in round 5, never measured on hardware (the round lost its GPU access), so the default
+# is the exact-f32 kernels and bench.py says which one ran.  tools/microbench_split.py times and checks it.
+MATRIX_SPLIT = int(_os.environ.get("PF_MATRIX_SPLIT", "0"))
+
+
+def split3_bf16(t):
+    """(hi, mid, lo) bfloat16 tensors with hi + mid + lo == t exactly for float32 t (each term the round-to-nearest
+    bfloat16 of what the previous ones left; the remainders are exact float32 differences)."""
+    t = t.detach().to(_F32)
+    hi = t.to(torch.bfloat16)
+    r1 = t - hi.to(_F32)
+    mid = r1.to(torch.bfloat16)
+    lo = (r1 - mid.to(_F32)).to(torch.bfloat16)
+    return hi, mid, lo
+
+
+def _pack_conv2d_wide_split(weight):
+    """(Cout, Cin, K, K) float32 -> (K*K*Cin/16, 3, 2, Cout, 8) bfloat16 for pf_conv2d_wide_split_sets_f32:
+    [t][s][h][co][j] = split s of w[co][16 kb + 8 h + j][kh][kw], t = (kh K + kw) Cin/16 + kb."""
+    cout, cin, k, _ = weight.shape
+    parts = []
+    for term in split3_bf16(weight):
+        w = term.permute(2, 3, 1, 0).reshape(k * k, cin // 16, 2, 8, cout)          # [tap][kb][h][j][co]
+        parts.append(w.permute(0, 1, 2, 4, 3).reshape(k * k * (cin // 16), 2, cout, 8))
+    return torch.stack(parts, dim=1).contiguous()
+
+
+def conv2d_wide_split_supported(conv):
+    return bool(MATRIX_SPLIT and conv2d_supported(conv) and _lib.load().pf_conv2d_wide_split_supported(
+        conv.in_channels, conv.out_channels, int(conv.kernel_size[0]), int(conv.stride[0])))
+
+
 def pack_conv2d_wide_weight(weight):
     """(Cout,Cin,K,K) -> (K, K, Cin/8, 2, Cout, 4): [kh][kw][kc][h][co][j] = w[co][8 kc + 4 h + j][kh][kw]
     (Cout 32 / 64: 32x32x2 MFMA), or, for Cout = 8 / 16 (16x16x4 MFMA), (K, K, 4, 16, Cin'/4) with Cin' = Cin
@@ -618,13 +669,24 @@ def conv2d_wide(x, conv, in_affine, samples_per_stat, want_stats, channel_last_o
     Cout = conv.out_channels
     ks, stride = conv.kernel_size[0], conv.stride[0]
     Ho, Wo = (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
-    wp = pack_conv2d_wide_weight(conv.weight)
+    split = conv2d_wide_split_supported(conv)
+    if split:
+        wp = _cached_pack(("c2wsp", id(conv.weight)), (conv.weight,), lambda: _pack_conv2d_wide_split(conv.weight))
+    else:
+        wp = pack_conv2d_wide_weight(conv.weight)
     y = torch.empty((N, Ho, Wo, Cout) if channel_last_out else (N, Cout, Ho, Wo), dtype=_F32, device=x.device)
     partials = None
     if want_stats:
         T = int(_lib.load().pf_conv2d_wide_blocks(Cout, Hi, Wi, int(stride)))
         partials = stat_rows(N, T, Cout, x.device)
     sc, sh, in_bn = _split_affine(in_affine)
+    if split:
+        _lib.call("pf_conv2d_wide_split_sets_f32", _lib.ptr(x), 0, _lib.ptr(wp), 0, 1, _lib.ptr(y), N, Cin, Cout, Hi, Wi,
+                  int(ks), int(stride), _lib.ptr(sc), _lib.ptr(sh), in_bn, int(samples_per_stat), _lib.ptr(partials),
+                  int(bool(channel_last_out)), _lib.stream(),
+                  algo_bytes=4.0 * N * (Cin * Hi * Wi + Cout * Ho * Wo) + 6.0 * ks * ks * Cin * Cout,
+                  flops=2.0 * N * Ho * Wo * ks * ks * Cin * Cout)
+        return y, partials
     _lib.call("pf_conv2d_wide_f32", _lib.ptr(x), _lib.ptr(wp), _lib.ptr(y), N, Cin, Cout, Hi, Wi, int(ks), int(stride),
               _lib.ptr(sc), _lib.ptr(sh), in_bn, int(samples_per_stat), _lib.ptr(partials), int(bool(channel_last_out)),
               _lib.stream(), algo_bytes=4.0 * N * (Cin * Hi * Wi + Cout * Ho * Wo) + 4.0 * ks * ks * Cin * Cout,
@@ -714,7 +776,13 @@ def conv2d_wide_sets(x, convs, in_affine, samples_per_stat, want_stats, interlea
     Cout = conv.out_channels
     ks, stride = conv.kernel_size[0], conv.stride[0]
     Ho, Wo = (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
-    wp = pack_conv2d_wide_weight_sets([c.weight for c in convs])
+    split = all(conv2d_wide_split_supported(c) for c in convs)
+    if split:
+        weights = tuple(c.weight for c in convs)
+        wp = _cached_pack(("c2wsps",) + tuple(id(w) for w in weights), weights,
+                          lambda: torch.stack([_pack_conv2d_wide_split(w) for w in weights]).contiguous())
+    else:
+        wp = pack_conv2d_wide_weight_sets([c.weight for c in convs])
     y = torch.empty((N, Cout, Ho, Wo), dtype=_F32, device=x.device)
     partials = None
     if want_stats:
@@ -722,6 +790,13 @@ def conv2d_wide_sets(x, convs, in_affine, samples_per_stat, want_stats, interlea
         partials = stat_rows(N, T, Cout, x.device)
     sc, sh, in_bn = (None, None, None) if in_affine is None else in_affine.split()
     mask = sum(1 << s for s in channel_last_sets)
+    if split:
+        _lib.call("pf_conv2d_wide_split_sets_f32", _lib.ptr(x), 2 if interleaved else 0, _lib.ptr(wp), int(wp[0].numel()),
+                  sets, _lib.ptr(y), N, Cin, Cout, Hi, Wi, int(ks), int(stride), _lib.ptr(sc), _lib.ptr(sh), in_bn,
+                  int(samples_per_stat), _lib.ptr(partials), int(mask), _lib.stream(),
+                  algo_bytes=4.0 * (x.numel() + N * Cout * Ho * Wo) + 6.0 * sets * ks * ks * Cin * Cout,
+                  flops=2.0 * N * Ho * Wo * ks * ks * Cin * Cout)
+        return y, partials
     _lib.call("pf_conv2d_wide_sets_f32", _lib.ptr(x), 2 if interleaved else 0, _lib.ptr(wp), int(wp[0].numel()), sets,
               _lib.ptr(y), N, Cin, Cout, Hi, Wi, int(ks), int(stride), _lib.ptr(sc), _lib.ptr(sh), in_bn,
               int(samples_per_stat), _lib.ptr(partials), int(mask), _lib.stream(),
@@ -1012,13 +1087,26 @@ def edge_conv_fused(X, point_major, ldx, K, G, Ng, idx, conv1_w, conv2_w, bn, co
             # training: one finalize per half that also keeps (mean, invstd) for the backward (pf_bn_train_rows_f32)
             from . import train_ops
             rows4 = torch.empty((4, S, cbn), dtype=_F32, device=dev)
-            if concat:
-                train_ops.bn_train_rows(bn, part_l, 0, C, float(groups_per_stat) * Ng, G, groups_per_stat,
-                                        unbias_n=n_pairs, rows=rows4, col_out=0, ch0=0, bump=False)
-                train_ops.bn_train_rows(bn, part_d, 0, C, n_pairs, G, groups_per_stat, rows=rows4, col_out=C, ch0=C,
-                                        bump=False)
+
+            def job4(partials, count, unbias_n, col, ch0):
+                j = bn_job(bn, partials, 0, C, count, unbias_n, G, groups_per_stat, rows4[0][:, col:], rows4[1][:, col:],
+                           ch0=ch0)
+                j.mean, j.invstd = rows4[2][:, col:].data_ptr(), rows4[3][:, col:].data_ptr()
+                return j
+
+            if not train_ops.TRAIN_LAZY_BN:          # round 4's form: one pf_bn_train_rows_f32 launch per half
+                if concat:
+                    train_ops.bn_train_rows(bn, part_l, 0, C, float(groups_per_stat) * Ng, G, groups_per_stat,
+                                            unbias_n=n_pairs, rows=rows4, col_out=0, ch0=0, bump=False)
+                    train_ops.bn_train_rows(bn, part_d, 0, C, n_pairs, G, groups_per_stat, rows=rows4, col_out=C, ch0=C,
+                                            bump=False)
+                else:
+                    train_ops.bn_train_rows(bn, part_d, 0, C, n_pairs, G, groups_per_stat, rows=rows4, bump=False)
+            elif concat:                   # central and difference halves: separate statistics, ONE launch
+                bn_finalize_jobs([job4(part_l, float(groups_per_stat) * Ng, n_pairs, 0, 0),
+                                  job4(part_d, n_pairs, n_pairs, C, C)])
             else:
-                train_ops.bn_train_rows(bn, part_d, 0, C, n_pairs, G, groups_per_stat, rows=rows4, bump=False)
+                bn_finalize_jobs([job4(part_d, n_pairs, n_pairs, 0, 0)])
             scale, shift = rows4[0], rows4[1]
         elif concat:
             bn_finalize_jobs([

@@ -174,6 +174,79 @@ def bn_train_rows(bn, partials, col0, C, count, G, groups_per_stat, unbias_n=Non
     return rows
 
 
+# PF_TRAIN_LAZY_BN=1: the training forward finalizes a BatchNorm on the critical path only where the rows are
+# needed at once (a materialised activation, EdgeConv's apply pass).  Everywhere else the CONSUMER resolves the pending
+# BatchNorm from the producer's statistics rows (``in_bn``, csrc/pf_bn_resolve.h, as the inference path does), and the
+# rows tensor (4, S, C) the BACKWARD reads -- [scale | shift | mean | invstd] -- is written for all such layers by the
+# batched finalize at the end of the forward (pointflow.flush_lazy_stats: <= 28 jobs per launch), together with the
+# running statistics.  0: one pf_bn_train_rows_f32 launch per BatchNorm (round 4: 46 launches of ~6.8 us in the chain).
+TRAIN_LAZY_BN = int(os.environ.get("PF_TRAIN_LAZY_BN", "0"))
+
+
+class _Rows(object):
+    """The rows tensor of a train-mode BatchNorm and its pending finalize: ``pending()`` is what the next kernel takes
+    as its input affine (a pointflow.LazyAffine while the finalize has not run, else the (scale, shift) rows),
+    ``now()`` runs the finalize if it has not run and returns the rows tensor."""
+
+    def __init__(self, rows, lazy):
+        self.rows, self.lazy = rows, lazy
+
+    def pending(self):
+        return (self.rows[0], self.rows[1]) if (self.lazy is None or self.lazy.done) else self.lazy
+
+    def now(self):
+        if self.lazy is not None and not self.lazy.done:
+            self.lazy.rows()
+        return self.rows
+
+
+def bn_rows(bn, partials, C, count, G, groups_per_stat, track=True, lazy=True):
+    """(4, S, C) rows of a train-mode BatchNorm from its producer's statistics partials (G, T, C, 2) as a _Rows: one
+    pf_bn_job that writes all four rows and (``track``) the running statistics -- deferred to the batched finalize at the
+    end of the forward when ``lazy`` and the consumer-side resolve is affordable (pointflow.LAZY_MAX_ELEMS)."""
+    if bn.momentum is None:
+        raise NotImplementedError("cumulative-average BatchNorm momentum is not supported")
+    S = G // groups_per_stat
+    rows = torch.empty((4, S, C), dtype=_F32, device=partials.device)
+    if not TRAIN_LAZY_BN:
+        bn_train_rows(bn, partials, 0, C, count, G, groups_per_stat, rows=rows, bump=track)
+        if not track:
+            raise RuntimeError("bn_rows(track=False) needs PF_TRAIN_LAZY_BN=1")
+        return _Rows(rows, None)
+    job = pointflow.bn_job(bn, partials, 0, C, count, count, G, groups_per_stat, rows[0], rows[1])
+    job.mean, job.invstd = rows[2].data_ptr(), rows[3].data_ptr()
+    if not track:                                           # (the caller's normalise pass updates them)
+        job.running_mean = job.running_var = None
+    else:
+        pointflow.bump_counter(bn, S)
+    z = pointflow.LazyAffine(job, (partials, rows) + pointflow._bn_tensors(bn), rows[0], rows[1])
+    z.origin = torch.cuda.current_stream(partials.device)
+    if not track:
+        z.defer()                                           # nobody resolves it: only the backward reads these rows
+    elif not (lazy and pointflow.LAZY_BN and groups_per_stat * partials.shape[1] * C <= pointflow.LAZY_MAX_ELEMS):
+        z.rows()                                            # too many statistics rows for a consumer block: finalize now
+    else:
+        z.defer()
+    return _Rows(rows, z)
+
+
+def channel_bn_apply(y, bn, partials, addend=None):
+    """z = relu(BatchNorm(y)) (+ addend), out of place, with the finalize inside the pass (pf_channel_bn_apply_f32: every
+    block reduces its (group, channel) partials itself) and the running statistics updated by it: VolumeConv's materialised
+    activations and its decoder's skip adds (reference networks.py:163-166) without a finalize launch in front."""
+    N, C = y.shape[:2]
+    S = y[0, 0].numel()
+    z = torch.empty_like(y)
+    track = bn.track_running_stats and bn.running_mean is not None
+    _lib.call("pf_channel_bn_apply_f32", _lib.ptr(y), _lib.ptr(z), _lib.ptr(partials), int(partials.shape[1]), N, C, S, 1,
+              float(S), _lib.ptr(bn.weight.detach()), _lib.ptr(bn.bias.detach()),
+              _lib.ptr(bn.running_mean if track else None), _lib.ptr(bn.running_var if track else None),
+              float(bn.momentum), float(bn.eps), 1, _lib.ptr(addend), _lib.stream(),
+              algo_bytes=(8.0 if addend is None else 12.0) * N * C * S)
+    pointflow.bump_counter(bn, N)
+    return z
+
+
 def channel_affine(y, rows, samples_per_stat, relu=True):
     """z = act(y * scale + shift), out of place (y stays: the backward needs the raw convolution output)."""
     N, C = y.shape[:2]
@@ -477,17 +550,18 @@ class _TowerTrain(torch.autograd.Function):
         saved, outs = [], []
         pending = None
         with torch.cuda.device(x.device):
+            prev = None                                      # the previous layer's _Rows (its BatchNorm + ReLU is pending)
             for name, stage_end, conv, bn in blocks:
-                y, partials = pointflow.conv2d_wide(x, conv, pending, 1, bn is not None)
-                rows = None
+                y, partials = pointflow.conv2d_wide(x, conv, None if prev is None else prev.pending(), 1, bn is not None)
+                cur = None
                 if bn is not None:
-                    S = y[0, 0].numel()
-                    rows = bn_train_rows(bn, partials, 0, conv.out_channels, float(S), V, 1)
-                saved.append((x, pending, y, rows))
+                    cur = bn_rows(bn, partials, conv.out_channels, float(y[0, 0].numel()), V, 1)
+                saved.append((x, None if prev is None else (prev.rows[0], prev.rows[1]), y,
+                              None if cur is None else cur.rows))
                 if stage_end and name in want:
-                    outs.append(y if rows is None else channel_affine(y, rows, 1, True))
-                x, pending = y, (None if rows is None else (rows[0], rows[1]))
-            pointflow.flush_counters()
+                    outs.append(y if cur is None else channel_affine(y, cur.now(), 1, True))
+                x, prev = y, cur
+            pointflow.flush_counters()                       # (the deferred finalizes: here, or at the end of the step's forward)
         ctx.tower, ctx.want, ctx.saved = tower, tuple(want), saved
         return tuple(outs)
 
@@ -584,12 +658,17 @@ class _VolumeTrain(torch.autograd.Function):
         x0 = cost.detach().contiguous()
         rec = {}
 
-        def bn_act(name, y, partials):
+        def bn_act(name, y, partials, addend=None):
             blk = getattr(vc, name)
             S = y[0, 0].numel()
-            rows = bn_train_rows(blk.bn, partials, 0, y.shape[1], float(S), 1, 1)
-            z = channel_affine(y, rows, 1, True)
-            return rows, z
+            if not TRAIN_LAZY_BN:
+                rows = bn_train_rows(blk.bn, partials, 0, y.shape[1], float(S), 1, 1)
+                z = channel_affine(y, rows, 1, True)
+                return rows, (z if addend is None else z + addend)
+            # the normalise pass finalizes for itself (and adds the decoder's skip tensor); the rows the backward reads come
+            # from the batched finalize at the end of the forward
+            z = channel_bn_apply(y, blk.bn, partials, addend)
+            return bn_rows(blk.bn, partials, y.shape[1], float(S), 1, 1, track=False, lazy=True).rows, z
 
         def conv(name, x, stride):
             blk = getattr(vc, name)
@@ -611,17 +690,14 @@ class _VolumeTrain(torch.autograd.Function):
             z11 = conv("conv1_1", z10, 1)
             z21 = conv("conv2_1", z20, 1)
             y40, p40 = pointflow.deconv3d_bottom(z31, vc.conv4_0.conv, None, 1, True)
-            r40, z40 = bn_act("conv4_0", y40, p40)
+            r40, s5 = bn_act("conv4_0", y40, p40, z21)                 # s5 = z40 + z21 (networks.py:163)
             rec["conv4_0"] = (z31, y40, r40)
-            s5 = z40 + z21
             y50, p50 = pointflow.deconv3d_k3s2(s5, None, vc.conv5_0.conv.weight, True)
-            r50, z50 = bn_act("conv5_0", y50, p50)
+            r50, s6 = bn_act("conv5_0", y50, p50, z11)                 # s6 = z50 + z11
             rec["conv5_0"] = (s5, y50, r50)
-            s6 = z50 + z11
             y60, p60 = pointflow.deconv3d_k3s2(s6, None, vc.conv6_0.conv.weight, True)
-            r60, z60 = bn_act("conv6_0", y60, p60)
+            r60, s7 = bn_act("conv6_0", y60, p60, z01)                 # s7 = z60 + z01
             rec["conv6_0"] = (s6, y60, r60)
-            s7 = z60 + z01
             out = pointflow.conv3d_k3_few(s7, vc.conv6_2.weight)
             rec["conv6_2"] = (s7, None, None)
             pointflow.flush_counters()
@@ -823,18 +899,18 @@ class _MLPTrain(torch.autograd.Function):
             X = X.contiguous()
         N = X.shape[0]
         saved = []
-        affine = None
+        prev = None
         ldx, K = int(X.stride(0)), X.shape[1]
         with torch.cuda.device(X.device):
             for blk in shared:
                 Wt, cout = pointflow.pack_weight_t(blk.conv.weight)
                 Z = torch.empty((N, cout), dtype=_F32, device=X.device)
-                part = pointflow.pointwise_gemm(X, True, ldx, Wt, Z, cout, 1, N, K, cout, in_affine=affine,
-                                                want_stats=True)
-                rows = bn_train_rows(blk.bn, part, 0, cout, float(N), 1, 1)
-                saved.append((X, affine, Z, rows, K, cout))
-                X, ldx, K, affine = Z, cout, cout, (rows[0], rows[1])
-            out = rows_affine(X, saved[-1][3], K, 1, N, 1, True)
+                part = pointflow.pointwise_gemm(X, True, ldx, Wt, Z, cout, 1, N, K, cout,
+                                                in_affine=None if prev is None else prev.pending(), want_stats=True)
+                cur = bn_rows(blk.bn, part, cout, float(N), 1, 1)
+                saved.append((X, None if prev is None else (prev.rows[0], prev.rows[1]), Z, cur.rows, K, cout))
+                X, ldx, K, prev = Z, cout, cout, cur
+            out = rows_affine(X, prev.now(), K, 1, N, 1, True)
             pointflow.flush_counters()
         ctx.shared, ctx.saved, ctx.N = shared, saved, N
         return out

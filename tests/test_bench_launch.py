@@ -70,3 +70,21 @@ def test_two_rccl_ranks_end_to_end_when_two_gpus_are_visible():
     assert p.returncode == 0, p.stderr[-3000:]
     out = _last_json(p.stdout)
     assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["value"] > 0 and out["cpu_baseline"] is None
+
+
+def test_train_block_failure_costs_the_train_entry_not_the_line():
+    """The train block runs in a child process (bench.train_block_in_child): here, without a GPU, the child fails -- the
+    parent gets an ``error`` entry back instead of an exception, i.e. the headline line would still be printed."""
+    import argparse
+    sys.path.insert(0, ROOT)
+    import bench
+    args = argparse.Namespace(train_steps=2, train_timeout=300.0)
+    saved = {k: os.environ.pop(k) for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT") if k in os.environ}
+    try:
+        out = bench.train_block_in_child(args, 0, 1)
+    finally:
+        os.environ.update(saved)
+    if torch.cuda.is_available():
+        assert out.get("value", 0) > 0 or "error" in out
+    else:
+        assert set(out) >= {"error"} and "without a result" in out["error"], out

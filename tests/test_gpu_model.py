@@ -372,12 +372,12 @@ def test_batch_of_two_scenes_vs_oracle(dev):
         assert float(rel.median()) < 1e-4 and float(rel.max()) < 2e-2
 
 
-@pytest.mark.parametrize("cfg,fused", [("tiny", 1), ("tiny", 0), ("cfg4", 1)])
+@pytest.mark.parametrize("cfg,fused", [("tiny", 1), ("tiny", 0)])
 def test_train_step_parameter_gradients_vs_oracle_autograd(dev, monkeypatch, cfg, fused):
-    """BASELINE config 4's step -- on "tiny", and (round 5) at ITS OWN size "cfg4": one 640x512 scene, 3 views, 48 planes,
-    flow-2 on one 102 400-point lattice, i.e. with exactly the launch plans bench.py's train block times (the oracle's
-    float32 and float64 steps take about a minute and ~30 GB on the host) -- forward (train mode) + PointMVSNetLoss +
-    backward on our own kernels
+    """BASELINE config 4's step -- here on "tiny"; tests/test_gpu_zz_train_cfg4.py calls this function with cfg = "cfg4",
+    the step at ITS OWN size (one 640x512 scene, 3 views, 48 planes, flow-2 on one 102 400-point lattice, i.e. with
+    exactly the launch plans bench.py's train block times; the oracle's float32 and float64 steps take minutes and
+    ~30 GB on the host) -- forward (train mode) + PointMVSNetLoss + backward on our own kernels
     (fused=1: the seven hand-written autograd nodes of train_ops.py; fused=0: the reference's composition on the HIP
     gather_knn / fetch backward and ATen) against autograd of the CPU oracle (the reference's composition).
     Neighbour choices are discontinuous in the coarse depth (tests/test_sensitivity.py), so the oracle's own kNN
@@ -482,7 +482,9 @@ def test_train_step_parameter_gradients_vs_oracle_autograd(dev, monkeypatch, cfg
         assert l2_gpu64 < max(2.5 * l2_ref64, 8e-4), (l2_gpu64, l2_ref64)
     # the whole 698 936-element gradient, relative L2 (the oracle's own float32 error enters: host dependent)
     assert l2 < max(6e-4 if fused else 1e-3, 1.6 * l2_ref64), (l2, l2_ref64)
-    assert errs[0][0] < 3e-3, errs[:5]
+    # (every tensor: 3e-3 of its largest entry, or -- where the float32 oracle itself is further than 1e-3 from its
+    # float64 run on some tensor, as it may be on other lattice sizes than "tiny" -- three times that)
+    assert errs[0][0] < max(3e-3, 3.0 * errs_ref64[0][0]), (errs[:5], errs_ref64[:3])
 
 
 def test_train_step_runs_and_updates_through_the_bucket(dev):
@@ -563,9 +565,9 @@ def test_flat_rmsprop_equals_torch_rmsprop(dev, weight_decay):
     assert abs(flat.lr - 0.5e-3) < 1e-12
 
 
-@pytest.mark.parametrize("cfg", ["tiny", "cfg4"])
+@pytest.mark.parametrize("cfg", ["tiny"])
 def test_train_step_gradient_is_bit_reproducible(dev, cfg):
-    """("cfg4": at the size of BASELINE configs[3], i.e. with the position splits, tiles and row modes of the real step.)
+    """(tests/test_gpu_zz_train_cfg4.py calls this with "cfg4": the position splits, tiles and row modes of the real step.)
     Round 4: no float atomics and no library split-K solver is left in the step -- every convolution / BatchNorm /
     warp gradient is a fixed-order sum (train_ops.py) -- so two steps from the same state give the same 698 936
     gradient bits (the reference's step is not reproducible: atomicAdd scatters in gather_knn_kernel.cu:50-89 and in
@@ -585,9 +587,10 @@ def test_train_step_gradient_is_bit_reproducible(dev, cfg):
     assert torch.equal(grads[0], grads[1]) and float(grads[0].abs().sum()) > 0
 
 
-@pytest.mark.parametrize("cfg", ["tiny", "cfg4"])
+@pytest.mark.parametrize("cfg", ["tiny"])
 def test_graphed_train_step_matches_the_eager_step(dev, cfg):
-    """("cfg4": the captured step bench.py times, at its own size.)  GraphedTrainStep (zero_grad + forward + loss + backward replayed from ONE hipGraph, packs re-packed inside
+    """(tests/test_gpu_zz_train_cfg4.py calls this with "cfg4": the captured step bench.py times, at its own size.)
+    GraphedTrainStep (zero_grad + forward + loss + backward replayed from ONE hipGraph, packs re-packed inside
     it) against the eager TrainStep: same losses and the same 698 936 gradients on four consecutive steps over two
     alternating scenes, the parameters changing between the replays -- the later steps only agree if a replay really
     runs on the UPDATED parameters and on the new scene's constants."""
