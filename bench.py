@@ -131,8 +131,10 @@ def parse_args():
     ap.add_argument("--no-train-block", action="store_true",
                     help="cfg2 only: do not time BASELINE configs[3]'s training step after the headline's timed region")
     ap.add_argument("--train-steps", type=int, default=20, help="timed replays of the training step in the train block")
-    ap.add_argument("--train-timeout", type=float, default=240.0,
+    ap.add_argument("--train-timeout", type=float, default=300.0,
                     help="seconds the train block's child process may take before it is killed (the headline is kept)")
+    ap.add_argument("--no-experiments", action="store_true",
+                    help="train block: skip the round's default-off experiments (PF_TRAIN_LAZY_BN, PF_MATRIX_SPLIT)")
     ap.add_argument("--train-block-only", action="store_true",
                     help="(internal) be the train block's child process: time BASELINE configs[3]'s step, print its JSON")
     ap.add_argument("--cpu-repeats", type=int, default=3)
@@ -241,10 +243,23 @@ def cpu_baseline(net, data, img_scales, inter_scales, repeats, text, train=False
         labels = {"gt_depth_img": synthetic.make_gt_depth(data), "cam_params_list": data["cam_params_list"]}
         names = set(k for k, _ in net.named_parameters())
 
+        def gather_unexpanded(feature, index):
+            # the oracle's gather follows the reference (expand to (B, C, N, N), then gather: functions/functions.py:65-67),
+            # whose BACKWARD materialises that tensor -- 2.7 TB at 102 400 points; the same values through torch.gather on
+            # the unexpanded tensor (autograd: a scatter-add), which is also what makes this baseline runnable at all
+            B, C, N = feature.shape
+            K = index.shape[2]
+            return feature.gather(2, index.reshape(B, 1, N * K).expand(B, C, N * K)).view(B, C, N, K)
+
         def run():
             leaves = {k: (v.clone().requires_grad_(True) if k in names else v.clone()) for k, v in sd.items()}
-            preds = O.forward(leaves, data, img_scales, inter_scales, True, False)
-            sum(loss_fn(preds, labels, True).values()).backward()
+            saved = O.gather_knn
+            O.gather_knn = gather_unexpanded
+            try:
+                preds = O.forward(leaves, data, img_scales, inter_scales, True, False)
+                sum(loss_fn(preds, labels, True).values()).backward()
+            finally:
+                O.gather_knn = saved
     else:
         def run():
             with torch.no_grad():
@@ -446,6 +461,138 @@ def train_block(dev, rank, world, steps=20, warmup=3):
 
     return out, count_dispatches
 
+def experiments_block(dev, out, publish):
+    """Round 5's two default-off experiments, measured in the train block's CHILD process (bench.py's headline fields
+    never see them; each part publishes an updated line when it is done, so a part that dies costs only itself):
+
+      lazy_bn   PF_TRAIN_LAZY_BN: the training step with its BatchNorms resolved by their consumers and the backward's rows
+                from one batched finalize (train_ops.bn_rows) -- ms per captured step beside the default's, same box;
+      bf16x3    PF_MATRIX_SPLIT: the 32- / 64-channel tower layers on conv2d_wide_split_kernel -- stand-alone microseconds
+                and the largest error against a float64 convolution beside the exact-f32 kernel's, per layer; then the
+                headline workload (cfg 2, four lanes, graph replay) with it switched off and on, same box, same process.
+    Neither had run on hardware when this was written (the round lost its GPU access); the numbers in the line are the
+    first measurement."""
+    import torch.nn.functional as F
+    from pointmvsnet_amd import pointflow, train_ops
+    from pointmvsnet_amd.train_step import GraphedTrainStep, TrainStep
+    exp = out.setdefault("experiments", {})
+
+    def timed_train(lazy):
+        train_ops.TRAIN_LAZY_BN = int(lazy)
+        _, _, _, _, _, img_scales, inter_scales = synthetic.CONFIGS["cfg4"]
+        data, _, _ = synthetic.make_config("cfg4", seed=0, train_intrinsics=True)
+        batch = to_device(data, dev)
+        batch["gt_depth_img"] = synthetic.make_gt_depth(data, seed=0).to(dev)
+        net = PointMVSNet()
+        synthetic.seed_weights(net, seed=0)
+        net = net.to(dev).train()
+        trainer = TrainStep(net)
+        loss, _, _ = trainer(batch, img_scales, inter_scales)
+        grad = trainer.bucket.flat.detach().clone()
+        graphed = GraphedTrainStep(trainer, batch, img_scales, inter_scales)
+        for _ in range(3):
+            graphed(batch)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            graphed(batch)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / 20 * 1e3, float(loss), grad
+
+    try:
+        ms0, l0, g0 = timed_train(0)
+        ms1, l1, g1 = timed_train(1)
+        exp["lazy_bn"] = {"ms_per_step_default": ms0, "ms_per_step_lazy": ms1, "speedup": ms0 / ms1,
+                          "first_step_loss_rel_diff": abs(l1 - l0) / max(abs(l0), 1e-30),
+                          "first_step_grad_rel_l2_diff": float((g1 - g0).norm() / g0.norm())}
+    except Exception as exc:
+        exp["lazy_bn"] = {"error": repr(exc)}
+    finally:
+        train_ops.TRAIN_LAZY_BN = 0
+    publish(out)
+
+    def timeit(fn, reps=50):
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1000 / reps
+
+    try:
+        rows = []
+        torch.manual_seed(0)
+        for name, cin, cout, h, w, ks, stride in (("16->32 5x5/2", 16, 32, 256, 320, 5, 2), ("32->32 3x3", 32, 32, 128, 160, 3, 1),
+                                                  ("32->64 5x5/2", 32, 64, 128, 160, 5, 2), ("64->64 3x3", 64, 64, 64, 80, 3, 1)):
+            conv = torch.nn.Conv2d(cin, cout, ks, stride=stride, padding=ks // 2, bias=False).to(dev)
+            x = torch.randn(6, cin, h, w, device=dev)                      # both towers' samples of a cfg-2 scene
+            sc = torch.rand(6, cin, device=dev) + 0.5
+            sh = torch.randn(6, cin, device=dev) * 0.1
+            ref = F.conv2d(F.relu(x * sc.view(6, cin, 1, 1) + sh.view(6, cin, 1, 1)).double(), conv.weight.double(), None,
+                           stride, ks // 2)
+            row = {"layer": name, "flops": 2.0 * ref.numel() * ks * ks * cin}
+            for split in (0, 1):
+                pointflow.MATRIX_SPLIT = split
+                y, _ = pointflow.conv2d_wide(x, conv, (sc, sh), 1, True)
+                tag = "bf16x3" if split else "f32"
+                row[tag + "_max_err_vs_f64"] = float((y.double() - ref).abs().max() / ref.abs().max())
+                row[tag + "_us"] = timeit(lambda: pointflow.conv2d_wide(x, conv, (sc, sh), 1, True))
+            row["speedup"] = row["f32_us"] / row["bf16x3_us"]
+            rows.append(row)
+        exp["bf16x3_layers"] = rows
+    except Exception as exc:
+        exp["bf16x3_layers"] = {"error": repr(exc)}
+    finally:
+        pointflow.MATRIX_SPLIT = 0
+    publish(out)
+
+    try:                                       # the headline workload with the switch off and on: same box, same process
+        from pointmvsnet_amd.graph import LanedForward
+        h, w, V, D, _, img_scales, inter_scales = synthetic.CONFIGS["cfg2"]
+        scenes = [to_device(synthetic.make_config("cfg2", seed=i)[0], dev) for i in range(4)]
+        rates = {}
+        for split in (0, 1, 0, 1):
+            pointflow.MATRIX_SPLIT = split
+            net = PointMVSNet()
+            synthetic.seed_weights(net, seed=0)
+            net = net.to(dev).train()
+            with torch.no_grad():
+                laned = LanedForward(net, scenes[0], img_scales, inter_scales, isFlow=True, isTest=True, lanes=4)
+                for i in range(64):
+                    laned.submit(scenes[i % 4])
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(512):
+                    laned.submit(scenes[i % 4])
+                torch.cuda.synchronize()
+            rates.setdefault("bf16x3" if split else "f32", []).append(512 / (time.perf_counter() - t0))
+            del laned, net
+        exp["bf16x3_headline_ab"] = {"depth_maps_per_s": rates, "workload": WORKLOAD_TEXT["cfg2"],
+                                      "arms": "f32, bf16x3, f32, bf16x3 (512 scenes each, 4 lanes, graph replay)",
+                                      "ratio": (sum(rates["bf16x3"]) / len(rates["bf16x3"]))
+                                               / (sum(rates["f32"]) / len(rates["f32"]))}
+    except Exception as exc:
+        exp["bf16x3_headline_ab"] = {"error": repr(exc)}
+    finally:
+        pointflow.MATRIX_SPLIT = 0
+    publish(out)
+
+    try:          # the training step's CPU baseline: ONE oracle step (forward + loss + backward) on this host's cores
+        net = PointMVSNet()
+        synthetic.seed_weights(net, seed=0)
+        data_cpu, img_scales, inter_scales = synthetic.make_config("cfg4", seed=0, train_intrinsics=True)
+        out["cpu_baseline"] = cpu_baseline(net, data_cpu, img_scales, inter_scales, 1, WORKLOAD_TEXT["cfg4"], train=True)
+        out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+    except Exception as exc:
+        out["cpu_baseline"] = {"error": repr(exc)}
+    publish(out)
+
+
+
 def train_block_in_child(args, rank, world):
     """Run train_block in a CHILD process per rank (``--train-block-only``) and return rank 0's JSON (None on the other
     ranks): a crash, an exception on one rank or a hang in there -- the step's RCCL path has never run on more than one
@@ -460,27 +607,36 @@ def train_block_in_child(args, rank, world):
         env.pop("TORCHELASTIC_USE_AGENT_STORE", None)      # rank 0's child hosts the store of the children's group
     cmd = [sys.executable, os.path.abspath(__file__), "--train-block-only", "--gpus", str(world),
            "--train-steps", str(max(1, args.train_steps)), "--no-cpu-baseline"]
+    if getattr(args, "no_experiments", False):
+        cmd.append("--no-experiments")
     t0 = time.perf_counter()
+    text, note = "", None
     try:
         proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True,
                               timeout=float(args.train_timeout))
-    except subprocess.TimeoutExpired:
-        return {"error": "the train block's child process did not finish within %.0f s and was killed"
-                         % float(args.train_timeout)} if rank == 0 else None
+        text = proc.stdout or ""
+        if proc.returncode != 0:
+            note = "child exited with code %s: %s" % (proc.returncode, (proc.stderr or "")[-400:])
+    except subprocess.TimeoutExpired as exc:      # what it had printed by then is kept (it publishes part by part)
+        text = exc.stdout or ""
+        if isinstance(text, bytes):
+            text = text.decode("utf8", "replace")
+        note = "child killed after %.0f s (--train-timeout)" % float(args.train_timeout)
     except OSError as exc:
-        return {"error": repr(exc)} if rank == 0 else None
+        note = repr(exc)
     if rank != 0:
         return None
-    for line in reversed(proc.stdout.splitlines()):
+    for line in reversed(text.splitlines()):
         if line.startswith("{"):
             try:
                 out = json.loads(line)
-                out["child_wall_s"] = time.perf_counter() - t0
-                return out
             except ValueError:
-                break
-    return {"error": "the train block's child process exited with code %s without a result" % (proc.returncode,),
-            "stderr_tail": proc.stderr[-600:]}
+                continue
+            out["child_wall_s"] = time.perf_counter() - t0
+            if note is not None:
+                out["child_note"] = note
+            return out
+    return {"error": "the train block's child process left no result (%s)" % (note or "no JSON line on its stdout")}
 
 
 def train_block_child(args):
@@ -503,6 +659,11 @@ def train_block_child(args):
         try:
             out = recount()
             print(json.dumps(out), flush=True)
+        except Exception:
+            pass
+    if world == 1 and "error" not in out and not args.no_experiments:
+        try:
+            experiments_block(dev, out, lambda o: print(json.dumps(o), flush=True))
         except Exception:
             pass
     if world > 1:

@@ -192,7 +192,7 @@ int pf_bn_finalize_f32(const double* partials, int T, int pcols, int col0, int C
                        float* running_var, float momentum, float eps, int G, int groups_per_stat,
                        float* scale, float* shift, int ld_affine, void* stream);
 
-/* The same, for 1..28 independent jobs in one launch (e.g. the central and the difference half of an
+/* The same, for 1..32 independent jobs in one launch (e.g. the central and the difference half of an
  * EdgeConv BatchNorm, reference networks.py:33-36).  Fields = the arguments of pf_bn_finalize_f32; the
  * jobs must write disjoint scale/shift/running-stat ranges. */
 typedef struct pf_bn_job {
@@ -208,11 +208,11 @@ typedef struct pf_bn_job {
   float* scale;
   float* shift;
   int32_t ld_affine;
-  /* optional (NULL: not wanted), written by pf_bn_finalize_jobs_f32 at the same [s*ld_affine + c] as scale / shift: the
-   * batch statistics a BatchNorm BACKWARD needs (the training step's rows tensor (4, S, ld) = [scale | shift | mean |
-   * invstd]).  Consumers that resolve the job themselves (`in_bn`) never read or write them. */
-  float* mean;
-  float* invstd;
+  /* != 0: scale / shift are rows 0 / 1 of a rows tensor (4, S, ld_affine) = [scale | shift | mean | invstd] -- shift =
+   * scale + S * ld_affine -- and pf_bn_finalize_jobs_f32 also writes rows 2 / 3, the batch statistics a BatchNorm
+   * BACKWARD needs (the training step).  Consumers that resolve the job themselves (`in_bn`) ignore it.  (The field
+   * sits in what was the struct's tail padding: size and offsets of everything else are unchanged.) */
+  int32_t rows4;
 } pf_bn_job;
 int pf_bn_finalize_jobs_f32(const pf_bn_job* jobs, int njobs, void* stream);
 

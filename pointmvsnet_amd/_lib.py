@@ -21,7 +21,7 @@ class BnJob(ctypes.Structure):
                 ("C", ctypes.c_int32), ("count", _d), ("unbias_n", _d), ("gamma", _vp), ("beta", _vp),
                 ("running_mean", _vp), ("running_var", _vp), ("momentum", _f), ("eps", _f),
                 ("G", ctypes.c_int32), ("groups_per_stat", ctypes.c_int32), ("scale", _vp), ("shift", _vp),
-                ("ld_affine", ctypes.c_int32), ("mean", _vp), ("invstd", _vp)]
+                ("ld_affine", ctypes.c_int32), ("rows4", ctypes.c_int32)]
 
 
 # name -> argtypes; every entry must exist in include/pointflow_hip.h (tests/test_abi.py checks both ways)

@@ -929,7 +929,7 @@ __global__ __launch_bounds__(256) void edge_bwd_inverse_kernel(const float* __re
 // One launch serves up to kBnJobs independent finalize jobs (blockIdx.y) and splits the channels of a job
 // over blocks of kBnCB channels (blockIdx.x): the partial sums of one layer are up to ~1 MB, which a single
 // workgroup pulls through one CU's L1 in 5-13 us; channels are independent, so 8-16 CUs share the read.
-constexpr int kBnJobs = 28;   // (28 x 128 bytes = 3.5 KB of kernel arguments; the limit is 4 KB)
+constexpr int kBnJobs = 32;   // (3.3 KB of kernel arguments)
 constexpr int kBnThreads = 256;
 // Channels per block: the kernel is a chain of dependent L2 round trips (rows -> LDS -> statistics), so the more
 // blocks share the rows of a job the fewer batches each thread walks through -- in principle; measured
@@ -1009,8 +1009,11 @@ __global__ __launch_bounds__(kBnThreads) void bn_finalize_kernel(BnJobs jobs, in
         const float a_ = invstd * g_;
         J.scale[(int64_t)(s0 + si) * J.ld_affine + c_base + tid] = a_;
         J.shift[(int64_t)(s0 + si) * J.ld_affine + c_base + tid] = b_ - (float)mv.x * a_;
-        if (J.mean != nullptr) J.mean[(int64_t)(s0 + si) * J.ld_affine + c_base + tid] = (float)mv.x;
-        if (J.invstd != nullptr) J.invstd[(int64_t)(s0 + si) * J.ld_affine + c_base + tid] = invstd;
+        if (J.rows4) {                                     // rows 2 / 3 of the (4, S, ld) rows tensor: mean, invstd
+          const int64_t row = J.shift - J.scale;
+          J.scale[2 * row + (int64_t)(s0 + si) * J.ld_affine + c_base + tid] = (float)mv.x;
+          J.scale[3 * row + (int64_t)(s0 + si) * J.ld_affine + c_base + tid] = invstd;
+        }
         if (track) {
           const double unbiased = J.unbias_n > 1.0 ? mv.y * (J.unbias_n / (J.unbias_n - 1.0)) : mv.y;
           rm = (1.0f - J.momentum) * rm + J.momentum * (float)mv.x;
@@ -1345,8 +1348,7 @@ int pf_bn_finalize_f32(const double* partials, int T, int pcols, int col0, int C
   j.scale = scale;
   j.shift = shift;
   j.ld_affine = ld_affine;
-  j.mean = nullptr;
-  j.invstd = nullptr;
+  j.rows4 = 0;
   return pf_bn_finalize_jobs_f32(&j, 1, stream);
 }
 

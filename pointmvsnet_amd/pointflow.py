@@ -268,7 +268,7 @@ def bn_job(bn, partials, col0, C, count, unbias_n, G, groups_per_stat, scale, sh
                       int(scale.stride(0)))
 
 
-MAX_BN_JOBS = 28          # jobs per pf_bn_finalize_jobs_f32 launch (kBnJobs of csrc/edgeconv.hip: 4 KB of kernel arguments)
+MAX_BN_JOBS = 32          # jobs per pf_bn_finalize_jobs_f32 launch (kBnJobs of csrc/edgeconv.hip)
 
 
 def bn_finalize_jobs(jobs):
@@ -1091,7 +1091,7 @@ def edge_conv_fused(X, point_major, ldx, K, G, Ng, idx, conv1_w, conv2_w, bn, co
             def job4(partials, count, unbias_n, col, ch0):
                 j = bn_job(bn, partials, 0, C, count, unbias_n, G, groups_per_stat, rows4[0][:, col:], rows4[1][:, col:],
                            ch0=ch0)
-                j.mean, j.invstd = rows4[2][:, col:].data_ptr(), rows4[3][:, col:].data_ptr()
+                j.rows4 = 1                # (rows 2 / 3 = mean / invstd, at the same columns)
                 return j
 
             if not train_ops.TRAIN_LAZY_BN:          # round 4's form: one pf_bn_train_rows_f32 launch per half

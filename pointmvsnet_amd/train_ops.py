@@ -214,7 +214,7 @@ def bn_rows(bn, partials, C, count, G, groups_per_stat, track=True, lazy=True):
             raise RuntimeError("bn_rows(track=False) needs PF_TRAIN_LAZY_BN=1")
         return _Rows(rows, None)
     job = pointflow.bn_job(bn, partials, 0, C, count, count, G, groups_per_stat, rows[0], rows[1])
-    job.mean, job.invstd = rows[2].data_ptr(), rows[3].data_ptr()
+    job.rows4 = 1                                           # rows[2], rows[3]: mean, invstd
     if not track:                                           # (the caller's normalise pass updates them)
         job.running_mean = job.running_var = None
     else:

@@ -87,4 +87,19 @@ def test_train_block_failure_costs_the_train_entry_not_the_line():
     if torch.cuda.is_available():
         assert out.get("value", 0) > 0 or "error" in out
     else:
-        assert set(out) >= {"error"} and "without a result" in out["error"], out
+        assert set(out) >= {"error"} and "left no result" in out["error"], out
+
+
+def test_train_block_keeps_what_a_killed_child_had_published(monkeypatch):
+    """The child publishes its result part by part (timing first, then the dispatch count, then each experiment); a child
+    that is killed at --train-timeout still leaves the last complete line."""
+    import argparse
+    sys.path.insert(0, ROOT)
+    import bench
+
+    def fake_run(cmd, **kw):
+        raise subprocess.TimeoutExpired(cmd, kw.get("timeout"), output='junk\n{"value": 1.0}\n{"value": 2.0, "experiments": {}}\n{"val')
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    out = bench.train_block_in_child(argparse.Namespace(train_steps=2, train_timeout=1.0, no_experiments=False), 0, 1)
+    assert out["value"] == 2.0 and "killed" in out["child_note"] and out["child_wall_s"] >= 0.0

@@ -372,12 +372,22 @@ def test_batch_of_two_scenes_vs_oracle(dev):
         assert float(rel.median()) < 1e-4 and float(rel.max()) < 2e-2
 
 
+def _gather_knn_unexpanded(feature, index):
+    """oracle.gather_knn's values through torch.gather on the UNexpanded (B, C, N) tensor (autograd: a scatter-add into
+    (B, C, N)).  The oracle follows the reference and expands to (B, C, N, N) first (functions/functions.py:65-67), whose
+    backward materialises that tensor: 2.7 TB at config 4's 102 400 points.  Same forward bits (asserted where it is used)."""
+    B, C, N = feature.shape
+    K = index.shape[2]
+    return feature.gather(2, index.reshape(B, 1, N * K).expand(B, C, N * K)).view(B, C, N, K)
+
+
 @pytest.mark.parametrize("cfg,fused", [("tiny", 1), ("tiny", 0)])
 def test_train_step_parameter_gradients_vs_oracle_autograd(dev, monkeypatch, cfg, fused):
     """BASELINE config 4's step -- here on "tiny"; tests/test_gpu_zz_train_cfg4.py calls this function with cfg = "cfg4",
     the step at ITS OWN size (one 640x512 scene, 3 views, 48 planes, flow-2 on one 102 400-point lattice, i.e. with
-    exactly the launch plans bench.py's train block times; the oracle's float32 and float64 steps take minutes and
-    ~30 GB on the host) -- forward (train mode) + PointMVSNetLoss + backward on our own kernels
+    exactly the launch plans bench.py's train block times; the oracle's float32 and float64 steps take about a minute and
+    15 GB on the host, and at that size its OWN float32 gradient is 1.6e-3 in relative L2 from its float64 one, worst
+    tensor 1.4e-2 -- measured on the build host -- which is why every gate below is tied to that yardstick) -- forward (train mode) + PointMVSNetLoss + backward on our own kernels
     (fused=1: the seven hand-written autograd nodes of train_ops.py; fused=0: the reference's composition on the HIP
     gather_knn / fetch backward and ATen) against autograd of the CPU oracle (the reference's composition).
     Neighbour choices are discontinuous in the coarse depth (tests/test_sensitivity.py), so the oracle's own kNN
@@ -406,6 +416,10 @@ def test_train_step_parameter_gradients_vs_oracle_autograd(dev, monkeypatch, cfg
     synthetic.seed_weights(net, seed=0)
     names = [k for k, _ in net.named_parameters()]
     sd = {k: (v.detach().clone().requires_grad_(True) if k in names else v.clone()) for k, v in net.state_dict().items()}
+    if cfg != "tiny":                # (the oracle's own expand + gather cannot allocate its backward at this size)
+        probe, probe_idx = torch.randn(1, 4, 50), torch.randint(0, 50, (1, 50, 16))
+        assert torch.equal(_gather_knn_unexpanded(probe, probe_idx), O.gather_knn(probe, probe_idx))
+        monkeypatch.setattr(O, "gather_knn", _gather_knn_unexpanded)
     recorded = []
     orig_knn = O.knn_lattice
 
