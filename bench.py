@@ -852,7 +852,7 @@ def main():
     # wall time until the last step is ENQUEUED (diagnostic only).  Not the host's cost: a lane's pinned constant block is
     # refilled only after its previous upload has run, which queues behind the lane's previous replay, so the enqueue
     # loop is paced by the GPU (one replay queued per lane); the host's own share is ~0.1 ms of camera algebra + ~0.3 ms
-    # of copies and graph launch per scene (profiles/r03b_lanes_queues.md)
+    # of copies and graph launch per scene (profiles/archive/r03/r03b_lanes_queues.md)
     issued = time.perf_counter() - t0
     torch.cuda.synchronize()
     barrier()

@@ -106,7 +106,7 @@ struct PatchStager {
   static_assert(CIN % 4 == 0 || CIN < 4, "a padded quad: one quad only");
   static_assert(PH < 256 && PW < 256, "patch coordinates are packed in bytes");
   float rx[NIT][4];
-  // Round 4 (profiles/r03i: ~9 vector instructions per load and ~25 per committed item of index arithmetic, bounds and
+  // Round 4 (profiles/archive/r03/r03i: ~9 vector instructions per load and ~25 per committed item of index arithmetic, bounds and
   // padding selects cost the 8- and 16-channel layers as much time as their matrix instructions): everything about an
   // item that does not depend on the tile -- its offset inside a tile's input window, its patch coordinates, its
   // channel quad -- is computed ONCE per block (init); a tile then costs one add per load, and a tile whose window
@@ -327,7 +327,7 @@ __device__ __forceinline__ void wide_epilogue(const f32x16& acc, float* __restri
 // The B operands (weights) come straight from global memory / L2 into a ring of registers: no weight rows in LDS
 // (27-55 KB of patch per block instead of the 75-130 KB of round 2's row-staged form, so several blocks -- waves per
 // SIMD -- share a CU and cover each other's prologue, LDS and memory latencies; two towers' worth of the 64-channel
-// layer in one launch: 25.9 us against 31.8, profiles/r03c_microbench_conv2d_wide.log) and no barrier inside the tile.
+// layer in one launch: 25.9 us against 31.8, profiles/archive/r03/r03c_microbench_conv2d_wide.log) and no barrier inside the tile.
 // A lane's B operand for four MFMA steps is one 16-byte load; a wave's load is two contiguous 512-byte runs of the
 // host-packed weights.
 
@@ -441,7 +441,7 @@ int launch_wide(const float* x, const float* wp, float* y, WideGeom g, int64_t N
 // accumulated in float32 by the matrix core (smallest first); the dropped terms a_m b_l + a_l b_m + a_l b_l are below
 // 2^-24 |a b|, i.e. under the rounding of the float32 product itself.  16x the f32 matrix rate / 6 products = 2.67x fewer
 // matrix cycles per MAC; bf16 MFMAs also leave issue slots to the vector pipe, f32 MFMAs do not
-// (profiles/r03j_f32_mfma_shares_the_valu.md).  Not bit-identical to the f32 kernel: |error| ~ 2^-23 relative per
+// (profiles/archive/r03/r03j_f32_mfma_shares_the_valu.md).  Not bit-identical to the f32 kernel: |error| ~ 2^-23 relative per
 // product with a float32 accumulation whose order inside a 16-deep block is the hardware's.
 //   LDS patch: [pixel][split][CIN] bf16 (+16 bytes per pixel: consecutive pixels fall on distinct 16-byte bank slots);
 //   lane (pixel m, half h) reads its 8 reduction channels 16 kb + 8 h .. + 7 of split sp as ONE ds_read_b128;
@@ -829,9 +829,9 @@ __global__ __launch_bounds__(256) void conv2d_wide16_kernel(const float* __restr
 // Blocks per sample of the 16-wide kernel: a block walks PF_W16_TPB tiles with a stride of the block count (neighbouring
 // blocks stay on neighbouring tiles).  Two tiles per block were best for ONE forward at a time (1 / 3 / 4 slower,
 // profiles/archive/r02/r02aj_small_ab.txt: too few blocks on the small maps); with four scene lanes in flight the chip is full
-// anyway and the ~190-instruction block prologue (vector instructions cost matrix time, profiles/r03j) is worth
+// anyway and the ~190-instruction block prologue (vector instructions cost matrix time, profiles/archive/r03/r03j) is worth
 // amortising: 2 / 3 / 4 / 5 / 8 tiles per block = 1 065 / 1 078 / 1 083 depth maps/s on one box, 994 / - / 1 015 / 1 016 /
-// 1 015 on a slower one (profiles/r03l_block_policies_ab.log).
+// 1 015 on a slower one (profiles/archive/r03/r03l_block_policies_ab.log).
 #ifndef PF_W16_TPB
 #define PF_W16_TPB 4
 #endif

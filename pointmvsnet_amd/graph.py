@@ -148,7 +148,7 @@ class LanedForward(object):
 
     Why: a depth map is a chain of ~85 dependent kernels, most of them too small to fill 256 CUs and each paying ~5 us
     of dependency latency; other scenes fill those holes.  Measured on MI355X (BASELINE config 2,
-    profiles/r03b_lanes_queues.md): 640 depth maps/s with one lane, 895 with two, 970 with three, 1030 with four
+    profiles/archive/r03/r03b_lanes_queues.md): 640 depth maps/s with one lane, 895 with two, 970 with three, 1030 with four
     (more lanes add nothing: four hardware queues).
 
     Every lane is captured as a single chain (``pointflow.concurrency(0)``): forks inside the graphs take hardware

@@ -396,7 +396,7 @@ def flush_lazy_stats(device=None):
 # 2 = + lattice kNN beside the first EdgeConv GEMM (default: best for ONE scene at a time, 422 / 487 depth maps/s for
 # 0 / 2 in round 1).  With several scenes in flight (graph.LanedForward) the lanes ARE the concurrency and every
 # lane is captured as a single chain (level 0): forks inside the graphs cost hardware queues that the lanes need
-# (profiles/r03b_lanes_queues.md: 3 lanes 771 / 938 / 808 depth maps/s at levels 0 / 1 / 2, 4 lanes on 4 queues 1030).
+# (profiles/archive/r03/r03b_lanes_queues.md: 3 lanes 771 / 938 / 808 depth maps/s at levels 0 / 1 / 2, 4 lanes on 4 queues 1030).
 CONCURRENCY = int(_os.environ.get("PF_CONCURRENCY", "2"))
 
 

@@ -37,7 +37,7 @@ ENVELOPE = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)
 
 # Round 4: the factors on the reference's own self-deviation are 1.25x (fraction of pixels beyond 1e-4) and 1.5x
 # (largest deviation); rounds 1-3 measured the fused pipeline at <= 0.95x the reference's fraction at the BASELINE sizes
-# (1.29x on "tiny", 1 536 pixels: inside the sampling-noise term) and at <= 1.0x its maximum (profiles/r03_parity_report.jsonl).
+# (1.29x on "tiny", 1 536 pixels: inside the sampling-noise term) and at <= 1.0x its maximum (profiles/archive/r03/r03_parity_report.jsonl).
 FRAC_FACTOR, MAX_FACTOR = 1.25, 1.5
 
 
