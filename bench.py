@@ -842,6 +842,7 @@ def main():
         _lib.set_timer(None)
     split = cal.summary()
     dominant = max(split.items(), key=lambda kv: kv[1]["ms"])[0] if split else None
+    by_tag = getattr(cal, "by_tag", {})
 
     # ---- hipGraph capture of the whole forward (default) ------------------------------------------
     execution = "eager"
@@ -956,6 +957,15 @@ def main():
                      TRAFFIC_TABLE + " (two rocprofv3 --pmc passes of a committed earlier job, FETCH_SIZE / WRITE_SIZE; "
                      "a constant of that job, not measured in this run)",
                      "under_load": under_load_instantiations(("conv2d_wide",)) if dominant in TOWERS else None,
+                     # the entry point dispatches to one template instantiation per layer shape: the same clock per shape
+                     # (eager, single chain -- `under_load` is the same table from the trace of the timed execution mode)
+                     "instantiations": sorted(
+                         ({"layer": tag, "launches": v["launches"], "avg_launch_us": v["ms"] * 1e3 / v["launches"],
+                           "TFLOPs": v["flops"] / (v["ms"] / 1e3) / 1e12 if v["ms"] > 0 else None,
+                           "frac_of_f32_mfma_peak": v["flops"] / (v["ms"] / 1e3) / 1e12 / MFMA_F32_PEAK_TF if v["ms"] > 0 else None,
+                           "algo_GBps": v["bytes"] / (v["ms"] / 1e3) / 1e9 if v["ms"] > 0 else None}
+                          for (entry, tag), v in by_tag.items() if entry == dominant),
+                         key=lambda r: -(r["avg_launch_us"] * r["launches"])) or None,
                      "avg_launch_us": avg_s * 1e6,
                      "launches": s["launches"], "algorithmic_bytes_per_launch": avg_bytes,
                      "event_pair_floor_us": s["event_floor_ms"] * 1e3,

@@ -201,7 +201,7 @@ class KernelTimer(object):
 
     def __init__(self, only=None):
         self.only = only
-        self.records = []          # (name, start_event, end_event, algo_bytes, flops)
+        self.records = []          # (name, start_event, end_event, algo_bytes, flops, tag)
 
     def wants(self, name):
         return self.only is None or name == self.only
@@ -223,12 +223,17 @@ class KernelTimer(object):
         torch.cuda.synchronize()
         floor = self._pair_overhead_ms()
         out = {}
-        for name, e0, e1, nbytes, flops in self.records:
-            s = out.setdefault(name, {"launches": 0, "ms": 0.0, "bytes": 0.0, "flops": 0.0, "event_floor_ms": floor})
-            s["launches"] += 1
-            s["ms"] += e0.elapsed_time(e1)                 # raw pair time; the floor is REPORTED, not subtracted
-            s["bytes"] += float(nbytes or 0)
-            s["flops"] += float(flops or 0)
+        self.by_tag = {}           # (entry point, tag) -> the same sums: one row per template instantiation behind an entry
+        for name, e0, e1, nbytes, flops, tag in self.records:
+            ms = e0.elapsed_time(e1)                       # raw pair time; the floor is REPORTED, not subtracted
+            for table, key in ((out, name), (self.by_tag, (name, tag))):
+                if table is self.by_tag and tag is None:
+                    continue
+                s = table.setdefault(key, {"launches": 0, "ms": 0.0, "bytes": 0.0, "flops": 0.0, "event_floor_ms": floor})
+                s["launches"] += 1
+                s["ms"] += ms
+                s["bytes"] += float(nbytes or 0)
+                s["flops"] += float(flops or 0)
         return out
 
 
@@ -248,6 +253,7 @@ def call(name, *args, **kw):
     algorithmic HBM byte count of this launch, used only by KernelTimer."""
     algo_bytes = kw.pop("algo_bytes", None)
     flops = kw.pop("flops", None)
+    tag = kw.pop("tag", None)          # which template instantiation this call selects (KernelTimer.by_tag), e.g. "64->64 3x3/1"
     fn = getattr(load(), name)
     t = _timer
     if t is not None and t.wants(name):
@@ -256,7 +262,7 @@ def call(name, *args, **kw):
         e0.record()
         code = fn(*args)
         e1.record()
-        t.records.append((name, e0, e1, algo_bytes, flops))
+        t.records.append((name, e0, e1, algo_bytes, flops, tag))
     else:
         code = fn(*args)
         if _PROBE and name in _PROBE:

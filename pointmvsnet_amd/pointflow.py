@@ -685,12 +685,14 @@ def conv2d_wide(x, conv, in_affine, samples_per_stat, want_stats, channel_last_o
                   int(ks), int(stride), _lib.ptr(sc), _lib.ptr(sh), in_bn, int(samples_per_stat), _lib.ptr(partials),
                   int(bool(channel_last_out)), _lib.stream(),
                   algo_bytes=4.0 * N * (Cin * Hi * Wi + Cout * Ho * Wo) + 6.0 * ks * ks * Cin * Cout,
-                  flops=2.0 * N * Ho * Wo * ks * ks * Cin * Cout)
+                  flops=2.0 * N * Ho * Wo * ks * ks * Cin * Cout,
+              tag="%d->%d %dx%d/%d" % (Cin, Cout, ks, ks, stride))
         return y, partials
     _lib.call("pf_conv2d_wide_f32", _lib.ptr(x), _lib.ptr(wp), _lib.ptr(y), N, Cin, Cout, Hi, Wi, int(ks), int(stride),
               _lib.ptr(sc), _lib.ptr(sh), in_bn, int(samples_per_stat), _lib.ptr(partials), int(bool(channel_last_out)),
               _lib.stream(), algo_bytes=4.0 * N * (Cin * Hi * Wi + Cout * Ho * Wo) + 4.0 * ks * ks * Cin * Cout,
-              flops=2.0 * N * Ho * Wo * ks * ks * Cin * Cout)
+              flops=2.0 * N * Ho * Wo * ks * ks * Cin * Cout,
+              tag="%d->%d %dx%d/%d" % (Cin, Cout, ks, ks, stride))
     return y, partials
 
 
@@ -758,7 +760,8 @@ def conv2d_wide_stacked(x, convs, want_stats):
     _lib.call("pf_conv2d_wide_f32", _lib.ptr(x), _lib.ptr(wp), _lib.ptr(y), N, Cin, Cout, Hi, Wi, int(ks), int(stride),
               None, None, None, 1, _lib.ptr(partials), 0, _lib.stream(),
               algo_bytes=4.0 * N * (Cin * Hi * Wi + Cout * Ho * Wo) + 4.0 * ks * ks * Cin * Cout,
-              flops=2.0 * N * Ho * Wo * ks * ks * Cin * Cout)
+              flops=2.0 * N * Ho * Wo * ks * ks * Cin * Cout,
+              tag="%d->%d %dx%d/%d" % (Cin, Cout, ks, ks, stride))
     return y, partials
 
 
@@ -795,13 +798,15 @@ def conv2d_wide_sets(x, convs, in_affine, samples_per_stat, want_stats, interlea
                   sets, _lib.ptr(y), N, Cin, Cout, Hi, Wi, int(ks), int(stride), _lib.ptr(sc), _lib.ptr(sh), in_bn,
                   int(samples_per_stat), _lib.ptr(partials), int(mask), _lib.stream(),
                   algo_bytes=4.0 * (x.numel() + N * Cout * Ho * Wo) + 6.0 * sets * ks * ks * Cin * Cout,
-                  flops=2.0 * N * Ho * Wo * ks * ks * Cin * Cout)
+                  flops=2.0 * N * Ho * Wo * ks * ks * Cin * Cout,
+              tag="%d->%d %dx%d/%d" % (Cin, Cout, ks, ks, stride))
         return y, partials
     _lib.call("pf_conv2d_wide_sets_f32", _lib.ptr(x), 2 if interleaved else 0, _lib.ptr(wp), int(wp[0].numel()), sets,
               _lib.ptr(y), N, Cin, Cout, Hi, Wi, int(ks), int(stride), _lib.ptr(sc), _lib.ptr(sh), in_bn,
               int(samples_per_stat), _lib.ptr(partials), int(mask), _lib.stream(),
               algo_bytes=4.0 * (x.numel() + N * Cout * Ho * Wo) + 4.0 * sets * ks * ks * Cin * Cout,
-              flops=2.0 * N * Ho * Wo * ks * ks * Cin * Cout)
+              flops=2.0 * N * Ho * Wo * ks * ks * Cin * Cout,
+              tag="%d->%d %dx%d/%d" % (Cin, Cout, ks, ks, stride))
     return y, partials
 
 
