@@ -509,9 +509,13 @@ __global__ __launch_bounds__(256) void conv2d_wide_split_kernel(const float* __r
   }
   __syncthreads();
 
-  f32x16 acc;
+  // Two accumulators: the leading products a_h b_h in `acc` -- as many float32 roundings per output as the exact-f32 kernel
+  // makes -- and the five correction products (2^-8 .. 2^-16 of it) in `cor`, whose own rounding is negligible; one add
+  // at the end.  (One accumulator for all six made the result ~2x less accurate than the f32 kernel in the emulator's
+  // worst-case model of the matrix core's accumulation, tests/test_emulated_kernels.py.)
+  f32x16 acc, cor;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+  for (int i = 0; i < 16; ++i) acc[i] = cor[i] = 0.0f;
   const char* abase = patch + ((2 * wm + (m >> 4)) * STRIDE * PW + (m & 15) * STRIDE) * RSB + 16 * h;
   u32x4 a[3];
 #pragma unroll
@@ -531,12 +535,12 @@ __global__ __launch_bounds__(256) void conv2d_wide_split_kernel(const float* __r
     const bf16x8 bh = __builtin_bit_cast(bf16x8, bq[t % D][0]), bm = __builtin_bit_cast(bf16x8, bq[t % D][1]),
                  bl = __builtin_bit_cast(bf16x8, bq[t % D][2]);
     __builtin_amdgcn_sched_barrier(0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+    cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, cor, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+    cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, cor, 0, 0, 0);
+    cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, cor, 0, 0, 0);
+    cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, cor, 0, 0, 0);
+    cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, cor, 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
     if (t + D < NP) {
 #pragma unroll
@@ -545,6 +549,8 @@ __global__ __launch_bounds__(256) void conv2d_wide_split_kernel(const float* __r
 #pragma unroll
     for (int sp = 0; sp < 3; ++sp) a[sp] = an[sp];
   }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] += cor[i];
   wide_epilogue<C, COUT>(acc, y, g, partials, red, n, oh0, ow0, wm, wn, wave, m, h, tid, (g.cl_out >> set) & 1);
 }
 

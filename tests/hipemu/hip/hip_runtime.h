@@ -1,0 +1,170 @@
+// A HIP-on-CPU shim for TESTS (tests/hipemu): enough of the HIP programming model to run this repository's kernels --
+// unchanged source, recompiled for the host with clang++ -- on a machine without a GPU, one OS thread per GPU thread.
+//
+// Why: round 5 lost its GPU access while a new kernel (conv2d_wide_split_kernel) was being written.  hipcc -S shows that
+// a kernel compiles, not that its indexing is right; this shim executes it.  What it models:
+//   * a launch = the blocks of the grid one after the other, 256 (blockDim.x) OS threads per block; threadIdx /
+//     blockIdx / gridDim / blockDim are thread-local; __syncthreads() is a barrier over the block's threads;
+//   * `extern __shared__` / `__shared__` storage is one static buffer per declaration (blocks run sequentially);
+//   * wave-collective operations (v_mfma_f32_32x32x2_f32, v_mfma_f32_16x16x4_f32, v_mfma_f32_32x32x16_bf16, __shfl_xor)
+//     rendezvous the 64 threads of a wave: every lane publishes its operands, the lanes meet, every lane computes its own
+//     registers from the published operands with the lane <-> element maps of the CDNA4 ISA (A: row = lane % 32,
+//     k = 8 * (lane / 32) + j for 32x32x16; C/D: col = lane % 32, row = (r % 4) + 8 * (r / 4) + 4 * (lane / 32)), f32
+//     products accumulated as an fmaf chain in k order -- the documented behaviour of the f32 forms; for the bf16 form the
+//     order inside a 16-deep block is the emulator's choice (the hardware's is unspecified).
+// What it does NOT model: timing, bank conflicts, occupancy, memory faults (an out-of-bounds access is a host
+// out-of-bounds access: run the tests under -fsanitize=address to catch those), divergent collectives.
+#pragma once
+#include <atomic>
+#include <barrier>
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstring>
+#include <functional>
+#include <thread>
+#include <vector>
+
+#define __HIPCC__ 1
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {}
+};
+struct hipemu_uint3 { unsigned x, y, z; };
+extern thread_local hipemu_uint3 threadIdx, blockIdx;
+extern thread_local dim3 gridDim, blockDim;
+
+typedef void* hipStream_t;
+typedef int hipError_t;
+constexpr hipError_t hipSuccess = 0;
+constexpr int hipFuncAttributeMaxDynamicSharedMemorySize = 8;
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
+
+struct float2 { float x, y; };
+struct float4 { float x, y, z, w; };
+struct double2 { double x, y; };
+static inline float4 make_float4(float a, float b, float c, float d) { return float4{a, b, c, d}; }
+static inline float2 make_float2(float a, float b) { return float2{a, b}; }
+static inline double2 make_double2(double a, double b) { return double2{a, b}; }
+static inline int min(int a, int b) { return a < b ? a : b; }
+static inline int max(int a, int b) { return a > b ? a : b; }
+
+// ---- the block / wave machinery (tests/hipemu/hipemu.cpp) -------------------------------------------------------------
+namespace hipemu {
+struct Wave {                       // the rendezvous area of one wave: what every lane publishes for a collective
+  alignas(16) unsigned char a[64][64];
+  alignas(16) unsigned char b[64][64];
+  std::barrier<>* bar;
+};
+extern thread_local Wave* wave;     // this thread's wave
+extern thread_local int lane;       // 0..63
+void block_barrier();
+void launch(dim3 grid, dim3 block, const std::function<void()>& body);
+}  // namespace hipemu
+
+#define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) \
+  ::hipemu::launch((grid), (block), [=]() { kernel(__VA_ARGS__); })
+
+static inline void __syncthreads() { hipemu::block_barrier(); }
+#define __builtin_amdgcn_readfirstlane(x) (x)
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
+
+template <class T>
+static inline T __shfl_xor(T v, int mask) {
+  static_assert(sizeof(T) <= 64, "shuffle payload");
+  std::memcpy(hipemu::wave->a[hipemu::lane], &v, sizeof(T));
+  hipemu::wave->bar->arrive_and_wait();
+  T out;
+  std::memcpy(&out, hipemu::wave->a[hipemu::lane ^ mask], sizeof(T));
+  hipemu::wave->bar->arrive_and_wait();
+  return out;
+}
+
+typedef float hipemu_f32x16 __attribute__((ext_vector_type(16)));
+typedef float hipemu_f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 hipemu_bf16x8 __attribute__((ext_vector_type(8)));
+
+// v_mfma_f32_32x32x2_f32: A[i = lane % 32][k = lane / 32], B[k = lane / 32][j = lane % 32]; D += A B as an fmaf chain in k
+static inline hipemu_f32x16 hipemu_mfma_32x32x2_f32(float a, float b, hipemu_f32x16 c) {
+  using namespace hipemu;
+  std::memcpy(wave->a[lane], &a, 4);
+  std::memcpy(wave->b[lane], &b, 4);
+  wave->bar->arrive_and_wait();
+  const int col = lane & 31, hi = lane >> 5;
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+    float acc = c[r];
+    for (int k = 0; k < 2; ++k) {
+      float av, bv;
+      std::memcpy(&av, wave->a[row + 32 * k], 4);
+      std::memcpy(&bv, wave->b[col + 32 * k], 4);
+      acc = fmaf(av, bv, acc);
+    }
+    c[r] = acc;
+  }
+  wave->bar->arrive_and_wait();
+  return c;
+}
+
+// v_mfma_f32_16x16x4_f32: A[i = lane % 16][k = lane / 16], B[k = lane / 16][j = lane % 16]; C/D: col = lane % 16,
+// row = 4 * (lane / 16) + r
+static inline hipemu_f32x4 hipemu_mfma_16x16x4_f32(float a, float b, hipemu_f32x4 c) {
+  using namespace hipemu;
+  std::memcpy(wave->a[lane], &a, 4);
+  std::memcpy(wave->b[lane], &b, 4);
+  wave->bar->arrive_and_wait();
+  const int col = lane & 15, q = lane >> 4;
+  for (int r = 0; r < 4; ++r) {
+    const int row = 4 * q + r;
+    float acc = c[r];
+    for (int k = 0; k < 4; ++k) {
+      float av, bv;
+      std::memcpy(&av, wave->a[row + 16 * k], 4);
+      std::memcpy(&bv, wave->b[col + 16 * k], 4);
+      acc = fmaf(av, bv, acc);
+    }
+    c[r] = acc;
+  }
+  wave->bar->arrive_and_wait();
+  return c;
+}
+
+// v_mfma_f32_32x32x16_bf16: A[i = lane % 32][k = 8 (lane / 32) + j], B[k = 8 (lane / 32) + j][col = lane % 32], j = 0..7
+static inline float hipemu_bf16_bits_to_float(uint16_t h) {
+  uint32_t u = (uint32_t)h << 16;
+  float f;
+  std::memcpy(&f, &u, 4);
+  return f;
+}
+static inline hipemu_f32x16 hipemu_mfma_32x32x16_bf16(hipemu_bf16x8 a, hipemu_bf16x8 b, hipemu_f32x16 c) {
+  using namespace hipemu;
+  std::memcpy(wave->a[lane], &a, 16);
+  std::memcpy(wave->b[lane], &b, 16);
+  wave->bar->arrive_and_wait();
+  const int col = lane & 31, hi = lane >> 5;
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+    float acc = c[r];
+    for (int kh = 0; kh < 2; ++kh) {
+      uint16_t av[8], bv[8];
+      std::memcpy(av, wave->a[row + 32 * kh], 16);
+      std::memcpy(bv, wave->b[col + 32 * kh], 16);
+      for (int j = 0; j < 8; ++j) acc = fmaf(hipemu_bf16_bits_to_float(av[j]), hipemu_bf16_bits_to_float(bv[j]), acc);
+    }
+    c[r] = acc;
+  }
+  wave->bar->arrive_and_wait();
+  return c;
+}
+
+#define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) hipemu_mfma_32x32x2_f32((a), (b), (c))
+#define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) hipemu_mfma_16x16x4_f32((a), (b), (c))
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) hipemu_mfma_32x32x16_bf16((a), (b), (c))

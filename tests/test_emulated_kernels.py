@@ -1,0 +1,149 @@
+"""Kernels of pointmvsnet_amd/csrc EXECUTED on the CPU (tests/hipemu: the unchanged kernel source recompiled for the host on a
+HIP shim -- one OS thread per GPU thread, barriers for __syncthreads, the wave-collective MFMA / shuffle instructions
+emulated with the ISA's lane <-> element maps) through the package's own Python wrappers and C ABI.
+
+Round 5 lost its GPU access while conv2d_wide_split_kernel (the bf16x3 tower kernel, PF_MATRIX_SPLIT) was being written;
+`hipcc` shows that a kernel compiles, this shows that its indexing, staging, weight layout, statistics rows and epilogue are
+right.  The emulator itself is pinned by the kernels that HAVE run on an MI355X (the exact-f32 tower kernels, green against
+float64 on hardware since round 2): if it reproduces them, its model of blocks, LDS, barriers and matrix instructions holds.
+
+Not modelled: timing, bank conflicts, the hardware's summation order inside a 16-deep bf16 block (the emulator uses an fmaf
+chain in k order: the pessimistic case).  Speed and the last bits need the device (tools/microbench_split.py, bench.py).
+"""
+import ctypes
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from pointmvsnet_amd import _lib, pointflow
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def emu(lib_built):
+    """libpointflow_emu.so behind the package's ctypes layer: compute entry points come from the emulated library, host-side
+    helpers (block counts, *_supported) from the real one (they need no GPU)."""
+    sys.path.insert(0, os.path.join(HERE, "hipemu"))
+    import build_emu
+    lib = ctypes.CDLL(build_emu.build())
+    real = _lib.load()
+
+    class Proxy(object):
+        def __getattr__(self, name):
+            try:
+                fn = getattr(lib, name)
+            except AttributeError:
+                return getattr(real, name)
+            fn.argtypes, fn.restype = _lib.PROTOTYPES[name]
+            return fn
+
+    saved = (_lib._lib, _lib.stream, pointflow.MATRIX_SPLIT)
+    _lib._lib, _lib.stream = Proxy(), (lambda: None)
+    yield lib
+    _lib._lib, _lib.stream, pointflow.MATRIX_SPLIT = saved
+
+
+def _case(cin, cout, k, stride, hw, n, seed, affine):
+    g = torch.Generator().manual_seed(seed)
+    conv = torch.nn.Conv2d(cin, cout, k, stride=stride, padding=k // 2, bias=False)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * (2.0 / (cin * k * k)) ** 0.5)
+    x = torch.randn((n, cin) + hw, generator=g)
+    aff, xin = None, x.double()
+    if affine:
+        sc = (1.0 + 0.3 * torch.randn((n, cin), generator=g)).contiguous()
+        sh = (0.2 * torch.randn((n, cin), generator=g)).contiguous()
+        aff = (sc, sh)
+        xin = torch.relu(xin * sc.double().view(n, cin, 1, 1) + sh.double().view(n, cin, 1, 1))
+    ref = F.conv2d(xin, conv.weight.detach().double(), None, stride, k // 2)
+    return conv, x, aff, ref
+
+
+def _check(y, part, ref, tol):
+    scale = ref.abs().max()
+    err = float((y.double() - ref).abs().max() / scale)
+    s_err = float((part.sum(dim=1)[..., 0] - ref.sum(dim=(2, 3))).abs().max() / ref.sum(dim=(2, 3)).abs().max())
+    q_err = float((part.sum(dim=1)[..., 1] - (ref * ref).sum(dim=(2, 3))).abs().max() / (ref * ref).sum(dim=(2, 3)).abs().max())
+    assert err < tol and s_err < 1e-5 and q_err < 1e-5, (err, s_err, q_err)
+    return err
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,hw", [(64, 64, 3, 1, (5, 18)), (16, 32, 5, 2, (14, 30)), (16, 16, 3, 1, (7, 19))])
+def test_emulator_reproduces_the_hardware_validated_f32_tower_kernels(emu, cin, cout, k, stride, hw):
+    """The emulator's own pin: kernels that are green against float64 on an MI355X (v_mfma_f32_32x32x2_f32 and
+    v_mfma_f32_16x16x4_f32 forms, border tiles included) give the same answer here."""
+    pointflow.MATRIX_SPLIT = 0
+    conv, x, aff, ref = _case(cin, cout, k, stride, hw, 2, 11, True)
+    y, part = pointflow.conv2d_wide(x, conv, aff, 1, True)
+    _check(y, part, ref, 2e-6)
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,hw", [(64, 64, 3, 1, (5, 18)), (32, 32, 3, 1, (9, 17)), (32, 64, 5, 2, (9, 34)),
+                                                 (16, 32, 5, 2, (14, 30))])
+@pytest.mark.parametrize("affine", [False, True])
+def test_split_kernel_executes_correctly_on_the_emulator(emu, cin, cout, k, stride, hw, affine):
+    """conv2d_wide_split_kernel, all four instantiations, interior and border tiles, with and without the pending
+    BatchNorm + ReLU applied while staging: output and statistics rows against a float64 convolution, and no worse than
+    the exact-f32 kernel on the same operands (two accumulators: leading products / corrections)."""
+    conv, x, aff, ref = _case(cin, cout, k, stride, hw, 2, 5, affine)
+    pointflow.MATRIX_SPLIT = 0
+    y32, part32 = pointflow.conv2d_wide(x, conv, aff, 1, True)
+    e32 = _check(y32, part32, ref, 2e-6)
+    pointflow.MATRIX_SPLIT = 1
+    assert pointflow.conv2d_wide_split_supported(conv)
+    y, part = pointflow.conv2d_wide(x, conv, aff, 1, True)
+    e = _check(y, part, ref, 2e-6)
+    print("emulated %d->%d k%d/%d affine %d: bf16x3 %.2e, f32 %.2e of the largest output against float64"
+          % (cin, cout, k, stride, int(affine), e, e32))
+    assert e < 1.5 * e32 + 1e-7, (e, e32)
+
+
+def test_split_kernel_resolves_a_pending_batchnorm_and_serves_two_towers(emu):
+    """The two remaining modes: the pending BatchNorm resolved by the kernel's own blocks from the producer's statistics
+    rows (`in_bn`, AFFINE = 2), and both towers in one launch (parameter sets, set 0 written channel-last) -- each
+    against the same layer run set by set with explicit affine rows."""
+    pointflow.MATRIX_SPLIT = 1
+    g = torch.Generator().manual_seed(3)
+    cin = cout = 32
+    n, hw = 2, (9, 17)
+    convs = [torch.nn.Conv2d(cin, cout, 3, padding=1, bias=False) for _ in range(2)]
+    bns = [torch.nn.BatchNorm2d(cin).train() for _ in range(2)]
+    for c, b in zip(convs, bns):
+        with torch.no_grad():
+            c.weight.copy_(torch.randn(c.weight.shape, generator=g) * 0.08)
+            b.weight.copy_(1.0 + 0.2 * torch.randn(cin, generator=g))
+            b.bias.copy_(0.1 * torch.randn(cin, generator=g))
+    x = torch.randn((2 * n, cin) + hw, generator=g)                       # set s owns samples [s n, (s + 1) n)
+    # statistics rows of x as a producer would leave them: 3 partial rows per sample
+    xd = x.double().reshape(2 * n, cin, -1)
+    cuts = [0, 40, 100, xd.shape[2]]
+    partials = torch.zeros((2 * n, 3, cin, 2), dtype=torch.float64)
+    for t in range(3):
+        seg = xd[:, :, cuts[t]:cuts[t + 1]]
+        partials[:, t, :, 0], partials[:, t, :, 1] = seg.sum(-1), (seg * seg).sum(-1)
+    count = float(xd.shape[2])
+    outs = []
+    for s in range(2):
+        sl = slice(s * n, (s + 1) * n)
+        scale, shift = torch.empty((n, cin)), torch.empty((n, cin))
+        job = pointflow.bn_job(bns[s], partials[sl].contiguous(), 0, cin, count, count, n, 1, scale, shift)
+        lazy = pointflow.LazyAffine(job, (partials, scale, shift), scale, shift)
+        y_lazy, _ = pointflow.conv2d_wide(x[sl].contiguous(), convs[s], lazy, 1, True)       # AFFINE = 2 in the kernel
+        mean = xd[sl].mean(-1)
+        var = (xd[sl] * xd[sl]).mean(-1) - mean * mean
+        a = bns[s].weight.detach().double() / torch.sqrt(var + bns[s].eps)
+        rows = (a.float().contiguous(), (bns[s].bias.detach().double() - mean * a).float().contiguous())
+        y_rows, _ = pointflow.conv2d_wide(x[sl].contiguous(), convs[s], rows, 1, True)       # AFFINE = 1
+        assert float((y_lazy - y_rows).abs().max() / y_rows.abs().max()) < 2e-6
+        outs.append((y_rows, rows))
+    sc = torch.cat([o[1][0] for o in outs]).contiguous()
+    sh = torch.cat([o[1][1] for o in outs]).contiguous()
+    y2, part2 = pointflow.conv2d_wide_sets(x, convs, pointflow.AffineSets(sc, sh, 2), 1, True, channel_last_sets=(0,))
+    y2 = y2.view(2, n, -1)
+    got0 = y2[0].view(n, hw[0], hw[1], cout).permute(0, 3, 1, 2)                                # set 0: channel-last
+    got1 = y2[1].view(n, cout, hw[0], hw[1])
+    assert torch.equal(got0, outs[0][0]) and torch.equal(got1, outs[1][0])                       # bit-identical per set
