@@ -36,10 +36,19 @@ def lib_built():
 
 @pytest.fixture(scope="session")
 def dev():
+    """cuda:0 -- or, with PF_EMULATE=1 on a machine WITHOUT a GPU, the CPU with tests/hipemu behind the C ABI for the whole
+    session: the gpu-marked tests then execute the kernel sources on the host (tests/hipemu/on_cpu.py).  A development
+    aid for rounds without GPU access (slow, no timing, not a substitute: the driver's `pytest -m gpu` runs on an MI355X)."""
+    if os.environ.get("PF_EMULATE") == "1" and not torch.cuda.is_available():
+        sys.path.insert(0, os.path.join(ROOT, "tests", "hipemu"))
+        from on_cpu import emulated_gpu
+        with emulated_gpu():
+            yield torch.device("cpu")
+        return
     assert torch.cuda.is_available(), "gpu-marked test collected on a machine without a GPU"
     from pointmvsnet_amd import _lib
     _lib.load()                      # fail loudly if the HIP library is missing
-    return torch.device("cuda:0")
+    yield torch.device("cuda:0")
 
 
 def report(name, **values):

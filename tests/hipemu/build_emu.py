@@ -4,7 +4,8 @@
 
 Test infrastructure only (tests/test_emulated_kernels.py).  The kernel sources are used UNCHANGED except for the two
 spellings of shared memory, which a host compiler cannot give HIP's meaning: `extern __shared__ ... lds[]` becomes a
-pointer to the emulator's one static buffer, `__shared__ T name[...]` a static array (blocks run one after the other).
+pointer to the emulator's per-OS-thread buffer, `__shared__ T name[...]` a `static thread_local` array (a block's GPU
+threads are fibers of one OS thread).
 """
 import os
 import re
@@ -16,15 +17,21 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "pointmvsnet_amd", "csrc")
 OUT = os.path.join(HERE, "build")
 LIB = os.path.join(OUT, "libpointflow_emu.so")
-SOURCES = ["conv2d_wide.hip"]
+SOURCES = ["pf_core.hip", "gather_knn.hip", "knn_lattice.hip", "fetch.hip", "edgeconv.hip", "norm.hip", "conv3d.hip", "conv3d_pair.hip", "deconv3d.hip", "conv3d_bottom.hip", "conv2d_wide.hip", "eval_out.hip", "knn_inverse.hip", "norm_bwd.hip", "conv_wgrad.hip", "conv_dgrad.hip", "warp_bwd.hip", "train_heads.hip"]
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 
 
 def _host_source(text):
-    text = re.sub(r"extern\s+__shared__\s+__attribute__\(\(aligned\(16\)\)\)\s+float\s+lds\[\];",
-                  "float* lds = ::hipemu_shared_memory();", text)
+    text = re.sub(r"extern\s+__shared__\s+__attribute__\(\(aligned\(16\)\)\)\s+(float|char|unsigned char)\s+(\w+)\[\];",
+                  lambda m: "%s* %s = reinterpret_cast<%s*>(::hipemu_shared_memory());" % (m.group(1), m.group(2), m.group(1)),
+                  text)
     assert "extern __shared__" not in text, "an extern __shared__ declaration the emulator does not know"
-    return re.sub(r"\b__shared__\s+", "static ", text)
+    # the two gfx950 instructions written as inline assembly (knn_lattice.hip: keys are never NaN, so these are plain
+    # ordered comparisons of doubles)
+    text = text.replace('asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));', "r = b < a ? b : a;")
+    text = text.replace('asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));', "r = b < a ? a : b;")
+    assert "asm(" not in text and "asm volatile" not in text, "inline assembly the emulator does not know"
+    return re.sub(r"\b__shared__\s+", "static thread_local ", text)
 
 
 def build(force=False):
@@ -44,7 +51,8 @@ def build(force=False):
         units.append(dst)
     shared = os.path.join(OUT, "shared_memory.cpp")
     with open(shared, "w") as f:
-        f.write("alignas(64) static float g_lds[160 * 1024 / 4];\nfloat* hipemu_shared_memory() { return g_lds; }\n")
+        f.write("alignas(64) static thread_local float g_lds[160 * 1024 / 4];\n"
+                "float* hipemu_shared_memory() { return g_lds; }\n")
     units.append(shared)
     cmd = [CLANG, "-std=c++20", "-O1", "-ffp-contract=off", "-fPIC", "-shared", "-pthread", "-w",
            "-I" + HERE, "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-x", "c++"] + units + ["-o", LIB]
