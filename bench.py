@@ -381,10 +381,11 @@ def train_block(dev, rank, world, steps=20, warmup=3):
     72-86).  ``steps`` replays timed between synchronisations (and barriers when N > 1), MAX over ranks."""
     from pointmvsnet_amd import model as _model
     from pointmvsnet_amd.train_step import GraphedTrainStep, TrainStep
-    _, _, _, _, _, img_scales, inter_scales = synthetic.CONFIGS["cfg4"]
+    cfg = os.environ.get("PF_TRAIN_BLOCK_CONFIG", "cfg4")          # ("tiny": the emulator's dry run of this function)
+    _, _, _, _, _, img_scales, inter_scales = synthetic.CONFIGS[cfg]
     scenes = []
     for i in range(2):
-        data, _, _ = synthetic.make_config("cfg4", seed=rank + world * i, train_intrinsics=True)
+        data, _, _ = synthetic.make_config(cfg, seed=rank + world * i, train_intrinsics=True)
         batch = to_device(data, dev)
         batch["gt_depth_img"] = synthetic.make_gt_depth(data, seed=rank + world * i).to(dev)
         scenes.append(batch)
@@ -432,7 +433,8 @@ def train_block(dev, rank, world, steps=20, warmup=3):
         allreduce_us = statistics.median(ev[j].elapsed_time(ev[j + 1]) for j in range(1, 21)) * 1e3
     assert torch.isfinite(loss)
     ms = elapsed / steps * 1e3
-    out = {"metric": "train-scenes/sec (DTU 640x512, 3 views, 1 scene per GPU, forward+loss+backward+all-reduce+RMSprop)",
+    out = {"metric": "train-scenes/sec (DTU 640x512, 3 views, 1 scene per GPU, forward+loss+backward+all-reduce+RMSprop)"
+                     if cfg == "cfg4" else "train-scenes/sec (%s: dry run)" % cfg,
            "value": world * steps / elapsed, "unit": "train-scenes/s", "ms_per_step": ms, "steps": steps,
            "warmup": warmup, "n_gpus": world, "allreduce_us": allreduce_us,
            "execution": "hipGraph replay of zero_grad + forward + loss + backward%s; all-reduce + RMSprop step eager"
@@ -476,11 +478,16 @@ def experiments_block(dev, out, publish):
     from pointmvsnet_amd import pointflow, train_ops
     from pointmvsnet_amd.train_step import GraphedTrainStep, TrainStep
     exp = out.setdefault("experiments", {})
+    # PF_EXPERIMENTS_DRY=1 (the emulator's dry run of this function): the same code on "tiny" scenes, one repetition
+    dry = os.environ.get("PF_EXPERIMENTS_DRY") == "1"
+    train_cfg, infer_cfg = ("tiny", "tiny") if dry else ("cfg4", "cfg2")
+    if dry:
+        exp["dry_run"] = True
 
     def timed_train(lazy):
         train_ops.TRAIN_LAZY_BN = int(lazy)
-        _, _, _, _, _, img_scales, inter_scales = synthetic.CONFIGS["cfg4"]
-        data, _, _ = synthetic.make_config("cfg4", seed=0, train_intrinsics=True)
+        _, _, _, _, _, img_scales, inter_scales = synthetic.CONFIGS[train_cfg]
+        data, _, _ = synthetic.make_config(train_cfg, seed=0, train_intrinsics=True)
         batch = to_device(data, dev)
         batch["gt_depth_img"] = synthetic.make_gt_depth(data, seed=0).to(dev)
         net = PointMVSNet()
@@ -489,7 +496,7 @@ def experiments_block(dev, out, publish):
         trainer = TrainStep(net)
         loss, _, _ = trainer(batch, img_scales, inter_scales)
         grad = trainer.bucket.flat.detach().clone()
-        graphed = GraphedTrainStep(trainer, batch, img_scales, inter_scales)
+        graphed = GraphedTrainStep(trainer, batch, img_scales, inter_scales, warmup=1 if dry else 3)
         for _ in range(3):
             graphed(batch)
         torch.cuda.synchronize()
@@ -512,7 +519,9 @@ def experiments_block(dev, out, publish):
     publish(out)
 
     def timeit(fn, reps=50):
-        for _ in range(10):
+        if dry:
+            reps = 1
+        for _ in range(1 if dry else 10):
             fn()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -528,6 +537,8 @@ def experiments_block(dev, out, publish):
         torch.manual_seed(0)
         for name, cin, cout, h, w, ks, stride in (("16->32 5x5/2", 16, 32, 256, 320, 5, 2), ("32->32 3x3", 32, 32, 128, 160, 3, 1),
                                                   ("32->64 5x5/2", 32, 64, 128, 160, 5, 2), ("64->64 3x3", 64, 64, 64, 80, 3, 1)):
+            if dry:
+                h, w = h // 8, w // 8
             conv = torch.nn.Conv2d(cin, cout, ks, stride=stride, padding=ks // 2, bias=False).to(dev)
             x = torch.randn(6, cin, h, w, device=dev)                      # both towers' samples of a cfg-2 scene
             sc = torch.rand(6, cin, device=dev) + 0.5
@@ -552,26 +563,28 @@ def experiments_block(dev, out, publish):
 
     try:                                       # the headline workload with the switch off and on: same box, same process
         from pointmvsnet_amd.graph import LanedForward
-        h, w, V, D, _, img_scales, inter_scales = synthetic.CONFIGS["cfg2"]
-        scenes = [to_device(synthetic.make_config("cfg2", seed=i)[0], dev) for i in range(4)]
+        h, w, V, D, _, img_scales, inter_scales = synthetic.CONFIGS[infer_cfg]
+        scenes = [to_device(synthetic.make_config(infer_cfg, seed=i)[0], dev) for i in range(4)]
         rates = {}
-        for split in (0, 1, 0, 1):
+        n_warm, n_timed = (1, 1) if dry else (64, 512)
+        for split in ((0, 1) if dry else (0, 1, 0, 1)):
             pointflow.MATRIX_SPLIT = split
             net = PointMVSNet()
             synthetic.seed_weights(net, seed=0)
             net = net.to(dev).train()
             with torch.no_grad():
-                laned = LanedForward(net, scenes[0], img_scales, inter_scales, isFlow=True, isTest=True, lanes=4)
-                for i in range(64):
+                laned = LanedForward(net, scenes[0], img_scales, inter_scales, isFlow=True, isTest=True,
+                                     lanes=1 if dry else 4, warmup=1 if dry else 3)
+                for i in range(n_warm):
                     laned.submit(scenes[i % 4])
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                for i in range(512):
+                for i in range(n_timed):
                     laned.submit(scenes[i % 4])
                 torch.cuda.synchronize()
-            rates.setdefault("bf16x3" if split else "f32", []).append(512 / (time.perf_counter() - t0))
+            rates.setdefault("bf16x3" if split else "f32", []).append(n_timed / (time.perf_counter() - t0))
             del laned, net
-        exp["bf16x3_headline_ab"] = {"depth_maps_per_s": rates, "workload": WORKLOAD_TEXT["cfg2"],
+        exp["bf16x3_headline_ab"] = {"depth_maps_per_s": rates, "workload": WORKLOAD_TEXT[infer_cfg],
                                       "arms": "f32, bf16x3, f32, bf16x3 (512 scenes each, 4 lanes, graph replay)",
                                       "ratio": (sum(rates["bf16x3"]) / len(rates["bf16x3"]))
                                                / (sum(rates["f32"]) / len(rates["f32"]))}
@@ -583,28 +596,30 @@ def experiments_block(dev, out, publish):
 
     try:          # the headline workload with every scene's images starting in PINNED HOST memory (never `value`)
         from pointmvsnet_amd.graph import LanedForward
-        h, w, V, D, _, img_scales, inter_scales = synthetic.CONFIGS["cfg2"]
-        scenes = [to_device(synthetic.make_config("cfg2", seed=i)[0], dev) for i in range(4)]
+        h, w, V, D, _, img_scales, inter_scales = synthetic.CONFIGS[infer_cfg]
+        scenes = [to_device(synthetic.make_config(infer_cfg, seed=i)[0], dev) for i in range(4)]
         hosted = []
         for b in scenes:
             hb = dict(b)
-            hb["img_list"] = b["img_list"].cpu().pin_memory()            # 3 x 3 x 512 x 640 floats = 11.8 MB per scene
+            hb["img_list"] = b["img_list"].cpu() if dry else b["img_list"].cpu().pin_memory()   # 11.8 MB per cfg-2 scene
             hosted.append(hb)
         net = PointMVSNet()
         synthetic.seed_weights(net, seed=0)
         net = net.to(dev).train()
         rates = {}
         with torch.no_grad():
-            laned = LanedForward(net, scenes[0], img_scales, inter_scales, isFlow=True, isTest=True, lanes=4)
+            laned = LanedForward(net, scenes[0], img_scales, inter_scales, isFlow=True, isTest=True,
+                                 lanes=1 if dry else 4, warmup=1 if dry else 3)
+            n_warm, n_timed = (1, 1) if dry else (32, 384)
             for tag, batches in (("resident", scenes), ("pinned_host", hosted), ("resident", scenes), ("pinned_host", hosted)):
-                for i in range(32):
+                for i in range(n_warm):
                     laned.submit(batches[i % 4])
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                for i in range(384):
+                for i in range(n_timed):
                     laned.submit(batches[i % 4])
                 torch.cuda.synchronize()
-                rates.setdefault(tag, []).append(384 / (time.perf_counter() - t0))
+                rates.setdefault(tag, []).append(n_timed / (time.perf_counter() - t0))
         exp["pcie_inclusive"] = {"depth_maps_per_s": rates, "bytes_per_scene_host_to_device": int(hosted[0]["img_list"].numel() * 4),
                                  "note": "images in pinned host memory, one asynchronous H2D per scene on the lane's stream "
                                          "before its graph replay; the cameras are host-side already (one 2 KB H2D per scene "
@@ -617,8 +632,8 @@ def experiments_block(dev, out, publish):
     try:          # the training step's CPU baseline: ONE oracle step (forward + loss + backward) on this host's cores
         net = PointMVSNet()
         synthetic.seed_weights(net, seed=0)
-        data_cpu, img_scales, inter_scales = synthetic.make_config("cfg4", seed=0, train_intrinsics=True)
-        out["cpu_baseline"] = cpu_baseline(net, data_cpu, img_scales, inter_scales, 1, WORKLOAD_TEXT["cfg4"], train=True)
+        data_cpu, img_scales, inter_scales = synthetic.make_config(train_cfg, seed=0, train_intrinsics=True)
+        out["cpu_baseline"] = cpu_baseline(net, data_cpu, img_scales, inter_scales, 1, WORKLOAD_TEXT[train_cfg], train=True)
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
     except Exception as exc:
         out["cpu_baseline"] = {"error": repr(exc)}
@@ -672,8 +687,15 @@ def train_block_in_child(args, rank, world):
     return {"error": "the train block's child process left no result (%s)" % (note or "no JSON line on its stdout")}
 
 
-def train_block_child(args):
+def train_block_child(args, emulate=False):
     """``--train-block-only``: this process IS the child of train_block_in_child."""
+    if emulate:                                   # (PF_EMULATE=1: a dry run of this function's code on tests/hipemu)
+        out, recount = train_block(torch.device("cpu"), 0, 1, steps=max(1, args.train_steps), warmup=1)
+        print(json.dumps(out), flush=True)
+        print(json.dumps(recount()), flush=True)
+        if not args.no_experiments:
+            experiments_block(torch.device("cpu"), out, lambda o: print(json.dumps(o), flush=True))
+        return
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         torch.set_num_threads(int(os.environ.get("OMP_NUM_THREADS") or host_threads_per_rank(os.environ["WORLD_SIZE"])))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -708,6 +730,21 @@ def train_block_child(args):
 
 def main():
     args = parse_args()
+    if os.environ.get("PF_EMULATE") == "1" and not torch.cuda.is_available() and not args.launch_check:
+        # development aid for a machine without a GPU (tests/hipemu): the SAME code path -- scenes, model, calibration
+        # clock, timed loop, assembly of the JSON line -- with the kernels executed on the host.  Eager, one lane, no
+        # child processes; the numbers are the emulator's speed and mean nothing, the line's SHAPE is what gets exercised
+        sys.path.insert(0, os.path.join(ROOT, "tests", "hipemu"))
+        from on_cpu import emulated_gpu
+        args.eager, args.lanes, args.no_cpu_baseline, args.no_train_block, args.gpus = True, 1, True, True, 1
+        with emulated_gpu():
+            if args.train_block_only:
+                return train_block_child(args, emulate=True)
+            return run(args, emulate=True)
+    return run(args, emulate=False)
+
+
+def run(args, emulate):
     if args.train_block_only:
         if not torch.cuda.is_available():
             raise RuntimeError("bench.py needs a GPU: the hot path has no CPU fallback")
@@ -729,14 +766,17 @@ def main():
             torch.distributed.barrier()
             torch.distributed.destroy_process_group()
         return
-    if not torch.cuda.is_available():
-        raise RuntimeError("bench.py needs a GPU: the hot path has no CPU fallback")
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if local >= torch.cuda.device_count():
-        raise SystemExit("bench.py: LOCAL_RANK %d but only %d GPUs visible" % (local, torch.cuda.device_count()))
-    torch.cuda.set_device(local)
-    rank, world, local = distributed.init_from_env()
-    dev = torch.device("cuda", local)
+    if emulate:
+        rank, world, local, dev = 0, 1, 0, torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise RuntimeError("bench.py needs a GPU: the hot path has no CPU fallback")
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        if local >= torch.cuda.device_count():
+            raise SystemExit("bench.py: LOCAL_RANK %d but only %d GPUs visible" % (local, torch.cuda.device_count()))
+        torch.cuda.set_device(local)
+        rank, world, local = distributed.init_from_env()
+        dev = torch.device("cuda", local)
     _lib.load()
     rccl_ranks = count_ranks(dev)
     assert rccl_ranks == world == args.gpus, (rccl_ranks, world, args.gpus)

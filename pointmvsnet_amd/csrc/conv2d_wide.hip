@@ -446,7 +446,7 @@ int launch_wide(const float* x, const float* wp, float* y, WideGeom g, int64_t N
 //   LDS patch: [pixel][split][CIN] bf16 (+16 bytes per pixel: consecutive pixels fall on distinct 16-byte bank slots);
 //   lane (pixel m, half h) reads its 8 reduction channels 16 kb + 8 h .. + 7 of split sp as ONE ds_read_b128;
 //   weights host-packed [tap][kb][split][h][c_out][8] bf16: a lane's B operand is one 16-byte load, a wave's two
-//   contiguous 512-byte runs, two K blocks ahead.
+//   contiguous 512-byte runs, four K blocks ahead.
 // ------------------------------------------------------------------------------------------------
 template <int KS, int STRIDE, int CIN, int COUT>
 struct SplitCfg {
@@ -490,7 +490,10 @@ __global__ __launch_bounds__(256) void conv2d_wide_split_kernel(const float* __r
   const float* xb = x + (int64_t)wide_input_sample(g, n, set) * CIN * plane_i;
 
   constexpr int NP = KS * KS * S::KB;                  // 16-deep reduction blocks of the tile
-  constexpr int D = 2;                                 // blocks of B (three pieces each) in flight per lane
+  // blocks of B (three 16-byte pieces each) in flight per lane: a K block is 6 MFMAs = 192 cycles of matrix work, an L2
+  // round trip several hundred -- four blocks ahead (12 registers of 16 bytes) cover it where the f32 kernel's six
+  // pieces cover 1 536 cycles
+  constexpr int D = 4;
   const u32x4* bg = reinterpret_cast<const u32x4*>(wp + set * g.w_stride) + (h * COUT + wn * 32 + m);
   u32x4 bq[D][3];
 #pragma unroll

@@ -21,11 +21,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 class FakeEvent(object):
+    """Launches run to completion before they return here, so an event is the wall clock at ``record()``."""
+
     def __init__(self, *a, **kw):
-        pass
+        self.t = 0.0
 
     def record(self, stream=None):
-        pass
+        import time
+        self.t = time.perf_counter()
 
     def synchronize(self):
         pass
@@ -37,7 +40,7 @@ class FakeEvent(object):
         return True
 
     def elapsed_time(self, other):
-        return 0.0
+        return (other.t - self.t) * 1e3
 
 
 class FakeStream(object):
@@ -64,6 +67,21 @@ class FakeStream(object):
 
     def __hash__(self):
         return 1
+
+
+class FakeGraph(object):
+    """torch.cuda.CUDAGraph for dry runs: the "capture" executes its body once, eagerly; ``replay()`` does NOTHING (the
+    outputs stay what the capture computed).  Enough to walk code that builds and replays graphs -- bench.py's training
+    child -- not to test what a replay computes (the graph tests stay on the hardware)."""
+
+    def __init__(self, *a, **kw):
+        pass
+
+    def replay(self):
+        pass
+
+    def raw_cuda_graph(self):
+        raise RuntimeError("tests/hipemu has no hipGraphs")
 
 
 _STREAM = FakeStream()
@@ -95,6 +113,8 @@ def emulated_gpu():
     patch(torch.cuda, "Event", FakeEvent)
     patch(torch.cuda, "synchronize", lambda device=None: None)
     patch(torch.cuda, "current_device", lambda: "cpu")
+    patch(torch.cuda, "CUDAGraph", FakeGraph)
+    patch(torch.cuda, "graph", null)
     patch(torch.Tensor, "is_cuda", property(lambda self: True))
     patch(torch.Tensor, "record_stream", lambda self, stream: None)
     # host == device here, so ``x.to(dev)`` would ALIAS x where on a GPU it copies: in-place kernels would then overwrite the

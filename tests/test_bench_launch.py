@@ -103,3 +103,27 @@ def test_train_block_keeps_what_a_killed_child_had_published(monkeypatch):
     monkeypatch.setattr(subprocess, "run", fake_run)
     out = bench.train_block_in_child(argparse.Namespace(train_steps=2, train_timeout=1.0, no_experiments=False), 0, 1)
     assert out["value"] == 2.0 and "killed" in out["child_note"] and out["child_wall_s"] >= 0.0
+
+
+def test_bench_line_assembles_on_the_emulator():
+    """bench.py end to end WITHOUT a GPU (PF_EMULATE=1: tests/hipemu behind the C ABI; eager, one lane, "tiny"): scenes,
+    model, the HIP-event calibration clock per entry point and per template instantiation, the timed loop and the assembly
+    of the ONE JSON line all execute -- the numbers are the emulator's speed and mean nothing, the contract fields and the
+    round-5 keys must be there.  (A Python error in that assembly would cost the driver's headline line.)"""
+    if torch.cuda.is_available():
+        pytest.skip("the emulator is for machines without a GPU")
+    p = subprocess.run([sys.executable, BENCH, "--config", "tiny", "--steps", "1", "--warmup", "1", "--scenes-per-step", "1",
+                        "--calibration-steps", "1"], env=_env(PF_EMULATE="1"), capture_output=True, text=True, timeout=1800)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = _last_json(p.stdout)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "kernels", "train", "cpu_baseline"):
+        assert key in out, key
+    assert out["value"] > 0 and out["steps"] == 1 and out["dtype"] == "f32" and out["config"]["workload"].startswith("tiny")
+    roof = out["roofline"]
+    assert roof["kernel"].startswith("pf_conv2d_wide") and roof["bound"] in ("mfma", "hbm") and 0.0 < roof["frac"] < 1.0
+    assert roof["traffic_source"] is None or "not measured in this run" in roof["traffic_source"]
+    inst = roof["instantiations"]
+    assert inst and {"layer", "launches", "avg_launch_us", "frac_of_f32_mfma_peak"} <= set(inst[0])
+    assert any(r["layer"] == "64->64 3x3/1" for r in inst)
+    assert roof["under_load"] is None or roof["under_load"]["worst"]["frac_mfma_peak"] < roof["under_load"]["best"]["frac_mfma_peak"]

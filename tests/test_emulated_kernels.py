@@ -147,3 +147,31 @@ def test_split_kernel_resolves_a_pending_batchnorm_and_serves_two_towers(emu):
     got0 = y2[0].view(n, hw[0], hw[1], cout).permute(0, 3, 1, 2)                                # set 0: channel-last
     got1 = y2[1].view(n, cout, hw[0], hw[1])
     assert torch.equal(got0, outs[0][0]) and torch.equal(got1, outs[1][0])                       # bit-identical per set
+
+
+def test_whole_forward_executes_on_the_emulator_and_matches_the_reference_golden():
+    """PointMVSNet.forward(isFlow=True, isTest=True) on "tiny" -- both towers, the coarse warp, VolumeConv, soft argmin, two
+    PointFlow iterations (feature assembly, lattice kNN, EdgeConv x3, MLP, head; the second one on 4 sub-grids): ~150
+    launches of ~40 different kernels, every one of them EXECUTED from its unchanged source on the host -- against the depth
+    maps the reference itself produced (tests/golden/model_tiny_test.npz), with the bounds of the GPU test
+    (tests/test_gpu_model.py::_compare: coarse depth 1e-5 in the max norm, refined maps inside the reference's measured
+    self-sensitivity).  What the driver's `pytest -m gpu` shows on an MI355X, shown here without one."""
+    sys.path.insert(0, os.path.join(HERE, "hipemu"))
+    from on_cpu import emulated_gpu
+    from conftest import load_golden
+    import test_gpu_model as TM
+    from pointmvsnet_amd import synthetic
+    from pointmvsnet_amd.model import PointMVSNet
+    g = load_golden("model_tiny_test")
+    data, img_scales, inter_scales = synthetic.make_config("tiny")
+    net = PointMVSNet()
+    synthetic.seed_weights(net, seed=0)
+    net.train()                                              # the reference evaluates in train() mode (test.py:58)
+    batch = dict(data)
+    batch["cam_params_list_host"] = data["cam_params_list"]
+    batch["mean_host"], batch["std_host"] = data["mean"], data["std"]
+    with emulated_gpu(), torch.no_grad():
+        preds = net(batch, img_scales, inter_scales, isFlow=True, isTest=True)
+        status = _lib.status()
+    worst, err_wp = TM._compare(preds, g, "emulated_model_tiny_test", "tiny")
+    assert worst < TM.DEPTH_RTOL and err_wp < 1e-3 and status == 0

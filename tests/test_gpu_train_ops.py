@@ -155,10 +155,23 @@ def _grads(params):
     return [p.grad.detach().clone() for p in params]
 
 
-def test_image_tower_node_vs_float64_autograd(dev, size=(64, 96)):
+def _oracle32_yardstick(fn, leaves64):
+    """Worst per-tensor deviation (max |diff| / max |ref|) of a FLOAT32 evaluation of the reference's own composition (the
+    oracle's functional restatement on plain ATen operators, same device) from the float64 gradients ``leaves64``:
+    ``fn(dtype)`` evaluates it in ``dtype`` and returns the gradient list in the same order.  What a correct float32
+    implementation deviates by at this size -- ReLU masks of pre-activations within rounding of zero and eleven BatchNorm
+    layers amplify float32 rounding with the number of positions, so an absolute gate that holds on (64, 96) maps cannot
+    hold on (512, 640) ones (measured on the emulator: 5.5e-3 on conv2.0's weight, the oracle itself 1.4e-2 on the
+    whole step, profiles/r05_oracle_cfg4_yardstick.md)."""
+    g32 = fn(torch.float32)
+    return max(_rel(a, b) for a, b in zip(g32, leaves64))
+
+
+def test_image_tower_node_vs_float64_autograd(dev, size=(64, 96), yardstick=False):
     """The whole ImageConv tower (eleven layers, per-view BatchNorm statistics) as ONE autograd node against the ATen
     composition in float64: the three stage outputs, every parameter gradient, the running statistics.
-    (tests/test_gpu_zz_train_cfg4.py calls this at (512, 640), the size of BASELINE configs[3].)"""
+    (tests/test_gpu_zz_train_cfg4.py calls this at (512, 640), the size of BASELINE configs[3], with ``yardstick``: the
+    gradient gate is then tied to what the oracle's own float32 evaluation deviates by.)"""
     tower = networks.ImageConv(8)
     synthetic.seed_weights(tower, seed=3)
     tower = tower.to(dev).train()
@@ -185,8 +198,23 @@ def test_image_tower_node_vs_float64_autograd(dev, size=(64, 96)):
         worst = max(worst, e)
         assert e < 2e-5, (n, e)
     errs = sorted(((_rel(a, p.grad), k) for a, (k, p) in zip(mine, ref.named_parameters())), reverse=True)
-    report("tower_node" if tuple(size) == (64, 96) else "tower_node_%dx%d" % tuple(size), out_rel=worst, worst_grad_rel=errs[0][0], median_grad_rel=errs[len(errs) // 2][0])
-    assert errs[0][0] < 2e-4, errs[:5]
+    gate, yard = 2e-4, 0.0
+    if yardstick:
+        from oracle import pointflow_oracle as O
+        sd = {"t." + k: v.detach() for k, v in tower.state_dict().items()}
+        pnames = [k for k, _ in tower.named_parameters()]
+
+        def oracle_grads(dtype):
+            leaves = {k: (v.to(dtype).clone().requires_grad_(True) if k[2:] in pnames else v.clone()) for k, v in sd.items()}
+            outs = [O.image_conv(img[v:v + 1].to(dtype), leaves, "t") for v in range(3)]
+            sum((torch.cat([outs[v][n] for v in range(3)]) * gs[n].to(dtype)).sum() for n in names).backward()
+            return [leaves["t." + k].grad for k in pnames]
+
+        yard = _oracle32_yardstick(oracle_grads, [p.grad for p in ref.parameters()])
+        gate = max(gate, 3.0 * yard)
+    report("tower_node" if tuple(size) == (64, 96) else "tower_node_%dx%d" % tuple(size), out_rel=worst, worst_grad_rel=errs[0][0],
+           median_grad_rel=errs[len(errs) // 2][0], oracle32_worst_grad_rel=yard)
+    assert errs[0][0] < gate, (errs[:5], yard)
     for (k, a), (_, b) in zip(tower.named_buffers(), ref.named_buffers()):
         if "num_batches" in k:
             assert int(a) == 2 * int(b) == 6, k                          # two forwards of three views here
@@ -197,9 +225,10 @@ def test_image_tower_node_vs_float64_autograd(dev, size=(64, 96)):
     assert all(p.grad is not None for p in tower.parameters())
 
 
-def test_volume_conv_node_vs_float64_autograd(dev, size=(16, 32, 40)):
+def test_volume_conv_node_vs_float64_autograd(dev, size=(16, 32, 40), yardstick=False):
     """VolumeConv as ONE autograd node against the float64 ATen module (tests/test_gpu_zz_train_cfg4.py calls this at
-    (48, 64, 80), the size of BASELINE configs[3])."""
+    (48, 64, 80), the size of BASELINE configs[3], with ``yardstick``: the gradient gates are then tied to what the
+    oracle's own float32 evaluation deviates by, see _oracle32_yardstick)."""
     vc = networks.VolumeConv(64, 8)
     synthetic.seed_weights(vc, seed=4)
     vc = vc.to(dev).train()
@@ -223,9 +252,26 @@ def test_volume_conv_node_vs_float64_autograd(dev, size=(16, 32, 40)):
     (rout * g.double()).sum().backward()
     errs = sorted(((_rel(a, p.grad), k) for a, (k, p) in zip(mine, ref.named_parameters())), reverse=True)
     e_out, e_x = _rel(out, rout), _rel(gx, cd.grad)
-    report("volume_node" if tuple(size) == (16, 32, 40) else "volume_node_%dx%dx%d" % tuple(size), out_rel=e_out, dcost_rel=e_x, worst_grad_rel=errs[0][0], median_grad_rel=errs[len(errs) // 2][0])
-    assert e_out < 2e-5 and e_x < 1e-4, (e_out, e_x)
-    assert errs[0][0] < 2e-4, errs[:5]
+    gate_x, gate_w, yard = 1e-4, 2e-4, (0.0, 0.0)
+    if yardstick:
+        from oracle import pointflow_oracle as O
+        sd = {"v." + k: v.detach() for k, v in vc.state_dict().items()}
+        pnames = [k for k, _ in vc.named_parameters()]
+
+        def oracle_grads(dtype):
+            leaves = {k: (v.to(dtype).clone().requires_grad_(True) if k[2:] in pnames else v.clone()) for k, v in sd.items()}
+            c = cost.detach().to(dtype).requires_grad_(True)
+            (O.volume_conv(c, leaves, "v") * g.to(dtype)).sum().backward()
+            return [c.grad] + [leaves["v." + k].grad for k in pnames]
+
+        g32 = oracle_grads(torch.float32)
+        yard = (_rel(g32[0], cd.grad), max(_rel(a, p.grad) for a, p in zip(g32[1:], ref.parameters())))
+        gate_x, gate_w = max(gate_x, 3.0 * yard[0]), max(gate_w, 3.0 * yard[1])
+    report("volume_node" if tuple(size) == (16, 32, 40) else "volume_node_%dx%dx%d" % tuple(size), out_rel=e_out, dcost_rel=e_x,
+           worst_grad_rel=errs[0][0], median_grad_rel=errs[len(errs) // 2][0], oracle32_dcost_rel=yard[0],
+           oracle32_worst_grad_rel=yard[1])
+    assert e_out < 2e-5 and e_x < gate_x, (e_out, e_x, yard)
+    assert errs[0][0] < gate_w, (errs[:5], yard)
 
 
 def test_edge_chain_and_mlp_nodes_vs_composed_operators(dev):

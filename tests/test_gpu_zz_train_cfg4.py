@@ -310,16 +310,18 @@ def test_rows_bn_relu_backward_at_cfg4_points(dev, P, C):
 
 
 def test_image_tower_node_at_cfg4_size_vs_float64(dev):
-    """The tower node on the three 512x640 views of a cfg-4 scene against the float64 ATen modules (same gates as at
-    (64, 96): tests/test_gpu_train_ops.py)."""
+    """The tower node on the three 512x640 views of a cfg-4 scene against the float64 ATen modules: outputs at 2e-5,
+    parameter gradients within max(2e-4, 3 x what the ORACLE's float32 evaluation of the same tower deviates by from float64
+    on the same inputs) -- at this size a float32 backward through eleven BatchNorm + ReLU layers is 1e-3 .. 1e-2 from float64
+    per tensor whoever computes it (tests/test_gpu_train_ops.py::_oracle32_yardstick)."""
     import test_gpu_train_ops as T
-    T.test_image_tower_node_vs_float64_autograd(dev, (H, W))
+    T.test_image_tower_node_vs_float64_autograd(dev, (H, W), yardstick=True)
 
 
 def test_volume_conv_node_at_cfg4_size_vs_float64(dev):
     """The VolumeConv node on a (1, 64, 48, 64, 80) cost volume against the float64 ATen module."""
     import test_gpu_train_ops as T
-    T.test_volume_conv_node_vs_float64_autograd(dev, (D, H // 8, W // 8))
+    T.test_volume_conv_node_vs_float64_autograd(dev, (D, H // 8, W // 8), yardstick=True)
 
 
 def test_train_step_gradient_is_bit_reproducible_at_cfg4(dev):
