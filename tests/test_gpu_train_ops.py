@@ -167,6 +167,29 @@ def _oracle32_yardstick(fn, leaves64):
     return max(_rel(a, b) for a, b in zip(g32, leaves64))
 
 
+AMBIGUOUS = 2e-5            # |pre-activation| below this: its ReLU mask is undetermined at float32 resolution
+
+
+def _count_ambiguous_relu_inputs(ref):
+    """Forward hooks on the BatchNorm layers of the float64 reference module: how many ReLU inputs lie within AMBIGUOUS of
+    zero.  There a float32 and a float64 evaluation legitimately disagree about the mask, and ONE such flip moves the
+    gradient entry at that position by its whole incoming gradient (measured on the emulator, VolumeConv at 48x64x80: one
+    flip of 491 520 inputs of conv1_1 -- float64 pre-activation 8.8e-7 -- made dL/dy there -0.0088 instead of -0.52, 8e-2 of
+    the largest entry, and everything upstream of it inherits a localized 5e-3: profiles/r05_emulator_runs.md).  With ~2e7
+    ReLU inputs in a cfg-4 step a handful of them is always that close to zero; on (64, 96) maps usually none is."""
+    box = {"n": 0}
+
+    def hook(_m, _inp, out):
+        box["n"] += int((out.detach().abs() < AMBIGUOUS).sum())
+
+    handles = [m.register_forward_hook(hook) for m in ref.modules()
+               if isinstance(m, (torch.nn.BatchNorm2d, torch.nn.BatchNorm3d))]
+    return box, handles
+
+
+FLIP_GATE = 1e-1            # what flipped ReLU masks may move a gradient tensor by, relative to its largest entry
+
+
 def test_image_tower_node_vs_float64_autograd(dev, size=(64, 96), yardstick=False):
     """The whole ImageConv tower (eleven layers, per-view BatchNorm statistics) as ONE autograd node against the ATen
     composition in float64: the three stage outputs, every parameter gradient, the running statistics.
@@ -190,7 +213,10 @@ def test_image_tower_node_vs_float64_autograd(dev, size=(64, 96), yardstick=Fals
     sum((out_b[n] * gs[n]).sum() for n in names).backward()
     for a, b in zip(mine, _grads(tower.parameters())):
         assert torch.equal(a, b)                                        # bit-reproducible
+    amb, handles = _count_ambiguous_relu_inputs(ref)
     views = [ref(img[v:v + 1].double()) for v in range(3)]              # one call per view: per-view statistics
+    for h_ in handles:
+        h_.remove()
     sum((torch.cat([views[v][n] for v in range(3)]) * gs[n].double()).sum() for n in names).backward()
     worst = 0.0
     for n in names:
@@ -211,10 +237,10 @@ def test_image_tower_node_vs_float64_autograd(dev, size=(64, 96), yardstick=Fals
             return [leaves["t." + k].grad for k in pnames]
 
         yard = _oracle32_yardstick(oracle_grads, [p.grad for p in ref.parameters()])
-        gate = max(gate, 3.0 * yard)
+        gate = max(gate, 3.0 * yard, FLIP_GATE if amb["n"] else 0.0)
     report("tower_node" if tuple(size) == (64, 96) else "tower_node_%dx%d" % tuple(size), out_rel=worst, worst_grad_rel=errs[0][0],
-           median_grad_rel=errs[len(errs) // 2][0], oracle32_worst_grad_rel=yard)
-    assert errs[0][0] < gate, (errs[:5], yard)
+           median_grad_rel=errs[len(errs) // 2][0], oracle32_worst_grad_rel=yard, ambiguous_relu_inputs=amb["n"])
+    assert errs[0][0] < gate, (errs[:5], yard, amb)
     for (k, a), (_, b) in zip(tower.named_buffers(), ref.named_buffers()):
         if "num_batches" in k:
             assert int(a) == 2 * int(b) == 6, k                          # two forwards of three views here
@@ -248,10 +274,15 @@ def test_volume_conv_node_vs_float64_autograd(dev, size=(16, 32, 40), yardstick=
     for a, b in zip(mine, _grads(vc.parameters())):
         assert torch.equal(a, b)
     cd = cost.detach().double().requires_grad_(True)
+    amb, handles = _count_ambiguous_relu_inputs(ref)
     rout = ref(cd)
+    for h_ in handles:
+        h_.remove()
     (rout * g.double()).sum().backward()
     errs = sorted(((_rel(a, p.grad), k) for a, (k, p) in zip(mine, ref.named_parameters())), reverse=True)
     e_out, e_x = _rel(out, rout), _rel(gx, cd.grad)
+    # how much of d(cost) deviates at all: a flipped mask is a LOCAL event (its receptive field), a wrong kernel is not
+    frac_x = float(((gx.double() - cd.grad).abs() > 1e-4 * cd.grad.abs().max()).float().mean())
     gate_x, gate_w, yard = 1e-4, 2e-4, (0.0, 0.0)
     if yardstick:
         from oracle import pointflow_oracle as O
@@ -266,12 +297,13 @@ def test_volume_conv_node_vs_float64_autograd(dev, size=(16, 32, 40), yardstick=
 
         g32 = oracle_grads(torch.float32)
         yard = (_rel(g32[0], cd.grad), max(_rel(a, p.grad) for a, p in zip(g32[1:], ref.parameters())))
-        gate_x, gate_w = max(gate_x, 3.0 * yard[0]), max(gate_w, 3.0 * yard[1])
+        flip = FLIP_GATE if amb["n"] else 0.0
+        gate_x, gate_w = max(gate_x, 3.0 * yard[0], flip), max(gate_w, 3.0 * yard[1], flip)
     report("volume_node" if tuple(size) == (16, 32, 40) else "volume_node_%dx%dx%d" % tuple(size), out_rel=e_out, dcost_rel=e_x,
            worst_grad_rel=errs[0][0], median_grad_rel=errs[len(errs) // 2][0], oracle32_dcost_rel=yard[0],
-           oracle32_worst_grad_rel=yard[1])
-    assert e_out < 2e-5 and e_x < gate_x, (e_out, e_x, yard)
-    assert errs[0][0] < gate_w, (errs[:5], yard)
+           oracle32_worst_grad_rel=yard[1], ambiguous_relu_inputs=amb["n"], dcost_frac_beyond_1e4=frac_x)
+    assert e_out < 2e-5 and e_x < gate_x and frac_x < 1e-2, (e_out, e_x, frac_x, yard, amb)
+    assert errs[0][0] < gate_w and errs[len(errs) // 2][0] < 2e-5, (errs[:5], errs[len(errs) // 2], yard, amb)
 
 
 def test_edge_chain_and_mlp_nodes_vs_composed_operators(dev):
