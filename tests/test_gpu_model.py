@@ -488,6 +488,17 @@ def test_train_step_parameter_gradients_vs_oracle_autograd(dev, monkeypatch, cfg
            worst_grad_rel_vs_f64=errs_gpu64[0][0], oracle32_worst_grad_rel_vs_f64=errs_ref64[0][0],
            loss_rel_vs_f64=rel_loss64)
     assert rel_loss < 1e-5 and rel_loss64 < 1e-5
+    if cfg != "tiny":
+        # At config 4's size (~2e7 ReLU inputs per step) BOTH float32 evaluations draw a handful of ReLU-mask flips at
+        # pre-activations within rounding of zero -- a lottery per implementation and per host, each flip worth up to 1e-1
+        # of one tensor and ~1e-3 of the whole gradient (bisected on tests/hipemu, profiles/r05_emulator_runs.md: the
+        # oracle's float32 run 1.6e-3 / 1.4e-2 from its float64 run, ours 2.4e-3 / 1.4e-2).  So: three times the oracle's
+        # own deviation, with floors at the size of a few flips; a wrong kernel is O(1) on its tensors.
+        assert l2_gpu64 < max(3.0 * l2_ref64, 5e-3), (l2_gpu64, l2_ref64)
+        assert errs_gpu64[0][0] < max(3.0 * errs_ref64[0][0], 1e-1), (errs_gpu64[:3], errs_ref64[:3])
+        assert l2 < max(3.0 * l2_ref64, 5e-3), (l2, l2_ref64)
+        assert errs[len(errs) // 2][0] < 1e-2 and errs_gpu64[len(errs_gpu64) // 2][0] < 1e-2, (errs[len(errs) // 2], errs_gpu64[len(errs_gpu64) // 2])
+        return
     # (the oracle's float32 deviation depends on the host's reduction order: 2.7e-4 .. 3.9e-4 on the boxes seen)
     if fused:
         assert l2_gpu64 < max(1.5 * l2_ref64, 4.5e-4), (l2_gpu64, l2_ref64)
