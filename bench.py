@@ -585,7 +585,8 @@ def experiments_block(dev, out, publish):
             rates.setdefault("bf16x3" if split else "f32", []).append(n_timed / (time.perf_counter() - t0))
             del laned, net
         exp["bf16x3_headline_ab"] = {"depth_maps_per_s": rates, "workload": WORKLOAD_TEXT[infer_cfg],
-                                      "arms": "f32, bf16x3, f32, bf16x3 (512 scenes each, 4 lanes, graph replay)",
+                                      "arms": "f32, bf16x3%s (%d scenes each, %d lane(s), graph replay)"
+                                              % ("" if dry else ", f32, bf16x3", n_timed, 1 if dry else 4),
                                       "ratio": (sum(rates["bf16x3"]) / len(rates["bf16x3"]))
                                                / (sum(rates["f32"]) / len(rates["f32"]))}
     except Exception as exc:

@@ -126,12 +126,13 @@ def test_split_kernel_resolves_a_pending_batchnorm_and_serves_two_towers(emu):
         seg = xd[:, :, cuts[t]:cuts[t + 1]]
         partials[:, t, :, 0], partials[:, t, :, 1] = seg.sum(-1), (seg * seg).sum(-1)
     count = float(xd.shape[2])
-    outs = []
+    outs, lazies = [], []
     for s in range(2):
         sl = slice(s * n, (s + 1) * n)
         scale, shift = torch.empty((n, cin)), torch.empty((n, cin))
         job = pointflow.bn_job(bns[s], partials[sl].contiguous(), 0, cin, count, count, n, 1, scale, shift)
-        lazy = pointflow.LazyAffine(job, (partials, scale, shift), scale, shift)
+        lazy = pointflow.LazyAffine(job, (partials, scale, shift) + pointflow._bn_tensors(bns[s]), scale, shift)
+        lazies.append(lazy)
         y_lazy, _ = pointflow.conv2d_wide(x[sl].contiguous(), convs[s], lazy, 1, True)       # AFFINE = 2 in the kernel
         mean = xd[sl].mean(-1)
         var = (xd[sl] * xd[sl]).mean(-1) - mean * mean
@@ -147,6 +148,8 @@ def test_split_kernel_resolves_a_pending_batchnorm_and_serves_two_towers(emu):
     got0 = y2[0].view(n, hw[0], hw[1], cout).permute(0, 3, 1, 2)                                # set 0: channel-last
     got1 = y2[1].view(n, cout, hw[0], hw[1])
     assert torch.equal(got0, outs[0][0]) and torch.equal(got1, outs[1][0])                       # bit-identical per set
+    for lazy in lazies:                 # (consumer-resolved jobs are queued for their running-statistics update: run them
+        lazy.rows()                     # now, so that no later flush finds jobs whose modules are gone)
 
 
 def test_whole_forward_executes_on_the_emulator_and_matches_the_reference_golden():
