@@ -35,6 +35,8 @@ import statistics
 import sys
 import time
 
+PROCESS_T0 = time.perf_counter()          # (the child's experiment budget counts from here: imports included)
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -473,7 +475,8 @@ def experiments_block(dev, out, publish):
                 and the largest error against a float64 convolution beside the exact-f32 kernel's, per layer; then the
                 headline workload (cfg 2, four lanes, graph replay) with it switched off and on, same box, same process.
     Neither had run on hardware when this was written (the round lost its GPU access); the numbers in the line are the
-    first measurement."""
+    first measurement.  Also here, because they need no place in the headline's process: ``pcie_inclusive`` (the headline
+    workload with the images starting in pinned host memory; never `value`) and the training step's ``cpu_baseline``."""
     import torch.nn.functional as F
     from pointmvsnet_amd import pointflow, train_ops
     from pointmvsnet_amd.train_step import GraphedTrainStep, TrainStep
@@ -506,18 +509,6 @@ def experiments_block(dev, out, publish):
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / 20 * 1e3, float(loss), grad
 
-    try:
-        ms0, l0, g0 = timed_train(0)
-        ms1, l1, g1 = timed_train(1)
-        exp["lazy_bn"] = {"ms_per_step_default": ms0, "ms_per_step_lazy": ms1, "speedup": ms0 / ms1,
-                          "first_step_loss_rel_diff": abs(l1 - l0) / max(abs(l0), 1e-30),
-                          "first_step_grad_rel_l2_diff": float((g1 - g0).norm() / g0.norm())}
-    except Exception as exc:
-        exp["lazy_bn"] = {"error": repr(exc)}
-    finally:
-        train_ops.TRAIN_LAZY_BN = 0
-    publish(out)
-
     def timeit(fn, reps=50):
         if dry:
             reps = 1
@@ -532,114 +523,142 @@ def experiments_block(dev, out, publish):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1000 / reps
 
-    try:
-        rows = []
-        torch.manual_seed(0)
-        for name, cin, cout, h, w, ks, stride in (("16->32 5x5/2", 16, 32, 256, 320, 5, 2), ("32->32 3x3", 32, 32, 128, 160, 3, 1),
-                                                  ("32->64 5x5/2", 32, 64, 128, 160, 5, 2), ("64->64 3x3", 64, 64, 64, 80, 3, 1)):
-            if dry:
-                h, w = h // 8, w // 8
-            conv = torch.nn.Conv2d(cin, cout, ks, stride=stride, padding=ks // 2, bias=False).to(dev)
-            x = torch.randn(6, cin, h, w, device=dev)                      # both towers' samples of a cfg-2 scene
-            sc = torch.rand(6, cin, device=dev) + 0.5
-            sh = torch.randn(6, cin, device=dev) * 0.1
-            ref = F.conv2d(F.relu(x * sc.view(6, cin, 1, 1) + sh.view(6, cin, 1, 1)).double(), conv.weight.double(), None,
-                           stride, ks // 2)
-            row = {"layer": name, "flops": 2.0 * ref.numel() * ks * ks * cin}
-            for split in (0, 1):
-                pointflow.MATRIX_SPLIT = split
-                y, _ = pointflow.conv2d_wide(x, conv, (sc, sh), 1, True)
-                tag = "bf16x3" if split else "f32"
-                row[tag + "_max_err_vs_f64"] = float((y.double() - ref).abs().max() / ref.abs().max())
-                row[tag + "_us"] = timeit(lambda: pointflow.conv2d_wide(x, conv, (sc, sh), 1, True))
-            row["speedup"] = row["f32_us"] / row["bf16x3_us"]
-            rows.append(row)
-        exp["bf16x3_layers"] = rows
-    except Exception as exc:
-        exp["bf16x3_layers"] = {"error": repr(exc)}
-    finally:
-        pointflow.MATRIX_SPLIT = 0
-    publish(out)
+    def part_lazy_bn():
+        try:
+            ms0, l0, g0 = timed_train(0)
+            ms1, l1, g1 = timed_train(1)
+            exp["lazy_bn"] = {"ms_per_step_default": ms0, "ms_per_step_lazy": ms1, "speedup": ms0 / ms1,
+                              "first_step_loss_rel_diff": abs(l1 - l0) / max(abs(l0), 1e-30),
+                              "first_step_grad_rel_l2_diff": float((g1 - g0).norm() / g0.norm())}
+        except Exception as exc:
+            exp["lazy_bn"] = {"error": repr(exc)}
+        finally:
+            train_ops.TRAIN_LAZY_BN = 0
 
-    try:                                       # the headline workload with the switch off and on: same box, same process
-        from pointmvsnet_amd.graph import LanedForward
-        h, w, V, D, _, img_scales, inter_scales = synthetic.CONFIGS[infer_cfg]
-        scenes = [to_device(synthetic.make_config(infer_cfg, seed=i)[0], dev) for i in range(4)]
-        rates = {}
-        n_warm, n_timed = (1, 1) if dry else (64, 512)
-        for split in ((0, 1) if dry else (0, 1, 0, 1)):
-            pointflow.MATRIX_SPLIT = split
+    def part_pcie_inclusive():
+
+        try:          # the headline workload with every scene's images starting in PINNED HOST memory (never `value`)
+            from pointmvsnet_amd.graph import LanedForward
+            h, w, V, D, _, img_scales, inter_scales = synthetic.CONFIGS[infer_cfg]
+            scenes = [to_device(synthetic.make_config(infer_cfg, seed=i)[0], dev) for i in range(4)]
+            hosted = []
+            for b in scenes:
+                hb = dict(b)
+                hb["img_list"] = b["img_list"].cpu() if dry else b["img_list"].cpu().pin_memory()   # 11.8 MB per cfg-2 scene
+                hosted.append(hb)
             net = PointMVSNet()
             synthetic.seed_weights(net, seed=0)
             net = net.to(dev).train()
+            rates = {}
             with torch.no_grad():
                 laned = LanedForward(net, scenes[0], img_scales, inter_scales, isFlow=True, isTest=True,
                                      lanes=1 if dry else 4, warmup=1 if dry else 3)
-                for i in range(n_warm):
-                    laned.submit(scenes[i % 4])
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for i in range(n_timed):
-                    laned.submit(scenes[i % 4])
-                torch.cuda.synchronize()
-            rates.setdefault("bf16x3" if split else "f32", []).append(n_timed / (time.perf_counter() - t0))
+                n_warm, n_timed = (1, 1) if dry else (32, 384)
+                for tag, batches in (("resident", scenes), ("pinned_host", hosted), ("resident", scenes), ("pinned_host", hosted)):
+                    for i in range(n_warm):
+                        laned.submit(batches[i % 4])
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for i in range(n_timed):
+                        laned.submit(batches[i % 4])
+                    torch.cuda.synchronize()
+                    rates.setdefault(tag, []).append(n_timed / (time.perf_counter() - t0))
+            exp["pcie_inclusive"] = {"depth_maps_per_s": rates, "bytes_per_scene_host_to_device": int(hosted[0]["img_list"].numel() * 4),
+                                     "note": "images in pinned host memory, one asynchronous H2D per scene on the lane's stream "
+                                             "before its graph replay; the cameras are host-side already (one 2 KB H2D per scene "
+                                             "in both arms)"}
             del laned, net
-        exp["bf16x3_headline_ab"] = {"depth_maps_per_s": rates, "workload": WORKLOAD_TEXT[infer_cfg],
-                                      "arms": "f32, bf16x3%s (%d scenes each, %d lane(s), graph replay)"
-                                              % ("" if dry else ", f32, bf16x3", n_timed, 1 if dry else 4),
-                                      "ratio": (sum(rates["bf16x3"]) / len(rates["bf16x3"]))
-                                               / (sum(rates["f32"]) / len(rates["f32"]))}
-    except Exception as exc:
-        exp["bf16x3_headline_ab"] = {"error": repr(exc)}
-    finally:
-        pointflow.MATRIX_SPLIT = 0
-    publish(out)
+        except Exception as exc:
+            exp["pcie_inclusive"] = {"error": repr(exc)}
 
-    try:          # the headline workload with every scene's images starting in PINNED HOST memory (never `value`)
-        from pointmvsnet_amd.graph import LanedForward
-        h, w, V, D, _, img_scales, inter_scales = synthetic.CONFIGS[infer_cfg]
-        scenes = [to_device(synthetic.make_config(infer_cfg, seed=i)[0], dev) for i in range(4)]
-        hosted = []
-        for b in scenes:
-            hb = dict(b)
-            hb["img_list"] = b["img_list"].cpu() if dry else b["img_list"].cpu().pin_memory()   # 11.8 MB per cfg-2 scene
-            hosted.append(hb)
-        net = PointMVSNet()
-        synthetic.seed_weights(net, seed=0)
-        net = net.to(dev).train()
-        rates = {}
-        with torch.no_grad():
-            laned = LanedForward(net, scenes[0], img_scales, inter_scales, isFlow=True, isTest=True,
-                                 lanes=1 if dry else 4, warmup=1 if dry else 3)
-            n_warm, n_timed = (1, 1) if dry else (32, 384)
-            for tag, batches in (("resident", scenes), ("pinned_host", hosted), ("resident", scenes), ("pinned_host", hosted)):
-                for i in range(n_warm):
-                    laned.submit(batches[i % 4])
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for i in range(n_timed):
-                    laned.submit(batches[i % 4])
-                torch.cuda.synchronize()
-                rates.setdefault(tag, []).append(n_timed / (time.perf_counter() - t0))
-        exp["pcie_inclusive"] = {"depth_maps_per_s": rates, "bytes_per_scene_host_to_device": int(hosted[0]["img_list"].numel() * 4),
-                                 "note": "images in pinned host memory, one asynchronous H2D per scene on the lane's stream "
-                                         "before its graph replay; the cameras are host-side already (one 2 KB H2D per scene "
-                                         "in both arms)"}
-        del laned, net
-    except Exception as exc:
-        exp["pcie_inclusive"] = {"error": repr(exc)}
-    publish(out)
+    def part_cpu_baseline():
 
-    try:          # the training step's CPU baseline: ONE oracle step (forward + loss + backward) on this host's cores
-        net = PointMVSNet()
-        synthetic.seed_weights(net, seed=0)
-        data_cpu, img_scales, inter_scales = synthetic.make_config(train_cfg, seed=0, train_intrinsics=True)
-        out["cpu_baseline"] = cpu_baseline(net, data_cpu, img_scales, inter_scales, 1, WORKLOAD_TEXT[train_cfg], train=True)
-        out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
-    except Exception as exc:
-        out["cpu_baseline"] = {"error": repr(exc)}
-    publish(out)
+        try:          # the training step's CPU baseline: ONE oracle step (forward + loss + backward) on this host's cores
+            net = PointMVSNet()
+            synthetic.seed_weights(net, seed=0)
+            data_cpu, img_scales, inter_scales = synthetic.make_config(train_cfg, seed=0, train_intrinsics=True)
+            out["cpu_baseline"] = cpu_baseline(net, data_cpu, img_scales, inter_scales, 1, WORKLOAD_TEXT[train_cfg], train=True)
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        except Exception as exc:
+            out["cpu_baseline"] = {"error": repr(exc)}
 
+    def part_bf16x3_layers():
+
+        try:
+            rows = []
+            torch.manual_seed(0)
+            for name, cin, cout, h, w, ks, stride in (("16->32 5x5/2", 16, 32, 256, 320, 5, 2), ("32->32 3x3", 32, 32, 128, 160, 3, 1),
+                                                      ("32->64 5x5/2", 32, 64, 128, 160, 5, 2), ("64->64 3x3", 64, 64, 64, 80, 3, 1)):
+                if dry:
+                    h, w = h // 8, w // 8
+                conv = torch.nn.Conv2d(cin, cout, ks, stride=stride, padding=ks // 2, bias=False).to(dev)
+                x = torch.randn(6, cin, h, w, device=dev)                      # both towers' samples of a cfg-2 scene
+                sc = torch.rand(6, cin, device=dev) + 0.5
+                sh = torch.randn(6, cin, device=dev) * 0.1
+                ref = F.conv2d(F.relu(x * sc.view(6, cin, 1, 1) + sh.view(6, cin, 1, 1)).double(), conv.weight.double(), None,
+                               stride, ks // 2)
+                row = {"layer": name, "flops": 2.0 * ref.numel() * ks * ks * cin}
+                for split in (0, 1):
+                    pointflow.MATRIX_SPLIT = split
+                    y, _ = pointflow.conv2d_wide(x, conv, (sc, sh), 1, True)
+                    tag = "bf16x3" if split else "f32"
+                    row[tag + "_max_err_vs_f64"] = float((y.double() - ref).abs().max() / ref.abs().max())
+                    row[tag + "_us"] = timeit(lambda: pointflow.conv2d_wide(x, conv, (sc, sh), 1, True))
+                row["speedup"] = row["f32_us"] / row["bf16x3_us"]
+                rows.append(row)
+            exp["bf16x3_layers"] = rows
+        except Exception as exc:
+            exp["bf16x3_layers"] = {"error": repr(exc)}
+        finally:
+            pointflow.MATRIX_SPLIT = 0
+
+    def part_bf16x3_headline_ab():
+
+        try:                                       # the headline workload with the switch off and on: same box, same process
+            from pointmvsnet_amd.graph import LanedForward
+            h, w, V, D, _, img_scales, inter_scales = synthetic.CONFIGS[infer_cfg]
+            scenes = [to_device(synthetic.make_config(infer_cfg, seed=i)[0], dev) for i in range(4)]
+            rates = {}
+            n_warm, n_timed = (1, 1) if dry else (64, 512)
+            for split in ((0, 1) if dry else (0, 1, 0, 1)):
+                pointflow.MATRIX_SPLIT = split
+                net = PointMVSNet()
+                synthetic.seed_weights(net, seed=0)
+                net = net.to(dev).train()
+                with torch.no_grad():
+                    laned = LanedForward(net, scenes[0], img_scales, inter_scales, isFlow=True, isTest=True,
+                                         lanes=1 if dry else 4, warmup=1 if dry else 3)
+                    for i in range(n_warm):
+                        laned.submit(scenes[i % 4])
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for i in range(n_timed):
+                        laned.submit(scenes[i % 4])
+                    torch.cuda.synchronize()
+                rates.setdefault("bf16x3" if split else "f32", []).append(n_timed / (time.perf_counter() - t0))
+                del laned, net
+            exp["bf16x3_headline_ab"] = {"depth_maps_per_s": rates, "workload": WORKLOAD_TEXT[infer_cfg],
+                                          "arms": "f32, bf16x3%s (%d scenes each, %d lane(s), graph replay)"
+                                                  % ("" if dry else ", f32, bf16x3", n_timed, 1 if dry else 4),
+                                          "ratio": (sum(rates["bf16x3"]) / len(rates["bf16x3"]))
+                                                   / (sum(rates["f32"]) / len(rates["f32"]))}
+        except Exception as exc:
+            exp["bf16x3_headline_ab"] = {"error": repr(exc)}
+        finally:
+            pointflow.MATRIX_SPLIT = 0
+
+    # order: the parts that run only kernels hardware has executed before first; the bf16x3 kernel (never run on an MI355X
+    # when this was written) last, so that a fault in it costs nothing else.  A part that would start after the budget
+    # (PF_EXPERIMENTS_BUDGET_S seconds since this process started, default 200) is skipped and says so
+    budget = float(os.environ.get("PF_EXPERIMENTS_BUDGET_S", "200"))
+    for name, part in (("lazy_bn", part_lazy_bn), ("pcie_inclusive", part_pcie_inclusive), ("cpu_baseline", part_cpu_baseline),
+                       ("bf16x3_layers", part_bf16x3_layers), ("bf16x3_headline_ab", part_bf16x3_headline_ab)):
+        spent = time.perf_counter() - PROCESS_T0
+        if spent > budget:
+            exp.setdefault("skipped", []).append("%s (%.0f s of the child's %.0f s budget spent)" % (name, spent, budget))
+        else:
+            part()
+        publish(out)
 
 
 def train_block_in_child(args, rank, world):

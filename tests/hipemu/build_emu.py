@@ -15,7 +15,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "pointmvsnet_amd", "csrc")
-OUT = os.path.join(HERE, "build")
+ASAN = os.environ.get("HIPEMU_ASAN") == "1"      # AddressSanitizer build: run python under LD_PRELOAD=asan_runtime() (README.md)
+OUT = os.path.join(HERE, "build_asan" if ASAN else "build")
 LIB = os.path.join(OUT, "libpointflow_emu.so")
 SOURCES = ["pf_core.hip", "gather_knn.hip", "knn_lattice.hip", "fetch.hip", "edgeconv.hip", "norm.hip", "conv3d.hip", "conv3d_pair.hip", "deconv3d.hip", "conv3d_bottom.hip", "conv2d_wide.hip", "eval_out.hip", "knn_inverse.hip", "norm_bwd.hip", "conv_wgrad.hip", "conv_dgrad.hip", "warp_bwd.hip", "train_heads.hip"]
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
@@ -49,15 +50,15 @@ def build(force=False):
         with open(dst, "w") as f:
             f.write("float* hipemu_shared_memory();\n" + text)
         units.append(dst)
-    shared = os.path.join(OUT, "shared_memory.cpp")
-    with open(shared, "w") as f:
-        f.write("alignas(64) static thread_local float g_lds[160 * 1024 / 4];\n"
-                "float* hipemu_shared_memory() { return g_lds; }\n")
-    units.append(shared)
-    cmd = [CLANG, "-std=c++20", "-O1", "-ffp-contract=off", "-fPIC", "-shared", "-pthread", "-w",
+    san = ["-fsanitize=address", "-shared-libasan", "-g", "-fno-omit-frame-pointer"] if ASAN else []
+    cmd = [CLANG, "-std=c++20", "-O1", "-ffp-contract=off", "-fPIC", "-shared", "-pthread", "-w"] + san + [
            "-I" + HERE, "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-x", "c++"] + units + ["-o", LIB]
     subprocess.check_call(cmd)
     return LIB
+
+
+def asan_runtime():
+    return subprocess.check_output([CLANG, "-print-file-name=libclang_rt.asan-x86_64.so"], text=True).strip()
 
 
 if __name__ == "__main__":

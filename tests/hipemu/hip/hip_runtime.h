@@ -97,11 +97,11 @@ extern thread_local Wave* wave;     // this thread's wave
 extern thread_local int lane;       // 0..63
 void block_barrier();
 void wave_barrier();                // the 64 lanes of this thread's wave meet
-void launch(dim3 grid, dim3 block, const std::function<void()>& body);
+void launch(dim3 grid, dim3 block, size_t dynamic_lds, const std::function<void()>& body);
 }  // namespace hipemu
 
 #define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) \
-  ::hipemu::launch((grid), (block), [=]() { kernel(__VA_ARGS__); })
+  ::hipemu::launch((grid), (block), (size_t)(lds), [=]() { kernel(__VA_ARGS__); })
 
 static inline void __syncthreads() { hipemu::block_barrier(); }
 static inline void hipemu_wave_barrier() { hipemu::wave_barrier(); }

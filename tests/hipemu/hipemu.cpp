@@ -44,6 +44,7 @@ struct Worker {                       // everything one OS thread needs to run b
   dim3 block;
 };
 thread_local Worker* W = nullptr;
+thread_local float* g_dynamic_lds = nullptr;   // this OS thread's dynamic-LDS block: EXACTLY the bytes the launch asked for
 
 void trampoline() {
   Worker* w = W;
@@ -124,7 +125,11 @@ void wave_barrier() {
   }
 }
 
-void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
+void launch(dim3 grid, dim3 block, size_t dynamic_lds, const std::function<void()>& body) {
+  if (dynamic_lds > 160 * 1024) {
+    std::fprintf(stderr, "hipemu: a launch asks for %zu bytes of dynamic LDS (gfx950 has 160 KB per workgroup)\n", dynamic_lds);
+    std::abort();
+  }
   const int nthreads = (int)(block.x * block.y * block.z);
   const long long nblocks = (long long)grid.x * grid.y * grid.z;
   if (nthreads <= 0 || nblocks <= 0) return;
@@ -149,6 +154,15 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
     w.wave_size.resize(nwaves);
     for (int i = 0; i < nwaves; ++i) w.wave_size[i] = (unsigned)((i + 1) * 64 <= nthreads ? 64 : nthreads - i * 64);
     W = &w;
+    // exactly the requested bytes from the heap: under HIPEMU_ASAN=1 (build_emu.py) an access past the launch's own
+    // figure lands in a redzone instead of in the slack of a fixed buffer
+    void* lds = nullptr;
+    if (const char* e = std::getenv("HIPEMU_LDS_SHRINK")) {      // positive control of the sanitizer build: hand out LESS
+      const size_t cut = (size_t)std::atoi(e);                   // than asked, a kernel that uses its whole figure must trip
+      dynamic_lds = dynamic_lds > cut ? dynamic_lds - cut : 0;
+    }
+    if (dynamic_lds > 0 && posix_memalign(&lds, 64, dynamic_lds) != 0) std::abort();
+    g_dynamic_lds = static_cast<float*>(lds);
     blockDim = block;
     gridDim = grid;
     for (long long b = next.fetch_add(1); b < nblocks; b = next.fetch_add(1)) {
@@ -158,6 +172,8 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
       run_block(&w);
     }
     W = nullptr;
+    g_dynamic_lds = nullptr;
+    std::free(lds);
   };
   if (nworkers == 1) {
     work();
@@ -168,3 +184,5 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
   for (auto& th : pool) th.join();
 }
 }  // namespace hipemu
+
+float* hipemu_shared_memory() { return hipemu::g_dynamic_lds; }
