@@ -42,6 +42,7 @@ struct Worker {                       // everything one OS thread needs to run b
   int cur = 0;
   const std::function<void()>* body = nullptr;
   dim3 block;
+  std::vector<int> visit;            // HIPEMU_ORDER's permutation of the block's threads
 };
 thread_local Worker* W = nullptr;
 thread_local float* g_dynamic_lds = nullptr;   // this OS thread's dynamic-LDS block: EXACTLY the bytes the launch asked for
@@ -80,7 +81,11 @@ void run_block(Worker* w) {
   int live = n;
   while (live > 0) {
     bool progressed = false;
-    for (int t = 0; t < n; ++t) {
+    for (int v = 0; v < n; ++v) {
+      // HIPEMU_ORDER: the order in which runnable fibers are visited -- 0 ascending (default), 1 waves descending (lanes
+      // ascending), 2 everything descending.  The hardware promises no order between waves: a kernel without a race
+      // (and without floating-point atomics) gives bit-identical results under all three
+      const int t = w->visit[v];
       Fiber& f = w->fibers[t];
       if (f.done) continue;
       if (f.wait_ptr != nullptr && *f.wait_ptr == f.wait_val) continue;
@@ -145,6 +150,7 @@ void launch(dim3 grid, dim3 block, size_t dynamic_lds, const std::function<void(
     w.nthreads = nthreads;
     w.block = block;
     w.body = &body;
+
     w.fibers.resize(nthreads);
     w.stacks.resize((size_t)nthreads * kStack);
     const int nwaves = (nthreads + 63) / 64;
@@ -153,6 +159,12 @@ void launch(dim3 grid, dim3 block, size_t dynamic_lds, const std::function<void(
     w.wave_cnt.assign(nwaves, 0u);
     w.wave_size.resize(nwaves);
     for (int i = 0; i < nwaves; ++i) w.wave_size[i] = (unsigned)((i + 1) * 64 <= nthreads ? 64 : nthreads - i * 64);
+    int order = 0;
+    if (const char* e = std::getenv("HIPEMU_ORDER")) order = std::atoi(e);
+    for (int wi = 0; wi < nwaves; ++wi) {
+      const int src = order == 0 ? wi : nwaves - 1 - wi;
+      for (unsigned l = 0; l < w.wave_size[src]; ++l) w.visit.push_back(src * 64 + (int)(order == 2 ? w.wave_size[src] - 1 - l : l));
+    }
     W = &w;
     // exactly the requested bytes from the heap: under HIPEMU_ASAN=1 (build_emu.py) an access past the launch's own
     // figure lands in a redzone instead of in the slack of a fixed buffer
