@@ -679,9 +679,12 @@ def train_block_in_child(args, rank, world):
         cmd.append("--no-experiments")
     t0 = time.perf_counter()
     text, note = "", None
+    # N > 1 runs no experiments (they are one-GPU A/Bs), so the block is ~40 s of work: a hang in its never-yet-run RCCL
+    # path should not cost every N of a scaling sweep the whole one-GPU allowance
+    limit = float(args.train_timeout) if world == 1 else min(float(args.train_timeout), 150.0)
     try:
         proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True,
-                              timeout=float(args.train_timeout))
+                              timeout=limit)
         text = proc.stdout or ""
         if proc.returncode != 0:
             note = "child exited with code %s: %s" % (proc.returncode, (proc.stderr or "")[-400:])
@@ -689,7 +692,7 @@ def train_block_in_child(args, rank, world):
         text = exc.stdout or ""
         if isinstance(text, bytes):
             text = text.decode("utf8", "replace")
-        note = "child killed after %.0f s (--train-timeout)" % float(args.train_timeout)
+        note = "child killed after %.0f s (--train-timeout)" % limit
     except OSError as exc:
         note = repr(exc)
     if rank != 0:

@@ -207,7 +207,8 @@ class TrainStep(object):
         self.bucket.allreduce_sum(self.group)                      # SUM: the loss sums over the batch (networks.py:176-179)
         self.optimizer.step()
         self.steps_done += 1
-        if self.check_every > 0 and self.steps_done % self.check_every == 0:
+        if (self.check_every > 0 and self.steps_done % self.check_every == 0
+                and distributed.world_size(self.group) > 1):       # (one process: nothing to compare, no host sync)
             self.check_replicas()
 
     def check_replicas(self):

@@ -15,6 +15,36 @@ REFERENCE_DIR = "/root/reference"
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by `pytest -m gpu` on the GPU box)")
+    config.addinivalue_line("markers", "isolated: on hardware, run the test body in a child pytest process (device code "
+                                       "that has never run on an MI355X: a GPU fault there must not end this session)")
+
+
+def _isolate(item):
+    if item.get_closest_marker("isolated") is None or os.environ.get("PF_TEST_INNER") == "1":
+        return False
+    return torch.cuda.is_available() or os.environ.get("PF_TEST_ISOLATE") == "force"      # ("force": the mechanism's own test)
+
+
+@pytest.hookimpl(tryfirst=True)
+def pytest_pyfunc_call(pyfuncitem):
+    """``@pytest.mark.isolated``: the test runs as ``python -m pytest <nodeid> --runxfail`` in a child process and passes
+    iff that exits 0.  A memory fault or an abort inside a never-yet-run kernel kills the child; this session, with the
+    results of every test before it, goes on.  (The child appends its own lines to gpurun_out/parity_report.jsonl.)"""
+    if not _isolate(pyfuncitem):
+        return None
+    import subprocess
+    cmd = [sys.executable, "-m", "pytest", pyfuncitem.nodeid, "-m", "gpu", "-q", "-x", "--runxfail", "-p", "no:cacheprovider"]
+    env = dict(os.environ, PF_TEST_INNER="1")
+    try:
+        r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True,
+                           timeout=float(os.environ.get("PF_TEST_INNER_TIMEOUT", "900")))
+    except subprocess.TimeoutExpired as exc:
+        out = exc.stdout if isinstance(exc.stdout, str) else (exc.stdout or b"").decode("utf8", "replace")
+        pytest.fail("isolated test killed after %s s:\n%s" % (exc.timeout, out[-3000:]), pytrace=False)
+    if r.returncode != 0:
+        pytest.fail("isolated test failed in its child process (exit code %s):\n%s" % (r.returncode, r.stdout[-3000:]),
+                    pytrace=False)
+    return True
 
 
 def load_golden(name):

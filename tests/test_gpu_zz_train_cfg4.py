@@ -596,11 +596,14 @@ def test_edge_chain_and_mlp_nodes_vs_float64_functional(dev):
 
 
 # ---------------------------------------------------------------------------------------------
-# the two default-off experiments of round 5, on hardware for the first time when the driver runs this file
+# the two default-off experiments of round 5, on hardware for the first time when the driver runs this file.  They launch
+# device code no MI355X has executed (the bf16x3 tower kernel, the four-row batched finalize): `isolated` runs each in a
+# child pytest process (tests/conftest.py), so that a GPU fault there ends the child, not the session
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("cin,cout,k,stride,hw", [(64, 64, 3, 1, (64, 80)), (32, 32, 3, 1, (128, 160)),
                                                  (32, 64, 5, 2, (128, 160)), (16, 32, 5, 2, (256, 320))])
 @pytest.mark.parametrize("affine", [False, True])
+@pytest.mark.isolated
 def test_experiment_split_kernel_vs_float64(dev, monkeypatch, cin, cout, k, stride, hw, affine):
     """conv2d_wide_split_kernel (bf16x3 products, float32 accumulate; PF_MATRIX_SPLIT) on the cfg-2 tower shapes against
     a float64 convolution, beside the exact-f32 kernel on the same operands: output, BatchNorm statistics rows."""
@@ -630,6 +633,7 @@ def test_experiment_split_kernel_vs_float64(dev, monkeypatch, cin, cout, k, stri
     assert e["stats_sum"] < 1e-5 and e["stats_sq"] < 1e-5, e
 
 
+@pytest.mark.isolated
 def test_experiment_split_teacher_forced_cfg2(dev, monkeypatch):
     """VERDICT r4 item 4's gate: the teacher-forced max norm of BASELINE cfg 2 (every iteration against the oracle's on the
     same prior and neighbours, < 1e-5) with the 32- / 64-channel tower layers on the bf16x3 kernel."""
@@ -643,6 +647,7 @@ def test_experiment_split_teacher_forced_cfg2(dev, monkeypatch):
         torch.set_num_threads(threads)
 
 
+@pytest.mark.isolated
 def test_experiment_split_forward_vs_reference_golden_cfg2(dev, monkeypatch):
     import test_gpu_model as TM
     monkeypatch.setattr(pointflow, "MATRIX_SPLIT", 1)
@@ -666,6 +671,7 @@ def _tiny_step_gradient(dev):
     return float(loss), step.bucket.flat.detach().clone(), buffers
 
 
+@pytest.mark.isolated
 def test_experiment_lazy_bn_rows_step_equals_the_default_step(dev, monkeypatch):
     """PF_TRAIN_LAZY_BN (the training forward's BatchNorms resolved by their consumers, the rows for the backward from ONE
     batched finalize at the end of the forward; VolumeConv's normalise passes finalize for themselves): the same loss and
