@@ -595,7 +595,7 @@ def experiments_block(dev, out, publish):
                 x = torch.randn(6, cin, h, w, device=dev)                      # both towers' samples of a cfg-2 scene
                 sc = torch.rand(6, cin, device=dev) + 0.5
                 sh = torch.randn(6, cin, device=dev) * 0.1
-                ref = F.conv2d(F.relu(x * sc.view(6, cin, 1, 1) + sh.view(6, cin, 1, 1)).double(), conv.weight.double(), None,
+                ref = F.conv2d(F.relu(x * sc.view(6, cin, 1, 1) + sh.view(6, cin, 1, 1)).double(), conv.weight.detach().double(), None,
                                stride, ks // 2)
                 row = {"layer": name, "flops": 2.0 * ref.numel() * ks * ks * cin}
                 for split in (0, 1):
