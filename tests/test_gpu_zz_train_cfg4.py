@@ -35,7 +35,7 @@ from pointmvsnet_amd import _lib, networks, pointflow, synthetic, train_ops
 
 # Every test of this file is NEW in round 5 and has never run on an MI355X: gpurun lost three boxes in a row before their
 # commands started (lease faults) and closed for the round before the first run.  All of them except
-# the graph-replay one and the two cfg-2-sized experiment tests HAVE been executed -- green -- on tests/hipemu, the
+# the graph-replay one HAVE been executed -- green -- on tests/hipemu, the
 # HIP-on-CPU emulator that runs the unchanged kernel sources (profiles/r05_emulator_runs.md), whose arithmetic matched the
 # hardware's digit for digit on the tests that exist on both.  They stay marked xfail(strict=False) for ONE reason: the
 # driver's round-end `pytest -m gpu -x` is the only hardware run this round gets, and a first-ever hardware execution must
