@@ -50,7 +50,7 @@ MFMA_F32_PEAK_TF = 157.3         # same guide: dense f32-input MFMA peak (v_mfma
 
 
 TRAFFIC_TABLE = os.path.join("profiles", "pmc_traffic.json")
-UNDER_LOAD_TABLE = os.path.join("profiles", "r05_per_kernel_roofline.json")
+UNDER_LOAD_TABLE = os.path.join("profiles", "r06_per_kernel_roofline.json")
 
 
 def measured_traffic(entry):
@@ -988,15 +988,15 @@ def run(args, emulate):
     from pointmvsnet_amd import pointflow as _pf
     stage_timeline = _pf.timeline_report() if _pf.TIMELINE else None
 
-    train = None
-    if args.config == "cfg2" and args.route == "fused" and not args.no_train_block:
-        train = train_block_in_child(args, rank, world)    # (after the headline's timed region; its fields are not touched)
+    with_train = args.config == "cfg2" and args.route == "fused" and not args.no_train_block
     placement_by_rank = None
     if world > 1:
         gathered = [None] * world
         torch.distributed.all_gather_object(gathered, lane_probe)
         placement_by_rank = gathered
     if rank != 0:
+        if with_train:                                     # (every rank launches its child of the train block's group)
+            train_block_in_child(args, rank, world)
         return
     roof = None
     if dominant is not None:
@@ -1117,7 +1117,7 @@ def run(args, emulate):
         "stage_timeline_us": stage_timeline,
         "roofline": roof,
         "kernels": kernels,
-        "train": train,
+        "train": None,
     }
     if world == 1 and not args.no_cpu_baseline and (not training or args.train_cpu_baseline):
         data_cpu, _, _ = synthetic.make_config(args.config, seed=my_scenes[0], train_intrinsics=training)
@@ -1126,7 +1126,13 @@ def run(args, emulate):
         result["speedup_vs_cpu_baseline"] = result["value"] / result["cpu_baseline"]["value"]
     else:
         result["cpu_baseline"] = None
-    print(json.dumps(result))
+    if with_train:
+        # the headline line is COMPLETE and on stdout before the train block's child process starts: whatever happens in
+        # there (a hang, a GPU fault, the caller's own timeout) cannot cost it.  The final line repeats it with ``train``
+        # filled in; a consumer takes the last line it can parse.
+        print(json.dumps(result), flush=True)
+        result["train"] = train_block_in_child(args, rank, world)
+    print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":

@@ -21,8 +21,7 @@ tests/test_gpu_model.py with cfg = "cfg4"), its bit-reproducibility and graphed 
 node tests whose round-4 reference side ran on this package's own operators (flow features, coarse volume; the EdgeConv
 chain with every ATen call written out).
 
-The file sorts last on purpose (round 5 lost its GPU access before these tests could be run once on hardware -- DESIGN.md
-section 5): `pytest -x` reaches it after every test that has run green on an MI355X before.
+The file sorts last on purpose: these are the longest tests of the suite.
 """
 import ctypes
 
@@ -33,17 +32,10 @@ import torch.nn.functional as F
 from conftest import report
 from pointmvsnet_amd import _lib, networks, pointflow, synthetic, train_ops
 
-# Every test of this file is NEW in round 5 and has never run on an MI355X: gpurun lost three boxes in a row before their
-# commands started (lease faults) and closed for the round before the first run.  All of them except
-# the graph-replay one HAVE been executed -- green -- on tests/hipemu, the
-# HIP-on-CPU emulator that runs the unchanged kernel sources (profiles/r05_emulator_runs.md), whose arithmetic matched the
-# hardware's digit for digit on the tests that exist on both.  They stay marked xfail(strict=False) for ONE reason: the
-# driver's round-end `pytest -m gpu -x` is the only hardware run this round gets, and a first-ever hardware execution must
-# not be able to turn the validated suite red.  The driver's run reports each as XPASS (what a correct test on correct
-# kernels gives) or XFAIL (a defect of the test or of the kernel, to be read in the log; pytest.ini adds -rxX so that the
-# summary lists them by name).  The next run with GPU access removes the marker.
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.xfail(strict=False, reason="new in round 5: green on tests/hipemu, first hardware run pending")]
+# Round 5 wrote this file without GPU access and marked it xfail(strict=False); the driver's round-end run was its first
+# hardware execution and every test XPASSed (GPUTEST_r05: 340 passed, 82 xpassed).  Round 6 removed the marker: these
+# tests gate like every other one.
+pytestmark = [pytest.mark.gpu]
 
 V, H, W, D = 3, 512, 640, 48
 P1, P2 = 5 * 64 * 80, 5 * 128 * 160          # points of PointFlow iteration 1 / 2
