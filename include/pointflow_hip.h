@@ -441,21 +441,6 @@ int pf_conv2d_wide_sets_f32(const float* x, int x_layout, const float* wp, int64
                             const float* in_scale, const float* in_shift, const pf_bn_job* in_bn, int samples_per_stat,
                             double* partials, int out_channel_last, void* stream);
 
-/* EXPERIMENT (round 5, unmeasured on hardware -- DESIGN.md section 7): the 32- / 64-channel tower layers with the products
- * on the bf16 matrix cores at float32 accuracy.  Every float32 operand is split into three bf16 terms (hi + mid + lo =
- * the float32 value exactly: the weights by the caller, the activations by the kernel while it stages its patch) and a
- * product is the six terms a_h b_l + a_l b_h + a_m b_m + a_h b_m + a_m b_h + a_h b_h accumulated in float32 by
- * v_mfma_f32_32x32x16_bf16 (the three dropped terms are below 2^-24 |a b|).  Same contract, tiling, statistics rows and
- * arguments as pf_conv2d_wide_sets_f32 EXCEPT wp: the split weights as bf16 (K*K*Cin/16, 3 splits, 2 halves, Cout, 8) --
- * wp[t][s][h][co][j] = split s of w[co][16 kb + 8 h + j][kh][kw] with t = (kh K + kw) Cin/16 + kb -- 16-byte aligned,
- * wp_set_stride in bf16 elements.  Shapes: pf_conv2d_wide_split_supported.  Results differ from the f32 kernel's in the
- * last bits (not an fmaf chain); nothing in the default path calls it (PF_MATRIX_SPLIT=1 selects it in pointflow.py). */
-int pf_conv2d_wide_split_supported(int64_t Cin, int64_t Cout, int kernel_size, int stride);
-int pf_conv2d_wide_split_sets_f32(const float* x, int x_layout, const void* wp, int64_t wp_set_stride, int sets, float* y,
-                                  int64_t N, int64_t Cin, int64_t Cout, int64_t Hi, int64_t Wi, int kernel_size,
-                                  int stride, const float* in_scale, const float* in_shift, const pf_bn_job* in_bn,
-                                  int samples_per_stat, double* partials, int out_channel_last, void* stream);
-
 /* ---- rows M (last layer) + H + T : flow head ---------------------------------------------------
  * Z (G*Ng, ldz) holds the pre-BN output of the 64->16 MLP layer.  Per pixel of the (h,w) grid:
  * a = relu(Z*scale+shift); flow_d = sum_c w_out[c]*a_c for the 5 hypotheses; p = softmax(-flow);

@@ -73,9 +73,6 @@ PROTOTYPES = {
                             _vp, _i, _vp], _i),
     "pf_conv2d_wide_sets_f32": ([_vp, _i, _vp, _i64, _i, _vp, _i64, _i64, _i64, _i64, _i64, _i, _i, _vp, _vp,
                                  ctypes.POINTER(BnJob), _i, _vp, _i, _vp], _i),
-    "pf_conv2d_wide_split_supported": ([_i64, _i64, _i, _i], _i),
-    "pf_conv2d_wide_split_sets_f32": ([_vp, _i, _vp, _i64, _i, _vp, _i64, _i64, _i64, _i64, _i64, _i, _i, _vp, _vp,
-                                       ctypes.POINTER(BnJob), _i, _vp, _i, _vp], _i),
     "pf_norm_blocks": ([_i64], _i),
     "pf_channel_stats_f32": ([_vp, _i64, _i64, _i64, _vp, _vp], _i),
     "pf_channel_affine_f32": ([_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _vp], _i),

@@ -35,28 +35,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));   // (HIP's float4 struct in a register ARRAY ends up in scratch)
 
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-// v = hi + mid + lo with three bf16 terms per value, packed two values per dword (element 0 in the low half):
-// t[0] = hi of (v0, v1 | v2, v3), t[1] = mid, t[2] = lo.  hi = rn_bf16(v), mid = rn_bf16(v - hi), lo = rn_bf16(v - hi -
-// mid): both differences are exact in float32, and what is left after lo is below 2^-25 |v|.
-__device__ __forceinline__ void pf_split3(const f32x4& v, u32x2 t[3]) {
-  f32x2 a = {v[0], v[1]}, b = {v[2], v[3]};
-#pragma unroll
-  for (int sp = 0; sp < 3; ++sp) {
-    const unsigned pa = __builtin_bit_cast(unsigned, __builtin_convertvector(a, bf16x2));
-    const unsigned pb = __builtin_bit_cast(unsigned, __builtin_convertvector(b, bf16x2));
-    t[sp] = (u32x2){pa, pb};
-    if (sp < 2) {
-      a = (f32x2){a.x - __builtin_bit_cast(float, pa << 16), a.y - __builtin_bit_cast(float, pa & 0xffff0000u)};
-      b = (f32x2){b.x - __builtin_bit_cast(float, pb << 16), b.y - __builtin_bit_cast(float, pb & 0xffff0000u)};
-    }
-  }
-}
-
 struct WideGeom {
   int Hi, Wi, Ho, Wo, tiles_w, tiles_h, sps;
   int cl_out;      // bit s: parameter set s writes y as (Ho, Wo, C_out) per sample instead of (C_out, Ho, Wo)
@@ -180,34 +158,6 @@ struct PatchStager {
       }
       if (!interior && !((okmask >> r) & 1u)) v = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};   // zero padding applies AFTER it
       if (256 * (r + 1) <= ITEMS || it < ITEMS) *reinterpret_cast<f32x4*>(patch + (pr * PW + pc) * RS + 4 * q) = v;
-    }
-  }
-
-  // The same for the bf16x3 kernels (conv2d_wide_split_kernel below): every value leaves as THREE bf16 terms
-  // hi + mid + lo = v exactly (each the round-to-nearest bf16 of what the previous ones left; the remainders are exact
-  // float32 differences), written as [pixel][split][CIN] bf16 -- 8 bytes per (item, split).
-  template <bool AFF, int RSB>
-  __device__ __forceinline__ void commit_split(char* patch, const float* aff) const {
-    const int tid = threadIdx.x;
-#pragma unroll
-    for (int r = 0; r < NIT; ++r) {
-      const int it = tid + 256 * r;
-      const int pr = meta[r] & 255, pc = (meta[r] >> 8) & 255, q = meta[r] >> 16;
-      f32x4 v = {rx[r][0], rx[r][1], rx[r][2], rx[r][3]};
-      if (AFF) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(aff + 4 * q);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(aff + CIN + 4 * q);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(v[j], a[j], b[j]), 0.0f);
-      }
-      if (!interior && !((okmask >> r) & 1u)) v = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};   // zero padding applies AFTER it
-      u32x2 t3[3];
-      pf_split3(v, t3);
-      if (256 * (r + 1) <= ITEMS || it < ITEMS) {
-        char* dst = patch + (pr * PW + pc) * RSB + 8 * q;
-#pragma unroll
-        for (int sp = 0; sp < 3; ++sp) *reinterpret_cast<u32x2*>(dst + sp * 2 * CIN) = t3[sp];
-      }
     }
   }
 };
@@ -430,168 +380,6 @@ int launch_wide(const float* x, const float* wp, float* y, WideGeom g, int64_t N
   if (in_scale != nullptr)
     return launch_wide_mode<KS, STRIDE, CIN, COUT, 1>(x, wp, y, g, N, in_scale, in_shift, partials, none, none, s);
   return launch_wide_mode<KS, STRIDE, CIN, COUT, 0>(x, wp, y, g, N, nullptr, nullptr, partials, none, none, s);
-}
-
-// ------------------------------------------------------------------------------------------------
-// bf16x3 form of conv2d_wide_kernel (round 5, an EXPERIMENT behind PF_MATRIX_SPLIT / pf_conv2d_wide_split_sets_f32):
-// the same implicit GEMM, tiling, staging, epilogue and statistics, with the products on v_mfma_f32_32x32x16_bf16.
-// Every float32 operand is split into three bf16 terms (pf_split3: hi + mid + lo = the float32 value exactly; weights
-// on the host, activations while the patch is staged) and a product a * b is the six terms
-//     a_h b_l + a_l b_h + a_m b_m + a_h b_m + a_m b_h + a_h b_h
-// accumulated in float32 by the matrix core (smallest first); the dropped terms a_m b_l + a_l b_m + a_l b_l are below
-// 2^-24 |a b|, i.e. under the rounding of the float32 product itself.  16x the f32 matrix rate / 6 products = 2.67x fewer
-// matrix cycles per MAC; bf16 MFMAs also leave issue slots to the vector pipe, f32 MFMAs do not
-// (profiles/archive/r03/r03j_f32_mfma_shares_the_valu.md).  Not bit-identical to the f32 kernel: |error| ~ 2^-23 relative per
-// product with a float32 accumulation whose order inside a 16-deep block is the hardware's.
-//   LDS patch: [pixel][split][CIN] bf16 (+16 bytes per pixel: consecutive pixels fall on distinct 16-byte bank slots);
-//   lane (pixel m, half h) reads its 8 reduction channels 16 kb + 8 h .. + 7 of split sp as ONE ds_read_b128;
-//   weights host-packed [tap][kb][split][h][c_out][8] bf16: a lane's B operand is one 16-byte load, a wave's two
-//   contiguous 512-byte runs, four K blocks ahead.
-// ------------------------------------------------------------------------------------------------
-template <int KS, int STRIDE, int CIN, int COUT>
-struct SplitCfg {
-  using W = WideCfg<KS, STRIDE, CIN, COUT>;
-  static constexpr int RSB = 6 * CIN + 16;             // bytes per staged pixel
-  static constexpr int PATCHB = W::NPIX * RSB;
-  static constexpr int KB = CIN / 16;                  // 16-deep reduction blocks per tap
-  static constexpr size_t LDS = (size_t)PATCHB + sizeof(float) * 2 * CIN + sizeof(double) * 4 * 32 * 2;
-  static_assert(CIN % 16 == 0, "16-deep blocks");
-  static_assert(((RSB / 16) & 1) == 1, "odd number of 16-byte slots per pixel");
-  static_assert(PATCHB >= 4096, "pf_bn_resolve's scratch lives in the (still empty) patch");
-  static_assert(LDS <= 96 * 1024, "(32 -> 64 5x5/2: 80.6 KB, one block per CU; the others 37-75 KB)");
-};
-
-template <int KS, int STRIDE, int CIN, int COUT, int AFFINE>
-__global__ __launch_bounds__(256) void conv2d_wide_split_kernel(const float* __restrict__ x,
-                                                                  const unsigned short* __restrict__ wp,
-                                                                  float* __restrict__ y, WideGeom g,
-                                                                  const float* __restrict__ in_scale,
-                                                                  const float* __restrict__ in_shift,
-                                                                  double* __restrict__ partials, pf_bn_job in_bn,
-                                                                  pf_bn_job in_bn1) {
-  using C = WideCfg<KS, STRIDE, CIN, COUT>;
-  using S = SplitCfg<KS, STRIDE, CIN, COUT>;
-  constexpr int PW = C::PW, NPIX = C::NPIX, RSB = S::RSB;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  char* patch = reinterpret_cast<char*>(lds);
-  float* aff = reinterpret_cast<float*>(patch + S::PATCHB);
-  double* red = reinterpret_cast<double*>(aff + 2 * CIN);
-
-  const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int m = lane & 31, h = lane >> 5;
-  const int wm = wave / C::NWN, wn = wave % C::NWN;
-  const int n = blockIdx.y;
-  const int tw = blockIdx.x % g.tiles_w, th = blockIdx.x / g.tiles_w;
-  const int oh0 = th * C::TH, ow0 = tw * C::TW;
-  const int ih0 = oh0 * STRIDE - C::PAD, iw0 = ow0 * STRIDE - C::PAD;
-  const int plane_i = g.Hi * g.Wi;
-  const int set = wide_set(g, n);
-  const float* xb = x + (int64_t)wide_input_sample(g, n, set) * CIN * plane_i;
-
-  constexpr int NP = KS * KS * S::KB;                  // 16-deep reduction blocks of the tile
-  // blocks of B (three 16-byte pieces each) in flight per lane: a K block is 6 MFMAs = 192 cycles of matrix work, an L2
-  // round trip several hundred -- four blocks ahead (12 registers of 16 bytes) cover it where the f32 kernel's six
-  // pieces cover 1 536 cycles
-  constexpr int D = 4;
-  const u32x4* bg = reinterpret_cast<const u32x4*>(wp + set * g.w_stride) + (h * COUT + wn * 32 + m);
-  u32x4 bq[D][3];
-#pragma unroll
-  for (int d = 0; d < D; ++d)
-#pragma unroll
-    for (int sp = 0; sp < 3; ++sp) bq[d][sp] = bg[((d < NP ? d : 0) * 3 + sp) * 2 * COUT];
-
-  {
-    PatchStager<CIN, NPIX, PW, 0> st;
-    st.init(plane_i, g.Wi);
-    st.load(xb, plane_i, ih0, iw0, g.Hi, g.Wi);
-    wide_affine_prologue<CIN, AFFINE>(aff, in_scale, in_shift,
-                                      AFFINE == 2 ? (n - set * g.spset) / g.sps : n / g.sps, set ? in_bn1 : in_bn,
-                                      reinterpret_cast<double*>(patch));
-    st.template commit_split<(AFFINE != 0), RSB>(patch, aff);
-  }
-  __syncthreads();
-
-  // Two accumulators: the leading products a_h b_h in `acc` -- as many float32 roundings per output as the exact-f32 kernel
-  // makes -- and the five correction products (2^-8 .. 2^-16 of it) in `cor`, whose own rounding is negligible; one add
-  // at the end.  (One accumulator for all six made the result ~2x less accurate than the f32 kernel in the emulator's
-  // worst-case model of the matrix core's accumulation, tests/test_emulated_kernels.py.)
-  f32x16 acc, cor;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = cor[i] = 0.0f;
-  const char* abase = patch + ((2 * wm + (m >> 4)) * STRIDE * PW + (m & 15) * STRIDE) * RSB + 16 * h;
-  u32x4 a[3];
-#pragma unroll
-  for (int sp = 0; sp < 3; ++sp) a[sp] = *reinterpret_cast<const u32x4*>(abase + sp * 2 * CIN);
-#pragma unroll
-  for (int t = 0; t < NP; ++t) {
-    u32x4 an[3] = {a[0], a[1], a[2]};
-    if (t + 1 < NP) {
-      const int tap = (t + 1) / S::KB, kb = (t + 1) % S::KB;
-      const int kh = tap / KS, kw = tap % KS;
-#pragma unroll
-      for (int sp = 0; sp < 3; ++sp)
-        an[sp] = *reinterpret_cast<const u32x4*>(abase + (kh * PW + kw) * RSB + sp * 2 * CIN + 32 * kb);
-    }
-    const bf16x8 ah = __builtin_bit_cast(bf16x8, a[0]), am = __builtin_bit_cast(bf16x8, a[1]),
-                 al = __builtin_bit_cast(bf16x8, a[2]);
-    const bf16x8 bh = __builtin_bit_cast(bf16x8, bq[t % D][0]), bm = __builtin_bit_cast(bf16x8, bq[t % D][1]),
-                 bl = __builtin_bit_cast(bf16x8, bq[t % D][2]);
-    __builtin_amdgcn_sched_barrier(0);
-    cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, cor, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
-    cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, cor, 0, 0, 0);
-    cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, cor, 0, 0, 0);
-    cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, cor, 0, 0, 0);
-    cor = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, cor, 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (t + D < NP) {
-#pragma unroll
-      for (int sp = 0; sp < 3; ++sp) bq[t % D][sp] = bg[((t + D) * 3 + sp) * 2 * COUT];
-    }
-#pragma unroll
-    for (int sp = 0; sp < 3; ++sp) a[sp] = an[sp];
-  }
-#pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] += cor[i];
-  wide_epilogue<C, COUT>(acc, y, g, partials, red, n, oh0, ow0, wm, wn, wave, m, h, tid, (g.cl_out >> set) & 1);
-}
-
-template <int KS, int STRIDE, int CIN, int COUT, int AFFINE>
-int launch_split_mode(const float* x, const unsigned short* wp, float* y, WideGeom g, int64_t N, const float* in_scale,
-                      const float* in_shift, double* partials, const pf_bn_job& in_bn, const pf_bn_job& in_bn1,
-                      hipStream_t s) {
-  using C = WideCfg<KS, STRIDE, CIN, COUT>;
-  using S = SplitCfg<KS, STRIDE, CIN, COUT>;
-  if (S::LDS > 64 * 1024) {
-    static std::atomic<unsigned long long> done{0};   // per instantiation, one bit per device
-    const int rc = pf_allow_big_lds(
-        reinterpret_cast<const void*>(&conv2d_wide_split_kernel<KS, STRIDE, CIN, COUT, AFFINE>), (int)S::LDS, done);
-    if (rc != PF_OK) return rc;
-  }
-  g.tiles_w = (g.Wo + C::TW - 1) / C::TW;
-  const int tiles_h = (g.Ho + C::TH - 1) / C::TH;
-  dim3 grid((unsigned)(tiles_h * g.tiles_w), (unsigned)N);
-  hipLaunchKernelGGL((conv2d_wide_split_kernel<KS, STRIDE, CIN, COUT, AFFINE>), grid, dim3(256), S::LDS, s, x, wp, y, g,
-                     in_scale, in_shift, partials, in_bn, in_bn1);
-  return pf_launch_status();
-}
-
-template <int KS, int STRIDE, int CIN, int COUT>
-int launch_split(const float* x, const unsigned short* wp, float* y, WideGeom g, int64_t N, const float* in_scale,
-                 const float* in_shift, double* partials, const pf_bn_job* in_bn, hipStream_t s) {
-  if (in_bn != nullptr) {
-    for (int k = 0; k < g.sets; ++k) {
-      const int rc = pf_bn_in_check(in_bn + k, CIN, g.spset / g.sps);
-      if (rc != PF_OK) return rc;
-    }
-    return launch_split_mode<KS, STRIDE, CIN, COUT, 2>(x, wp, y, g, N, nullptr, nullptr, partials, in_bn[0],
-                                                       in_bn[g.sets - 1], s);
-  }
-  pf_bn_job none = {};
-  if (in_scale != nullptr)
-    return launch_split_mode<KS, STRIDE, CIN, COUT, 1>(x, wp, y, g, N, in_scale, in_shift, partials, none, none, s);
-  return launch_split_mode<KS, STRIDE, CIN, COUT, 0>(x, wp, y, g, N, nullptr, nullptr, partials, none, none, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -958,47 +746,6 @@ int pf_conv2d_wide_sets_f32(const float* x, int x_layout, const float* wp, int64
   }
   if (Cin == 32) return launch_wide<5, 2, 32, 64>(x, wp, y, g, N, in_scale, in_shift, partials, in_bn, s);
   return launch_wide<5, 2, 16, 32>(x, wp, y, g, N, in_scale, in_shift, partials, in_bn, s);
-}
-
-int pf_conv2d_wide_split_supported(int64_t Cin, int64_t Cout, int kernel_size, int stride) {
-  if (kernel_size == 3 && stride == 1) return (Cin == 64 && Cout == 64) || (Cin == 32 && Cout == 32);
-  if (kernel_size == 5 && stride == 2) return (Cin == 32 && Cout == 64) || (Cin == 16 && Cout == 32);
-  return 0;
-}
-
-int pf_conv2d_wide_split_sets_f32(const float* x, int x_layout, const void* wp, int64_t wp_set_stride, int sets, float* y,
-                                  int64_t N, int64_t Cin, int64_t Cout, int64_t Hi, int64_t Wi, int kernel_size,
-                                  int stride, const float* in_scale, const float* in_shift, const pf_bn_job* in_bn,
-                                  int samples_per_stat, double* partials, int out_channel_last, void* stream) {
-  PF_REQUIRE(N >= 0 && Cin >= 1 && Cout >= 1 && Hi >= 1 && Wi >= 1 && N <= 65535 && samples_per_stat >= 1);
-  PF_REQUIRE((sets == 1 || sets == 2) && N % sets == 0 && wp_set_stride >= 0 && (wp_set_stride & 7) == 0);
-  PF_REQUIRE(out_channel_last >= 0 && out_channel_last < (1 << sets) && x_layout >= 0 && x_layout <= 2);
-  PF_REQUIRE((in_scale == nullptr) == (in_shift == nullptr) && (in_bn == nullptr || in_scale == nullptr));
-  PF_REQUIRE((N / sets) % samples_per_stat == 0 || (in_bn == nullptr && sets == 1));
-  if (!pf_conv2d_wide_split_supported(Cin, Cout, kernel_size, stride)) return PF_ERR_UNSUPPORTED;
-  PF_REQUIRE(Cin * Hi * Wi <= INT32_MAX);
-  if (N == 0) return PF_OK;
-  PF_REQUIRE(x && wp && y && (reinterpret_cast<uintptr_t>(wp) & 15) == 0);
-  WideGeom g;
-  g.Hi = (int)Hi;
-  g.Wi = (int)Wi;
-  g.Ho = (int)((Hi - 1) / stride + 1);
-  g.Wo = (int)((Wi - 1) / stride + 1);
-  g.tiles_w = g.tiles_h = 0;
-  g.sps = samples_per_stat;
-  g.cl_out = out_channel_last;
-  g.sets = sets;
-  g.spset = (int)(N / sets);
-  g.x_mode = sets > 1 ? x_layout : 0;
-  g.w_stride = wp_set_stride;                           // bf16 elements between the sets' packed weights
-  hipStream_t s = (hipStream_t)stream;
-  const unsigned short* w = reinterpret_cast<const unsigned short*>(wp);
-  if (kernel_size == 3) {
-    if (Cin == 64) return launch_split<3, 1, 64, 64>(x, w, y, g, N, in_scale, in_shift, partials, in_bn, s);
-    return launch_split<3, 1, 32, 32>(x, w, y, g, N, in_scale, in_shift, partials, in_bn, s);
-  }
-  if (Cin == 32) return launch_split<5, 2, 32, 64>(x, w, y, g, N, in_scale, in_shift, partials, in_bn, s);
-  return launch_split<5, 2, 16, 32>(x, w, y, g, N, in_scale, in_shift, partials, in_bn, s);
 }
 
 }  // extern "C"

@@ -620,40 +620,6 @@ def _pack_conv2d_wide(weight):
     return w.permute(0, 1, 2, 3, 5, 4).contiguous()
 
 
-# PF_MATRIX_SPLIT=1: the 32- / 64-channel tower layers run with their products on the bf16 matrix cores at float32
-# accuracy (csrc/conv2d_wide.hip, conv2d_wide_split_kernel: three bf16 terms per operand, six products, float32
-# accumulate).  An EXPERIMENT: built in round 5, never measured on hardware (the round lost its GPU access), so the default
-# is the exact-f32 kernels and bench.py says which one ran.  tools/microbench_split.py times and checks it.
-MATRIX_SPLIT = int(_os.environ.get("PF_MATRIX_SPLIT", "0"))
-
-
-def split3_bf16(t):
-    """(hi, mid, lo) bfloat16 tensors with hi + mid + lo == t exactly for float32 t (each term the round-to-nearest
-    bfloat16 of what the previous ones left; the remainders are exact float32 differences)."""
-    t = t.detach().to(_F32)
-    hi = t.to(torch.bfloat16)
-    r1 = t - hi.to(_F32)
-    mid = r1.to(torch.bfloat16)
-    lo = (r1 - mid.to(_F32)).to(torch.bfloat16)
-    return hi, mid, lo
-
-
-def _pack_conv2d_wide_split(weight):
-    """(Cout, Cin, K, K) float32 -> (K*K*Cin/16, 3, 2, Cout, 8) bfloat16 for pf_conv2d_wide_split_sets_f32:
-    [t][s][h][co][j] = split s of w[co][16 kb + 8 h + j][kh][kw], t = (kh K + kw) Cin/16 + kb."""
-    cout, cin, k, _ = weight.shape
-    parts = []
-    for term in split3_bf16(weight):
-        w = term.permute(2, 3, 1, 0).reshape(k * k, cin // 16, 2, 8, cout)          # [tap][kb][h][j][co]
-        parts.append(w.permute(0, 1, 2, 4, 3).reshape(k * k * (cin // 16), 2, cout, 8))
-    return torch.stack(parts, dim=1).contiguous()
-
-
-def conv2d_wide_split_supported(conv):
-    return bool(MATRIX_SPLIT and conv2d_supported(conv) and _lib.load().pf_conv2d_wide_split_supported(
-        conv.in_channels, conv.out_channels, int(conv.kernel_size[0]), int(conv.stride[0])))
-
-
 def pack_conv2d_wide_weight(weight):
     """(Cout,Cin,K,K) -> (K, K, Cin/8, 2, Cout, 4): [kh][kw][kc][h][co][j] = w[co][8 kc + 4 h + j][kh][kw]
     (Cout 32 / 64: 32x32x2 MFMA), or, for Cout = 8 / 16 (16x16x4 MFMA), (K, K, 4, 16, Cin'/4) with Cin' = Cin
@@ -669,25 +635,13 @@ def conv2d_wide(x, conv, in_affine, samples_per_stat, want_stats, channel_last_o
     Cout = conv.out_channels
     ks, stride = conv.kernel_size[0], conv.stride[0]
     Ho, Wo = (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
-    split = conv2d_wide_split_supported(conv)
-    if split:
-        wp = _cached_pack(("c2wsp", id(conv.weight)), (conv.weight,), lambda: _pack_conv2d_wide_split(conv.weight))
-    else:
-        wp = pack_conv2d_wide_weight(conv.weight)
+    wp = pack_conv2d_wide_weight(conv.weight)
     y = torch.empty((N, Ho, Wo, Cout) if channel_last_out else (N, Cout, Ho, Wo), dtype=_F32, device=x.device)
     partials = None
     if want_stats:
         T = int(_lib.load().pf_conv2d_wide_blocks(Cout, Hi, Wi, int(stride)))
         partials = stat_rows(N, T, Cout, x.device)
     sc, sh, in_bn = _split_affine(in_affine)
-    if split:
-        _lib.call("pf_conv2d_wide_split_sets_f32", _lib.ptr(x), 0, _lib.ptr(wp), 0, 1, _lib.ptr(y), N, Cin, Cout, Hi, Wi,
-                  int(ks), int(stride), _lib.ptr(sc), _lib.ptr(sh), in_bn, int(samples_per_stat), _lib.ptr(partials),
-                  int(bool(channel_last_out)), _lib.stream(),
-                  algo_bytes=4.0 * N * (Cin * Hi * Wi + Cout * Ho * Wo) + 6.0 * ks * ks * Cin * Cout,
-                  flops=2.0 * N * Ho * Wo * ks * ks * Cin * Cout,
-              tag="%d->%d %dx%d/%d" % (Cin, Cout, ks, ks, stride))
-        return y, partials
     _lib.call("pf_conv2d_wide_f32", _lib.ptr(x), _lib.ptr(wp), _lib.ptr(y), N, Cin, Cout, Hi, Wi, int(ks), int(stride),
               _lib.ptr(sc), _lib.ptr(sh), in_bn, int(samples_per_stat), _lib.ptr(partials), int(bool(channel_last_out)),
               _lib.stream(), algo_bytes=4.0 * N * (Cin * Hi * Wi + Cout * Ho * Wo) + 4.0 * ks * ks * Cin * Cout,
@@ -779,13 +733,7 @@ def conv2d_wide_sets(x, convs, in_affine, samples_per_stat, want_stats, interlea
     Cout = conv.out_channels
     ks, stride = conv.kernel_size[0], conv.stride[0]
     Ho, Wo = (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
-    split = all(conv2d_wide_split_supported(c) for c in convs)
-    if split:
-        weights = tuple(c.weight for c in convs)
-        wp = _cached_pack(("c2wsps",) + tuple(id(w) for w in weights), weights,
-                          lambda: torch.stack([_pack_conv2d_wide_split(w) for w in weights]).contiguous())
-    else:
-        wp = pack_conv2d_wide_weight_sets([c.weight for c in convs])
+    wp = pack_conv2d_wide_weight_sets([c.weight for c in convs])
     y = torch.empty((N, Cout, Ho, Wo), dtype=_F32, device=x.device)
     partials = None
     if want_stats:
@@ -793,14 +741,6 @@ def conv2d_wide_sets(x, convs, in_affine, samples_per_stat, want_stats, interlea
         partials = stat_rows(N, T, Cout, x.device)
     sc, sh, in_bn = (None, None, None) if in_affine is None else in_affine.split()
     mask = sum(1 << s for s in channel_last_sets)
-    if split:
-        _lib.call("pf_conv2d_wide_split_sets_f32", _lib.ptr(x), 2 if interleaved else 0, _lib.ptr(wp), int(wp[0].numel()),
-                  sets, _lib.ptr(y), N, Cin, Cout, Hi, Wi, int(ks), int(stride), _lib.ptr(sc), _lib.ptr(sh), in_bn,
-                  int(samples_per_stat), _lib.ptr(partials), int(mask), _lib.stream(),
-                  algo_bytes=4.0 * (x.numel() + N * Cout * Ho * Wo) + 6.0 * sets * ks * ks * Cin * Cout,
-                  flops=2.0 * N * Ho * Wo * ks * ks * Cin * Cout,
-              tag="%d->%d %dx%d/%d" % (Cin, Cout, ks, ks, stride))
-        return y, partials
     _lib.call("pf_conv2d_wide_sets_f32", _lib.ptr(x), 2 if interleaved else 0, _lib.ptr(wp), int(wp[0].numel()), sets,
               _lib.ptr(y), N, Cin, Cout, Hi, Wi, int(ks), int(stride), _lib.ptr(sc), _lib.ptr(sh), in_bn,
               int(samples_per_stat), _lib.ptr(partials), int(mask), _lib.stream(),

@@ -174,13 +174,15 @@ def bn_train_rows(bn, partials, col0, C, count, G, groups_per_stat, unbias_n=Non
     return rows
 
 
-# PF_TRAIN_LAZY_BN=1: the training forward finalizes a BatchNorm on the critical path only where the rows are
-# needed at once (a materialised activation, EdgeConv's apply pass).  Everywhere else the CONSUMER resolves the pending
-# BatchNorm from the producer's statistics rows (``in_bn``, csrc/pf_bn_resolve.h, as the inference path does), and the
-# rows tensor (4, S, C) the BACKWARD reads -- [scale | shift | mean | invstd] -- is written for all such layers by the
-# batched finalize at the end of the forward (pointflow.flush_lazy_stats: <= 28 jobs per launch), together with the
-# running statistics.  0: one pf_bn_train_rows_f32 launch per BatchNorm (round 4: 46 launches of ~6.8 us in the chain).
-TRAIN_LAZY_BN = int(os.environ.get("PF_TRAIN_LAZY_BN", "0"))
+# PF_TRAIN_LAZY_BN=1 (default since round 6: measured on the driver's box in BENCH_r05 -- the step's loss, gradient and
+# running statistics equal the eager-finalize step's bit for bit, +1.7 % train-scenes/s): the training forward finalizes a
+# BatchNorm on the critical path only where the rows are needed at once (a materialised activation, EdgeConv's apply
+# pass).  Everywhere else the CONSUMER resolves the pending BatchNorm from the producer's statistics rows (``in_bn``,
+# csrc/pf_bn_resolve.h, as the inference path does), and the rows tensor (4, S, C) the BACKWARD reads -- [scale | shift |
+# mean | invstd] -- is written for all such layers by the batched finalize at the end of the forward
+# (pointflow.flush_lazy_stats: <= 32 jobs per launch, MAX_BN_JOBS), together with the running statistics.
+# 0: one pf_bn_train_rows_f32 launch per BatchNorm (round 4: 46 launches of ~6.8 us in the chain).
+TRAIN_LAZY_BN = int(os.environ.get("PF_TRAIN_LAZY_BN", "1"))
 
 
 class _Rows(object):
@@ -209,9 +211,9 @@ def bn_rows(bn, partials, C, count, G, groups_per_stat, track=True, lazy=True):
     S = G // groups_per_stat
     rows = torch.empty((4, S, C), dtype=_F32, device=partials.device)
     if not TRAIN_LAZY_BN:
-        bn_train_rows(bn, partials, 0, C, count, G, groups_per_stat, rows=rows, bump=track)
-        if not track:
+        if not track:                                       # (before anything is launched: no running statistic moves)
             raise RuntimeError("bn_rows(track=False) needs PF_TRAIN_LAZY_BN=1")
+        bn_train_rows(bn, partials, 0, C, count, G, groups_per_stat, rows=rows, bump=True)
         return _Rows(rows, None)
     job = pointflow.bn_job(bn, partials, 0, C, count, count, G, groups_per_stat, rows[0], rows[1])
     job.rows4 = 1                                           # rows[2], rows[3]: mean, invstd
@@ -656,6 +658,9 @@ class _VolumeTrain(torch.autograd.Function):
     def forward(ctx, cost, vc, *params):
         ctx.packs = _PACKS
         x0 = cost.detach().contiguous()
+        # one scene per process (volume_supported): both BatchNorm forms below advance num_batches_tracked by ONE here
+        # (the normalise pass counts samples, the rows launch statistic groups; they agree only for a batch of one)
+        assert x0.shape[0] == 1, "the fused VolumeConv training node is built for one scene per call"
         rec = {}
 
         def bn_act(name, y, partials, addend=None):

@@ -131,13 +131,12 @@ def test_bench_line_assembles_on_the_emulator():
 
 def test_experiments_past_the_childs_budget_are_skipped_by_name(monkeypatch):
     """bench.experiments_block: a part that would START after PF_EXPERIMENTS_BUDGET_S seconds of the child's life is skipped
-    and named, every part publishes an updated line, and the order is the one that puts the never-yet-run bf16x3 kernel last."""
+    and named, and every part publishes an updated line."""
     sys.path.insert(0, ROOT)
     import bench
     monkeypatch.setenv("PF_EXPERIMENTS_BUDGET_S", "0")
     out, published = {"value": 1.0}, []
     bench.experiments_block(torch.device("cpu"), out, lambda o: published.append(json.dumps(o)))
-    assert len(published) == 5 and json.loads(published[-1]) == out
-    assert [s.split()[0] for s in out["experiments"]["skipped"]] == [
-        "lazy_bn", "pcie_inclusive", "cpu_baseline", "bf16x3_layers", "bf16x3_headline_ab"]
+    assert len(published) == 2 and json.loads(published[-1]) == out
+    assert [s.split()[0] for s in out["experiments"]["skipped"]] == ["lazy_bn", "cpu_baseline"]
     assert "cpu_baseline" not in out

@@ -2,13 +2,13 @@
 HIP shim -- one OS thread per GPU thread, barriers for __syncthreads, the wave-collective MFMA / shuffle instructions
 emulated with the ISA's lane <-> element maps) through the package's own Python wrappers and C ABI.
 
-Round 5 lost its GPU access while conv2d_wide_split_kernel (the bf16x3 tower kernel, PF_MATRIX_SPLIT) was being written;
-`hipcc` shows that a kernel compiles, this shows that its indexing, staging, weight layout, statistics rows and epilogue are
-right.  The emulator itself is pinned by the kernels that HAVE run on an MI355X (the exact-f32 tower kernels, green against
-float64 on hardware since round 2): if it reproduces them, its model of blocks, LDS, barriers and matrix instructions holds.
+Written in round 5 (no GPU access): `hipcc` shows that a kernel compiles, this shows that its indexing, staging, weight
+layout, statistics rows and epilogue are right.  The emulator itself is pinned by the kernels that HAVE run on an MI355X
+(the exact-f32 tower kernels, green against float64 on hardware since round 2): if it reproduces them, its model of
+blocks, LDS, barriers and matrix instructions holds.  (The bf16x3 tower kernel these tests were first written for was
+measured on hardware in round 6 -- 1.23-1.42x per layer, +3 % on the headline, below its adoption rule -- and removed.)
 
-Not modelled: timing, bank conflicts, the hardware's summation order inside a 16-deep bf16 block (the emulator uses an fmaf
-chain in k order: the pessimistic case).  Speed and the last bits need the device (tools/microbench_split.py, bench.py).
+Not modelled: timing, bank conflicts.  Speed needs the device (bench.py).
 """
 import ctypes
 import os
@@ -41,10 +41,10 @@ def emu(lib_built):
             fn.argtypes, fn.restype = _lib.PROTOTYPES[name]
             return fn
 
-    saved = (_lib._lib, _lib.stream, pointflow.MATRIX_SPLIT)
+    saved = (_lib._lib, _lib.stream)
     _lib._lib, _lib.stream = Proxy(), (lambda: None)
     yield lib
-    _lib._lib, _lib.stream, pointflow.MATRIX_SPLIT = saved
+    _lib._lib, _lib.stream = saved
 
 
 def _case(cin, cout, k, stride, hw, n, seed, affine):
@@ -76,37 +76,15 @@ def _check(y, part, ref, tol):
 def test_emulator_reproduces_the_hardware_validated_f32_tower_kernels(emu, cin, cout, k, stride, hw):
     """The emulator's own pin: kernels that are green against float64 on an MI355X (v_mfma_f32_32x32x2_f32 and
     v_mfma_f32_16x16x4_f32 forms, border tiles included) give the same answer here."""
-    pointflow.MATRIX_SPLIT = 0
     conv, x, aff, ref = _case(cin, cout, k, stride, hw, 2, 11, True)
     y, part = pointflow.conv2d_wide(x, conv, aff, 1, True)
     _check(y, part, ref, 2e-6)
 
 
-@pytest.mark.parametrize("cin,cout,k,stride,hw", [(64, 64, 3, 1, (5, 18)), (32, 32, 3, 1, (9, 17)), (32, 64, 5, 2, (9, 34)),
-                                                 (16, 32, 5, 2, (14, 30))])
-@pytest.mark.parametrize("affine", [False, True])
-def test_split_kernel_executes_correctly_on_the_emulator(emu, cin, cout, k, stride, hw, affine):
-    """conv2d_wide_split_kernel, all four instantiations, interior and border tiles, with and without the pending
-    BatchNorm + ReLU applied while staging: output and statistics rows against a float64 convolution, and no worse than
-    the exact-f32 kernel on the same operands (two accumulators: leading products / corrections)."""
-    conv, x, aff, ref = _case(cin, cout, k, stride, hw, 2, 5, affine)
-    pointflow.MATRIX_SPLIT = 0
-    y32, part32 = pointflow.conv2d_wide(x, conv, aff, 1, True)
-    e32 = _check(y32, part32, ref, 2e-6)
-    pointflow.MATRIX_SPLIT = 1
-    assert pointflow.conv2d_wide_split_supported(conv)
-    y, part = pointflow.conv2d_wide(x, conv, aff, 1, True)
-    e = _check(y, part, ref, 2e-6)
-    print("emulated %d->%d k%d/%d affine %d: bf16x3 %.2e, f32 %.2e of the largest output against float64"
-          % (cin, cout, k, stride, int(affine), e, e32))
-    assert e < 1.5 * e32 + 1e-7, (e, e32)
-
-
-def test_split_kernel_resolves_a_pending_batchnorm_and_serves_two_towers(emu):
+def test_tower_kernel_resolves_a_pending_batchnorm_and_serves_two_towers(emu):
     """The two remaining modes: the pending BatchNorm resolved by the kernel's own blocks from the producer's statistics
     rows (`in_bn`, AFFINE = 2), and both towers in one launch (parameter sets, set 0 written channel-last) -- each
     against the same layer run set by set with explicit affine rows."""
-    pointflow.MATRIX_SPLIT = 1
     g = torch.Generator().manual_seed(3)
     cin = cout = 32
     n, hw = 2, (9, 17)

@@ -19,10 +19,13 @@ iteration i:
     4*sqrt(3*d2)*eps + 12*eps^2 (+ its own float32 rounding), and the 16th / 17th ranked candidates of such a row
     must be closer than that.  The kernel's exactness on ITS OWN input is pinned bit for bit by
     tests/test_gpu_ops.py (NumPy brute force including order).
-(C) cfg 2 only (a second oracle chain per iteration costs CPU minutes at cfg 3): the oracle's iteration with ITS OWN
-    neighbours.  Every pixel that deviates by more than the bound of (A) must lie in the receptive field of a row
-    of (B) -- EdgeConv x3 over 5x5x5 windows: a changed row reaches the E2 output of points up to 4 lattice steps away
-    in its own sub-grid -- and every pixel outside those fields must meet the bound.
+(C) the oracle's iteration with ITS OWN neighbours.  Every pixel that deviates by more than the bound of (A) must lie in
+    the receptive field of a row of (B) -- EdgeConv x3 over 5x5x5 windows: a changed row reaches the E2 output of points
+    up to 4 lattice steps away in its own sub-grid -- and every pixel outside those fields must meet the bound.  cfg 2
+    and cfg 4: every sub-grid.  cfg 3 and cfg 5 (round 6; a second oracle chain over all 16 sub-grids of 96 000 / 144 000
+    points costs CPU minutes): a DETERMINISTIC SAMPLE of sub-grids per iteration -- the first, the last, and the two with
+    the most rows of (B) (the worst cases) -- sub-grids are independent lattices with their own kNN and their own
+    BatchNorm statistics (model.py:231-267), so a sub-grid's check is complete in itself.
 
 (A) + (B) together say: on the same prior the GPU differs from the reference algorithm ONLY by the neighbour choice in
 rows where the choice is undetermined at float32 resolution of the inputs.
@@ -60,20 +63,23 @@ def _subgrid_major(t, C, hs, ws, r):
     return t.reshape(C, 5, hs, r, ws, r).permute(3, 5, 0, 1, 2, 4).reshape(r * r, C, -1)
 
 
-def _oracle_iteration(feature, xyz, cur, interval, sd, r, feed=None):
+def _oracle_iteration(feature, xyz, cur, interval, sd, r, feed=None, only=None):
     """The flow stage after feature assembly, sub-grids sequential (model.py:231-267); ``feed``: an iterator of
-    (1,Ng,16) index tensors that replaces the oracle's kNN, one per sub-flow call in (i, j) order."""
+    (1,Ng,16) index tensors that replaces the oracle's kNN, one per sub-flow call in (i, j) order; ``only``: the
+    sub-grids g = i r + j to evaluate (the others' pixels come back as NaN)."""
     _, _, _, h, w = xyz.shape
     hs, ws = h // r, w // r
     orig = O.knn_lattice
     if feed is not None:
         O.knn_lattice = lambda x, kernel_size=5, knn=16, return_code=False: next(feed)
     try:
-        flow = torch.zeros(1, 1, hs, r, ws, r)
+        flow = torch.zeros(1, 1, hs, r, ws, r) if only is None else torch.full((1, 1, hs, r, ws, r), float("nan"))
         f7 = feature.view(1, 136, 5, hs, r, ws, r)
         x7 = xyz.view(1, 3, 5, hs, r, ws, r)
         for i in range(r):
             for j in range(r):
+                if only is not None and i * r + j not in only:
+                    continue
                 fij, _ = O.sub_flow(x7[:, :, :, :, i, :, j], f7[:, :, :, :, i, :, j], interval, sd, 16)
                 flow[:, :, :, i, :, j] = fij
     finally:
@@ -81,8 +87,8 @@ def _oracle_iteration(feature, xyz, cur, interval, sd, r, feed=None):
     return cur + flow.view(1, 1, h, w)
 
 
-@pytest.mark.parametrize("cfg,with_own_knn,is_test", [("cfg2", True, True), ("cfg3", False, True), ("cfg5", False, True),
-                                                       ("cfg4", False, False)])
+@pytest.mark.parametrize("cfg,with_own_knn,is_test", [("cfg2", True, True), ("cfg3", "sampled", True),
+                                                       ("cfg5", "sampled", True), ("cfg4", True, False)])
 def test_teacher_forced_iterations_vs_oracle(dev, cfg, with_own_knn, is_test):
     """cfg5: BASELINE configs[4]'s size (1600x1152, 7 views, 3 iterations, 16 sub-grids of 144 000 points at the last
     one); cfg4: BASELINE configs[3]'s per-GPU scene in TRAIN mode (training intrinsics, every iteration ONE lattice:
@@ -156,15 +162,28 @@ def _run(dev, cfg, with_own_knn, is_test=True):
         assert float(differ.float().mean()) < 5e-2
         # ---- (C) the oracle with its own neighbours: deviations only inside the fields of the rows of (B) -------
         if with_own_knn:
+            G = r * r
+            only = None
+            if with_own_knn == "sampled" and G > 4:
+                per_grid = differ.sum(dim=1)
+                worst = torch.argsort(per_grid, descending=True, stable=True)[:2].tolist()
+                only = sorted(set([0, G - 1] + worst))
             with torch.no_grad():
-                want_c = _oracle_iteration(feature, xyz, cur, interval, sd, r)
+                want_c = _oracle_iteration(feature, xyz, cur, interval, sd, r, only=only)
             rel_c = ((got - want_c).abs() / want_c.abs())[0, 0]                          # (h, w)
             pix = differ.view(r, r, 5, hs, ws).any(dim=2).float()                         # rows -> pixels of a sub-grid
             field = F.max_pool2d(pix.view(1, r * r, hs, ws), 9, stride=1, padding=4).view(r, r, hs, ws)
             field = field.permute(2, 0, 3, 1).reshape(h, w) > 0                           # back to image order
-            outside = rel_c[~field]
-            report("teacher_own_knn_%s_it%d" % (cfg, it), rel_max=float(rel_c.max()),
-                   frac_gt_1e4=float((rel_c > 1e-4).float().mean()), field_frac=float(field.float().mean()),
-                   rel_max_outside_fields=float(outside.max()) if outside.numel() else 0.0)
-            assert not bool(((rel_c > TEACHER_RTOL) & ~field).any()), "a pixel outside every flipped row's field deviates"
+            checked = torch.isfinite(rel_c)                                               # the evaluated sub-grids' pixels
+            assert int(checked.sum()) == (G if only is None else len(only)) * hs * ws
+            rel_v = rel_c[checked]
+            outside = rel_c[checked & ~field]
+            report("teacher_own_knn_%s%s_it%d" % (cfg, "" if is_test else "_train", it), rel_max=float(rel_v.max()),
+                   frac_gt_1e4=float((rel_v > 1e-4).float().mean()),
+                   field_frac=float(field[checked].float().mean()),
+                   rel_max_outside_fields=float(outside.max()) if outside.numel() else 0.0,
+                   frac_outside_fields_gt_1e5=float((outside > TEACHER_RTOL).float().mean()) if outside.numel() else 0.0,
+                   subgrids_checked=float(G if only is None else len(only)), subgrids=float(G))
+            assert not bool((checked & (rel_c > TEACHER_RTOL) & ~field).any()), \
+                "a pixel outside every flipped row's field deviates"
         prior_dev = preds["flow%d" % (it + 1)]

@@ -587,64 +587,6 @@ def test_edge_chain_and_mlp_nodes_vs_float64_functional(dev):
     assert e_act < 2e-5 and e_x < 3e-3 and errs[0][0] < 1e-2 and errs[len(errs) // 2][0] < 1e-3, (e_act, e_x, errs[:5])
 
 
-# ---------------------------------------------------------------------------------------------
-# the two default-off experiments of round 5, on hardware for the first time when the driver runs this file.  They launch
-# device code no MI355X has executed (the bf16x3 tower kernel, the four-row batched finalize): `isolated` runs each in a
-# child pytest process (tests/conftest.py), so that a GPU fault there ends the child, not the session
-# ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("cin,cout,k,stride,hw", [(64, 64, 3, 1, (64, 80)), (32, 32, 3, 1, (128, 160)),
-                                                 (32, 64, 5, 2, (128, 160)), (16, 32, 5, 2, (256, 320))])
-@pytest.mark.parametrize("affine", [False, True])
-@pytest.mark.isolated
-def test_experiment_split_kernel_vs_float64(dev, monkeypatch, cin, cout, k, stride, hw, affine):
-    """conv2d_wide_split_kernel (bf16x3 products, float32 accumulate; PF_MATRIX_SPLIT) on the cfg-2 tower shapes against
-    a float64 convolution, beside the exact-f32 kernel on the same operands: output, BatchNorm statistics rows."""
-    conv = torch.nn.Conv2d(cin, cout, k, stride=stride, padding=k // 2, bias=False).to(dev)
-    x = _seeded((3, cin) + hw, dev, 61)
-    aff = None
-    xin = x.double()
-    if affine:
-        sc = (1.0 + 0.3 * _seeded((3, cin), dev, 62)).contiguous()
-        sh = (0.2 * _seeded((3, cin), dev, 63)).contiguous()
-        aff = (sc, sh)
-        xin = torch.relu(xin * sc.double().view(3, cin, 1, 1) + sh.double().view(3, cin, 1, 1))
-    ref = F.conv2d(xin, conv.weight.double(), None, stride, k // 2)
-    monkeypatch.setattr(pointflow, "MATRIX_SPLIT", 0)
-    y32, _ = pointflow.conv2d_wide(x, conv, aff, 1, True)
-    monkeypatch.setattr(pointflow, "MATRIX_SPLIT", 1)
-    assert pointflow.conv2d_wide_split_supported(conv)
-    y, part = pointflow.conv2d_wide(x, conv, aff, 1, True)
-    y2, part2 = pointflow.conv2d_wide(x, conv, aff, 1, True)
-    assert torch.equal(y, y2) and torch.equal(part, part2)
-    scale = ref.abs().max()
-    e = dict(split=float((y.double() - ref).abs().max() / scale), f32=float((y32.double() - ref).abs().max() / scale),
-             stats_sum=_rel(part.sum(dim=1)[..., 0], ref.sum(dim=(2, 3))),
-             stats_sq=_rel(part.sum(dim=1)[..., 1], (ref * ref).sum(dim=(2, 3))))
-    report("experiment_split_%dto%d_k%ds%d_aff%d" % (cin, cout, k, stride, int(affine)), **e)
-    assert e["split"] < 2e-6 and e["split"] < 4.0 * e["f32"] + 2e-7, e
-    assert e["stats_sum"] < 1e-5 and e["stats_sq"] < 1e-5, e
-
-
-@pytest.mark.isolated
-def test_experiment_split_teacher_forced_cfg2(dev, monkeypatch):
-    """VERDICT r4 item 4's gate: the teacher-forced max norm of BASELINE cfg 2 (every iteration against the oracle's on the
-    same prior and neighbours, < 1e-5) with the 32- / 64-channel tower layers on the bf16x3 kernel."""
-    import test_gpu_teacher as TT
-    monkeypatch.setattr(pointflow, "MATRIX_SPLIT", 1)
-    threads = torch.get_num_threads()
-    torch.set_num_threads(max(1, min(16, threads)))
-    try:
-        TT._run(dev, "cfg2", False, True)
-    finally:
-        torch.set_num_threads(threads)
-
-
-@pytest.mark.isolated
-def test_experiment_split_forward_vs_reference_golden_cfg2(dev, monkeypatch):
-    import test_gpu_model as TM
-    monkeypatch.setattr(pointflow, "MATRIX_SPLIT", 1)
-    TM.test_forward_test_mode_vs_reference(dev, "model_cfg2_test", "cfg2")
-
 
 def _tiny_step_gradient(dev):
     from pointmvsnet_amd.model import PointMVSNet
@@ -663,13 +605,12 @@ def _tiny_step_gradient(dev):
     return float(loss), step.bucket.flat.detach().clone(), buffers
 
 
-@pytest.mark.isolated
-def test_experiment_lazy_bn_rows_step_equals_the_default_step(dev, monkeypatch):
-    """PF_TRAIN_LAZY_BN (the training forward's BatchNorms resolved by their consumers, the rows for the backward from ONE
-    batched finalize at the end of the forward; VolumeConv's normalise passes finalize for themselves): the same loss and
-    gradient as the default step to float32 rounding of a statistic's summation order, the same running statistics, and
-    bit-reproducible; then the oracle gates and graphed == eager of tests/test_gpu_model.py with it switched on."""
-    import test_gpu_model as TM
+def test_lazy_bn_step_equals_the_eager_finalize_step(dev, monkeypatch):
+    """PF_TRAIN_LAZY_BN (default 1 since round 6: the training forward's BatchNorms resolved by their consumers, the rows
+    for the backward from ONE batched finalize at the end of the forward; VolumeConv's normalise passes finalize for
+    themselves) against PF_TRAIN_LAZY_BN=0 (one pf_bn_train_rows_f32 launch per BatchNorm): the same loss and gradient to
+    float32 rounding of a statistic's summation order, the same running statistics, and bit-reproducible.  (The oracle
+    gates and graphed == eager run with the default, i.e. with it on: tests/test_gpu_model.py and the cfg-4 tests above.)"""
     monkeypatch.setattr(train_ops, "TRAIN_LAZY_BN", 0)
     l0, g0, b0 = _tiny_step_gradient(dev)
     monkeypatch.setattr(train_ops, "TRAIN_LAZY_BN", 1)
@@ -678,10 +619,5 @@ def test_experiment_lazy_bn_rows_step_equals_the_default_step(dev, monkeypatch):
     assert l1 == l2 and torch.equal(g1, g2) and torch.equal(b1, b2)
     e = dict(loss=abs(l1 - l0) / abs(l0), grad_l2=float((g1 - g0).norm() / g0.norm()),
              buffers=float((b1 - b0).abs().max() / b0.abs().max()))
-    report("experiment_lazy_bn_vs_default", **e)
+    report("lazy_bn_vs_eager_finalize", **e)
     assert e["loss"] < 1e-6 and e["grad_l2"] < 1e-4 and e["buffers"] < 1e-5, e
-    TM.test_train_step_parameter_gradients_vs_oracle_autograd(dev, monkeypatch, "tiny", 1)
-    monkeypatch.undo()                                   # (that function leaves its kNN feed patched in)
-    monkeypatch.setattr(train_ops, "TRAIN_LAZY_BN", 1)
-    if dev.type == "cuda":                               # (hipGraphs do not exist under tests/hipemu)
-        TM.test_graphed_train_step_matches_the_eager_step(dev, "tiny")
