@@ -170,7 +170,29 @@ def ptr(t):
 
 
 def stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """The current HIP stream of the current device as a void pointer.  (torch.cuda.current_stream() builds a Stream
+    object through three layers of device-index helpers: 9 us per call, measured as 17 % of the drop-in route's host time
+    in round 6 -- profiles/r06b_route_profile.md; the raw handle is one C call.)"""
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
+
+
+class _NoGuard(object):
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def on_device(dev):
+    """``with on_device(t.device):`` = torch.cuda.device(dev) when ``dev`` is not the current device, else nothing
+    (the guard's enter / exit is ~10 us of Python per operator call on the eager route)."""
+    if dev.index is None or dev.index == torch._C._cuda_getDevice():
+        return _NO_GUARD
+    return torch.cuda.device(dev)
 
 
 def require_gpu(*tensors):

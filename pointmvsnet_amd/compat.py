@@ -37,6 +37,16 @@ def install_as_pointmvsnet():
         sys.modules[alias] = mod
         parent, _, leaf = alias.rpartition(".")
         setattr(sys.modules[parent], leaf, mod)
+    # the drop-in route's two switches (round 6; PF_DROPIN_FAST=0 keeps round 5's behaviour): the operator modules'
+    # inference forwards replay from per-module hipGraphs (graph.module_forward), and get_pixel_grids hands model.py a
+    # device tensor so that its ``.to(device)`` is no synchronous host-to-device copy (functions/functions.py)
+    import os
+    import torch
+    if os.environ.get("PF_DROPIN_FAST", "1") != "0" and torch.cuda.is_available():
+        from . import graph
+        from .functions import functions
+        graph.MODULE_GRAPHS = True
+        functions.PIXEL_GRID_ON_DEVICE = True
     return pkg
 
 

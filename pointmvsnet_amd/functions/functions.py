@@ -11,8 +11,30 @@ import torch
 from .gather_knn import gather_knn
 
 
+# Set by compat.install_as_pointmvsnet() (the drop-in route for the reference's model.py): get_pixel_grids then returns
+# its grid ON THE CURRENT GPU, built once per (height, width, device).  model.py:87-88,166-167 calls it once per stage and
+# moves the result with ``.to(img_list.device)`` -- from pageable host memory that is a SYNCHRONOUS copy of up to 1 MB
+# which drains the stream three times per depth map (profiles/r06b_route_profile.md: aten::copy_ = 44 % of the route's
+# host time); on the device ``.to()`` is a no-op.  Off by default: the reference's function returns a host tensor and a
+# direct caller may rely on that.
+PIXEL_GRID_ON_DEVICE = False
+_GRID_CACHE = {}
+
+
 def get_pixel_grids(height, width):
     """(3, height*width): rows x+0.5, y+0.5, 1 in row-major pixel order."""
+    if PIXEL_GRID_ON_DEVICE and torch.cuda.is_available():
+        key = (int(height), int(width), torch.cuda.current_device())
+        grid = _GRID_CACHE.get(key)
+        if grid is None:
+            if len(_GRID_CACHE) >= 16:
+                _GRID_CACHE.clear()
+            grid = _GRID_CACHE[key] = _pixel_grids_host(height, width).to(torch.device("cuda", key[2]))
+        return grid.clone()                 # a fresh tensor per call, like the reference's
+    return _pixel_grids_host(height, width)
+
+
+def _pixel_grids_host(height, width):
     with torch.no_grad():
         cols = torch.arange(width, dtype=torch.float32)
         rows = torch.arange(height, dtype=torch.float32)

@@ -39,7 +39,7 @@ class _Ext(object):
         K = index.size(2)
         x, idx = input.contiguous(), index.contiguous()
         out = torch.empty((B, C, N, K), dtype=x.dtype, device=x.device)
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             _lib.call("pf_gather_knn_forward_" + _SUFFIX[x.dtype], _lib.ptr(x), _lib.ptr(idx), _lib.ptr(out),
                       B, C, N, K, _lib.stream(),
                       algo_bytes=float(B) * (x.element_size() * C * N * (1 + K) + 8.0 * N * K))
@@ -53,7 +53,7 @@ class _Ext(object):
             raise RuntimeError("gather_knn_backward: index.size(2) != grad_output.size(3)")
         g, idx = grad_output.contiguous(), index.contiguous()
         grad_in = torch.empty((B, C, N), dtype=g.dtype, device=g.device)
-        with torch.cuda.device(g.device):
+        with _lib.on_device(g.device):
             # (default: the scatter as a gather over the inverted index lists -- bit-reproducible; the reference's
             # float atomics when pointflow.DETERMINISTIC_BACKWARD is off)
             from .. import pointflow

@@ -288,3 +288,110 @@ class LanedForward(object):
     def synchronize(self):
         for st in self.streams:
             st.synchronize()
+
+
+# ---------------------------------------------------------------------------------------------
+# Module-level replay for the DROP-IN route (round 6)
+# ---------------------------------------------------------------------------------------------
+# The reference's model.py calls the operator modules one at a time (model.py:71-77, 113, 140-148, 211-219): 6 ImageConv
+# forwards, 1 VolumeConv, 15 EdgeConv and 5 SharedMLP forwards per depth map at cfg 2 -- ~230 kernel launches of this
+# package issued from Python between the ATen calls of model.py, on a route that model.py's own host synchronisations
+# (linspace / view on device scalars, torch.tensor(...).to(device), torch.inverse) keep host-bound
+# (profiles/r06b_route_profile.md: 12.8 ms per depth map, the GPU idle most of it).  A module's inference forward is
+# device-only and a pure function of (inputs, parameters, buffers), so it is captured ONCE per input signature in a
+# hipGraph and replayed: one launch instead of 10-35.  Switched on by compat.install_as_pointmvsnet() (MODULE_GRAPHS);
+# the plain package default is off (module forwards launch their kernels eagerly).
+MODULE_GRAPHS = False
+MODULE_GRAPH_ENTRIES = 6             # signatures kept per module (least recently used goes first)
+
+
+class _ModuleGraph(object):
+    """One captured inference forward of ``module`` for one input signature."""
+
+    def __init__(self, module, fn, tensors):
+        self.module = module
+        self.static_in = [t.detach().clone(memory_format=torch.contiguous_format) for t in tensors]
+        self.graph = torch.cuda.CUDAGraph()
+        pointflow.pack_log_begin()
+        try:
+            with torch.no_grad(), torch.cuda.graph(self.graph):
+                self.out = fn(*self.static_in)
+        finally:
+            self.packs = pointflow.pack_log_end(pin=True)
+        self.watched = list(module.parameters()) + list(module.buffers())
+        self.addresses = [t.data_ptr() for t in self.watched]
+        self.state = _module_state(module)
+
+    def stale(self):
+        return (pointflow.pack_entries_stale(self.packs)
+                or any(t.data_ptr() != a for t, a in zip(self.watched, self.addresses))
+                or self.state != _module_state(self.module))
+
+    def release(self):
+        pointflow.pack_unpin(self.packs)
+        self.packs = []
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+    def replay(self, tensors):
+        for s, t in zip(self.static_in, tensors):
+            s.copy_(t, non_blocking=True)
+        self.graph.replay()
+        return _clone_tree(self.out)         # the static outputs are overwritten by the next replay
+
+
+def _module_state(module):
+    """What a captured forward bakes in besides addresses: every sub-module's train / eval flag and the BatchNorm
+    hyper-parameters that travel as kernel arguments (momentum, eps, track_running_stats)."""
+    out = []
+    for m in module.modules():
+        out.append(m.training)
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            out.append((m.momentum, m.eps, m.track_running_stats, m.running_mean is None))
+    return out
+
+
+def _clone_tree(x):
+    if torch.is_tensor(x):
+        return x.clone()
+    if isinstance(x, dict):
+        return type(x)((k, _clone_tree(v)) for k, v in x.items())
+    if isinstance(x, (list, tuple)):
+        return type(x)(_clone_tree(v) for v in x)
+    return x
+
+
+def module_forward(module, fn, *tensors):
+    """``fn(*tensors)`` -- the device-only inference forward of ``module`` -- through the module's graph cache when
+    MODULE_GRAPHS is on: the FIRST call with a signature runs eagerly (lazy allocations, packed weights; it is an
+    ordinary forward), the second captures and replays, later ones replay.  BatchNorm running statistics and
+    ``num_batches_tracked`` advance on every replay exactly as eagerly (the update kernels are nodes of the graph).  A
+    replay after an optimizer step / ``load_state_dict`` / ``.to()`` / ``train()`` / ``eval()`` / a changed BatchNorm
+    momentum re-captures instead of serving the old state (same checks as GraphedForward, over this module's tensors)."""
+    if not MODULE_GRAPHS or torch.cuda.is_current_stream_capturing():
+        return fn(*tensors)
+    key = tuple((tuple(t.shape), t.dtype, t.device.index) for t in tensors)
+    cache = module.__dict__.setdefault("_pf_graphs", {})
+    entry = cache.get(key)
+    if entry is None:
+        cache[key] = False                   # seen once: eager now, capture next time
+        return fn(*tensors)
+    if entry is False or entry.stale():
+        if entry is not False:
+            torch.cuda.synchronize()
+            entry.release()
+        while len(cache) > MODULE_GRAPH_ENTRIES:
+            old = next(iter(cache))
+            if cache[old] is not False:
+                torch.cuda.synchronize()
+                cache[old].release()
+            del cache[old]
+        entry = _ModuleGraph(module, fn, tensors)
+    else:
+        del cache[key]                       # (re-inserted below: dict order = recency)
+    cache[key] = entry
+    return entry.replay(tensors)

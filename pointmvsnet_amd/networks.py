@@ -43,7 +43,7 @@ class _EdgeConvTrain(torch.autograd.Function):
         idx = knn_inds.contiguous()
         out = torch.empty((B * N, width), dtype=torch.float32, device=x.device)
         keep = {}
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             pointflow.edge_conv_fused(x, False, 0, cin, B, N, idx, w1, w2, bn, concat, out, width,
                                       groups_per_stat=B, keep=keep)
             pointflow.flush_counters()
@@ -60,7 +60,7 @@ class _EdgeConvTrain(torch.autograd.Function):
         concat, C, k, B, N, cin = ctx.meta
         width = (2 if concat else 1) * C
         gy = grad_out.float().transpose(1, 2).contiguous().view(B * N, width)        # point-major rows
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             grad_le, grad_gamma, grad_beta = pointflow.edge_conv_backward(keep, idx, gy, C, k, B, N, B, concat)
         dle = grad_le.view(B, N, 2 * C)
         wcat = torch.cat([w1.detach().reshape(C, cin), w2.detach().reshape(C, cin)], dim=0).float()   # (2C, K)
@@ -107,7 +107,7 @@ class _EdgeConvBase(nn.Module):
         x = feature.detach().float().contiguous()
         idx = knn_inds.contiguous()
         out = torch.empty((B * N, width), dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             pointflow.edge_conv_fused(x, False, 0, cin, B, N, idx, self.conv1.weight, self.conv2.weight,
                                       self.bn, self.concat, out, width, groups_per_stat=B)
             pointflow.flush_counters()
@@ -128,6 +128,9 @@ class _EdgeConvBase(nn.Module):
             # the composed operators give the same result, like the reference, instead of an error
             with torch.no_grad():
                 return self._forward_autograd(feature, knn_inds)
+        if feature.dtype == torch.float32:
+            from . import graph
+            return graph.module_forward(self, self._forward_fused, feature, knn_inds)
         return self._forward_fused(feature, knn_inds)
 
 
@@ -194,6 +197,7 @@ def _block_fused(block, x, samples_per_stat):
         if block.bn is not None:
             return pointflow.batch_norm_act_(y, block.bn, block.relu, samples_per_stat, partials=partials)
         return F.relu(y, inplace=True) if block.relu else y
+    pointflow.warn_library_fallback("VolumeConv layer", conv)
     y = block._crop(conv(x), x)
     if block.bn is not None:
         return pointflow.batch_norm_act_(y.contiguous(), block.bn, block.relu, samples_per_stat)
@@ -225,9 +229,12 @@ class ImageConv(nn.Module):
         Without an autograd graph the HIP tower kernels run (the batched-views path with one view); with one, the
         stock ATen composition, whose backward the training step uses."""
         if pointflow.hip_inference(imgs, self):
-            out = self.forward_views(imgs.unsqueeze(1), need=("conv0", "conv1", "conv2", "conv3"))
-            pointflow.flush_counters()
-            return {k: v[:, 0] for k, v in out.items()}
+            def run(x):
+                out = self.forward_views(x.unsqueeze(1), need=("conv0", "conv1", "conv2", "conv3"))
+                pointflow.flush_counters()
+                return {k: v[:, 0] for k, v in out.items()}
+            from . import graph
+            return graph.module_forward(self, run, imgs)
         out = {}
         x = imgs
         for name in ("conv0", "conv1", "conv2", "conv3"):
@@ -334,6 +341,7 @@ def _conv2d_block_fused(block, x, pending, samples_per_stat, defer, lazy=False, 
         y, partials = pointflow.conv2d_wide(x, conv, pending, samples_per_stat, training_bn,
                                             channel_last_out=channel_last_out)
     else:                                      # a shape the tower kernels are not built for: the library convolution
+        pointflow.warn_library_fallback("ImageConv layer", conv)
         if pending is not None:
             x = pointflow.channel_affine_(x, pending, True, samples_per_stat)
         y = block._crop(conv(x), x).contiguous() if hasattr(block, "_crop") else conv(x).contiguous()
@@ -425,9 +433,12 @@ class VolumeConv(nn.Module):
 
     def forward(self, x):
         if pointflow.hip_inference(x, self):        # reference model.py:113-115 without an autograd graph: own kernels
-            y = self.forward_fused(x.float())
-            pointflow.flush_counters()
-            return y
+            def run(v):
+                y = self.forward_fused(v)
+                pointflow.flush_counters()
+                return y
+            from . import graph
+            return graph.module_forward(self, run, x)
         full = self.conv0_1(x)
         half = self.conv1_0(x)
         quarter = self.conv2_0(half)

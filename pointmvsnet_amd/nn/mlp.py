@@ -23,9 +23,10 @@ class SharedMLP(nn.ModuleList):
         if x.dim() == 3 and len(self) > 0:
             from .. import pointflow
             if pointflow.hip_inference(x, self):           # no autograd graph: the chain on the HIP GEMM kernels
-                y = pointflow.shared_mlp_forward(list(self), x)
-                if y is not None:
-                    return y
+                blocks = list(self)
+                if pointflow.shared_mlp_supported(blocks):
+                    from .. import graph
+                    return graph.module_forward(self, lambda v: pointflow.shared_mlp_forward(blocks, v), x)
         for layer in self:
             x = layer(x)
         return x

@@ -34,23 +34,47 @@ def hip_inference(x, module):
     return not (x.requires_grad or any(p.requires_grad for p in module.parameters()))
 
 
-def shared_mlp_forward(blocks, x):
-    """SharedMLP over points (reference nn/mlp.py:45-81 with ndim = 1: [Conv1d 1x1 -> BatchNorm1d -> ReLU] x n on
-    (B, C, N)) on pf_pointwise_gemm_f32: the chain stays point-major, every BatchNorm + ReLU is applied by the next
-    GEMM's A load, statistics pooled over the batch like BatchNorm1d.  Returns (B, C_out, N), or None when a block
-    is not of that form (the caller then runs the stock composition)."""
-    B, C, N = x.shape
+_LIBRARY_WARNED = set()
+
+
+def warn_library_fallback(what, conv):
+    """Say ONCE per layer shape that a convolution of the operator layer runs on the library (MIOpen through ATen)
+    instead of this package's kernels: widths / kernel sizes the HIP kernels are not built for keep the reference's
+    results but not the measured speed, and "no library kernel on the path" stops being true for that model."""
+    key = (what, type(conv).__name__, conv.in_channels, conv.out_channels, tuple(conv.kernel_size), tuple(conv.stride))
+    if key in _LIBRARY_WARNED:
+        return
+    _LIBRARY_WARNED.add(key)
+    import warnings
+    warnings.warn("pointmvsnet_amd: %s %s(%d -> %d, kernel %s, stride %s) is not a shape the HIP kernels are built for; "
+                  "it runs on the library convolution (same results, not the measured speed)"
+                  % (what, key[1], key[2], key[3], key[4], key[5]), RuntimeWarning, stacklevel=3)
+
+
+def shared_mlp_supported(blocks):
+    """The form shared_mlp_forward is built for: [Conv1d 1x1 (no bias) -> BatchNorm1d -> ReLU] blocks of GEMM widths."""
     for blk in blocks:
         conv, bn = blk.conv, blk.bn
         if (type(conv) is not torch.nn.Conv1d or conv.kernel_size != (1,) or conv.stride != (1,) or conv.groups != 1
                 or conv.bias is not None or bn is None or not blk.relu
                 or (conv.out_channels + 31) // 32 * 32 not in (32, 64, 128)       # pf_pointwise_gemm_f32's widths
                 or bn.momentum is None or not bn.affine):
-            return None
+            return False
+    return True
+
+
+def shared_mlp_forward(blocks, x):
+    """SharedMLP over points (reference nn/mlp.py:45-81 with ndim = 1: [Conv1d 1x1 -> BatchNorm1d -> ReLU] x n on
+    (B, C, N)) on pf_pointwise_gemm_f32: the chain stays point-major, every BatchNorm + ReLU is applied by the next
+    GEMM's A load, statistics pooled over the batch like BatchNorm1d.  Returns (B, C_out, N), or None when a block
+    is not of that form (the caller then runs the stock composition)."""
+    B, C, N = x.shape
+    if not shared_mlp_supported(blocks):
+        return None
     dev = x.device
     X, pm, ldx, K = x.contiguous(), False, 0, C
     affine = None
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         for blk in blocks:
             Wt, cout = pack_weight_t(blk.conv.weight)
             Z = torch.empty((B * N, cout), dtype=_F32, device=dev)
@@ -374,7 +398,7 @@ def flush_lazy_stats(device=None):
             while len(layers) <= k:
                 layers.append([])
             layers[k].append(z)
-        with torch.cuda.device(torch.device(dev)):
+        with _lib.on_device(torch.device(dev)):
             cur = None
             for z in lazy:                     # a job made on another stream (the training step's flow tower): its
                 origin = getattr(z, "origin", None)        # tensors are read here, tell the caching allocator

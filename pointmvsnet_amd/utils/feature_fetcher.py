@@ -17,7 +17,7 @@ class _Fetch(torch.autograd.Function):
         B, V, C, H, W = maps.shape
         N = pts.size(2)
         out = torch.empty((B, V, C, N), dtype=torch.float32, device=maps.device)
-        with torch.cuda.device(maps.device):
+        with _lib.on_device(maps.device):
             _lib.call("pf_fetch_forward_f32", _lib.ptr(maps), _lib.ptr(pts), _lib.ptr(K), _lib.ptr(E),
                       _lib.ptr(out), B, V, C, H, W, N, _lib.stream(),
                       algo_bytes=4.0 * B * (V * C * H * W + 3 * N + V * C * N))
@@ -33,7 +33,7 @@ class _Fetch(torch.autograd.Function):
         N = pts.size(2)
         g = grad_out.contiguous()
         grad_maps = torch.empty((B, V, C, H, W), dtype=torch.float32, device=g.device)
-        with torch.cuda.device(g.device):
+        with _lib.on_device(g.device):
             _lib.call("pf_fetch_backward_f32", _lib.ptr(g), _lib.ptr(pts), _lib.ptr(K),
                       _lib.ptr(E) if ctx.has_ext else None, _lib.ptr(grad_maps), B, V, C, H, W, N, _lib.stream(),
                       algo_bytes=4.0 * B * (V * C * H * W + 3 * N + V * C * N))
@@ -61,6 +61,17 @@ class FeatureFetcher(nn.Module):
 
     def forward(self, feature_maps, pts, cam_intrinsics, cam_extrinsics):
         maps, p, K, E = _prep(feature_maps, pts, cam_intrinsics, cam_extrinsics)
+        if not (torch.is_grad_enabled() and maps.requires_grad):
+            # nothing to differentiate (the reference's test loop, test.py:61): the launch without an autograd node --
+            # model.py makes 31 of these calls per depth map at cfg 2, the node's bookkeeping is most of their host cost
+            B, V, C, H, W = maps.shape
+            N = p.size(2)
+            out = torch.empty((B, V, C, N), dtype=torch.float32, device=maps.device)
+            with _lib.on_device(maps.device):
+                _lib.call("pf_fetch_forward_f32", _lib.ptr(maps), _lib.ptr(p), _lib.ptr(K), _lib.ptr(E),
+                          _lib.ptr(out), B, V, C, H, W, N, _lib.stream(),
+                          algo_bytes=4.0 * B * (V * C * H * W + 3 * N + V * C * N))
+            return out
         return _Fetch.apply(maps, p, K, E)
 
 
@@ -74,7 +85,7 @@ def fetch_variance(feature_maps, pts, cam_intrinsics, cam_extrinsics, ref_overri
     if ref_override and N % (H * W) != 0:
         raise RuntimeError("fetch_variance: ref_override needs N to be a multiple of H*W")
     out = torch.empty((B, C, N), dtype=torch.float32, device=maps.device)
-    with torch.cuda.device(maps.device):
+    with _lib.on_device(maps.device):
         _lib.call("pf_fetch_variance_f32", _lib.ptr(maps), _lib.ptr(p), _lib.ptr(K), _lib.ptr(E), _lib.ptr(out),
                   B, V, C, H, W, N, int(bool(ref_override)), _lib.stream(),
                   algo_bytes=4.0 * B * (V * C * H * W + 3 * N + C * N))
@@ -93,7 +104,7 @@ def to_channel_last(maps):
     C, H, W = maps.shape[-3:]
     P = maps.numel() // (C * H * W)
     out = torch.empty(tuple(maps.shape[:-3]) + (H, W, C), dtype=torch.float32, device=maps.device)
-    with torch.cuda.device(maps.device):
+    with _lib.on_device(maps.device):
         _lib.call("pf_nchw_to_nhwc_f32", _lib.ptr(maps), _lib.ptr(out), P, C, H * W, _lib.stream(),
                   algo_bytes=8.0 * maps.numel())
     return out
@@ -130,12 +141,12 @@ def frustum_variance(feature_maps, kinv, rinv, t, depths, cam_intrinsics, cam_ex
     if channel_last:
         if maps_cl is None:
             maps_cl = to_channel_last(maps)
-        with torch.cuda.device(maps.device):
+        with _lib.on_device(maps.device):
             _lib.call("pf_frustum_variance_cl_f32", _lib.ptr(maps_cl), _lib.ptr(kinv), _lib.ptr(rinv), _lib.ptr(t),
                       _lib.ptr(depths), _lib.ptr(K), _lib.ptr(E), _lib.ptr(out), _lib.ptr(world), B, V, C, H, W, D,
                       _lib.stream(), algo_bytes=4.0 * B * (V * C * H * W + (3 * N if want_points else 0) + C * N))
         return out, world
-    with torch.cuda.device(maps.device):
+    with _lib.on_device(maps.device):
         _lib.call("pf_frustum_variance_f32", _lib.ptr(maps), _lib.ptr(kinv), _lib.ptr(rinv), _lib.ptr(t),
                   _lib.ptr(depths), _lib.ptr(K), _lib.ptr(E), _lib.ptr(out), _lib.ptr(world), B, V, C, H, W, D,
                   _lib.stream(), algo_bytes=4.0 * B * (V * C * H * W + (3 * N if want_points else 0) + C * N))

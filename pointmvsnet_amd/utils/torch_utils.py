@@ -44,7 +44,7 @@ def knn_lattice(xyz, kernel_size=5, knn=16, with_codes=False, with_idx=True):
     idx = torch.empty((B, D * H * W, knn), dtype=torch.int64, device=xyz.device) if need_idx else None
     codes = torch.empty((B, D * H * W, knn), dtype=torch.uint8, device=xyz.device) if with_codes else None
     strides = (ctypes.c_int64 * 5)(*xyz.stride())
-    with torch.cuda.device(xyz.device):
+    with _lib.on_device(xyz.device):
         _lib.call("pf_knn_lattice_f32", _lib.ptr(xyz), strides, B, D, H, W, int(kernel_size), int(knn),
                   _lib.ptr(idx), _lib.ptr(codes), _lib.stream(),
                   algo_bytes=float(B * D * H * W) * (12.0 + (8.0 * knn if with_idx else 0.0) + (knn if with_codes else 0.0)))

@@ -211,6 +211,68 @@ def test_reference_model_py_runs_unchanged_on_our_operators(dev, tag, cfg):
     assert worst < DEPTH_RTOL and err_wp < 1e-3
 
 
+def test_module_graphs_of_the_drop_in_route_equal_the_eager_modules(dev, monkeypatch):
+    """graph.module_forward (round 6): the reference's model.py on the operator layer with the modules' inference forwards
+    replayed from per-module hipGraphs and get_pixel_grids on the device (compat.install_as_pointmvsnet's defaults)
+    against the same route with both switched off -- every prediction bit for bit, over three scenes (the first forward
+    meets every signature for the first time, later ones replay), the BatchNorm running statistics and
+    num_batches_tracked included; then a weight changed in place and a train() -> eval() flip must re-capture."""
+    from pointmvsnet_amd import compat, graph
+    from pointmvsnet_amd.functions import functions as FN
+    ref = compat.load_reference_model(_reference_model_file())
+    nets = []
+    for _ in range(2):
+        net = ref.PointMVSNet()
+        synthetic.seed_weights(net, seed=0)
+        nets.append(net.to(dev).train())
+    scenes = [synthetic.make_config("tiny", seed=s) for s in (0, 5, 9)]
+    img_scales, inter_scales = scenes[0][1], scenes[0][2]
+
+    def run(net, fast, data):
+        monkeypatch.setattr(graph, "MODULE_GRAPHS", fast)
+        monkeypatch.setattr(FN, "PIXEL_GRID_ON_DEVICE", fast)
+        with torch.no_grad():
+            return net({k: v.to(dev) for k, v in data.items()}, img_scales, inter_scales, isFlow=True, isTest=True)
+
+    def same(a, b):
+        for key in a:
+            assert torch.equal(a[key], b[key]), key
+        for (ka, va), (kb, vb) in zip(nets[0].state_dict().items(), nets[1].state_dict().items()):
+            assert torch.equal(va, vb), ka
+
+    for data, _, _ in scenes:
+        same(run(nets[0], False, data), run(nets[1], True, data))
+    replayed = [m for m in nets[1].modules() if any(e is not False for e in m.__dict__.get("_pf_graphs", {}).values())]
+    assert len(replayed) >= 6, "towers, VolumeConv?, EdgeConv x3 and the MLP should hold captured graphs"
+    with torch.no_grad():
+        for net in nets:
+            net.flow_mlp[0][0].conv.weight.mul_(1.5)             # in place: version counter moves, storage stays
+            net.coarse_img_conv.conv1[0].bn.momentum = 0.3
+    same(run(nets[0], False, scenes[1][0]), run(nets[1], True, scenes[1][0]))
+    for net in nets:
+        net.eval()
+    same(run(nets[0], False, scenes[2][0]), run(nets[1], True, scenes[2][0]))
+    same(run(nets[0], False, scenes[0][0]), run(nets[1], True, scenes[0][0]))
+
+
+def test_library_convolution_fallback_is_announced_once(dev):
+    """A tower of widths the HIP kernels are not built for keeps working on the library convolution -- and says so, once
+    per layer shape (the fallback used to be silent)."""
+    import warnings
+    from pointmvsnet_amd import pointflow
+    from pointmvsnet_amd.networks import ImageConv
+    pointflow._LIBRARY_WARNED.clear()
+    tower = ImageConv(12).to(dev).train()
+    x = torch.randn(1, 3, 64, 80, device=dev)
+    with torch.no_grad():
+        with pytest.warns(RuntimeWarning, match="runs on the library convolution"):
+            want = tower(x)
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")                       # second time: silence
+            again = tower(x)
+    assert want["conv3"].shape == again["conv3"].shape == (1, 96, 8, 10)
+
+
 def test_graphed_forward_matches_eager_and_replays_on_new_scenes(dev):
     from pointmvsnet_amd.graph import GraphedForward
     data_a, img_scales, inter_scales = synthetic.make_config("tiny", seed=0)
