@@ -320,12 +320,31 @@ class _ModuleGraph(object):
             self.packs = pointflow.pack_log_end(pin=True)
         self.watched = list(module.parameters()) + list(module.buffers())
         self.addresses = [t.data_ptr() for t in self.watched]
-        self.state = _module_state(module)
+        self.mods = list(module.modules())
+        self.bns = [m for m in self.mods if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)]
+        self.state = self._state()
+        self.replays = 0
+
+    def _state(self):
+        """What a captured forward bakes in besides addresses: every sub-module's train / eval flag and the BatchNorm
+        hyper-parameters that travel as kernel arguments (momentum, eps, track_running_stats)."""
+        return ([m.training for m in self.mods],
+                [(b.momentum, b.eps, b.track_running_stats, b.running_mean is None) for b in self.bns])
 
     def stale(self):
+        """Checked on EVERY replay: the packed weights' sources (version counter, storage), the storage address of every
+        parameter / buffer seen at capture, the sub-modules' modes and BatchNorm hyper-parameters.  The module TREE is
+        walked again only every 64th replay (a registered / removed sub-module or a parameter replaced by setattr
+        changes the objects): the walk costs more than the replay's own enqueue."""
+        self.replays += 1
+        if self.replays % 64 == 0:
+            if (len(self.mods) != sum(1 for _ in self.module.modules())
+                    or any(a is not b for a, b in zip(self.watched,
+                                                      list(self.module.parameters()) + list(self.module.buffers())))):
+                return True
         return (pointflow.pack_entries_stale(self.packs)
                 or any(t.data_ptr() != a for t, a in zip(self.watched, self.addresses))
-                or self.state != _module_state(self.module))
+                or self.state != self._state())
 
     def release(self):
         pointflow.pack_unpin(self.packs)
@@ -342,17 +361,6 @@ class _ModuleGraph(object):
             s.copy_(t, non_blocking=True)
         self.graph.replay()
         return _clone_tree(self.out)         # the static outputs are overwritten by the next replay
-
-
-def _module_state(module):
-    """What a captured forward bakes in besides addresses: every sub-module's train / eval flag and the BatchNorm
-    hyper-parameters that travel as kernel arguments (momentum, eps, track_running_stats)."""
-    out = []
-    for m in module.modules():
-        out.append(m.training)
-        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
-            out.append((m.momentum, m.eps, m.track_running_stats, m.running_mean is None))
-    return out
 
 
 def _clone_tree(x):

@@ -45,10 +45,21 @@ def _prep(feature_maps, pts, cam_intrinsics, cam_extrinsics):
     if feature_maps.dim() != 5 or pts.dim() != 3 or pts.size(1) != 3:
         raise RuntimeError("FeatureFetcher: expected feature_maps (B,V,C,H,W) and pts (B,3,N)")
     B, V = feature_maps.shape[:2]
-    maps = feature_maps.float().contiguous()
-    p = pts.detach().float().contiguous()
-    K = cam_intrinsics.detach().float().reshape(B, V, 3, 3).contiguous()
-    E = None if cam_extrinsics is None else cam_extrinsics.detach().float().reshape(B, V, 3, 4).contiguous()
+    f32 = torch.float32
+    # (the common case costs nothing: float32, contiguous tensors pass through untouched -- every no-op conversion is a
+    # dispatcher round trip, and model.py makes 31 of these calls per depth map)
+    maps = feature_maps if (feature_maps.dtype == f32 and feature_maps.is_contiguous()) else feature_maps.float().contiguous()
+    p = pts.detach()
+    if p.dtype != f32 or not p.is_contiguous():
+        p = p.float().contiguous()
+    K = cam_intrinsics.detach()
+    if K.dtype != f32 or not K.is_contiguous() or K.dim() != 4:
+        K = K.float().reshape(B, V, 3, 3).contiguous()
+    E = None
+    if cam_extrinsics is not None:
+        E = cam_extrinsics.detach()
+        if E.dtype != f32 or not E.is_contiguous() or E.dim() != 4:
+            E = E.float().reshape(B, V, 3, 4).contiguous()
     return maps, p, K, E
 
 
