@@ -441,21 +441,6 @@ int pf_conv2d_wide_sets_f32(const float* x, int x_layout, const float* wp, int64
                             const float* in_scale, const float* in_shift, const pf_bn_job* in_bn, int samples_per_stat,
                             double* partials, int out_channel_last, void* stream);
 
-/* The DIRECT (vector-pipe) form of the towers' 8- and 16-channel layers (round 6; csrc/conv2d_wide.hip,
- * conv2d_direct_kernel): the same convolution, staging, parameter sets, raw NCHW output and float64 statistics rows as
- * pf_conv2d_wide_sets_f32, computed with packed float32 multiply-adds (v_pk_fma_f32: on gfx950 the vector pipe's float32
- * peak equals the matrix pipe's) -- a lane owns 1-4 vertically adjacent output pixels x all output channels, the weights
- * are wave-uniform scalar-register pairs.  wp: (sets, K, K, Cin, Cout) float32, wp[kh][kw][ci][co] = w[co][ci][kh][kw],
- * 32-byte aligned, wp_set_stride in floats (a multiple of 8).  partials: (N, pf_conv2d_direct_blocks(...), Cout, 2).
- * Shapes: 3x3/1 8 -> 8 and 16 -> 16, 5x5/2 8 -> 16 (pf_conv2d_direct_supported); no channel-last output.  Exact float32
- * fmaf chains in (kw, kh, ci) order: results differ from the matrix form's in the last bits. */
-int pf_conv2d_direct_supported(int64_t Cin, int64_t Cout, int kernel_size, int stride);
-int pf_conv2d_direct_blocks(int64_t Cin, int64_t Cout, int64_t Hi, int64_t Wi, int kernel_size, int stride);
-int pf_conv2d_direct_sets_f32(const float* x, int x_layout, const float* wp, int64_t wp_set_stride, int sets, float* y,
-                              int64_t N, int64_t Cin, int64_t Cout, int64_t Hi, int64_t Wi, int kernel_size, int stride,
-                              const float* in_scale, const float* in_shift, const pf_bn_job* in_bn, int samples_per_stat,
-                              double* partials, void* stream);
-
 /* ---- rows M (last layer) + H + T : flow head ---------------------------------------------------
  * Z (G*Ng, ldz) holds the pre-BN output of the 64->16 MLP layer.  Per pixel of the (h,w) grid:
  * a = relu(Z*scale+shift); flow_d = sum_c w_out[c]*a_c for the 5 hypotheses; p = softmax(-flow);

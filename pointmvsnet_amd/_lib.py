@@ -71,10 +71,6 @@ PROTOTYPES = {
     "pf_conv2d_wide_blocks": ([_i64, _i64, _i64, _i], _i),
     "pf_conv2d_wide_f32": ([_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i, _i, _vp, _vp, ctypes.POINTER(BnJob), _i,
                             _vp, _i, _vp], _i),
-    "pf_conv2d_direct_supported": ([_i64, _i64, _i, _i], _i),
-    "pf_conv2d_direct_blocks": ([_i64, _i64, _i64, _i64, _i, _i], _i),
-    "pf_conv2d_direct_sets_f32": ([_vp, _i, _vp, _i64, _i, _vp, _i64, _i64, _i64, _i64, _i64, _i, _i, _vp, _vp,
-                                   ctypes.POINTER(BnJob), _i, _vp, _vp], _i),
     "pf_conv2d_wide_sets_f32": ([_vp, _i, _vp, _i64, _i, _vp, _i64, _i64, _i64, _i64, _i64, _i, _i, _vp, _vp,
                                  ctypes.POINTER(BnJob), _i, _vp, _i, _vp], _i),
     "pf_norm_blocks": ([_i64], _i),

@@ -674,276 +674,6 @@ int launch_wide16(const float* x, const float* wp, float* y, WideGeom g, int64_t
   return launch_wide16_mode<KS, STRIDE, CIN, COUT, 0>(x, wp, y, g, N, nullptr, nullptr, partials, none, none, s);
 }
 
-// ------------------------------------------------------------------------------------------------
-// DIRECT form of the 8- and 16-channel layers (round 6): the convolution on the VECTOR pipe.
-// Why: on gfx950 the f32 matrix peak equals the packed-f32 vector peak (157.3 TF both: v_mfma_f32_16x16x4_f32 does 256
-// flop per cycle and CU, v_pk_fma_f32 on 4 x 16 lanes 256 as well), an f32 MFMA and a VALU instruction cannot overlap on
-// a SIMD (profiles/archive/r03/r03j), and with 8 output channels half of an MFMA tile multiplies zeros.  So for these
-// layers the matrix core buys nothing and costs its operand traffic: one LDS read per MFMA step and lane, plus the
-// address arithmetic around it (r03i: the 8 -> 8 layer spends 51 of its 65 us with the MFMAs removed).  Here a lane owns
-// PXT vertically adjacent output pixels x ALL output channels in registers, reads an input pixel's channels ONCE (16-byte
-// LDS pieces, lanes = adjacent pixels) for up to KS x C_out x C_in / ... multiply-adds, and takes the weights as
-// wave-uniform SGPR pairs straight from the scalar cache -- host-packed [kh][kw][ci][co] -- so the inner instruction is
-//     v_pk_fma_f32  acc[pixel j][co, co+1] += in[j + kh][kw][ci] (one half of a register pair, picked by op_sel) * s[w pair]
-// with no operand movement at all: two multiply-adds per lane and cycle-slot, the pipe's full rate.
-// Same contract as conv2d_wide16_kernel: staging (PatchStager, pending BatchNorm + ReLU on the way), parameter sets,
-// raw NCHW output, float64 statistics rows per block; a block walks PF_DIRECT_TPB tiles with the next patch in flight.
-// ------------------------------------------------------------------------------------------------
-template <int KS, int STRIDE, int CIN, int COUT>
-struct DirectCfg {
-  static constexpr int TW = 32;                         // lanes along W (adjacent pixels: conflict-free 16-byte reads)
-  static constexpr int TR = 256 / TW;                   // thread rows
-  // vertically adjacent output pixels per lane (they share KS - 1 of their KS input rows)
-#ifndef PF_DIRECT_PXT
-#define PF_DIRECT_PXT 2
-#endif
-  static constexpr int PXT = STRIDE == 2 ? 1 : (CIN <= 8 ? PF_DIRECT_PXT : (PF_DIRECT_PXT > 2 ? 2 : PF_DIRECT_PXT));
-  static constexpr int TH = TR * PXT;
-  static constexpr int PAD = KS / 2;
-  static constexpr int PH = (TH - 1) * STRIDE + KS, PW = (TW - 1) * STRIDE + KS;
-  static constexpr int NPIX = PH * PW;
-  static constexpr int CINP = (CIN + 3) / 4 * 4;
-  static constexpr int RS = CINP + 4;
-  static constexpr int PATCH = NPIX * RS;
-  static constexpr int IR = (PXT - 1) * STRIDE + KS;    // input rows a lane's pixels touch
-  static constexpr size_t LDS = sizeof(float) * (size_t)(PATCH + 2 * CINP) + sizeof(double) * 4 * COUT * 2;
-  static_assert(COUT % 2 == 0 && CIN % 4 == 0, "channel pairs, 16-byte pieces");
-  static_assert(PATCH * sizeof(float) >= 4096, "pf_bn_resolve's scratch lives in the (still empty) patch");
-  static_assert(LDS <= 80 * 1024, "two blocks per CU");
-};
-
-typedef float f32x8 __attribute__((ext_vector_type(8)));
-
-// acc.xy += (hi ? in.y : in.x) * w.xy ; w wave-uniform (an SGPR pair)
-__device__ __forceinline__ void pk_fma_sel(f32x2& acc, const f32x2& in, const f32x2& w, bool hi) {
-  if (hi)
-    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(in), "s"(w));
-  else
-    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(in), "s"(w));
-}
-
-#ifndef PF_DIRECT_TPB
-#define PF_DIRECT_TPB 4
-#endif
-#ifndef PF_DIRECT_WAVES
-#define PF_DIRECT_WAVES 3                 // waves per SIMD the register allocation leaves room for (blocks per CU)
-#endif
-int direct_blocks(int tiles) { return (tiles + PF_DIRECT_TPB - 1) / PF_DIRECT_TPB; }
-
-template <int KS, int STRIDE, int CIN, int COUT, int AFFINE>
-__global__ __launch_bounds__(256, PF_DIRECT_WAVES) void conv2d_direct_kernel(const float* __restrict__ x, const float* __restrict__ wp,
-                                                            float* __restrict__ y, WideGeom g,
-                                                            const float* __restrict__ in_scale,
-                                                            const float* __restrict__ in_shift,
-                                                            double* __restrict__ partials, pf_bn_job in_bn,
-                                                            pf_bn_job in_bn1) {
-  using C = DirectCfg<KS, STRIDE, CIN, COUT>;
-  constexpr int PW = C::PW, RS = C::RS, NPIX = C::NPIX, PXT = C::PXT, IR = C::IR, CP = COUT / 2, CQ = CIN / 4;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* patch = lds;
-  float* aff = lds + C::PATCH;
-  double* red = reinterpret_cast<double*>(aff + 2 * C::CINP);
-
-  const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tx = tid & (C::TW - 1), ty = tid / C::TW;
-  const int n = blockIdx.y;
-  const int plane_i = g.Hi * g.Wi;
-  const int set = wide_set(g, n);
-  const float* xb = x + (int64_t)wide_input_sample(g, n, set) * CIN * plane_i;
-  const float* __restrict__ w = wp + (int64_t)set * g.w_stride;        // wave-uniform: scalar loads below
-  const int tiles = g.tiles_h * g.tiles_w;
-  const int nb = gridDim.x;
-
-  PatchStager<CIN, NPIX, PW, RS> st;
-  st.init(plane_i, g.Wi);
-  int tile = blockIdx.x;
-  auto tile_origin = [&](int t, int& oh0, int& ow0) {
-    const int th = t / g.tiles_w;
-    oh0 = th * C::TH;
-    ow0 = (t - th * g.tiles_w) * C::TW;
-  };
-  {
-    int oh0, ow0;
-    tile_origin(tile, oh0, ow0);
-    st.load(xb, plane_i, oh0 * STRIDE - C::PAD, ow0 * STRIDE - C::PAD, g.Hi, g.Wi);
-  }
-  wide_affine_prologue<CIN, AFFINE>(aff, in_scale, in_shift, AFFINE == 2 ? (n - set * g.spset) / g.sps : n / g.sps,
-                                    set ? in_bn1 : in_bn, reinterpret_cast<double*>(patch));
-
-  const float* pbase = patch + ((ty * PXT * STRIDE) * PW + tx * STRIDE) * RS;
-  const int plane_o = g.Ho * g.Wo;
-  float* const yn = y + (int64_t)n * COUT * plane_o;
-  float fs[COUT], fq[COUT];                            // this lane's sums over the block's tiles (<= TPB * PXT values each)
-#pragma unroll
-  for (int c = 0; c < COUT; ++c) fs[c] = fq[c] = 0.0f;
-#pragma unroll 1
-  for (; tile < tiles; tile += nb) {
-    int oh0, ow0;
-    tile_origin(tile, oh0, ow0);
-    st.template commit<(AFFINE != 0)>(patch, aff);
-    __syncthreads();
-    if (tile + nb < tiles) {
-      int noh0, now0;
-      tile_origin(tile + nb, noh0, now0);
-      st.load(xb, plane_i, noh0 * STRIDE - C::PAD, now0 * STRIDE - C::PAD, g.Hi, g.Wi);
-    }
-    f32x2 acc[PXT][CP];
-#pragma unroll
-    for (int j = 0; j < PXT; ++j)
-#pragma unroll
-      for (int c = 0; c < CP; ++c) acc[j][c] = (f32x2){0.0f, 0.0f};
-    // Weights: 32 floats per step ([CPS input channels][C_out], contiguous in the packed layout) as TWO 16-dword scalar
-    // loads, issued a whole step -- 64 packed multiply-adds, 256 issue cycles -- before their first use.  Scalar loads
-    // return out of order, so the only wait there is drains ALL of them: the step therefore starts with that wait (for
-    // the loads of the previous step: long done), THEN issues the next step's loads, then multiplies.  With the load next
-    // to its use (what the compiler schedules on its own) every 16 instructions waited out a scalar-cache round trip and
-    // the kernel ran at a quarter of the pipe's rate (round 6, first hardware run: 8 -> 8 68.6 us, matrix form 51.7).
-    constexpr int CPS = 32 / COUT;                       // input channels per step (4 or 2)
-    constexpr int TPK = CIN / CPS;                       // steps per row tap
-    constexpr int TS = KS * TPK;                         // steps per horizontal tap
-    static_assert(CIN % CPS == 0, "whole steps per row tap");
-    struct W32 {
-      f32x16 a, b;
-    };
-    auto wload = [&](int kw, int t) {
-      const float* p = w + (((t / TPK) * KS + kw) * CIN + (t % TPK) * CPS) * COUT;
-      W32 r;
-      r.a = *reinterpret_cast<const f32x16*>(p);
-      r.b = *reinterpret_cast<const f32x16*>(p + 16);
-      return r;
-    };
-    W32 cur = wload(0, 0);
-#pragma unroll
-    for (int kw = 0; kw < KS; ++kw) {
-      // the column of input pixels this lane's PXT outputs read at horizontal tap kw
-      f32x2 col[IR][CIN / 2];
-#pragma unroll
-      for (int r = 0; r < IR; ++r)
-#pragma unroll
-        for (int qd = 0; qd < CQ; ++qd) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(pbase + (r * PW + kw) * RS + 4 * qd);
-          col[r][2 * qd] = (f32x2){v[0], v[1]};
-          col[r][2 * qd + 1] = (f32x2){v[2], v[3]};
-        }
-#pragma unroll
-      for (int t = 0; t < TS; ++t) {
-        const bool last = kw + 1 == KS && t + 1 == TS;
-        __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0): `cur` (and this column's LDS reads) have landed
-        __builtin_amdgcn_sched_barrier(0);
-        const W32 nxt = last ? cur : (t + 1 < TS ? wload(kw, t + 1) : wload(kw + 1, 0));
-        __builtin_amdgcn_sched_barrier(0);               // (the next step's loads are in flight before this step's arithmetic)
-        const int kh = t / TPK;
-#pragma unroll
-        for (int cc = 0; cc < CPS; ++cc) {
-          const int ci = (t % TPK) * CPS + cc;
-          const int e0 = cc * COUT;                      // this channel's C_out weights inside the 32 floats
-#pragma unroll
-          for (int j = 0; j < PXT; ++j)
-#pragma unroll
-            for (int c = 0; c < CP; ++c) {
-              const int e = e0 + 2 * c;
-              const f32x2 wv = e < 16 ? (f32x2){cur.a[e], cur.a[e + 1]} : (f32x2){cur.b[e - 16], cur.b[e - 15]};
-              pk_fma_sel(acc[j][c], col[j * STRIDE + kh][ci >> 1], wv, (ci & 1) != 0);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        cur = nxt;
-      }
-    }
-    // epilogue: lane (ty, tx) holds output rows oh0 + ty PXT + j, column ow0 + tx, every channel
-    const int ow = ow0 + tx;
-    const bool whole = oh0 + C::TH <= g.Ho && ow0 + C::TW <= g.Wo;       // block-uniform
-    float* dst = yn + ((oh0 + ty * PXT) * g.Wo + ow);
-#pragma unroll
-    for (int j = 0; j < PXT; ++j) {
-      const bool ok = whole || (oh0 + ty * PXT + j < g.Ho && ow < g.Wo);
-      if (ok) {
-#pragma unroll
-        for (int c = 0; c < CP; ++c) {
-          dst[(2 * c) * plane_o + j * g.Wo] = acc[j][c][0];
-          dst[(2 * c + 1) * plane_o + j * g.Wo] = acc[j][c][1];
-          fs[2 * c] += acc[j][c][0];
-          fq[2 * c] += acc[j][c][0] * acc[j][c][0];
-          fs[2 * c + 1] += acc[j][c][1];
-          fq[2 * c + 1] += acc[j][c][1] * acc[j][c][1];
-        }
-      }
-    }
-    __syncthreads();                                   // every wave is done with the patch: the next commit may land
-  }
-  if (partials != nullptr) {
-    // lanes -> wave (fixed butterfly), waves -> block in wave order: one float64 row per block
-#pragma unroll
-    for (int c = 0; c < COUT; ++c) {
-      double ds = (double)fs[c], dq = (double)fq[c];
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        ds += __shfl_xor(ds, o);
-        dq += __shfl_xor(dq, o);
-      }
-      if ((tid & 63) == 0) {
-        red[(wave * COUT + c) * 2 + 0] = ds;
-        red[(wave * COUT + c) * 2 + 1] = dq;
-      }
-    }
-    __syncthreads();
-    if (tid < COUT) {
-      double ts = 0.0, tq = 0.0;
-#pragma unroll
-      for (int wv_ = 0; wv_ < 4; ++wv_) {
-        ts += red[(wv_ * COUT + tid) * 2 + 0];
-        tq += red[(wv_ * COUT + tid) * 2 + 1];
-      }
-      double* o = partials + (((int64_t)n * gridDim.x + blockIdx.x) * COUT + tid) * 2;
-      o[0] = ts;
-      o[1] = tq;
-    }
-  }
-}
-
-template <int KS, int STRIDE, int CIN, int COUT, int AFFINE>
-int launch_direct_mode(const float* x, const float* wp, float* y, WideGeom g, int64_t N, const float* in_scale,
-                       const float* in_shift, double* partials, const pf_bn_job& in_bn, const pf_bn_job& in_bn1,
-                       hipStream_t s) {
-  using C = DirectCfg<KS, STRIDE, CIN, COUT>;
-  if (C::LDS > 64 * 1024) {
-    static std::atomic<unsigned long long> done{0};
-    const int rc = pf_allow_big_lds(
-        reinterpret_cast<const void*>(&conv2d_direct_kernel<KS, STRIDE, CIN, COUT, AFFINE>), (int)C::LDS, done);
-    if (rc != PF_OK) return rc;
-  }
-  g.tiles_w = (g.Wo + C::TW - 1) / C::TW;
-  g.tiles_h = (g.Ho + C::TH - 1) / C::TH;
-  dim3 grid((unsigned)direct_blocks(g.tiles_h * g.tiles_w), (unsigned)N);
-  hipLaunchKernelGGL((conv2d_direct_kernel<KS, STRIDE, CIN, COUT, AFFINE>), grid, dim3(256), C::LDS, s, x, wp, y, g,
-                     in_scale, in_shift, partials, in_bn, in_bn1);
-  return pf_launch_status();
-}
-
-template <int KS, int STRIDE, int CIN, int COUT>
-int launch_direct(const float* x, const float* wp, float* y, WideGeom g, int64_t N, const float* in_scale,
-                  const float* in_shift, double* partials, const pf_bn_job* in_bn, hipStream_t s) {
-  pf_bn_job none = {};
-  if (in_bn != nullptr) {
-    for (int k = 0; k < g.sets; ++k) {
-      const int rc = pf_bn_in_check(in_bn + k, CIN, g.spset / g.sps);
-      if (rc != PF_OK) return rc;
-    }
-    return launch_direct_mode<KS, STRIDE, CIN, COUT, 2>(x, wp, y, g, N, nullptr, nullptr, partials, in_bn[0],
-                                                        in_bn[g.sets - 1], s);
-  }
-  if (in_scale != nullptr)
-    return launch_direct_mode<KS, STRIDE, CIN, COUT, 1>(x, wp, y, g, N, in_scale, in_shift, partials, none, none, s);
-  return launch_direct_mode<KS, STRIDE, CIN, COUT, 0>(x, wp, y, g, N, nullptr, nullptr, partials, none, none, s);
-}
-
-template <int KS, int STRIDE, int CIN, int COUT>
-int direct_blocks_for(int64_t Ho, int64_t Wo) {
-  using C = DirectCfg<KS, STRIDE, CIN, COUT>;
-  return direct_blocks((int)(((Ho + C::TH - 1) / C::TH) * ((Wo + C::TW - 1) / C::TW)));
-}
-
 int wide_tile_rows(int64_t Cout) { return Cout == 64 ? 4 : (Cout == 32 ? 8 : 16); }   // 8 and 16 channels: 16 x 16 tiles
 
 }  // namespace
@@ -1016,53 +746,6 @@ int pf_conv2d_wide_sets_f32(const float* x, int x_layout, const float* wp, int64
   }
   if (Cin == 32) return launch_wide<5, 2, 32, 64>(x, wp, y, g, N, in_scale, in_shift, partials, in_bn, s);
   return launch_wide<5, 2, 16, 32>(x, wp, y, g, N, in_scale, in_shift, partials, in_bn, s);
-}
-
-/* The DIRECT (vector-pipe) form of the towers' 8- and 16-channel layers: same contract and arguments as
- * pf_conv2d_wide_sets_f32 except the weights, which are [kh][kw][ci][co] (wp_set_stride in floats, 32-byte aligned).
- * Shapes: pf_conv2d_direct_supported; statistics rows per sample: pf_conv2d_direct_blocks. */
-int pf_conv2d_direct_supported(int64_t Cin, int64_t Cout, int kernel_size, int stride) {
-  if (kernel_size == 3 && stride == 1) return (Cin == 8 && Cout == 8) || (Cin == 16 && Cout == 16);
-  if (kernel_size == 5 && stride == 2) return Cin == 8 && Cout == 16;
-  return 0;
-}
-
-int pf_conv2d_direct_blocks(int64_t Cin, int64_t Cout, int64_t Hi, int64_t Wi, int kernel_size, int stride) {
-  if (!pf_conv2d_direct_supported(Cin, Cout, kernel_size, stride) || Hi <= 0 || Wi <= 0) return 0;
-  const int64_t Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;
-  if (stride == 2) return direct_blocks_for<5, 2, 8, 16>(Ho, Wo);
-  return Cin == 8 ? direct_blocks_for<3, 1, 8, 8>(Ho, Wo) : direct_blocks_for<3, 1, 16, 16>(Ho, Wo);
-}
-
-int pf_conv2d_direct_sets_f32(const float* x, int x_layout, const float* wp, int64_t wp_set_stride, int sets, float* y,
-                              int64_t N, int64_t Cin, int64_t Cout, int64_t Hi, int64_t Wi, int kernel_size, int stride,
-                              const float* in_scale, const float* in_shift, const pf_bn_job* in_bn, int samples_per_stat,
-                              double* partials, void* stream) {
-  PF_REQUIRE(N >= 0 && Cin >= 1 && Cout >= 1 && Hi >= 1 && Wi >= 1 && N <= 65535 && samples_per_stat >= 1);
-  PF_REQUIRE((sets == 1 || sets == 2) && N % sets == 0 && wp_set_stride >= 0 && (wp_set_stride & 7) == 0);
-  PF_REQUIRE(x_layout >= 0 && x_layout <= 2);
-  PF_REQUIRE((in_scale == nullptr) == (in_shift == nullptr) && (in_bn == nullptr || in_scale == nullptr));
-  PF_REQUIRE((N / sets) % samples_per_stat == 0 || (in_bn == nullptr && sets == 1));
-  if (!pf_conv2d_direct_supported(Cin, Cout, kernel_size, stride)) return PF_ERR_UNSUPPORTED;
-  PF_REQUIRE(Cin * Hi * Wi <= INT32_MAX);
-  if (N == 0) return PF_OK;
-  PF_REQUIRE(x && wp && y && (reinterpret_cast<uintptr_t>(wp) & 31) == 0);
-  WideGeom g;
-  g.Hi = (int)Hi;
-  g.Wi = (int)Wi;
-  g.Ho = (int)((Hi - 1) / stride + 1);
-  g.Wo = (int)((Wi - 1) / stride + 1);
-  g.tiles_w = g.tiles_h = 0;
-  g.sps = samples_per_stat;
-  g.cl_out = 0;
-  g.sets = sets;
-  g.spset = (int)(N / sets);
-  g.x_mode = sets > 1 ? x_layout : 0;
-  g.w_stride = wp_set_stride;
-  hipStream_t s = (hipStream_t)stream;
-  if (stride == 2) return launch_direct<5, 2, 8, 16>(x, wp, y, g, N, in_scale, in_shift, partials, in_bn, s);
-  if (Cin == 8) return launch_direct<3, 1, 8, 8>(x, wp, y, g, N, in_scale, in_shift, partials, in_bn, s);
-  return launch_direct<3, 1, 16, 16>(x, wp, y, g, N, in_scale, in_shift, partials, in_bn, s);
 }
 
 }  // extern "C"

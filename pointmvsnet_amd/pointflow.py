@@ -644,43 +644,6 @@ def _pack_conv2d_wide(weight):
     return w.permute(0, 1, 2, 3, 5, 4).contiguous()
 
 
-# PF_TOWER_DIRECT (round 6): the towers' 8 -> 8, 8 -> 16 5x5/2 and 16 -> 16 layers on the VECTOR pipe
-# (csrc/conv2d_wide.hip, conv2d_direct_kernel: packed f32 multiply-adds with the weights as scalar-register pairs) instead
-# of the 16x16x4 matrix tiles -- on gfx950 both pipes peak at 157.3 TF for float32 and the matrix form wastes half of its
-# columns at 8 output channels.  Exact float32 fmaf chains like the matrix form, in another summation order.
-TOWER_DIRECT = int(_os.environ.get("PF_TOWER_DIRECT", "0"))
-
-
-def conv2d_direct_supported(conv):
-    return bool(TOWER_DIRECT and conv2d_supported(conv) and _lib.load().pf_conv2d_direct_supported(
-        conv.in_channels, conv.out_channels, int(conv.kernel_size[0]), int(conv.stride[0])))
-
-
-def pack_conv2d_direct_weight_sets(weights):
-    """(sets, K, K, Cin, Cout): [kh][kw][ci][co] = w[co][ci][kh][kw] -- the C_out weights of a (tap, input channel) are
-    32 or 64 consecutive bytes, one scalar load of the direct kernel."""
-    def make():
-        return torch.stack([w.detach().to(_F32).permute(2, 3, 1, 0).contiguous() for w in weights]).contiguous()
-    return _cached_pack(("c2d",) + tuple(id(w) for w in weights), tuple(weights), make)
-
-
-def _conv2d_direct_launch(x, x_layout, convs, y, N, Cin, Cout, Hi, Wi, ks, stride, sc, sh, in_bn, samples_per_stat,
-                          want_stats):
-    sets = len(convs)
-    wp = pack_conv2d_direct_weight_sets([c.weight for c in convs])
-    Ho, Wo = (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
-    partials = None
-    if want_stats:
-        T = int(_lib.load().pf_conv2d_direct_blocks(Cin, Cout, Hi, Wi, int(ks), int(stride)))
-        partials = stat_rows(N, T, Cout, x.device)
-    _lib.call("pf_conv2d_direct_sets_f32", _lib.ptr(x), x_layout, _lib.ptr(wp), int(wp[0].numel()), sets, _lib.ptr(y), N,
-              Cin, Cout, Hi, Wi, int(ks), int(stride), _lib.ptr(sc), _lib.ptr(sh), in_bn, int(samples_per_stat),
-              _lib.ptr(partials), _lib.stream(),
-              algo_bytes=4.0 * (x.numel() + N * Cout * Ho * Wo) + 4.0 * sets * ks * ks * Cin * Cout,
-              flops=2.0 * N * Ho * Wo * ks * ks * Cin * Cout, tag="%d->%d %dx%d/%d direct" % (Cin, Cout, ks, ks, stride))
-    return partials
-
-
 def pack_conv2d_wide_weight(weight):
     """(Cout,Cin,K,K) -> (K, K, Cin/8, 2, Cout, 4): [kh][kw][kc][h][co][j] = w[co][8 kc + 4 h + j][kh][kw]
     (Cout 32 / 64: 32x32x2 MFMA), or, for Cout = 8 / 16 (16x16x4 MFMA), (K, K, 4, 16, Cin'/4) with Cin' = Cin
@@ -696,11 +659,6 @@ def conv2d_wide(x, conv, in_affine, samples_per_stat, want_stats, channel_last_o
     Cout = conv.out_channels
     ks, stride = conv.kernel_size[0], conv.stride[0]
     Ho, Wo = (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
-    if not channel_last_out and conv2d_direct_supported(conv):
-        y = torch.empty((N, Cout, Ho, Wo), dtype=_F32, device=x.device)
-        sc, sh, in_bn = _split_affine(in_affine)
-        return y, _conv2d_direct_launch(x, 0, [conv], y, N, Cin, Cout, Hi, Wi, ks, stride, sc, sh, in_bn,
-                                        samples_per_stat, want_stats)
     wp = pack_conv2d_wide_weight(conv.weight)
     y = torch.empty((N, Ho, Wo, Cout) if channel_last_out else (N, Cout, Ho, Wo), dtype=_F32, device=x.device)
     partials = None
@@ -799,11 +757,6 @@ def conv2d_wide_sets(x, convs, in_affine, samples_per_stat, want_stats, interlea
     Cout = conv.out_channels
     ks, stride = conv.kernel_size[0], conv.stride[0]
     Ho, Wo = (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
-    if not channel_last_sets and all(conv2d_direct_supported(c) for c in convs):
-        y = torch.empty((N, Cout, Ho, Wo), dtype=_F32, device=x.device)
-        sc, sh, in_bn = (None, None, None) if in_affine is None else in_affine.split()
-        return y, _conv2d_direct_launch(x, 2 if interleaved else 0, convs, y, N, Cin, Cout, Hi, Wi, ks, stride, sc, sh,
-                                        in_bn, samples_per_stat, want_stats)
     wp = pack_conv2d_wide_weight_sets([c.weight for c in convs])
     y = torch.empty((N, Cout, Ho, Wo), dtype=_F32, device=x.device)
     partials = None

@@ -31,11 +31,6 @@ def _host_source(text):
     # ordered comparisons of doubles)
     text = text.replace('asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));', "r = b < a ? b : a;")
     text = text.replace('asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));', "r = b < a ? a : b;")
-    # csrc/conv2d_wide.hip, pk_fma_sel: acc.xy += (in.y or in.x) * w.xy as two fmaf (what v_pk_fma_f32 computes per half)
-    text = text.replace('asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(in), "s"(w));',
-                        "{ acc[0] = fmaf(in[1], w[0], acc[0]); acc[1] = fmaf(in[1], w[1], acc[1]); }")
-    text = text.replace('asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(in), "s"(w));',
-                        "{ acc[0] = fmaf(in[0], w[0], acc[0]); acc[1] = fmaf(in[0], w[1], acc[1]); }")
     assert "asm(" not in text and "asm volatile" not in text, "inline assembly the emulator does not know"
     return re.sub(r"\b__shared__\s+", "static thread_local ", text)
 

@@ -81,32 +81,6 @@ def test_emulator_reproduces_the_hardware_validated_f32_tower_kernels(emu, cin, 
     _check(y, part, ref, 2e-6)
 
 
-@pytest.mark.parametrize("cin,cout,k,stride,hw", [(8, 8, 3, 1, (37, 45)), (16, 16, 3, 1, (19, 40)), (8, 16, 5, 2, (21, 70))])
-@pytest.mark.parametrize("affine", [False, True])
-def test_direct_tower_kernel_executes_correctly_on_the_emulator(emu, cin, cout, k, stride, hw, affine):
-    """conv2d_direct_kernel (round 6: the 8- and 16-channel tower layers on the vector pipe, weights as scalar-register
-    pairs): every instantiation, interior and border tiles (maps that are no multiple of the 32-wide tiles), with and without
-    the pending BatchNorm + ReLU -- output and statistics rows against a float64 convolution, beside the matrix-core kernel
-    on the same operands."""
-    conv, x, aff, ref = _case(cin, cout, k, stride, hw, 2, 21, affine)
-    saved = pointflow.TOWER_DIRECT
-    try:
-        pointflow.TOWER_DIRECT = 0
-        y0, part0 = pointflow.conv2d_wide(x, conv, aff, 1, True)
-        e0 = _check(y0, part0, ref, 2e-6)
-        pointflow.TOWER_DIRECT = 1
-        assert pointflow.conv2d_direct_supported(conv)
-        y1, part1 = pointflow.conv2d_wide(x, conv, aff, 1, True)
-        e1 = _check(y1, part1, ref, 2e-6)
-        y2, part2 = pointflow.conv2d_wide(x, conv, aff, 1, True)
-        assert torch.equal(y1, y2) and torch.equal(part1, part2)
-    finally:
-        pointflow.TOWER_DIRECT = saved
-    print("emulated %d->%d k%d/%d affine %d: direct %.2e, matrix %.2e of the largest output against float64"
-          % (cin, cout, k, stride, int(affine), e1, e0))
-    assert e1 < 2.0 * e0 + 1e-7, (e1, e0)
-
-
 def test_tower_kernel_resolves_a_pending_batchnorm_and_serves_two_towers(emu):
     """The two remaining modes: the pending BatchNorm resolved by the kernel's own blocks from the producer's statistics
     rows (`in_bn`, AFFINE = 2), and both towers in one launch (parameter sets, set 0 written channel-last) -- each
