@@ -53,6 +53,51 @@ TRAFFIC_TABLE = os.path.join("profiles", "pmc_traffic.json")
 UNDER_LOAD_TABLE = os.path.join("profiles", "r06_per_kernel_roofline.json")
 
 
+PARITY_REPORT = os.path.join("profiles", "r06_parity_report.jsonl")
+TRACED_SHA = os.path.join("profiles", "r06_traced_sha.txt")
+
+
+def traced_sha():
+    try:
+        return open(os.path.join(ROOT, TRACED_SHA)).read().strip() or None
+    except OSError:
+        return None
+
+
+def parity_summary():
+    """Per configuration, from the LAST committed parity report of the GPU test run (tests/conftest.report lines of
+    tests/test_gpu_teacher.py and tests/test_gpu_model.py; not measured by this run): the teacher-forced iterations --
+    the device against the oracle on the device's own prior and pyramid -- with the oracle's OWN neighbours (worst
+    iteration of the configuration: largest relative deviation, fraction of pixels beyond 1e-4, fraction of the pixels
+    OUTSIDE every flipped neighbour row's receptive field that deviate by more than 1e-5, which the tests assert to be
+    zero), with the device's neighbours fed to the oracle (max norm over every pixel), and the whole forward against the
+    reference's golden maps (fraction beyond 1e-4 and largest deviation of the last refined map)."""
+    try:
+        lines = [json.loads(l) for l in open(os.path.join(ROOT, PARITY_REPORT)) if l.startswith("{")]
+    except (OSError, ValueError):
+        return None
+    out = {}
+    for cfg in ("cfg2", "cfg3", "cfg4", "cfg5"):
+        own = [r for r in lines if r.get("name", "").startswith("teacher_own_knn_%s" % cfg)]
+        same = [r for r in lines if r.get("name", "").startswith("teacher_%s" % cfg) and "rel_max_same_knn" in r]
+        if not own and not same:
+            continue
+        row = {}
+        if own:
+            row.update(max_rel=max(r["rel_max"] for r in own), frac_gt_1e4=max(r["frac_gt_1e4"] for r in own),
+                       frac_outside_fields_gt_1e5=max(r.get("frac_outside_fields_gt_1e5", 0.0) for r in own),
+                       max_rel_outside_fields=max(r["rel_max_outside_fields"] for r in own),
+                       subgrids_checked=[int(r.get("subgrids_checked", 0)) for r in own],
+                       subgrids=[int(r.get("subgrids", 0)) for r in own])
+        if same:
+            row["max_rel_same_neighbours"] = max(r["rel_max_same_knn"] for r in same)
+        out[cfg] = row
+    if not out:
+        return None
+    out["source"] = PARITY_REPORT + " (GPU test run of the traced build %s; committed, not this run)" % (traced_sha() or "?")
+    return out
+
+
 def measured_traffic(entry):
     """HBM bytes per launch of C-ABI entry point `entry` READ FROM THE COMMITTED PMC passes (rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE, separate runs of an earlier job; tools/pmc_to_traffic.py), or None.  Not measured by this run: the line
@@ -68,7 +113,7 @@ def under_load_instantiations(prefixes):
     """Best / worst template instantiation of the dominant kernel family UNDER LOAD (four lanes, graph replay), from the
     committed rocprofv3 kernel trace folded by tools/per_kernel_roofline.py -- the calibration clock of this run times
     eager single-chain launches and cannot see them.  None when the table is not there."""
-    for name in (UNDER_LOAD_TABLE, os.path.join("profiles", "r04_per_kernel_roofline.json")):
+    for name in (UNDER_LOAD_TABLE, os.path.join("profiles", "r06a_per_kernel_roofline.json")):
         try:
             table = json.load(open(os.path.join(ROOT, name)))
         except (OSError, ValueError):
@@ -992,8 +1037,8 @@ def run(args, emulate):
         traffic = measured_traffic(dominant)
         roof.update({"traffic": traffic,
                      "traffic_source": None if traffic is None else
-                     TRAFFIC_TABLE + " (two rocprofv3 --pmc passes of a committed earlier job, FETCH_SIZE / WRITE_SIZE; "
-                     "a constant of that job, not measured in this run)",
+                     TRAFFIC_TABLE + " (two rocprofv3 --pmc passes of a committed earlier job at git %s, FETCH_SIZE / "
+                     "WRITE_SIZE; a constant of that job, not measured in this run)" % (traced_sha() or "?"),
                      "under_load": under_load_instantiations(("conv2d_wide",)) if dominant in TOWERS else None,
                      # the entry point dispatches to one template instantiation per layer shape: the same clock per shape
                      # (eager, single chain -- `under_load` is the same table from the trace of the timed execution mode)
@@ -1096,6 +1141,7 @@ def run(args, emulate):
         "gap_probe": gap_probe,
         "stage_timeline_us": stage_timeline,
         "roofline": roof,
+        "parity": parity_summary() if not training else None,
         "kernels": kernels,
         "train": None,
     }

@@ -67,6 +67,7 @@ struct WgGeom {
   // point-major rows (taps == 1): Gr (P, ldg), X (P, ldx)
   int point_major;
   int64_t P, ldg, ldx;
+  int dbg;                            // PF_WGRAD_DBG (tools only): 1 = no staging, 2 = no MFMA loop, 4 = no partial store
 };
 
 // NTW: column tiles per wave = ceil(NTILES / 4).  Every wave runs NTW tiles -- one that does not exist reads column 0's
@@ -156,7 +157,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ Gr
     constexpr int kU = MT == 4 ? 4 : 8, kG = 4, kUR = 4;
     const int grows = min(MT * 16, g.Cg - cg0);          // rows / channels that exist: the rest of the LDS tiles is
     const int creal = min(cbtot, g.Cx - ci0);            // never stored from (their products are not written)
-    if (g.point_major) {
+    if (g.dbg & 1) {
+    } else if (g.point_major) {
       // R * 16 consecutive points; thread = (point, 4 channels): coalesced 16-byte row pieces, transposed into LDS
       const int PT = R * 16;
       const int64_t p0 = (int64_t)tile * PT;
@@ -368,7 +370,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ Gr
     }
     __syncthreads();
 
-    for (int r = 0; r < R; ++r) {
+    for (int r = 0; r < ((g.dbg & 2) ? 0 : R); ++r) {
       const int d = r >> g.lgTH, h = r & (g.TH - 1);
       float a[MT][4];
 #pragma unroll
@@ -403,7 +405,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ Gr
     const int cil = li & (g.CBP - 1), tl = li >> g.lgCBP;
     const int tap = tg * g.TPT + tl;
     const int ci = ci0 + sub * g.CBP + cil;
-    if (tap >= g.T || ci >= g.Cx) continue;
+    if (tap >= g.T || ci >= g.Cx || (g.dbg & 4)) continue;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
 #pragma unroll
@@ -555,6 +557,11 @@ WgPlan make_plan_mt(int64_t N, int64_t Cg, int64_t Cx, int64_t Do, int64_t Ho, i
   g.x_sps = 1;
   g.x_pps = 1;
   g.point_major = rows ? 1 : 0;
+  static const int dbg = []() {
+    const char* e = getenv("PF_WGRAD_DBG");
+    return e == nullptr ? 0 : atoi(e);
+  }();
+  g.dbg = dbg;
   g.P = P;
   g.ldg = g.ldx = 0;
   g.CBP = Cx >= 16 ? 16 : (Cx > 4 ? 8 : 4);

@@ -712,11 +712,19 @@ def test_conv3d_k3_few_vs_fp64(dev, N, Cin, Cout, D, H, W):
     assert err < 3e-6 * float(ref.abs().max())
 
 
-@pytest.mark.parametrize("N,Cin,Cout,D,H,W", [(1, 16, 8, 24, 32, 40), (2, 32, 16, 12, 16, 20), (1, 5, 3, 3, 5, 7),
-                                              (1, 4, 6, 1, 1, 1), (1, 64, 32, 6, 8, 10)])
+@pytest.mark.parametrize("N,Cin,Cout,D,H,W,form", [(1, 16, 8, 24, 32, 40, ""), (2, 32, 16, 12, 16, 20, ""), (1, 5, 3, 3, 5, 7, ""),
+                                                   (1, 4, 6, 1, 1, 1, ""), (1, 64, 32, 6, 8, 10, ""),
+                                                   # the matrix-core form: config 4's data gradient of conv1_0 takes it by
+                                                   # the shape rule; forced on ragged shapes (half-empty channel group,
+                                                   # cells that are no multiple of 16, two samples) and forced off
+                                                   (1, 16, 64, 24, 32, 40, ""), (1, 16, 64, 24, 32, 40, "VALU"),
+                                                   (2, 32, 16, 12, 16, 20, "MFMA"), (1, 8, 24, 3, 5, 7, "MFMA"),
+                                                   (1, 4, 6, 1, 1, 1, "MFMA"), (1, 16, 8, 24, 32, 40, "MFMA")])
 @pytest.mark.parametrize("skip", [False, True])
-def test_deconv3d_k3s2_vs_fp64(dev, N, Cin, Cout, D, H, W, skip):
+def test_deconv3d_k3s2_vs_fp64(dev, N, Cin, Cout, D, H, W, form, skip, monkeypatch):
     # VolumeConv decoder rows (reference networks.py:141-143): float64 ConvTranspose3d of (xa + xb)
+    if form:
+        monkeypatch.setenv("PF_DECONV_" + form, "1")
     gen = torch.Generator().manual_seed(Cin * 100 + D * H * W + int(skip))
     xa = torch.randn(N, Cin, D, H, W, generator=gen)
     xb = torch.randn(N, Cin, D, H, W, generator=gen) if skip else None
@@ -1262,8 +1270,12 @@ def test_conv3d_k3_applies_pending_batchnorm_while_staging(dev, N, Cin, Cout, st
 
 @pytest.mark.parametrize("skip", [False, True])
 @pytest.mark.parametrize("affine", ["rows", "lazy"])
-def test_deconv3d_k3s2_applies_pending_batchnorm_before_the_skip_add(dev, skip, affine):
-    """pf_deconv3d_k3s2_f32 with the BatchNorm + ReLU of xa pending: y = deconv(relu(bn(xa)) + xb)."""
+@pytest.mark.parametrize("form", ["", "MFMA"])
+def test_deconv3d_k3s2_applies_pending_batchnorm_before_the_skip_add(dev, skip, affine, form, monkeypatch):
+    """pf_deconv3d_k3s2_f32 with the BatchNorm + ReLU of xa pending: y = deconv(relu(bn(xa)) + xb); both forms of the
+    kernel (the shape rule would pick the lane-per-cell one here; PF_DECONV_MFMA=1 forces the matrix-core one)."""
+    if form:
+        monkeypatch.setenv("PF_DECONV_" + form, "1")
     gen = torch.Generator().manual_seed(7 + int(skip))
     N, Cin, Cout, D, H, W = 1, 32, 16, 6, 8, 10
     conv = torch.nn.ConvTranspose3d(Cin, Cout, 3, stride=2, padding=1, output_padding=1, bias=False)

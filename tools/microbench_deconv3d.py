@@ -26,7 +26,8 @@ def timeit(fn, reps=20):
 
 
 for name, cin, cout, d, h, w in (("conv4_0", 64, 32, 6, 8, 10), ("conv5_0", 32, 16, 12, 16, 20),
-                                 ("conv6_0", 16, 8, 24, 32, 40)):
+                                 ("conv6_0", 16, 8, 24, 32, 40), ("dgrad conv1_0", 16, 64, 24, 32, 40),
+                                 ("dgrad conv2_0", 32, 16, 12, 16, 20)):
     xa = torch.randn(1, cin, d, h, w, device=dev)
     xb = torch.randn(1, cin, d, h, w, device=dev)
     wt = torch.randn(cin, cout, 3, 3, 3, device=dev) * 0.05
