@@ -571,9 +571,11 @@ WgPlan make_plan_mt(int64_t N, int64_t Cg, int64_t Cx, int64_t Do, int64_t Ho, i
   p.MT = MT;
   p.mblocks = (int)((Cg + 16 * MT - 1) / (16 * MT));
   const int cx_pad = (int)((Cx + g.CBP - 1) / g.CBP);          // channel sub-blocks in all
-  // tile candidates: 3-D volumes 2 x 4 x 16, else 1 x 8 x 16, 1 x 4 x 16; 2-D layers try 1 x 16 x 16 first when it
-  // fits the soft LDS budget: twice the matrix work between two barriers of a latency-bound loop
-  const int cand[4][2] = {{1, 16}, {2, 4}, {1, 8}, {1, 4}};
+  // tile candidates: 3-D volumes 4 x 4 x 16 where it still leaves two blocks per CU (round 6: the patch halo costs
+  // 1.5 x 1.5 x 1.25 instead of 2 x 1.5 x 1.25 staged floats per position -- conv0_1's gradient 201 -> 188 us, conv1_1's
+  // 35 -> 30, profiles/r06j_wgrad_plans.md), then 2 x 4 x 16, 1 x 8 x 16, 1 x 4 x 16; 2-D layers try 1 x 16 x 16 first
+  // when it fits the soft LDS budget: twice the matrix work between two barriers of a latency-bound loop
+  const int cand[5][2] = {{1, 16}, {2, 4}, {1, 8}, {1, 4}, {4, 4}};
   static const bool big_tile = []() {
     const char* e = getenv("PF_WGRAD_BIG_TILE");
     return e == nullptr || e[0] != '0';
@@ -582,13 +584,14 @@ WgPlan make_plan_mt(int64_t N, int64_t Cg, int64_t Cx, int64_t Do, int64_t Ho, i
     const char* e = getenv("PF_WGRAD_BIG_ROWS");
     return e == nullptr || e[0] != '0';
   }();
-  int seq[4], nseq = 0;
+  int seq[5], nseq = 0;
   if (rows) {
     if (big_rows) seq[nseq++] = 2;                             // 128 points per tile (E1, mlp3: +0.3 % on the step)
     seq[nseq++] = 3;
   } else if (first_tile == 2) {
     seq[nseq++] = 3;
   } else if (Do > 1) {
+    if (Do >= 4 && Ho >= 4 && first_tile != 1) seq[nseq++] = 4;
     seq[nseq++] = 1;
     seq[nseq++] = 2;
     seq[nseq++] = 3;
@@ -599,6 +602,7 @@ WgPlan make_plan_mt(int64_t N, int64_t Cg, int64_t Cx, int64_t Do, int64_t Ho, i
   }
   for (int si = 0; si < nseq; ++si) {
     const int ci = seq[si];
+    const size_t soft = ci == 4 ? 78 * 1024 : kLdsSoft;       // (4 x 4 x 16: 73-75 KB, still two blocks per CU)
     g.TD = cand[ci][0];
     g.TH = cand[ci][1];
     g.lgTH = ilog2(g.TH);
@@ -626,10 +630,10 @@ WgPlan make_plan_mt(int64_t N, int64_t Cg, int64_t Cx, int64_t Do, int64_t Ho, i
       g.ntasks = rows ? 0 : cblk * g.CBP * g.ID * g.IH;
       p.lds_bytes = sizeof(float) * (size_t)(g.gs_floats + g.xs_floats) + sizeof(int) * 4 * (size_t)g.ntasks +
                     (rows ? 0 : sizeof(int) * 2 * (size_t)(p.MT * 16 * g.TD * g.TH));
-      if (p.lds_bytes <= kLdsSoft) break;
+      if (p.lds_bytes <= soft) break;
     }
     if ((ci == 0 || (rows && ci == 2)) && g.CBLK != cblk_max) continue;   // the big tile only where it costs no channel block
-    if (g.CBLK >= 1 && p.lds_bytes <= kLdsSoft && g.NTILES <= kMaxNTW * 4) {
+    if (g.CBLK >= 1 && p.lds_bytes <= soft && g.NTILES <= kMaxNTW * 4) {
       p.ok = true;
       break;
     }
@@ -672,10 +676,20 @@ WgPlan make_plan_mt(int64_t N, int64_t Cg, int64_t Cx, int64_t Do, int64_t Ho, i
 // then fewer rows per block and the smallest tile, i.e. more blocks with less work each.
 WgPlan make_plan(int64_t N, int64_t Cg, int64_t Cx, int64_t Do, int64_t Ho, int64_t Wo, int64_t Di, int64_t Hi,
                  int64_t Wi, int KD, int KH, int KW, int stride, int pd, int ph, int pw, bool rows, int64_t P) {
+  // Rows of Gr per block.  Point-major rows (one tap): as many as there are, up to 64 -- the operands are re-read per
+  // row tile.  Planar layers: 16 (32 for the 64-row stride-1 layers): a block's partial dW is rows x channels x taps
+  // floats per position slice, and with ~480 resident blocks the slices of the 25-tap and 32-row layers wrote and re-read
+  // 18-25 MB -- 10-25 us of their 40-67 us (PF_WGRAD_DBG=4); fewer rows per block = more row blocks = fewer slices
+  // (tower 16->32 / 32->64 5x5: 67 -> 55 us, 32->32: 41 -> 36, conv2_1: 36 -> 26; 64->64 3x3 is best at 32 rows: 40).
   int MT = Cg <= 16 ? 1 : (Cg <= 32 ? 2 : 4);
+  if (!rows) MT = (Cg >= 64 && stride == 1) ? 2 : 1;
   WgPlan p = make_plan_mt(N, Cg, Cx, Do, Ho, Wo, Di, Hi, Wi, KD, KH, KW, stride, pd, ph, pw, rows, P, MT, -1);
   if (!p.ok || rows) return p;
   const auto blocks = [](const WgPlan& q) { return (int64_t)q.splits * q.cblocks * q.mblocks; };
+  if (blocks(p) < kCUs / 2 && p.g.TD == 4) {                   // (a small volume: the 2 x 4 x 16 tile first)
+    const WgPlan q = make_plan_mt(N, Cg, Cx, Do, Ho, Wo, Di, Hi, Wi, KD, KH, KW, stride, pd, ph, pw, rows, P, MT, 1);
+    if (q.ok && blocks(q) > blocks(p)) p = q;
+  }
   if (blocks(p) < kCUs / 2) {
     const WgPlan q = make_plan_mt(N, Cg, Cx, Do, Ho, Wo, Di, Hi, Wi, KD, KH, KW, stride, pd, ph, pw, rows, P, MT, 2);
     if (q.ok && blocks(q) > blocks(p)) p = q;
@@ -692,7 +706,7 @@ WgPlan make_plan(int64_t N, int64_t Cg, int64_t Cx, int64_t Do, int64_t Ho, int6
 
 template <int MT, int STRIDE, int NTW>
 int launch_wgrad(const float* Gr, const float* X, float* part, const WgPlan& p, hipStream_t s) {
-  if (p.lds_bytes > kLdsSoft) {
+  if (p.lds_bytes > 64 * 1024) {
     static std::atomic<unsigned long long> done{0};
     const int rc = pf_allow_big_lds(reinterpret_cast<const void*>(&wgrad_kernel<MT, STRIDE, NTW>), (int)kLdsHard, done);
     if (rc != PF_OK) return rc;
