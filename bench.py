@@ -164,6 +164,12 @@ def parse_args():
                          "process default, PF_CONCURRENCY; scene lanes are always single chains, level 0)")
     ap.add_argument("--calibration-steps", type=int, default=10,
                     help="instrumented eager forwards (HIP events around every entry point) before the timed region")
+    ap.add_argument("--sync-dir", default=None,
+                    help="(route workers) directory of the start barrier: the process writes ready.<pid> after its warm-up "
+                         "and starts its timed region when the file `go` appears; the line then carries wall_t0 / wall_t1")
+    ap.add_argument("--route-workers", type=int, default=4,
+                    help="worker PROCESSES of the drop-in route's second figure (each: the reference's model.py, eager, one "
+                         "scene at a time, all on this GPU); 1 = only the one-process figure")
     ap.add_argument("--route", default="fused", choices=["fused", "reference-model"],
                     help="reference-model: time the REFERENCE'S OWN model graph (its unmodified pointmvsnet/model.py, "
                          "--reference-model-py) running eagerly on this package's operator layer "
@@ -631,12 +637,60 @@ def route_in_child(args):
                 d = json.loads(line)
             except ValueError:
                 continue
-            return {"value": d["value"], "unit": d["unit"], "ms_per_depth_map": d["ms_per_depth_map"],
-                    "execution": "eager: the reference's unmodified model.py on pointmvsnet_amd's operator layer "
-                                 "(compat.install_as_pointmvsnet), one scene at a time",
-                    "steps": d["steps"], "scenes_per_step": d["scenes_per_step"],
-                    "child_wall_s": time.perf_counter() - t0}
+            out = {"value": d["value"], "unit": d["unit"], "ms_per_depth_map": d["ms_per_depth_map"],
+                   "execution": "eager: the reference's unmodified model.py on pointmvsnet_amd's operator layer "
+                                "(compat.install_as_pointmvsnet), one scene at a time, ONE process",
+                   "steps": d["steps"], "scenes_per_step": d["scenes_per_step"],
+                   "child_wall_s": time.perf_counter() - t0}
+            if args.route_workers > 1:
+                out["workers"] = route_workers_in_children(args, cmd, args.route_workers)
+            return out
     return {"error": "no result (exit code %s): %s" % (proc.returncode, (proc.stderr or "")[-300:])}
+
+
+def route_workers_in_children(args, cmd, workers):
+    """The drop-in route is HOST-bound (profiles/r06c_route_profile_module_graphs.md: the reference's model.py spends its
+    8.5 ms per depth map in its own Python and ATen calls and in the host synchronisations of linspace / inverse / .to();
+    the GPU idles most of it) -- the way a deployment fills the GPU with an unmodified model.py is several worker
+    PROCESSES per GPU, as the headline route keeps four scene lanes in flight.  `workers` children, each the one-process
+    route above (its own interpreter, its own copy of the weights and scenes, all on this GPU), warm up, meet at a start
+    barrier (--sync-dir) and run their timed steps together: depth maps of all workers / (last end - first start)."""
+    import shutil
+    import subprocess
+    import tempfile
+    sync = tempfile.mkdtemp(prefix="pf_route_")
+    t0 = time.perf_counter()
+    procs = []
+    try:
+        for _ in range(workers):
+            procs.append(subprocess.Popen(cmd + ["--sync-dir", sync, "--steps", "10"], stdout=subprocess.PIPE,
+                                          stderr=subprocess.PIPE, universal_newlines=True))
+        while len([f for f in os.listdir(sync) if f.startswith("ready.")]) < workers:
+            if time.perf_counter() - t0 > 120 or any(p.poll() is not None for p in procs):
+                raise RuntimeError("a worker did not reach the start barrier")
+            time.sleep(0.01)
+        open(os.path.join(sync, "go"), "w").close()
+        lines = []
+        for p in procs:
+            so, se = p.communicate(timeout=120)
+            got = [l for l in (so or "").splitlines() if l.startswith("{")]
+            if not got:
+                raise RuntimeError("worker exit code %s: %s" % (p.returncode, (se or "")[-200:]))
+            lines.append(json.loads(got[-1]))
+        maps = sum(d["steps"] * d["scenes_per_step"] for d in lines)
+        span = max(d["wall_t1"] for d in lines) - min(d["wall_t0"] for d in lines)
+        return {"processes": workers, "value": maps / span, "unit": "depth-maps/s",
+                "per_worker": [round(d["value"], 1) for d in lines],
+                "start_skew_ms": round(1e3 * (max(d["wall_t0"] for d in lines) - min(d["wall_t0"] for d in lines)), 2),
+                "note": "all workers' depth maps / (last end - first start); every worker is the unmodified model.py, eager",
+                "child_wall_s": time.perf_counter() - t0}
+    except Exception as exc:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        return {"error": repr(exc)}
+    finally:
+        shutil.rmtree(sync, ignore_errors=True)
 
 
 def train_block_in_child(args, rank, world):
@@ -924,6 +978,14 @@ def run(args, emulate):
         run_step(k)
     barrier()
     torch.cuda.synchronize()
+    if args.sync_dir:                                    # route workers: start together (route_workers_in_children)
+        open(os.path.join(args.sync_dir, "ready.%d" % os.getpid()), "w").close()
+        t_wait = time.perf_counter()
+        while not os.path.exists(os.path.join(args.sync_dir, "go")):
+            if time.perf_counter() - t_wait > 150:
+                raise SystemExit("bench.py --sync-dir: no `go` within 150 s")
+            time.sleep(0.0005)
+    wall_t0 = time.time()
     t0 = time.perf_counter()
     for k in range(args.steps):
         preds = run_step(args.warmup + k)
@@ -935,6 +997,7 @@ def run(args, emulate):
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    wall_t1 = time.time()
     allreduce_us = None
     if training and world > 1:                   # the step's one collective on its own: 2.8 MB SUM all-reduce over RCCL
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(22)]
@@ -1134,6 +1197,8 @@ def run(args, emulate):
                    "PointMVSNet.forward(isFlow=True, isTest=True), BatchNorm in train mode (test.py:58)"},
         "execution": train_execution if training else execution,
         "route": args.route,
+        "wall_t0": wall_t0 if args.sync_dir else None,
+        "wall_t1": wall_t1 if args.sync_dir else None,
         "enqueue_wall_ms_per_depth_map": issued / (args.steps * sps) * 1e3,
         "lane_placement_probe_maps_per_s": lane_probe,
         "lane_placement_probe_by_rank": placement_by_rank,
