@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpointflow_hip.so")
+# (PF_LIB_PATH: tools only -- the ablation builds of tools/experiments/build_dbg_variants.sh; the product loads the in-tree library)
+LIB_PATH = os.environ.get("PF_LIB_PATH") or os.path.join(_HERE, "libpointflow_hip.so")
 
 _vp, _i, _i64, _f, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double
 

@@ -15,7 +15,7 @@
 // A pending BatchNorm handed to its CONSUMER (`in_bn` of pf_conv2d_wide_f32 / pf_pointwise_gemm_f32 /
 // pf_flow_head_f32, resolved per block by pf_bn_resolve below): the job must describe finished statistics rows.
 #ifndef PF_RESOLVE_BATCH
-#define PF_RESOLVE_BATCH 20
+#define PF_RESOLVE_BATCH 5
 #endif
 constexpr int kResolveBatch = PF_RESOLVE_BATCH;
 constexpr int kResolveMaxRows = 4096;   // rows behind one statistic; beyond that the re-reduction per block is absurd
@@ -53,8 +53,12 @@ __device__ __forceinline__ void pf_bn_resolve(const pf_bn_job& J, int s, float* 
   if (sl < slices) {
     const double2* base = reinterpret_cast<const double2*>(J.partials) + (int64_t)s * per_stat * J.pcols + J.col0 + c;
     const int r0 = sl * per, r1 = min(per_stat, r0 + per);
-    // kResolveBatch rows in flight: the tower layers hand every slice exactly 20 rows (80 / 160 / 320 / 640 rows for
-    // 64 / 32 / 16 / 8 channels), i.e. ONE round trip instead of two
+    // kResolveBatch rows in flight.  The tower layers hand every slice exactly 20 rows (80 / 160 / 320 / 640 rows for
+    // 64 / 32 / 16 / 8 channels); rounds 3-5 kept all 20 in flight (one round trip) -- 80 VGPRs that live only in this
+    // prologue but set the whole kernel's register allocation: the 8 -> 8 tower kernel ran 3 waves per SIMD instead of 5,
+    // 32 -> 32 and 64 -> 64 2 instead of 4 (build/resource_usage.json).  5 in flight = four round trips of a prologue that
+    // other resident blocks cover, and the occupancy of the instantiations without a pending BatchNorm: +1.6 % on the
+    // headline, same box, two repetitions (profiles/r06n_resolve_batch.md).  The sums are added in the same order.
     for (int r = r0; r < r1; r += kResolveBatch) {
       double2 v[kResolveBatch];
 #pragma unroll
