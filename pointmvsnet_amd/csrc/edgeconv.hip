@@ -231,8 +231,11 @@ __global__ __launch_bounds__(256, 2) void pointwise_gemm_kernel(
 // ------------------------------------------------------------------------------------------------
 // AFFINE: 0 = rows as they are; 1 = relu(x * in_scale + in_shift); 2 = the same, the rows computed by every block
 // from the producer's statistics (pf_bn_resolve, pf_bn_resolve.h: the pending BatchNorm gets no launch of its own)
+// (EdgeConv 64 -> [64 | 64], KJ = 8, NT = 4: the default allocation is 138 VGPRs + 64 AGPRs = 2 waves per SIMD; asked for 3
+// the compiler fits it in 168 registers without scratch -- stand-alone 12.4 -> 11.5 us at 25 600 points, 29.7 -> 28.6 at
+// 102 400; headline unchanged, profiles/r06n_resolve_batch.md)
 template <int KJ, int NT, int AFFINE>
-__global__ __launch_bounds__(256) void pointwise_gemm_direct_kernel(
+__global__ __launch_bounds__(256, (KJ == 8 && NT == 4) ? 3 : 1) void pointwise_gemm_direct_kernel(
     const float* __restrict__ X, int64_t ldx, const float* __restrict__ Wt, float* __restrict__ Y, int64_t ldy,
     int Ng, int K, int Nc_store, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
     int groups_per_stat, double* __restrict__ partials, int T, pf_bn_job in_bn) {
