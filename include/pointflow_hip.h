@@ -558,6 +558,16 @@ int pf_rows_wgrad_f32(const float* gr, int64_t ldg, const float* x, int64_t ldx,
  * each in the same fixed order as the single call (bit-identical results): dws[i][e] (+)= sum_k parts[i][k][e]. */
 int pf_wgrad_reduce_batch_f32(const float* const* parts, float* const* dws, const int64_t* elems, const int* splits,
                               int n, int accumulate, void* stream);
+/* The same with SWAPPED-OPERAND layers among them (round 6).  For a stride-1 'same' convolution the two operands of
+ * pf_conv_wgrad_f32 may change places -- gr' = x, x' = dL/dy -- which gives dW'[cx][cg][k'] = dW[cg][cx][K-1-k'] per axis:
+ * the rows of the MFMA tile are then the layer's INPUT channels and the patch with the halo is the (narrow) gradient
+ * tensor.  VolumeConv's conv0_1 (64 -> 8: 8 of 16 MFMA rows used, a 64-channel halo patch staged per tile) and conv6_2
+ * (8 -> 1: 1 of 16 rows) take it (reference networks.py:134,147 under train.py:80).  swap_rows[i] = 0: layer i as in the
+ * call above; = R > 0: parts[i] is (splits, R, elems / (R * taps[i]), taps[i]) and element ((a, b), t) is added to
+ * dws[i][(b * R + a) * taps[i] + taps[i] - 1 - t] -- nn.ConvNd's (Cout, Cin, k...) order.  Same fixed summation order. */
+int pf_wgrad_reduce_batch_swapped_f32(const float* const* parts, float* const* dws, const int64_t* elems,
+                                      const int* splits, const int* swap_rows, const int* taps, int n, int accumulate,
+                                      void* stream);
 
 
 /* Data gradient of ImageConv's 5x5 / stride 2 / pad 2 convolutions (reference networks.py:93,98,103), i.e.

@@ -417,12 +417,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ Gr
   }
 }
 
-// dw[e] = sum over the splits, in a fixed order: 16 elements x 16 slices per block; slice sl adds splits sl, sl + 16, ...
-// and the 16 slice sums are added in slice order.
+// dw[e] = sum over the splits, in a fixed order: slice sl of 16 adds splits sl, sl + 16, ... and the 16 slice sums are added
+// in slice order.  Block = 64 elements x 16 slices (round 6; it was 16 x 16: a wave then read four 64-byte pieces per load
+// instruction -- the towers' ~95 MB of partials at ~2 TB/s; now a wave reads one 256-byte run.  Same sums, same order).
+// swap_rows = R > 0: the partials are a SWAPPED-OPERAND gradient (R, elems / (R * taps), taps) with every tap axis
+// reversed (pf_wgrad_reduce_batch_swapped_f32); element e = (a * Cb + b) * taps + t lands at (b * R + a) * taps + taps-1-t.
+constexpr int kRedEl = 64, kRedThreads = 16 * kRedEl;
 __device__ __forceinline__ void reduce_block(const float* __restrict__ part, float* __restrict__ dw, int64_t elems,
-                                             int splits, int accumulate, int64_t block, float (*red)[17]) {
-  const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  const int64_t e = block * 16 + el;
+                                             int splits, int accumulate, int64_t block, float (*red)[kRedEl + 1],
+                                             int swap_rows = 0, int taps = 1) {
+  const int el = threadIdx.x & (kRedEl - 1), sl = threadIdx.x / kRedEl;
+  const int64_t e = block * kRedEl + el;
   float s = 0.0f;
   if (e < elems) {
     int k = sl;
@@ -439,16 +444,24 @@ __device__ __forceinline__ void reduce_block(const float* __restrict__ part, flo
   red[sl][el] = s;
   __syncthreads();
   if (sl == 0 && e < elems) {
-    float t = accumulate ? dw[e] : 0.0f;
+    int64_t eo = e;
+    if (swap_rows > 0) {
+      const int64_t cb = elems / ((int64_t)swap_rows * taps);
+      const int64_t tp = e % taps, ab = e / taps;
+      const int64_t a = ab / cb, b = ab - a * cb;
+      eo = (b * swap_rows + a) * taps + (taps - 1 - tp);
+    }
+    float t = accumulate ? dw[eo] : 0.0f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) t += red[i][el];
-    dw[e] = t;
+    dw[eo] = t;
   }
 }
 
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
-                                                           int64_t elems, int splits, int accumulate) {
-  __shared__ float red[16][17];
+__global__ __launch_bounds__(kRedThreads) void wgrad_reduce_kernel(const float* __restrict__ part,
+                                                                   float* __restrict__ dw, int64_t elems, int splits,
+                                                                   int accumulate) {
+  __shared__ float red[16][kRedEl + 1];
   reduce_block(part, dw, elems, splits, accumulate, blockIdx.x, red);
 }
 
@@ -460,15 +473,18 @@ struct RedBatch {
   float* dw[kRedBatch];
   int64_t elems[kRedBatch];
   int splits[kRedBatch];
+  int swap_rows[kRedBatch];
+  int taps[kRedBatch];
   int first_block[kRedBatch + 1];
   int n, accumulate;
 };
 
-__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(RedBatch b) {
-  __shared__ float red[16][17];
+__global__ __launch_bounds__(kRedThreads) void wgrad_reduce_batch_kernel(RedBatch b) {
+  __shared__ float red[16][kRedEl + 1];
   int d = 0;
   while (d + 1 < b.n && (int)blockIdx.x >= b.first_block[d + 1]) ++d;      // block-uniform
-  reduce_block(b.part[d], b.dw[d], b.elems[d], b.splits[d], b.accumulate, (int64_t)blockIdx.x - b.first_block[d], red);
+  reduce_block(b.part[d], b.dw[d], b.elems[d], b.splits[d], b.accumulate, (int64_t)blockIdx.x - b.first_block[d], red,
+               b.swap_rows[d], b.taps[d]);
 }
 
 int ilog2(int v) {
@@ -744,8 +760,8 @@ int run_plan(const float* Gr, const float* X, float* dw, const WgPlan& p, int st
                    : (p.MT == 2 ? launch_wgrad_ntw<2, 2>(Gr, X, part, p, s) : launch_wgrad_ntw<4, 2>(Gr, X, part, p, s));
   }
   if (rc != PF_OK || dw == nullptr) return rc;          // dw == NULL: the partials only (pf_wgrad_reduce_batch_f32 later)
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)pf_cdiv(elems, 16)), dim3(256), 0, s, part, dw, elems,
-                     p.splits, accumulate);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)pf_cdiv(elems, kRedEl)), dim3(kRedThreads), 0, s, part, dw,
+                     elems, p.splits, accumulate);
   return pf_launch_status();
 }
 
@@ -847,7 +863,13 @@ int pf_rows_wgrad_f32(const float* gr, int64_t ldg, const float* x, int64_t ldx,
 
 int pf_wgrad_reduce_batch_f32(const float* const* parts, float* const* dws, const int64_t* elems, const int* splits,
                               int n, int accumulate, void* stream) {
-  PF_REQUIRE(n >= 0 && (n == 0 || (parts && dws && elems && splits)));
+  return pf_wgrad_reduce_batch_swapped_f32(parts, dws, elems, splits, nullptr, nullptr, n, accumulate, stream);
+}
+
+int pf_wgrad_reduce_batch_swapped_f32(const float* const* parts, float* const* dws, const int64_t* elems,
+                                      const int* splits, const int* swap_rows, const int* taps, int n, int accumulate,
+                                      void* stream) {
+  PF_REQUIRE(n >= 0 && (n == 0 || (parts && dws && elems && splits)) && (swap_rows == nullptr) == (taps == nullptr));
   for (int base = 0; base < n; base += kRedBatch) {
     RedBatch b;
     b.n = n - base < kRedBatch ? n - base : kRedBatch;
@@ -859,12 +881,16 @@ int pf_wgrad_reduce_batch_f32(const float* const* parts, float* const* dws, cons
       b.dw[i] = dws[base + i];
       b.elems[i] = elems[base + i];
       b.splits[i] = splits[base + i];
+      b.swap_rows[i] = swap_rows ? swap_rows[base + i] : 0;
+      b.taps[i] = swap_rows ? taps[base + i] : 1;
+      PF_REQUIRE(b.swap_rows[i] >= 0 && b.taps[i] >= 1 &&
+                 (b.swap_rows[i] == 0 || elems[base + i] % ((int64_t)b.swap_rows[i] * b.taps[i]) == 0));
       b.first_block[i] = (int)blocks;
-      blocks += pf_cdiv(elems[base + i], 16);
+      blocks += pf_cdiv(elems[base + i], kRedEl);
       PF_REQUIRE(blocks <= INT32_MAX);
     }
     b.first_block[b.n] = (int)blocks;
-    hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, b);
+    hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)blocks), dim3(kRedThreads), 0, (hipStream_t)stream, b);
     const int rc = pf_launch_status();
     if (rc != PF_OK) return rc;
   }

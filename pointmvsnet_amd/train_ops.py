@@ -115,8 +115,8 @@ WGRAD_BATCH = int(os.environ.get("PF_WGRAD_BATCH", "1"))
 _REDUCE_PENDING = []
 
 
-def _queue_reduce(work, into, elems, nbytes):
-    _REDUCE_PENDING.append((work, into, int(elems), int(nbytes // (4 * elems))))
+def _queue_reduce(work, into, elems, nbytes, swap_rows=0, taps=1):
+    _REDUCE_PENDING.append((work, into, int(elems), int(nbytes // (4 * elems)), int(swap_rows), int(taps)))
 
 
 def _reduce_flush():
@@ -129,12 +129,19 @@ def _reduce_flush():
     dws = (ctypes.c_void_p * n)(*[p[1].data_ptr() for p in pending])
     elems = (ctypes.c_int64 * n)(*[p[2] for p in pending])
     splits = (ctypes.c_int * n)(*[p[3] for p in pending])
+    swapped = any(p[4] for p in pending)
     with torch.cuda.device(pending[0][0].device):
         cur = torch.cuda.current_stream()
         for p in pending:                      # (a partial may have been written on the side stream)
             p[0].record_stream(cur)
-        _lib.call("pf_wgrad_reduce_batch_f32", parts, dws, elems, splits, n, 1, _lib.stream(),
-                  algo_bytes=4.0 * sum(p[2] * p[3] for p in pending))
+        if swapped:
+            rows = (ctypes.c_int * n)(*[p[4] for p in pending])
+            taps = (ctypes.c_int * n)(*[p[5] for p in pending])
+            _lib.call("pf_wgrad_reduce_batch_swapped_f32", parts, dws, elems, splits, rows, taps, n, 1, _lib.stream(),
+                      algo_bytes=4.0 * sum(p[2] * p[3] for p in pending))
+        else:
+            _lib.call("pf_wgrad_reduce_batch_f32", parts, dws, elems, splits, n, 1, _lib.stream(),
+                      algo_bytes=4.0 * sum(p[2] * p[3] for p in pending))
 
 
 def _with_packs(backward):
@@ -323,6 +330,9 @@ def conv_wgrad(gr, x, kernel, stride, pad, x_affine=None, x_samples_per_stat=1, 
     nd = gr.dim() - 2
     N, Cg = gr.shape[:2]
     Cx = x.shape[1]
+    if (WGRAD_SWAP and stride == 1 and x_affine is None and Cg <= 8 and Cg < Cx and gr.shape[2:] == x.shape[2:]
+            and all(2 * p + 1 == k for p, k in zip(pad, kernel))):
+        return _conv_wgrad_swapped(gr, x, kernel, pad, into)
     go = (1,) * (3 - nd) + tuple(gr.shape[2:])
     xi = (1,) * (3 - nd) + tuple(x.shape[2:])
     k3 = (1,) * (3 - nd) + tuple(kernel)
@@ -349,6 +359,44 @@ def conv_wgrad(gr, x, kernel, stride, pad, x_affine=None, x_samples_per_stat=1, 
         return dw if into is None else None
 
     return launch()
+
+
+# Stride-1 'same' layers with at most 8 output channels (VolumeConv's conv0_1 64 -> 8 and conv6_2 8 -> 1): the operands
+# change places (include/pointflow_hip.h, pf_wgrad_reduce_batch_swapped_f32) -- the MFMA rows are the INPUT channels
+# (64 of 64 rows used instead of 8 of 16) and the patch that is staged with its halo is the 8-channel gradient instead of
+# the 64-channel activation.  PF_WGRAD_SWAP=0: the plain form.
+WGRAD_SWAP = int(os.environ.get("PF_WGRAD_SWAP", "1"))
+
+
+def _conv_wgrad_swapped(gr, x, kernel, pad, into):
+    """conv_wgrad(gr, x) as pf_conv_wgrad_f32(gr' = x, x' = gr): partials (Cx, Cg, taps) with reversed taps, put into
+    nn.ConvNd's order by the batched reduce (the step) or by a transpose + flip (a stand-alone call)."""
+    nd = gr.dim() - 2
+    N, Cg = gr.shape[:2]
+    Cx = x.shape[1]
+    sp = (1,) * (3 - nd) + tuple(gr.shape[2:])
+    k3 = (1,) * (3 - nd) + tuple(kernel)
+    p3 = (0,) * (3 - nd) + tuple(pad)
+    taps = k3[0] * k3[1] * k3[2]
+    lib = _lib.load()
+    nbytes = int(lib.pf_conv_wgrad_workspace(N, Cx, Cg, sp[0], sp[1], sp[2], sp[0], sp[1], sp[2], k3[0], k3[1], k3[2], 1))
+    if nbytes < 0:
+        raise RuntimeError("conv_wgrad: unsupported shape")
+    work = torch.empty((max(nbytes, 4) // 4,), dtype=_F32, device=gr.device)
+    batched = into is not None and WGRAD_BATCH and DIRECT_GRADS and into.is_contiguous()
+    dwt = None if batched else torch.empty((Cx, Cg) + tuple(kernel), dtype=_F32, device=gr.device)
+    _lib.call("pf_conv_wgrad_f32", _lib.ptr(x), _lib.ptr(gr), _lib.ptr(dwt), N, Cx, Cg, sp[0], sp[1], sp[2], sp[0], sp[1],
+              sp[2], k3[0], k3[1], k3[2], 1, p3[0], p3[1], p3[2], None, None, 1, _lib.ptr(work), nbytes, 0, _lib.stream(),
+              algo_bytes=4.0 * (gr.numel() + x.numel()) + 4.0 * Cg * Cx * taps,
+              flops=2.0 * N * sp[0] * sp[1] * sp[2] * taps * Cg * Cx)
+    if batched:
+        _queue_reduce(work, into, Cg * Cx * taps, nbytes, swap_rows=Cx, taps=taps)
+        return None
+    dw = dwt.transpose(0, 1).flip(*range(2, 2 + nd)).contiguous()
+    if into is None:
+        return dw
+    into.add_(dw)
+    return None
 
 
 def rows_wgrad(gr, x, Cg, Cx, x_affine=None, x_rows_per_stat=None, into=None):

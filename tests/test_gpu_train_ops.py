@@ -100,6 +100,39 @@ def test_conv_weight_gradient_vs_float64_autograd(dev, N, Cout, Cin, sp, k, stri
     assert dw.shape == w.shape and err < 2e-5, err
 
 
+@pytest.mark.parametrize("N,Cout,Cin,sp", [(1, 8, 64, (8, 16, 24)), (1, 1, 8, (8, 16, 24)), (2, 8, 16, (24, 40)),
+                                           (1, 8, 64, (5, 7, 19))])
+def test_swapped_operand_weight_gradient_in_the_batched_reduce(dev, N, Cout, Cin, sp, monkeypatch):
+    """Stride-1 layers with <= 8 output channels run pf_conv_wgrad_f32 with the operands swapped; inside the step the
+    (Cin, Cout, reversed taps) partials are put into nn.ConvNd's order by pf_wgrad_reduce_batch_swapped_f32, ADDED into the
+    gradient slot, in one launch with a plain layer's partials.  Against float64 autograd, and against PF_WGRAD_SWAP=0."""
+    nd = len(sp)
+    conv = F.conv2d if nd == 2 else F.conv3d
+    x = _seeded((N, Cin) + sp, dev, 11)
+    dy = _seeded((N, Cout) + sp, dev, 12)
+    x2 = _seeded((N, 16) + sp, dev, 13)                  # a second, plain layer (16 -> 16) in the same reduce launch
+    dy2 = _seeded((N, 16) + sp, dev, 14)
+    w = torch.zeros((Cout, Cin) + (3,) * nd, dtype=torch.float64, device=dev, requires_grad=True)
+    w2 = torch.zeros((16, 16) + (3,) * nd, dtype=torch.float64, device=dev, requires_grad=True)
+    conv(x.double(), w, None, 1, 1).backward(dy.double())
+    conv(x2.double(), w2, None, 1, 1).backward(dy2.double())
+    outs = {}
+    for swap in (1, 0):
+        monkeypatch.setattr(train_ops, "WGRAD_SWAP", swap)
+        slot = torch.full(w.shape, 0.25, dtype=torch.float32, device=dev)      # "into": the bucket's slot, dw is ADDED
+        slot2 = torch.full(w2.shape, -0.5, dtype=torch.float32, device=dev)
+        with train_ops.direct_grads(True):
+            assert train_ops.conv_wgrad(dy, x, (3,) * nd, 1, (1,) * nd, into=slot) is None
+            assert train_ops.conv_wgrad(dy2, x2, (3,) * nd, 1, (1,) * nd, into=slot2) is None
+            assert len(train_ops._REDUCE_PENDING) == 2 and bool(train_ops._REDUCE_PENDING[0][4]) == bool(swap)
+            train_ops._reduce_flush()
+        outs[swap] = (slot - 0.25, slot2 + 0.5)
+    e1, e0, e2 = _rel(outs[1][0], w.grad), _rel(outs[0][0], w.grad), _rel(outs[1][1], w2.grad)
+    report("conv_wgrad_swapped_%dd_%dto%d" % (nd, Cin, Cout), rel=e1, rel_plain=e0, rel_neighbour=e2)
+    assert e1 < 2e-5 and e0 < 2e-5 and e2 < 2e-5, (e1, e0, e2)
+    assert torch.equal(outs[1][1], outs[0][1])                     # the plain neighbour does not notice
+
+
 @pytest.mark.parametrize("Cin,Cout,sp", [(64, 32, (2, 4, 6)), (32, 16, (4, 8, 12)), (16, 8, (8, 8, 12))])
 def test_transposed_conv_weight_gradient_vs_float64_autograd(dev, Cin, Cout, sp):
     """ConvTranspose3d(3, stride 2, pad 1, output_padding 1), VolumeConv's decoder (networks.py:141-143): the layer

@@ -72,6 +72,8 @@ def _wgrad_key_conv2d(cout, cin, sp, k, stride, affine):
 def _wgrad_key_volume(kind, cout, cin, sp, stride):
     if kind == "conv":
         o = _out(sp, stride)
+        if stride == 1 and cout <= 8 and cout < cin:     # operands swapped (train_ops.WGRAD_SWAP): conv0_1, conv6_2
+            return ("conv", 1, cin, cout) + tuple(sp) + o + (3, 3, 3, 1, False)
         return ("conv", 1, cout, cin) + o + tuple(sp) + (3, 3, 3, stride, False)
     fine = tuple(2 * s for s in sp)                     # transposed: gr = the layer input (coarse), x = dL/dy (fine)
     return ("conv", 1, cin, cout) + tuple(sp) + fine + (3, 3, 3, 2, False)
@@ -176,6 +178,8 @@ def test_volume_weight_gradient_at_cfg4_shape(dev, name, kind, Cout, Cin, sp, st
         F.conv3d(x.double(), w, None, stride, 1).backward(dy.double())
         run = lambda: train_ops.conv_wgrad(dy, x, (3, 3, 3), stride, (1, 1, 1))
         plan = _plan_conv(1, Cout, Cin, osp, sp, (3, 3, 3), stride)
+        if stride == 1 and Cout <= 8 and Cout < Cin:             # conv0_1, conv6_2: the launch runs with the operands swapped
+            plan = _plan_conv(1, Cin, Cout, sp, osp, (3, 3, 3), 1)
     else:
         osp = tuple(2 * s for s in sp)
         dy = _seeded((1, Cout) + osp, dev, 10)
