@@ -553,21 +553,20 @@ int64_t pf_rows_wgrad_workspace(int64_t P, int Cg, int Cx);
 int pf_rows_wgrad_f32(const float* gr, int64_t ldg, const float* x, int64_t ldx, float* dw, int64_t P, int Cg, int Cx,
                       const float* x_scale, const float* x_shift, int64_t x_rows_per_stat, void* workspace,
                       int64_t workspace_bytes, int accumulate, void* stream);
-/* dw == NULL in the two calls above: the split partials only (workspace holds (splits, Cg, Cx, taps), splits =
- * workspace bytes / (4 * Cg * Cx * taps)); pf_wgrad_reduce_batch_f32 then adds the partials of n layers in ONE launch,
- * each in the same fixed order as the single call (bit-identical results): dws[i][e] (+)= sum_k parts[i][k][e]. */
+/* dw == NULL in the two calls above: the split partials only.  The workspace then holds (splits, Cg, taps, Cx), splits =
+ * workspace bytes / (4 * Cg * Cx * taps) -- the channel index fastest: what the kernel's lanes store as 64-byte runs
+ * (round 6; it was (splits, Cg, Cx, taps)).  pf_wgrad_reduce_batch_f32 adds the partials of n layers in ONE launch, each
+ * in the same fixed order as the single call (bit-identical results), and puts the sums into nn.ConvNd's order:
+ * rows[i] = the Cg and taps[i] the KD * KH * KW (1 for pf_rows_wgrad_f32) of the call that wrote parts[i];
+ *   swapped[i] == 0:  dws[i][(a * B + b) * T + t]         (+)= sum_k parts[i][k][(a * T + t) * B + b],  B = elems / (rows * T);
+ *   swapped[i] != 0:  dws[i][(b * A + a) * T + T - 1 - t] (+)= the same sum,  A = rows[i].
+ * SWAPPED: for a stride-1 'same' convolution the two operands of pf_conv_wgrad_f32 may change places -- gr' = x,
+ * x' = dL/dy -- which gives dW'[cx][cg][k'] = dW[cg][cx][K-1-k'] per axis: the rows of the MFMA tile are then the layer's
+ * INPUT channels and the patch staged with its halo is the (narrow) gradient tensor.  VolumeConv's conv0_1 (64 -> 8: 8 of
+ * 16 MFMA rows used, a 64-channel halo patch per tile) and conv6_2 (8 -> 1: 1 of 16 rows) take it (reference
+ * networks.py:134,147 under train.py:80; round 6: 185 -> 115 us and 38 -> 27 us at config 4). */
 int pf_wgrad_reduce_batch_f32(const float* const* parts, float* const* dws, const int64_t* elems, const int* splits,
-                              int n, int accumulate, void* stream);
-/* The same with SWAPPED-OPERAND layers among them (round 6).  For a stride-1 'same' convolution the two operands of
- * pf_conv_wgrad_f32 may change places -- gr' = x, x' = dL/dy -- which gives dW'[cx][cg][k'] = dW[cg][cx][K-1-k'] per axis:
- * the rows of the MFMA tile are then the layer's INPUT channels and the patch with the halo is the (narrow) gradient
- * tensor.  VolumeConv's conv0_1 (64 -> 8: 8 of 16 MFMA rows used, a 64-channel halo patch staged per tile) and conv6_2
- * (8 -> 1: 1 of 16 rows) take it (reference networks.py:134,147 under train.py:80).  swap_rows[i] = 0: layer i as in the
- * call above; = R > 0: parts[i] is (splits, R, elems / (R * taps[i]), taps[i]) and element ((a, b), t) is added to
- * dws[i][(b * R + a) * taps[i] + taps[i] - 1 - t] -- nn.ConvNd's (Cout, Cin, k...) order.  Same fixed summation order. */
-int pf_wgrad_reduce_batch_swapped_f32(const float* const* parts, float* const* dws, const int64_t* elems,
-                                      const int* splits, const int* swap_rows, const int* taps, int n, int accumulate,
-                                      void* stream);
+                              const int* rows, const int* taps, const int* swapped, int n, int accumulate, void* stream);
 
 
 /* Data gradient of ImageConv's 5x5 / stride 2 / pad 2 convolutions (reference networks.py:93,98,103), i.e.

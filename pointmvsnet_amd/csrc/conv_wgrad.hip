@@ -29,9 +29,11 @@
 //     the 32 lanes of a half-wave read 32 different LDS banks for A and for B (stride 1);
 //   * column tiles are dealt round-robin to the four waves; every wave reads the A operands (Gr) of a position row
 //     once and reuses them for all its column tiles;
-//   * at the end each block writes its partial dW to a workspace (split, Cg, Cx, taps); a second kernel adds the
-//     splits in split order: plain stores, fixed order -- the gradient is bit-reproducible run to run (the library's
-//     split-K solvers use float atomics).
+//   * at the end each block writes its partial dW to a workspace (split, Cg, taps, Cx) -- channel fastest (round 6): the
+//     16 lanes of a column tile hold 16 consecutive channels, so a store instruction writes four 64-byte runs where
+//     (split, Cg, Cx, taps) made it 64 four-byte pieces 36-100 bytes apart; a second kernel adds the splits in split
+//     order and puts the sums into nn.ConvNd's (Cg, Cx, taps) order: plain stores, fixed order -- the gradient is
+//     bit-reproducible run to run (the library's split-K solvers use float atomics).
 // Bound: fp32 MFMA (2 * taps * Cg * Cx flop per position against 4 * (Cg + Cx) bytes); the 8-channel layers fill half
 // of the 16 MFMA rows.
 #include <stdlib.h>
@@ -411,7 +413,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ Gr
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int cg = cg0 + m * 16 + lk * 4 + r;
-        if (cg < g.Cg) pb[((int64_t)cg * g.Cx + ci) * g.T + tap] = acc[m][t][r];
+        if (cg < g.Cg) pb[((int64_t)cg * g.T + tap) * g.Cx + ci] = acc[m][t][r];
       }
     }
   }
@@ -420,12 +422,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ Gr
 // dw[e] = sum over the splits, in a fixed order: slice sl of 16 adds splits sl, sl + 16, ... and the 16 slice sums are added
 // in slice order.  Block = 64 elements x 16 slices (round 6; it was 16 x 16: a wave then read four 64-byte pieces per load
 // instruction -- the towers' ~95 MB of partials at ~2 TB/s; now a wave reads one 256-byte run.  Same sums, same order).
-// swap_rows = R > 0: the partials are a SWAPPED-OPERAND gradient (R, elems / (R * taps), taps) with every tap axis
-// reversed (pf_wgrad_reduce_batch_swapped_f32); element e = (a * Cb + b) * taps + t lands at (b * R + a) * taps + taps-1-t.
+// The partials are (rows A, taps T, columns B), B fastest (what wgrad_kernel stores); element e' = (a * T + t) * B + b lands
+// at (a * B + b) * T + t -- or, for a SWAPPED-OPERAND launch (rows = the layer's input channels, every tap axis reversed),
+// at (b * A + a) * T + T - 1 - t: nn.ConvNd's (Cout, Cin, taps) order either way.
 constexpr int kRedEl = 64, kRedThreads = 16 * kRedEl;
 __device__ __forceinline__ void reduce_block(const float* __restrict__ part, float* __restrict__ dw, int64_t elems,
                                              int splits, int accumulate, int64_t block, float (*red)[kRedEl + 1],
-                                             int swap_rows = 0, int taps = 1) {
+                                             int rows, int taps, int swapped) {
   const int el = threadIdx.x & (kRedEl - 1), sl = threadIdx.x / kRedEl;
   const int64_t e = block * kRedEl + el;
   float s = 0.0f;
@@ -444,13 +447,10 @@ __device__ __forceinline__ void reduce_block(const float* __restrict__ part, flo
   red[sl][el] = s;
   __syncthreads();
   if (sl == 0 && e < elems) {
-    int64_t eo = e;
-    if (swap_rows > 0) {
-      const int64_t cb = elems / ((int64_t)swap_rows * taps);
-      const int64_t tp = e % taps, ab = e / taps;
-      const int64_t a = ab / cb, b = ab - a * cb;
-      eo = (b * swap_rows + a) * taps + (taps - 1 - tp);
-    }
+    const int64_t cols = elems / ((int64_t)rows * taps);
+    const int64_t b = e % cols, at = e / cols;
+    const int64_t a = at / taps, tp = at - a * taps;
+    const int64_t eo = swapped ? (b * rows + a) * taps + (taps - 1 - tp) : (a * cols + b) * taps + tp;
     float t = accumulate ? dw[eo] : 0.0f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) t += red[i][el];
@@ -460,9 +460,9 @@ __device__ __forceinline__ void reduce_block(const float* __restrict__ part, flo
 
 __global__ __launch_bounds__(kRedThreads) void wgrad_reduce_kernel(const float* __restrict__ part,
                                                                    float* __restrict__ dw, int64_t elems, int splits,
-                                                                   int accumulate) {
+                                                                   int accumulate, int rows, int taps) {
   __shared__ float red[16][kRedEl + 1];
-  reduce_block(part, dw, elems, splits, accumulate, blockIdx.x, red);
+  reduce_block(part, dw, elems, splits, accumulate, blockIdx.x, red, rows, taps, 0);
 }
 
 // Up to kRedBatch layers' reductions in one launch (the training step queues a node's weight gradients and reduces
@@ -473,8 +473,9 @@ struct RedBatch {
   float* dw[kRedBatch];
   int64_t elems[kRedBatch];
   int splits[kRedBatch];
-  int swap_rows[kRedBatch];
+  int rows[kRedBatch];
   int taps[kRedBatch];
+  int swapped[kRedBatch];
   int first_block[kRedBatch + 1];
   int n, accumulate;
 };
@@ -484,7 +485,7 @@ __global__ __launch_bounds__(kRedThreads) void wgrad_reduce_batch_kernel(RedBatc
   int d = 0;
   while (d + 1 < b.n && (int)blockIdx.x >= b.first_block[d + 1]) ++d;      // block-uniform
   reduce_block(b.part[d], b.dw[d], b.elems[d], b.splits[d], b.accumulate, (int64_t)blockIdx.x - b.first_block[d], red,
-               b.swap_rows[d], b.taps[d]);
+               b.rows[d], b.taps[d], b.swapped[d]);
 }
 
 int ilog2(int v) {
@@ -761,7 +762,7 @@ int run_plan(const float* Gr, const float* X, float* dw, const WgPlan& p, int st
   }
   if (rc != PF_OK || dw == nullptr) return rc;          // dw == NULL: the partials only (pf_wgrad_reduce_batch_f32 later)
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)pf_cdiv(elems, kRedEl)), dim3(kRedThreads), 0, s, part, dw,
-                     elems, p.splits, accumulate);
+                     elems, p.splits, accumulate, p.g.Cg, p.g.T);
   return pf_launch_status();
 }
 
@@ -862,14 +863,8 @@ int pf_rows_wgrad_f32(const float* gr, int64_t ldg, const float* x, int64_t ldx,
 }
 
 int pf_wgrad_reduce_batch_f32(const float* const* parts, float* const* dws, const int64_t* elems, const int* splits,
-                              int n, int accumulate, void* stream) {
-  return pf_wgrad_reduce_batch_swapped_f32(parts, dws, elems, splits, nullptr, nullptr, n, accumulate, stream);
-}
-
-int pf_wgrad_reduce_batch_swapped_f32(const float* const* parts, float* const* dws, const int64_t* elems,
-                                      const int* splits, const int* swap_rows, const int* taps, int n, int accumulate,
-                                      void* stream) {
-  PF_REQUIRE(n >= 0 && (n == 0 || (parts && dws && elems && splits)) && (swap_rows == nullptr) == (taps == nullptr));
+                              const int* rows, const int* taps, const int* swapped, int n, int accumulate, void* stream) {
+  PF_REQUIRE(n >= 0 && (n == 0 || (parts && dws && elems && splits && rows && taps && swapped)));
   for (int base = 0; base < n; base += kRedBatch) {
     RedBatch b;
     b.n = n - base < kRedBatch ? n - base : kRedBatch;
@@ -881,10 +876,10 @@ int pf_wgrad_reduce_batch_swapped_f32(const float* const* parts, float* const* d
       b.dw[i] = dws[base + i];
       b.elems[i] = elems[base + i];
       b.splits[i] = splits[base + i];
-      b.swap_rows[i] = swap_rows ? swap_rows[base + i] : 0;
-      b.taps[i] = swap_rows ? taps[base + i] : 1;
-      PF_REQUIRE(b.swap_rows[i] >= 0 && b.taps[i] >= 1 &&
-                 (b.swap_rows[i] == 0 || elems[base + i] % ((int64_t)b.swap_rows[i] * b.taps[i]) == 0));
+      b.rows[i] = rows[base + i];
+      b.taps[i] = taps[base + i];
+      b.swapped[i] = swapped[base + i] ? 1 : 0;
+      PF_REQUIRE(b.rows[i] >= 1 && b.taps[i] >= 1 && elems[base + i] % ((int64_t)b.rows[i] * b.taps[i]) == 0);
       b.first_block[i] = (int)blocks;
       blocks += pf_cdiv(elems[base + i], kRedEl);
       PF_REQUIRE(blocks <= INT32_MAX);

@@ -115,8 +115,10 @@ WGRAD_BATCH = int(os.environ.get("PF_WGRAD_BATCH", "1"))
 _REDUCE_PENDING = []
 
 
-def _queue_reduce(work, into, elems, nbytes, swap_rows=0, taps=1):
-    _REDUCE_PENDING.append((work, into, int(elems), int(nbytes // (4 * elems)), int(swap_rows), int(taps)))
+def _queue_reduce(work, into, elems, nbytes, rows, taps=1, swapped=False):
+    """``rows`` / ``taps``: the Cg and the tap count of the launch that wrote ``work`` (its partials are (splits, rows, taps,
+    columns)); ``swapped``: a swapped-operand launch (_conv_wgrad_swapped)."""
+    _REDUCE_PENDING.append((work, into, int(elems), int(nbytes // (4 * elems)), int(rows), int(taps), int(bool(swapped))))
 
 
 def _reduce_flush():
@@ -129,19 +131,15 @@ def _reduce_flush():
     dws = (ctypes.c_void_p * n)(*[p[1].data_ptr() for p in pending])
     elems = (ctypes.c_int64 * n)(*[p[2] for p in pending])
     splits = (ctypes.c_int * n)(*[p[3] for p in pending])
-    swapped = any(p[4] for p in pending)
+    rows = (ctypes.c_int * n)(*[p[4] for p in pending])
+    taps = (ctypes.c_int * n)(*[p[5] for p in pending])
+    swapped = (ctypes.c_int * n)(*[p[6] for p in pending])
     with torch.cuda.device(pending[0][0].device):
         cur = torch.cuda.current_stream()
         for p in pending:                      # (a partial may have been written on the side stream)
             p[0].record_stream(cur)
-        if swapped:
-            rows = (ctypes.c_int * n)(*[p[4] for p in pending])
-            taps = (ctypes.c_int * n)(*[p[5] for p in pending])
-            _lib.call("pf_wgrad_reduce_batch_swapped_f32", parts, dws, elems, splits, rows, taps, n, 1, _lib.stream(),
-                      algo_bytes=4.0 * sum(p[2] * p[3] for p in pending))
-        else:
-            _lib.call("pf_wgrad_reduce_batch_f32", parts, dws, elems, splits, n, 1, _lib.stream(),
-                      algo_bytes=4.0 * sum(p[2] * p[3] for p in pending))
+        _lib.call("pf_wgrad_reduce_batch_f32", parts, dws, elems, splits, rows, taps, swapped, n, 1, _lib.stream(),
+                  algo_bytes=4.0 * sum(p[2] * p[3] for p in pending))
 
 
 def _with_packs(backward):
@@ -355,14 +353,14 @@ def conv_wgrad(gr, x, kernel, stride, pad, x_affine=None, x_samples_per_stat=1, 
                   algo_bytes=4.0 * (gr.numel() + x.numel()) + 4.0 * dw.numel(),
                   flops=2.0 * N * go[0] * go[1] * go[2] * taps * Cg * Cx)
         if batched:
-            _queue_reduce(work, into, Cg * Cx * taps, nbytes)
+            _queue_reduce(work, into, Cg * Cx * taps, nbytes, Cg, taps)
         return dw if into is None else None
 
     return launch()
 
 
 # Stride-1 'same' layers with at most 8 output channels (VolumeConv's conv0_1 64 -> 8 and conv6_2 8 -> 1): the operands
-# change places (include/pointflow_hip.h, pf_wgrad_reduce_batch_swapped_f32) -- the MFMA rows are the INPUT channels
+# change places (include/pointflow_hip.h, pf_wgrad_reduce_batch_f32's `swapped`) -- the MFMA rows are the INPUT channels
 # (64 of 64 rows used instead of 8 of 16) and the patch that is staged with its halo is the 8-channel gradient instead of
 # the 64-channel activation.  PF_WGRAD_SWAP=0: the plain form.
 WGRAD_SWAP = int(os.environ.get("PF_WGRAD_SWAP", "1"))
@@ -390,7 +388,7 @@ def _conv_wgrad_swapped(gr, x, kernel, pad, into):
               algo_bytes=4.0 * (gr.numel() + x.numel()) + 4.0 * Cg * Cx * taps,
               flops=2.0 * N * sp[0] * sp[1] * sp[2] * taps * Cg * Cx)
     if batched:
-        _queue_reduce(work, into, Cg * Cx * taps, nbytes, swap_rows=Cx, taps=taps)
+        _queue_reduce(work, into, Cg * Cx * taps, nbytes, Cx, taps, swapped=True)
         return None
     dw = dwt.transpose(0, 1).flip(*range(2, 2 + nd)).contiguous()
     if into is None:
@@ -417,7 +415,7 @@ def rows_wgrad(gr, x, Cg, Cx, x_affine=None, x_rows_per_stat=None, into=None):
                   int(x_rows_per_stat or P), _lib.ptr(work), nbytes, 0 if into is None else 1, _lib.stream(),
                   algo_bytes=4.0 * P * (Cg + Cx) + 4.0 * Cg * Cx, flops=2.0 * P * Cg * Cx)
         if batched:
-            _queue_reduce(work, into, int(Cg) * int(Cx), nbytes)
+            _queue_reduce(work, into, int(Cg) * int(Cx), nbytes, int(Cg), 1)
         return dw if into is None else None
 
     return launch()

@@ -104,7 +104,7 @@ def test_conv_weight_gradient_vs_float64_autograd(dev, N, Cout, Cin, sp, k, stri
                                            (1, 8, 64, (5, 7, 19))])
 def test_swapped_operand_weight_gradient_in_the_batched_reduce(dev, N, Cout, Cin, sp, monkeypatch):
     """Stride-1 layers with <= 8 output channels run pf_conv_wgrad_f32 with the operands swapped; inside the step the
-    (Cin, Cout, reversed taps) partials are put into nn.ConvNd's order by pf_wgrad_reduce_batch_swapped_f32, ADDED into the
+    (Cin, Cout, reversed taps) partials are put into nn.ConvNd's order by pf_wgrad_reduce_batch_f32 (swapped), ADDED into the
     gradient slot, in one launch with a plain layer's partials.  Against float64 autograd, and against PF_WGRAD_SWAP=0."""
     nd = len(sp)
     conv = F.conv2d if nd == 2 else F.conv3d
@@ -124,7 +124,7 @@ def test_swapped_operand_weight_gradient_in_the_batched_reduce(dev, N, Cout, Cin
         with train_ops.direct_grads(True):
             assert train_ops.conv_wgrad(dy, x, (3,) * nd, 1, (1,) * nd, into=slot) is None
             assert train_ops.conv_wgrad(dy2, x2, (3,) * nd, 1, (1,) * nd, into=slot2) is None
-            assert len(train_ops._REDUCE_PENDING) == 2 and bool(train_ops._REDUCE_PENDING[0][4]) == bool(swap)
+            assert len(train_ops._REDUCE_PENDING) == 2 and bool(train_ops._REDUCE_PENDING[0][6]) == bool(swap)
             train_ops._reduce_flush()
         outs[swap] = (slot - 0.25, slot2 + 0.5)
     e1, e0, e2 = _rel(outs[1][0], w.grad), _rel(outs[0][0], w.grad), _rel(outs[1][1], w2.grad)
