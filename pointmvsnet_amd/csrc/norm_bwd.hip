@@ -334,23 +334,74 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const float* __
 // ------------------------------------------------------------------------------------------------
 // point-major rows (P, ld): the flow MLP's BatchNorm1d (reference nn/conv.py:24-35 via nn/mlp.py:45-81)
 // ------------------------------------------------------------------------------------------------
-// G groups of Ng rows; block (t, g) reduces rows [t*chunk, (t+1)*chunk) of group g: thread = (column c = tid % C,
-// row phase tid / C), C in {16, 32, 64, 128}.  partials (G, T, C, 2).
-constexpr int kRowT = 512;     // blocks per group (at most)
+// G groups of Ng rows; block (t, g) reduces rows [t*chunk, (t+1)*chunk) of group g.  partials (G, T, C, 2).
+// Round 6: 64 rows per block (was 256: 100 blocks of serial 4-byte loads took 22 us for the 13 MB of a 25 600-point
+// layer) and, where the rows allow 16-byte loads, thread = (4 columns, row phase); else thread = (column, row phase).
+constexpr int kRowT = 2048;    // blocks per group (at most)
+constexpr int kRowsPerBlock = 64;
 
 __global__ __launch_bounds__(256) void rows_bn_bwd_reduce_kernel(const float* __restrict__ g, int64_t ldg,
                                                                  const float* __restrict__ y, int64_t ldy,
                                                                  const float* __restrict__ rows, int C, int Ng,
                                                                  int chunk, int gps, int relu,
-                                                                 double* __restrict__ partials, int T) {
-  __shared__ double2 red[256];
+                                                                 double* __restrict__ partials, int T, int vec) {
+  __shared__ double2 red[256 * 4];
   const int tid = threadIdx.x;
   const int t = blockIdx.x, grp = blockIdx.y;
-  const int c = tid % C, ph = tid / C, nph = 256 / C;
   const int64_t SC = (int64_t)(gridDim.y / gps) * C;
+  const int lo = t * chunk, hi = min(Ng, lo + chunk);
+  if (vec) {
+    const int C4 = C >> 2;
+    const int cq = tid % C4, ph = tid / C4, nph = 256 / C4;
+    const float* r = rows + (int64_t)(grp / gps) * C + 4 * cq;
+    const float4 sc = *reinterpret_cast<const float4*>(r), sh = *reinterpret_cast<const float4*>(r + SC);
+    const float4 mean = *reinterpret_cast<const float4*>(r + 2 * SC), invstd = *reinterpret_cast<const float4*>(r + 3 * SC);
+    float s[4] = {0.0f, 0.0f, 0.0f, 0.0f}, q[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    double ds[4] = {0.0, 0.0, 0.0, 0.0}, dq[4] = {0.0, 0.0, 0.0, 0.0};
+    int cnt = 0;
+    for (int m = lo + ph; m < hi; m += nph) {
+      const int64_t row = (int64_t)grp * Ng + m;
+      const float4 gv = *reinterpret_cast<const float4*>(g + row * ldg + 4 * cq);
+      const float4 yv = *reinterpret_cast<const float4*>(y + row * ldy + 4 * cq);
+      const float mk0 = masked(gv.x, yv.x, sc.x, sh.x, relu), mk1 = masked(gv.y, yv.y, sc.y, sh.y, relu);
+      const float mk2 = masked(gv.z, yv.z, sc.z, sh.z, relu), mk3 = masked(gv.w, yv.w, sc.w, sh.w, relu);
+      s[0] += mk0;
+      s[1] += mk1;
+      s[2] += mk2;
+      s[3] += mk3;
+      q[0] += mk0 * ((yv.x - mean.x) * invstd.x);
+      q[1] += mk1 * ((yv.y - mean.y) * invstd.y);
+      q[2] += mk2 * ((yv.z - mean.z) * invstd.z);
+      q[3] += mk3 * ((yv.w - mean.w) * invstd.w);
+      if (++cnt == 64) {            // float32 over short runs, float64 across them
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          ds[j] += (double)s[j];
+          dq[j] += (double)q[j];
+          s[j] = q[j] = 0.0f;
+        }
+        cnt = 0;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[(ph * C4 + cq) * 4 + j] = make_double2(ds[j] + (double)s[j], dq[j] + (double)q[j]);
+    __syncthreads();
+    if (tid < C) {                  // column tid: its quad's phases in order
+      const int qd = tid >> 2, j = tid & 3;
+      double a = 0.0, b = 0.0;
+      for (int i = 0; i < nph; ++i) {
+        a += red[(i * C4 + qd) * 4 + j].x;
+        b += red[(i * C4 + qd) * 4 + j].y;
+      }
+      double* o = partials + (((int64_t)grp * T + t) * C + tid) * 2;
+      o[0] = a;
+      o[1] = b;
+    }
+    return;
+  }
+  const int c = tid % C, ph = tid / C, nph = 256 / C;
   const float* r = rows + (int64_t)(grp / gps) * C + c;
   const float sc = r[0], sh = r[SC], mean = r[2 * SC], invstd = r[3 * SC];
-  const int lo = t * chunk, hi = min(Ng, lo + chunk);
   double ds = 0.0, dq = 0.0;
   float s = 0.0f, q = 0.0f;
   int cnt = 0;
@@ -571,7 +622,7 @@ int pf_bn_bwd_apply_f32(const float* g, const float* y, const float* rows, const
 
 int pf_rows_bn_blocks(int G, int Ng) {
   if (G <= 0 || Ng <= 0) return 0;
-  const int t = (Ng + 255) / 256;            // >= 256 rows per block
+  const int t = (Ng + kRowsPerBlock - 1) / kRowsPerBlock;
   return t > kRowT ? kRowT : t;
 }
 
@@ -583,8 +634,10 @@ int pf_rows_bn_bwd_reduce_f32(const float* g, int64_t ldg, const float* y, int64
   PF_REQUIRE(g && y && rows && partials && (G % groups_per_stat) == 0);
   const int T = pf_rows_bn_blocks(G, Ng);
   const int chunk = (Ng + T - 1) / T;
+  const int vec = ((ldg | ldy) & 3) == 0 && (((uintptr_t)g | (uintptr_t)y | (uintptr_t)rows) & 15) == 0 &&
+                  ((int64_t)(G / groups_per_stat) * C & 3) == 0;
   hipLaunchKernelGGL(rows_bn_bwd_reduce_kernel, dim3((unsigned)T, (unsigned)G), dim3(256), 0, (hipStream_t)stream, g, ldg,
-                     y, ldy, rows, C, Ng, chunk, groups_per_stat, relu, partials, T);
+                     y, ldy, rows, C, Ng, chunk, groups_per_stat, relu, partials, T, vec);
   return pf_launch_status();
 }
 

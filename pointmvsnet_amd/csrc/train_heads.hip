@@ -22,7 +22,44 @@ __device__ __forceinline__ float linspace_at(float start, float end, float step,
   return (k < D / 2) ? (start + step * (float)k) : (end - step * (float)(D - 1 - k));
 }
 
-// one thread per pixel: softmax(-cost) recomputed exactly as the forward kernel rounds it (max, sum of expf, quotient)
+// one thread per pixel: softmax(-cost) recomputed exactly as the forward kernel rounds it (max, sum of expf, quotient).
+// DT = the number of depth planes at compile time (48: BASELINE configs 2 and 4; 96: config 3) or 0 (any D, below).
+// With D a run-time bound the three passes were 3 x 48 loads one round trip after the other on 20 blocks of 256 pixels
+// (40 us for 1 MB at config 4); with D known the column sits in registers after ONE batch of loads, and 64-pixel blocks
+// put the 5 120 pixels on 80 CUs (round 6).  Same arithmetic in the same order.
+template <int DT>
+__global__ __launch_bounds__(64) void softargmin_bwd_fixed_kernel(const float* __restrict__ cost,
+                                                                  const float* __restrict__ params,
+                                                                  const float* __restrict__ depth,
+                                                                  const float* __restrict__ gdepth,
+                                                                  float* __restrict__ gcost, int64_t HW) {
+  constexpr int D = DT;
+  const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  const int64_t b = blockIdx.y;
+  if (i >= HW) return;
+  const float start = params[b * 3 + 0], end = params[b * 3 + 1];
+  const float step = (D > 1) ? (end - start) / (float)(D - 1) : 0.0f;
+  const float* c = cost + b * D * HW + i;
+  float* gc = gcost + b * D * HW + i;
+  float cv[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) cv[k] = -c[(int64_t)k * HW];
+  float mx = -__builtin_huge_valf();
+#pragma unroll
+  for (int k = 0; k < D; ++k) mx = fmaxf(mx, cv[k]);
+  constexpr int dq = (D + 3) >> 2;
+  float part[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    cv[k] = expf(cv[k] - mx);
+    part[k / dq] += cv[k];
+  }
+  const float den = ((part[0] + part[1]) + part[2]) + part[3];
+  const float dep = depth[b * HW + i], g = gdepth[b * HW + i];
+#pragma unroll
+  for (int k = 0; k < D; ++k) gc[(int64_t)k * HW] = -g * (cv[k] / den) * (linspace_at(start, end, step, k, D) - dep);
+}
+
 __global__ __launch_bounds__(256) void softargmin_bwd_kernel(const float* __restrict__ cost,
                                                              const float* __restrict__ params,
                                                              const float* __restrict__ depth,
@@ -152,13 +189,23 @@ __global__ __launch_bounds__(256) void flow_head_bwd_kernel(const float* __restr
         ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
 
-__global__ __launch_bounds__(64) void flow_head_wsum_kernel(const double* __restrict__ partials, int blocks,
-                                                            float* __restrict__ gw, int accumulate) {
-  const int c = threadIdx.x;
-  if (c >= 16) return;
+// 16 weights x 16 slices: slice sl adds blocks sl, sl + 16, ... and the slices are added in slice order (fixed order).
+// (Round 6: it was 16 threads adding `blocks` dependent loads each -- 24 us for the 80 partial rows of a 20 480-pixel map.)
+__global__ __launch_bounds__(256) void flow_head_wsum_kernel(const double* __restrict__ partials, int blocks,
+                                                             float* __restrict__ gw, int accumulate) {
+  __shared__ double red[16][16];
+  const int c = threadIdx.x & 15, sl = threadIdx.x >> 4;
   double s = 0.0;
-  for (int b = 0; b < blocks; ++b) s += partials[(int64_t)b * 16 + c];
-  gw[c] = (accumulate ? gw[c] : 0.0f) + (float)s;
+#pragma unroll 4
+  for (int b = sl; b < blocks; b += 16) s += partials[(int64_t)b * 16 + c];
+  red[sl][c] = s;
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    double t = 0.0;
+#pragma unroll 1
+    for (int i = 0; i < 16; ++i) t += red[i][c];
+    gw[c] = (accumulate ? gw[c] : 0.0f) + (float)t;
+  }
 }
 
 // ---- masked MAE ----------------------------------------------------------------------------------------------
@@ -180,12 +227,25 @@ __global__ __launch_bounds__(1024) void masked_mae_kernel(const float* __restric
   double total = 0.0;
   for (int b = 0; b < B; ++b) {
     double e = 0.0, c = 0.0;
-    for (int i = threadIdx.x; i < h * w; i += 1024) {
-      const int y = i / w, x = i - y * w;
-      const float g = gt[((int64_t)b * H + nearest_src(y, sy, H)) * W + nearest_src(x, sx, W)];
-      if (g != 0.0f) {
-        c += 1.0;
-        e += (double)fabsf(pred[(int64_t)b * h * w + i] - g);
+    // four pixels per trip, both loads unconditional: the loop was 2 dependent round trips per pixel on ONE block
+    // (19 us for a 20 480-pixel map); a thread still adds its pixels in ascending order
+    for (int i0 = threadIdx.x; i0 < h * w; i0 += 4096) {
+      float gv[4], pv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + 1024 * u;
+        const int ii = i < h * w ? i : 0;
+        const int y = ii / w, x = ii - y * w;
+        gv[u] = gt[((int64_t)b * H + nearest_src(y, sy, H)) * W + nearest_src(x, sx, W)];
+        pv[u] = pred[(int64_t)b * h * w + ii];
+        if (i >= h * w) gv[u] = 0.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (gv[u] != 0.0f) {
+          c += 1.0;
+          e += (double)fabsf(pv[u] - gv[u]);
+        }
       }
     }
 #pragma unroll
@@ -279,6 +339,16 @@ int pf_softargmin_backward_f32(const float* cost, const float* params, const flo
   PF_REQUIRE(B >= 0 && D >= 1 && HW >= 0 && B <= 65535 && D <= INT32_MAX);
   if (B == 0 || HW == 0) return PF_OK;
   PF_REQUIRE(cost && params && depth && gdepth && gcost);
+  if (D == 48 || D == 96) {
+    dim3 grid64((unsigned)pf_cdiv(HW, 64), (unsigned)B);
+    if (D == 48)
+      hipLaunchKernelGGL(softargmin_bwd_fixed_kernel<48>, grid64, dim3(64), 0, (hipStream_t)stream, cost, params, depth,
+                         gdepth, gcost, HW);
+    else
+      hipLaunchKernelGGL(softargmin_bwd_fixed_kernel<96>, grid64, dim3(64), 0, (hipStream_t)stream, cost, params, depth,
+                         gdepth, gcost, HW);
+    return pf_launch_status();
+  }
   dim3 grid((unsigned)pf_cdiv(HW, 256), (unsigned)B);
   hipLaunchKernelGGL(softargmin_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, cost, params, depth, gdepth,
                      gcost, (int)D, HW);
@@ -309,7 +379,7 @@ int pf_flow_head_backward_f32(const float* act, int64_t ld, const float* w16, co
                      interval, prob, goffset, hw, gact, partials);
   int rc = pf_launch_status();
   if (rc != PF_OK) return rc;
-  hipLaunchKernelGGL(flow_head_wsum_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partials, (int)blocks, gw16,
+  hipLaunchKernelGGL(flow_head_wsum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, (int)blocks, gw16,
                      accumulate);
   return pf_launch_status();
 }

@@ -24,11 +24,32 @@ tensors (``bn.weight.data = ...``, a swapped buffer) re-captures too; in-place u
 them.  The warm-up forwards run on a snapshot of the BatchNorm buffers, which is restored before capture:
 constructing a GraphedForward does not advance running statistics or ``num_batches_tracked``.
 """
+import contextlib
 import copy
+import gc
 
 import torch
 
 from . import pointflow
+
+
+@contextlib.contextmanager
+def capturing(graph, **kw):
+    """``torch.cuda.graph(graph)`` with the cyclic garbage collector OFF for the duration of the capture.  A collection
+    that starts inside a capture may finalize another object that owns a hipGraph or device memory (a _ModuleGraph of a
+    model that went out of scope, a lane of an earlier test) -- destroying a graph / freeing into the pool while a stream
+    is capturing aborts the process (round 6: `Fatal Python error: Aborted ... Garbage-collecting` inside a lane's capture,
+    whole-suite run on hardware).  torch.cuda.graph itself collects once BEFORE the capture starts; nothing stops a
+    threshold-triggered collection DURING it."""
+    was = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph, **kw):
+            yield
+    finally:
+        if was:
+            gc.enable()
 
 
 class GraphedForward(object):
@@ -63,7 +84,7 @@ class GraphedForward(object):
         pointflow.set_lane(self._lane)
         pointflow.pack_log_begin()
         try:
-            with pointflow.concurrency(self._level), torch.cuda.graph(self.graph):
+            with pointflow.concurrency(self._level), capturing(self.graph):
                 self.outputs = self.model.run(self.plan, self.static_img, self.isFlow)
         finally:
             self._packs = pointflow.pack_log_end(pin=True)
@@ -314,7 +335,7 @@ class _ModuleGraph(object):
         self.graph = torch.cuda.CUDAGraph()
         pointflow.pack_log_begin()
         try:
-            with torch.no_grad(), torch.cuda.graph(self.graph):
+            with torch.no_grad(), capturing(self.graph):
                 self.out = fn(*self.static_in)
         finally:
             self.packs = pointflow.pack_log_end(pin=True)

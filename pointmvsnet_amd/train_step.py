@@ -274,7 +274,8 @@ class GraphedTrainStep(object):
                     b.copy_(saved)
             # keep_graph: the hipGraph itself stays reachable (raw_cuda_graph(): bench.py counts its kernel nodes)
             self.graph = torch.cuda.CUDAGraph(keep_graph=True) if keep_graph else torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            from .graph import capturing
+            with capturing(self.graph):
                 self.total, self.losses, self.preds = self._forward_backward()
 
     def _forward_backward(self):
