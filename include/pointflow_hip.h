@@ -511,6 +511,15 @@ int pf_bn_bwd_apply_f32(const float* g, const float* y, const float* rows, const
 int pf_bn_bwd_apply_fused_f32(const float* g, const float* y, const float* rows, const double* partials, int T,
                               double count, float* dy, int64_t N, int64_t C, int64_t S, int samples_per_stat, int relu,
                               float* dgamma, float* dbeta, int accumulate, void* stream);
+/* The whole BatchNorm(+ReLU) backward of planar tensors in ONE launch where a plane fits one block's registers (round 6):
+ * samples_per_stat == 1 (every sample its own statistic group: the towers' per-view statistics, VolumeConv's one sample),
+ * S % 4 == 0, S <= 32 768 (pf_bn_bwd_plane_supported), 16-byte aligned tensors.  rows (4, N, C) as pf_bn_train_rows_f32
+ * writes them; dy (N, C, S); dgamma / dbeta (C) = the sums over the N samples in sample order (added when accumulate;
+ * NULL: not wanted).  One block per channel loads a plane's (g, y) once, reduces, and writes dy from the registers:
+ * 12 bytes per element and one launch where pf_bn_bwd_reduce_f32 + pf_bn_bwd_apply_fused_f32 are 20 and two. */
+int pf_bn_bwd_plane_supported(int64_t S, int samples_per_stat);
+int pf_bn_bwd_plane_f32(const float* g, const float* y, const float* rows, int64_t N, int64_t C, int64_t S, int relu,
+                        float* dy, float* dgamma, float* dbeta, int accumulate, void* stream);
 /* The same on point-major rows (G groups of Ng rows, ld floats per row; C in {16, 32, 64, 128} for reduce,
  * C % 4 == 0 for apply / affine): the flow MLP's BatchNorm1d.  reduce partials: (G, pf_rows_bn_blocks(G, Ng), C, 2).
  * pf_rows_affine_f32: z = act(y * scale + shift), the normalised activation handed on. */

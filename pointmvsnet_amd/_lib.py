@@ -107,6 +107,8 @@ PROTOTYPES = {
     "pf_masked_mae_backward_f32": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp], _i),
     "pf_wgrad_reduce_batch_f32": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp], _i),
     "pf_bn_bwd_apply_fused_f32": ([_vp, _vp, _vp, _vp, _i, _d, _vp, _i64, _i64, _i64, _i, _i, _vp, _vp, _i, _vp], _i),
+    "pf_bn_bwd_plane_supported": ([_i64, _i], _i),
+    "pf_bn_bwd_plane_f32": ([_vp, _vp, _vp, _i64, _i64, _i64, _i, _vp, _vp, _vp, _i, _vp], _i),
     "pf_edge_backward_coeffs_f32": ([_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp], _i),
     "pf_bn_bwd_coeffs_f32": ([_vp, _i, _i, _i, _i, _d, _i, _i, _vp, _vp, _vp, _vp, _i, _vp], _i),
     "pf_bn_bwd_apply_f32": ([_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _vp], _i),

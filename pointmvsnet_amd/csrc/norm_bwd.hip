@@ -332,6 +332,101 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const float* __
 }
 
 // ------------------------------------------------------------------------------------------------
+// planar, ONE pass (round 6): a plane that fits the registers of one block
+// ------------------------------------------------------------------------------------------------
+// The config-4 step runs 18 BatchNorm backwards over planes of 480 .. 30 720 elements (the towers' 32- and 64-channel
+// layers, VolumeConv below 48x64x80): `reduce` + `apply_fused` are two launches of 5-8 us each that read (g, y) twice.  Here
+// one block of 1024 threads owns a CHANNEL and walks its N samples (each sample its own statistic group: samples_per_stat
+// 1): a plane's (g, y) is loaded ONCE into registers (KQ 16-byte pieces of each per thread), summed (float per thread,
+// float64 across threads, fixed order), turned into dy from the registers and stored; dgamma / dbeta are the sums over the
+// samples in sample order.  12 bytes per element instead of 20, one launch instead of two.
+template <int KQ>
+__global__ __launch_bounds__(1024) void bn_bwd_plane_kernel(const float* __restrict__ g, const float* __restrict__ y,
+                                                            const float* __restrict__ rows, int N, int C, int S,
+                                                            int relu, float* __restrict__ dy,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            int accumulate) {
+  __shared__ double2 red[16];
+  __shared__ double2 tot;
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int n4 = S >> 2;
+  const int64_t SC = (int64_t)N * C;
+  double tb = 0.0, tg = 0.0;
+  for (int n = 0; n < N; ++n) {
+    const float* r = rows + (int64_t)n * C + c;
+    const float sc = r[0], sh = r[SC], mean = r[2 * SC], invstd = r[3 * SC];
+    const float4* g4 = reinterpret_cast<const float4*>(g + ((int64_t)n * C + c) * S);
+    const float4* y4 = reinterpret_cast<const float4*>(y + ((int64_t)n * C + c) * S);
+    float4* o4 = reinterpret_cast<float4*>(dy + ((int64_t)n * C + c) * S);
+    float4 gv[KQ], yv[KQ];
+#pragma unroll
+    for (int u = 0; u < KQ; ++u) {
+      const int i = tid + 1024 * u;
+      gv[u] = i < n4 ? g4[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      yv[u] = i < n4 ? y4[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    float s = 0.0f, q = 0.0f;
+#pragma unroll
+    for (int u = 0; u < KQ; ++u) {
+      if (tid + 1024 * u < n4) {
+        gv[u].x = masked(gv[u].x, yv[u].x, sc, sh, relu);
+        gv[u].y = masked(gv[u].y, yv[u].y, sc, sh, relu);
+        gv[u].z = masked(gv[u].z, yv[u].z, sc, sh, relu);
+        gv[u].w = masked(gv[u].w, yv[u].w, sc, sh, relu);
+        s += gv[u].x;
+        q += gv[u].x * ((yv[u].x - mean) * invstd);
+        s += gv[u].y;
+        q += gv[u].y * ((yv[u].y - mean) * invstd);
+        s += gv[u].z;
+        q += gv[u].z * ((yv[u].z - mean) * invstd);
+        s += gv[u].w;
+        q += gv[u].w * ((yv[u].w - mean) * invstd);
+      }
+    }
+    double ds = (double)s, dq = (double)q;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      ds += __shfl_xor(ds, off);
+      dq += __shfl_xor(dq, off);
+    }
+    __syncthreads();                                   // (the previous sample's reads of red / tot are done)
+    if (lane == 0) red[wave] = make_double2(ds, dq);
+    __syncthreads();
+    if (tid == 0) {
+      double a = 0.0, b = 0.0;
+      for (int w = 0; w < 16; ++w) {
+        a += red[w].x;
+        b += red[w].y;
+      }
+      tot = make_double2(a, b);
+    }
+    __syncthreads();
+    const double sb = tot.x, sg = tot.y;
+    tb += sb;
+    tg += sg;
+    const double scd = (double)sc;
+    const float k1 = (float)(scd * sb / (double)S), k2 = (float)(scd * (double)invstd * sg / (double)S);
+#pragma unroll
+    for (int u = 0; u < KQ; ++u) {
+      const int i = tid + 1024 * u;
+      if (i < n4) {
+        float4 v;
+        v.x = fmaf(-k2, yv[u].x - mean, fmaf(sc, gv[u].x, -k1));
+        v.y = fmaf(-k2, yv[u].y - mean, fmaf(sc, gv[u].y, -k1));
+        v.z = fmaf(-k2, yv[u].z - mean, fmaf(sc, gv[u].z, -k1));
+        v.w = fmaf(-k2, yv[u].w - mean, fmaf(sc, gv[u].w, -k1));
+        o4[i] = v;
+      }
+    }
+  }
+  if (tid == 0) {
+    if (dgamma != nullptr) dgamma[c] = (accumulate ? dgamma[c] : 0.0f) + (float)tg;
+    if (dbeta != nullptr) dbeta[c] = (accumulate ? dbeta[c] : 0.0f) + (float)tb;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // point-major rows (P, ld): the flow MLP's BatchNorm1d (reference nn/conv.py:24-35 via nn/mlp.py:45-81)
 // ------------------------------------------------------------------------------------------------
 // G groups of Ng rows; block (t, g) reduces rows [t*chunk, (t+1)*chunk) of group g.  partials (G, T, C, 2).
@@ -568,6 +663,30 @@ int pf_bn_bwd_reduce_f32(const float* g, const float* y, const float* rows, int6
   dim3 grid((unsigned)T, (unsigned)C, (unsigned)N);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(256), 0, (hipStream_t)stream, g, y, rows, (int)C, S, chunk,
                      samples_per_stat, relu, partials, T);
+  return pf_launch_status();
+}
+
+int pf_bn_bwd_plane_supported(int64_t S, int samples_per_stat) {
+  return samples_per_stat == 1 && S >= 4 && (S & 3) == 0 && S <= 4 * 1024 * 8;
+}
+
+int pf_bn_bwd_plane_f32(const float* g, const float* y, const float* rows, int64_t N, int64_t C, int64_t S, int relu,
+                        float* dy, float* dgamma, float* dbeta, int accumulate, void* stream) {
+  PF_REQUIRE(N >= 0 && C >= 0 && N <= 65535 && C <= 65535);
+  if (!pf_bn_bwd_plane_supported(S, 1)) return PF_ERR_UNSUPPORTED;
+  if (N == 0 || C == 0) return PF_OK;
+  PF_REQUIRE(g && y && rows && dy && (((uintptr_t)g | (uintptr_t)y | (uintptr_t)dy) & 15) == 0);
+  const int kq = (int)pf_cdiv(S >> 2, 1024);
+  hipStream_t st = (hipStream_t)stream;
+#define PF_PLANE(K)                                                                                                  \
+  hipLaunchKernelGGL(bn_bwd_plane_kernel<K>, dim3((unsigned)C), dim3(1024), 0, st, g, y, rows, (int)N, (int)C, (int)S, \
+                     relu, dy, dgamma, dbeta, accumulate)
+  if (kq <= 1) PF_PLANE(1);
+  else if (kq <= 2) PF_PLANE(2);
+  else if (kq <= 4) PF_PLANE(4);
+  else if (kq <= 6) PF_PLANE(6);
+  else PF_PLANE(8);
+#undef PF_PLANE
   return pf_launch_status();
 }
 

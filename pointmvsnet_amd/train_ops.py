@@ -264,6 +264,9 @@ def channel_affine(y, rows, samples_per_stat, relu=True):
     return z
 
 
+BN_BWD_PLANE = int(os.environ.get("PF_BN_BWD_PLANE", "1"))      # 0: always the two-launch form
+
+
 def bn_backward(g, y, rows, samples_per_stat, relu=True, into=None):
     """BatchNorm(+ReLU) backward on planar (N, C, *spatial) tensors: (dy, dgamma, dbeta).  ``into`` = (dgamma, dbeta)
     tensors to ADD the parameter gradients to (then the returned ones are None)."""
@@ -271,6 +274,17 @@ def bn_backward(g, y, rows, samples_per_stat, relu=True, into=None):
     S = y[0, 0].numel()
     g = g.contiguous()
     dev = y.device
+    if BN_BWD_PLANE and y.is_contiguous() and _lib.load().pf_bn_bwd_plane_supported(S, int(samples_per_stat)):
+        # a plane that fits one block's registers: reduce + coefficients + apply in ONE launch (csrc/norm_bwd.hip)
+        if into is None:
+            dgamma = torch.empty((C,), dtype=_F32, device=dev)
+            dbeta = torch.empty((C,), dtype=_F32, device=dev)
+        else:
+            dgamma, dbeta = into
+        dy = torch.empty_like(y)
+        _lib.call("pf_bn_bwd_plane_f32", _lib.ptr(g), _lib.ptr(y), _lib.ptr(rows), N, C, S, int(bool(relu)), _lib.ptr(dy),
+                  _lib.ptr(dgamma), _lib.ptr(dbeta), 0 if into is None else 1, _lib.stream(), algo_bytes=12.0 * N * C * S)
+        return (dy, dgamma, dbeta) if into is None else (dy, None, None)
     T = int(_lib.load().pf_norm_blocks(S))
     partials = torch.empty((N, T, C, 2), dtype=torch.float64, device=dev)
     _lib.call("pf_bn_bwd_reduce_f32", _lib.ptr(g), _lib.ptr(y), _lib.ptr(rows), N, C, S, int(samples_per_stat),

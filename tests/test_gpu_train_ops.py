@@ -25,10 +25,18 @@ def _seeded(shape, dev, seed, scale=1.0):
     return (torch.randn(shape, generator=g) * scale).to(dev)
 
 
+@pytest.mark.parametrize("plane", [1, 0])
 @pytest.mark.parametrize("N,C,S,sps,relu", [(3, 8, (40, 56), 1, True), (2, 16, (6, 10, 12), 2, True),
-                                            (1, 64, (3, 4, 5), 1, False)])
-def test_bn_relu_backward_vs_float64_autograd(dev, N, C, S, sps, relu):
-    """pf_bn_train_rows + pf_bn_bwd_reduce / _coeffs / _apply against autograd of F.batch_norm(training) (+ relu)."""
+                                            (1, 64, (3, 4, 5), 1, False),
+                                            # the one-launch form's five register depths (<= 1, 2, 4, 6, 8 pieces per
+                                            # thread), three samples; and shapes it must leave to the two-launch form
+                                            (3, 4, (6, 8, 10), 1, True), (3, 5, (64, 80), 1, True), (3, 3, (80, 128), 1, False),
+                                            (2, 3, (128, 160), 1, True), (1, 2, (24, 32, 40), 1, True),
+                                            (1, 2, (7, 9, 11), 1, True), (1, 2, (256, 160), 1, True)])
+def test_bn_relu_backward_vs_float64_autograd(dev, N, C, S, sps, relu, plane, monkeypatch):
+    """pf_bn_train_rows + pf_bn_bwd_reduce / _coeffs / _apply -- or, where a plane fits one block's registers,
+    pf_bn_bwd_plane_f32 -- against autograd of F.batch_norm(training) (+ relu)."""
+    monkeypatch.setattr(train_ops, "BN_BWD_PLANE", plane)
     y = _seeded((N, C) + S, dev, 1, 2.0) + 0.3
     g = _seeded((N, C) + S, dev, 2)
     bn = (torch.nn.BatchNorm2d if len(S) == 2 else torch.nn.BatchNorm3d)(C).to(dev).train()

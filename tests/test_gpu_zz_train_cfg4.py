@@ -276,11 +276,12 @@ _BN_PLANAR = sorted(set(k[1] for k in EXPECTED_BN if k[0] == "planar"))
 
 
 @pytest.mark.parametrize("shape", _BN_PLANAR, ids=lambda s: "x".join(str(v) for v in s))
-def test_bn_relu_backward_at_cfg4_shape(dev, shape):
-    """pf_bn_bwd_reduce + pf_bn_bwd_apply_fused on every (samples, channels, spatial) the step has: the towers'
-    per-view statistics (3 statistic groups), VolumeConv's single sample."""
+def test_bn_relu_backward_at_cfg4_shape(dev, shape, monkeypatch):
+    """The BatchNorm backward on every (samples, channels, spatial) the step has -- the towers' per-view statistics (3
+    statistic groups), VolumeConv's single sample -- in the form the step runs it (pf_bn_bwd_plane_f32 where a plane fits
+    one block, else pf_bn_bwd_reduce + pf_bn_bwd_apply_fused)."""
     import test_gpu_train_ops as T
-    T.test_bn_relu_backward_vs_float64_autograd(dev, shape[0], shape[1], tuple(shape[2:]), 1, True)
+    T.test_bn_relu_backward_vs_float64_autograd(dev, shape[0], shape[1], tuple(shape[2:]), 1, True, 1, monkeypatch)
 
 
 @pytest.mark.parametrize("P", [P1, P2])
