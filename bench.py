@@ -118,7 +118,9 @@ def under_load_instantiations(prefixes):
             table = json.load(open(os.path.join(ROOT, name)))
         except (OSError, ValueError):
             continue
-        rows = [k for k in table.get("kernels", []) if k.get("frac_mfma_peak") and k["kernel"].startswith(prefixes)]
+        # (an instantiation with a fraction of a launch per depth map is a warm-up / calibration launch of another mode)
+        rows = [k for k in table.get("kernels", []) if k.get("frac_mfma_peak") and k["kernel"].startswith(prefixes)
+                and k.get("launches_per_depth_map", 1.0) >= 0.5]
         if not rows:
             continue
         rows.sort(key=lambda k: k["frac_mfma_peak"])

@@ -16,7 +16,7 @@ timeout 900 python bench.py --steps 20 --warmup 5 $BENCH_ARGS > gpurun_out/bench
 grep "^{" gpurun_out/bench.log | tail -1 > gpurun_out/bench_cfg2.json
 timeout 600 python bench.py --config cfg4 --no-cpu-baseline 2> gpurun_out/bench_cfg4.err | grep "^{" | tail -1 > gpurun_out/bench_cfg4.json
 # kernel trace of the timed execution mode: 4 captured lanes, graph replay
-timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof -o r1 -- python $R/bench.py --steps 4 --warmup 2 --calibration-steps 2 --no-cpu-baseline --no-train-block > $R/gpurun_out/rocprof.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof -o r1 -- python $R/bench.py --steps 4 --warmup 2 --calibration-steps 2 --no-cpu-baseline --no-train-block --no-extras > $R/gpurun_out/rocprof.log 2>&1
 echo "rocprof exit $?" >> $R/gpurun_out/rocprof.log
 DB=$(find gpurun_out/prof -name "*.db" | head -1)
 python tools/per_kernel_roofline.py summarize $DB gpurun_out/kernel_trace_cfg2_lanes4.json
