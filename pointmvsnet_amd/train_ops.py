@@ -118,14 +118,28 @@ _REDUCE_PENDING = []
 def _queue_reduce(work, into, elems, nbytes, rows, taps=1, swapped=False):
     """``rows`` / ``taps``: the Cg and the tap count of the launch that wrote ``work`` (its partials are (splits, rows, taps,
     columns)); ``swapped``: a swapped-operand launch (_conv_wgrad_swapped)."""
-    _REDUCE_PENDING.append((work, into, int(elems), int(nbytes // (4 * elems)), int(rows), int(taps), int(bool(swapped))))
+    _REDUCE_PENDING.append((work, into, int(elems), int(nbytes // (4 * elems)), int(rows), int(taps), int(bool(swapped)),
+                            torch.cuda.current_stream(work.device)))
 
 
 def _reduce_flush():
+    """One pf_wgrad_reduce_batch_f32 launch per stream the node's weight gradients were issued on (normally one: the
+    current stream; with model.TRAIN_FORK = 3 the PointFlow nodes' weight gradients and their reduction run on the side
+    stream, where nothing of the chain waits for them)."""
     if not _REDUCE_PENDING:
         return
-    pending = list(_REDUCE_PENDING)
+    everything = list(_REDUCE_PENDING)
     del _REDUCE_PENDING[:]
+    streams = []
+    for p in everything:
+        if not any(p[7] == st for st in streams):
+            streams.append(p[7])
+    for st in streams:
+        with torch.cuda.stream(st):
+            _reduce_launch([p for p in everything if p[7] == st])
+
+
+def _reduce_launch(pending):
     n = len(pending)
     parts = (ctypes.c_void_p * n)(*[p[0].data_ptr() for p in pending])
     dws = (ctypes.c_void_p * n)(*[p[1].data_ptr() for p in pending])
@@ -411,8 +425,10 @@ def _conv_wgrad_swapped(gr, x, kernel, pad, into):
     return None
 
 
-def rows_wgrad(gr, x, Cg, Cx, x_affine=None, x_rows_per_stat=None, into=None):
-    """dw (Cg, Cx) = sum_p gr[p, :Cg]^T act(x[p, :Cx]) on point-major row views (pf_rows_wgrad_f32)."""
+def rows_wgrad(gr, x, Cg, Cx, x_affine=None, x_rows_per_stat=None, into=None, side=None):
+    """dw (Cg, Cx) = sum_p gr[p, :Cg]^T act(x[p, :Cx]) on point-major row views (pf_rows_wgrad_f32).  ``side``: a stream to
+    issue the launch (and, later, its reduction) on when the result is ADDED into the gradient bucket -- nothing inside the
+    step reads it, so the chain does not have to wait for it (model.TRAIN_FORK = 3)."""
     P = gr.shape[0]
     lib = _lib.load()
     nbytes = int(lib.pf_rows_wgrad_workspace(P, int(Cg), int(Cx)))
@@ -432,6 +448,12 @@ def rows_wgrad(gr, x, Cg, Cx, x_affine=None, x_rows_per_stat=None, into=None):
             _queue_reduce(work, into, int(Cg) * int(Cx), nbytes, int(Cg), 1)
         return dw if into is None else None
 
+    if side is not None and into is not None and WGRAD_BATCH and DIRECT_GRADS and into.is_contiguous():
+        side.wait_stream(torch.cuda.current_stream(gr.device))
+        for t in (gr, x) + (() if x_affine is None else tuple(x_affine)):
+            t.record_stream(side)
+        with torch.cuda.stream(side):
+            return launch()
     return launch()
 
 
@@ -869,6 +891,7 @@ class _EdgeChainTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feature, idx, edge_convs, *params):
         ctx.packs = _PACKS
+        ctx.side = _on_side(3)
         x = feature.detach().contiguous()
         N, cin = x.shape
         idx = idx.contiguous()
@@ -916,7 +939,7 @@ class _EdgeChainTrain(torch.autograd.Function):
                 into = None
                 if t1 is not None and t2 is not None and t2.data_ptr() == t1.data_ptr() + 4 * C * K:
                     into = torch.as_strided(t1, (2 * C, K), (K, 1))
-                dw = rows_wgrad(grad_le, X, 2 * C, K, into=into)
+                dw = rows_wgrad(grad_le, X, 2 * C, K, into=into, side=ctx.side)
                 dX = gemm_rows(grad_le, wcat, 2 * C, K, chunks)                            # (N, K)
                 if col == 0:
                     gx = dX
@@ -959,6 +982,7 @@ class _MLPTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, shared, *params):
         ctx.packs = _PACKS
+        ctx.side = _on_side(3)
         X = x.detach()
         if X.stride(1) != 1:
             X = X.contiguous()
@@ -993,7 +1017,7 @@ class _MLPTrain(torch.autograd.Function):
                 dZ, dgamma, dbeta = rows_bn_backward(g, Z, rows, cout, 1, N, 1, True, into=into)
                 tw = _grad_target(blk.conv.weight)
                 dw = rows_wgrad(dZ, X, cout, K, x_affine=affine, x_rows_per_stat=N,
-                                into=None if tw is None else tw.view(cout, K))
+                                into=None if tw is None else tw.view(cout, K), side=ctx.side)
                 g = gemm_rows(dZ, blk.conv.weight.detach().reshape(cout, K), cout, K,
                               _packed("rows", blk.conv.weight))                           # gradient w.r.t. act(X)
                 gparams = [None if dw is None else dw.reshape(blk.conv.weight.shape), dgamma, dbeta] + gparams
