@@ -369,7 +369,7 @@ GATHER_PATH_MB = {"cfg1": 404.1, "cfg2": 1658.8, "cfg3": 25194.4, "cfg5": 38116.
 
 
 TRAIN_GROUPS = (
-    ("weight_gradients", ("pf_conv_wgrad_f32", "pf_rows_wgrad_f32")),
+    ("weight_gradients", ("pf_conv_wgrad_f32", "pf_conv_wgrad_batch_f32", "pf_rows_wgrad_f32")),
     ("batchnorm_backward", ("pf_bn_bwd_reduce_f32", "pf_bn_bwd_coeffs_f32", "pf_bn_bwd_apply_f32",
                             "pf_bn_bwd_apply_fused_f32", "pf_rows_bn_bwd_reduce_f32", "pf_rows_bn_bwd_apply_f32")),
     ("warp_backward", ("pf_warp_taps_flow_f32", "pf_warp_taps_frustum_f32", "pf_sort_pairs_by_key",

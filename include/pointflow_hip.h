@@ -562,6 +562,24 @@ int64_t pf_rows_wgrad_workspace(int64_t P, int Cg, int Cx);
 int pf_rows_wgrad_f32(const float* gr, int64_t ldg, const float* x, int64_t ldx, float* dw, int64_t P, int Cg, int Cx,
                       const float* x_scale, const float* x_shift, int64_t x_rows_per_stat, void* workspace,
                       int64_t workspace_bytes, int accumulate, void* stream);
+/* Several layers' pf_conv_wgrad_f32 (partials only, as with dw == NULL) in as few launches as their kernel instantiations
+ * allow (round 6): a training node queues the weight gradients of its layers -- nothing in the step waits for them -- and
+ * issues them together once its data-gradient chain is done; layers that share an instantiation (VolumeConv's 96-384-block
+ * layers below 24x32x40 beside conv1_0) ride in ONE grid.  Each item's arguments mean what pf_conv_wgrad_f32's mean; the
+ * partials land in item.workspace (>= pf_conv_wgrad_workspace bytes) in the layout described below and are summed by
+ * pf_wgrad_reduce_batch_f32.  n <= 64. */
+typedef struct pf_wgrad_item {
+  const float* gr;
+  const float* x;
+  int64_t N, Cg, Cx, Do, Ho, Wo, Di, Hi, Wi;
+  int KD, KH, KW, stride, pd, ph, pw;
+  int x_samples_per_stat;
+  const float* x_scale;
+  const float* x_shift;
+  void* workspace;
+  int64_t workspace_bytes;
+} pf_wgrad_item;
+int pf_conv_wgrad_batch_f32(const pf_wgrad_item* items, int n, void* stream);
 /* dw == NULL in the two calls above: the split partials only.  The workspace then holds (splits, Cg, taps, Cx), splits =
  * workspace bytes / (4 * Cg * Cx * taps) -- the channel index fastest: what the kernel's lanes store as 64-byte runs
  * (round 6; it was (splits, Cg, Cx, taps)).  pf_wgrad_reduce_batch_f32 adds the partials of n layers in ONE launch, each

@@ -25,6 +25,13 @@ class BnJob(ctypes.Structure):
                 ("ld_affine", ctypes.c_int32), ("rows4", ctypes.c_int32)]
 
 
+class WgradItem(ctypes.Structure):
+    """``pf_wgrad_item`` of include/pointflow_hip.h (one layer of pf_conv_wgrad_batch_f32)."""
+    _fields_ = [("gr", _vp), ("x", _vp)] + [(n, _i64) for n in ("N", "Cg", "Cx", "Do", "Ho", "Wo", "Di", "Hi", "Wi")] + \
+               [(n, ctypes.c_int32) for n in ("KD", "KH", "KW", "stride", "pd", "ph", "pw", "x_samples_per_stat")] + \
+               [("x_scale", _vp), ("x_shift", _vp), ("workspace", _vp), ("workspace_bytes", _i64)]
+
+
 # name -> argtypes; every entry must exist in include/pointflow_hip.h (tests/test_abi.py checks both ways)
 PROTOTYPES = {
     "pf_version": ([], ctypes.c_char_p),
@@ -106,6 +113,7 @@ PROTOTYPES = {
     "pf_masked_mae_f32": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp], _i),
     "pf_masked_mae_backward_f32": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp], _i),
     "pf_wgrad_reduce_batch_f32": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp], _i),
+    "pf_conv_wgrad_batch_f32": ([ctypes.POINTER(WgradItem), _i, _vp], _i),
     "pf_bn_bwd_apply_fused_f32": ([_vp, _vp, _vp, _vp, _i, _d, _vp, _i64, _i64, _i64, _i, _i, _vp, _vp, _i, _vp], _i),
     "pf_bn_bwd_plane_supported": ([_i64, _i], _i),
     "pf_bn_bwd_plane_f32": ([_vp, _vp, _vp, _i64, _i64, _i64, _i, _vp, _vp, _vp, _i, _vp], _i),

@@ -78,8 +78,8 @@ struct WgGeom {
 // files on every position row (~16 VALU instructions per MFMA, profiles/r04b_wgrad_sq_counters.md).  The block waits
 // for its fullest wave either way.
 template <int MT, int STRIDE, int NTW>
-__global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ Gr, const float* __restrict__ X,
-                                                    float* __restrict__ part, WgGeom g) {
+__device__ __forceinline__ void wgrad_body(const float* __restrict__ Gr, const float* __restrict__ X,
+                                           float* __restrict__ part, const WgGeom& g, int bx, int by, int bz) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* gs = lds;                                    // [MT*16][GPLANE]
   float* xs = lds + g.gs_floats;                      // [CBLK*CBP][XPLANE]
@@ -88,10 +88,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ Gr
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int li = lane & 15, lk = lane >> 4;
-  const int split = blockIdx.x;
+  const int split = bx;
   const int cbtot = g.CBLK * g.CBP;
-  const int ci0 = blockIdx.y * cbtot;
-  const int cg0 = blockIdx.z * (MT * 16);
+  const int ci0 = by * cbtot;
+  const int cg0 = bz * (MT * 16);
   const int R = g.TD * g.TH;
   const int plane_i = g.Hi * g.Wi, vol_i = plane_i * g.Di;
   const int plane_o = g.Ho * g.Wo, vol_o = plane_o * g.Do;
@@ -417,6 +417,38 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ Gr
       }
     }
   }
+}
+
+template <int MT, int STRIDE, int NTW>
+__global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ Gr, const float* __restrict__ X,
+                                                    float* __restrict__ part, WgGeom g) {
+  wgrad_body<MT, STRIDE, NTW>(Gr, X, part, g, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Several layers' weight gradients of ONE instantiation in one launch (round 6; pf_conv_wgrad_batch_f32).  VolumeConv's
+// layers below 24x32x40 are 96-384 blocks of ~20 us each -- prologue, two staging round trips, 112 MFMAs per wave, the
+// partial store -- one after the other in the backward chain, although nothing in the step waits for a weight gradient: a
+// node now queues its layers and launches them together when its data-gradient chain is done, the small ones riding in
+// the grid of the large one of the same instantiation.  Block b belongs to entry e with first_block[e] <= b.
+constexpr int kWgBatch = 8;
+struct WgBatchArgs {
+  const float* Gr[kWgBatch];
+  const float* X[kWgBatch];
+  float* part[kWgBatch];
+  WgGeom g[kWgBatch];
+  int first_block[kWgBatch + 1];
+  int gx[kWgBatch], gy[kWgBatch];
+  int n;
+};
+static_assert(sizeof(WgBatchArgs) <= 3584, "kernel arguments");
+
+template <int MT, int STRIDE, int NTW>
+__global__ __launch_bounds__(256) void wgrad_batch_kernel(WgBatchArgs b) {
+  int e = 0;
+  while (e + 1 < b.n && (int)blockIdx.x >= b.first_block[e + 1]) ++e;          // block-uniform
+  const int lb = (int)blockIdx.x - b.first_block[e];
+  const int bx = lb % b.gx[e], r = lb / b.gx[e];
+  wgrad_body<MT, STRIDE, NTW>(b.Gr[e], b.X[e], b.part[e], b.g[e], bx, r % b.gy[e], r / b.gy[e]);
 }
 
 // dw[e] = sum over the splits, in a fixed order: slice sl of 16 adds splits sl, sl + 16, ... and the 16 slice sums are added
@@ -766,6 +798,42 @@ int run_plan(const float* Gr, const float* X, float* dw, const WgPlan& p, int st
   return pf_launch_status();
 }
 
+template <int MT, int STRIDE, int NTW>
+int launch_wgrad_batch(const WgBatchArgs& b, int blocks, size_t lds_bytes, hipStream_t s) {
+  if (lds_bytes > kLdsSoft) {
+    static std::atomic<unsigned long long> done{0};
+    const int rc = pf_allow_big_lds(reinterpret_cast<const void*>(&wgrad_batch_kernel<MT, STRIDE, NTW>), (int)kLdsHard,
+                                    done);
+    if (rc != PF_OK) return rc;
+  }
+  hipLaunchKernelGGL((wgrad_batch_kernel<MT, STRIDE, NTW>), dim3((unsigned)blocks), dim3(256), lds_bytes, s, b);
+  return pf_launch_status();
+}
+
+template <int MT, int STRIDE>
+int launch_wgrad_batch_ntw(const WgBatchArgs& b, int ntw, int blocks, size_t lds_bytes, hipStream_t s) {
+  switch (ntw) {
+    case 1: return launch_wgrad_batch<MT, STRIDE, 1>(b, blocks, lds_bytes, s);
+    case 2: return launch_wgrad_batch<MT, STRIDE, 2>(b, blocks, lds_bytes, s);
+    case 3: return launch_wgrad_batch<MT, STRIDE, 3>(b, blocks, lds_bytes, s);
+    case 4: return launch_wgrad_batch<MT, STRIDE, 4>(b, blocks, lds_bytes, s);
+    case 5: return launch_wgrad_batch<MT, STRIDE, 5>(b, blocks, lds_bytes, s);
+    case 6: return launch_wgrad_batch<MT, STRIDE, 6>(b, blocks, lds_bytes, s);
+    case 7: return launch_wgrad_batch<MT, STRIDE, 7>(b, blocks, lds_bytes, s);
+    default: return PF_ERR_UNSUPPORTED;
+  }
+}
+
+int launch_wgrad_batch_any(const WgBatchArgs& b, int MT, int stride, int ntw, int blocks, size_t lds_bytes, hipStream_t s) {
+  if (stride == 1)
+    return MT == 1 ? launch_wgrad_batch_ntw<1, 1>(b, ntw, blocks, lds_bytes, s)
+                   : (MT == 2 ? launch_wgrad_batch_ntw<2, 1>(b, ntw, blocks, lds_bytes, s)
+                              : launch_wgrad_batch_ntw<4, 1>(b, ntw, blocks, lds_bytes, s));
+  return MT == 1 ? launch_wgrad_batch_ntw<1, 2>(b, ntw, blocks, lds_bytes, s)
+                 : (MT == 2 ? launch_wgrad_batch_ntw<2, 2>(b, ntw, blocks, lds_bytes, s)
+                            : launch_wgrad_batch_ntw<4, 2>(b, ntw, blocks, lds_bytes, s));
+}
+
 bool conv_args_ok(int64_t N, int64_t Cg, int64_t Cx, int64_t Do, int64_t Ho, int64_t Wo, int64_t Di, int64_t Hi,
                   int64_t Wi, int KD, int KH, int KW, int stride) {
   return N >= 1 && Cg >= 1 && Cx >= 1 && Do >= 1 && Ho >= 1 && Wo >= 1 && Di >= 1 && Hi >= 1 && Wi >= 1 && KD >= 1 &&
@@ -836,6 +904,65 @@ int pf_conv_wgrad_f32(const float* gr, const float* x, float* dw, int64_t N, int
   p.g.x_shift = x_shift;
   p.g.x_sps = x_samples_per_stat;
   return run_plan(gr, x, dw, p, stride, workspace, workspace_bytes, accumulate, (hipStream_t)stream);
+}
+
+int pf_conv_wgrad_batch_f32(const pf_wgrad_item* items, int n, void* stream) {
+  PF_REQUIRE(n >= 0 && (n == 0 || items != nullptr) && n <= 64);
+  WgPlan plans[64];
+  bool done[64];
+  for (int i = 0; i < n; ++i) {
+    const pf_wgrad_item& it = items[i];
+    PF_REQUIRE(conv_args_ok(it.N, it.Cg, it.Cx, it.Do, it.Ho, it.Wo, it.Di, it.Hi, it.Wi, it.KD, it.KH, it.KW, it.stride));
+    PF_REQUIRE(it.pd >= 0 && it.ph >= 0 && it.pw >= 0 && it.x_samples_per_stat >= 1 &&
+               (it.x_scale == nullptr) == (it.x_shift == nullptr) && it.gr && it.x && it.workspace);
+    plans[i] = make_plan(it.N, it.Cg, it.Cx, it.Do, it.Ho, it.Wo, it.Di, it.Hi, it.Wi, it.KD, it.KH, it.KW, it.stride,
+                         it.pd, it.ph, it.pw, false, 0);
+    if (!plans[i].ok) return PF_ERR_UNSUPPORTED;
+    plans[i].g.x_scale = it.x_scale;
+    plans[i].g.x_shift = it.x_shift;
+    plans[i].g.x_sps = it.x_samples_per_stat;
+    PF_REQUIRE(it.workspace_bytes >= 4 * (int64_t)it.Cg * it.Cx * plans[i].g.T * plans[i].splits);
+    done[i] = false;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  for (int i = 0; i < n; ++i) {
+    if (done[i]) continue;
+    const int MT = plans[i].MT, stride = items[i].stride, ntw = (plans[i].g.NTILES + 3) / 4;
+    WgBatchArgs b;
+    b.n = 0;
+    int blocks = 0;
+    size_t lds = 0;
+    auto flush = [&]() {
+      if (b.n == 0) return PF_OK;
+      b.first_block[b.n] = blocks;
+      const int rc = launch_wgrad_batch_any(b, MT, stride, ntw, blocks, lds, s);
+      b.n = 0;
+      blocks = 0;
+      lds = 0;
+      return rc;
+    };
+    for (int j = i; j < n; ++j) {
+      if (done[j] || plans[j].MT != MT || items[j].stride != stride || (plans[j].g.NTILES + 3) / 4 != ntw) continue;
+      const WgPlan& p = plans[j];
+      b.Gr[b.n] = items[j].gr;
+      b.X[b.n] = items[j].x;
+      b.part[b.n] = reinterpret_cast<float*>(items[j].workspace);
+      b.g[b.n] = p.g;
+      b.first_block[b.n] = blocks;
+      b.gx[b.n] = p.splits;
+      b.gy[b.n] = p.cblocks;
+      blocks += p.splits * p.cblocks * p.mblocks;
+      lds = p.lds_bytes > lds ? p.lds_bytes : lds;
+      done[j] = true;
+      if (++b.n == kWgBatch) {
+        const int rc = flush();
+        if (rc != PF_OK) return rc;
+      }
+    }
+    const int rc = flush();
+    if (rc != PF_OK) return rc;
+  }
+  return PF_OK;
 }
 
 int64_t pf_rows_wgrad_workspace(int64_t P, int Cg, int Cx) {

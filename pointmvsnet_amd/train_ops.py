@@ -122,10 +122,48 @@ def _queue_reduce(work, into, elems, nbytes, rows, taps=1, swapped=False):
                             torch.cuda.current_stream(work.device)))
 
 
+# Convolution weight gradients that are ADDED into the bucket are not even launched where they are computed: a node queues
+# them and issues them together when its backward returns (pf_conv_wgrad_batch_f32: layers that share a kernel instantiation
+# ride in ONE grid -- VolumeConv's 96-384-block layers of ~20 us each beside conv1_0's), then the one batched reduction.
+# PF_WGRAD_DEFER=0: every layer launched in place (round 5's order).
+WGRAD_DEFER = int(os.environ.get("PF_WGRAD_DEFER", "1"))
+_WGRAD_DEFERRED = []
+
+
+def _defer_wgrad(gr, x, N, Cg, Cx, go, xi, k3, stride, p3, sc, sh, sps, work, nbytes, flops, algo_bytes):
+    _WGRAD_DEFERRED.append((gr, x, int(N), int(Cg), int(Cx), tuple(int(v) for v in go), tuple(int(v) for v in xi),
+                            tuple(int(v) for v in k3), int(stride), tuple(int(v) for v in p3), sc, sh, int(sps), work,
+                            int(nbytes), float(flops), float(algo_bytes)))
+
+
+def _wgrad_flush_deferred():
+    if not _WGRAD_DEFERRED:
+        return
+    todo = list(_WGRAD_DEFERRED)
+    del _WGRAD_DEFERRED[:]
+    items = (_lib.WgradItem * len(todo))()
+    for it, (gr, x, N, Cg, Cx, go, xi, k3, stride, p3, sc, sh, sps, work, nbytes, _fl, _by) in zip(items, todo):
+        it.gr, it.x = gr.data_ptr(), x.data_ptr()
+        it.N, it.Cg, it.Cx = N, Cg, Cx
+        it.Do, it.Ho, it.Wo = go
+        it.Di, it.Hi, it.Wi = xi
+        it.KD, it.KH, it.KW = k3
+        it.stride = stride
+        it.pd, it.ph, it.pw = p3
+        it.x_samples_per_stat = sps
+        it.x_scale = None if sc is None else sc.data_ptr()
+        it.x_shift = None if sh is None else sh.data_ptr()
+        it.workspace, it.workspace_bytes = work.data_ptr(), nbytes
+    with torch.cuda.device(todo[0][0].device):
+        _lib.call("pf_conv_wgrad_batch_f32", items, len(todo), _lib.stream(),
+                  algo_bytes=sum(t[16] for t in todo), flops=sum(t[15] for t in todo))
+
+
 def _reduce_flush():
     """One pf_wgrad_reduce_batch_f32 launch per stream the node's weight gradients were issued on (normally one: the
     current stream; with model.TRAIN_FORK = 3 the PointFlow nodes' weight gradients and their reduction run on the side
     stream, where nothing of the chain waits for them)."""
+    _wgrad_flush_deferred()
     if not _REDUCE_PENDING:
         return
     everything = list(_REDUCE_PENDING)
@@ -375,6 +413,11 @@ def conv_wgrad(gr, x, kernel, stride, pad, x_affine=None, x_samples_per_stat=1, 
         work = torch.empty((max(nbytes, 4) // 4,), dtype=_F32, device=gr.device)
         dw = torch.empty((Cg, Cx) + tuple(kernel), dtype=_F32, device=gr.device) if into is None else into   # into: dw +=
         batched = into is not None and WGRAD_BATCH and DIRECT_GRADS and into.is_contiguous()
+        if batched and WGRAD_DEFER:
+            _defer_wgrad(gr, x, N, Cg, Cx, go, xi, k3, stride, p3, sc, sh, x_samples_per_stat, work, nbytes,
+                         2.0 * N * go[0] * go[1] * go[2] * taps * Cg * Cx, 4.0 * (gr.numel() + x.numel()) + 4.0 * dw.numel())
+            _queue_reduce(work, into, Cg * Cx * taps, nbytes, Cg, taps)
+            return None
         _lib.call("pf_conv_wgrad_f32", _lib.ptr(gr), _lib.ptr(x), None if batched else _lib.ptr(dw), N, Cg, Cx, go[0],
                   go[1], go[2], xi[0], xi[1], xi[2], k3[0], k3[1], k3[2], int(stride), p3[0], p3[1], p3[2], _lib.ptr(sc),
                   _lib.ptr(sh), int(x_samples_per_stat), _lib.ptr(work), nbytes, 0 if into is None else 1, _lib.stream(),
@@ -410,6 +453,11 @@ def _conv_wgrad_swapped(gr, x, kernel, pad, into):
         raise RuntimeError("conv_wgrad: unsupported shape")
     work = torch.empty((max(nbytes, 4) // 4,), dtype=_F32, device=gr.device)
     batched = into is not None and WGRAD_BATCH and DIRECT_GRADS and into.is_contiguous()
+    if batched and WGRAD_DEFER:
+        _defer_wgrad(x, gr, N, Cx, Cg, sp, sp, k3, 1, p3, None, None, 1, work, nbytes,
+                     2.0 * N * sp[0] * sp[1] * sp[2] * taps * Cg * Cx, 4.0 * (gr.numel() + x.numel()) + 4.0 * Cg * Cx * taps)
+        _queue_reduce(work, into, Cg * Cx * taps, nbytes, Cx, taps, swapped=True)
+        return None
     dwt = None if batched else torch.empty((Cx, Cg) + tuple(kernel), dtype=_F32, device=gr.device)
     _lib.call("pf_conv_wgrad_f32", _lib.ptr(x), _lib.ptr(gr), _lib.ptr(dwt), N, Cx, Cg, sp[0], sp[1], sp[2], sp[0], sp[1],
               sp[2], k3[0], k3[1], k3[2], 1, p3[0], p3[1], p3[2], None, None, 1, _lib.ptr(work), nbytes, 0, _lib.stream(),

@@ -345,6 +345,11 @@ def test_step_launches_exactly_the_tabulated_shapes(dev, monkeypatch):
     def call(name, *args, **kw):
         if name == "pf_conv_wgrad_f32":
             seen_w.add(("conv",) + tuple(int(a) for a in args[3:16]) + (args[19] is not None,))
+        elif name == "pf_conv_wgrad_batch_f32":              # a node's layers, queued and issued together
+            for it in args[0][:int(args[1])]:
+                seen_w.add(("conv", int(it.N), int(it.Cg), int(it.Cx), int(it.Do), int(it.Ho), int(it.Wo), int(it.Di),
+                            int(it.Hi), int(it.Wi), int(it.KD), int(it.KH), int(it.KW), int(it.stride),
+                            bool(it.x_scale)))
         elif name == "pf_rows_wgrad_f32":
             seen_w.add(("rows", int(args[5]), int(args[6]), int(args[7]), args[8] is not None))
         elif name == "pf_conv3d_k3_c1_f32":
