@@ -565,7 +565,8 @@ int pf_rows_wgrad_f32(const float* gr, int64_t ldg, const float* x, int64_t ldx,
 /* Several layers' pf_conv_wgrad_f32 (partials only, as with dw == NULL) in as few launches as their kernel instantiations
  * allow (round 6): a training node queues the weight gradients of its layers -- nothing in the step waits for them -- and
  * issues them together once its data-gradient chain is done; layers that share an instantiation (VolumeConv's 96-384-block
- * layers below 24x32x40 beside conv1_0) ride in ONE grid.  Each item's arguments mean what pf_conv_wgrad_f32's mean; the
+ * layers below 24x32x40 beside conv1_0; the 25 600-point PointFlow iteration's 1x1 layers beside the 102 400-point one's)
+ * ride in ONE grid.  Each item's arguments mean what pf_conv_wgrad_f32's mean; the
  * partials land in item.workspace (>= pf_conv_wgrad_workspace bytes) in the layout described below and are summed by
  * pf_wgrad_reduce_batch_f32.  n <= 64. */
 typedef struct pf_wgrad_item {
@@ -578,6 +579,10 @@ typedef struct pf_wgrad_item {
   const float* x_shift;
   void* workspace;
   int64_t workspace_bytes;
+  /* rows_P > 0: the item is a pf_rows_wgrad_f32 call instead -- gr (rows_P, ldg), x (rows_P, ldx) point-major rows, Cg / Cx
+   * columns of them, x_rows_per_stat rows behind one (x_scale, x_shift) row; the grid / kernel / pad fields are unused
+   * (stride must be 1). */
+  int64_t rows_P, ldg, ldx, x_rows_per_stat;
 } pf_wgrad_item;
 int pf_conv_wgrad_batch_f32(const pf_wgrad_item* items, int n, void* stream);
 /* dw == NULL in the two calls above: the split partials only.  The workspace then holds (splits, Cg, taps, Cx), splits =

@@ -29,7 +29,8 @@ class WgradItem(ctypes.Structure):
     """``pf_wgrad_item`` of include/pointflow_hip.h (one layer of pf_conv_wgrad_batch_f32)."""
     _fields_ = [("gr", _vp), ("x", _vp)] + [(n, _i64) for n in ("N", "Cg", "Cx", "Do", "Ho", "Wo", "Di", "Hi", "Wi")] + \
                [(n, ctypes.c_int32) for n in ("KD", "KH", "KW", "stride", "pd", "ph", "pw", "x_samples_per_stat")] + \
-               [("x_scale", _vp), ("x_shift", _vp), ("workspace", _vp), ("workspace_bytes", _i64)]
+               [("x_scale", _vp), ("x_shift", _vp), ("workspace", _vp), ("workspace_bytes", _i64)] + \
+               [(n, _i64) for n in ("rows_P", "ldg", "ldx", "x_rows_per_stat")]
 
 
 # name -> argtypes; every entry must exist in include/pointflow_hip.h (tests/test_abi.py checks both ways)

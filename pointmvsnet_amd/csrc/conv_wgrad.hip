@@ -912,9 +912,24 @@ int pf_conv_wgrad_batch_f32(const pf_wgrad_item* items, int n, void* stream) {
   bool done[64];
   for (int i = 0; i < n; ++i) {
     const pf_wgrad_item& it = items[i];
+    PF_REQUIRE((it.x_scale == nullptr) == (it.x_shift == nullptr) && it.gr && it.x && it.workspace);
+    if (it.rows_P > 0) {                                       // point-major rows: what pf_rows_wgrad_f32 takes
+      PF_REQUIRE(it.Cg >= 1 && it.Cx >= 1 && it.ldg >= it.Cg && it.ldx >= it.Cx && it.x_rows_per_stat >= 1 && it.stride == 1);
+      if ((it.Cg & 3) || (it.Cx & 3) || (it.ldg & 3) || (it.ldx & 3)) return PF_ERR_UNSUPPORTED;
+      PF_REQUIRE((((uintptr_t)it.gr | (uintptr_t)it.x | (uintptr_t)it.x_scale | (uintptr_t)it.x_shift) & 15) == 0);
+      plans[i] = make_plan(1, it.Cg, it.Cx, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, true, it.rows_P);
+      if (!plans[i].ok) return PF_ERR_UNSUPPORTED;
+      plans[i].g.x_scale = it.x_scale;
+      plans[i].g.x_shift = it.x_shift;
+      plans[i].g.x_pps = it.x_rows_per_stat;
+      plans[i].g.ldg = it.ldg;
+      plans[i].g.ldx = it.ldx;
+      PF_REQUIRE(it.workspace_bytes >= 4 * (int64_t)it.Cg * it.Cx * plans[i].splits);
+      done[i] = false;
+      continue;
+    }
     PF_REQUIRE(conv_args_ok(it.N, it.Cg, it.Cx, it.Do, it.Ho, it.Wo, it.Di, it.Hi, it.Wi, it.KD, it.KH, it.KW, it.stride));
-    PF_REQUIRE(it.pd >= 0 && it.ph >= 0 && it.pw >= 0 && it.x_samples_per_stat >= 1 &&
-               (it.x_scale == nullptr) == (it.x_shift == nullptr) && it.gr && it.x && it.workspace);
+    PF_REQUIRE(it.pd >= 0 && it.ph >= 0 && it.pw >= 0 && it.x_samples_per_stat >= 1);
     plans[i] = make_plan(it.N, it.Cg, it.Cx, it.Do, it.Ho, it.Wo, it.Di, it.Hi, it.Wi, it.KD, it.KH, it.KW, it.stride,
                          it.pd, it.ph, it.pw, false, 0);
     if (!plans[i].ok) return PF_ERR_UNSUPPORTED;

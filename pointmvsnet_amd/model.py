@@ -56,6 +56,7 @@ def join_fork_streams():
     training forward run it before they read gradients: autograd joins a side stream at the end of backward only
     where an AccumulateGrad node ran on it, and with ``train_ops.direct_grads()`` the nodes add into the bucket
     themselves."""
+    train_ops.flush_late()              # weight gradients that waited for the end of the backward (train_ops.WGRAD_LATE)
     for stream in _FORK_STREAMS.values():
         torch.cuda.current_stream(stream.device).wait_stream(stream)
 

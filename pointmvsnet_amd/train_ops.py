@@ -67,6 +67,10 @@ DIRECT_GRADS = False
 def direct_grads(on=True):
     global DIRECT_GRADS
     saved, DIRECT_GRADS = DIRECT_GRADS, bool(on)
+    if on:                                  # (a step that died in its backward must not leave launches for the next one)
+        del _WGRAD_DEFERRED[:]
+        del _LATE["wgrad"][:]
+        del _LATE["reduce"][:]
     try:
         yield
     finally:
@@ -127,13 +131,47 @@ def _queue_reduce(work, into, elems, nbytes, rows, taps=1, swapped=False):
 # ride in ONE grid -- VolumeConv's 96-384-block layers of ~20 us each beside conv1_0's), then the one batched reduction.
 # PF_WGRAD_DEFER=0: every layer launched in place (round 5's order).
 WGRAD_DEFER = int(os.environ.get("PF_WGRAD_DEFER", "1"))
+# ... and the 1x1 layers of the PointFlow nodes (EdgeConv chain, MLP: point-major rows) wait even longer: until the END of the
+# backward (flush_late(), called by model.join_fork_streams()), where the 25 600-point iteration's six launches of 10-30 us
+# ride in the grids of the 102 400-point iteration's.  PF_WGRAD_LATE=0: flushed with their own node.
+WGRAD_LATE = int(os.environ.get("PF_WGRAD_LATE", "1"))
 _WGRAD_DEFERRED = []
+_LATE = {"wgrad": [], "reduce": []}
 
 
 def _defer_wgrad(gr, x, N, Cg, Cx, go, xi, k3, stride, p3, sc, sh, sps, work, nbytes, flops, algo_bytes):
-    _WGRAD_DEFERRED.append((gr, x, int(N), int(Cg), int(Cx), tuple(int(v) for v in go), tuple(int(v) for v in xi),
-                            tuple(int(v) for v in k3), int(stride), tuple(int(v) for v in p3), sc, sh, int(sps), work,
-                            int(nbytes), float(flops), float(algo_bytes)))
+    _WGRAD_DEFERRED.append(dict(gr=gr, x=x, N=int(N), Cg=int(Cg), Cx=int(Cx), go=tuple(int(v) for v in go),
+                                xi=tuple(int(v) for v in xi), k3=tuple(int(v) for v in k3), stride=int(stride),
+                                p3=tuple(int(v) for v in p3), sc=sc, sh=sh, sps=int(sps), work=work, nbytes=int(nbytes),
+                                flops=float(flops), bytes=float(algo_bytes), rows=None))
+
+
+def _wgrad_launch_items(todo):
+    items = (_lib.WgradItem * len(todo))()
+    for it, d in zip(items, todo):
+        it.gr, it.x = d["gr"].data_ptr(), d["x"].data_ptr()
+        it.Cg, it.Cx = d["Cg"], d["Cx"]
+        it.x_scale = None if d["sc"] is None else d["sc"].data_ptr()
+        it.x_shift = None if d["sh"] is None else d["sh"].data_ptr()
+        it.workspace, it.workspace_bytes = d["work"].data_ptr(), d["nbytes"]
+        if d["rows"] is not None:
+            it.rows_P, it.ldg, it.ldx, it.x_rows_per_stat = d["rows"]
+            it.stride = 1
+            continue
+        it.N = d["N"]
+        it.Do, it.Ho, it.Wo = d["go"]
+        it.Di, it.Hi, it.Wi = d["xi"]
+        it.KD, it.KH, it.KW = d["k3"]
+        it.stride = d["stride"]
+        it.pd, it.ph, it.pw = d["p3"]
+        it.x_samples_per_stat = d["sps"]
+    with torch.cuda.device(todo[0]["gr"].device):
+        for base in range(0, len(todo), 64):                      # (the entry point takes <= 64 items)
+            n = min(64, len(todo) - base)
+            chunk = (_lib.WgradItem * n).from_address(ctypes.addressof(items) + base * ctypes.sizeof(_lib.WgradItem))
+            _lib.call("pf_conv_wgrad_batch_f32", chunk, n, _lib.stream(),
+                      algo_bytes=sum(d["bytes"] for d in todo[base:base + n]),
+                      flops=sum(d["flops"] for d in todo[base:base + n]))
 
 
 def _wgrad_flush_deferred():
@@ -141,22 +179,20 @@ def _wgrad_flush_deferred():
         return
     todo = list(_WGRAD_DEFERRED)
     del _WGRAD_DEFERRED[:]
-    items = (_lib.WgradItem * len(todo))()
-    for it, (gr, x, N, Cg, Cx, go, xi, k3, stride, p3, sc, sh, sps, work, nbytes, _fl, _by) in zip(items, todo):
-        it.gr, it.x = gr.data_ptr(), x.data_ptr()
-        it.N, it.Cg, it.Cx = N, Cg, Cx
-        it.Do, it.Ho, it.Wo = go
-        it.Di, it.Hi, it.Wi = xi
-        it.KD, it.KH, it.KW = k3
-        it.stride = stride
-        it.pd, it.ph, it.pw = p3
-        it.x_samples_per_stat = sps
-        it.x_scale = None if sc is None else sc.data_ptr()
-        it.x_shift = None if sh is None else sh.data_ptr()
-        it.workspace, it.workspace_bytes = work.data_ptr(), nbytes
-    with torch.cuda.device(todo[0][0].device):
-        _lib.call("pf_conv_wgrad_batch_f32", items, len(todo), _lib.stream(),
-                  algo_bytes=sum(t[16] for t in todo), flops=sum(t[15] for t in todo))
+    _wgrad_launch_items(todo)
+
+
+def flush_late():
+    """The end of a backward (model.join_fork_streams()): the weight gradients that waited for it, then their reduction."""
+    todo, reds = list(_LATE["wgrad"]), list(_LATE["reduce"])
+    del _LATE["wgrad"][:]
+    del _LATE["reduce"][:]
+    if todo:
+        _wgrad_launch_items(todo)
+    if reds:
+        with torch.cuda.device(reds[0][0].device):
+            for base in range(0, len(reds), 16):
+                _reduce_launch(reds[base:base + 16])
 
 
 def _reduce_flush():
@@ -488,6 +524,13 @@ def rows_wgrad(gr, x, Cg, Cx, x_affine=None, x_rows_per_stat=None, into=None, si
         work = torch.empty((max(nbytes, 4) // 4,), dtype=_F32, device=gr.device)
         dw = torch.empty((Cg, Cx), dtype=_F32, device=gr.device) if into is None else into
         batched = into is not None and WGRAD_BATCH and DIRECT_GRADS and into.is_contiguous()
+        if batched and WGRAD_DEFER and WGRAD_LATE and side is None:
+            _LATE["wgrad"].append(dict(gr=gr, x=x, Cg=int(Cg), Cx=int(Cx), sc=sc, sh=sh, work=work, nbytes=int(nbytes),
+                                       flops=2.0 * P * Cg * Cx, bytes=4.0 * P * (Cg + Cx) + 4.0 * Cg * Cx,
+                                       rows=(int(P), int(gr.stride(0)), int(x.stride(0)), int(x_rows_per_stat or P))))
+            _LATE["reduce"].append((work, into, int(Cg) * int(Cx), int(nbytes // (4 * int(Cg) * int(Cx))), int(Cg), 1, 0,
+                                    torch.cuda.current_stream(work.device)))
+            return None
         _lib.call("pf_rows_wgrad_f32", _lib.ptr(gr), int(gr.stride(0)), _lib.ptr(x), int(x.stride(0)),
                   None if batched else _lib.ptr(dw), P, int(Cg), int(Cx), _lib.ptr(sc), _lib.ptr(sh),
                   int(x_rows_per_stat or P), _lib.ptr(work), nbytes, 0 if into is None else 1, _lib.stream(),
