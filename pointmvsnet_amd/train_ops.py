@@ -68,6 +68,7 @@ def direct_grads(on=True):
     global DIRECT_GRADS
     saved, DIRECT_GRADS = DIRECT_GRADS, bool(on)
     if on:                                  # (a step that died in its backward must not leave launches for the next one)
+        _MAIN["stream"] = torch.cuda.current_stream() if torch.cuda.is_available() else None
         del _WGRAD_DEFERRED[:]
         del _LATE["wgrad"][:]
         del _LATE["reduce"][:]
@@ -122,7 +123,9 @@ _REDUCE_PENDING = []
 def _queue_reduce(work, into, elems, nbytes, rows, taps=1, swapped=False):
     """``rows`` / ``taps``: the Cg and the tap count of the launch that wrote ``work`` (its partials are (splits, rows, taps,
     columns)); ``swapped``: a swapped-operand launch (_conv_wgrad_swapped)."""
-    _REDUCE_PENDING.append((work, into, int(elems), int(nbytes // (4 * elems)), int(rows), int(taps), int(bool(swapped)),
+    late = (WGRAD_DEFER and WGRAD_LATE >= 2 and _MAIN["stream"] is not None
+            and torch.cuda.current_stream(work.device) == _MAIN["stream"])
+    (_LATE["reduce"] if late else _REDUCE_PENDING).append((work, into, int(elems), int(nbytes // (4 * elems)), int(rows), int(taps), int(bool(swapped)),
                             torch.cuda.current_stream(work.device)))
 
 
@@ -133,14 +136,20 @@ def _queue_reduce(work, into, elems, nbytes, rows, taps=1, swapped=False):
 WGRAD_DEFER = int(os.environ.get("PF_WGRAD_DEFER", "1"))
 # ... and the 1x1 layers of the PointFlow nodes (EdgeConv chain, MLP: point-major rows) wait even longer: until the END of the
 # backward (flush_late(), called by model.join_fork_streams()), where the 25 600-point iteration's six launches of 10-30 us
-# ride in the grids of the 102 400-point iteration's.  PF_WGRAD_LATE=0: flushed with their own node.
-WGRAD_LATE = int(os.environ.get("PF_WGRAD_LATE", "1"))
+# ride in the grids of the 102 400-point iteration's (6.21 -> 6.10 ms per step).  2 (default): the convolution layers of the
+# nodes that run on the step's main stream (coarse tower, VolumeConv) wait for the end too (6.10 -> 6.07 ms); the flow tower's,
+# on its own stream, are issued there when its node returns.  PF_WGRAD_LATE=0: everything flushed with its own node.
+WGRAD_LATE = int(os.environ.get("PF_WGRAD_LATE", "2"))
 _WGRAD_DEFERRED = []
 _LATE = {"wgrad": [], "reduce": []}
 
 
+_MAIN = {"stream": None}
+
+
 def _defer_wgrad(gr, x, N, Cg, Cx, go, xi, k3, stride, p3, sc, sh, sps, work, nbytes, flops, algo_bytes):
-    _WGRAD_DEFERRED.append(dict(gr=gr, x=x, N=int(N), Cg=int(Cg), Cx=int(Cx), go=tuple(int(v) for v in go),
+    late = WGRAD_LATE >= 2 and _MAIN["stream"] is not None and torch.cuda.current_stream(gr.device) == _MAIN["stream"]
+    (_LATE["wgrad"] if late else _WGRAD_DEFERRED).append(dict(gr=gr, x=x, N=int(N), Cg=int(Cg), Cx=int(Cx), go=tuple(int(v) for v in go),
                                 xi=tuple(int(v) for v in xi), k3=tuple(int(v) for v in k3), stride=int(stride),
                                 p3=tuple(int(v) for v in p3), sc=sc, sh=sh, sps=int(sps), work=work, nbytes=int(nbytes),
                                 flops=float(flops), bytes=float(algo_bytes), rows=None))
