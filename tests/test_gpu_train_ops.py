@@ -108,12 +108,16 @@ def test_conv_weight_gradient_vs_float64_autograd(dev, N, Cout, Cin, sp, k, stri
     assert dw.shape == w.shape and err < 2e-5, err
 
 
+@pytest.mark.parametrize("late", [0, 2])
 @pytest.mark.parametrize("N,Cout,Cin,sp", [(1, 8, 64, (8, 16, 24)), (1, 1, 8, (8, 16, 24)), (2, 8, 16, (24, 40)),
                                            (1, 8, 64, (5, 7, 19))])
-def test_swapped_operand_weight_gradient_in_the_batched_reduce(dev, N, Cout, Cin, sp, monkeypatch):
+def test_swapped_operand_weight_gradient_in_the_batched_reduce(dev, N, Cout, Cin, sp, late, monkeypatch):
     """Stride-1 layers with <= 8 output channels run pf_conv_wgrad_f32 with the operands swapped; inside the step the
     (Cin, Cout, reversed taps) partials are put into nn.ConvNd's order by pf_wgrad_reduce_batch_f32 (swapped), ADDED into the
-    gradient slot, in one launch with a plain layer's partials.  Against float64 autograd, and against PF_WGRAD_SWAP=0."""
+    gradient slot, in one launch with a plain layer's partials.  Against float64 autograd, and against PF_WGRAD_SWAP=0.
+    ``late``: the layers are queued until the node returns (0: _reduce_flush) or until the end of the backward (2, the
+    default: flush_late) and issued together by pf_conv_wgrad_batch_f32 either way."""
+    monkeypatch.setattr(train_ops, "WGRAD_LATE", late)
     nd = len(sp)
     conv = F.conv2d if nd == 2 else F.conv3d
     x = _seeded((N, Cin) + sp, dev, 11)
@@ -132,8 +136,14 @@ def test_swapped_operand_weight_gradient_in_the_batched_reduce(dev, N, Cout, Cin
         with train_ops.direct_grads(True):
             assert train_ops.conv_wgrad(dy, x, (3,) * nd, 1, (1,) * nd, into=slot) is None
             assert train_ops.conv_wgrad(dy2, x2, (3,) * nd, 1, (1,) * nd, into=slot2) is None
-            assert len(train_ops._REDUCE_PENDING) == 2 and bool(train_ops._REDUCE_PENDING[0][6]) == bool(swap)
-            train_ops._reduce_flush()
+            queue = train_ops._LATE["reduce"] if late else train_ops._REDUCE_PENDING
+            assert len(queue) == 2 and bool(queue[0][6]) == bool(swap)
+            if late:
+                assert not train_ops._REDUCE_PENDING and len(train_ops._LATE["wgrad"]) == 2
+                train_ops.flush_late()
+            else:
+                train_ops._reduce_flush()
+            assert not train_ops._LATE["reduce"] and not train_ops._REDUCE_PENDING and not train_ops._WGRAD_DEFERRED
         outs[swap] = (slot - 0.25, slot2 + 0.5)
     e1, e0, e2 = _rel(outs[1][0], w.grad), _rel(outs[0][0], w.grad), _rel(outs[1][1], w2.grad)
     report("conv_wgrad_swapped_%dd_%dto%d" % (nd, Cin, Cout), rel=e1, rel_plain=e0, rel_neighbour=e2)
