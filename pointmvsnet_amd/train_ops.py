@@ -371,7 +371,10 @@ def bn_backward(g, y, rows, samples_per_stat, relu=True, into=None):
     S = y[0, 0].numel()
     g = g.contiguous()
     dev = y.device
-    if BN_BWD_PLANE and y.is_contiguous() and _lib.load().pf_bn_bwd_plane_supported(S, int(samples_per_stat)):
+    # (one block per channel walks the N samples: with three views of 20 480 elements on 32 blocks -- the towers' 32-channel
+    # layers -- that is 21 us against 13.5 for the two launches, r06_cfg4_last_steps.md; so: one sample, or small planes)
+    if (BN_BWD_PLANE and y.is_contiguous() and (N == 1 or S <= 8192)
+            and _lib.load().pf_bn_bwd_plane_supported(S, int(samples_per_stat))):
         # a plane that fits one block's registers: reduce + coefficients + apply in ONE launch (csrc/norm_bwd.hip)
         if into is None:
             dgamma = torch.empty((C,), dtype=_F32, device=dev)

@@ -30,8 +30,10 @@ def _seeded(shape, dev, seed, scale=1.0):
                                             (1, 64, (3, 4, 5), 1, False),
                                             # the one-launch form's five register depths (<= 1, 2, 4, 6, 8 pieces per
                                             # thread), three samples; and shapes it must leave to the two-launch form
-                                            (3, 4, (6, 8, 10), 1, True), (3, 5, (64, 80), 1, True), (3, 3, (80, 128), 1, False),
-                                            (2, 3, (128, 160), 1, True), (1, 2, (24, 32, 40), 1, True),
+                                            (3, 4, (6, 8, 10), 1, True), (3, 5, (64, 80), 1, True), (1, 3, (80, 128), 1, False),
+                                            (1, 3, (128, 160), 1, True), (1, 2, (24, 32, 40), 1, True),
+                                            (3, 3, (128, 160), 1, True),      # three big planes: the two-launch form
+
                                             (1, 2, (7, 9, 11), 1, True), (1, 2, (256, 160), 1, True)])
 def test_bn_relu_backward_vs_float64_autograd(dev, N, C, S, sps, relu, plane, monkeypatch):
     """pf_bn_train_rows + pf_bn_bwd_reduce / _coeffs / _apply -- or, where a plane fits one block's registers,
