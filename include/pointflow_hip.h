@@ -284,6 +284,28 @@ int pf_edge_backward_apply_f32(const float* LE, int64_t ldle, int C, const int64
                                int ld_affine, int groups_per_stat, int concat, float* grad_le,
                                const uint32_t* inv_order, const uint32_t* inv_start, void* stream);
 
+/* The same backward in TWO walks over the neighbourhoods instead of three (round 6).  dl = -sum_j dd_j is linear in
+ * (c1, c2): dl = -a * ((sum_j g_j - k * c1) - c2 * sum_j xhat_j), so the reduce pass can leave every point's own sums
+ * behind and nobody has to walk the forward lists again.
+ *   sums  : pf_edge_backward_reduce_f32 + grad_le (G*Ng, ldle): row n = [sum_j g_j (C) | sum_j xhat_j (C)].
+ *           grad_acc (G*Ng, ld_acc) or NULL: a second upstream gradient in grad_y's column order (the next layer's data
+ *           gradient, model.py:209-216's chain); the pass uses grad_y + grad_acc and stores that sum back into grad_acc,
+ *           which the caller hands to `finish` as its grad_y (one element-wise launch less per layer).
+ *   finish: (after pf_edge_backward_coeffs_f32) the gather over the inverted lists (inv_order / inv_start are required)
+ *           writes de AND turns the row's sums into dl (+ the central half of a concat layer): grad_le = [dl | de], plain
+ *           stores, bit-reproducible.  dl differs from pf_edge_backward_apply_f32's in float32 rounding only (the sum is
+ *           taken before the coefficients are applied instead of after).
+ * Replaces networks.py:18-45's autograd graph like the three-pass form above. */
+int pf_edge_backward_sums_f32(const float* LE, int64_t ldle, int C, const int64_t* idx, int k, int G, int Ng,
+                              const float* grad_y, int64_t ldg, const float* scale, const float* shift,
+                              const float* mean, const float* invstd, int ld_affine, int groups_per_stat, int concat,
+                              double* partials, float* grad_le, float* grad_acc, int64_t ld_acc, void* stream);
+int pf_edge_backward_finish_f32(const float* LE, int64_t ldle, int C, int k, int G, int Ng, const float* grad_y,
+                                int64_t ldg, const float* scale, const float* shift, const float* mean,
+                                const float* invstd, const float* c1, const float* c2, int ld_affine,
+                                int groups_per_stat, int concat, float* grad_le, const uint32_t* inv_order,
+                                const uint32_t* inv_start, void* stream);
+
 /* Between the two passes above: partials (G, pf_stat_blocks(G, Ng), cbn, 2) -> c1, c2 (G / groups_per_stat, cbn) =
  * the statistic set's (sum g', sum g' * xhat) / m in a fixed order (m = groups_per_stat * Ng points for the central
  * half [0, C) of a concat layer, * k pairs else), and dbeta / dgamma (cbn,) = the sums over the sets (NULL: not

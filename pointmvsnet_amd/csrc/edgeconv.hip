@@ -666,7 +666,12 @@ __global__ __launch_bounds__(256) void edge_apply_kernel(const float* __restrict
 //   pass 3 (edge_bwd_inverse) de rows WITHOUT atomics: point m sums dd over the pairs (n, j) that gathered it, in
 //                             ascending pair order, from the inverted index tensor (knn_inverse.hip) -- the same
 //                             dd expression as pass 2, so dl and de are bit-reproducible from run to run
-// The two GEMMs that follow (dX = [dl|de] W, dW = [dl|de]^T X) are plain library GEMMs on the host side.
+// Round 6, the default with inverted lists: TWO walks.  dl = -sum_j dd_j is linear in (dbeta, dgamma):
+//   dl = -a * ((sum_j g_j - k * dbeta/M) - (dgamma/M) * sum_j xhat_j),
+// so pass 1 (edge_bwd_reduce<.., SUMS>) leaves each point's (sum_j g_j | sum_j xhat_j) in its dLE row and pass 3
+// (edge_bwd_inverse<.., FINISH>) turns them into dl while it gathers de: pass 2's walk over the forward lists (186 us of
+// the config-4 step) is gone; dl differs from the three-pass form in float32 rounding only.
+// The two GEMMs that follow (dX = [dl|de] W, dW = [dl|de]^T X) are pointwise_gemm / conv_wgrad launches.
 // ------------------------------------------------------------------------------------------------
 struct EdgeBwdAffine {
   const float* scale;      // (S, ld) [central C | diff C] (concat) or [diff C]
@@ -678,12 +683,13 @@ struct EdgeBwdAffine {
   int ld, groups_per_stat, concat;
 };
 
-template <int C, int K>
+template <int C, int K, bool SUMS>
 __global__ __launch_bounds__(256) void edge_bwd_reduce_kernel(const float* __restrict__ LE, int64_t ldle,
                                                               const int64_t* __restrict__ idx, int k, int Ng,
                                                               const float* __restrict__ Gy, int64_t ldg,
                                                               EdgeBwdAffine A, double* __restrict__ partials, int T,
-                                                              unsigned* __restrict__ status) {
+                                                              unsigned* __restrict__ status, float* __restrict__ sums,
+                                                              float* __restrict__ gacc, int64_t lda) {
   constexpr int Q = C / 4;
   constexpr int PPB = 256 / Q;
   __shared__ double red[256 * 16];
@@ -715,12 +721,18 @@ __global__ __launch_bounds__(256) void edge_bwd_reduce_kernel(const float* __res
       if (n >= Ng) break;
       const int64_t row = gbase + n;
       const float4 l = ld4(LE + row * ldle + 4 * q);
-      const float4 gy = ld4(Gy + row * ldg + doff + 4 * q);
+      float4 gy = ld4(Gy + row * ldg + doff + 4 * q);
+      if (SUMS && gacc != nullptr) {     // a second gradient meets this one here (the next layer's data gradient):
+        float* ga = gacc + row * lda + doff + 4 * q;           // the sum replaces it, the later passes read gacc
+        const float4 h = ld4(ga);
+        gy = make_float4(gy.x + h.x, gy.y + h.y, gy.z + h.z, gy.w + h.w);
+        *reinterpret_cast<float4*>(ga) = gy;
+      }
       const float gd[4] = {gy.x / kf, gy.y / kf, gy.z / kf, gy.w / kf};
       const float lv[4] = {l.x, l.y, l.z, l.w};
       const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
       const float mv[4] = {mu.x, mu.y, mu.z, mu.w}, iv[4] = {is.x, is.y, is.z, is.w};
-      float sg[4] = {0, 0, 0, 0}, sx[4] = {0, 0, 0, 0};
+      float sg[4] = {0, 0, 0, 0}, sx[4] = {0, 0, 0, 0}, sd[4] = {0, 0, 0, 0};
       const int64_t* ip = idx + row * k;
       auto pair = [&](const float4& e) {
         const float ev[4] = {e.x, e.y, e.z, e.w};
@@ -731,6 +743,7 @@ __global__ __launch_bounds__(256) void edge_bwd_reduce_kernel(const float* __res
           const float gg = u > 0.0f ? gd[c] : 0.0f;
           sg[c] += gg;
           sx[c] += gg * ((d - mv[c]) * iv[c]);
+          if (SUMS) sd[c] += d;
         }
       };
       if constexpr (K > 0) {
@@ -753,8 +766,20 @@ __global__ __launch_bounds__(256) void edge_bwd_reduce_kernel(const float* __res
         acc[c] += (double)sg[c];
         acc[4 + c] += (double)sx[c];
       }
+      if (SUMS) {   // the point's own sums over its k pairs: [sum g | sum xhat] in the row the finish pass turns into [dl | de]
+        float* o = sums + row * ldle + 4 * q;
+        *reinterpret_cast<float4*>(o) = make_float4(sg[0], sg[1], sg[2], sg[3]);
+        *reinterpret_cast<float4*>(o + C) = make_float4((sd[0] - kf * mv[0]) * iv[0], (sd[1] - kf * mv[1]) * iv[1],
+                                                        (sd[2] - kf * mv[2]) * iv[2], (sd[3] - kf * mv[3]) * iv[3]);
+      }
       if (A.concat) {
-        const float4 gc4 = ld4(Gy + row * ldg + 4 * q);
+        float4 gc4 = ld4(Gy + row * ldg + 4 * q);
+        if (SUMS && gacc != nullptr) {
+          float* ga = gacc + row * lda + 4 * q;
+          const float4 h = ld4(ga);
+          gc4 = make_float4(gc4.x + h.x, gc4.y + h.y, gc4.z + h.z, gc4.w + h.w);
+          *reinterpret_cast<float4*>(ga) = gc4;
+        }
         const float gcv[4] = {gc4.x, gc4.y, gc4.z, gc4.w};
         const float acv[4] = {ac.x, ac.y, ac.z, ac.w}, bcv[4] = {bc.x, bc.y, bc.z, bc.w};
         const float mcv[4] = {muc.x, muc.y, muc.z, muc.w}, icv[4] = {isc.x, isc.y, isc.z, isc.w};
@@ -870,12 +895,12 @@ __global__ __launch_bounds__(256) void edge_bwd_apply_kernel(const float* __rest
   }
 }
 
-template <int C>
+template <int C, bool FINISH>
 __global__ __launch_bounds__(256) void edge_bwd_inverse_kernel(const float* __restrict__ LE, int64_t ldle, int k, int Ng,
                                                                const float* __restrict__ Gy, int64_t ldg,
                                                                EdgeBwdAffine A, const uint32_t* __restrict__ order,
                                                                const uint32_t* __restrict__ start,
-                                                               float* __restrict__ dLE, int64_t rows) {
+                                                               float* __restrict__ dLE, int64_t rows, int dbg) {
   constexpr int Q = C / 4;
   constexpr int PPB = 256 / Q;
   const int tid = threadIdx.x;
@@ -894,6 +919,15 @@ __global__ __launch_bounds__(256) void edge_bwd_inverse_kernel(const float* __re
     const float ev[4] = {e.x, e.y, e.z, e.w};
     const uint32_t t0 = start[row], t1 = start[row + 1];
     float de[4] = {0, 0, 0, 0};
+    float4 sg4 = {0, 0, 0, 0}, sx4 = {0, 0, 0, 0}, l4 = {0, 0, 0, 0}, gc4 = {0, 0, 0, 0};
+    if (FINISH && !(dbg & 1)) {       // issued before the list walk: their latency hides behind it
+      sg4 = ld4(dLE + row * ldle + 4 * q);
+      sx4 = ld4(dLE + row * ldle + C + 4 * q);
+      if (A.concat && !(dbg & 4)) {
+        l4 = ld4(LE + row * ldle + 4 * q);
+        gc4 = ld4(Gy + row * ldg + 4 * q);
+      }
+    }
     for (uint32_t t = t0; t < t1; t += 4) {
       int64_t nrow[4];
       float4 l[4], gy[4];
@@ -921,6 +955,30 @@ __global__ __launch_bounds__(256) void edge_bwd_inverse_kernel(const float* __re
           }
         }
       }
+    }
+    if (FINISH) {
+      // dl from the row's own sums (edge_bwd_reduce_kernel<.., true>): dl = -sum_j dd_j is linear in (c1, c2), so
+      //   dl = -a * ((sum_j g_j - k * c1) - c2 * sum_j xhat_j)  -- no second walk over the neighbour rows.
+      const float sgv[4] = {sg4.x, sg4.y, sg4.z, sg4.w}, sxv[4] = {sx4.x, sx4.y, sx4.z, sx4.w};
+      float dl[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) dl[c] = -av[c] * ((sgv[c] - kf * c1v[c]) - c2v[c] * sxv[c]);
+      if (A.concat && !(dbg & 4)) {
+        const int64_t sc = (int64_t)(g / A.groups_per_stat) * A.ld + 4 * q;
+        const float4 ac = ld4(A.scale + sc), bc = ld4(A.shift + sc), muc = ld4(A.mean + sc), isc = ld4(A.invstd + sc);
+        const float4 k1c = ld4(A.c1 + sc), k2c = ld4(A.c2 + sc);
+        const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, gcv[4] = {gc4.x, gc4.y, gc4.z, gc4.w};
+        const float acv[4] = {ac.x, ac.y, ac.z, ac.w}, bcv[4] = {bc.x, bc.y, bc.z, bc.w};
+        const float mcv[4] = {muc.x, muc.y, muc.z, muc.w}, icv[4] = {isc.x, isc.y, isc.z, isc.w};
+        const float c1c[4] = {k1c.x, k1c.y, k1c.z, k1c.w}, c2c[4] = {k2c.x, k2c.y, k2c.z, k2c.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float u = fmaf(lv[c], acv[c], bcv[c]);
+          const float gg = u > 0.0f ? gcv[c] : 0.0f;
+          dl[c] += acv[c] * ((gg - c1c[c]) - ((lv[c] - mcv[c]) * icv[c]) * c2c[c]);
+        }
+      }
+      if (!(dbg & 2)) *reinterpret_cast<float4*>(dLE + row * ldle + 4 * q) = make_float4(dl[0], dl[1], dl[2], dl[3]);
     }
     *reinterpret_cast<float4*>(dLE + row * ldle + C + 4 * q) = make_float4(de[0], de[1], de[2], de[3]);
   }
@@ -1384,11 +1442,13 @@ int pf_edge_apply_f32(const float* LE, int64_t ldle, int C, const int64_t* idx, 
   return pf_launch_status();
 }
 
-int pf_edge_backward_reduce_f32(const float* LE, int64_t ldle, int C, const int64_t* idx, int k, int G, int Ng,
+extern "C++" {
+static int edge_backward_reduce(const float* LE, int64_t ldle, int C, const int64_t* idx, int k, int G, int Ng,
                                 const float* grad_y, int64_t ldg, const float* scale, const float* shift,
                                 const float* mean, const float* invstd, int ld_affine, int groups_per_stat,
-                                int concat, double* partials, void* stream) {
+                                int concat, double* partials, float* sums, float* gacc, int64_t lda, void* stream) {
   PF_REQUIRE(G >= 0 && Ng >= 0 && k >= 1 && ldle >= 2 * (int64_t)C && (ldle % 4) == 0 && G <= 65535);
+  PF_REQUIRE(gacc == nullptr || (sums != nullptr && (lda % 4) == 0 && lda >= (concat ? 2 : 1) * (int64_t)C));
   PF_REQUIRE(groups_per_stat >= 1 && (ldg % 4) == 0 && ldg >= (concat ? 2 : 1) * (int64_t)C);
   PF_REQUIRE((ld_affine % 4) == 0 && ld_affine >= (concat ? 2 : 1) * C);
   if (C != 32 && C != 64) return PF_ERR_UNSUPPORTED;
@@ -1400,15 +1460,58 @@ int pf_edge_backward_reduce_f32(const float* LE, int64_t ldle, int C, const int6
   const int T = pf_stat_blocks(G, Ng);
   dim3 grid((unsigned)T, (unsigned)G);
   hipStream_t s = (hipStream_t)stream;
-#define PF_EBR(CV, KV) hipLaunchKernelGGL((edge_bwd_reduce_kernel<CV, KV>), grid, dim3(256), 0, s, LE, ldle, idx, k, Ng, grad_y, ldg, A, partials, T, status)
-  if (k == 16) {
-    if (C == 32) PF_EBR(32, 16); else PF_EBR(64, 16);
+#define PF_EBR(CV, KV, SV) hipLaunchKernelGGL((edge_bwd_reduce_kernel<CV, KV, SV>), grid, dim3(256), 0, s, LE, ldle, idx, k, Ng, grad_y, ldg, A, partials, T, status, sums, gacc, lda)
+  if (sums != nullptr) {
+    if (k == 16) {
+      if (C == 32) PF_EBR(32, 16, true); else PF_EBR(64, 16, true);
+    } else {
+      if (C == 32) PF_EBR(32, 0, true); else PF_EBR(64, 0, true);
+    }
+  } else if (k == 16) {
+    if (C == 32) PF_EBR(32, 16, false); else PF_EBR(64, 16, false);
   } else {
-    if (C == 32) PF_EBR(32, 0); else PF_EBR(64, 0);
+    if (C == 32) PF_EBR(32, 0, false); else PF_EBR(64, 0, false);
   }
 #undef PF_EBR
   return pf_launch_status();
 }
+}  // extern "C++"
+
+int pf_edge_backward_reduce_f32(const float* LE, int64_t ldle, int C, const int64_t* idx, int k, int G, int Ng,
+                                const float* grad_y, int64_t ldg, const float* scale, const float* shift,
+                                const float* mean, const float* invstd, int ld_affine, int groups_per_stat,
+                                int concat, double* partials, void* stream) {
+  return edge_backward_reduce(LE, ldle, C, idx, k, G, Ng, grad_y, ldg, scale, shift, mean, invstd, ld_affine,
+                              groups_per_stat, concat, partials, nullptr, nullptr, 0, stream);
+}
+
+int pf_edge_backward_sums_f32(const float* LE, int64_t ldle, int C, const int64_t* idx, int k, int G, int Ng,
+                              const float* grad_y, int64_t ldg, const float* scale, const float* shift,
+                              const float* mean, const float* invstd, int ld_affine, int groups_per_stat, int concat,
+                              double* partials, float* grad_le, float* grad_acc, int64_t ld_acc, void* stream) {
+  PF_REQUIRE(grad_le != nullptr || G == 0 || Ng == 0);
+  return edge_backward_reduce(LE, ldle, C, idx, k, G, Ng, grad_y, ldg, scale, shift, mean, invstd, ld_affine,
+                              groups_per_stat, concat, partials, grad_le, grad_acc, ld_acc, stream);
+}
+
+extern "C++" {
+template <bool FINISH>
+static void edge_backward_inverse_launch(const float* LE, int64_t ldle, int C, int k, int G, int Ng, const float* grad_y,
+                                         int64_t ldg, const EdgeBwdAffine& A, const uint32_t* inv_order,
+                                         const uint32_t* inv_start, float* grad_le, hipStream_t s) {
+  const int64_t rows = (int64_t)G * Ng;
+  const int ppb = 256 / (C / 4);
+  int64_t blocks = pf_cdiv(rows, ppb);
+  if (blocks > 16384) blocks = 16384;
+  static const int dbg = getenv("PF_EDGE_FINISH_DBG") ? atoi(getenv("PF_EDGE_FINISH_DBG")) : 0;   // tools only: wrong results
+  if (C == 32)
+    hipLaunchKernelGGL((edge_bwd_inverse_kernel<32, FINISH>), dim3((unsigned)blocks), dim3(256), 0, s, LE, ldle, k, Ng,
+                       grad_y, ldg, A, inv_order, inv_start, grad_le, rows, dbg);
+  else
+    hipLaunchKernelGGL((edge_bwd_inverse_kernel<64, FINISH>), dim3((unsigned)blocks), dim3(256), 0, s, LE, ldle, k, Ng,
+                       grad_y, ldg, A, inv_order, inv_start, grad_le, rows, dbg);
+}
+}  // extern "C++"
 
 int pf_edge_backward_apply_f32(const float* LE, int64_t ldle, int C, const int64_t* idx, int k, int G, int Ng,
                                const float* grad_y, int64_t ldg, const float* scale, const float* shift,
@@ -1446,16 +1549,24 @@ int pf_edge_backward_apply_f32(const float* LE, int64_t ldle, int C, const int64
     if (C == 32) PF_EBA(32, 0, false); else PF_EBA(64, 0, false);
   }
 #undef PF_EBA
-  const int64_t rows = (int64_t)G * Ng;
-  const int ppb = 256 / (C / 4);
-  int64_t blocks = pf_cdiv(rows, ppb);
-  if (blocks > 16384) blocks = 16384;
-  if (C == 32)
-    hipLaunchKernelGGL((edge_bwd_inverse_kernel<32>), dim3((unsigned)blocks), dim3(256), 0, s, LE, ldle, k, Ng, grad_y, ldg,
-                       A, inv_order, inv_start, grad_le, rows);
-  else
-    hipLaunchKernelGGL((edge_bwd_inverse_kernel<64>), dim3((unsigned)blocks), dim3(256), 0, s, LE, ldle, k, Ng, grad_y, ldg,
-                       A, inv_order, inv_start, grad_le, rows);
+  edge_backward_inverse_launch<false>(LE, ldle, C, k, G, Ng, grad_y, ldg, A, inv_order, inv_start, grad_le, s);
+  return pf_launch_status();
+}
+
+int pf_edge_backward_finish_f32(const float* LE, int64_t ldle, int C, int k, int G, int Ng, const float* grad_y,
+                                int64_t ldg, const float* scale, const float* shift, const float* mean,
+                                const float* invstd, const float* c1, const float* c2, int ld_affine,
+                                int groups_per_stat, int concat, float* grad_le, const uint32_t* inv_order,
+                                const uint32_t* inv_start, void* stream) {
+  PF_REQUIRE(G >= 0 && Ng >= 0 && k >= 1 && ldle >= 2 * (int64_t)C && (ldle % 4) == 0 && G <= 65535);
+  PF_REQUIRE(groups_per_stat >= 1 && (ldg % 4) == 0 && ldg >= (concat ? 2 : 1) * (int64_t)C);
+  PF_REQUIRE((ld_affine % 4) == 0 && ld_affine >= (concat ? 2 : 1) * C);
+  if (C != 32 && C != 64) return PF_ERR_UNSUPPORTED;
+  if (G == 0 || Ng == 0) return PF_OK;
+  PF_REQUIRE(LE && grad_y && scale && shift && mean && invstd && c1 && c2 && grad_le && inv_order && inv_start);
+  const EdgeBwdAffine A{scale, shift, mean, invstd, c1, c2, ld_affine, groups_per_stat, concat};
+  edge_backward_inverse_launch<true>(LE, ldle, C, k, G, Ng, grad_y, ldg, A, inv_order, inv_start, grad_le,
+                                     (hipStream_t)stream);
   return pf_launch_status();
 }
 

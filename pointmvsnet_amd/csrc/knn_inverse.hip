@@ -11,11 +11,11 @@
 //   start[m] = number of pairs with key < m, m in [0, G * Ng]
 //   order    = the pair ids grouped by key, ascending inside a group: pairs of m = order[start[m] .. start[m+1])
 //
-// A counting sort in seven kernel launches and nothing else -- no memset / memcpy nodes, no library call -- so the whole
+// A counting sort in five kernel launches (seven beyond 4 M rows) and nothing else -- no memset / memcpy nodes, no library call -- so the whole
 // thing can sit inside a captured hipGraph (train_step.GraphedTrainStep; rocPRIM's radix sort clears its look-back
 // state with hipMemsetAsync, and memset nodes recorded from the autograd thread are not replayed reliably, see
-// pf_common.h):  count (integer atomics: the totals do not depend on arrival order) -> exclusive scan (per-block
-// sums, one block over the block sums, per-block scan) -> fill (a slot per pair from an atomic cursor: arrival order)
+// pf_common.h):  count (integer atomics: the totals do not depend on arrival order) -> exclusive scan (one
+// chained launch) -> fill (a slot per pair from an atomic cursor: arrival order)
 // -> every list sorted by pair id (one wave per list, rank counting in LDS), which makes the result independent of the
 // arrival order again.
 #include "pf_common.h"
@@ -33,10 +33,11 @@ __device__ __forceinline__ uint32_t pair_key(const int64_t* __restrict__ idx, in
 }
 
 __global__ __launch_bounds__(256) void inverse_zero_kernel(uint32_t* __restrict__ a, int64_t na, uint32_t* __restrict__ b,
-                                                           int64_t nb) {
+                                                           int64_t nb, uint32_t* __restrict__ c, int64_t nc) {
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < na; i += stride) a[i] = 0u;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nb; i += stride) b[i] = 0u;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nc; i += stride) c[i] = 0u;
 }
 
 __global__ __launch_bounds__(256) void inverse_count_kernel(const int64_t* __restrict__ idx, int64_t pairs, int k, int Ng,
@@ -105,6 +106,60 @@ __global__ __launch_bounds__(256) void scan_blocks_kernel(uint32_t* __restrict__
     __syncthreads();
   }
   uint32_t run = sums[blockIdx.x] + part[threadIdx.x] - s;   // exclusive prefix of this thread's four elements
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    if (base + u < n) v[base + u] = run;
+    run += x[u];
+  }
+}
+
+// exclusive scan of count[0 .. n) in place, ONE launch (round 6; the three launches above cost ~14 us of launch latency,
+// five times per training step).  Every block takes a ticket (so it only ever waits for blocks that already run), scans its
+// 1024 elements in LDS, publishes its total at once and then LOOKS BACK: its 256 threads read the totals of all earlier
+// tickets in parallel (spinning on the few that are not there yet) and the block adds them up -- no chain of dependent
+// waits from block to block (a serial hand-over took 26 us for 101 blocks).  Integer sums: the result does not depend
+// on the arrival order.  chain[0] = the ticket counter, chain[1 + t] = (1 << 32) | total of ticket t; all zeroed by
+// inverse_zero_kernel.  Quadratic in the number of blocks, so scan_in_place() below uses it up to kChainBlocks.
+constexpr int kChainBlocks = 4096;
+__global__ __launch_bounds__(256) void scan_chain_kernel(uint32_t* __restrict__ v, int64_t n,
+                                                         unsigned long long* __restrict__ chain) {
+  __shared__ uint32_t part[256];
+  __shared__ uint32_t look[256];
+  __shared__ unsigned long long ticket;
+  if (threadIdx.x == 0) ticket = atomicAdd(chain, 1ull);
+  __syncthreads();
+  const int64_t t = (int64_t)ticket;
+  const int64_t base = t * kScanBlock + 4 * threadIdx.x;
+  uint32_t x[4], s = 0;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    x[u] = base + u < n ? v[base + u] : 0u;
+    s += x[u];
+  }
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    const uint32_t tt = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+    __syncthreads();
+    part[threadIdx.x] += tt;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) atomicAdd(chain + 1 + t, (1ull << 32) | (unsigned long long)part[255]);   // (the slot was zero)
+  uint32_t acc = 0;
+  for (int64_t u = threadIdx.x; u < t; u += 256) {
+    unsigned long long got;
+    do {
+      got = atomicAdd(chain + 1 + u, 0ull);                     // (an atomic read at the L2: never a stale line)
+    } while ((got >> 32) == 0ull);
+    acc += (uint32_t)got;
+  }
+  look[threadIdx.x] = acc;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) look[threadIdx.x] += look[threadIdx.x + w];
+    __syncthreads();
+  }
+  uint32_t run = look[0] + part[threadIdx.x] - s;              // exclusive prefix of this thread's four elements
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     if (base + u < n) v[base + u] = run;
@@ -220,6 +275,18 @@ __global__ __launch_bounds__(256) void sort_lists_wave_kernel(const uint32_t* __
 
 size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
+// `chain`: (nblocks + 1) zeroed 64-bit words (the one-launch form) that double as the nblocks block sums of the three-launch form
+void scan_in_place(uint32_t* v, int64_t n, int nblocks, unsigned long long* chain, hipStream_t s) {
+  if (nblocks <= kChainBlocks) {
+    hipLaunchKernelGGL(scan_chain_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, v, n, chain);
+    return;
+  }
+  uint32_t* sums = reinterpret_cast<uint32_t*>(chain);
+  hipLaunchKernelGGL(scan_block_sums_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, v, n, sums);
+  hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, s, sums, nblocks);
+  hipLaunchKernelGGL(scan_blocks_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, v, n, sums);
+}
+
 }  // namespace
 
 extern "C" {
@@ -228,7 +295,7 @@ int64_t pf_knn_inverse_workspace(int G, int Ng, int k) {
   if (G <= 0 || Ng <= 0 || k <= 0) return 0;
   const int64_t rows = (int64_t)G * Ng;
   const int64_t nblocks = pf_cdiv(rows + 1, kScanBlock);
-  return (int64_t)(align256(sizeof(uint32_t) * (size_t)rows) + align256(sizeof(uint32_t) * (size_t)nblocks) +
+  return (int64_t)(align256(sizeof(uint32_t) * (size_t)rows) + align256(sizeof(uint64_t) * (size_t)(nblocks + 1)) +
                    align256(sizeof(uint32_t) * (size_t)rows * (size_t)k));
 }
 
@@ -242,18 +309,16 @@ int pf_knn_inverse(const int64_t* idx, int k, int G, int Ng, uint32_t* order, ui
   hipStream_t s = (hipStream_t)stream;
   char* w = reinterpret_cast<char*>(workspace);
   uint32_t* cursor = reinterpret_cast<uint32_t*>(w);
-  uint32_t* sums = reinterpret_cast<uint32_t*>(w + align256(sizeof(uint32_t) * (size_t)rows));
+  unsigned long long* chain = reinterpret_cast<unsigned long long*>(w + align256(sizeof(uint32_t) * (size_t)rows));
   const int64_t n = rows + 1;                                  // start[rows] = pairs closes the last list
   const int nblocks = (int)pf_cdiv(n, kScanBlock);
   uint32_t* scratch = reinterpret_cast<uint32_t*>(w + align256(sizeof(uint32_t) * (size_t)rows) +
-                                                  align256(sizeof(uint32_t) * (size_t)nblocks));
+                                                  align256(sizeof(uint64_t) * (size_t)(nblocks + 1)));
   const unsigned pb = (unsigned)pf_cdiv(pairs, 256);
   hipLaunchKernelGGL(inverse_zero_kernel, dim3((unsigned)(pf_cdiv(n, 256) > 2048 ? 2048 : pf_cdiv(n, 256))), dim3(256), 0, s,
-                     start, n, cursor, rows);
+                     start, n, cursor, rows, reinterpret_cast<uint32_t*>(chain), 2 * ((int64_t)nblocks + 1));
   hipLaunchKernelGGL(inverse_count_kernel, dim3(pb), dim3(256), 0, s, idx, pairs, k, Ng, start);
-  hipLaunchKernelGGL(scan_block_sums_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, start, n, sums);
-  hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, s, sums, nblocks);
-  hipLaunchKernelGGL(scan_blocks_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, start, n, sums);
+  scan_in_place(start, n, nblocks, chain, s);
   hipLaunchKernelGGL(inverse_fill_kernel, dim3(pb), dim3(256), 0, s, idx, pairs, k, Ng, start, cursor, order);
   // lists ascending by pair id: one wave per list, rank counting in LDS (round 4; the one-thread-per-list insertion sort
   // took 300-430 us at 1.6 M pairs and was quadratic in the list length)
@@ -265,7 +330,7 @@ int pf_knn_inverse(const int64_t* idx, int k, int G, int Ng, uint32_t* order, ui
 int64_t pf_sort_pairs_workspace(int64_t pairs, int64_t nkeys) {
   if (pairs <= 0 || nkeys <= 0) return 0;
   const int64_t nblocks = pf_cdiv(nkeys + 1, kScanBlock);
-  return (int64_t)(align256(sizeof(uint32_t) * (size_t)nkeys) + align256(sizeof(uint32_t) * (size_t)nblocks) +
+  return (int64_t)(align256(sizeof(uint32_t) * (size_t)nkeys) + align256(sizeof(uint64_t) * (size_t)(nblocks + 1)) +
                    align256(sizeof(uint32_t) * (size_t)pairs));
 }
 
@@ -276,21 +341,19 @@ int pf_sort_pairs_by_key(const uint32_t* keys, int64_t pairs, int64_t nkeys, uin
   hipStream_t s = (hipStream_t)stream;
   char* w = reinterpret_cast<char*>(workspace);
   uint32_t* cursor = reinterpret_cast<uint32_t*>(w);
-  uint32_t* sums = reinterpret_cast<uint32_t*>(w + align256(sizeof(uint32_t) * (size_t)nkeys));
+  unsigned long long* chain = reinterpret_cast<unsigned long long*>(w + align256(sizeof(uint32_t) * (size_t)nkeys));
   const int64_t n = nkeys + 1;
   const int nblocks = (int)pf_cdiv(n, kScanBlock);
   uint32_t* scratch = reinterpret_cast<uint32_t*>(w + align256(sizeof(uint32_t) * (size_t)nkeys) +
-                                                  align256(sizeof(uint32_t) * (size_t)nblocks));
+                                                  align256(sizeof(uint64_t) * (size_t)(nblocks + 1)));
   hipLaunchKernelGGL(inverse_zero_kernel, dim3((unsigned)(pf_cdiv(n, 256) > 2048 ? 2048 : pf_cdiv(n, 256))), dim3(256), 0, s,
-                     start, n, cursor, nkeys);
+                     start, n, cursor, nkeys, reinterpret_cast<uint32_t*>(chain), 2 * ((int64_t)nblocks + 1));
   if (pairs > 0) {
     PF_REQUIRE(keys && order);
     hipLaunchKernelGGL(keys_count_kernel, dim3((unsigned)pf_cdiv(pairs, 256)), dim3(256), 0, s, keys, pairs,
                        (uint32_t)nkeys, start);
   }
-  hipLaunchKernelGGL(scan_block_sums_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, start, n, sums);
-  hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, s, sums, nblocks);
-  hipLaunchKernelGGL(scan_blocks_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, start, n, sums);
+  scan_in_place(start, n, nblocks, chain, s);
   if (pairs > 0) {
     hipLaunchKernelGGL(keys_fill_kernel, dim3((unsigned)pf_cdiv(pairs, 256)), dim3(256), 0, s, keys, pairs,
                        (uint32_t)nkeys, start, cursor, order);

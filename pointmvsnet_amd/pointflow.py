@@ -1129,23 +1129,43 @@ def knn_inverse(idx, G, Ng, k):
 # True: the de rows of the EdgeConv backward are gathered over the inverted index lists (bit-reproducible); False: the
 # reference's float atomics (module attribute for the tests that compare the two, not an environment switch)
 DETERMINISTIC_BACKWARD = True
+# PF_EDGE_BWD_SUMS=0: round 4's three walks (reduce, apply over the forward lists, gather over the inverted lists)
+# instead of two (reduce leaves the per-point sums, the inverted-list gather finishes dl as well)
+EDGE_BWD_SUMS = _os.environ.get("PF_EDGE_BWD_SUMS", "1") != "0"
 
 
-def edge_conv_backward(keep, idx, grad_y, C, k, G, Ng, groups_per_stat, concat, into=None):
+def edge_conv_backward(keep, idx, grad_y, C, k, G, Ng, groups_per_stat, concat, into=None, grad_acc=None):
     """Gradient of edge_conv_fused's output rows w.r.t. LE = [l | e] and the BatchNorm affine parameters
     (pf_edge_backward_reduce_f32 / _coeffs_f32 / _apply_f32: d = e[idx] - l is recomputed, nothing of size N*k is
     stored).  grad_y: (G*Ng, cbn) point-major.  Returns (grad_LE (G*Ng, 2C), grad_gamma (cbn,), grad_beta (cbn,));
-    ``into`` = (dgamma, dbeta) tensors to ADD the parameter gradients to (then the returned ones are None)."""
+    ``into`` = (dgamma, dbeta) tensors to ADD the parameter gradients to (then the returned ones are None).
+    ``grad_acc``: a second upstream gradient (G*Ng, cbn), contiguous and OWNED by the caller -- the gradient is
+    grad_y + grad_acc; the two-walk form adds them inside its first pass (grad_acc then holds the sum)."""
     LE, scale, shift, mean, invstd = keep["LE"], keep["scale"], keep["shift"], keep["mean"], keep["invstd"]
     dev = LE.device
     cbn = 2 * C if concat else C
     S = G // groups_per_stat
     T = stat_blocks(G, Ng)
     partials = torch.empty((G, T, cbn, 2), dtype=torch.float64, device=dev)
-    _lib.call("pf_edge_backward_reduce_f32", _lib.ptr(LE), 2 * C, C, _lib.ptr(idx), k, G, Ng, _lib.ptr(grad_y),
-              int(grad_y.stride(0)), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(mean), _lib.ptr(invstd), cbn,
-              groups_per_stat, int(bool(concat)), _lib.ptr(partials), _lib.stream(),
-              algo_bytes=float(G) * Ng * (4.0 * C + 8.0 * k + 4.0 * C * k + 4.0 * cbn))
+    grad_le = torch.empty((G * Ng, 2 * C), dtype=_F32, device=dev)
+    two_walks = DETERMINISTIC_BACKWARD and EDGE_BWD_SUMS
+    if grad_acc is not None and not two_walks:
+        grad_y, grad_acc = grad_y + grad_acc, None
+    if two_walks:
+        # the reduce pass leaves every point's own (sum g, sum xhat) in grad_le: dl is linear in the coefficients, so
+        # the finish pass (the gather over the inverted lists) completes it without walking the forward lists again
+        _lib.call("pf_edge_backward_sums_f32", _lib.ptr(LE), 2 * C, C, _lib.ptr(idx), k, G, Ng, _lib.ptr(grad_y),
+                  int(grad_y.stride(0)), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(mean), _lib.ptr(invstd), cbn,
+                  groups_per_stat, int(bool(concat)), _lib.ptr(partials), _lib.ptr(grad_le), _lib.ptr(grad_acc),
+                  0 if grad_acc is None else int(grad_acc.stride(0)), _lib.stream(),
+                  algo_bytes=float(G) * Ng * (12.0 * C + 8.0 * k + 4.0 * C * k + 4.0 * cbn))
+        if grad_acc is not None:
+            grad_y = grad_acc
+    else:
+        _lib.call("pf_edge_backward_reduce_f32", _lib.ptr(LE), 2 * C, C, _lib.ptr(idx), k, G, Ng, _lib.ptr(grad_y),
+                  int(grad_y.stride(0)), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(mean), _lib.ptr(invstd), cbn,
+                  groups_per_stat, int(bool(concat)), _lib.ptr(partials), _lib.stream(),
+                  algo_bytes=float(G) * Ng * (4.0 * C + 8.0 * k + 4.0 * C * k + 4.0 * cbn))
     c1 = torch.empty((S, cbn), dtype=_F32, device=dev)
     c2 = torch.empty((S, cbn), dtype=_F32, device=dev)
     if into is None:
@@ -1156,12 +1176,18 @@ def edge_conv_backward(keep, idx, grad_y, C, k, G, Ng, groups_per_stat, concat, 
     _lib.call("pf_edge_backward_coeffs_f32", _lib.ptr(partials), G, T, cbn, C, int(bool(concat)), groups_per_stat, Ng, k,
               _lib.ptr(c1), _lib.ptr(c2), _lib.ptr(dgamma), _lib.ptr(dbeta), 0 if into is None else 1, _lib.stream(),
               algo_bytes=16.0 * G * T * cbn)
-    grad_le = torch.empty((G * Ng, 2 * C), dtype=_F32, device=dev)
     order, start = knn_inverse(idx, G, Ng, k) if DETERMINISTIC_BACKWARD else (None, None)
-    _lib.call("pf_edge_backward_apply_f32", _lib.ptr(LE), 2 * C, C, _lib.ptr(idx), k, G, Ng, _lib.ptr(grad_y),
-              int(grad_y.stride(0)), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(c1),
-              _lib.ptr(c2), cbn, groups_per_stat, int(bool(concat)), _lib.ptr(grad_le), _lib.ptr(order), _lib.ptr(start),
-              _lib.stream(), algo_bytes=float(G) * Ng * (8.0 * C + 8.0 * k + 8.0 * C * k + 4.0 * cbn))
+    if two_walks:
+        _lib.call("pf_edge_backward_finish_f32", _lib.ptr(LE), 2 * C, C, k, G, Ng, _lib.ptr(grad_y),
+                  int(grad_y.stride(0)), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(c1),
+                  _lib.ptr(c2), cbn, groups_per_stat, int(bool(concat)), _lib.ptr(grad_le), _lib.ptr(order),
+                  _lib.ptr(start), _lib.stream(),
+                  algo_bytes=float(G) * Ng * (16.0 * C + 4.0 * k + 8.0 * C * k + 4.0 * cbn))
+    else:
+        _lib.call("pf_edge_backward_apply_f32", _lib.ptr(LE), 2 * C, C, _lib.ptr(idx), k, G, Ng, _lib.ptr(grad_y),
+                  int(grad_y.stride(0)), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(c1),
+                  _lib.ptr(c2), cbn, groups_per_stat, int(bool(concat)), _lib.ptr(grad_le), _lib.ptr(order), _lib.ptr(start),
+                  _lib.stream(), algo_bytes=float(G) * Ng * (8.0 * C + 8.0 * k + 8.0 * C * k + 4.0 * cbn))
     return (grad_le, dgamma, dbeta) if into is None else (grad_le, None, None)
 
 

@@ -1029,11 +1029,10 @@ class _EdgeChainTrain(torch.autograd.Function):
             for m, (keep, X, ldx, K, col, wdt) in reversed(list(zip(edge_convs, keeps))):
                 C = m.conv1.weight.shape[0]
                 gy = g[:, col:col + wdt]
-                if carry is not None:
-                    gy = gy + carry
                 tg, tb = _grad_target(m.bn.weight), _grad_target(m.bn.bias)
                 grad_le, dgamma, dbeta = pointflow.edge_conv_backward(
-                    keep, idx, gy, C, k, 1, N, 1, m.concat, into=(tg, tb) if (tg is not None and tb is not None) else None)
+                    keep, idx, gy, C, k, 1, N, 1, m.concat, into=(tg, tb) if (tg is not None and tb is not None) else None,
+                    grad_acc=carry)                      # (+ the next layer's data gradient, added inside the first pass)
                 chunks = _packed("rows", m.conv1.weight)
                 wcat = None if chunks is not None else torch.cat(
                     [m.conv1.weight.detach().reshape(C, K), m.conv2.weight.detach().reshape(C, K)], dim=0)

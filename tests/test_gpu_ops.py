@@ -547,6 +547,14 @@ def test_edgeconv_backward_is_bit_reproducible_and_matches_the_scatter(dev, cls,
     first, second = grads(), grads()
     for a, b in zip(first, second):
         assert torch.equal(a, b)
+    # round 6: the default takes TWO walks (the reduce pass leaves every point's sums, the inverted-list gather finishes
+    # dl); the three-walk form (PF_EDGE_BWD_SUMS=0) differs in float32 rounding only, and is bit-reproducible as well
+    assert pointflow.EDGE_BWD_SUMS
+    monkeypatch.setattr(pointflow, "EDGE_BWD_SUMS", False)
+    three, three_again = grads(), grads()
+    for a, b, c in zip(first, three, three_again):
+        assert torch.equal(b, c)
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
     monkeypatch.setattr(pointflow, "DETERMINISTIC_BACKWARD", False)
     scattered = grads()
     for a, b in zip(first, scattered):
