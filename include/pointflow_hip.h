@@ -295,16 +295,21 @@ int pf_edge_backward_apply_f32(const float* LE, int64_t ldle, int C, const int64
  *           writes de AND turns the row's sums into dl (+ the central half of a concat layer): grad_le = [dl | de], plain
  *           stores, bit-reproducible.  dl differs from pf_edge_backward_apply_f32's in float32 rounding only (the sum is
  *           taken before the coefficients are applied instead of after).
+ * plane: points per lattice plane (H*W of the D x H x W lattice the neighbours come from) or 0 = unknown -- a hint for
+ * the XCD-aware block order only (each of the 8 L2s serves a band of pixel rows in every plane instead of every eighth
+ * tile of the whole lattice); results do not depend on it.  pf_edge_stats_f32 / pf_edge_apply_f32 take the same hint as
+ * (lat_ks 0, lat_h, lat_w) when they are given an index tensor instead of window codes.
  * Replaces networks.py:18-45's autograd graph like the three-pass form above. */
 int pf_edge_backward_sums_f32(const float* LE, int64_t ldle, int C, const int64_t* idx, int k, int G, int Ng,
                               const float* grad_y, int64_t ldg, const float* scale, const float* shift,
                               const float* mean, const float* invstd, int ld_affine, int groups_per_stat, int concat,
-                              double* partials, float* grad_le, float* grad_acc, int64_t ld_acc, void* stream);
+                              double* partials, float* grad_le, float* grad_acc, int64_t ld_acc, int plane,
+                              void* stream);
 int pf_edge_backward_finish_f32(const float* LE, int64_t ldle, int C, int k, int G, int Ng, const float* grad_y,
                                 int64_t ldg, const float* scale, const float* shift, const float* mean,
                                 const float* invstd, const float* c1, const float* c2, int ld_affine,
                                 int groups_per_stat, int concat, float* grad_le, const uint32_t* inv_order,
-                                const uint32_t* inv_start, void* stream);
+                                const uint32_t* inv_start, int plane, void* stream);
 
 /* Between the two passes above: partials (G, pf_stat_blocks(G, Ng), cbn, 2) -> c1, c2 (G / groups_per_stat, cbn) =
  * the statistic set's (sum g', sum g' * xhat) / m in a fixed order (m = groups_per_stat * Ng points for the central

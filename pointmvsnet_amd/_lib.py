@@ -94,9 +94,9 @@ PROTOTYPES = {
     "pf_edge_backward_apply_f32": ([_vp, _i64, _i, _vp, _i, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i,
                                     _vp, _vp, _vp, _vp], _i),
     "pf_edge_backward_sums_f32": ([_vp, _i64, _i, _vp, _i, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp,
-                                   _i64, _vp], _i),
+                                   _i64, _i, _vp], _i),
     "pf_edge_backward_finish_f32": ([_vp, _i64, _i, _i, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i,
-                                     _vp, _vp, _vp, _vp], _i),
+                                     _vp, _vp, _vp, _i, _vp], _i),
     "pf_knn_inverse_workspace": ([_i, _i, _i], _i64),
     "pf_knn_inverse": ([_vp, _i, _i, _i, _vp, _vp, _vp, _i64, _vp], _i),
     "pf_bn_finalize_f32": ([_vp, _i, _i, _i, _i, _d, _d, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _i, _vp], _i),

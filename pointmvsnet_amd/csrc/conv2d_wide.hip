@@ -197,8 +197,8 @@ __device__ __forceinline__ void wide_stage_patch(const float* __restrict__ xb, i
 // stores straight to NCHW as 16-byte pieces (or channel-last), statistics per lane -> halves -> waves -> one row.
 template <class C, int COUT>
 __device__ __forceinline__ void wide_epilogue(const f32x16& acc, float* __restrict__ y, const WideGeom& g,
-                                              double* __restrict__ partials, double* red, int n, int oh0, int ow0,
-                                              int wm, int wn, int wave, int m, int h, int tid, bool cl_out) {
+                                              double* __restrict__ partials, double* red, int n, int bx, int oh0,
+                                              int ow0, int wm, int wn, int wave, int m, int h, int tid, bool cl_out) {
   // ---- epilogue: C/D layout column (channel) = lane & 31, row (pixel) = (r & 3) + 8 (r >> 2) + 4 h -----------------
   const int co = wn * 32 + m;
   float* yb = y + ((int64_t)n * COUT + co) * ((int64_t)g.Ho * g.Wo);
@@ -265,7 +265,7 @@ __device__ __forceinline__ void wide_epilogue(const f32x16& acc, float* __restri
         ds += red[((w * C::NWN + cn) * 32 + cm) * 2 + 0];
         dq += red[((w * C::NWN + cn) * 32 + cm) * 2 + 1];
       }
-      double* o = partials + (((int64_t)n * gridDim.x + blockIdx.x) * COUT + tid) * 2;
+      double* o = partials + (((int64_t)n * gridDim.x + bx) * COUT + tid) * 2;
       o[0] = ds;
       o[1] = dq;
     }
@@ -299,8 +299,10 @@ __global__ __launch_bounds__(256) void conv2d_wide_kernel(const float* __restric
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int m = lane & 31, h = lane >> 5;
   const int wm = wave / C::NWN, wn = wave % C::NWN;
-  const int n = blockIdx.y;
-  const int tw = blockIdx.x % g.tiles_w, th = blockIdx.x / g.tiles_w;
+  unsigned xb_, xn_;
+  pf_xcd_xy<PF_XCD_TOWER>(xb_, xn_);                  // XCD x owns a band of tile rows, not every eighth tile (pf_common.h)
+  const int n = (int)xn_, bx = (int)xb_;
+  const int tw = bx % g.tiles_w, th = bx / g.tiles_w;
   const int oh0 = th * C::TH, ow0 = tw * C::TW;
   const int ih0 = oh0 * STRIDE - C::PAD, iw0 = ow0 * STRIDE - C::PAD;
   const int plane_i = g.Hi * g.Wi;
@@ -343,7 +345,7 @@ __global__ __launch_bounds__(256) void conv2d_wide_kernel(const float* __restric
     if (t + D < NP) bq[t % D] = bg[(t + D) * 2 * COUT];
     a = an;
   }
-  wide_epilogue<C, COUT>(acc, y, g, partials, red, n, oh0, ow0, wm, wn, wave, m, h, tid, (g.cl_out >> set) & 1);
+  wide_epilogue<C, COUT>(acc, y, g, partials, red, n, bx, oh0, ow0, wm, wn, wave, m, h, tid, (g.cl_out >> set) & 1);
 }
 
 template <int KS, int STRIDE, int CIN, int COUT, int AFFINE>
@@ -435,7 +437,9 @@ __global__ __launch_bounds__(256) void conv2d_wide16_kernel(const float* __restr
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int li = lane & 15, kq = lane >> 4;
-  const int n = blockIdx.y;
+  unsigned xb_, xn_;
+  pf_xcd_xy<PF_XCD_TOWER>(xb_, xn_);
+  const int n = (int)xn_, bx = (int)xb_;
   const int plane_i = g.Hi * g.Wi;
   const int set = wide_set(g, n);
   const float* xb = x + (int64_t)wide_input_sample(g, n, set) * CIN * plane_i;
@@ -456,7 +460,7 @@ __global__ __launch_bounds__(256) void conv2d_wide16_kernel(const float* __restr
   // they all load, then all multiply, then all store -- each phase leaving the other units idle.
   PatchStager<CIN, NPIX, PW, RS> st;
   st.init(plane_i, g.Wi);
-  int tile = blockIdx.x;
+  int tile = bx;
   auto tile_origin = [&](int t, int& oh0, int& ow0) {
     const int th = t / g.tiles_w;
     oh0 = th * C::TH;
@@ -616,7 +620,7 @@ __global__ __launch_bounds__(256) void conv2d_wide16_kernel(const float* __restr
         ts += red[(w * 16 + tid) * 2 + 0];
         tq += red[(w * 16 + tid) * 2 + 1];
       }
-      double* o = partials + (((int64_t)n * gridDim.x + blockIdx.x) * COUT + tid) * 2;
+      double* o = partials + (((int64_t)n * gridDim.x + bx) * COUT + tid) * 2;
       o[0] = ts;
       o[1] = tq;
     }

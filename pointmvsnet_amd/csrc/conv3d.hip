@@ -89,7 +89,9 @@ __global__ __launch_bounds__(256, MINW) void conv3d_k3_kernel(const float* __res
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int li = lane & 15, lk = lane >> 4;
-  const int n = blockIdx.y;
+  unsigned xb_, xn_;
+  pf_xcd_xy<PF_XCD_CONV3D>(xb_, xn_);                 // XCD x owns a contiguous run of each pass's items (pf_common.h)
+  const int n = (int)xn_, bx = (int)xb_;
   const int plane_i = g.Hi * g.Wi, vol_i = plane_i * g.Di;       // Cin * vol_i < 2^31 (checked on the host)
   const int64_t plane_o = (int64_t)g.Ho * g.Wo, vol_o = plane_o * g.Do;
   const float* xb = x + (int64_t)n * g.Cin * vol_i;
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(256, MINW) void conv3d_k3_kernel(const float* __res
   }
 
   const int total = g.tiles_d * g.tiles_h * g.tiles_w;
-  for (int item = blockIdx.x; item < total; item += gridDim.x) {
+  for (int item = bx; item < total; item += gridDim.x) {
     const int tw = item % g.tiles_w;
     const int rest = item / g.tiles_w;
     const int th = rest % g.tiles_h;
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(256, MINW) void conv3d_k3_kernel(const float* __res
         s += red[((w * NCP) + tid) * 2 + 0];
         q += red[((w * NCP) + tid) * 2 + 1];
       }
-      double* o = partials + (((int64_t)n * gridDim.x + blockIdx.x) * g.Cout + tid) * 2;
+      double* o = partials + (((int64_t)n * gridDim.x + bx) * g.Cout + tid) * 2;
       o[0] = s;
       o[1] = q;
     }

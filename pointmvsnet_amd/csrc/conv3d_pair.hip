@@ -70,7 +70,9 @@ __global__ __launch_bounds__(256, MINW) void conv3d_k3_pair_kernel(const float* 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int li = lane & 15, lk = lane >> 4;
-  const int n = blockIdx.y;
+  unsigned xb_, xn_;
+  pf_xcd_xy<PF_XCD_CONV3D>(xb_, xn_);                 // XCD x owns a contiguous run of each pass's items (pf_common.h)
+  const int n = (int)xn_, bx = (int)xb_;
   const int plane_i = g.H * g.W, vol = plane_i * g.D;            // Cin * vol < 2^31 (checked on the host)
   const float* xb = x + (int64_t)n * g.Cin * vol;
   float* yb = y + (int64_t)n * g.Cout * vol;
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(256, MINW) void conv3d_k3_pair_kernel(const float* 
   double ssum = 0.0, ssq = 0.0;
 
   const int total = g.tiles_d * g.tiles_h * g.tiles_w;
-  for (int item = blockIdx.x; item < total; item += gridDim.x) {
+  for (int item = bx; item < total; item += gridDim.x) {
     const int tw = item % g.tiles_w;
     const int rest = item / g.tiles_w;
     const int th = rest % g.tiles_h;
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(256, MINW) void conv3d_k3_pair_kernel(const float* 
         s += red[(w * 16 + tid) * 2 + 0];
         q += red[(w * 16 + tid) * 2 + 1];
       }
-      double* o = partials + (((int64_t)n * gridDim.x + blockIdx.x) * g.Cout + tid) * 2;
+      double* o = partials + (((int64_t)n * gridDim.x + bx) * g.Cout + tid) * 2;
       o[0] = s;
       o[1] = q;
     }

@@ -467,7 +467,20 @@ __device__ __forceinline__ void gather_rows(const float* __restrict__ LE, int64_
 // `lut` (LDS) maps a code to its offset (pd-hk)*H*W + (ph-hk)*W + (pw-hk).
 struct Lattice {
   int ks, H, W;     // window size and lattice plane shape; ks == 0: neighbours come from the int64 index tensor
+  int band;         // > 0: XCD-aware tile order (xcd_tile below), tiles of a plane per XCD; 0: tile = block
 };
+
+// Workgroups go to the 8 XCDs round-robin (block b -> XCD b % 8) and every XCD has its own 4 MB L2.  With tile = block,
+// the eight neighbours of a tile -- which gather the same rows -- sit on eight different L2s, so every L2 ends up holding
+// the whole lattice's rows.  With a band, XCD x owns the x-th eighth of EVERY plane (the window reaches all planes at
+// the same pixels, +-2 rows): its L2 holds an eighth of the rows plus a halo.  Needs whole tiles per plane, a multiple
+// of 8 of them, and one tile per block (the host side checks); the partial rows stay in tile order (same bits).
+__device__ __forceinline__ int xcd_tile(int tb, const Lattice& lat) {
+  if (lat.band == 0) return tb;
+  const int x = tb & 7, j = tb >> 3;
+  const int d = j / lat.band, o = j - d * lat.band;
+  return d * (lat.band * 8) + x * lat.band + o;
+}
 
 __device__ __forceinline__ void build_code_lut(int* lut, const Lattice& lat) {
   const int hk = lat.ks >> 1, k2 = lat.ks * lat.ks;
@@ -515,7 +528,8 @@ __global__ __launch_bounds__(256) void edge_stats_kernel(const float* __restrict
   const int64_t gbase = (int64_t)g * Ng;
   double ds[4] = {0, 0, 0, 0}, dq[4] = {0, 0, 0, 0};
   bool bad = false;
-  for (int tile = tb; tile < tiles; tile += T) {
+  const int tile0 = xcd_tile(tb, lat);
+  for (int tile = tile0; tile < tiles; tile += T) {
     const int n0 = tile * TILE;
     for (int p = pl; p < TILE; p += PPB) {
       const int n = n0 + p;
@@ -566,7 +580,7 @@ __global__ __launch_bounds__(256) void edge_stats_kernel(const float* __restrict
     const int qq = tid / 8, comp = tid % 8;
     double acc = 0.0;
     for (int s = 0; s < PPB; ++s) acc += red[(s * Q + qq) * 8 + comp];
-    double* o = partials + (((int64_t)g * T + tb) * C + 4 * qq + (comp & 3)) * 2 + (comp >> 2);
+    double* o = partials + (((int64_t)g * T + tile0) * C + 4 * qq + (comp & 3)) * 2 + (comp >> 2);
     *o = acc;
   }
 }
@@ -598,7 +612,7 @@ __global__ __launch_bounds__(256) void edge_apply_kernel(const float* __restrict
   }
   const float kf = (float)k;
   bool bad = false;
-  for (int tile = tb; tile < tiles; tile += T) {
+  for (int tile = xcd_tile(tb, lat); tile < tiles; tile += T) {
     const int n0 = tile * TILE;
     for (int p = pl; p < TILE; p += PPB) {
       const int n = n0 + p;
@@ -689,7 +703,7 @@ __global__ __launch_bounds__(256) void edge_bwd_reduce_kernel(const float* __res
                                                               const float* __restrict__ Gy, int64_t ldg,
                                                               EdgeBwdAffine A, double* __restrict__ partials, int T,
                                                               unsigned* __restrict__ status, float* __restrict__ sums,
-                                                              float* __restrict__ gacc, int64_t lda) {
+                                                              float* __restrict__ gacc, int64_t lda, int band) {
   constexpr int Q = C / 4;
   constexpr int PPB = 256 / Q;
   __shared__ double red[256 * 16];
@@ -714,7 +728,9 @@ __global__ __launch_bounds__(256) void edge_bwd_reduce_kernel(const float* __res
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.0;
   bool bad = false;
-  for (int tile = tb; tile < tiles; tile += T) {
+  const Lattice xo{0, 1, 1, band};                    // XCD-aware tile order (xcd_tile); the partial row stays the tile's
+  const int tile0 = xcd_tile(tb, xo);
+  for (int tile = tile0; tile < tiles; tile += T) {
     const int n0 = tile * TILE;
     for (int p = pl; p < TILE; p += PPB) {
       const int n = n0 + p;
@@ -807,7 +823,7 @@ __global__ __launch_bounds__(256) void edge_bwd_reduce_kernel(const float* __res
     const int slot = (central ? 8 : 0) + 4 * comp + cc;
     double v = 0.0;
     for (int s = 0; s < PPB; ++s) v += red[(s * Q + qq) * 16 + slot];
-    partials[(((int64_t)g * T + tb) * cols + col) * 2 + comp] = v;
+    partials[(((int64_t)g * T + tile0) * cols + col) * 2 + comp] = v;
   }
 }
 
@@ -900,14 +916,16 @@ __global__ __launch_bounds__(256) void edge_bwd_inverse_kernel(const float* __re
                                                                const float* __restrict__ Gy, int64_t ldg,
                                                                EdgeBwdAffine A, const uint32_t* __restrict__ order,
                                                                const uint32_t* __restrict__ start,
-                                                               float* __restrict__ dLE, int64_t rows, int dbg) {
+                                                               float* __restrict__ dLE, int64_t rows, int dbg,
+                                                               int band) {
   constexpr int Q = C / 4;
   constexpr int PPB = 256 / Q;
   const int tid = threadIdx.x;
   const int q = tid % Q, pl = tid / Q;
   const int doff = A.concat ? C : 0;
   const float kf = (float)k;
-  for (int64_t row = (int64_t)blockIdx.x * PPB + pl; row < rows; row += (int64_t)gridDim.x * PPB) {
+  const Lattice xo{0, 1, 1, band};                    // XCD-aware order of the blocks' row groups (band > 0: one group per block)
+  for (int64_t row = (int64_t)xcd_tile((int)blockIdx.x, xo) * PPB + pl; row < rows; row += (int64_t)gridDim.x * PPB) {
     const int g = (int)(row / Ng);
     const int64_t so = (int64_t)(g / A.groups_per_stat) * A.ld + doff + 4 * q;
     const float4 a = ld4(A.scale + so), b = ld4(A.shift + so), mu = ld4(A.mean + so), is = ld4(A.invstd + so);
@@ -1328,8 +1346,15 @@ static int check_lattice(const int64_t* idx, const uint8_t* codes, int k, int Ng
                          Lattice& lat) {
   lat.ks = 0;
   lat.H = lat.W = 1;
+  lat.band = 0;
   if (codes == nullptr) {
     PF_REQUIRE(idx != nullptr);
+    // no window codes, but the caller may still name the lattice plane (lat_ks 0, lat_h x lat_w): a hint for the
+    // XCD-aware tile order below, ignored when it does not divide the group
+    if (lat_ks == 0 && lat_h >= 1 && lat_w >= 1 && (int64_t)lat_h * lat_w > 1 && Ng % ((int64_t)lat_h * lat_w) == 0) {
+      lat.H = lat_h;
+      lat.W = lat_w;
+    }
     return PF_OK;
   }
   PF_REQUIRE(k == 16 && (lat_ks == 3 || lat_ks == 5) && lat_h >= 1 && lat_w >= 1);
@@ -1339,6 +1364,15 @@ static int check_lattice(const int64_t* idx, const uint8_t* codes, int k, int Ng
   lat.W = lat_w;
   return PF_OK;
 }
+
+// XCD-aware tile order (Lattice::band) where the launch allows it: whole tiles per plane, a multiple of 8 of them, one
+// tile per block.  PF_EDGE_XCD=0 keeps tile = block (tools: the A/B arm).
+static int xcd_band(int64_t plane, int unit, int64_t Ng, int64_t blocks) {      // units of `unit` points per block
+  static const bool on = !(getenv("PF_EDGE_XCD") && atoi(getenv("PF_EDGE_XCD")) == 0);
+  if (!on || plane <= 1 || plane % unit != 0 || (plane / unit) % 8 != 0 || Ng % plane != 0 || blocks != Ng / unit) return 0;
+  return (int)(plane / unit / 8);
+}
+static void lattice_band(Lattice& lat, int Ng, int T) { lat.band = xcd_band((int64_t)lat.H * lat.W, TILE, Ng, T); }
 
 int pf_edge_stats_f32(const float* LE, int64_t ldle, int C, const int64_t* idx, int k, int G, int Ng,
                       double* partials, const uint8_t* codes, int lat_ks, int lat_h, int lat_w, void* stream) {
@@ -1354,6 +1388,7 @@ int pf_edge_stats_f32(const float* LE, int64_t ldle, int C, const int64_t* idx, 
   unsigned* status = pf_status_ptr();
   PF_REQUIRE(status != nullptr);
   const int T = pf_stat_blocks(G, Ng);
+  lattice_band(lat, Ng, T);
   dim3 grid((unsigned)T, (unsigned)G);
   hipStream_t s = (hipStream_t)stream;
 #define PF_ES(CV, KV) hipLaunchKernelGGL((edge_stats_kernel<CV, KV>), grid, dim3(256), 0, s, LE, ldle, idx, k, Ng, partials, T, status, codes, lat)
@@ -1428,6 +1463,7 @@ int pf_edge_apply_f32(const float* LE, int64_t ldle, int C, const int64_t* idx, 
     if (rc != PF_OK) return rc;
   }
   const int T = pf_stat_blocks(G, Ng);
+  lattice_band(lat, Ng, T);
   dim3 grid((unsigned)T, (unsigned)G);
   hipStream_t s = (hipStream_t)stream;
 #define PF_EA(CV, KV)                                                                                         \
@@ -1446,7 +1482,8 @@ extern "C++" {
 static int edge_backward_reduce(const float* LE, int64_t ldle, int C, const int64_t* idx, int k, int G, int Ng,
                                 const float* grad_y, int64_t ldg, const float* scale, const float* shift,
                                 const float* mean, const float* invstd, int ld_affine, int groups_per_stat,
-                                int concat, double* partials, float* sums, float* gacc, int64_t lda, void* stream) {
+                                int concat, double* partials, float* sums, float* gacc, int64_t lda, int plane,
+                                void* stream) {
   PF_REQUIRE(G >= 0 && Ng >= 0 && k >= 1 && ldle >= 2 * (int64_t)C && (ldle % 4) == 0 && G <= 65535);
   PF_REQUIRE(gacc == nullptr || (sums != nullptr && (lda % 4) == 0 && lda >= (concat ? 2 : 1) * (int64_t)C));
   PF_REQUIRE(groups_per_stat >= 1 && (ldg % 4) == 0 && ldg >= (concat ? 2 : 1) * (int64_t)C);
@@ -1458,9 +1495,10 @@ static int edge_backward_reduce(const float* LE, int64_t ldle, int C, const int6
   PF_REQUIRE(status != nullptr);
   const EdgeBwdAffine A{scale, shift, mean, invstd, nullptr, nullptr, ld_affine, groups_per_stat, concat};
   const int T = pf_stat_blocks(G, Ng);
+  const int band = xcd_band(plane, TILE, Ng, T);
   dim3 grid((unsigned)T, (unsigned)G);
   hipStream_t s = (hipStream_t)stream;
-#define PF_EBR(CV, KV, SV) hipLaunchKernelGGL((edge_bwd_reduce_kernel<CV, KV, SV>), grid, dim3(256), 0, s, LE, ldle, idx, k, Ng, grad_y, ldg, A, partials, T, status, sums, gacc, lda)
+#define PF_EBR(CV, KV, SV) hipLaunchKernelGGL((edge_bwd_reduce_kernel<CV, KV, SV>), grid, dim3(256), 0, s, LE, ldle, idx, k, Ng, grad_y, ldg, A, partials, T, status, sums, gacc, lda, band)
   if (sums != nullptr) {
     if (k == 16) {
       if (C == 32) PF_EBR(32, 16, true); else PF_EBR(64, 16, true);
@@ -1482,34 +1520,37 @@ int pf_edge_backward_reduce_f32(const float* LE, int64_t ldle, int C, const int6
                                 const float* mean, const float* invstd, int ld_affine, int groups_per_stat,
                                 int concat, double* partials, void* stream) {
   return edge_backward_reduce(LE, ldle, C, idx, k, G, Ng, grad_y, ldg, scale, shift, mean, invstd, ld_affine,
-                              groups_per_stat, concat, partials, nullptr, nullptr, 0, stream);
+                              groups_per_stat, concat, partials, nullptr, nullptr, 0, 0, stream);
 }
 
 int pf_edge_backward_sums_f32(const float* LE, int64_t ldle, int C, const int64_t* idx, int k, int G, int Ng,
                               const float* grad_y, int64_t ldg, const float* scale, const float* shift,
                               const float* mean, const float* invstd, int ld_affine, int groups_per_stat, int concat,
-                              double* partials, float* grad_le, float* grad_acc, int64_t ld_acc, void* stream) {
+                              double* partials, float* grad_le, float* grad_acc, int64_t ld_acc, int plane,
+                              void* stream) {
   PF_REQUIRE(grad_le != nullptr || G == 0 || Ng == 0);
+  PF_REQUIRE(plane >= 0);
   return edge_backward_reduce(LE, ldle, C, idx, k, G, Ng, grad_y, ldg, scale, shift, mean, invstd, ld_affine,
-                              groups_per_stat, concat, partials, grad_le, grad_acc, ld_acc, stream);
+                              groups_per_stat, concat, partials, grad_le, grad_acc, ld_acc, plane, stream);
 }
 
 extern "C++" {
 template <bool FINISH>
 static void edge_backward_inverse_launch(const float* LE, int64_t ldle, int C, int k, int G, int Ng, const float* grad_y,
                                          int64_t ldg, const EdgeBwdAffine& A, const uint32_t* inv_order,
-                                         const uint32_t* inv_start, float* grad_le, hipStream_t s) {
+                                         const uint32_t* inv_start, float* grad_le, int plane, hipStream_t s) {
   const int64_t rows = (int64_t)G * Ng;
   const int ppb = 256 / (C / 4);
   int64_t blocks = pf_cdiv(rows, ppb);
   if (blocks > 16384) blocks = 16384;
+  const int band = G == 1 ? xcd_band(plane, ppb, Ng, blocks) : 0;
   static const int dbg = getenv("PF_EDGE_FINISH_DBG") ? atoi(getenv("PF_EDGE_FINISH_DBG")) : 0;   // tools only: wrong results
   if (C == 32)
     hipLaunchKernelGGL((edge_bwd_inverse_kernel<32, FINISH>), dim3((unsigned)blocks), dim3(256), 0, s, LE, ldle, k, Ng,
-                       grad_y, ldg, A, inv_order, inv_start, grad_le, rows, dbg);
+                       grad_y, ldg, A, inv_order, inv_start, grad_le, rows, dbg, band);
   else
     hipLaunchKernelGGL((edge_bwd_inverse_kernel<64, FINISH>), dim3((unsigned)blocks), dim3(256), 0, s, LE, ldle, k, Ng,
-                       grad_y, ldg, A, inv_order, inv_start, grad_le, rows, dbg);
+                       grad_y, ldg, A, inv_order, inv_start, grad_le, rows, dbg, band);
 }
 }  // extern "C++"
 
@@ -1549,7 +1590,7 @@ int pf_edge_backward_apply_f32(const float* LE, int64_t ldle, int C, const int64
     if (C == 32) PF_EBA(32, 0, false); else PF_EBA(64, 0, false);
   }
 #undef PF_EBA
-  edge_backward_inverse_launch<false>(LE, ldle, C, k, G, Ng, grad_y, ldg, A, inv_order, inv_start, grad_le, s);
+  edge_backward_inverse_launch<false>(LE, ldle, C, k, G, Ng, grad_y, ldg, A, inv_order, inv_start, grad_le, 0, s);
   return pf_launch_status();
 }
 
@@ -1557,15 +1598,15 @@ int pf_edge_backward_finish_f32(const float* LE, int64_t ldle, int C, int k, int
                                 int64_t ldg, const float* scale, const float* shift, const float* mean,
                                 const float* invstd, const float* c1, const float* c2, int ld_affine,
                                 int groups_per_stat, int concat, float* grad_le, const uint32_t* inv_order,
-                                const uint32_t* inv_start, void* stream) {
-  PF_REQUIRE(G >= 0 && Ng >= 0 && k >= 1 && ldle >= 2 * (int64_t)C && (ldle % 4) == 0 && G <= 65535);
+                                const uint32_t* inv_start, int plane, void* stream) {
+  PF_REQUIRE(G >= 0 && Ng >= 0 && k >= 1 && ldle >= 2 * (int64_t)C && (ldle % 4) == 0 && G <= 65535 && plane >= 0);
   PF_REQUIRE(groups_per_stat >= 1 && (ldg % 4) == 0 && ldg >= (concat ? 2 : 1) * (int64_t)C);
   PF_REQUIRE((ld_affine % 4) == 0 && ld_affine >= (concat ? 2 : 1) * C);
   if (C != 32 && C != 64) return PF_ERR_UNSUPPORTED;
   if (G == 0 || Ng == 0) return PF_OK;
   PF_REQUIRE(LE && grad_y && scale && shift && mean && invstd && c1 && c2 && grad_le && inv_order && inv_start);
   const EdgeBwdAffine A{scale, shift, mean, invstd, c1, c2, ld_affine, groups_per_stat, concat};
-  edge_backward_inverse_launch<true>(LE, ldle, C, k, G, Ng, grad_y, ldg, A, inv_order, inv_start, grad_le,
+  edge_backward_inverse_launch<true>(LE, ldle, C, k, G, Ng, grad_y, ldg, A, inv_order, inv_start, grad_le, plane,
                                      (hipStream_t)stream);
   return pf_launch_status();
 }

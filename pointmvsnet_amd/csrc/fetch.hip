@@ -422,7 +422,9 @@ __global__ __launch_bounds__(256) void flow_features_hyp_kernel(const float* __r
   const int q = threadIdx.x & (kFeatLanes - 1);
   const int pl = threadIdx.x / kFeatLanes;
   const int tiles_x = (w + kFeatPX - 1) / kFeatPX;
-  const int bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
+  // (XCD x owns a band of patch rows: the bilinear footprints of neighbouring patches overlap -- pf_common.h)
+  const unsigned blk = (PF_XCD & PF_XCD_FETCH) ? pf_xcd_chunk(blockIdx.x, gridDim.x) : blockIdx.x;
+  const int bx = (int)blk % tiles_x, by = (int)blk / tiles_x;
   const int y_raw = by * kFeatPY + pl / kFeatPX, x_raw = bx * kFeatPX + pl % kFeatPX;
   const bool live = y_raw < h && x_raw < w;
   const int y = live ? y_raw : h - 1, x = live ? x_raw : w - 1;

@@ -62,6 +62,45 @@ static inline int pf_zero_async(void* p, size_t bytes, hipStream_t s) {
 }
 #endif
 
+// ---- XCD-aware block order ------------------------------------------------------------------------
+// Workgroups are dealt to the 8 XCDs round-robin in dispatch order (linear block id % 8) and every XCD has its own 4 MB
+// L2.  With tile = block, the eight neighbours of a tile -- which read the same halo rows / gather the same point rows --
+// sit on eight different L2s.  pf_xcd_chunk relabels the blocks so that XCD x owns the x-th contiguous eighth of the
+// launch's tiles: neighbours share an L2.  A pure relabelling (a bijection of the grid): results are bit-identical as long
+// as everything a kernel derives from blockIdx -- the BatchNorm partial row included -- comes from the relabelled ids.
+// PF_XCD is a bit mask of kernel families (tools/experiments/build_xcd_variants.sh: A/B builds); 0 = tile = block
+// everywhere.  Measured same-box on the headline (profiles/r06t_xcd_block_order.md): towers +1.0 %, conv3d -0.6 %, flow
+// feature assembly +-0 -- so only the towers take it by default.  (The EdgeConv gather passes use their own band order,
+// csrc/edgeconv.hip: xcd_tile, +2.3 %.)
+#ifndef PF_XCD
+#define PF_XCD 1
+#endif
+#define PF_XCD_TOWER 1
+#define PF_XCD_CONV3D 2
+#define PF_XCD_FETCH 4
+#define PF_XCD_KNN 8
+#define PF_XCD_EDGE 16
+#ifdef __HIPCC__
+__device__ __forceinline__ unsigned pf_xcd_chunk(unsigned lin, unsigned total) {
+  const unsigned per = total >> 3, rem = total & 7u;
+  const unsigned x = lin & 7u, j = lin >> 3;
+  return x * per + (x < rem ? x : rem) + j;
+}
+// the relabelled (blockIdx.x, blockIdx.y) of a 2-D grid (x fastest in dispatch order)
+template <int FAMILY>
+__device__ __forceinline__ void pf_xcd_xy(unsigned& bx, unsigned& by) {
+  if ((PF_XCD & FAMILY) == 0) {
+    bx = blockIdx.x;
+    by = blockIdx.y;
+    return;
+  }
+  const unsigned gx = gridDim.x;
+  const unsigned L = pf_xcd_chunk(blockIdx.y * gx + blockIdx.x, gx * gridDim.y);
+  by = L / gx;
+  bx = L - by * gx;
+}
+#endif
+
 // ---- projection + bilinear taps shared by the fetch kernels -------------------------------------
 // Follows reference utils/feature_fetcher.py:36-55 on the arithmetic of ATen's CPU grid_sample with
 // align_corners=True (the oracle): un-normalise with (g + 1) * ((size - 1) / 2), weights

@@ -680,7 +680,7 @@ class PointMVSNet(nn.Module):
                 and self.flow_mlp[1].bias is None and self.flow_mlp[1].out_channels == 1):
             # EdgeConv x3 + the shared MLP as two autograd nodes on point-major rows; the 16 -> 1 convolution and
             # everything after it are a few element-wise ATen operations on (N, 16)
-            edges = train_ops.edge_chain_train(self.flow_edge_conv, rows, nn_idx)          # (N, 224)
+            edges = train_ops.edge_chain_train(self.flow_edge_conv, rows, nn_idx, plane_hw=(hs, ws))   # (N, 224)
             if train_ops.mlp_supported(self.flow_mlp[0], edges):
                 act = train_ops.mlp_train(self.flow_mlp[0], edges)                             # (N, 16)
                 if train_ops.flow_head_supported(act, self.flow_mlp[1], D) and interval.numel() == 1:

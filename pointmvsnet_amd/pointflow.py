@@ -1031,7 +1031,12 @@ def edge_conv_fused(X, point_major, ldx, K, G, Ng, idx, conv1_w, conv2_w, bn, co
     affine rows and the batch statistics (mean, invstd) in the BatchNorm's channel order."""
     C = conv1_w.shape[0]
     k = idx.shape[-1] if idx is not None else int(codes.shape[-1])
-    lat = (0, 1, 1) if codes is None else tuple(int(v) for v in lattice)
+    # (without codes a lattice (0, H, W) is only a hint for the XCD-aware tile order of the two gather passes)
+    lat = tuple(int(v) for v in lattice) if lattice is not None else (0, 1, 1)
+    if codes is None:
+        lat = (0, lat[1], lat[2])
+    if keep is not None:
+        keep["plane"] = lat[1] * lat[2] if lat[1] * lat[2] > 1 else 0
     dev = Y.device
     S = G // groups_per_stat
     training = bn.training or not bn.track_running_stats
@@ -1157,7 +1162,7 @@ def edge_conv_backward(keep, idx, grad_y, C, k, G, Ng, groups_per_stat, concat, 
         _lib.call("pf_edge_backward_sums_f32", _lib.ptr(LE), 2 * C, C, _lib.ptr(idx), k, G, Ng, _lib.ptr(grad_y),
                   int(grad_y.stride(0)), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(mean), _lib.ptr(invstd), cbn,
                   groups_per_stat, int(bool(concat)), _lib.ptr(partials), _lib.ptr(grad_le), _lib.ptr(grad_acc),
-                  0 if grad_acc is None else int(grad_acc.stride(0)), _lib.stream(),
+                  0 if grad_acc is None else int(grad_acc.stride(0)), int(keep.get("plane", 0)), _lib.stream(),
                   algo_bytes=float(G) * Ng * (12.0 * C + 8.0 * k + 4.0 * C * k + 4.0 * cbn))
         if grad_acc is not None:
             grad_y = grad_acc
@@ -1181,7 +1186,7 @@ def edge_conv_backward(keep, idx, grad_y, C, k, G, Ng, groups_per_stat, concat, 
         _lib.call("pf_edge_backward_finish_f32", _lib.ptr(LE), 2 * C, C, k, G, Ng, _lib.ptr(grad_y),
                   int(grad_y.stride(0)), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(c1),
                   _lib.ptr(c2), cbn, groups_per_stat, int(bool(concat)), _lib.ptr(grad_le), _lib.ptr(order),
-                  _lib.ptr(start), _lib.stream(),
+                  _lib.ptr(start), int(keep.get("plane", 0)), _lib.stream(),
                   algo_bytes=float(G) * Ng * (16.0 * C + 4.0 * k + 8.0 * C * k + 4.0 * cbn))
     else:
         _lib.call("pf_edge_backward_apply_f32", _lib.ptr(LE), 2 * C, C, _lib.ptr(idx), k, G, Ng, _lib.ptr(grad_y),

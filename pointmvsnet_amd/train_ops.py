@@ -992,7 +992,7 @@ class _EdgeChainTrain(torch.autograd.Function):
     (reference model.py:209-216: each layer's output is the next one's input and a slice of the MLP's input)."""
 
     @staticmethod
-    def forward(ctx, feature, idx, edge_convs, *params):
+    def forward(ctx, feature, idx, edge_convs, lattice, *params):
         ctx.packs = _PACKS
         ctx.side = _on_side(3)
         x = feature.detach().contiguous()
@@ -1008,7 +1008,7 @@ class _EdgeChainTrain(torch.autograd.Function):
                 keep = {}
                 Y = edges[:, col:]
                 pointflow.edge_conv_fused(X, True, ldx, K, 1, N, idx, m.conv1.weight, m.conv2.weight, m.bn, m.concat, Y,
-                                          ctot, groups_per_stat=1, keep=keep)
+                                          ctot, groups_per_stat=1, lattice=lattice, keep=keep)
                 keeps.append((keep, X, ldx, K, col, wdt))
                 X, ldx, K = Y, ctot, wdt
                 col += wdt
@@ -1049,11 +1049,14 @@ class _EdgeChainTrain(torch.autograd.Function):
                     carry = dX
                 gparams = [None if dw is None else dw[:C].reshape(m.conv1.weight.shape),
                            None if dw is None else dw[C:].reshape(m.conv2.weight.shape), dgamma, dbeta] + gparams
-        return (gx, None, None) + tuple(gparams)
+        return (gx, None, None, None) + tuple(gparams)
 
 
-def edge_chain_train(edge_convs, feature, idx):
-    return _EdgeChainTrain.apply(feature, idx, edge_convs, *edge_chain_params(edge_convs))
+def edge_chain_train(edge_convs, feature, idx, plane_hw=None):
+    """``plane_hw`` = (H, W) of the D x H x W lattice ``idx`` was searched on (model.py:_sub_flow_autograd), or None: a hint
+    for the XCD-aware block order of the gather passes (csrc/edgeconv.hip: xcd_tile); results do not depend on it."""
+    lattice = None if plane_hw is None else (0, int(plane_hw[0]), int(plane_hw[1]))
+    return _EdgeChainTrain.apply(feature, idx, edge_convs, lattice, *edge_chain_params(edge_convs))
 
 
 def mlp_supported(shared, x):
