@@ -925,7 +925,14 @@ __global__ __launch_bounds__(256) void edge_bwd_inverse_kernel(const float* __re
   const int doff = A.concat ? C : 0;
   const float kf = (float)k;
   const Lattice xo{0, 1, 1, band};                    // XCD-aware order of the blocks' row groups (band > 0: one group per block)
-  for (int64_t row = (int64_t)xcd_tile((int)blockIdx.x, xo) * PPB + pl; row < rows; row += (int64_t)gridDim.x * PPB) {
+  constexpr int NG = 64 / Q;                          // row groups of a wave
+  constexpr uint32_t HEAD = 24;                       // pairs a row's own lanes walk; what is left is shared by the wave
+  const int lane = (int)(tid & 63);
+  const int gl = lane & ~(Q - 1), gi = lane / Q;
+  // every lane stays in the loop (the tail below is a wave-level collective); `live` = the lane has a row
+  for (int64_t row0 = (int64_t)xcd_tile((int)blockIdx.x, xo) * PPB; row0 < rows; row0 += (int64_t)gridDim.x * PPB) {
+    const bool live = row0 + pl < rows;
+    const int64_t row = live ? row0 + pl : rows - 1;
     const int g = (int)(row / Ng);
     const int64_t so = (int64_t)(g / A.groups_per_stat) * A.ld + doff + 4 * q;
     const float4 a = ld4(A.scale + so), b = ld4(A.shift + so), mu = ld4(A.mean + so), is = ld4(A.invstd + so);
@@ -935,7 +942,7 @@ __global__ __launch_bounds__(256) void edge_bwd_inverse_kernel(const float* __re
     const float c1v[4] = {k1.x, k1.y, k1.z, k1.w}, c2v[4] = {k2.x, k2.y, k2.z, k2.w};
     const float4 e = ld4(LE + row * ldle + C + 4 * q);
     const float ev[4] = {e.x, e.y, e.z, e.w};
-    const uint32_t t0 = start[row], t1 = start[row + 1];
+    const uint32_t t0 = start[row], t1 = live ? start[row + 1] : t0;
     float de[4] = {0, 0, 0, 0};
     float4 sg4 = {0, 0, 0, 0}, sx4 = {0, 0, 0, 0}, l4 = {0, 0, 0, 0}, gc4 = {0, 0, 0, 0};
     if (FINISH && !(dbg & 1)) {       // issued before the list walk: their latency hides behind it
@@ -946,30 +953,89 @@ __global__ __launch_bounds__(256) void edge_bwd_inverse_kernel(const float* __re
         gc4 = ld4(Gy + row * ldg + 4 * q);
       }
     }
-    for (uint32_t t = t0; t < t1; t += 4) {
-      int64_t nrow[4];
-      float4 l[4], gy[4];
+    auto pair_term = [&](const float4& lq, const float4& gq, const float* evv, float* acc) {
+      const float lv[4] = {lq.x, lq.y, lq.z, lq.w};
+      const float gv[4] = {gq.x / kf, gq.y / kf, gq.z / kf, gq.w / kf};
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const uint32_t p = order[t + u < t1 ? t + u : t1 - 1];
-        nrow[u] = (int64_t)(k == 16 ? (p >> 4) : (p / (uint32_t)k));
+      for (int c = 0; c < 4; ++c) {
+        const float d = evv[c] - lv[c];
+        const float uu = fmaf(d, av[c], bv[c]);
+        const float gg = uu > 0.0f ? gv[c] : 0.0f;
+        acc[c] += av[c] * ((gg - c1v[c]) - ((d - mv[c]) * iv[c]) * c2v[c]);
       }
+    };
+    // The list's pair ids arrive Q at a time -- ONE coalesced load by the row's Q lanes, a chunk ahead of its use, handed
+    // round by wave shuffles -- and the rows of 8 pairs are in flight together: ~n / 8 dependent round trips for n pairs
+    // (round 4's walk: 4 ids, then 4 row pairs -- 2 dependent round trips per 4 pairs).
+    const uint32_t len = t1 - t0;
+    const uint32_t head = len < HEAD ? len : HEAD;
+    uint32_t idn = (uint32_t)q < head ? order[t0 + q] : 0u;
+    for (uint32_t c0 = 0; c0 < head; c0 += Q) {
+      const uint32_t idc = idn;
+      idn = c0 + Q + q < head ? order[t0 + c0 + Q + q] : 0u;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        l[u] = ld4(LE + nrow[u] * ldle + 4 * q);
-        gy[u] = ld4(Gy + nrow[u] * ldg + doff + 4 * q);
+      for (int sub = 0; sub < Q; sub += 8) {
+        if (c0 + sub >= head) break;
+        uint32_t nrow[8];
+        float4 l[8], gy[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const uint32_t p = (uint32_t)__shfl((int)idc, gl + sub + u);
+          nrow[u] = c0 + sub + u < head ? (k == 16 ? (p >> 4) : (p / (uint32_t)k)) : (uint32_t)row;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          l[u] = ld4(LE + (int64_t)nrow[u] * ldle + 4 * q);
+          gy[u] = ld4(Gy + (int64_t)nrow[u] * ldg + doff + 4 * q);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (c0 + sub + u < head) pair_term(l[u], gy[u], ev, de);
       }
+    }
+    // Hub rows.  The kernel lasts as long as its longest list, and the config-4 step has lists of 79-87 pairs against a
+    // mean of 16 (tools/knn_indegree.py: p99 = 28) -- a 25 600-point pass took 62-72 us there against 22-35 us on a lattice
+    // without hubs.  What a list holds beyond HEAD pairs is shared by the wave's NG row groups: group i takes pairs
+    // HEAD + i, HEAD + i + NG, ... of the owner's list (its lanes hold the same channel quads as the owner's), and the
+    // partial sums join the owner's in group order -- a fixed order, so the result stays bit-reproducible.  Needs one set of
+    // BatchNorm rows per wave (the lanes use their own): checked, else the owner walks its tail alone.
+    {
+      const bool same = __all(g == __shfl(g, 0)) != 0;
+      unsigned long long todo = __ballot(live && len > HEAD);
+      while (todo != 0ull) {
+        const int og = (__ffsll((long long)todo) - 1) & ~(Q - 1);
+        todo &= ~(((1ull << Q) - 1ull) << og);
+        const uint32_t ot0 = (uint32_t)__shfl((int)t0, og), olen = (uint32_t)__shfl((int)len, og);
+        float oe[4], part[4] = {0, 0, 0, 0};
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (t + u < t1) {
-          const float lv[4] = {l[u].x, l[u].y, l[u].z, l[u].w};
-          const float gv[4] = {gy[u].x / kf, gy[u].y / kf, gy[u].z / kf, gy[u].w / kf};
+        for (int c = 0; c < 4; ++c) oe[c] = __shfl(ev[c], og + q);
+        const uint32_t step = same ? (uint32_t)NG : 1u;
+        uint32_t t = HEAD + (same ? (uint32_t)gi : 0u);
+        const bool mine = same || gl == og;
+        for (; mine && t < olen; t += 4 * step) {
+          uint32_t nr[4];
+          float4 l[4], gy[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const uint32_t tt = t + u * step;
+            const uint32_t p = order[ot0 + (tt < olen ? tt : olen - 1)];
+            nr[u] = k == 16 ? (p >> 4) : (p / (uint32_t)k);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            l[u] = ld4(LE + (int64_t)nr[u] * ldle + 4 * q);
+            gy[u] = ld4(Gy + (int64_t)nr[u] * ldg + doff + 4 * q);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (t + u * step < olen) pair_term(l[u], gy[u], oe, part);
+        }
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
-            const float d = ev[c] - lv[c];
-            const float uu = fmaf(d, av[c], bv[c]);
-            const float gg = uu > 0.0f ? gv[c] : 0.0f;
-            de[c] += av[c] * ((gg - c1v[c]) - ((d - mv[c]) * iv[c]) * c2v[c]);
+            const float v = __shfl(part[c], i * Q + q);
+            if (gl == og) de[c] += v;
           }
         }
       }
@@ -996,9 +1062,9 @@ __global__ __launch_bounds__(256) void edge_bwd_inverse_kernel(const float* __re
           dl[c] += acv[c] * ((gg - c1c[c]) - ((lv[c] - mcv[c]) * icv[c]) * c2c[c]);
         }
       }
-      if (!(dbg & 2)) *reinterpret_cast<float4*>(dLE + row * ldle + 4 * q) = make_float4(dl[0], dl[1], dl[2], dl[3]);
+      if (!(dbg & 2) && live) *reinterpret_cast<float4*>(dLE + row * ldle + 4 * q) = make_float4(dl[0], dl[1], dl[2], dl[3]);
     }
-    *reinterpret_cast<float4*>(dLE + row * ldle + C + 4 * q) = make_float4(de[0], de[1], de[2], de[3]);
+    if (live) *reinterpret_cast<float4*>(dLE + row * ldle + C + 4 * q) = make_float4(de[0], de[1], de[2], de[3]);
   }
 }
 

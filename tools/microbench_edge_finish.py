@@ -14,7 +14,17 @@ from pointmvsnet_amd.utils.torch_utils import get_knn_3d  # noqa: E402
 dev = torch.device("cuda:0")
 
 
+FLUSH = os.environ.get("PF_MB_FLUSH", "0") != "0"     # evict the caches between repetitions (a 1 GB fill)
+_junk = torch.empty((256 << 20,), dtype=torch.float32, device=dev) if FLUSH else None
+
+
 def timeit(fn, reps=20):
+    if FLUSH:
+        inner = fn
+
+        def fn():
+            _junk.fill_(1.0)
+            inner()
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
