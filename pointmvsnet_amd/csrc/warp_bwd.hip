@@ -200,15 +200,30 @@ __global__ __launch_bounds__(256) void warp_gather_kernel(const float* __restric
     const int yi = y - (k >> 1), xi = x - (k & 1);
     const uint32_t key = (uint32_t)v * cells + (uint32_t)(yi + 1) * (uint32_t)(W + 1) + (uint32_t)(xi + 1);
     const uint32_t t0 = start[key], t1 = start[key + 1];
-    for (uint32_t e = t0; e < t1; ++e) {
-      const uint32_t p = order[e];
-      const float2 f = fxy[p];
-      const float wy = (k >> 1) ? f.y : 1.0f - f.y;
-      const float wx = (k & 1) ? f.x : 1.0f - f.x;
-      const float wgt = wy * wx;
-      const f32x4 g = *reinterpret_cast<const f32x4*>(gval + (int64_t)p * ctot + 4 * q);
+    // 8 pairs per trip: their ids in one batch of loads, then their offsets and rows in another -- two dependent round
+    // trips per 8 pairs (round 4: two per PAIR; a texel of the coarse volume sums ~4 x 48 pairs): 133 -> 74 us there.
+    // Same summation order.  (A lane per cell list, the four sums joined by shuffles, was slower: 98 us.)
+    for (uint32_t e = t0; e < t1; e += 8) {
+      uint32_t p[8];
+      float2 f[8];
+      f32x4 g[8];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = fmaf(g[j], wgt, acc[j]);
+      for (int u = 0; u < 8; ++u) p[u] = order[e + u < t1 ? e + u : t1 - 1];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        f[u] = fxy[p[u]];
+        g[u] = *reinterpret_cast<const f32x4*>(gval + (int64_t)p[u] * ctot + 4 * q);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (e + u < t1) {
+          const float wy = (k >> 1) ? f[u].y : 1.0f - f[u].y;
+          const float wx = (k & 1) ? f[u].x : 1.0f - f[u].x;
+          const float wgt = wy * wx;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j] = fmaf(g[u][j], wgt, acc[j]);
+        }
+      }
     }
   }
   *reinterpret_cast<f32x4*>(dmaps + ((int64_t)v * H * W + texel) * ctot + 4 * q) = acc;
