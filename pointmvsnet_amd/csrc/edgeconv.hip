@@ -912,7 +912,7 @@ __global__ __launch_bounds__(256) void edge_bwd_apply_kernel(const float* __rest
 }
 
 template <int C, bool FINISH>
-__global__ __launch_bounds__(256) void edge_bwd_inverse_kernel(const float* __restrict__ LE, int64_t ldle, int k, int Ng,
+__global__ __launch_bounds__(256, 3) void edge_bwd_inverse_kernel(const float* __restrict__ LE, int64_t ldle, int k, int Ng,
                                                                const float* __restrict__ Gy, int64_t ldg,
                                                                EdgeBwdAffine A, const uint32_t* __restrict__ order,
                                                                const uint32_t* __restrict__ start,
@@ -969,13 +969,14 @@ __global__ __launch_bounds__(256) void edge_bwd_inverse_kernel(const float* __re
     // (round 4's walk: 4 ids, then 4 row pairs -- 2 dependent round trips per 4 pairs).
     const uint32_t len = t1 - t0;
     const uint32_t head = len < HEAD ? len : HEAD;
+    // (wave-uniform trip counts -- the shuffles are wave collectives; a group past its own head idles through the rest)
     uint32_t idn = (uint32_t)q < head ? order[t0 + q] : 0u;
-    for (uint32_t c0 = 0; c0 < head; c0 += Q) {
+    for (uint32_t c0 = 0; __any(c0 < head); c0 += Q) {
       const uint32_t idc = idn;
       idn = c0 + Q + q < head ? order[t0 + c0 + Q + q] : 0u;
 #pragma unroll
       for (int sub = 0; sub < Q; sub += 8) {
-        if (c0 + sub >= head) break;
+        if (!__any(c0 + sub < head)) break;
         uint32_t nrow[8];
         float4 l[8], gy[8];
 #pragma unroll
@@ -983,14 +984,16 @@ __global__ __launch_bounds__(256) void edge_bwd_inverse_kernel(const float* __re
           const uint32_t p = (uint32_t)__shfl((int)idc, gl + sub + u);
           nrow[u] = c0 + sub + u < head ? (k == 16 ? (p >> 4) : (p / (uint32_t)k)) : (uint32_t)row;
         }
+        if (c0 + sub < head) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          l[u] = ld4(LE + (int64_t)nrow[u] * ldle + 4 * q);
-          gy[u] = ld4(Gy + (int64_t)nrow[u] * ldg + doff + 4 * q);
+          for (int u = 0; u < 8; ++u) {
+            l[u] = ld4(LE + (int64_t)nrow[u] * ldle + 4 * q);
+            gy[u] = ld4(Gy + (int64_t)nrow[u] * ldg + doff + 4 * q);
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (c0 + sub + u < head) pair_term(l[u], gy[u], ev, de);
         }
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-          if (c0 + sub + u < head) pair_term(l[u], gy[u], ev, de);
       }
     }
     // Hub rows.  The kernel lasts as long as its longest list, and the config-4 step has lists of 79-87 pairs against a

@@ -163,6 +163,24 @@ static inline T __shfl(T v, int src, int width = 64) {
   const int base = hipemu::lane & ~(width - 1);
   return hipemu_shfl_from(v, base + (src & (width - 1)));
 }
+// wave votes (round 6: the inverted-list gather of the EdgeConv backward): every lane of the wave takes part
+static inline unsigned long long __ballot(int pred) {
+  const int mine = pred ? 1 : 0;
+  std::memcpy(hipemu::wave->a[hipemu::lane], &mine, sizeof(int));
+  hipemu::wave_barrier();
+  unsigned long long out = 0ull;
+  for (int i = 0; i < 64; ++i) {
+    int v;
+    std::memcpy(&v, hipemu::wave->a[i], sizeof(int));
+    if (v) out |= 1ull << i;
+  }
+  hipemu::wave_barrier();
+  return out;
+}
+static inline int __any(int pred) { return __ballot(pred) != 0ull; }
+static inline int __all(int pred) { return __ballot(!pred) == 0ull; }
+static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
+
 template <class T>
 static inline T __shfl_down(T v, unsigned delta, int width = 64) {
   const int self = hipemu::lane, pos = self & (width - 1);

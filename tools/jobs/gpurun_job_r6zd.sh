@@ -2,7 +2,7 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
 for size in small big; do for fl in 0 1; do
 rm -rf /tmp/prof_e
-PF_MB_FLUSH=$fl timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_e -o e -- python tools/microbench_edge_finish.py $size > /tmp/e.log 2>&1
+MB_FLUSH=$fl timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_e -o e -- python tools/microbench_edge_finish.py $size > /tmp/e.log 2>&1
 echo "== $size flush $fl"
 DB=$(find /tmp/prof_e -name "*.db" | head -1) python - <<'P'
 import os, sqlite3

@@ -1,7 +1,7 @@
 # round-6 job zg: the EdgeConv backward kernels of an EAGER cfg-4 step (real neighbour lists, no graph) under rocprofv3
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
 rm -rf /tmp/prof_e
-PF_WITH_BACKWARD=1 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_e -o e -- python tools/knn_indegree.py cfg4 > /tmp/e.log 2>&1
+WITH_BACKWARD=1 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_e -o e -- python tools/knn_indegree.py cfg4 > /tmp/e.log 2>&1
 tail -3 /tmp/e.log | cut -c1-200
 DB=$(find /tmp/prof_e -name "*.db" | head -1) python - <<'P'
 import os, sqlite3

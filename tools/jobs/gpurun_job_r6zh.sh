@@ -3,7 +3,7 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 for what in step synth; do
-if [ $what = step ]; then CMD="python $R/tools/knn_indegree.py cfg4"; export PF_WITH_BACKWARD=1; else CMD="python $R/tools/microbench_edge_finish.py small big"; fi
+if [ $what = step ]; then CMD="python $R/tools/knn_indegree.py cfg4"; export WITH_BACKWARD=1; else CMD="python $R/tools/microbench_edge_finish.py small big"; fi
 rm -rf /tmp/pa /tmp/pb
 timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM --kernel-trace -d /tmp/pa -o a -- $CMD > /tmp/pa.log 2>&1
 timeout 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum --kernel-trace -d /tmp/pb -o b -- $CMD > /tmp/pb.log 2>&1

@@ -31,7 +31,7 @@ def spy(edge_convs, feature, idx, plane_hw=None):
 
 train_ops.edge_chain_train = spy
 preds = net(batch, img_scales, inter_scales, isFlow=True, isTest=False)
-if os.environ.get("PF_WITH_BACKWARD", "0") != "0":          # (under rocprofv3: the eager backward's kernel times)
+if os.environ.get("WITH_BACKWARD", "0") != "0":          # (under rocprofv3: the eager backward's kernel times)
     from pointmvsnet_amd.model import PointMVSNetLoss
     for _ in range(3):
         losses = PointMVSNetLoss(8.0)(preds, batch, True)

@@ -14,7 +14,7 @@ from pointmvsnet_amd.utils.torch_utils import get_knn_3d  # noqa: E402
 dev = torch.device("cuda:0")
 
 
-FLUSH = os.environ.get("PF_MB_FLUSH", "0") != "0"     # evict the caches between repetitions (a 1 GB fill)
+FLUSH = os.environ.get("MB_FLUSH", "0") != "0"     # evict the caches between repetitions (a 1 GB fill)
 _junk = torch.empty((256 << 20,), dtype=torch.float32, device=dev) if FLUSH else None
 
 
