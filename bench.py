@@ -375,6 +375,9 @@ TRAIN_GROUPS = (
     ("warp_backward", ("pf_warp_taps_flow_f32", "pf_warp_taps_frustum_f32", "pf_sort_pairs_by_key",
                        "pf_variance_grad_f32", "pf_warp_gather_f32", "pf_resize_bilinear_backward_f32",
                        "pf_flow_depth_grad_f32")),
+    # round 6: two walks over the neighbourhoods (sums, finish) instead of three (reduce, apply + inverse gather)
+    ("edgeconv_backward", ("pf_edge_backward_sums_f32", "pf_edge_backward_reduce_f32", "pf_edge_backward_coeffs_f32",
+                           "pf_edge_backward_apply_f32", "pf_edge_backward_finish_f32", "pf_knn_inverse")),
 )
 
 

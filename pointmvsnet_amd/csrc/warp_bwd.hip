@@ -202,7 +202,8 @@ __global__ __launch_bounds__(256) void warp_gather_kernel(const float* __restric
     const uint32_t t0 = start[key], t1 = start[key + 1];
     // 8 pairs per trip: their ids in one batch of loads, then their offsets and rows in another -- two dependent round
     // trips per 8 pairs (round 4: two per PAIR; a texel of the coarse volume sums ~4 x 48 pairs): 133 -> 74 us there.
-    // Same summation order.  (A lane per cell list, the four sums joined by shuffles, was slower: 98 us.)
+    // Same summation order.  (Measured and not kept: a lane per cell list, the four sums joined by shuffles -- 98 us; the
+    // first 4 pairs of all four lists fetched together -- the flow stage 85 -> 117 us at 142 VGPRs.)
     for (uint32_t e = t0; e < t1; e += 8) {
       uint32_t p[8];
       float2 f[8];

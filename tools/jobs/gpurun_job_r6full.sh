@@ -38,7 +38,7 @@ if [ -z "$SKIP_TRAIN" ]; then
 # cfg-4 step trace (one stream: with the flow tower on its second stream kernels overlap and their durations stop adding up)
 PF_TRAIN_FORK=0 timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_train -o r4 -- python bench.py --config cfg4 --no-cpu-baseline --steps 4 --warmup 2 > gpurun_out/prof_train.log 2>&1
 DB=$(find gpurun_out/prof_train -name "*.db" | head -1)
-python tools/last_steps_stats.py $DB gpurun_out/cfg4_last_steps.md --marker "edge_bwd_apply_kernel<64" --per-step 2 --steps 2 --top 90 --title "cfg4 training step, steady state (hipGraph replay, PF_TRAIN_FORK=0: one stream)" > /dev/null
+python tools/last_steps_stats.py $DB gpurun_out/cfg4_last_steps.md --marker "edge_bwd_reduce_kernel<64" --per-step 2 --steps 2 --top 90 --title "cfg4 training step, steady state (hipGraph replay, PF_TRAIN_FORK=0: one stream)" > /dev/null
 python tools/dispatch_list.py $DB gpurun_out/cfg4_last_step_dispatches.txt "conv3d_k3_pair_kernel" > /dev/null
 rm -rf gpurun_out/prof_train
 timeout 600 python tools/microbench_train_ops.py > gpurun_out/microbench_train_ops.log 2>&1

@@ -13,5 +13,5 @@ import json; d=json.loads(open('gpurun_out/bench_cfg4.json').readline()); print(
 rm -rf gpurun_out/prof_train
 timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_train -o r4 -- python bench.py --config cfg4 --no-cpu-baseline --steps 4 --warmup 2 > gpurun_out/prof_train.log 2>&1
 DB=$(find gpurun_out/prof_train -name "*.db" | head -1)
-python tools/last_steps_stats.py $DB gpurun_out/cfg4_last_steps.md --marker "edge_bwd_apply_kernel<64" --per-step 2 --steps 2 --top 60 --title "cfg4 training step, steady state" | head -90
+python tools/last_steps_stats.py $DB gpurun_out/cfg4_last_steps.md --marker "edge_bwd_reduce_kernel<64" --per-step 2 --steps 2 --top 60 --title "cfg4 training step, steady state" | head -90
 rm -rf gpurun_out/prof_train

@@ -1,7 +1,7 @@
 """Per-kernel time of the LAST n steps of a rocprofv3 kernel trace (steady state: library autotuning of the first
 steps excluded).  A step boundary is every `per_step`-th dispatch of the kernel whose name contains `marker`.
 
-    python tools/last_steps_stats.py results.db out.md --marker "edge_bwd_apply_kernel<64" --per-step 2 --steps 2
+    python tools/last_steps_stats.py results.db out.md --marker "edge_bwd_reduce_kernel<64" --per-step 2 --steps 2
 """
 import argparse
 import sqlite3
