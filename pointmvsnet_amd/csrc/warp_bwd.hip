@@ -308,6 +308,55 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(const float* __restrict
   dlevel[(((int64_t)v * C + c) * IH + iy) * IW + ix] = acc;
 }
 
+// The same adjoint with thread = (source texel, channel QUAD): the channel-last rows of dres are read as 16-byte pieces,
+// the Q lanes of a texel one contiguous run (the kernel above reads ONE float per lane out of every 4 * ld-byte row and
+// repeats the window arithmetic per channel: 64 us for the 64-channel level of the 102 400-point iteration).  Same sums
+// in the same (oy, ox) order: the same bits.  Needs C, c0 and ld multiples of 4.
+__global__ __launch_bounds__(256) void resize_bwd_quad_kernel(const float* __restrict__ dres, int ld, int c0, int C, int OH,
+                                                              int OW, int IH, int IW, float* __restrict__ dlevel) {
+  const int Q = C >> 2;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t texel = i / Q;
+  const int q = (int)(i - texel * Q);
+  const int v = blockIdx.y;
+  if (texel >= (int64_t)IH * IW) return;
+  const int iy = (int)(texel / IW), ix = (int)(texel - (int64_t)iy * IW);
+  const float* src = dres + (int64_t)v * OH * OW * ld + c0 + 4 * q;
+  f32x4 acc = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+  if (IH == OH && IW == OW) {
+    acc = *reinterpret_cast<const f32x4*>(src + texel * ld);
+  } else {
+    const float sy = (float)IH / (float)OH, sx = (float)IW / (float)OW;
+    int oy_lo = (int)floorf(((float)iy - 0.5f) / sy - 0.5f) - 1, oy_hi = (int)ceilf(((float)iy + 1.5f) / sy - 0.5f) + 1;
+    int ox_lo = (int)floorf(((float)ix - 0.5f) / sx - 0.5f) - 1, ox_hi = (int)ceilf(((float)ix + 1.5f) / sx - 0.5f) + 1;
+    oy_lo = oy_lo < 0 ? 0 : oy_lo;
+    ox_lo = ox_lo < 0 ? 0 : ox_lo;
+    oy_hi = oy_hi > OH - 1 ? OH - 1 : oy_hi;
+    ox_hi = ox_hi > OW - 1 ? OW - 1 : ox_hi;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      int y0, y1;
+      float ly0, ly1;
+      wb_resize_axis(oy, sy, IH, y0, y1, ly0, ly1);
+      const float wy = (y0 == iy ? ly0 : 0.0f) + (y1 == iy ? ly1 : 0.0f);
+      if (wy == 0.0f) continue;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        int x0, x1;
+        float lx0, lx1;
+        wb_resize_axis(ox, sx, IW, x0, x1, lx0, lx1);
+        const float wx = (x0 == ix ? lx0 : 0.0f) + (x1 == ix ? lx1 : 0.0f);
+        if (wx != 0.0f) {
+          const f32x4 g = *reinterpret_cast<const f32x4*>(src + ((int64_t)oy * OW + ox) * ld);
+          const float w = wy * wx;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j] = fmaf(g[j], w, acc[j]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) dlevel[(((int64_t)v * C + 4 * q + j) * IH + iy) * IW + ix] = acc[j];
+}
+
 template <int V>
 void launch_vgrad(const WbLevels& L, int H, int W, int64_t N, const uint32_t* keys, const float2* fxy, const float* dvar,
                   int64_t ldv, int ref_override, float* gval, hipStream_t s) {
@@ -414,8 +463,12 @@ int pf_resize_bilinear_backward_f32(const float* dres, int ld, int c0, int C, in
                                     float* dlevel, void* stream) {
   PF_REQUIRE(V >= 1 && C >= 1 && c0 >= 0 && ld >= c0 + C && OH >= 1 && OW >= 1 && IH >= 1 && IW >= 1 && dres && dlevel);
   PF_REQUIRE(C <= 65535 && V <= 65535);
-  hipLaunchKernelGGL(resize_bwd_kernel, dim3((unsigned)pf_cdiv((int64_t)IH * IW, 256), (unsigned)C, (unsigned)V),
-                     dim3(256), 0, (hipStream_t)stream, dres, ld, c0, C, OH, OW, IH, IW, dlevel);
+  if ((C & 3) == 0 && (c0 & 3) == 0 && (ld & 3) == 0 && ((uintptr_t)dres & 15) == 0)
+    hipLaunchKernelGGL(resize_bwd_quad_kernel, dim3((unsigned)pf_cdiv((int64_t)IH * IW * (C >> 2), 256), (unsigned)V),
+                       dim3(256), 0, (hipStream_t)stream, dres, ld, c0, C, OH, OW, IH, IW, dlevel);
+  else
+    hipLaunchKernelGGL(resize_bwd_kernel, dim3((unsigned)pf_cdiv((int64_t)IH * IW, 256), (unsigned)C, (unsigned)V),
+                       dim3(256), 0, (hipStream_t)stream, dres, ld, c0, C, OH, OW, IH, IW, dlevel);
   return pf_launch_status();
 }
 

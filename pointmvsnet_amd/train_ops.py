@@ -1152,10 +1152,13 @@ class _SoftArgminTrain(torch.autograd.Function):
         depth, prob = pointflow.soft_argmin_params(cost, params)
         ctx.saved = (cost, params, depth)
         ctx.mark_non_differentiable(prob)
+        ctx.set_materialize_grads(False)       # (else autograd fills a zero tensor for prob's gradient every step)
         return depth, prob
 
     @staticmethod
     def backward(ctx, gdepth, _gprob):
+        if gdepth is None:
+            return None, None
         cost, params, depth = ctx.saved
         B, D, H, W = cost.shape
         g = torch.empty_like(cost)
@@ -1185,10 +1188,13 @@ class _FlowHeadTrain(torch.autograd.Function):
                       _lib.ptr(offset), _lib.ptr(prob), _lib.stream(), algo_bytes=4.0 * hw * (5 * 16 + 6))
         ctx.saved = (a, w, interval, prob, weight)
         ctx.mark_non_differentiable(prob)
+        ctx.set_materialize_grads(False)       # (no zero-filled gradient for prob)
         return offset, prob
 
     @staticmethod
     def backward(ctx, goffset, _gprob):
+        if goffset is None:
+            return None, None, None, None
         a, w, interval, prob, weight = ctx.saved
         hw = prob.shape[1]
         gact = torch.empty((5 * hw, 16), dtype=_F32, device=a.device)
@@ -1303,11 +1309,14 @@ class _FlowFeaturesTrain(torch.autograd.Function):
         ctx.shapes = [tuple(t.shape) for t in lv]
         ctx.side = _on_side(2)
         ctx.mark_non_differentiable(xyz)
+        ctx.set_materialize_grads(False)       # (no zero-filled gradient for xyz)
         return feature.view(feature.shape[1], feature.shape[2]), xyz
 
     @staticmethod
     @_with_packs
     def backward(ctx, dfeature, _dxyz):
+        if dfeature is None:
+            return (None,) * 8
         levels, depth, interval, cam = ctx.levels, ctx.depth, ctx.interval, ctx.cam
         h, w = ctx.hw
         V = levels[0].shape[0]
@@ -1368,11 +1377,14 @@ class _CoarseVolumeTrain(torch.autograd.Function):
         ctx.cl = cl
         ctx.cams = tuple(x.detach().float().contiguous() for x in (kinv, rinv, t, depths, K, E))
         ctx.mark_non_differentiable(world)
+        ctx.set_materialize_grads(False)       # (no zero-filled gradient for world)
         return cost, world
 
     @staticmethod
     @_with_packs
     def backward(ctx, dcost, _dworld):
+        if dcost is None:
+            return (None,) * 7
         cl = ctx.cl
         kinv, rinv, t, depths, K, E = ctx.cams
         V, FH, FW, C = cl.shape

@@ -45,8 +45,17 @@ class FlatRMSprop(torch.optim.Optimizer):
     (the CPU TrainStep, the reference's checkpointer)."""
 
     def __init__(self, bucket, named_parameters, lr=1e-3, alpha=0.9, eps=1e-8, weight_decay=0.0):
+        named_parameters = list(named_parameters)
         names = {id(p): n for n, p in named_parameters}
         params = bucket.params
+        # torch.optim.RMSprop on the reference's param_groups keeps EVERY parameter and both groups; this class indexes its
+        # state over the bucket (the trainable parameters).  The two layouts agree only when nothing is frozen: say so here
+        # instead of failing in load_state_dict on group sizes (ADVICE r5).
+        held = {id(p) for p in params}
+        frozen = [n for n, p in named_parameters if id(p) not in held]
+        if frozen:
+            raise ValueError("FlatRMSprop: every parameter must be trainable (its state layout is torch.optim.RMSprop's over "
+                             "ALL parameters); not in the gradient bucket: %s" % ", ".join(frozen[:5]))
         is_bn = [".bn." in names.get(id(p), "") for p in params]
         groups = [dict(params=[p for p, bn in zip(params, is_bn) if not bn], weight_decay=float(weight_decay)),
                   dict(params=[p for p, bn in zip(params, is_bn) if bn], weight_decay=0.0)]
@@ -92,6 +101,8 @@ class FlatRMSprop(torch.optim.Optimizer):
                 raise NotImplementedError("FlatRMSprop: one lr / alpha / eps for all groups (the reference's solver)")
         if any(g.get("momentum", 0.0) != 0.0 or g.get("centered", False) for g in self.param_groups):
             raise NotImplementedError("FlatRMSprop: momentum / centered RMSprop is not built (reference: plain RMSprop)")
+        if any(g.get("maximize", False) for g in self.param_groups):       # (a loaded checkpoint may carry the key)
+            raise NotImplementedError("FlatRMSprop: maximize=True is not built (reference: plain RMSprop)")
         return float(g0["lr"]), float(g0["alpha"]), float(g0["eps"])
 
     # kept as attributes for callers of the round-4 interface
@@ -228,11 +239,21 @@ class TrainStep(object):
         with train_ops.direct_grads():                             # the fused nodes add into the bucket themselves
             preds = self.model(batch, img_scales, inter_scales, isFlow=is_flow, isTest=False)
             losses = self.loss_fn(preds, batch, is_flow)
-            total = sum(losses.values())
+            total = _total(losses)
             total.backward()
         join_fork_streams()                                        # the flow tower's backward ran beside the coarse stage's
         self.finish()
         return total.detach(), losses, preds
+
+
+def _total(losses):
+    """sum(losses.values()) as the reference writes it (train.py:74), without the launch that adds the int 0 first
+    (0 + x is x bit for bit)."""
+    vals = list(losses.values())
+    total = vals[0]
+    for v in vals[1:]:
+        total = total + v
+    return total
 
 
 class GraphedTrainStep(object):
@@ -284,7 +305,7 @@ class GraphedTrainStep(object):
             preds = self.t.model.run_autograd(self.plan, self.img, self.is_flow)
             labels = {"gt_depth_img": self.gt, "cam_params_list": self.cams}
             losses = self.t.loss_fn(preds, labels, self.is_flow)
-            total = sum(losses.values())
+            total = _total(losses)
             total.backward()
         join_fork_streams()
         return total.detach(), {k: v.detach() for k, v in losses.items()}, {k: v.detach() for k, v in preds.items()}

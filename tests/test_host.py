@@ -309,3 +309,11 @@ def test_flat_rmsprop_state_is_interchangeable_with_torch_rmsprop():
     assert flat.lr == 5e-4 and sched is not None
     flat.zero_grad(set_to_none=True)                        # must keep the bucket views
     assert bucket.attached() and float(bucket.flat.abs().sum()) == 0.0
+    # a frozen parameter would shift torch's state indices against ours: refused with a message, not a size mismatch later
+    net2 = PointMVSNet()
+    next(net2.parameters()).requires_grad_(False)
+    with pytest.raises(ValueError, match="trainable"):
+        FlatRMSprop(distributed.GradBucket(net2), list(net2.named_parameters()))
+    flat.param_groups[0]["maximize"] = True
+    with pytest.raises(NotImplementedError):
+        flat._hyper()

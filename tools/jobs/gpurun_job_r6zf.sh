@@ -10,5 +10,5 @@ PF_TRAIN_FORK=0 timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_
 DB=$(find gpurun_out/prof_train -name "*.db" | head -1)
 python tools/last_steps_stats.py $DB gpurun_out/cfg4_last_steps.md --marker "edge_bwd_reduce_kernel<64" --per-step 2 --steps 2 --top 90 --title "cfg4 training step, steady state (one stream)" | head -8 | cut -c1-150
 python tools/dispatch_list.py $DB gpurun_out/cfg4_last_step_dispatches.txt "conv3d_k3_pair_kernel" > /dev/null
-grep -E 'warp_gather|variance_grad|resize_bwd' gpurun_out/cfg4_last_step_dispatches.txt | awk '{print $1, $3, $11, $12, $13}' | cut -c1-110
+grep -E 'resize_bwd' gpurun_out/cfg4_last_step_dispatches.txt | awk '{print $1, $3, $11, $12, $13}' | cut -c1-110
 rm -rf gpurun_out/prof_train
