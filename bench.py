@@ -64,6 +64,18 @@ def traced_sha():
         return None
 
 
+PMC_SHA = os.path.join("profiles", "r06_pmc_sha.txt")
+
+
+def pmc_sha():
+    """The commit the committed PMC passes were taken at (they are not re-taken by every artefact job: the inference kernels
+    they count did not change between that commit and the traced one); falls back to the traced commit."""
+    try:
+        return open(os.path.join(ROOT, PMC_SHA)).read().strip() or traced_sha()
+    except OSError:
+        return traced_sha()
+
+
 def parity_summary():
     """Per configuration, from the LAST committed parity report of the GPU test run (tests/conftest.report lines of
     tests/test_gpu_teacher.py and tests/test_gpu_model.py; not measured by this run): the teacher-forced iterations --
@@ -1106,7 +1118,7 @@ def run(args, emulate):
         roof.update({"traffic": traffic,
                      "traffic_source": None if traffic is None else
                      TRAFFIC_TABLE + " (two rocprofv3 --pmc passes of a committed earlier job at git %s, FETCH_SIZE / "
-                     "WRITE_SIZE; a constant of that job, not measured in this run)" % (traced_sha() or "?"),
+                     "WRITE_SIZE; a constant of that job, not measured in this run)" % (pmc_sha() or "?"),
                      "under_load": under_load_instantiations(("conv2d_wide",)) if dominant in TOWERS else None,
                      # the entry point dispatches to one template instantiation per layer shape: the same clock per shape
                      # (eager, single chain -- `under_load` is the same table from the trace of the timed execution mode)
