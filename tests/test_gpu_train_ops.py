@@ -11,7 +11,7 @@ import torch
 import torch.nn.functional as F
 
 from conftest import report
-from pointmvsnet_amd import networks, synthetic, train_ops
+from pointmvsnet_amd import _lib, networks, synthetic, train_ops
 
 pytestmark = pytest.mark.gpu
 
@@ -357,6 +357,37 @@ def test_volume_conv_node_vs_float64_autograd(dev, size=(16, 32, 40), yardstick=
            oracle32_worst_grad_rel=yard[1], ambiguous_relu_inputs=amb["n"], dcost_frac_beyond_1e4=frac_x)
     assert e_out < 2e-5 and e_x < gate_x and frac_x < 1e-2, (e_out, e_x, frac_x, yard, amb)
     assert errs[0][0] < gate_w and errs[len(errs) // 2][0] < 2e-5, (errs[:5], errs[len(errs) // 2], yard, amb)
+
+
+def test_edge_chain_xcd_band_order_is_a_pure_relabelling(dev):
+    """Round 6: with the lattice's plane shape as a hint the EdgeConv gather passes -- forward statistics / apply, backward
+    reduce and inverted-list gather -- number their blocks so that an XCD owns a band of pixel rows in every plane
+    (csrc/edgeconv.hip: xcd_tile; here 5 planes of 16 x 32 points: 8 tiles per plane, band = 1).  A relabelling of the grid
+    only: outputs, the input gradient and every parameter gradient are the SAME BITS as without the hint, and the
+    BatchNorm running statistics too (the partial rows stay in tile order)."""
+    from pointmvsnet_amd.model import PointMVSNet
+    from pointmvsnet_amd.utils.torch_utils import get_knn_3d
+    D, h, w = 5, 16, 32
+    N = D * h * w
+    xyz = _seeded((1, 3, D, h, w), dev, 31)
+    idx = get_knn_3d(xyz, 5, knn=16)
+    g = None
+    got = []
+    for plane_hw in (None, (h, w)):
+        net = PointMVSNet()
+        synthetic.seed_weights(net, seed=0)
+        net = net.to(dev).train()
+        feat = _seeded((N, 136), dev, 32).requires_grad_(True)
+        edges = train_ops.edge_chain_train(net.flow_edge_conv, feat, idx, plane_hw=plane_hw)
+        g = _seeded(tuple(edges.shape), dev, 33) if g is None else g
+        (edges * g).sum().backward()
+        params = list(net.flow_edge_conv.parameters())
+        got.append([edges.detach().clone(), feat.grad.detach().clone()] + _grads(params)
+                   + [b.detach().clone() for b in net.flow_edge_conv.buffers()])
+    assert len(got[0]) == len(got[1])
+    for a, b in zip(*got):
+        assert torch.equal(a, b)
+    assert _lib.status() == 0
 
 
 def test_edge_chain_and_mlp_nodes_vs_composed_operators(dev):
