@@ -208,8 +208,12 @@ __global__ __launch_bounds__(256) void frustum_variance_cl_kernel(const float* _
   __shared__ float tile[64 + 3][PTS + 1];
   const int q = threadIdx.x & 15, pl = threadIdx.x >> 4;
   const int64_t b = blockIdx.y;
-  const int64_t n0 = (int64_t)blockIdx.x * PTS;
   const int hw = H * W;
+  // (XCD x owns a band of pixel rows at ALL depths: the depth planes of a pixel sample neighbouring texels -- pf_common.h)
+  unsigned ptile = blockIdx.x;
+  if ((PF_XCD & PF_XCD_FRUSTUM) != 0 && hw % PTS == 0 && (int64_t)gridDim.x * PTS == N && (gridDim.x & 7u) == 0u)
+    ptile = pf_xcd_band(ptile, (unsigned)(hw / PTS));
+  const int64_t n0 = (int64_t)ptile * PTS;
   const float* ki = fr.kinv + b * 9;
   const float* ri = fr.rinv + b * 9;
   const float* tt = fr.t + b * 3;

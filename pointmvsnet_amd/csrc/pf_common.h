@@ -70,7 +70,7 @@ static inline int pf_zero_async(void* p, size_t bytes, hipStream_t s) {
 // as everything a kernel derives from blockIdx -- the BatchNorm partial row included -- comes from the relabelled ids.
 // PF_XCD is a bit mask of kernel families (tools/experiments/build_xcd_variants.sh: A/B builds); 0 = tile = block
 // everywhere.  Measured same-box on the headline (profiles/r06t_xcd_block_order.md): towers +1.0 %, conv3d -0.6 %, flow
-// feature assembly +-0 -- so only the towers take it by default.  (The EdgeConv gather passes use their own band order,
+// feature assembly +-0, the coarse warp by pixel-row bands (bit 32) +0.4 % inside the spread -- so only the towers take it by default.  (The EdgeConv gather passes use their own band order,
 // csrc/edgeconv.hip: xcd_tile, +2.3 %.)
 #ifndef PF_XCD
 #define PF_XCD 1
@@ -80,11 +80,22 @@ static inline int pf_zero_async(void* p, size_t bytes, hipStream_t s) {
 #define PF_XCD_FETCH 4
 #define PF_XCD_KNN 8
 #define PF_XCD_EDGE 16
+#define PF_XCD_FRUSTUM 32
 #ifdef __HIPCC__
 __device__ __forceinline__ unsigned pf_xcd_chunk(unsigned lin, unsigned total) {
   const unsigned per = total >> 3, rem = total & 7u;
   const unsigned x = lin & 7u, j = lin >> 3;
   return x * per + (x < rem ? x : rem) + j;
+}
+// Band order for point tiles of a D x (H x W) volume (tile = `unit` consecutive points, x fastest, then y, then d): XCD x owns
+// the x-th eighth of EVERY plane's tiles -- a band of pixel rows at all depths -- instead of every eighth tile.  Needs whole
+// tiles per plane and a multiple of 8 of them (else: identity).
+__device__ __forceinline__ unsigned pf_xcd_band(unsigned b, unsigned tiles_per_plane) {
+  if ((tiles_per_plane & 7u) != 0u) return b;
+  const unsigned band = tiles_per_plane >> 3;
+  const unsigned x = b & 7u, j = b >> 3;
+  const unsigned d = j / band, o = j - d * band;
+  return d * tiles_per_plane + x * band + o;
 }
 // the relabelled (blockIdx.x, blockIdx.y) of a 2-D grid (x fastest in dispatch order)
 template <int FAMILY>
