@@ -56,8 +56,9 @@ def join_fork_streams():
     training forward run it before they read gradients: autograd joins a side stream at the end of backward only
     where an AccumulateGrad node ran on it, and with ``train_ops.direct_grads()`` the nodes add into the bucket
     themselves."""
-    train_ops.flush_late()              # weight gradients that waited for the end of the backward (train_ops.WGRAD_LATE)
-    for stream in _FORK_STREAMS.values():
+    streams = list(_FORK_STREAMS.values())
+    train_ops.flush_late(side=streams[0] if streams else None)   # weight gradients that waited for the end of the backward
+    for stream in streams:
         torch.cuda.current_stream(stream.device).wait_stream(stream)
 
 

@@ -191,12 +191,54 @@ def _wgrad_flush_deferred():
     _wgrad_launch_items(todo)
 
 
-def flush_late():
+# The late weight gradients go out on PF_WGRAD_STREAMS streams (default 2: the caller's and a fork stream; 1 = one stream),
+# dealt by their flops: each is a chip-filling grid of 85-240 us that drains for a good part of its run time, and nothing
+# orders one layer's weight gradient against another's -- on two streams the drain of one overlaps the next one's start
+# (cfg-4 step 5.60 -> 5.50 ms, same box, three alternations).
+WGRAD_STREAMS = int(os.environ.get("PF_WGRAD_STREAMS", "2"))
+_EXTRA_STREAMS = {}
+
+
+def _wgrad_streams(side, n):
+    """``n`` - 1 streams beside the current one: the fork stream first, then streams of this module's own."""
+    out = [side]
+    key = str(side.device)
+    pool = _EXTRA_STREAMS.setdefault(key, [])
+    while len(pool) < n - 2:
+        pool.append(torch.cuda.Stream(device=side.device))
+    return out + pool[:max(0, n - 2)]
+
+
+def flush_late(side=None):
     """The end of a backward (model.join_fork_streams()): the weight gradients that waited for it, then their reduction."""
     todo, reds = list(_LATE["wgrad"]), list(_LATE["reduce"])
     del _LATE["wgrad"][:]
     del _LATE["reduce"][:]
-    if todo:
+    if todo and WGRAD_STREAMS >= 2 and side is not None and len(todo) >= 2:
+        streams = _wgrad_streams(side, WGRAD_STREAMS)
+        groups = [[] for _ in range(len(streams) + 1)]       # groups[0]: the current stream
+        load = [0.0] * len(groups)
+        for i in sorted(range(len(todo)), key=lambda i: -todo[i].get("flops", 0.0)):
+            g = load.index(min(load))                        # greedy: the next largest to the lightest stream
+            groups[g].append(todo[i])
+            load[g] += todo[i].get("flops", 0.0)
+        cur = torch.cuda.current_stream(side.device)
+        for st, grp in zip(streams, groups[1:]):
+            if not grp:
+                continue
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                _wgrad_launch_items(grp)
+                for d in grp:
+                    d["work"].record_stream(st)
+        if groups[0]:
+            _wgrad_launch_items(groups[0])
+        for st, grp in zip(streams, groups[1:]):
+            if grp:
+                cur.wait_stream(st)
+        # (the reductions stay on ONE stream, in queue order: two PointFlow iterations add into the same parameters'
+        # gradients -- on two streams that is a race, and it was measured to buy nothing: 5.50 -> 5.49 ms)
+    elif todo:
         _wgrad_launch_items(todo)
     if reds:
         with torch.cuda.device(reds[0][0].device):
